@@ -1,0 +1,119 @@
+"""Oracle: restatement of the reference's hot-path losses and eval metric.
+
+Test infrastructure only (see oracle/__init__.py).  Cites are into /root/reference.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def mask_to_one_hot(mask, n_classes):
+    """lib/transforms.py:675-689: B x 1 x ... index mask -> B x C x ... float one-hot (zeros + scatter_)."""
+    shape = list(mask.shape)
+    shape[1] = n_classes
+    one_hot = torch.zeros(shape, dtype=torch.float32, device=mask.device)
+    one_hot.scatter_(1, mask.long(), 1)
+    return one_hot
+
+
+def dice_loss(source, target, n_class, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6):
+    """DiceLossMultiClass.forward, lib/loss.py:410-476."""
+    assert source.shape[0] == target.shape[0]
+    shape = list(source.shape)
+    if softmax:
+        source = F.softmax(source, dim=1)                                   # :426-427
+    src = source.reshape(shape[0], shape[1], -1)
+    if target.dim() == len(shape) - 1:                                      # :433-434 index target
+        tgt = mask_to_one_hot(target.reshape(shape[0], 1, -1), n_class).to(src.dtype)
+    elif target.shape[1] == shape[1]:                                       # :435-436 soft target
+        tgt = target.reshape(shape[0], shape[1], -1)
+    else:
+        raise ValueError("Incorrect size of target tensor")                 # :437-440
+    if no_bg:                                                               # :444-446
+        src, tgt = src[:, 1:, :], tgt[:, 1:, :]
+    sv, tv = src.sum(2), tgt.sum(2)                                         # :449-450
+    if weight_type == 'Simple':                                             # :452-454
+        w = (tv.float() ** (1. / 3.) + eps).reciprocal()
+    elif weight_type == 'Volume':                                           # :458-463
+        w = (tv + eps).float().reciprocal()
+        tmp = torch.where(torch.isinf(w), torch.ones_like(w), w)
+        mx = tmp.max(dim=1, keepdim=True)[0]
+        w = torch.where(torch.isinf(w), torch.ones_like(w) * mx, w)
+    elif weight_type == 'Uniform':                                          # :464-465
+        w = torch.ones(shape[0], shape[1] - int(no_bg))
+    else:
+        raise ValueError("Class weighting type {} does not exists!".format(weight_type))
+    w = (w / w.max()).to(src.dtype)                                         # :468
+    inter = (src * tgt).sum(2)                                              # :472
+    scores = (2. * inter + eps) / ((sv + tv) + 2 * eps)                     # :473-474
+    return 1 - (w * scores).sum() / w.sum()                                 # :476
+
+
+def ncc_loss(inp, tgt):
+    """NormalizedCrossCorrelationLoss.forward, lib/loss.py:493-501 (no eps, not squared)."""
+    x = inp.reshape(inp.shape[0], -1)
+    y = tgt.reshape(tgt.shape[0], -1)
+    xm = x - x.mean(1, keepdim=True)
+    ym = y - y.mean(1, keepdim=True)
+    ncc = (xm * ym).mean(1) / (torch.sqrt((xm ** 2).mean(1)) * torch.sqrt((ym ** 2).mean(1)))
+    return 1 - ncc.mean()
+
+
+def bending_energy_loss(disp, spacing=(1., 1., 1.), normalize=True):
+    """BendingEnergyLoss.forward (norm='L2'), lib/loss.py:687-730.
+
+    Keeps the reference's quirks: mixed differences are not divided by 4; the per-axis
+    weight vector spatial_dims=(D,H,W)/min is broadcast over the CHANNEL axis (:694-696,
+    :722-727), i.e. channel c is weighted by dim c of (D,H,W)."""
+    sp = torch.tensor(spacing, dtype=torch.float32)
+    if normalize:
+        sp = sp / sp.min()
+    sp = sp.to(disp.dtype)
+    dims = torch.tensor(disp.shape[2:], dtype=torch.float32)
+    if normalize:
+        dims = dims / dims.min()
+    dims = dims.to(disp.dtype)
+    u = disp
+    B, C = u.shape[0], u.shape[1]
+    c = u[:, :, 1:-1, 1:-1, 1:-1]
+    ddx = (u[:, :, 2:, 1:-1, 1:-1] + u[:, :, :-2, 1:-1, 1:-1] - 2 * c).abs().reshape(B, C, -1)
+    ddy = (u[:, :, 1:-1, 2:, 1:-1] + u[:, :, 1:-1, :-2, 1:-1] - 2 * c).abs().reshape(B, C, -1)
+    ddz = (u[:, :, 1:-1, 1:-1, 2:] + u[:, :, 1:-1, 1:-1, :-2] - 2 * c).abs().reshape(B, C, -1)
+    dxdy = (u[:, :, 2:, 2:, 1:-1] + u[:, :, :-2, :-2, 1:-1] - u[:, :, 2:, :-2, 1:-1] - u[:, :, :-2, 2:, 1:-1]).abs().reshape(B, C, -1)
+    dydz = (u[:, :, 1:-1, 2:, 2:] + u[:, :, 1:-1, :-2, :-2] - u[:, :, 1:-1, 2:, :-2] - u[:, :, 1:-1, :-2, 2:]).abs().reshape(B, C, -1)
+    dxdz = (u[:, :, 2:, 1:-1, 2:] + u[:, :, :-2, 1:-1, :-2] - u[:, :, 2:, 1:-1, :-2] - u[:, :, :-2, 1:-1, 2:]).abs().reshape(B, C, -1)
+    ddx = (ddx ** 2).mean(2) * (dims * sp / (sp[0] ** 2)) ** 2
+    ddy = (ddy ** 2).mean(2) * (dims * sp / (sp[1] ** 2)) ** 2
+    ddz = (ddz ** 2).mean(2) * (dims * sp / (sp[2] ** 2)) ** 2
+    dxdy = (dxdy ** 2).mean(2) * (dims * sp / (sp[0] * sp[1])) ** 2
+    dydz = (dydz ** 2).mean(2) * (dims * sp / (sp[1] * sp[2])) ** 2
+    dxdz = (dxdz ** 2).mean(2) * (dims * sp / (sp[2] * sp[0])) ** 2
+    return (ddx.mean() + ddy.mean() + ddz.mean() + 2 * dxdy.mean() + 2 * dydz.mean() + 2 * dxdz.mean()) / 9.0
+
+
+def eval_dice_per_class(logits, truth, n_classes):
+    """models/segmentation.py:188-194 + lib/evalMetrics.py:58-68: argmax (first max index,
+    torch.max(pred,1)[1]) then for c in 1..n_classes-1:
+    1 - scipy.spatial.distance.dice(pred==c, truth==c) = 2|P&T| / (|P|+|T|) (NaN when both empty).
+    Returns (dice[n_classes-1] float64 ndarray, argmax LongTensor)."""
+    pred = torch.max(logits, 1)[1]
+    p = pred.reshape(-1).numpy()
+    t = truth.reshape(-1).numpy()
+    out = np.zeros(n_classes - 1, dtype=np.float64)
+    for c in range(1, n_classes):
+        pc, tc = (p == c), (t == c)
+        ntt = np.count_nonzero(pc & tc)
+        ntf = np.count_nonzero(pc & ~tc)
+        nft = np.count_nonzero(~pc & tc)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            out[c - 1] = 1.0 - np.float64(ntf + nft) / np.float64(2 * ntt + ntf + nft)
+    return out, pred
+
+
+def multiclass_dice(pred, truth, n_class, eps=1e-11):
+    """lib/evalMetrics.py:184-217 get_multiclass_dice for index masks (B x D x H x W)."""
+    B = truth.shape[0]
+    p1 = mask_to_one_hot(pred.reshape(B, 1, -1), n_class)[:, 1:, :]
+    t1 = mask_to_one_hot(truth.reshape(B, 1, -1), n_class)[:, 1:, :]
+    inter = (p1 * t1).sum(2)
+    return (2. * inter) / ((p1.sum(2) + t1.sum(2)) + eps)

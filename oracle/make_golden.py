@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""Generate golden vectors by IMPORTING THE REFERENCE (/root/reference) in the build container.
+
+Run:  python -m oracle.make_golden            (writes tests/golden/*.npz)
+
+The reference's Python files never travel: only inputs/outputs (data) are committed.  Inputs and
+weights are closed-form (oracle/nets.py closed_form_*), so fixtures stay small; big tensors are
+stored as (sum, abs-sum, l2, strided sample) summaries.
+
+Reference symbols exercised (file:line in /root/reference):
+  lib/network_factory/__init__.py:9-27 get_network; unets.py:182-280 UNet_generator/UNetTemplate;
+  voxel_morph.py:29-92 VoxelMorphCVPR2018; lib/loss.py:397-476 DiceLossMultiClass, :485-501 NCC,
+  :674-730 BendingEnergyLoss; lib/transforms.py:675-689 mask_to_one_hot; lib/utils.py:78-102
+  get_identity_transform_batch; lib/evalMetrics.py:17-21,58-68 metricEval('dice'), :184-217
+  get_multiclass_dice; torch.optim.Adam as used at models/segmentation.py:91.
+"""
+import os
+import sys
+import types
+import copy
+import numpy as np
+import torch
+
+REF = os.environ.get('DEEPATLAS_REFERENCE', '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def import_reference():
+    sitk = types.ModuleType('SimpleITK')          # only default-arg attrs are touched (transforms.py:167,208,287)
+    sitk.sitkLinear, sitk.sitkBSpline, sitk.sitkNearestNeighbor = 1, 2, 3
+    sys.modules.setdefault('SimpleITK', sitk)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import lib.network_factory as nf
+    import lib.network_factory.unets as unets
+    import lib.loss as loss
+    import lib.utils as utils
+    import lib.transforms as transforms
+    import lib.evalMetrics as metrics
+    return types.SimpleNamespace(nf=nf, unets=unets, loss=loss, utils=utils, transforms=transforms, metrics=metrics)
+
+
+def summary(t, nsample=512):
+    t = t.detach().double().reshape(-1)
+    n = t.numel()
+    stride = max(1, n // nsample)
+    idx = torch.arange(0, n, stride)[:nsample]
+    return np.concatenate([[t.sum().item(), t.abs().sum().item(), t.norm().item(), float(n), float(stride)],
+                           t[idx].numpy()])
+
+
+def np32(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def load_sd(model, sd):
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+
+
+def run_seg(ref, model_cls, spec_name, in_ch, n_classes, shape, N, out, prefix, full, dtype=torch.float32, steps=3):
+    from oracle import nets
+    spec = getattr(nets, spec_name)
+    shapes = nets.unet_param_shapes(in_ch, n_classes, spec['encoders'], spec['decoders'], bias=True, BN=True)
+    sd0 = nets.closed_form_fill(shapes, seed=1)
+    model = model_cls(in_channel=in_ch, n_classes=n_classes, bias=True, BN=True)
+    assert set(model.state_dict().keys()) == set(sd0.keys()), (set(model.state_dict()) ^ set(sd0))
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(sd0[k].shape), k
+    load_sd(model, sd0)
+    model = model.to(dtype)
+    x = nets.closed_form_volume((N, in_ch) + shape, seed=2).to(dtype)
+    y = nets.closed_form_labels((N,) + shape, n_classes, seed=3)
+    crit = ref.loss.get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    tag = prefix + ('' if dtype == torch.float32 else '_f64')
+    for s in range(1, steps + 1):
+        model.train()
+        opt.zero_grad()
+        logits = model(x)
+        loss = crit(logits, y.long())
+        loss.backward()
+        if s == 1:
+            out[f'{tag}/loss'] = np.float64(loss.item())
+            out[f'{tag}/logits'] = np32(logits) if full else summary(logits)
+            pred = torch.max(logits, 1)[1]
+            out[f'{tag}/argmax'] = np32(pred).astype(np.uint8) if full else summary(pred)
+            for n, p in model.named_parameters():
+                out[f'{tag}/grad/{n}'] = np32(p.grad) if full else summary(p.grad)
+        opt.step()
+        if dtype == torch.float32 and s in (1, steps):
+            out[f'{tag}/loss_step{s}'] = np.float64(loss.item())
+            for n, v in model.state_dict().items():
+                if v.dtype.is_floating_point:
+                    out[f'{tag}/after{s}/{n}'] = np32(v) if full else summary(v)
+    if dtype == torch.float32:
+        # eval-mode forward + eval Dice (models/segmentation.py:179-201) on the 3-step model
+        model.eval()
+        with torch.no_grad():
+            pred = model(x)
+            dice = np.zeros((N, n_classes - 1))
+            for b in range(N):
+                for c in range(1, n_classes):
+                    dice[b, c - 1] = ref.metrics.metricEval('dice', torch.max(pred[b:b + 1], 1)[1].squeeze().numpy() == c,
+                                                            y[b].numpy() == c, num_labels=2)
+            out[f'{tag}/eval_logits'] = np32(pred) if full else summary(pred)
+            out[f'{tag}/eval_dice'] = dice
+            out[f'{tag}/eval_multiclass_dice'] = np32(ref.metrics.get_multiclass_dice(torch.max(pred, 1)[1], y.long(), n_class=n_classes))
+    return x, y
+
+
+def run_reg(ref, shape, out, prefix, full_small=True, dtype=torch.float32, steps=3, lam=1.0):
+    from oracle import nets
+    shapes = nets.voxelmorph_param_shapes()
+    sd0 = nets.closed_form_fill(shapes, seed=4)
+    model = ref.nf.get_network('voxel_morph_cvpr')()
+    assert set(model.state_dict().keys()) == set(sd0.keys())
+    load_sd(model, sd0)
+    model = model.to(dtype)
+    src = nets.closed_form_volume((1, 1) + shape, seed=5).to(dtype)
+    tgt = nets.closed_form_volume((1, 1) + shape, seed=6).to(dtype)
+    ncc = ref.loss.get_loss_function('ncc')()
+    bend = ref.loss.get_loss_function('bendingEnergy')()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    tag = prefix + ('' if dtype == torch.float32 else '_f64')
+    for s in range(1, steps + 1):
+        opt.zero_grad()
+        disp, warped, deform = model(src, tgt)
+        l_sim = ncc(warped, tgt)
+        l_reg = bend(disp)
+        loss = l_sim + lam * l_reg
+        loss.backward()
+        if s == 1:
+            out[f'{tag}/loss'] = np.float64(loss.item())
+            out[f'{tag}/ncc'] = np.float64(l_sim.item())
+            out[f'{tag}/bending'] = np.float64(l_reg.item())
+            out[f'{tag}/disp'] = np32(disp)
+            out[f'{tag}/warped'] = np32(warped)
+            out[f'{tag}/deform'] = summary(deform)
+            for n, p in model.named_parameters():
+                small = p.numel() <= 4096
+                out[f'{tag}/grad/{n}'] = np32(p.grad) if small else summary(p.grad)
+        opt.step()
+        if dtype == torch.float32 and s in (1, steps):
+            out[f'{tag}/loss_step{s}'] = np.float64(loss.item())
+            for n, v in model.state_dict().items():
+                out[f'{tag}/after{s}/{n}'] = np32(v) if v.numel() <= 4096 else summary(v)
+
+
+def run_ops(ref, out):
+    """Per-op fixtures: losses (all weight types / soft target / no_bg), warp with out-of-range taps,
+    identity grid, one-hot, nearest up-sampling with odd sizes, max-pool, eval Dice."""
+    from oracle import nets
+    import torch.nn.functional as F
+    D, H, W = 6, 10, 14
+    C = 5
+    logits = (nets.closed_form_volume((2, C, D, H, W), seed=7) * 4 - 2).requires_grad_(True)
+    labels = nets.closed_form_labels((2, D, H, W), C, seed=8)
+    out['ops/dice/logits'] = np32(logits)
+    out['ops/dice/labels'] = np32(labels)
+    for wt in ('Uniform', 'Simple', 'Volume'):
+        for no_bg in (False, True):
+            crit = ref.loss.DiceLossMultiClass(n_class=C, weight_type=wt, no_bg=no_bg, softmax=True, eps=1e-6)
+            l = crit(logits, labels.long())
+            g, = torch.autograd.grad(l, logits)
+            out[f'ops/dice/{wt}_{int(no_bg)}/loss'] = np.float64(l.item())
+            out[f'ops/dice/{wt}_{int(no_bg)}/grad'] = np32(g)
+    # soft (5-D) target, softmax=False : the path the joint step uses (loss.py:435-436)
+    prob = F.softmax(logits.detach(), 1).requires_grad_(True)
+    soft_t = F.softmax(nets.closed_form_volume((2, C, D, H, W), seed=9) * 3, 1)
+    crit = ref.loss.DiceLossMultiClass(n_class=C, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)
+    l = crit(prob, soft_t)
+    g, = torch.autograd.grad(l, prob)
+    out['ops/dice_soft/source'] = np32(prob)
+    out['ops/dice_soft/target'] = np32(soft_t)
+    out['ops/dice_soft/loss'] = np.float64(l.item())
+    out['ops/dice_soft/grad'] = np32(g)
+    # one-hot
+    out['ops/onehot'] = np32(ref.transforms.mask_to_one_hot(labels.view(2, 1, D, H, W), C))
+    # NCC
+    a = nets.closed_form_volume((2, 1, D, H, W), seed=10).requires_grad_(True)
+    b = nets.closed_form_volume((2, 1, D, H, W), seed=11)
+    l = ref.loss.NormalizedCrossCorrelationLoss()(a, b)
+    g, = torch.autograd.grad(l, a)
+    out['ops/ncc/a'], out['ops/ncc/b'] = np32(a), np32(b)
+    out['ops/ncc/loss'], out['ops/ncc/grad'] = np.float64(l.item()), np32(g)
+    # bending (D != H != W pins the channel/axis quirk)
+    u = ((nets.closed_form_volume((2, 3, D, H, W), seed=12) - 0.5) * 0.3).requires_grad_(True)
+    l = ref.loss.BendingEnergyLoss()(u)
+    g, = torch.autograd.grad(l, u)
+    out['ops/bending/u'] = np32(u)
+    out['ops/bending/loss'], out['ops/bending/grad'] = np.float64(l.item()), np32(g)
+    l = ref.loss.BendingEnergyLoss(spacing=(1.0, 2.0, 1.5))(u)
+    out['ops/bending/loss_spacing'] = np.float64(l.item())
+    # identity grid
+    out['ops/identity'] = np32(ref.utils.get_identity_transform_batch((1, 1, D, H, W)))
+    # warp: displacement large enough to push taps out of range on every side
+    idt = ref.utils.get_identity_transform_batch((1, 1, D, H, W))
+    disp = ((nets.closed_form_volume((2, 3, D, H, W), seed=13) - 0.5) * 1.2).requires_grad_(True)
+    for ch, nm in ((1, 'warp1'), (C, 'warpC')):
+        src = nets.closed_form_volume((2, ch, D, H, W), seed=14 + ch).requires_grad_(True)
+        deform = disp + idt
+        w = F.grid_sample(src, deform.permute(0, 2, 3, 4, 1), mode='bilinear', padding_mode='zeros', align_corners=True)
+        gout = nets.closed_form_volume(tuple(w.shape), seed=20) - 0.5
+        gs, gd = torch.autograd.grad((w * gout).sum(), (src, disp))
+        out[f'ops/{nm}/src'], out[f'ops/{nm}/disp'] = np32(src), np32(disp)
+        out[f'ops/{nm}/out'], out[f'ops/{nm}/gout'] = np32(w), np32(gout)
+        out[f'ops/{nm}/grad_src'], out[f'ops/{nm}/grad_disp'] = np32(gs), np32(gd)
+    # nearest up-sampling (F.interpolate default) incl. odd pyramid sizes (voxel_morph.py:72-80)
+    t = nets.closed_form_volume((1, 2, 2, 3, 5), seed=30)
+    out['ops/nearest/in'] = np32(t)
+    out['ops/nearest/out_3_5_10'] = np32(F.interpolate(t, size=(3, 5, 10)))
+    out['ops/nearest/out_4_6_10'] = np32(F.interpolate(t, size=(4, 6, 10)))
+    # max-pool (incl. exact ties: constant block)
+    p = nets.closed_form_volume((1, 2, 4, 4, 6), seed=31).clone()
+    p[0, 0, :2, :2, :2] = 0.25
+    p.requires_grad_(True)
+    q = F.max_pool3d(p, 2)
+    g, = torch.autograd.grad(q.sum(), p)
+    out['ops/maxpool/in'], out['ops/maxpool/out'], out['ops/maxpool/grad'] = np32(p), np32(q), np32(g)
+    # eval Dice incl. an empty class (NaN) -- scipy path, models/segmentation.py:190-194
+    pred = nets.closed_form_labels((1, D, H, W), 4, seed=40)
+    truth = nets.closed_form_labels((1, D, H, W), 4, seed=41)
+    dice = np.array([ref.metrics.metricEval('dice', pred.numpy() == c, truth.numpy() == c, num_labels=2) for c in range(1, 6)])
+    out['ops/evaldice/pred'], out['ops/evaldice/truth'], out['ops/evaldice/dice'] = np32(pred), np32(truth), dice
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    from oracle import nets
+
+    out = {}
+    run_ops(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'ops.npz'), **out)
+    print('ops.npz', len(out))
+
+    out = {}
+    tiny_cls = ref.unets.UNet_generator(encoders=nets.UNET_TINY['encoders'], decoders=nets.UNET_TINY['decoders'],
+                                        act='LeakyReLU', maxpool=True, upsample=False, res=False)
+    run_seg(ref, tiny_cls, 'UNET_TINY', 1, 5, (16, 24, 32), 2, out, 'seg_tiny', full=True)
+    run_seg(ref, tiny_cls, 'UNET_TINY', 1, 5, (16, 24, 32), 2, out, 'seg_tiny', full=True, dtype=torch.float64, steps=1)
+    np.savez_compressed(os.path.join(OUT, 'seg_tiny.npz'), **out)
+    print('seg_tiny.npz', len(out))
+
+    out = {}
+    light = ref.nf.get_network('UNet_light')
+    run_seg(ref, light, 'UNET_LIGHT', 1, 32, (16, 24, 32), 1, out, 'seg_light', full=False)
+    run_seg(ref, light, 'UNET_LIGHT', 1, 32, (16, 24, 32), 1, out, 'seg_light', full=False, dtype=torch.float64, steps=1)
+    np.savez_compressed(os.path.join(OUT, 'seg_light.npz'), **out)
+    print('seg_light.npz', len(out))
+
+    out = {}
+    run_reg(ref, (20, 24, 20), out, 'reg_odd')
+    run_reg(ref, (20, 24, 20), out, 'reg_odd', dtype=torch.float64, steps=1)
+    run_reg(ref, (16, 24, 32), out, 'reg_even')
+    np.savez_compressed(os.path.join(OUT, 'reg.npz'), **out)
+    print('reg.npz', len(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,40 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+        return cache[name]
+    return load
+
+
+def summary_of(t, nsample=512):
+    """Same (sum, abs-sum, l2, n, stride, strided sample) summary oracle/make_golden.py stores."""
+    import torch
+    t = t.detach().double().reshape(-1).cpu()
+    n = t.numel()
+    stride = max(1, n // nsample)
+    idx = torch.arange(0, n, stride)[:nsample]
+    return np.concatenate([[t.sum().item(), t.abs().sum().item(), t.norm().item(), float(n), float(stride)], t[idx].numpy()])
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
