@@ -1,0 +1,140 @@
+"""ctypes binding of libdeepatlas_hip.so (C ABI declared in include/deepatlas_hip.h).
+
+PyTorch is used here only as plumbing: device memory (torch.empty), the current HIP stream and
+(elsewhere) torch.distributed.  There is NO fallback: if the shared library is missing the import of any
+op fails loudly with the build command.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_float, c_longlong, c_size_t, c_void_p, c_char_p, POINTER
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdeepatlas_hip.so')
+
+P = c_void_p
+I = c_int
+F = c_float
+LL = c_longlong
+SZ = c_size_t
+
+# name -> (restype, argtypes); mirrors include/deepatlas_hip.h one to one
+SIGNATURES = {
+    'da_version': (I, []),
+    'da_device_info': (I, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_char_p, I]),
+    'da_w_oik_to_tio': (I, [P, P, I, I, I, P]),
+    'da_w_tio_to_oik': (I, [P, P, I, I, I, P]),
+    'da_w_iok_to_tio': (I, [P, P, I, I, I, P]),
+    'da_w_tio_to_iok': (I, [P, P, I, I, I, P]),
+    'da_conv3d_k3_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
+    'da_conv3d_k3_fwd': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    'da_conv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, I, P, SZ, P]),
+    'da_conv3d_k3_wgrad': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_set_conv_direct': (I, [I]),
+    'da_conv1x1_fwd': (I, [P, P, P, P, LL, I, I, P]),
+    'da_conv1x1_dgrad': (I, [P, P, P, LL, I, I, P]),
+    'da_conv1x1_wgrad_ws_bytes': (SZ, [LL, I, I]),
+    'da_conv1x1_wgrad': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
+    'da_deconv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    'da_deconv_k2s2_dgrad': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'da_deconv_k2s2_wgrad_ws_bytes': (SZ, [I, I, I, I, I, I]),
+    'da_deconv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_bn_ws_bytes': (SZ, [LL, I]),
+    'da_bn_train_stats': (I, [P, LL, I, P, P, F, F, P, P, P, P, P, P, P, SZ, P]),
+    'da_bn_eval_affine': (I, [P, P, P, P, F, I, P, P, P, P, P]),
+    'da_bn_act_fwd': (I, [P, P, P, F, P, LL, I, P]),
+    'da_bn_act_bwd': (I, [P, P, P, P, P, P, P, F, I, P, P, P, LL, I, P, SZ, P]),
+    'da_act_bwd': (I, [P, P, F, P, LL, P]),
+    'da_colsum': (I, [P, LL, I, P, P, SZ, P]),
+    'da_maxpool2_fwd': (I, [P, P, I, I, I, I, I, P]),
+    'da_maxpool2_bwd': (I, [P, P, P, I, I, I, I, I, P]),
+    'da_upsample_nearest_fwd': (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    'da_upsample_nearest_bwd': (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    'da_warp_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
+    'da_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    'da_identity_grid': (I, [P, I, I, I, I, P]),
+    'da_dice_ws_bytes': (SZ, [I, LL, I]),
+    'da_dice_fwd': (I, [P, P, I, P, I, LL, I, I, I, I, F, P, P, P, SZ, P]),
+    'da_dice_bwd': (I, [P, P, I, P, P, P, P, I, LL, I, I, P]),
+    'da_softmax_fwd': (I, [P, P, LL, I, P]),
+    'da_softmax_bwd': (I, [P, P, P, LL, I, P]),
+    'da_one_hot': (I, [P, I, P, LL, I, P]),
+    'da_ncc_ws_bytes': (SZ, [I, LL]),
+    'da_ncc_fwd': (I, [P, P, I, LL, P, P, P, SZ, P]),
+    'da_ncc_bwd': (I, [P, P, P, P, P, P, I, LL, P]),
+    'da_bending_ws_bytes': (SZ, [I, I, I, I]),
+    'da_bending_fwd': (I, [P, I, I, I, I, P, I, P, P, SZ, P]),
+    'da_bending_bwd': (I, [P, P, P, I, I, I, I, P, I, P]),
+    'da_argmax_dice_counts': (I, [P, P, I, I, LL, I, P, P, P]),
+    'da_adam_step': (I, [P, P, P, P, LL, F, F, F, F, I, F, P]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdeepatlas_hip.so once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise NativeError(
+                "deepatlas_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback for the hot path." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)            # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+_ERR = {-1: 'DA_ERR_BADARG', -2: 'DA_ERR_WS_SMALL', -3: 'DA_ERR_UNSUPPORTED'}
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise NativeError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NativeError("deepatlas_amd ops run only on the GPU (HIP kernels); got a CPU tensor. "
+                              "The CPU restatement lives in oracle/ and is test infrastructure only.")
+
+
+class _Workspace:
+    """One growing scratch buffer per device; kernels on one stream are ordered, so it is shared by all ops."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        nbytes = int(nbytes) + 256
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return c_void_p(b.data_ptr()), c_size_t(b.numel())
+
+
+workspace = _Workspace()

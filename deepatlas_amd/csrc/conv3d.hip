@@ -1,0 +1,337 @@
+// 3x3x3 convolution (padding 1, stride 1|2): C-ABI dispatch + the direct (VALU) kernels.
+// Rows a1/a7/a9 of SURVEY.md §8: nn.Conv3d(k=3,p=1) at unets.py:30,36, modules.py:48, voxel_morph.py:57.
+//
+// Two families live behind da_conv3d_k3_{fwd,dgrad,wgrad}:
+//   * conv3d_mfma.hip : implicit-GEMM on v_mfma_f32_16x16x4_f32 (exact fp32) with LDS-staged halo tiles --
+//                       the MFMA-bound path for Cin % 8 == 0 layers, which carry >95 % of the FLOPs.
+//   * this file       : direct kernels -- one output voxel per lane, all (or a group of) output channels in
+//                       registers, weights fetched through wave-uniform (scalar) loads.  Used where the layer
+//                       is HBM-bound or tiny (Cin in {1,2,3}, Cout = 3, stride-2 dgrad) and as the reference
+//                       implementation the MFMA kernels are A/B-checked against on the GPU.
+#include "common.h"
+#include "conv3d_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// forward, direct.  in = concat(in1[C1], in2[C2]); out channels [0,Cs1) -> out1, [Cs1, Cout) -> out2.
+// ---------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ void __launch_bounds__(256)
+conv3_direct_fwd_kernel(const float* __restrict__ in1, int C1, const float* __restrict__ in2, int C2,
+                        const float* __restrict__ w, const float* __restrict__ bias,
+                        float* __restrict__ out1, int Cs1, float* __restrict__ out2, int Cs2,
+                        int N, int D, int H, int W, int Do, int Ho, int Wo, int Cout, int stride, float slope) {
+    const long long nvox = (long long)N * Do * Ho * Wo;
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int co0 = blockIdx.y * CT;
+    const int Cin = C1 + C2;
+    long long r = v;
+    const int ow = (int)(r % Wo); r /= Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do); const int n = (int)(r / Do);
+    float acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int id = od * stride - 1 + kd;
+        if (id < 0 || id >= D) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * stride - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * stride - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                const long long iv = (((long long)n * D + id) * H + ih) * W + iw;
+                const float* wt = w + (size_t)tap * Cin * Cout + co0;
+                {
+                    const float* p = in1 + iv * C1;
+                    if ((C1 & 3) == 0) {
+                        for (int ci = 0; ci < C1; ci += 4) {
+                            const float4 x = *reinterpret_cast<const float4*>(p + ci);
+#pragma unroll
+                            for (int j = 0; j < CT; ++j) {
+                                if (co0 + j < Cout) {
+                                    acc[j] += x.x * wt[(size_t)(ci + 0) * Cout + j];
+                                    acc[j] += x.y * wt[(size_t)(ci + 1) * Cout + j];
+                                    acc[j] += x.z * wt[(size_t)(ci + 2) * Cout + j];
+                                    acc[j] += x.w * wt[(size_t)(ci + 3) * Cout + j];
+                                }
+                            }
+                        }
+                    } else {
+                        for (int ci = 0; ci < C1; ++ci) {
+                            const float x = p[ci];
+#pragma unroll
+                            for (int j = 0; j < CT; ++j) if (co0 + j < Cout) acc[j] += x * wt[(size_t)ci * Cout + j];
+                        }
+                    }
+                }
+                if (C2 > 0) {
+                    const float* p = in2 + iv * C2;
+                    const float* wt2 = wt + (size_t)C1 * Cout;
+                    if ((C2 & 3) == 0) {
+                        for (int ci = 0; ci < C2; ci += 4) {
+                            const float4 x = *reinterpret_cast<const float4*>(p + ci);
+#pragma unroll
+                            for (int j = 0; j < CT; ++j) {
+                                if (co0 + j < Cout) {
+                                    acc[j] += x.x * wt2[(size_t)(ci + 0) * Cout + j];
+                                    acc[j] += x.y * wt2[(size_t)(ci + 1) * Cout + j];
+                                    acc[j] += x.z * wt2[(size_t)(ci + 2) * Cout + j];
+                                    acc[j] += x.w * wt2[(size_t)(ci + 3) * Cout + j];
+                                }
+                            }
+                        }
+                    } else {
+                        for (int ci = 0; ci < C2; ++ci) {
+                            const float x = p[ci];
+#pragma unroll
+                            for (int j = 0; j < CT; ++j) if (co0 + j < Cout) acc[j] += x * wt2[(size_t)ci * Cout + j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = da_act(acc[j], slope);
+    // stores: 16-byte when the whole group sits in one destination and is aligned
+    const bool vec = (CT % 4 == 0) && (co0 + CT <= Cout) && ((co0 + CT <= Cs1 && (Cs1 & 3) == 0) || (co0 >= Cs1 && (Cs2 & 3) == 0 && ((co0 - Cs1) & 3) == 0));
+    if (vec) {
+        float* o = (co0 + CT <= Cs1) ? out1 + v * Cs1 + co0 : out2 + v * Cs2 + (co0 - Cs1);
+#pragma unroll
+        for (int j = 0; j + 3 < CT; j += 4) *reinterpret_cast<float4*>(o + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int c = co0 + j;
+            if (c < Cout) { if (c < Cs1) out1[v * Cs1 + c] = acc[j]; else out2[v * Cs2 + (c - Cs1)] = acc[j]; }
+        }
+    }
+}
+
+// w_tio [27][Cin][Cout] -> flipped + transposed [27][Cout][Cin]: stride-1 dgrad is a forward conv with it.
+__global__ void w_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cin, int Cout) {
+    const int total = 27 * Cin * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout; const int ci = (i / Cout) % Cin; const int t = i / (Cout * Cin);
+        wf[((size_t)(26 - t) * Cout + co) * Cin + ci] = w[i];
+    }
+}
+
+// stride-2 data gradient (gather): dx[p][ci] = sum_{t, co : 2o - 1 + t = p} dy[o][co] * w[t][ci][co]
+template <int CT>
+__global__ void __launch_bounds__(256)
+conv3_s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                      float* __restrict__ dx1, int C1, float* __restrict__ dx2, int C2,
+                      int N, int D, int H, int W, int Do, int Ho, int Wo, int Cout) {
+    const long long nvox = (long long)N * D * H * W;
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int Cin = C1 + C2;
+    const int ci0 = blockIdx.y * CT;
+    long long r = v;
+    const int iw = (int)(r % W); r /= W;
+    const int ih = (int)(r % H); r /= H;
+    const int id = (int)(r % D); const int n = (int)(r / D);
+    float acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int td = id + 1 - kd;
+        if (td < 0 || (td & 1)) continue;
+        const int od = td >> 1; if (od >= Do) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int th = ih + 1 - kh;
+            if (th < 0 || (th & 1)) continue;
+            const int oh = th >> 1; if (oh >= Ho) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tw = iw + 1 - kw;
+                if (tw < 0 || (tw & 1)) continue;
+                const int ow = tw >> 1; if (ow >= Wo) continue;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                const float* g = dy + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * Cout;
+                const float* wt = w + (size_t)tap * Cin * Cout;
+                for (int co = 0; co < Cout; ++co) {
+                    const float gv = g[co];
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) if (ci0 + j < Cin) acc[j] += gv * wt[(size_t)(ci0 + j) * Cout + co];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int c = ci0 + j;
+        if (c < Cin) { if (c < C1) dx1[v * C1 + c] = acc[j]; else dx2[v * C2 + (c - C1)] = acc[j]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight gradient, direct: every block owns a run of output rows (n, od, oh) and produces a partial
+// dW[27][Cin][Cout]; a second launch sums the partials in double (deterministic).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv3_direct_wgrad_kernel(const float* __restrict__ in1, int C1, const float* __restrict__ in2, int C2,
+                          const float* __restrict__ dy, float* __restrict__ partial,
+                          int N, int D, int H, int W, int Do, int Ho, int Wo, int Cout, int stride, int rows_per_block) {
+    const int Cin = C1 + C2;
+    const int O = 27 * Cin * Cout;
+    const long long nrows = (long long)N * Do * Ho;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block; if (r1 > nrows) r1 = nrows;
+    for (int o = threadIdx.x; o < O; o += blockDim.x) {
+        const int co = o % Cout; const int ci = (o / Cout) % Cin; const int tap = o / (Cout * Cin);
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const float* src; int Cs, cs;
+        if (ci < C1) { src = in1; Cs = C1; cs = ci; } else { src = in2; Cs = C2; cs = ci - C1; }
+        float acc = 0.f;
+        for (long long row = r0; row < r1; ++row) {
+            const int oh = (int)(row % Ho); const int od = (int)((row / Ho) % Do); const int n = (int)(row / ((long long)Ho * Do));
+            const int id = od * stride - 1 + kd, ih = oh * stride - 1 + kh;
+            if (id < 0 || id >= D || ih < 0 || ih >= H) continue;
+            const float* g = dy + (row * Wo) * Cout + co;
+            const float* x = src + ((((long long)n * D + id) * H + ih) * W) * Cs + cs;
+            for (int ow = 0; ow < Wo; ++ow) {
+                const int iw = ow * stride - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                acc += g[(long long)ow * Cout] * x[(long long)iw * Cs];
+            }
+        }
+        partial[(size_t)blockIdx.x * O + o] = acc;
+    }
+}
+
+__global__ void partial_reduce_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nparts; ++b) s += (double)partial[(size_t)b * O + o];
+        out[o] = (float)s;
+    }
+}
+
+template <int CT, typename... Args>
+static int launch_fwd(long long nvox, int Cout, hipStream_t st, Args... args) {
+    hipLaunchKernelGGL((conv3_direct_fwd_kernel<CT>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cout, CT)), dim3(256), 0, st, args...);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// internal entry points (also used by the MFMA dispatcher and the tests' A/B switch)
+// ---------------------------------------------------------------------------------------------------
+int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
+                        float* out1, int Cs1, float* out2, int Cs2,
+                        int N, int D, int H, int W, int Cout, int stride, float slope, hipStream_t st) {
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long nvox = (long long)N * Do * Ho * Wo;
+    if (Cout <= 4)  return launch_fwd<4>(nvox, Cout, st, in1, C1, in2, C2, w, bias, out1, Cs1, out2, Cs2, N, D, H, W, Do, Ho, Wo, Cout, stride, slope);
+    if (Cout <= 8)  return launch_fwd<8>(nvox, Cout, st, in1, C1, in2, C2, w, bias, out1, Cs1, out2, Cs2, N, D, H, W, Do, Ho, Wo, Cout, stride, slope);
+    return launch_fwd<16>(nvox, Cout, st, in1, C1, in2, C2, w, bias, out1, Cs1, out2, Cs2, N, D, H, W, Do, Ho, Wo, Cout, stride, slope);
+}
+
+static size_t wgrad_direct_parts(long long nrows, int O, int* rows_per_block) {
+    long long parts = nrows < 1024 ? nrows : 1024;
+    const long long cap = (long long)(64ull << 20) / ((long long)O * 4);
+    if (parts > cap) parts = cap;
+    if (parts < 1) parts = 1;
+    *rows_per_block = (int)da_cdiv(nrows, parts);
+    return (size_t)da_cdiv(nrows, *rows_per_block);
+}
+
+extern "C" size_t da_conv3d_k3_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int stride) {
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1;
+    const int O = 27 * Cin * Cout;
+    int rpb;
+    const size_t parts = wgrad_direct_parts((long long)N * Do * Ho, O, &rpb);
+    size_t direct = da_align(parts * (size_t)O * sizeof(float));
+    size_t mfma = da_conv3_mfma_ws_bytes(N, D, H, W, Cin, Cout, stride);
+    size_t packed = da_align((size_t)2 * O * sizeof(float) + 65536);
+    const int Cm = Cin > Cout ? Cin : Cout;
+    return packed + (direct > mfma ? direct : mfma) + da_bn_ws_bytes(0, Cm) + 4096;
+}
+
+static int g_force_direct = -1;
+static bool force_direct() {
+    if (g_force_direct < 0) { const char* e = getenv("DA_CONV_DIRECT"); g_force_direct = (e && e[0] == '1') ? 1 : 0; }
+    return g_force_direct == 1;
+}
+extern "C" int da_set_conv_direct(int on) { const int prev = force_direct() ? 1 : 0; g_force_direct = on ? 1 : 0; return prev; }
+
+extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int C2,
+                                const float* w_tio, const float* bias, float* out,
+                                int N, int D, int H, int W, int Cout, int stride, float act_slope,
+                                void* ws, size_t ws_bytes, void* stream) {
+    if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
+        return DA_ERR_BADARG;
+    hipStream_t st = da_stream(stream);
+    if (!force_direct() && da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) {
+        if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+        return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
+                                 N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
+    }
+    return da_conv3_direct_fwd(in1, C1, in2, C2, w_tio, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, stride, act_slope, st);
+}
+
+extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
+                                  int N, int D, int H, int W, int Cout, int stride,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w_tio || !dx1 || C1 <= 0 || C2 < 0 || (C2 > 0 && !dx2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
+    hipStream_t st = da_stream(stream);
+    const int Cin = C1 + C2;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)) return DA_ERR_WS_SMALL;
+    if (stride == 1) {
+        // dX = conv(dY, flip/transpose(W)) : Cin' = Cout, Cout' = Cin, output split over (dx1, dx2)
+        if (!force_direct() && da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1)) {
+            return da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, dx1, C1, dx2, C2,
+                                     N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, st);
+        }
+        float* wf = (float*)ws;
+        hipLaunchKernelGGL(w_flip_transpose_kernel, dim3(da_grid(27 * Cin * Cout, 256)), dim3(256), 0, st, w_tio, wf, Cin, Cout);
+        DA_LAUNCH_CHECK();
+        return da_conv3_direct_fwd(dy, Cout, nullptr, 0, wf, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, 1, -1.f, st);
+    }
+    const int Do = (D - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long nvox = (long long)N * D * H * W;
+    hipLaunchKernelGGL((conv3_s2_dgrad_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cin, 16)), dim3(256), 0, st,
+                       dy, w_tio, dx1, C1, dx2, C2, N, D, H, W, Do, Ho, Wo, Cout);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy,
+                                  float* dw_tio, float* dbias,
+                                  int N, int D, int H, int W, int Cout, int stride,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    if (!in1 || !dy || !dw_tio || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
+    hipStream_t st = da_stream(stream);
+    const int Cin = C1 + C2;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)) return DA_ERR_WS_SMALL;
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int O = 27 * Cin * Cout;
+    int rc = 0;
+    if (!force_direct() && da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) {
+        rc = da_conv3_mfma_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, st);
+    } else {
+        int rpb;
+        const size_t parts = wgrad_direct_parts((long long)N * Do * Ho, O, &rpb);
+        float* partial = (float*)ws;
+        hipLaunchKernelGGL(conv3_direct_wgrad_kernel, dim3((unsigned)parts), dim3(256), 0, st, in1, C1, in2, C2, dy, partial,
+                           N, D, H, W, Do, Ho, Wo, Cout, stride, rpb);
+        DA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, (int)parts, O, dw_tio);
+        DA_LAUNCH_CHECK();
+    }
+    if (rc) return rc;
+    if (dbias) {
+        // the column-sum scratch sits after the largest partial region
+        const size_t off = ws_bytes - da_bn_ws_bytes(0, Cout);
+        rc = da_colsum(dy, (long long)N * Do * Ho * Wo, Cout, dbias, (char*)ws + (off / 256) * 256, da_bn_ws_bytes(0, Cout), stream);
+    }
+    return rc;
+}

@@ -1,0 +1,24 @@
+// Internal (non-ABI) entry points shared between conv3d.hip (dispatch + direct kernels) and
+// conv3d_mfma.hip (implicit-GEMM MFMA kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int stride);
+
+// forward-shaped implicit GEMM.  in = concat(in1[C1], in2[C2]); output channels [0,Cs1) -> out1, rest -> out2.
+// w_is_flipped_tr != 0: `w_tio` is the ORIGINAL layer's [27][Cout][C1] tensor and the kernel runs the data-gradient
+// convolution (taps flipped, channels transposed) -- i.e. logical Cin = C1, logical Cout = `Cout`.
+bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride);
+int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
+                      const float* bias, float* out1, int Cs1, float* out2, int Cs2,
+                      int N, int D, int H, int W, int Cout, int stride, float slope,
+                      void* ws, size_t ws_bytes, hipStream_t st);
+
+bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride);
+int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st);
+
+int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
+                        float* out1, int Cs1, float* out2, int Cs2,
+                        int N, int D, int H, int W, int Cout, int stride, float slope, hipStream_t st);

@@ -1,0 +1,292 @@
+// 2x2x2 stride-2 transposed convolution (row a3: nn.ConvTranspose3d(k=2,s=2), unets.py:49,55,240-241) and the
+// 1x1x1 segmentation head (row a5: nn.Conv3d(dec[-1], n_classes, 1), unets.py:249-250).  NDHWC, fp32.
+// Both are HBM-bound at DeepAtlas' widths (the up-sampled tensor is the largest activation): one input voxel
+// per lane, weights through wave-uniform scalar loads, each lane writes contiguous runs of output channels.
+#include "common.h"
+
+namespace {
+
+// One lane = one INPUT voxel and one (i, j) output row parity; it emits both k = 0, 1 outputs, i.e. a contiguous
+// run of 2*Cout floats, for CT output channels at a time.
+template <int CT>
+__global__ void __launch_bounds__(256)
+deconv_k2s2_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                       float* __restrict__ out, int N, int D, int H, int W, int Cin, int Cout) {
+    const long long nvox = (long long)N * D * H * W;
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int co0 = blockIdx.y * CT;
+    long long r = v;
+    const int iw = (int)(r % W); r /= W;
+    const int ih = (int)(r % H); r /= H;
+    const int id = (int)(r % D); const int n = (int)(r / D);
+    const float* x = in + v * Cin;
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+#pragma unroll 1
+    for (int ij = 0; ij < 4; ++ij) {
+        const int i = ij >> 1, j = ij & 1;
+        float acc[2][CT];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[k][c] = (bias && co0 + c < Cout) ? bias[co0 + c] : 0.f;
+        const float* w0 = w + ((size_t)(ij * 2 + 0) * Cin) * Cout + co0;
+        const float* w1 = w + ((size_t)(ij * 2 + 1) * Cin) * Cout + co0;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = x[ci];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (co0 + c < Cout) {
+                    acc[0][c] += xv * w0[(size_t)ci * Cout + c];
+                    acc[1][c] += xv * w1[(size_t)ci * Cout + c];
+                }
+            }
+        }
+        float* o = out + ((((long long)n * Do + 2 * id + i) * Ho + 2 * ih + j) * Wo + 2 * iw) * Cout + co0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if ((CT % 4 == 0) && (Cout % 4 == 0) && co0 + CT <= Cout) {
+#pragma unroll
+                for (int c = 0; c < CT; c += 4) *reinterpret_cast<float4*>(o + (size_t)k * Cout + c) = make_float4(acc[k][c], acc[k][c + 1], acc[k][c + 2], acc[k][c + 3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) if (co0 + c < Cout) o[(size_t)k * Cout + c] = acc[k][c];
+            }
+        }
+    }
+}
+
+// dx[v][ci] = sum_{tap, co} dy[2v + tap][co] * w[tap][ci][co]
+template <int CT>
+__global__ void __launch_bounds__(256)
+deconv_k2s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                         int N, int D, int H, int W, int Cin, int Cout) {
+    const long long nvox = (long long)N * D * H * W;
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int ci0 = blockIdx.y * CT;
+    long long r = v;
+    const int iw = (int)(r % W); r /= W;
+    const int ih = (int)(r % H); r /= H;
+    const int id = (int)(r % D); const int n = (int)(r / D);
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 8; ++tap) {
+        const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
+        const float* g = dy + ((((long long)n * Do + 2 * id + i) * Ho + 2 * ih + j) * Wo + 2 * iw + k) * Cout;
+        const float* wt = w + (size_t)tap * Cin * Cout;
+        for (int co = 0; co < Cout; ++co) {
+            const float gv = g[co];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) if (ci0 + c < Cin) acc[c] += gv * wt[(size_t)(ci0 + c) * Cout + co];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (ci0 + c < Cin) dx[v * Cin + ci0 + c] = acc[c];
+}
+
+// dW[tap][ci][co] partials: each block owns a run of input voxels; thread o handles outputs o, o+256, ...
+__global__ void __launch_bounds__(256)
+deconv_k2s2_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy, float* __restrict__ partial,
+                         int N, int D, int H, int W, int Cin, int Cout, long long vox_per_block) {
+    const int O = 8 * Cin * Cout;
+    const long long nvox = (long long)N * D * H * W;
+    const long long v0 = (long long)blockIdx.x * vox_per_block;
+    long long v1 = v0 + vox_per_block; if (v1 > nvox) v1 = nvox;
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+    for (int o = threadIdx.x; o < O; o += blockDim.x) {
+        const int co = o % Cout; const int ci = (o / Cout) % Cin; const int tap = o / (Cout * Cin);
+        const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
+        float acc = 0.f;
+        for (long long v = v0; v < v1; ++v) {
+            long long r = v;
+            const int iw = (int)(r % W); r /= W;
+            const int ih = (int)(r % H); r /= H;
+            const int id = (int)(r % D); const int n = (int)(r / D);
+            acc += in[v * Cin + ci] * dy[((((long long)n * Do + 2 * id + i) * Ho + 2 * ih + j) * Wo + 2 * iw + k) * Cout + co];
+        }
+        partial[(size_t)blockIdx.x * O + o] = acc;
+    }
+}
+
+__global__ void reduce_parts_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nparts; ++b) s += (double)partial[(size_t)b * O + o];
+        out[o] = (float)s;
+    }
+}
+
+// 1x1x1 conv: out[row][co] = bias[co] + sum_ci in[row][ci] * w[ci][co]   (transposed != 0: w is [Cout][Cin])
+template <int CT>
+__global__ void __launch_bounds__(256)
+conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+               float* __restrict__ out, long long M, int Cin, int Cout, int transposed) {
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const int co0 = blockIdx.y * CT;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = (bias && co0 + c < Cout) ? bias[co0 + c] : 0.f;
+    const float* x = in + row * Cin;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float xv = x[ci];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (co0 + c < Cout) acc[c] += xv * (transposed ? w[(size_t)(co0 + c) * Cin + ci] : w[(size_t)ci * Cout + co0 + c]);
+    }
+    float* o = out + row * Cout + co0;
+    if ((CT % 4 == 0) && (Cout % 4 == 0) && co0 + CT <= Cout) {
+#pragma unroll
+        for (int c = 0; c < CT; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) if (co0 + c < Cout) o[c] = acc[c];
+    }
+}
+
+// dW[ci][co] partials: rows staged through LDS in tiles of R rows; thread t owns outputs t, t+256, ... (<= 16 each)
+constexpr int kWgR = 64;
+__global__ void __launch_bounds__(256)
+conv1x1_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy, float* __restrict__ partial,
+                     long long M, int Cin, int Cout, long long rows_per_block) {
+    extern __shared__ float sh[];   // [R][Cin] then [R][Cout]
+    float* sx = sh; float* sg = sh + kWgR * Cin;
+    const int O = Cin * Cout;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (long long base = r0; base < r1; base += kWgR) {
+        const int nr = (int)((r1 - base) < kWgR ? (r1 - base) : kWgR);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nr * Cin; idx += blockDim.x) sx[idx] = in[base * Cin + idx];
+        for (int idx = threadIdx.x; idx < nr * Cout; idx += blockDim.x) sg[idx] = dy[base * Cout + idx];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int o = threadIdx.x + k * 256;
+            if (o < O) {
+                const int ci = o / Cout, co = o % Cout;
+                float a = acc[k];
+                for (int rr = 0; rr < nr; ++rr) a += sx[rr * Cin + ci] * sg[rr * Cout + co];
+                acc[k] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int o = threadIdx.x + k * 256;
+        if (o < O) partial[(size_t)blockIdx.x * O + o] = acc[k];
+    }
+}
+
+static int parts_for(long long units, int O, long long* per) {
+    long long parts = units < 1024 ? units : 1024;
+    const long long cap = (long long)(64ull << 20) / ((long long)O * 4);
+    if (parts > cap) parts = cap;
+    if (parts < 1) parts = 1;
+    *per = da_cdiv(units, parts);
+    return (int)da_cdiv(units, *per);
+}
+
+}  // namespace
+
+extern "C" int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const float* bias, float* out,
+                                  int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+    if (!in || !w_tio || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    const long long nvox = (long long)N * D * H * W;
+    hipLaunchKernelGGL((deconv_k2s2_fwd_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cout, 16)), dim3(256), 0, da_stream(stream),
+                       in, w_tio, bias, out, N, D, H, W, Cin, Cout);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
+                                    int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+    if (!dy || !w_tio || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    const long long nvox = (long long)N * D * H * W;
+    hipLaunchKernelGGL((deconv_k2s2_dgrad_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cin, 16)), dim3(256), 0, da_stream(stream),
+                       dy, w_tio, dx, N, D, H, W, Cin, Cout);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    long long per;
+    const int O = 8 * Cin * Cout;
+    const int parts = parts_for((long long)N * D * H * W, O, &per);
+    const int Cm = Cout;
+    return da_align((size_t)parts * O * sizeof(float)) + da_bn_ws_bytes(0, Cm) + 512;
+}
+
+extern "C" int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_tio, float* dbias,
+                                    int N, int D, int H, int W, int Cin, int Cout,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !dy || !dw_tio || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (ws_bytes < da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    long long per;
+    const int O = 8 * Cin * Cout;
+    const int parts = parts_for((long long)N * D * H * W, O, &per);
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel, dim3(parts), dim3(256), 0, st, in, dy, partial, N, D, H, W, Cin, Cout, per);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, parts, O, dw_tio);
+    DA_LAUNCH_CHECK();
+    if (dbias) {
+        char* cs = (char*)ws + da_align((size_t)parts * O * sizeof(float));
+        return da_colsum(dy, (long long)N * D * H * W * 8, Cout, dbias, cs, da_bn_ws_bytes(0, Cout), stream);
+    }
+    return 0;
+}
+
+extern "C" int da_conv1x1_fwd(const float* in, const float* w_io, const float* bias, float* out,
+                              long long M, int Cin, int Cout, void* stream) {
+    if (!in || !w_io || !out || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (Cout >= 32) hipLaunchKernelGGL((conv1x1_kernel<32>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cout, 32)), dim3(256), 0, da_stream(stream), in, w_io, bias, out, M, Cin, Cout, 0);
+    else hipLaunchKernelGGL((conv1x1_kernel<8>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cout, 8)), dim3(256), 0, da_stream(stream), in, w_io, bias, out, M, Cin, Cout, 0);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout, void* stream) {
+    if (!dy || !w_io || !dx || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    // dx[row][ci] = sum_co dy[row][co] * w[ci][co] : a 1x1 conv with "Cin" = Cout, "Cout" = Cin and w read transposed
+    if (Cin >= 32) hipLaunchKernelGGL((conv1x1_kernel<32>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cin, 32)), dim3(256), 0, da_stream(stream), dy, w_io, nullptr, dx, M, Cout, Cin, 1);
+    else hipLaunchKernelGGL((conv1x1_kernel<8>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cin, 8)), dim3(256), 0, da_stream(stream), dy, w_io, nullptr, dx, M, Cout, Cin, 1);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t da_conv1x1_wgrad_ws_bytes(long long M, int Cin, int Cout) {
+    long long per;
+    const int O = Cin * Cout;
+    const int parts = parts_for(da_cdiv(M, kWgR), O, &per);
+    return da_align((size_t)parts * O * sizeof(float)) + da_bn_ws_bytes(0, Cout) + 512;
+}
+
+extern "C" int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, float* dbias,
+                                long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !dy || !dw_io || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    const int O = Cin * Cout;
+    if (O > 4096) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv1x1_wgrad_ws_bytes(M, Cin, Cout)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    long long per;
+    const int parts = parts_for(da_cdiv(M, kWgR), O, &per);
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(parts), dim3(256), (size_t)kWgR * (Cin + Cout) * sizeof(float), st, in, dy, partial, M, Cin, Cout, per * kWgR);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, parts, O, dw_io);
+    DA_LAUNCH_CHECK();
+    if (dbias) {
+        char* cs = (char*)ws + da_align((size_t)parts * O * sizeof(float));
+        return da_colsum(dy, M, Cout, dbias, cs, da_bn_ws_bytes(0, Cout), stream);
+    }
+    return 0;
+}

@@ -1,0 +1,308 @@
+// BatchNorm3d (train/eval) + LeakyReLU/ReLU forward & backward, per-channel column sums.
+// Rows a1/a3 of SURVEY.md §8: nn.BatchNorm3d + nn.LeakyReLU at unets.py:31-32,51-52.
+// Layout: x[M][C] (NDHWC flattened, M = N*D*H*W).  All kernels are HBM-bound streaming passes:
+// 16-byte accesses per lane, per-thread fp32 partials, per-block and cross-block sums in double,
+// cross-block reduction in a second tiny launch (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 1024;
+
+struct RowPlan { int vec, cq, rpi, block, grid; long long rows_per_block; };
+
+static RowPlan plan_rows(long long M, int C) {
+    RowPlan p;
+    p.vec = (C % 4 == 0) ? 4 : 1;
+    p.cq = C / p.vec;
+    p.rpi = 256 / p.cq; if (p.rpi < 1) p.rpi = 1;
+    p.block = p.cq * p.rpi;
+    long long g = da_cdiv(M, (long long)p.rpi * 16);
+    if (g > kMaxBlocks) g = kMaxBlocks;
+    if (g < 1) g = 1;
+    p.grid = (int)g;
+    p.rows_per_block = da_cdiv(M, g);
+    return p;
+}
+
+// partial[b][k][C] doubles, k < NK.  MODE 0: (sum x, sum x^2); MODE 1: (sum x); MODE 2: BN backward sums
+template <int VEC, int MODE>
+__global__ void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                   long long M, int C, long long rows_per_block, double* __restrict__ partial) {
+    extern __shared__ double sh[];   // [2][rpi][C]
+    const int cq = C / VEC;
+    const int rpi = blockDim.x / cq;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    float a0[VEC], a1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+    float mu[VEC], rs[VEC], sc[VEC], sf[VEC];
+    if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { mu[j] = mean[q * VEC + j]; rs[j] = rstd[q * VEC + j]; sc[j] = scale[q * VEC + j]; sf[j] = shift[q * VEC + j]; }
+    }
+    for (long long row = r0 + r; row < r1; row += rpi) {
+        float xv[VEC], gv[VEC];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + row * C + q * 4);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            if (MODE == 2) {
+                const float4 g = *reinterpret_cast<const float4*>(dy + row * C + q * 4);
+                gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+            }
+        } else {
+            xv[0] = x[row * C + q];
+            if (MODE == 2) gv[0] = dy[row * C + q];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (MODE == 0) { a0[j] += xv[j]; a1[j] += xv[j] * xv[j]; }
+            else if (MODE == 1) { a0[j] += xv[j]; }
+            else {
+                const float z = xv[j] * sc[j] + sf[j];
+                const float dz = gv[j] * da_act_grad(z, slope);
+                const float xh = (xv[j] - mu[j]) * rs[j];
+                a0[j] += dz; a1[j] += dz * xh;
+            }
+        }
+    }
+    double* s0 = sh;
+    double* s1 = sh + (size_t)rpi * C;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s0[r * C + q * VEC + j] = (double)a0[j]; s1[r * C + q * VEC + j] = (double)a1[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int rr = 0; rr < rpi; ++rr) { t0 += s0[rr * C + c]; t1 += s1[rr * C + c]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = t0;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = t1;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblocks, long long M, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   float* mean, float* rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    const double m = s / (double)M;
+    double var = ss / (double)M - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = mf; rstd[c] = rs;
+    const float sc = g * rs;
+    scale[c] = sc; shift[c] = b - mf * sc;
+    if (running_mean) {
+        const double unbiased = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* mean, float* rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rs = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = rm[c]; rstd[c] = rs; scale[c] = g * rs; shift[c] = b - rm[c] * g * rs;
+}
+
+template <int VEC>
+__global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float slope, float* __restrict__ y,
+                                  long long nvec, int cq) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        if (VEC == 4) {
+            const float4 t = reinterpret_cast<const float4*>(x)[i];
+            const float4 sc = reinterpret_cast<const float4*>(scale)[q];
+            const float4 sf = reinterpret_cast<const float4*>(shift)[q];
+            float4 o;
+            o.x = da_act(t.x * sc.x + sf.x, slope); o.y = da_act(t.y * sc.y + sf.y, slope);
+            o.z = da_act(t.z * sc.z + sf.z, slope); o.w = da_act(t.w * sc.w + sf.w, slope);
+            reinterpret_cast<float4*>(y)[i] = o;
+        } else {
+            y[i] = da_act(x[i] * scale[q] + shift[q], slope);
+        }
+    }
+}
+
+// finalize BN-backward sums: dgamma = s2, dbeta = s1, cm[0][c] = s1/M, cm[1][c] = s2/M
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long long M, int C,
+                                       float* dgamma, float* dbeta, float* cm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s1 += partial[((size_t)b * 2) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    cm[c] = (float)(s1 / (double)M);
+    cm[C + c] = (float)(s2 / (double)M);
+}
+
+template <int VEC>
+__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ cm, float slope, int train,
+                                        float* __restrict__ dx, long long nvec, int cq, int C) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        float xv[VEC], gv[VEC], o[VEC];
+        if (VEC == 4) {
+            const float4 t = reinterpret_cast<const float4*>(x)[i];
+            const float4 g = reinterpret_cast<const float4*>(dy)[i];
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+        } else { xv[0] = x[i]; gv[0] = dy[i]; }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = q * VEC + j;
+            const float sc = scale[c];
+            const float z = xv[j] * sc + shift[c];
+            const float dz = gv[j] * da_act_grad(z, slope);
+            if (train) {
+                const float xh = (xv[j] - mean[c]) * rstd[c];
+                o[j] = sc * (dz - cm[c] - xh * cm[C + c]);
+            } else {
+                o[j] = sc * dz;
+            }
+        }
+        if (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        else dx[i] = o[0];
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float slope,
+                               float* __restrict__ dx, long long n) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 g = reinterpret_cast<const float4*>(dy)[i];
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        float4 o;
+        o.x = g.x * (v.x > 0.f ? 1.f : slope); o.y = g.y * (v.y > 0.f ? 1.f : slope);
+        o.z = g.z * (v.z > 0.f ? 1.f : slope); o.w = g.w * (v.w > 0.f ? 1.f : slope);
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * (y[i] > 0.f ? 1.f : slope);
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 2) * C + c];
+    out[c] = (float)s;
+}
+
+template <int MODE>
+int launch_partial(const RowPlan& p, const float* x, const float* dy, const float* mean, const float* rstd,
+                   const float* scale, const float* shift, float slope, long long M, int C, double* partial, hipStream_t st) {
+    const size_t shm = (size_t)2 * p.rpi * C * sizeof(double);
+    if (p.vec == 4)
+        hipLaunchKernelGGL((col_partial_kernel<4, MODE>), dim3(p.grid), dim3(p.block), shm, st, x, dy, mean, rstd, scale, shift, slope, M, C, p.rows_per_block, partial);
+    else
+        hipLaunchKernelGGL((col_partial_kernel<1, MODE>), dim3(p.grid), dim3(p.block), shm, st, x, dy, mean, rstd, scale, shift, slope, M, C, p.rows_per_block, partial);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t da_bn_ws_bytes(long long M, int C) {
+    (void)M;
+    return da_align((size_t)kMaxBlocks * 2 * C * sizeof(double)) + da_align((size_t)2 * C * sizeof(float));
+}
+
+extern "C" int da_bn_train_stats(const float* x, long long M, int C, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 float* mean, float* rstd, float* scale, float* shift,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!x || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    double* partial = (double*)ws;
+    int rc = launch_partial<0>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, da_stream(stream), partial, p.grid, M, C,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float eps, int C, float* mean, float* rstd, float* scale, float* shift, void* stream) {
+    if (!running_mean || !running_var || C <= 0) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, da_stream(stream), gamma, beta, running_mean, running_var, eps, C, mean, rstd, scale, shift);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_bn_act_fwd(const float* x, const float* scale, const float* shift, float act_slope, float* y,
+                             long long M, int C, void* stream) {
+    if (!x || !y || M <= 0 || C <= 0) return DA_ERR_BADARG;
+    if (C % 4 == 0) {
+        const long long nvec = M * C / 4;
+        hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(da_grid(nvec, 256)), dim3(256), 0, da_stream(stream), x, scale, shift, act_slope, y, nvec, C / 4);
+    } else {
+        const long long nvec = M * C;
+        hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(da_grid(nvec, 256)), dim3(256), 0, da_stream(stream), x, scale, shift, act_slope, y, nvec, C);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* scale, const float* shift, float act_slope, int train,
+                             float* dx, float* dgamma, float* dbeta, long long M, int C,
+                             void* ws, size_t ws_bytes, void* stream) {
+    (void)gamma;
+    if (!dy || !x || !dx || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    double* partial = (double*)ws;
+    float* cm = (float*)((char*)ws + da_align((size_t)kMaxBlocks * 2 * C * sizeof(double)));
+    hipStream_t st = da_stream(stream);
+    int rc = launch_partial<2>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm);
+    DA_LAUNCH_CHECK();
+    if (C % 4 == 0) {
+        const long long nvec = M * C / 4;
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C / 4, C);
+    } else {
+        const long long nvec = M * C;
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<1>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C, C);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream) {
+    if (!dy || !y || !dx || numel <= 0) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(da_grid(numel / 4 + 1, 256)), dim3(256), 0, da_stream(stream), dy, y, act_slope < 0.f ? 1.f : act_slope, dx, numel);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    double* partial = (double*)ws;
+    int rc = launch_partial<1>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, da_stream(stream), partial, p.grid, C, out);
+    DA_LAUNCH_CHECK();
+    return 0;
+}

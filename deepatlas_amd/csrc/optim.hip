@@ -1,0 +1,81 @@
+// Adam (torch.optim.Adam defaults, models/segmentation.py:91) over one flat parameter bucket, weight layout
+// transforms between the reference's state_dict layouts and the kernels' tap-major layouts, library info.
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float lr_over_bc1, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;       // sqrt(v)/sqrt(bc2) + eps
+        p[i] = p[i] - lr_over_bc1 * (mi / denom);
+    }
+}
+
+// generic 3-axis permutation of a [A][B][K] tensor into [K][P][Q]; mode selects which of (A,B) is Cin
+__global__ void w_to_tio_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B, int K, int a_is_cout) {
+    const long long total = (long long)A * B * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); const int b = (int)((i / K) % B); const int a = (int)(i / ((long long)K * B));
+        // src[a][b][k]; dst[k][ci][co]
+        const int Cin = a_is_cout ? B : A, Cout = a_is_cout ? A : B;
+        const int ci = a_is_cout ? b : a, co = a_is_cout ? a : b;
+        dst[((size_t)k * Cin + ci) * Cout + co] = src[i];
+    }
+}
+__global__ void tio_to_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B, int K, int a_is_cout) {
+    const long long total = (long long)A * B * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); const int b = (int)((i / K) % B); const int a = (int)(i / ((long long)K * B));
+        const int Cin = a_is_cout ? B : A, Cout = a_is_cout ? A : B;
+        const int ci = a_is_cout ? b : a, co = a_is_cout ? a : b;
+        dst[i] = src[((size_t)k * Cin + ci) * Cout + co];
+    }
+}
+
+}  // namespace
+
+extern "C" int da_version(void) { return 100; }
+
+extern "C" int da_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return 0;
+}
+
+extern "C" int da_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                            float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return DA_ERR_BADARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(da_grid(n, 256)), dim3(256), 0, da_stream(stream), p, g, m, v, n,
+                       (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DA_W_LAUNCH(KERN, A, B, K, FLAG)                                                                              \
+    do {                                                                                                              \
+        if (!src || !dst || (A) <= 0 || (B) <= 0 || (K) <= 0) return DA_ERR_BADARG;                                   \
+        hipLaunchKernelGGL(KERN, dim3(da_grid((long long)(A) * (B) * (K), 256, 1024)), dim3(256), 0, da_stream(stream), src, dst, A, B, K, FLAG); \
+        DA_LAUNCH_CHECK();                                                                                            \
+        return 0;                                                                                                     \
+    } while (0)
+
+extern "C" int da_w_oik_to_tio(const float* src, float* dst, int Cout, int Cin, int K3, void* stream) { DA_W_LAUNCH(w_to_tio_kernel, Cout, Cin, K3, 1); }
+extern "C" int da_w_tio_to_oik(const float* src, float* dst, int Cout, int Cin, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cout, Cin, K3, 1); }
+extern "C" int da_w_iok_to_tio(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(w_to_tio_kernel, Cin, Cout, K3, 0); }
+extern "C" int da_w_tio_to_iok(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cin, Cout, K3, 0); }

@@ -1,0 +1,183 @@
+// MaxPool3d(2) forward/backward and nearest-neighbour up-sampling forward/backward (NDHWC).
+// Rows a2 / a8 of SURVEY.md §8: nn.MaxPool3d(2) at unets.py:230,267; F.interpolate(x, size=...) (nearest)
+// at voxel_morph.py:72,74,76,80.  HBM-bound gathers: one 16-byte channel quad per lane.
+#include "common.h"
+
+namespace {
+
+template <int VEC>
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                    int N, int D, int H, int W, int C) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
+    const long long total = (long long)N * Do * Ho * Wo * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        float m[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            const float* p = x + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+            if (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(p);
+                // PyTorch: update if (val > max) || isnan(val)
+                m[0] = (a.x > m[0] || a.x != a.x) ? a.x : m[0]; m[1] = (a.y > m[1] || a.y != a.y) ? a.y : m[1];
+                m[2] = (a.z > m[2] || a.z != a.z) ? a.z : m[2]; m[3] = (a.w > m[3] || a.w != a.w) ? a.w : m[3];
+            } else {
+                const float a = *p; m[0] = (a > m[0] || a != a) ? a : m[0];
+            }
+        }
+        float* o = y + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+        if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
+        else *o = m[0];
+    }
+}
+
+// One thread per OUTPUT window and channel group: recompute the arg-max (first maximum in scan order),
+// write all eight input-gradient positions (dense stores, no atomics).  Voxels of odd trailing planes
+// (floor mode) are zeroed by the caller's memset when D/H/W are odd.
+template <int VEC>
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                    int N, int D, int H, int W, int C) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
+    const long long total = (long long)N * Do * Ho * Wo * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        float m[VEC], g[VEC]; int am[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = 0; }
+        const float* gp = dy + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+        if (VEC == 4) { const float4 a = *reinterpret_cast<const float4*>(gp); g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; }
+        else g[0] = *gp;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            const float* p = x + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+            float a[VEC];
+            if (VEC == 4) { const float4 b = *reinterpret_cast<const float4*>(p); a[0] = b.x; a[1] = b.y; a[2] = b.z; a[3] = b.w; }
+            else a[0] = *p;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) if (a[j] > m[j] || a[j] != a[j]) { m[j] = a[j]; am[j] = t; }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            float* p = dx + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+            if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(am[0] == t ? g[0] : 0.f, am[1] == t ? g[1] : 0.f, am[2] == t ? g[2] : 0.f, am[3] == t ? g[3] : 0.f);
+            else *p = (am[0] == t) ? g[0] : 0.f;
+        }
+    }
+}
+
+// PyTorch nearest (legacy "nearest", not "nearest-exact"): src = min(floor(dst * (float)in/out), in-1)
+__device__ __forceinline__ int nearest_src(int dst, int in, int out, float scale) {
+    if (in == out) return dst;
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+template <int VEC>
+__global__ void upsample_nearest_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                            int N, int D, int H, int W, int C, int Do, int Ho, int Wo) {
+    const int cq = C / VEC;
+    const float sd = (float)D / (float)Do, sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    const long long total = (long long)N * Do * Ho * Wo * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        const int d = nearest_src(od, D, Do, sd), h = nearest_src(oh, H, Ho, sh), w = nearest_src(ow, W, Wo, sw);
+        const float* p = x + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+        float* o = y + i * VEC;
+        if (VEC == 4) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(p);
+        else *o = *p;
+    }
+}
+
+// gather form of the backward: every input voxel sums the output voxels that map onto it.
+template <int VEC>
+__global__ void upsample_nearest_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                            int N, int D, int H, int W, int C, int Do, int Ho, int Wo) {
+    const int cq = C / VEC;
+    const float sd = (float)D / (float)Do, sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    const long long total = (long long)N * D * H * W * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H); v /= H;
+        const int d = (int)(v % D); const int n = (int)(v / D);
+        // candidate output range per axis: [floor(i*out/in) - 1, floor((i+1)*out/in) + 1]
+        const int d0 = max(0, (int)((long long)d * Do / D) - 1), d1 = min(Do - 1, (int)((long long)(d + 1) * Do / D) + 1);
+        const int h0 = max(0, (int)((long long)h * Ho / H) - 1), h1 = min(Ho - 1, (int)((long long)(h + 1) * Ho / H) + 1);
+        const int w0 = max(0, (int)((long long)w * Wo / W) - 1), w1 = min(Wo - 1, (int)((long long)(w + 1) * Wo / W) + 1);
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        for (int od = d0; od <= d1; ++od) {
+            if (nearest_src(od, D, Do, sd) != d) continue;
+            for (int oh = h0; oh <= h1; ++oh) {
+                if (nearest_src(oh, H, Ho, sh) != h) continue;
+                for (int ow = w0; ow <= w1; ++ow) {
+                    if (nearest_src(ow, W, Wo, sw) != w) continue;
+                    const float* p = dy + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+                    if (VEC == 4) { const float4 a = *reinterpret_cast<const float4*>(p); acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; }
+                    else acc[0] += *p;
+                }
+            }
+        }
+        float* o = dx + i * VEC;
+        if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else *o = acc[0];
+    }
+}
+
+}  // namespace
+
+#define DA_VEC_DISPATCH(KERNEL, total, ...)                                                                      \
+    do {                                                                                                          \
+        if (C % 4 == 0) hipLaunchKernelGGL((KERNEL<4>), dim3(da_grid((total) / 4, 256)), dim3(256), 0, da_stream(stream), __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<1>), dim3(da_grid((total), 256)), dim3(256), 0, da_stream(stream), __VA_ARGS__);                 \
+        DA_LAUNCH_CHECK();                                                                                        \
+    } while (0)
+
+extern "C" int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    DA_VEC_DISPATCH(maxpool2_fwd_kernel, total, x, y, N, D, H, W, C);
+    return 0;
+}
+
+extern "C" int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream) {
+    if (!dy || !x || !dx || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
+    if ((D | H | W) & 1) {   // floor mode leaves trailing planes without gradient
+        hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * D * H * W * C * sizeof(float), da_stream(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    DA_VEC_DISPATCH(maxpool2_bwd_kernel, total, dy, x, dx, N, D, H, W, C);
+    return 0;
+}
+
+extern "C" int da_upsample_nearest_fwd(const float* x, float* y, int N, int D, int H, int W, int C,
+                                       int Do, int Ho, int Wo, void* stream) {
+    if (!x || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return DA_ERR_BADARG;
+    const long long total = (long long)N * Do * Ho * Wo * C;
+    DA_VEC_DISPATCH(upsample_nearest_fwd_kernel, total, x, y, N, D, H, W, C, Do, Ho, Wo);
+    return 0;
+}
+
+extern "C" int da_upsample_nearest_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C,
+                                       int Do, int Ho, int Wo, void* stream) {
+    if (!dy || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return DA_ERR_BADARG;
+    const long long total = (long long)N * D * H * W * C;
+    DA_VEC_DISPATCH(upsample_nearest_bwd_kernel, total, dy, dx, N, D, H, W, C, Do, Ho, Wo);
+    return 0;
+}

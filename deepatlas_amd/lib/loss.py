@@ -1,0 +1,113 @@
+"""Loss registry: host-side mirror of lib/loss.py:739-761 with the hot-path losses as fused HIP kernels.
+
+Hot path: 'dice' -> DiceLossMultiClass, 'ncc' -> NormalizedCrossCorrelationLoss,
+'bendingEnergy' -> BendingEnergyLoss.  'mse' / 'L2' are one-line compositions; the remaining registry
+names (lncc, gradient, focal, cross_entropy, soft_cross_entropy) are outside this round's scope
+ and raise NotImplementedError on construction instead of silently running elsewhere.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class DiceLossMultiClass(nn.Module):
+    """Dice loss between a probability map / logits and a mask (lib/loss.py:397-476)."""
+
+    def __init__(self, n_class=None, weight_type='Simple', no_bg=False, softmax=False, eps=1e-7):
+        super(DiceLossMultiClass, self).__init__()
+        self.weight_type = weight_type
+        self.n_class = n_class
+        self.eps = eps
+        self.no_bg = no_bg
+        self.softmax = softmax
+
+    def forward(self, source, target):
+        """source: B x C x D x M x N logits (softmax=True) or probabilities; target: B x D x M x N index mask,
+        or B x C x D x M x N class probabilities (lib/loss.py:410-416)."""
+        assert source.shape[0] == target.shape[0]
+        assert source.shape[-3:] == target.squeeze().shape[-3:]
+        if self.n_class is None:
+            self.n_class = max(torch.unique(target).max(), torch.unique(source).max()).long().item() + 1
+        shape = list(source.shape)
+        if self.weight_type not in ('Simple', 'Volume', 'Uniform'):
+            raise ValueError("Class weighting type {} does not exists!".format(self.weight_type))
+        if len(target.shape) == len(shape) - 1:
+            if shape[1] != self.n_class:
+                raise ValueError("source has {} channels but n_class is {}".format(shape[1], self.n_class))
+            return ops.DiceFn.apply(source, target, None, self.weight_type, self.no_bg, self.softmax, self.eps)
+        elif target.shape[1] == shape[1]:
+            return ops.DiceFn.apply(source, None, target, self.weight_type, self.no_bg, self.softmax, self.eps)
+        raise ValueError("Incorrect size of target tensor: {}, should be {} or []".format(target.shape, shape,
+                                                                                         shape[:1] + [1, ] + shape[2:]))
+
+
+class NormalizedCrossCorrelationLoss(nn.Module):
+    """1 - NCC (lib/loss.py:485-501)."""
+
+    def __init__(self):
+        super(NormalizedCrossCorrelationLoss, self).__init__()
+
+    def forward(self, input, target):
+        return ops.NCCFn.apply(input, target)
+
+
+class BendingEnergyLoss(nn.Module):
+    """Bending energy of a 3D displacement field (lib/loss.py:674-730), norm='L2'."""
+
+    def __init__(self, norm='L2', spacing=(1, 1, 1), normalize=True):
+        super(BendingEnergyLoss, self).__init__()
+        if norm != 'L2':
+            raise NotImplementedError("only norm='L2' does anything in the reference (lib/loss.py:721)")
+        self.norm = norm
+        self.spacing = torch.tensor(spacing).float()
+        self.normalize = normalize
+        if self.normalize:
+            self.spacing /= self.spacing.min()
+
+    def forward(self, input):
+        return ops.BendingFn.apply(input, tuple(float(s) for s in self.spacing), self.normalize)
+
+
+class MSELoss(nn.Module):
+    def forward(self, input, target):
+        return ((input - target) ** 2).mean()
+
+
+class L2Loss(nn.Module):
+    def forward(self, input):
+        return (input ** 2).mean()
+
+
+def _out_of_scope(name, cite):
+    class _Unavailable(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            raise NotImplementedError("loss '%s' (%s) has no HIP kernel yet (SURVEY.md §8f)" % (name, cite))
+    _Unavailable.__name__ = name
+    return _Unavailable
+
+
+loss_dict = {
+    'ncc': NormalizedCrossCorrelationLoss,
+    'lncc': _out_of_scope('lncc', 'lib/loss.py:589-617'),
+    'mse': MSELoss,
+    'gradient': _out_of_scope('gradient', 'lib/loss.py:625-671'),
+    'bendingEnergy': BendingEnergyLoss,
+    'dice': DiceLossMultiClass,
+    'L2': L2Loss,
+    'focal': _out_of_scope('focal', 'lib/loss.py:157-213'),
+    'cross_entropy': _out_of_scope('cross_entropy', 'torch.nn.CrossEntropyLoss'),
+    'soft_cross_entropy': _out_of_scope('soft_cross_entropy', 'lib/loss.py:100-154'),
+}
+
+
+def get_loss_function(loss_name):
+    if loss_name in get_available_losses():
+        return loss_dict[loss_name]
+    else:
+        raise KeyError("Network {} is not avaiable!\n Choose from: {}".format(loss_name, get_available_losses()))
+
+
+def get_available_losses():
+    return loss_dict.keys()

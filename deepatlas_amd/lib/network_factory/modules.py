@@ -1,0 +1,164 @@
+"""Building blocks of the networks: host-side mirrors of the reference's blocks whose forward is HIP.
+
+Parameter holders are the stock torch modules (nn.Conv3d / nn.ConvTranspose3d / nn.BatchNorm3d) so that
+state_dict keys, shapes, default initialisation and `weights_init` behave exactly as in the reference
+(lib/network_factory/unets.py:24-67, modules.py:28-86); their own forward() is never used -- the block
+forward launches the HIP kernels through deepatlas_amd.ops.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+available_activations = {'ReLU': nn.ReLU, 'LeakyReLU': nn.LeakyReLU}
+
+
+def get_activation_function(act):
+    """unets.py:9-19 / modules.py:15-25 (unknown names return None, as in the reference)."""
+    if act in available_activations:
+        return available_activations[act]
+    return None
+
+
+def _slope_of(act_cls):
+    if act_cls is None:
+        return -1.0
+    if act_cls is nn.ReLU:
+        return 0.0
+    if act_cls is nn.LeakyReLU:
+        return 0.01                      # nn.LeakyReLU() default negative_slope
+    raise NotImplementedError('activation %r has no HIP kernel' % (act_cls,))
+
+
+class SegBlock(nn.Sequential):
+    """unets.convBlock (unets.py:24-39): children 'conv' [, 'BN'], 'nonlinear' -- same state_dict keys.
+    forward(x, skip=None) convolves concat(x, skip) without materialising it (unets.py:275)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True, batchnorm=False, act='ReLU'):
+        act_F = get_activation_function(act)
+        mods = OrderedDict()
+        mods['conv'] = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        if batchnorm:
+            mods['BN'] = nn.BatchNorm3d(out_channels)
+        mods['nonlinear'] = act_F()
+        super().__init__(mods)
+        if kernel_size != 3 or padding != 1 or stride not in (1, 2):
+            raise NotImplementedError('HIP conv path covers kernel 3, padding 1, stride 1|2')
+        self.stride = stride
+        self.slope = _slope_of(act_F)
+        self.batchnorm = batchnorm
+
+    def forward(self, x, skip=None):
+        conv = self.conv
+        if self.batchnorm:
+            y = ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, -1.0)
+            bn = self.BN
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            return ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     self.training, bn.momentum, bn.eps, self.slope)
+        return ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, self.slope)
+
+
+class SegUpBlock(nn.Sequential):
+    """unets.deconvBlock (unets.py:42-58): 'deconv' [, 'BN'], 'nonlinear'; kernel 2, stride 2."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0,
+                 bias=True, batchnorm=False, act='ReLU'):
+        act_F = get_activation_function(act)
+        mods = OrderedDict()
+        mods['deconv'] = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                            output_padding=output_padding, bias=bias)
+        if batchnorm:
+            mods['BN'] = nn.BatchNorm3d(out_channels)
+        mods['nonlinear'] = act_F()
+        super().__init__(mods)
+        if kernel_size != 2 or stride != 2 or padding != 0 or output_padding != 0:
+            raise NotImplementedError('HIP transposed-conv path covers kernel 2, stride 2')
+        self.slope = _slope_of(act_F)
+        self.batchnorm = batchnorm
+
+    def forward(self, x):
+        y = ops.DeconvK2S2Fn.apply(x, self.deconv.weight, self.deconv.bias)
+        if self.batchnorm:
+            bn = self.BN
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            return ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     self.training, bn.momentum, bn.eps, self.slope)
+        return ops.ActFn.apply(y, self.slope)
+
+
+class HeadConv(nn.Conv3d):
+    """nn.Conv3d(C, n_classes, 1) output layer (unets.py:249-250) -- keys '<idx>.weight', '<idx>.bias'."""
+
+    def forward(self, x):
+        return ops.Conv1x1Fn.apply(x, self.weight, self.bias)
+
+
+class MaxPool2(nn.MaxPool3d):
+    """nn.MaxPool3d(2) (unets.py:230)."""
+
+    def forward(self, x):
+        return ops.MaxPool2Fn.apply(x)
+
+
+class convBlock(nn.Module):
+    """modules.convBlock (modules.py:28-62), the registration net's block: conv -> optional BN -> act class
+    instantiated per call -> optional `x += x`.  Child names 'conv' / 'bn' as in the reference."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1,
+                 bias=False, batchnorm=False, act=nn.ReLU, residual=False):
+        super(convBlock, self).__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.bn = nn.BatchNorm3d(out_channels) if batchnorm else None
+        self.nonlinear = get_activation_function(act) if type(act) is str else act
+        self.residual = residual
+        if kernel_size != 3 or padding != 1 or stride not in (1, 2):
+            raise NotImplementedError('HIP conv path covers kernel 3, padding 1, stride 1|2')
+        self.stride = stride
+
+    def forward(self, x, skip=None):
+        slope = _slope_of(self.nonlinear)
+        if self.bn is not None:
+            y = ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, -1.0)
+            bn = self.bn
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            y = ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, slope)
+        else:
+            y = ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, slope)
+        if self.residual:
+            y = y + y                         # modules.py:59-60 `x += x`
+        return y
+
+
+class deconvBlock(nn.Module):
+    """modules.deconvBlock (modules.py:65-86); only the k=2, s=2 form has a HIP kernel."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0,
+                 bias=False, batchnorm=False, residual=False, act=nn.ReLU):
+        super(deconvBlock, self).__init__()
+        self.deconv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                         output_padding=output_padding, bias=bias)
+        self.bn = nn.BatchNorm3d(out_channels) if batchnorm else None
+        self.nonlinear = get_activation_function(act) if type(act) is str else act
+        self.residual = residual
+        if kernel_size != 2 or stride != 2 or padding != 0 or output_padding != 0:
+            raise NotImplementedError('HIP transposed-conv path covers kernel 2, stride 2')
+
+    def forward(self, input):
+        slope = _slope_of(self.nonlinear)
+        y = ops.DeconvK2S2Fn.apply(input, self.deconv.weight, self.deconv.bias)
+        if self.bn is not None:
+            bn = self.bn
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            y = ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, slope)
+        else:
+            y = ops.ActFn.apply(y, slope)
+        if self.residual:
+            y = y + input
+        return y

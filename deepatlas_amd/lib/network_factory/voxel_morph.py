@@ -1,0 +1,67 @@
+"""Registration net: host-side mirror of lib/network_factory/voxel_morph.py with HIP forwards/backwards."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .modules import convBlock
+
+
+class FlowConv(nn.Conv3d):
+    """`self.flow` (voxel_morph.py:57): 3x3x3 conv to the displacement field, no activation; keys flow.weight/bias."""
+
+    def forward(self, x, skip=None):
+        return ops.Conv3dK3Fn.apply(x, skip, self.weight, self.bias, 1, -1.0)
+
+
+class VoxelMorphCVPR2018(nn.Module):
+    """voxel_morph.py:18-101.  forward(source, target) -> (disp_field, warped_source, deform_field)."""
+
+    def __init__(self, input_channel=2, output_channel=3, enc_filters=(16, 32, 32, 32, 32), dec_filters=(32, 32, 32, 8, 8)):
+        super(VoxelMorphCVPR2018, self).__init__()
+        self.input_channel = input_channel
+        self.output_channel = output_channel
+        self.enc_filters = enc_filters
+        self.dec_filters = dec_filters
+        self.encoders = nn.ModuleList()
+        self.decoders = nn.ModuleList()
+        for i in range(len(enc_filters)):
+            if i == 0:
+                self.encoders.append(convBlock(input_channel, enc_filters[i], stride=1, bias=True))
+            else:
+                self.encoders.append(convBlock(enc_filters[i - 1], enc_filters[i], stride=2, bias=True))
+        for i in range(len(dec_filters)):
+            if i == 0:
+                self.decoders.append(convBlock(enc_filters[-1], dec_filters[i], stride=1, bias=True))
+            elif i < 4:
+                self.decoders.append(convBlock(dec_filters[i - 1] + enc_filters[4 - i], dec_filters[i], stride=1, bias=True))
+            else:
+                self.decoders.append(convBlock(dec_filters[i - 1], dec_filters[i], stride=1, bias=True))
+        self.flow = FlowConv(dec_filters[-1] + enc_filters[0], output_channel, kernel_size=3, stride=1, padding=1, bias=True)
+        self.id_transform = None      # kept for attribute parity; the identity grid is generated inside the warp kernel
+
+    def forward(self, source, target):
+        up = ops.UpsampleNearestFn.apply
+        # cat(source, target) is a two-pointer conv input (voxel_morph.py:65)
+        e1 = self.encoders[0](source, target)
+        e2 = self.encoders[1](e1)
+        e3 = self.encoders[2](e2)
+        e4 = self.encoders[3](e3)
+        e5 = self.encoders[4](e4)
+        d1 = self.decoders[0](up(e5, e4.shape[2:]))
+        # F.interpolate(cat(a, b)) == cat(F.interpolate(a), F.interpolate(b)) for nearest (voxel_morph.py:74,76)
+        d2 = self.decoders[1](up(d1, e3.shape[2:]), up(e4, e3.shape[2:]))
+        d3 = self.decoders[2](up(d2, e2.shape[2:]), up(e3, e2.shape[2:]))
+        d4 = self.decoders[3](d3, e2)
+        d5 = self.decoders[4](up(d4, e1.shape[2:]))
+        disp_field = self.flow(d5, e1)
+        warped_source, deform_field = ops.WarpFn.apply(source, disp_field)
+        return disp_field, warped_source, deform_field
+
+    def weights_init(self):
+        for m in self.modules():
+            classname = m.__class__.__name__
+            if classname.find('Conv') != -1:
+                if not m.weight is None:
+                    nn.init.xavier_normal_(m.weight.data)
+                if not m.bias is None:
+                    m.bias.data.zero_()

@@ -1,0 +1,505 @@
+"""torch.autograd.Function wrappers around the C-ABI launchers of libdeepatlas_hip.so.
+
+Tensor convention at this layer: the *logical* shape is the reference's N x C x D x H x W, the *physical*
+layout is dense channels-last ("NDHWC", torch.channels_last_3d strides).  `ndhwc(x)` returns the
+N x D x H x W x C view (copying only when a caller hands in a differently-strided tensor); ops allocate
+their outputs as N x D x H x W x C and return the permuted N x C x D x H x W view.
+
+Every op is a HIP kernel launch on the current torch stream; there is no eager fallback.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _native as nat
+from ._native import call, ptr, stream, workspace
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------
+def ndhwc(x):
+    """N x C x D x H x W (any strides) -> dense N x D x H x W x C tensor (a view when already channels-last)."""
+    nat.require_cuda(x)
+    if x.dtype != torch.float32:
+        raise nat.NativeError('deepatlas_amd kernels are fp32; got %s' % x.dtype)
+    xp = x.permute(0, 2, 3, 4, 1)
+    return xp if xp.is_contiguous() else xp.contiguous()
+
+
+def ncdhw(t):
+    """dense N x D x H x W x C -> logical N x C x D x H x W view."""
+    return t.permute(0, 4, 1, 2, 3)
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _ws(nbytes, like):
+    return workspace.get(nbytes, like.device)
+
+
+def _labels(t):
+    """Index target -> (tensor kept alive, label_bytes).  uint8 and int64 are consumed in place."""
+    nat.require_cuda(t)
+    if t.dtype == torch.uint8:
+        return t.contiguous(), 1
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t.contiguous(), 8
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions
+# ------------------------------------------------------------------------------------------------
+class Conv3dK3Fn(Function):
+    """nn.Conv3d(k=3, p=1, stride 1|2) on concat(x1, x2) (+ optional fused ReLU/LeakyReLU).
+    Reference call sites: unets.py:30,36; modules.py:48,56-58; voxel_morph.py:57,82."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, stride, act_slope):
+        a1 = ndhwc(x1)
+        a2 = ndhwc(x2) if x2 is not None else None
+        N, D, H, W, C1 = a1.shape
+        C2 = a2.shape[-1] if a2 is not None else 0
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if Cin != C1 + C2 or tuple(weight.shape[2:]) != (3, 3, 3):
+            raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
+        st = stream()
+        w_tio = _empty((27, Cin, Cout), a1)
+        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
+        Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = _empty((N, Do, Ho, Wo, Cout), a1)
+        wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
+        wp, wn = _ws(wsb, a1)
+        b = bias.detach().contiguous() if bias is not None else None
+        call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(out),
+             N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
+        ctx.dims = (N, D, H, W, C1, C2, Cout, stride, float(act_slope), wsb)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a1, a2, w_tio, out if act_slope >= 0 else None)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a1, a2, w_tio, out = ctx.saved_tensors
+        N, D, H, W, C1, C2, Cout, stride, slope, wsb = ctx.dims
+        st = stream()
+        g = ndhwc(gout)
+        if out is not None:                      # fused activation: dy = dout * act'(y)
+            g2 = torch.empty_like(g)
+            call('da_act_bwd', ptr(g), ptr(out), slope, ptr(g2), g.numel(), st)
+            g = g2
+        wp, wn = _ws(wsb, a1)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
+            dx1 = _empty(a1.shape, a1)
+            dx2 = _empty(a2.shape, a1) if a2 is not None else None
+            call('da_conv3d_k3_dgrad', ptr(g), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, stride, wp, wn, st)
+        dw = db = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw_tio = torch.empty_like(w_tio)
+            db = _empty((Cout,), a1) if ctx.has_bias else None
+            call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(db), N, D, H, W, Cout, stride, wp, wn, st)
+            dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
+            call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+        return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None)
+
+
+class Conv1x1Fn(Function):
+    """nn.Conv3d(Cin, Cout, 1): the segmentation head (unets.py:249-250)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        a = ndhwc(x)
+        N, D, H, W, Cin = a.shape
+        Cout = weight.shape[0]
+        st = stream()
+        w_io = _empty((Cin, Cout), a)
+        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_io), Cout, Cin, 1, st)
+        out = _empty((N, D, H, W, Cout), a)
+        M = N * D * H * W
+        b = bias.detach().contiguous() if bias is not None else None
+        call('da_conv1x1_fwd', ptr(a), ptr(w_io), ptr(b), ptr(out), M, Cin, Cout, st)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a, w_io)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, w_io = ctx.saved_tensors
+        Cin, Cout = w_io.shape
+        M = a.numel() // Cin
+        st = stream()
+        g = ndhwc(gout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(a)
+            call('da_conv1x1_dgrad', ptr(g), ptr(w_io), ptr(dx), M, Cin, Cout, st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw_io = torch.empty_like(w_io)
+            db = _empty((Cout,), a) if ctx.has_bias else None
+            wp, wn = _ws(nat.lib().da_conv1x1_wgrad_ws_bytes(M, Cin, Cout), a)
+            call('da_conv1x1_wgrad', ptr(a), ptr(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
+            dw = _empty((Cout, Cin, 1, 1, 1), a)
+            call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), Cout, Cin, 1, st)
+        return (ncdhw(dx) if dx is not None else None), dw, db
+
+
+class DeconvK2S2Fn(Function):
+    """nn.ConvTranspose3d(k=2, s=2) (unets.py:49,55)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        a = ndhwc(x)
+        N, D, H, W, Cin = a.shape
+        Cout = weight.shape[1]
+        if weight.shape[0] != Cin or tuple(weight.shape[2:]) != (2, 2, 2):
+            raise ValueError('ConvTranspose3d weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
+        st = stream()
+        w_tio = _empty((8, Cin, Cout), a)
+        call('da_w_iok_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 8, st)
+        out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
+        b = bias.detach().contiguous() if bias is not None else None
+        call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cin, Cout, st)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a, w_tio)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, w_tio = ctx.saved_tensors
+        N, D, H, W, Cin = a.shape
+        Cout = w_tio.shape[2]
+        st = stream()
+        g = ndhwc(gout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(a)
+            call('da_deconv_k2s2_dgrad', ptr(g), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw_tio = torch.empty_like(w_tio)
+            db = _empty((Cout,), a) if ctx.has_bias else None
+            wp, wn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
+            call('da_deconv_k2s2_wgrad', ptr(a), ptr(g), ptr(dw_tio), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
+            dw = _empty((Cin, Cout, 2, 2, 2), a)
+            call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
+        return (ncdhw(dx) if dx is not None else None), dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm3d + activation
+# ------------------------------------------------------------------------------------------------
+class BNActFn(Function):
+    """nn.BatchNorm3d followed by LeakyReLU/ReLU (unets.py:31-32,51-52), one fused pass each way.
+    running_mean / running_var are updated in place in training mode (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        a = ndhwc(y)
+        C = a.shape[-1]
+        M = a.numel() // C
+        st = stream()
+        stats = _empty((4, C), a)                     # mean, rstd, scale, shift
+        g = gamma.detach().contiguous() if gamma is not None else None
+        b = beta.detach().contiguous() if beta is not None else None
+        wsb = nat.lib().da_bn_ws_bytes(M, C)
+        if training or running_mean is None:
+            wp, wn = _ws(wsb, a)
+            call('da_bn_train_stats', ptr(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
+                 ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
+        else:
+            call('da_bn_eval_affine', ptr(g), ptr(b), ptr(running_mean), ptr(running_var), float(eps), C,
+                 ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
+        out = torch.empty_like(a)
+        call('da_bn_act_fwd', ptr(a), ptr(stats[2]), ptr(stats[3]), float(slope), ptr(out), M, C, st)
+        ctx.cfg = (M, C, float(slope), bool(training or running_mean is None), wsb)
+        ctx.save_for_backward(a, stats, g)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, stats, g = ctx.saved_tensors
+        M, C, slope, train, wsb = ctx.cfg
+        st = stream()
+        go = ndhwc(gout)
+        dx = torch.empty_like(a)
+        dgb = _empty((2, C), a)
+        wp, wn = _ws(wsb, a)
+        call('da_bn_act_bwd', ptr(go), ptr(a), ptr(stats[0]), ptr(stats[1]), ptr(g), ptr(stats[2]), ptr(stats[3]),
+             slope, 1 if train else 0, ptr(dx), ptr(dgb[0]), ptr(dgb[1]), M, C, wp, wn, st)
+        return ncdhw(dx), dgb[0], dgb[1], None, None, None, None, None, None
+
+
+class ActFn(Function):
+    """Stand-alone ReLU / LeakyReLU (used when a block has no BatchNorm and the conv did not fuse it)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        a = ndhwc(x)
+        C = a.shape[-1]
+        ones = torch.ones(C, dtype=torch.float32, device=a.device)
+        zeros = torch.zeros(C, dtype=torch.float32, device=a.device)
+        out = torch.empty_like(a)
+        call('da_bn_act_fwd', ptr(a), ptr(ones), ptr(zeros), float(slope), ptr(out), a.numel() // C, C, stream())
+        ctx.slope = float(slope)
+        ctx.save_for_backward(out)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        out, = ctx.saved_tensors
+        g = ndhwc(gout)
+        dx = torch.empty_like(out)
+        call('da_act_bwd', ptr(g), ptr(out), ctx.slope, ptr(dx), g.numel(), stream())
+        return ncdhw(dx), None
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / resampling
+# ------------------------------------------------------------------------------------------------
+class MaxPool2Fn(Function):
+    """nn.MaxPool3d(2) (unets.py:230,267)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        a = ndhwc(x)
+        N, D, H, W, C = a.shape
+        out = _empty((N, D // 2, H // 2, W // 2, C), a)
+        call('da_maxpool2_fwd', ptr(a), ptr(out), N, D, H, W, C, stream())
+        ctx.save_for_backward(a)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, = ctx.saved_tensors
+        N, D, H, W, C = a.shape
+        g = ndhwc(gout)
+        dx = torch.empty_like(a)
+        call('da_maxpool2_bwd', ptr(g), ptr(a), ptr(dx), N, D, H, W, C, stream())
+        return ncdhw(dx)
+
+
+class UpsampleNearestFn(Function):
+    """F.interpolate(x, size=...) with the default 'nearest' mode (voxel_morph.py:72,74,76,80)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        a = ndhwc(x)
+        N, D, H, W, C = a.shape
+        Do, Ho, Wo = int(size[0]), int(size[1]), int(size[2])
+        out = _empty((N, Do, Ho, Wo, C), a)
+        call('da_upsample_nearest_fwd', ptr(a), ptr(out), N, D, H, W, C, Do, Ho, Wo, stream())
+        ctx.dims = (N, D, H, W, C, Do, Ho, Wo)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        N, D, H, W, C, Do, Ho, Wo = ctx.dims
+        g = ndhwc(gout)
+        dx = _empty((N, D, H, W, C), g)
+        call('da_upsample_nearest_bwd', ptr(g), ptr(dx), N, D, H, W, C, Do, Ho, Wo, stream())
+        return ncdhw(dx), None
+
+
+class WarpFn(Function):
+    """deform = disp + identity; warped = grid_sample(src, deform, bilinear, zeros, align_corners=True)
+    (voxel_morph.py:85-91, lib/utils.py:89-102).  Returns (warped, deform)."""
+
+    @staticmethod
+    def forward(ctx, src, disp):
+        s = ndhwc(src)
+        u = ndhwc(disp)
+        N, D, H, W, C = s.shape
+        if tuple(u.shape) != (N, D, H, W, 3):
+            raise ValueError('displacement field must be N x 3 x D x H x W matching the source volume')
+        out = torch.empty_like(s)
+        deform = torch.empty_like(u)
+        call('da_warp_fwd', ptr(s), ptr(u), ptr(deform), ptr(out), N, D, H, W, C, stream())
+        ctx.save_for_backward(s, u)
+        return ncdhw(out), ncdhw(deform)
+
+    @staticmethod
+    def backward(ctx, g_out, g_deform):
+        s, u = ctx.saved_tensors
+        N, D, H, W, C = s.shape
+        st = stream()
+        d_disp = d_src = None
+        go = ndhwc(g_out) if g_out is not None else torch.zeros_like(s)
+        if ctx.needs_input_grad[1]:
+            d_disp = torch.empty_like(u)
+        if ctx.needs_input_grad[0]:
+            d_src = torch.zeros_like(s)
+        call('da_warp_bwd', ptr(go), ptr(s), ptr(u), ptr(d_disp), ptr(d_src), N, D, H, W, C, st)
+        if d_disp is not None and g_deform is not None:
+            d_disp = d_disp + ndhwc(g_deform)
+        return (ncdhw(d_src) if d_src is not None else None), (ncdhw(d_disp) if d_disp is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+_WEIGHT_TYPES = {'Uniform': 0, 'Simple': 1, 'Volume': 2}
+
+
+class DiceFn(Function):
+    """DiceLossMultiClass.forward (lib/loss.py:410-476) with the softmax and the one-hot fused in."""
+
+    @staticmethod
+    def forward(ctx, source, target, soft_target, weight_type, no_bg, softmax, eps):
+        s = ndhwc(source)
+        N, C = s.shape[0], s.shape[-1]
+        V = s.numel() // (N * C)
+        st = stream()
+        lab = soft = None
+        lab_bytes = 0
+        if soft_target is not None:
+            soft = ndhwc(soft_target)
+        else:
+            lab, lab_bytes = _labels(target)
+        loss = _empty((1,), s)
+        coef = _empty((2, N, C), s)
+        wp, wn = _ws(nat.lib().da_dice_ws_bytes(N, V, C), s)
+        call('da_dice_fwd', ptr(s), ptr(lab), lab_bytes, ptr(soft), N, V, C, 1 if softmax else 0,
+             _WEIGHT_TYPES[weight_type], 1 if no_bg else 0, float(eps), ptr(loss), ptr(coef), wp, wn, st)
+        ctx.cfg = (N, V, C, 1 if softmax else 0, lab_bytes)
+        ctx.save_for_backward(s, lab, soft, coef)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        s, lab, soft, coef = ctx.saved_tensors
+        N, V, C, softmax, lab_bytes = ctx.cfg
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        d_src = torch.empty_like(s)
+        call('da_dice_bwd', ptr(s), ptr(lab), lab_bytes, ptr(soft), ptr(coef), ptr(gl), ptr(d_src), N, V, C, softmax, stream())
+        return ncdhw(d_src), None, None, None, None, None, None
+
+
+class SoftmaxFn(Function):
+    """F.softmax(x, dim=1) on N x C x D x H x W (lib/loss.py:427; joint step: probabilities to warp)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        a = ndhwc(x)
+        C = a.shape[-1]
+        out = torch.empty_like(a)
+        call('da_softmax_fwd', ptr(a), ptr(out), a.numel() // C, C, stream())
+        ctx.save_for_backward(out)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        out, = ctx.saved_tensors
+        C = out.shape[-1]
+        g = ndhwc(gout)
+        dx = torch.empty_like(out)
+        call('da_softmax_bwd', ptr(g), ptr(out), ptr(dx), out.numel() // C, C, stream())
+        return ncdhw(dx)
+
+
+class NCCFn(Function):
+    """NormalizedCrossCorrelationLoss.forward (lib/loss.py:493-501)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        nat.require_cuda(x, y)
+        a = ndhwc(x) if x.dim() == 5 else x.contiguous()
+        b = ndhwc(y) if y.dim() == 5 else y.contiguous()
+        N = a.shape[0]
+        V = a.numel() // N
+        loss = _empty((1,), a)
+        stats = torch.empty((N, 8), dtype=torch.float64, device=a.device)
+        wp, wn = _ws(nat.lib().da_ncc_ws_bytes(N, V), a)
+        call('da_ncc_fwd', ptr(a), ptr(b), N, V, ptr(loss), ptr(stats), wp, wn, stream())
+        ctx.five = (x.dim() == 5, y.dim() == 5)
+        ctx.save_for_backward(a, b, stats)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        a, b, stats = ctx.saved_tensors
+        N = a.shape[0]
+        V = a.numel() // N
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        dx = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        call('da_ncc_bwd', ptr(a), ptr(b), ptr(stats), ptr(gl), ptr(dx), ptr(dy), N, V, stream())
+        if dx is not None and ctx.five[0]:
+            dx = ncdhw(dx)
+        if dy is not None and ctx.five[1]:
+            dy = ncdhw(dy)
+        return dx, dy
+
+
+class BendingFn(Function):
+    """BendingEnergyLoss.forward, norm='L2' (lib/loss.py:687-730)."""
+
+    @staticmethod
+    def forward(ctx, disp, spacing, normalize):
+        u = ndhwc(disp)
+        N, D, H, W, C = u.shape
+        if C != 3:
+            raise ValueError('bending energy expects a N x 3 x D x H x W displacement field')
+        sp = (ctypes_float3(spacing))
+        loss = _empty((1,), u)
+        wp, wn = _ws(nat.lib().da_bending_ws_bytes(N, D, H, W), u)
+        call('da_bending_fwd', ptr(u), N, D, H, W, sp, 1 if normalize else 0, ptr(loss), wp, wn, stream())
+        ctx.cfg = (tuple(float(s) for s in spacing), bool(normalize))
+        ctx.save_for_backward(u)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        u, = ctx.saved_tensors
+        N, D, H, W, _ = u.shape
+        spacing, normalize = ctx.cfg
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        du = torch.empty_like(u)
+        call('da_bending_bwd', ptr(u), ptr(gl), ptr(du), N, D, H, W, ctypes_float3(spacing), 1 if normalize else 0, stream())
+        return ncdhw(du), None, None
+
+
+def ctypes_float3(v):
+    import ctypes
+    arr = (ctypes.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))
+    return ctypes.cast(arr, ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------
+# non-differentiable utilities
+# ------------------------------------------------------------------------------------------------
+def one_hot(mask, n_classes):
+    """lib/transforms.py:675-689 mask_to_one_hot for a B x 1 x ... index mask -> B x C x ... float (channels-last)."""
+    nat.require_cuda(mask)
+    if mask.shape[1] != 1:
+        raise ValueError('mask must be B x 1 x ...')
+    lab, nbytes = _labels(mask.reshape(mask.shape[0], -1))
+    M = lab.numel()
+    out = torch.empty((M, n_classes), dtype=torch.float32, device=mask.device)
+    call('da_one_hot', ptr(lab), nbytes, ptr(out), M, n_classes, stream())
+    spatial = list(mask.shape[2:])
+    out = out.reshape([mask.shape[0]] + spatial + [n_classes])
+    perm = [0, len(spatial) + 1] + list(range(1, len(spatial) + 1))
+    return out.permute(perm)
+
+
+def identity_grid(size, normalize=True, device='cuda'):
+    """lib/utils.py:89-102 get_identity_transform: 3 x D x H x W."""
+    D, H, W = int(size[0]), int(size[1]), int(size[2])
+    out = torch.empty((3, D, H, W), dtype=torch.float32, device=device)
+    call('da_identity_grid', ptr(out), D, H, W, 1 if normalize else 0, stream())
+    return out
+
+
+def argmax_dice_counts(logits, truth):
+    """Eval path (models/segmentation.py:188-194): first-max argmax + exact integer overlap counts.
+    Returns (counts[N][C][3] int64 = (|pred==c|, |truth==c|, |both|), pred uint8 N x D x H x W)."""
+    a = ndhwc(logits)
+    N, C = a.shape[0], a.shape[-1]
+    V = a.numel() // (N * C)
+    lab, nbytes = _labels(truth.reshape(N, -1))
+    counts = torch.zeros((N, C, 3), dtype=torch.int64, device=a.device)
+    pred = torch.empty((N, V), dtype=torch.uint8, device=a.device)
+    call('da_argmax_dice_counts', ptr(a), ptr(lab), nbytes, N, V, C, ptr(counts), ptr(pred), stream())
+    return counts, pred.reshape((N,) + tuple(a.shape[1:4]))

@@ -1,0 +1,186 @@
+/*
+ * deepatlas_hip.h -- C ABI of libdeepatlas_hip.so, the MI355X (gfx950) native hot path for
+ * uncbiag/DeepAtlas' 3D volumetric training step.
+ *
+ * The reference has no FFI layer: its hot path is Python (L2) calling PyTorch ATen ops (L1)
+ * (SURVEY.md §1, §8b).  This header is the seam a maintainer would bind instead of those ATen
+ * calls; each entry cites the reference call site(s) it replaces (file:line in uncbiag/DeepAtlas).
+ *
+ * Conventions
+ *   - every activation tensor is fp32, channels-last 3D ("NDHWC"): [N][D][H][W][C], dense.
+ *     (torch side: a N x C x D x H x W tensor with torch.channels_last_3d strides.)
+ *   - raw device pointers, explicit dims, no hidden allocation: scratch memory is passed in as
+ *     (ws, ws_bytes); da_*_ws_bytes() returns the size a call needs.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work.
+ *   - return value: 0 on success, otherwise a hipError_t, or DA_ERR_* (negative) for bad arguments.
+ *   - 3x3x3 conv weights use the "TIO" layout [27 taps (kd,kh,kw)][Cin][Cout]; 2x2x2 transposed-conv
+ *     weights [8 taps][Cin][Cout]; 1x1x1 weights [Cin][Cout].  da_w_* convert from/to the PyTorch
+ *     state_dict layouts ([Cout][Cin][k][k][k], ConvTranspose [Cin][Cout][k][k][k]).
+ */
+#ifndef DEEPATLAS_HIP_H
+#define DEEPATLAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DA_ERR_BADARG   (-1)
+#define DA_ERR_WS_SMALL (-2)
+#define DA_ERR_UNSUPPORTED (-3)
+
+/* library / device info */
+int  da_version(void);
+int  da_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- weight layout transforms (tiny) -------------------------------------------------------- */
+/* [Cout][Cin][k^3] (nn.Conv3d, unets.py:30,36,250; modules.py:48; voxel_morph.py:57) <-> [k^3][Cin][Cout] */
+int da_w_oik_to_tio(const float* w_oik, float* w_tio, int Cout, int Cin, int K3, void* stream);
+int da_w_tio_to_oik(const float* w_tio, float* w_oik, int Cout, int Cin, int K3, void* stream);
+/* [Cin][Cout][k^3] (nn.ConvTranspose3d, unets.py:49,55) <-> [k^3][Cin][Cout] */
+int da_w_iok_to_tio(const float* w_iok, float* w_tio, int Cin, int Cout, int K3, void* stream);
+int da_w_tio_to_iok(const float* w_tio, float* w_iok, int Cin, int Cout, int K3, void* stream);
+
+/* ---- 3x3x3 convolution, padding 1, stride 1|2 (rows a1, a7, a9) ----------------------------- */
+/* replaces nn.Conv3d(k=3,p=1) forward: unets.py:30,36; modules.py:48,56; voxel_morph.py:57,82.
+ * Input = channel-concat(in1[C1], in2[C2]) without materialising it (torch.cat at unets.py:275,
+ * voxel_morph.py:65,74,76,78,82); in2 may be NULL with C2 = 0.
+ * out[N][Do][Ho][Wo][Cout], Do = (D-1)/stride+1.  bias may be NULL.
+ * act_slope < 0: no activation; == 0: ReLU (modules.py:58); > 0: LeakyReLU(slope) fused in the epilogue.
+ * stats (optional, may be NULL): per-channel double [2][Cout] (sum, sum of squares) of the PRE-activation
+ * output, ACCUMULATED into by the kernel's epilogue is not done here; see da_bn_stats. */
+size_t da_conv3d_k3_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int stride);
+int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int C2,
+                     const float* w_tio, const float* bias, float* out,
+                     int N, int D, int H, int W, int Cout, int stride, float act_slope,
+                     void* ws, size_t ws_bytes, void* stream);
+/* data gradient (autograd of the above): dx = concat(dx1[C1], dx2[C2]); D,H,W are the INPUT dims. */
+int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
+                       int N, int D, int H, int W, int Cout, int stride,
+                       void* ws, size_t ws_bytes, void* stream);
+/* weight / bias gradient: dw_tio[27][C1+C2][Cout], dbias[Cout] (may be NULL). */
+int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy,
+                       float* dw_tio, float* dbias,
+                       int N, int D, int H, int W, int Cout, int stride,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* test/diagnostic knob: force the direct (VALU) kernels instead of the MFMA implicit-GEMM path (also env
+ * DA_CONV_DIRECT=1); returns the previous setting.  Used by the GPU tests to A/B the two implementations. */
+int da_set_conv_direct(int on);
+
+/* ---- 1x1x1 convolution (segmentation head, row a5; unets.py:249-250) ------------------------- */
+int da_conv1x1_fwd(const float* in, const float* w_io, const float* bias, float* out,
+                   long long M, int Cin, int Cout, void* stream);
+int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout, void* stream);
+size_t da_conv1x1_wgrad_ws_bytes(long long M, int Cin, int Cout);
+int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, float* dbias,
+                     long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- 2x2x2 stride-2 transposed convolution (row a3; unets.py:49,55,240-241) ------------------ */
+/* out[N][2D][2H][2W][Cout] = bias + sum_ci in[N][D][H][W][ci] * w_tio[tap(i,j,k)][ci][co] */
+int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const float* bias, float* out,
+                       int N, int D, int H, int W, int Cin, int Cout, void* stream);
+int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
+                         int N, int D, int H, int W, int Cin, int Cout, void* stream);
+size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_tio, float* dbias,
+                         int N, int D, int H, int W, int Cin, int Cout,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNorm3d + LeakyReLU (rows a1, a3; unets.py:31,51 + :5-6) ---------------------------- */
+/* Train-mode statistics over M = N*D*H*W rows of x[M][C]: writes mean[C], rstd[C] (1/sqrt(biased var+eps)),
+ * scale[C] = gamma*rstd, shift[C] = beta - mean*scale, and updates running_mean/var in place with
+ * `momentum` and the UNBIASED variance (nn.BatchNorm3d semantics).  running_* may be NULL. */
+size_t da_bn_ws_bytes(long long M, int C);
+int da_bn_train_stats(const float* x, long long M, int C, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean, float* rstd, float* scale, float* shift,
+                      void* ws, size_t ws_bytes, void* stream);
+/* Eval-mode affine from running statistics. */
+int da_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int C, float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* y = act(x*scale + shift); act_slope as in da_conv3d_k3_fwd. */
+int da_bn_act_fwd(const float* x, const float* scale, const float* shift, float act_slope, float* y,
+                  long long M, int C, void* stream);
+/* Backward of act(BN_train(x)): given dy (grad wrt y) and the saved x, mean, rstd, gamma, scale, shift:
+ * dx[M][C], dgamma[C], dbeta[C].  train != 0: full batch-statistics backward; train == 0: dx = dz*scale. */
+int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                  const float* scale, const float* shift, float act_slope, int train,
+                  float* dx, float* dgamma, float* dbeta, long long M, int C,
+                  void* ws, size_t ws_bytes, void* stream);
+/* Backward of a bare activation from its OUTPUT y (ReLU / LeakyReLU): dx = dy * (y > 0 ? 1 : slope). */
+int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream);
+/* Per-channel column sum of x[M][C] -> out[C] (bias gradients). */
+int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- MaxPool3d(2) (row a2; unets.py:230,267) ------------------------------------------------- */
+int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
+/* dx (input-sized) from dy and the saved input x; gradient goes to the first maximum in (d,h,w) scan order. */
+int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream);
+
+/* ---- nearest-neighbour up-sampling to a given size (row a8; voxel_morph.py:72,74,76,80) ------ */
+int da_upsample_nearest_fwd(const float* x, float* y, int N, int D, int H, int W, int C,
+                            int Do, int Ho, int Wo, void* stream);
+int da_upsample_nearest_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C,
+                            int Do, int Ho, int Wo, void* stream);
+
+/* ---- deformation-field trilinear warp (rows a9-a10; voxel_morph.py:85-91, lib/utils.py:89-102) */
+/* deform = disp + identity (identity generated in-kernel, channel order (x,y,z) = (W,H,D) axis, normalised
+ * to [-1,1]); out = grid_sample(src, deform, bilinear, zeros, align_corners=True).
+ * src[N][D][H][W][C], disp[N][D][H][W][3], deform (may be NULL) [N][D][H][W][3], out[N][D][H][W][C]. */
+int da_warp_fwd(const float* src, const float* disp, float* deform, float* out,
+                int N, int D, int H, int W, int C, void* stream);
+/* gradients: d_disp[N][D][H][W][3] (may be NULL) and d_src (may be NULL; must be ZERO-FILLED by the caller,
+ * accumulated with float atomics). */
+int da_warp_bwd(const float* dout, const float* src, const float* disp, float* d_disp, float* d_src,
+                int N, int D, int H, int W, int C, void* stream);
+/* lib/utils.py:78-102 get_identity_transform(_batch): out[3][D][H][W] (reference layout, channel-first) */
+int da_identity_grid(float* out, int D, int H, int W, int normalize, void* stream);
+
+/* ---- fused softmax + Dice loss (row a11; lib/loss.py:410-476, lib/transforms.py:675-689) ------ */
+/* src[N][V][C] logits (softmax != 0) or probabilities; target: labels (label_bytes = 1 uint8 | 8 int64,
+ * [N][V]) or, when soft_target != NULL, a soft target [N][V][C] (loss.py:435-436).
+ * weight_type: 0 Uniform, 1 Simple, 2 Volume.  Writes loss[1] and coef[2][N][C] for the backward. */
+size_t da_dice_ws_bytes(int N, long long V, int C);
+int da_dice_fwd(const float* src, const void* labels, int label_bytes, const float* soft_target,
+                int N, long long V, int C, int softmax, int weight_type, int no_bg, float eps,
+                float* loss, float* coef, void* ws, size_t ws_bytes, void* stream);
+/* d_src[N][V][C] = dloss * dL/dsrc; d_soft (may be NULL) = dloss * dL/dsoft_target is not provided. */
+int da_dice_bwd(const float* src, const void* labels, int label_bytes, const float* soft_target,
+                const float* coef, const float* dloss, float* d_src,
+                int N, long long V, int C, int softmax, void* stream);
+/* softmax over the channel axis of x[M][C] (joint step: probabilities to warp), and its backward. */
+int da_softmax_fwd(const float* x, float* y, long long M, int C, void* stream);
+int da_softmax_bwd(const float* dy, const float* y, float* dx, long long M, int C, void* stream);
+/* lib/transforms.py:675-689 mask_to_one_hot: labels[N][V] -> out[N][V][C] float */
+int da_one_hot(const void* labels, int label_bytes, float* out, long long M, int C, void* stream);
+
+/* ---- NCC loss (row a12; lib/loss.py:493-501) -------------------------------------------------- */
+size_t da_ncc_ws_bytes(int N, long long V);
+int da_ncc_fwd(const float* x, const float* y, int N, long long V, float* loss, double* stats /*[N][8]*/,
+               void* ws, size_t ws_bytes, void* stream);
+int da_ncc_bwd(const float* x, const float* y, const double* stats, const float* dloss,
+               float* dx, float* dy, int N, long long V, void* stream);
+
+/* ---- bending-energy loss (row a13; lib/loss.py:687-730) --------------------------------------- */
+size_t da_bending_ws_bytes(int N, int D, int H, int W);
+int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize,
+                   float* loss, void* ws, size_t ws_bytes, void* stream);
+int da_bending_bwd(const float* disp, const float* dloss, float* d_disp, int N, int D, int H, int W,
+                   const float* spacing3, int normalize, void* stream);
+
+/* ---- eval: argmax + per-class overlap counts (row a15; models/segmentation.py:188-194) -------- */
+/* counts[N][C][3] uint64 = (|pred==c|, |truth==c|, |pred==c & truth==c|), must be zero-filled; pred (may be NULL) uint8 [N][V]. */
+int da_argmax_dice_counts(const float* logits, const void* truth, int label_bytes, int N, long long V, int C,
+                          unsigned long long* counts, unsigned char* pred, void* stream);
+
+/* ---- optimiser (models/segmentation.py:91 torch.optim.Adam defaults) -------------------------- */
+int da_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                 float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPATLAS_HIP_H */

@@ -1,0 +1,380 @@
+"""GPU parity tests, op level: every C-ABI launcher (called through deepatlas_amd.ops -> ctypes -> HIP) against
+(a) the golden vectors produced by the reference itself (tests/golden/ops.npz) and (b) torch-CPU, the reference's
+own arithmetic provider, on seeded inputs.  Tolerance: 1e-4 relative fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def cl(x):
+    """to the device in channels-last-3d physical layout"""
+    return x.to(dev()).contiguous(memory_format=torch.channels_last_3d) if x.dim() == 5 else x.to(dev())
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def check(a, b, tol=TOL, what=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    e = rel_l2(a, b)
+    assert e < tol, '%s rel-l2 %.3e' % (what, e)
+
+
+CONV_CASES = [
+    # C1, C2, Cout, stride, (N, D, H, W), slope
+    (1, 0, 8, 1, (2, 6, 10, 12), -1.0),        # seg enc0.0 (direct)
+    (2, 0, 16, 1, (1, 5, 7, 9), 0.0),          # reg enc0 as a concat-free 2-channel input
+    (1, 1, 16, 1, (1, 6, 8, 10), 0.0),         # reg enc0 as two 1-channel pointers (source, target)
+    (8, 0, 16, 1, (1, 8, 16, 20), -1.0),       # CK = 8 MFMA path, partial x tile
+    (16, 0, 16, 1, (2, 8, 16, 16), 0.01),      # CK = 16 MFMA, exact tiles
+    (16, 0, 32, 1, (1, 6, 9, 18), -1.0),       # NREP 2, ragged tiles
+    (32, 16, 16, 1, (1, 8, 8, 32), -1.0),      # decoder concat 48 -> 16 (dgrad: 16 -> 32 | 16 split output)
+    (64, 32, 32, 1, (1, 4, 8, 16), -1.0),      # 96 -> 32
+    (64, 0, 64, 1, (1, 4, 6, 20), -1.0),       # NT = 4 -> two cout groups
+    (8, 16, 3, 1, (1, 6, 8, 18), -1.0),        # flow conv 24 -> 3 (direct)
+    (64, 0, 8, 1, (1, 4, 8, 16), 0.0),         # reg dec3 64 -> 8
+    (16, 0, 32, 2, (1, 9, 10, 11), 0.0),       # stride 2, odd sizes (ceil(n/2))
+    (32, 0, 32, 2, (1, 4, 6, 8), 0.0),
+    (5, 0, 7, 1, (1, 4, 5, 6), -1.0),          # odd channel counts (generic direct path)
+]
+
+
+@pytest.mark.parametrize('direct', [0, 1])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'c%d+%d_o%d_s%d' % (c[0], c[1], c[2], c[3]))
+def test_conv3d_fwd_bwd(case, direct):
+    from deepatlas_amd import ops, _native
+    C1, C2, Cout, stride, (N, D, H, W), slope = case
+    x1 = rnd((N, C1, D, H, W), 1)
+    x2 = rnd((N, C2, D, H, W), 2) if C2 else None
+    w = rnd((Cout, C1 + C2, 3, 3, 3), 3, 0.2)
+    b = rnd((Cout,), 4, 0.1)
+    # reference: torch CPU
+    xr1 = x1.clone().requires_grad_(True)
+    xr2 = x2.clone().requires_grad_(True) if C2 else None
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = torch.cat((xr1, xr2), 1) if C2 else xr1
+    yr = F.conv3d(xin, wr, br, stride=stride, padding=1)
+    if slope >= 0:
+        yr = F.leaky_relu(yr, slope) if slope > 0 else F.relu(yr)
+    go = rnd(tuple(yr.shape), 5)
+    yr.backward(go)
+    prev = _native.lib().da_set_conv_direct(direct)
+    try:
+        xg1 = cl(x1).requires_grad_(True)
+        xg2 = cl(x2).requires_grad_(True) if C2 else None
+        wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+        yg = ops.Conv3dK3Fn.apply(xg1, xg2, wg, bg, stride, slope)
+        yg.backward(cl(go))
+        torch.cuda.synchronize()
+    finally:
+        _native.lib().da_set_conv_direct(prev)
+    check(yg, yr, what='fwd')
+    check(xg1.grad, xr1.grad, what='dgrad1')
+    if C2:
+        check(xg2.grad, xr2.grad, what='dgrad2')
+    check(wg.grad, wr.grad, what='wgrad')
+    check(bg.grad, br.grad, what='bgrad')
+
+
+def test_conv3d_mfma_asymmetric_identity():
+    """A = I style check with an ASYMMETRIC weight pattern: catches row/col swaps in the MFMA C/D mapping."""
+    from deepatlas_amd import ops
+    N, C, D, H, W = 1, 16, 4, 8, 16
+    x = torch.zeros(N, C, D, H, W)
+    x[0, 3, 2, 5, 7] = 1.0                      # one hot voxel / channel
+    w = torch.zeros(16, 16, 3, 3, 3)
+    for co in range(16):
+        for ci in range(16):
+            w[co, ci] = (co * 16 + ci) * 1e-3 + torch.arange(27).float().view(3, 3, 3) * 1e-5
+    y = ops.Conv3dK3Fn.apply(cl(x), None, w.to(dev()), None, 1, -1.0)
+    check(y, F.conv3d(x, w, None, padding=1), tol=1e-6, what='impulse response')
+
+
+@pytest.mark.parametrize('Cin,Cout,dims', [(16, 16, (1, 3, 4, 5)), (64, 64, (1, 2, 3, 5)), (32, 32, (2, 4, 4, 6)), (6, 5, (1, 2, 3, 4))])
+def test_deconv_k2s2(Cin, Cout, dims):
+    from deepatlas_amd import ops
+    N, D, H, W = dims
+    x, w, b = rnd((N, Cin, D, H, W), 1), rnd((Cin, Cout, 2, 2, 2), 2, 0.3), rnd((Cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2)
+    go = rnd(tuple(yr.shape), 4)
+    yr.backward(go)
+    xg, wg, bg = cl(x).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    yg = ops.DeconvK2S2Fn.apply(xg, wg, bg)
+    yg.backward(cl(go))
+    check(yg, yr, what='fwd'); check(xg.grad, xr.grad, what='dgrad'); check(wg.grad, wr.grad, what='wgrad'); check(bg.grad, br.grad, what='bgrad')
+
+
+@pytest.mark.parametrize('Cin,Cout', [(16, 32), (8, 5), (16, 3)])
+def test_conv1x1(Cin, Cout):
+    from deepatlas_amd import ops
+    x, w, b = rnd((2, Cin, 4, 6, 10), 1), rnd((Cout, Cin, 1, 1, 1), 2, 0.3), rnd((Cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br)
+    go = rnd(tuple(yr.shape), 4)
+    yr.backward(go)
+    xg, wg, bg = cl(x).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    yg = ops.Conv1x1Fn.apply(xg, wg, bg)
+    yg.backward(cl(go))
+    check(yg, yr, what='fwd'); check(xg.grad, xr.grad, what='dgrad'); check(wg.grad, wr.grad, what='wgrad'); check(bg.grad, br.grad, what='bgrad')
+
+
+@pytest.mark.parametrize('C,training', [(8, True), (16, True), (64, True), (5, True), (16, False)])
+def test_bn_act(C, training):
+    from deepatlas_amd import ops
+    x = rnd((2, C, 6, 8, 10), 1, 2.0) + 0.5
+    gamma, beta = 1 + rnd((C,), 2, 0.2), rnd((C,), 3, 0.2)
+    rm, rv = rnd((C,), 4, 0.1), 1 + rnd((C,), 5, 0.3)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.leaky_relu(F.batch_norm(xr, rmr, rvr, gr, br, training, 0.1, 1e-5), 0.01)
+    go = rnd(tuple(yr.shape), 6)
+    yr.backward(go)
+    xg, gg, bg = cl(x).requires_grad_(True), gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
+    rmg, rvg = rm.to(dev()), rv.to(dev())
+    yg = ops.BNActFn.apply(xg, gg, bg, rmg, rvg, training, 0.1, 1e-5, 0.01)
+    yg.backward(cl(go))
+    check(yg, yr, what='fwd'); check(xg.grad, xr.grad, what='dx'); check(gg.grad, gr.grad, what='dgamma'); check(bg.grad, br.grad, what='dbeta')
+    check(rmg, rmr, what='running_mean'); check(rvg, rvr, what='running_var')
+
+
+def test_maxpool_golden_and_random(golden):
+    from deepatlas_amd import ops
+    g = golden('ops')
+    p = cl(T(g['ops/maxpool/in'])).requires_grad_(True)
+    q = ops.MaxPool2Fn.apply(p)
+    q.sum().backward()
+    assert np.array_equal(q.detach().cpu().numpy(), g['ops/maxpool/out'])
+    assert np.array_equal(p.grad.cpu().numpy(), g['ops/maxpool/grad'])       # ties: first maximum gets the gradient
+    x = rnd((2, 16, 6, 8, 10), 3)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 2); go = rnd(tuple(yr.shape), 4); yr.backward(go)
+    xg = cl(x).requires_grad_(True)
+    yg = ops.MaxPool2Fn.apply(xg); yg.backward(cl(go))
+    assert torch.equal(yg.detach().cpu(), yr.detach()) and torch.equal(xg.grad.cpu(), xr.grad)
+
+
+def test_upsample_nearest_golden_odd_sizes(golden):
+    from deepatlas_amd import ops
+    g = golden('ops')
+    t = T(g['ops/nearest/in'])
+    for key, size in (('out_3_5_10', (3, 5, 10)), ('out_4_6_10', (4, 6, 10))):
+        xg = cl(t).requires_grad_(True)
+        y = ops.UpsampleNearestFn.apply(xg, size)
+        assert np.array_equal(y.detach().cpu().numpy(), g['ops/nearest/' + key])
+        go = rnd(tuple(y.shape), 7)
+        y.backward(cl(go))
+        xr = t.clone().requires_grad_(True)
+        F.interpolate(xr, size=size).backward(go)
+        check(xg.grad, xr.grad, tol=1e-6, what='nearest bwd')
+
+
+@pytest.mark.parametrize('nm', ['warp1', 'warpC'])
+def test_warp_golden(golden, nm):
+    from deepatlas_amd import ops
+    g = golden('ops')
+    src = cl(T(g[f'ops/{nm}/src'])).requires_grad_(True)
+    disp = cl(T(g[f'ops/{nm}/disp'])).requires_grad_(True)
+    out, deform = ops.WarpFn.apply(src, disp)
+    check(out, g[f'ops/{nm}/out'], tol=1e-5, what='warp fwd')
+    idt = T(g['ops/identity'])
+    check(deform, T(g[f'ops/{nm}/disp']) + idt, tol=1e-6, what='deform')
+    (out * cl(T(g[f'ops/{nm}/gout']))).sum().backward()
+    check(src.grad, g[f'ops/{nm}/grad_src'], tol=1e-5, what='grad_src')
+    check(disp.grad, g[f'ops/{nm}/grad_disp'], tol=1e-5, what='grad_disp')
+
+
+def test_warp_c32_vs_torch():
+    from deepatlas_amd import ops
+    from oracle import nets
+    N, C, D, H, W = 1, 32, 6, 10, 12
+    src, disp = rnd((N, C, D, H, W), 1), rnd((N, 3, D, H, W), 2, 0.4)
+    sr, dr = src.clone().requires_grad_(True), disp.clone().requires_grad_(True)
+    wr = nets.warp_trilinear(sr, dr + nets.identity_transform((D, H, W)))
+    go = rnd(tuple(wr.shape), 3); wr.backward(go)
+    sg, dg = cl(src).requires_grad_(True), cl(disp).requires_grad_(True)
+    wg, _ = ops.WarpFn.apply(sg, dg); wg.backward(cl(go))
+    check(wg, wr, tol=1e-5, what='fwd'); check(sg.grad, sr.grad, tol=1e-5, what='grad_src'); check(dg.grad, dr.grad, tol=1e-5, what='grad_disp')
+
+
+def test_identity_grid_and_onehot(golden):
+    from deepatlas_amd.lib import utils, transforms
+    g = golden('ops')
+    D, H, W = g['ops/identity'].shape[1:]
+    idt = utils.get_identity_transform_batch((1, 1, D, H, W))
+    assert np.array_equal(idt.cpu().numpy(), g['ops/identity'])
+    labels = T(g['ops/dice/labels']).to(dev())
+    oh = transforms.mask_to_one_hot(labels.view(2, 1, *labels.shape[1:]), 5)
+    assert np.array_equal(oh.cpu().numpy(), g['ops/onehot'])
+
+
+def test_dice_golden_all_weightings(golden):
+    from deepatlas_amd.lib.loss import DiceLossMultiClass
+    g = golden('ops')
+    for wt in ('Uniform', 'Simple', 'Volume'):
+        for no_bg in (False, True):
+            logits = cl(T(g['ops/dice/logits'])).requires_grad_(True)
+            labels = T(g['ops/dice/labels']).to(dev())
+            crit = DiceLossMultiClass(n_class=5, weight_type=wt, no_bg=no_bg, softmax=True, eps=1e-6)
+            l = crit(logits, labels.long())
+            l.backward()
+            assert abs(l.item() - g[f'ops/dice/{wt}_{int(no_bg)}/loss']) < 1e-5, (wt, no_bg)
+            check(logits.grad, g[f'ops/dice/{wt}_{int(no_bg)}/grad'], what='dice grad %s %d' % (wt, no_bg))
+    # uint8 labels are consumed without a cast
+    logits = cl(T(g['ops/dice/logits']))
+    l8 = DiceLossMultiClass(n_class=5, weight_type='Uniform', softmax=True, eps=1e-6)(logits, T(g['ops/dice/labels']).to(dev()))
+    assert abs(l8.item() - g['ops/dice/Uniform_0/loss']) < 1e-5
+
+
+def test_dice_soft_target_golden(golden):
+    from deepatlas_amd.lib.loss import DiceLossMultiClass
+    g = golden('ops')
+    src = cl(T(g['ops/dice_soft/source'])).requires_grad_(True)
+    l = DiceLossMultiClass(n_class=5, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)(src, cl(T(g['ops/dice_soft/target'])))
+    l.backward()
+    assert abs(l.item() - g['ops/dice_soft/loss']) < 1e-5
+    check(src.grad, g['ops/dice_soft/grad'], what='soft dice grad')
+
+
+def test_dice_c32_vs_oracle():
+    from deepatlas_amd.lib.loss import DiceLossMultiClass
+    from oracle import losses, nets
+    logits = rnd((2, 32, 8, 12, 10), 1, 3.0)
+    labels = nets.closed_form_labels((2, 8, 12, 10), 32, seed=1)
+    lr = logits.clone().requires_grad_(True)
+    lo = losses.dice_loss(lr, labels.long(), 32); lo.backward()
+    lg = cl(logits).requires_grad_(True)
+    l = DiceLossMultiClass(n_class=32, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)(lg, labels.to(dev()).long())
+    l.backward()
+    assert abs(l.item() - lo.item()) < 1e-5
+    check(lg.grad, lr.grad, what='dice c32 grad')
+
+
+def test_dice_errors():
+    from deepatlas_amd.lib.loss import DiceLossMultiClass, get_loss_function
+    crit = DiceLossMultiClass(n_class=5, weight_type='Uniform')
+    with pytest.raises(ValueError):
+        crit(torch.zeros(1, 5, 4, 4, 4, device=dev()), torch.zeros(1, 3, 4, 4, 4, device=dev()))
+    with pytest.raises(KeyError):
+        get_loss_function('nope')
+
+
+def test_ncc_bending_golden(golden):
+    from deepatlas_amd.lib.loss import NormalizedCrossCorrelationLoss, BendingEnergyLoss
+    g = golden('ops')
+    a = T(g['ops/ncc/a']).to(dev()).requires_grad_(True)
+    l = NormalizedCrossCorrelationLoss()(a, T(g['ops/ncc/b']).to(dev()))
+    l.backward()
+    assert abs(l.item() - g['ops/ncc/loss']) < 1e-5
+    check(a.grad, g['ops/ncc/grad'], what='ncc grad')
+    u = cl(T(g['ops/bending/u'])).requires_grad_(True)
+    l = BendingEnergyLoss()(u)
+    l.backward()
+    assert abs(l.item() - g['ops/bending/loss']) < 1e-4 * abs(g['ops/bending/loss'])
+    check(u.grad, g['ops/bending/grad'], what='bending grad')
+    l2 = BendingEnergyLoss(spacing=(1.0, 2.0, 1.5))(cl(T(g['ops/bending/u'])))
+    assert abs(l2.item() - g['ops/bending/loss_spacing']) < 1e-4 * abs(g['ops/bending/loss_spacing'])
+
+
+def test_softmax():
+    from deepatlas_amd import ops
+    for C in (32, 5):
+        x = rnd((2, C, 4, 6, 5), 1, 4.0)
+        xr = x.clone().requires_grad_(True)
+        yr = F.softmax(xr, 1); go = rnd(tuple(yr.shape), 2); yr.backward(go)
+        xg = cl(x).requires_grad_(True)
+        yg = ops.SoftmaxFn.apply(xg); yg.backward(cl(go))
+        check(yg, yr, tol=1e-6, what='softmax'); check(xg.grad, xr.grad, tol=1e-5, what='softmax bwd')
+
+
+def test_eval_dice_golden_bit_exact(golden):
+    from deepatlas_amd.lib import evalMetrics as M
+    from deepatlas_amd import ops
+    g = golden('ops')
+    pred, truth = T(g['ops/evaldice/pred']), T(g['ops/evaldice/truth'])
+    logits = ops.one_hot(pred.to(dev()).view(1, 1, *pred.shape[1:]), 6)
+    d = M.metricEval('dice', logits, truth.to(dev()))[0]
+    ref = g['ops/evaldice/dice']
+    assert np.array_equal(np.isnan(d), np.isnan(ref))
+    assert np.array_equal(d[~np.isnan(ref)], ref[~np.isnan(ref)])             # integer counts -> bit-equal
+    counts, am = M.eval_dice_counts(logits, truth.to(dev()))
+    assert np.array_equal(am.cpu().numpy(), pred.numpy())
+
+
+def test_argmax_first_max_on_ties():
+    from deepatlas_amd import ops
+    logits = torch.zeros(1, 32, 2, 2, 4)
+    logits[0, 7] = 1.0; logits[0, 19] = 1.0                                   # exact tie -> index 7 (torch.max)
+    truth = torch.full((1, 2, 2, 4), 7, dtype=torch.uint8)
+    counts, pred = ops.argmax_dice_counts(cl(logits), truth.to(dev()))
+    assert int(pred.min()) == 7 and int(pred.max()) == 7
+    assert counts[0, 7].tolist() == [16, 16, 16]
+
+
+def test_adam_vs_oracle():
+    from deepatlas_amd.optim import FlatAdam
+    from oracle import steps
+    ps = [torch.nn.Parameter(rnd((7, 5), 1).to(dev())), torch.nn.Parameter(rnd((33,), 2).to(dev()))]
+    sd = {'a': ps[0].detach().cpu().clone(), 'b': ps[1].detach().cpu().clone()}
+    opt = FlatAdam(ps, lr=1e-3)
+    o = steps.Adam(['a', 'b'], lr=1e-3)
+    for s in range(3):
+        gs = {'a': rnd((7, 5), 10 + s), 'b': rnd((33,), 20 + s)}
+        opt.zero_grad()
+        ps[0].grad.copy_(gs['a']); ps[1].grad.copy_(gs['b'])
+        opt.step()
+        o.step(sd, gs)
+    check(ps[0], sd['a'], tol=1e-6, what='adam a'); check(ps[1], sd['b'], tol=1e-6, what='adam b')
+    st = opt.state_dict()
+    assert set(st['state'][0].keys()) >= {'step', 'exp_avg', 'exp_avg_sq'}
+
+
+# ---- full-size, size-independent properties (BASELINE config sizes) ---------------------------------
+FULL = (160, 192, 160)
+
+
+def test_full_size_identity_warp_and_ncc():
+    from deepatlas_amd import ops
+    from deepatlas_amd.lib.loss import NormalizedCrossCorrelationLoss, BendingEnergyLoss
+    D, H, W = FULL
+    g = torch.Generator(device='cpu').manual_seed(230)
+    src = torch.rand((1, 1, D, H, W), generator=g).to(dev())
+    disp = torch.zeros((1, 3, D, H, W), device=dev()).contiguous(memory_format=torch.channels_last_3d)
+    out, deform = ops.WarpFn.apply(src, disp)
+    assert float((out - src).abs().max()) < 2e-5                           # identity warp reproduces the input (1.5e-6 in the survey)
+    assert abs(NormalizedCrossCorrelationLoss()(src, src).item()) < 1e-5   # NCC(x, x) = 1
+    # bending energy of an affine displacement field is zero
+    idt = ops.identity_grid((D, H, W)).unsqueeze(0)
+    aff = (0.3 * idt + 0.1).contiguous(memory_format=torch.channels_last_3d)
+    assert abs(BendingEnergyLoss()(aff).item()) < 1e-8
+
+
+def test_full_size_dice_of_identical_onehots_and_counts():
+    from deepatlas_amd import ops
+    from deepatlas_amd.lib.loss import DiceLossMultiClass
+    from deepatlas_amd.lib.datasets import structured_labels
+    lab = structured_labels(FULL, 32).unsqueeze(0).to(dev())
+    oh = ops.one_hot(lab.unsqueeze(1), 32)
+    l = DiceLossMultiClass(n_class=32, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)(oh, lab)
+    assert abs(l.item()) < 1e-6
+    counts, pred = ops.argmax_dice_counts(oh, lab)
+    assert torch.equal(pred, lab)
+    assert int(counts[0, :, 0].sum()) == lab.numel() and torch.equal(counts[0, :, 0], counts[0, :, 2])

@@ -1,0 +1,86 @@
+"""CPU: host-side logic -- registries, state_dict parity with the oracle's key list (= the reference's, pinned in
+make_golden.py), C-ABI library loads and exports every declared symbol, loud failure without a GPU."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    lib_path = ge.build()
+    lib = ctypes.CDLL(lib_path)
+    header = open(os.path.join(ROOT, 'include', 'deepatlas_hip.h')).read()
+    names = sorted(set(re.findall(r'\b(da_[a-z0-9_]+)\s*\(', header)))
+    assert len(names) > 40
+    for n in names:
+        assert hasattr(lib, n), n
+    from deepatlas_amd import _native
+    assert set(names) == set(_native.SIGNATURES.keys())
+    assert lib.da_version() == 100
+
+
+def test_registries_match_reference_names():
+    from deepatlas_amd.lib.network_factory import get_network, get_available_networks
+    from deepatlas_amd.lib.loss import get_loss_function, get_available_losses
+    assert get_available_networks() == ('voxel_morph_cvpr', 'UNet', 'UNet_light')
+    assert list(get_available_losses()) == ['ncc', 'lncc', 'mse', 'gradient', 'bendingEnergy', 'dice', 'L2', 'focal',
+                                            'cross_entropy', 'soft_cross_entropy']
+    with pytest.raises(KeyError):
+        get_network('nope')
+    with pytest.raises(KeyError):
+        get_loss_function('nope')
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    from oracle import nets
+    from deepatlas_amd.lib.network_factory import get_network
+    m = get_network('UNet_light')(in_channel=1, n_classes=32, bias=True, BN=True)
+    ref = nets.unet_param_shapes(1, 32, nets.UNET_LIGHT['encoders'], nets.UNET_LIGHT['decoders'])
+    sd = m.state_dict()
+    assert list(sd.keys()) != [] and set(sd.keys()) == set(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k]), k
+    assert sum(p.numel() for p in m.parameters()) == 874864
+    r = get_network('voxel_morph_cvpr')()
+    rref = nets.voxelmorph_param_shapes()
+    assert set(r.state_dict().keys()) == set(rref.keys())
+    assert sum(p.numel() for p in r.parameters()) == 253627
+    # strict load of a reference-shaped state dict
+    m.load_state_dict(nets.closed_form_fill(ref, seed=1), strict=True)
+    m.weights_init()
+    assert float(m.state_dict()['encoders.0.0.conv.bias'].abs().max()) == 0.0
+
+
+def test_no_cpu_fallback():
+    from deepatlas_amd.lib.network_factory import get_network
+    from deepatlas_amd import _native
+    m = get_network('UNet_light')(in_channel=1, n_classes=32, bias=True, BN=True)
+    with pytest.raises(_native.NativeError):
+        m(torch.zeros(1, 1, 8, 8, 8))
+
+
+def test_out_of_scope_constructors_raise():
+    from deepatlas_amd.lib.network_factory import get_network
+    from deepatlas_amd.lib.loss import get_loss_function
+    with pytest.raises(NotImplementedError):
+        get_network('UNet')(1, 2)
+    with pytest.raises(NotImplementedError):
+        get_loss_function('lncc')()
+
+
+def test_train_seg_config_matches_reference_dict():
+    import argparse
+    import train_seg
+    ns = argparse.Namespace(device='0', debug=False, preload=False, num_samples=21, num_epochs=100, lr=1e-3, test_only=False,
+                            data_root='./data', log_root='./logs', shape=[64, 64, 64])
+    c = train_seg.build_config(ns)
+    assert c['model'] == 'UNet_light' and c['random_seed'] == 230 and c['batch_size'] == 1
+    assert c['model_settings'] == {'in_channel': 1, 'n_classes': 32, 'bias': True, 'BN': True}
+    assert c['loss_settings'] == {'n_class': 32, 'weight_type': 'Uniform', 'no_bg': False, 'softmax': True, 'eps': 1e-6}
+    assert c['lr_mode'] == 'multiStep' and c['milestones'] == [0.5, 1] and c['gamma'] == 0.2
+    assert c['samples_per_epoch'] == 42 and c['crop_size'] == [0, 10, 7, 14, 8, 7]
