@@ -32,12 +32,13 @@ SIGNATURES = {
     'da_conv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, I, P, SZ, P]),
     'da_conv3d_k3_wgrad': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_set_conv_direct': (I, [I]),
-    'da_conv1x1_fwd': (I, [P, P, P, P, LL, I, I, P]),
-    'da_conv1x1_dgrad': (I, [P, P, P, LL, I, I, P]),
+    'da_pointwise_ws_bytes': (SZ, [I, I, I]),
+    'da_conv1x1_fwd': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
+    'da_conv1x1_dgrad': (I, [P, P, P, LL, I, I, P, SZ, P]),
     'da_conv1x1_wgrad_ws_bytes': (SZ, [LL, I, I]),
     'da_conv1x1_wgrad': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
-    'da_deconv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P]),
-    'da_deconv_k2s2_dgrad': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'da_deconv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_deconv_k2s2_dgrad': (I, [P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_deconv_k2s2_wgrad_ws_bytes': (SZ, [I, I, I, I, I, I]),
     'da_deconv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_bn_ws_bytes': (SZ, [LL, I]),
@@ -97,8 +98,39 @@ def lib():
 _ERR = {-1: 'DA_ERR_BADARG', -2: 'DA_ERR_WS_SMALL', -3: 'DA_ERR_UNSUPPORTED'}
 
 
+class CallProfiler:
+    """Optional per-call timing with HIP events on the launch stream (torch's current stream is the stream every
+    launcher is given).  key = (C-ABI name, tuple of the call's integer arguments = the layer shape)."""
+
+    def __init__(self, names=None):
+        self.names = set(names) if names else None
+        self.records = {}
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def summary(self):
+        """{key: (n_calls, total_ms)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for key, evs in self.records.items():
+            out[key] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+        return out
+
+
+profiler = None          # set to a CallProfiler to time calls
+
+
 def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+    prof = profiler
+    if prof is not None and prof.wants(name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib(), name)(*args)
+        b.record()
+        key = (name, tuple(x for x in args if isinstance(x, int)))
+        prof.records.setdefault(key, []).append((a, b))
+    else:
+        rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise NativeError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
 

@@ -3,6 +3,7 @@
 // Both are HBM-bound at DeepAtlas' widths (the up-sampled tensor is the largest activation): one input voxel
 // per lane, weights through wave-uniform scalar loads, each lane writes contiguous runs of output channels.
 #include "common.h"
+#include "pointwise_internal.h"
 
 namespace {
 
@@ -196,10 +197,14 @@ static int parts_for(long long units, int O, long long* per) {
 
 }  // namespace
 
+extern "C" size_t da_pointwise_ws_bytes(int ntaps, int Cin, int Cout) { return da_pw_packed_bytes(ntaps, Cin, Cout) + 256; }
+
 extern "C" int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const float* bias, float* out,
-                                  int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+                                  int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (!in || !w_tio || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
     const long long nvox = (long long)N * D * H * W;
+    if (da_pw_supported(Cin, Cout))
+        return da_pw_gemm(in, w_tio, 0, bias, out, nvox, D, H, W, Cin, Cout, 8, 1, 0, ws, ws_bytes, da_stream(stream));
     hipLaunchKernelGGL((deconv_k2s2_fwd_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cout, 16)), dim3(256), 0, da_stream(stream),
                        in, w_tio, bias, out, N, D, H, W, Cin, Cout);
     DA_LAUNCH_CHECK();
@@ -207,9 +212,11 @@ extern "C" int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const flo
 }
 
 extern "C" int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
-                                    int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+                                    int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w_tio || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
     const long long nvox = (long long)N * D * H * W;
+    if (da_pw_supported(Cout, Cin))
+        return da_pw_gemm(dy, w_tio, 1, nullptr, dx, nvox, D, H, W, Cout, Cin, 8, 1, 1, ws, ws_bytes, da_stream(stream));
     hipLaunchKernelGGL((deconv_k2s2_dgrad_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cin, 16)), dim3(256), 0, da_stream(stream),
                        dy, w_tio, dx, N, D, H, W, Cin, Cout);
     DA_LAUNCH_CHECK();
@@ -221,7 +228,10 @@ extern "C" size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int 
     const int O = 8 * Cin * Cout;
     const int parts = parts_for((long long)N * D * H * W, O, &per);
     const int Cm = Cout;
-    return da_align((size_t)parts * O * sizeof(float)) + da_bn_ws_bytes(0, Cm) + 512;
+    size_t direct = da_align((size_t)parts * O * sizeof(float));
+    const size_t mf = da_pw_supported(Cin, Cout) ? da_pw_wgrad_ws_bytes((long long)N * D * H * W, 8, Cin, Cout) : 0;
+    if (mf > direct) direct = mf;
+    return direct + da_bn_ws_bytes(0, Cm) + 512;
 }
 
 extern "C" int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_tio, float* dbias,
@@ -233,29 +243,38 @@ extern "C" int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_
     long long per;
     const int O = 8 * Cin * Cout;
     const int parts = parts_for((long long)N * D * H * W, O, &per);
-    float* partial = (float*)ws;
-    hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel, dim3(parts), dim3(256), 0, st, in, dy, partial, N, D, H, W, Cin, Cout, per);
-    DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, parts, O, dw_tio);
-    DA_LAUNCH_CHECK();
-    if (dbias) {
-        char* cs = (char*)ws + da_align((size_t)parts * O * sizeof(float));
-        return da_colsum(dy, (long long)N * D * H * W * 8, Cout, dbias, cs, da_bn_ws_bytes(0, Cout), stream);
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    if (da_pw_supported(Cin, Cout)) {
+        int rc = da_pw_wgrad(in, dy, dw_tio, (long long)N * D * H * W, D, H, W, Cin, Cout, 8, 1, ws, cs_off, st);
+        if (rc) return rc;
+    } else {
+        float* partial = (float*)ws;
+        hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel, dim3(parts), dim3(256), 0, st, in, dy, partial, N, D, H, W, Cin, Cout, per);
+        DA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, parts, O, dw_tio);
+        DA_LAUNCH_CHECK();
     }
+    if (dbias)
+        return da_colsum(dy, (long long)N * D * H * W * 8, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
     return 0;
 }
 
 extern "C" int da_conv1x1_fwd(const float* in, const float* w_io, const float* bias, float* out,
-                              long long M, int Cin, int Cout, void* stream) {
+                              long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (!in || !w_io || !out || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (da_pw_supported(Cin, Cout))
+        return da_pw_gemm(in, w_io, 0, bias, out, M, 1, 1, 1, Cin, Cout, 1, 0, 0, ws, ws_bytes, da_stream(stream));
     if (Cout >= 32) hipLaunchKernelGGL((conv1x1_kernel<32>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cout, 32)), dim3(256), 0, da_stream(stream), in, w_io, bias, out, M, Cin, Cout, 0);
     else hipLaunchKernelGGL((conv1x1_kernel<8>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cout, 8)), dim3(256), 0, da_stream(stream), in, w_io, bias, out, M, Cin, Cout, 0);
     DA_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout, void* stream) {
+extern "C" int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout,
+                                void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w_io || !dx || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (da_pw_supported(Cout, Cin))
+        return da_pw_gemm(dy, w_io, 1, nullptr, dx, M, 1, 1, 1, Cout, Cin, 1, 0, 1, ws, ws_bytes, da_stream(stream));
     // dx[row][ci] = sum_co dy[row][co] * w[ci][co] : a 1x1 conv with "Cin" = Cout, "Cout" = Cin and w read transposed
     if (Cin >= 32) hipLaunchKernelGGL((conv1x1_kernel<32>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cin, 32)), dim3(256), 0, da_stream(stream), dy, w_io, nullptr, dx, M, Cout, Cin, 1);
     else hipLaunchKernelGGL((conv1x1_kernel<8>), dim3((unsigned)da_cdiv(M, 256), (unsigned)da_cdiv(Cin, 8)), dim3(256), 0, da_stream(stream), dy, w_io, nullptr, dx, M, Cout, Cin, 1);
@@ -267,26 +286,33 @@ extern "C" size_t da_conv1x1_wgrad_ws_bytes(long long M, int Cin, int Cout) {
     long long per;
     const int O = Cin * Cout;
     const int parts = parts_for(da_cdiv(M, kWgR), O, &per);
-    return da_align((size_t)parts * O * sizeof(float)) + da_bn_ws_bytes(0, Cout) + 512;
+    size_t direct = da_align((size_t)parts * O * sizeof(float));
+    const size_t mf = da_pw_supported(Cin, Cout) ? da_pw_wgrad_ws_bytes(M, 1, Cin, Cout) : 0;
+    if (mf > direct) direct = mf;
+    return direct + da_bn_ws_bytes(0, Cout) + 512;
 }
 
 extern "C" int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, float* dbias,
                                 long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (!in || !dy || !dw_io || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
     const int O = Cin * Cout;
-    if (O > 4096) return DA_ERR_UNSUPPORTED;
+    if (O > 4096 && !da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_conv1x1_wgrad_ws_bytes(M, Cin, Cout)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
     long long per;
     const int parts = parts_for(da_cdiv(M, kWgR), O, &per);
-    float* partial = (float*)ws;
-    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(parts), dim3(256), (size_t)kWgR * (Cin + Cout) * sizeof(float), st, in, dy, partial, M, Cin, Cout, per * kWgR);
-    DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, parts, O, dw_io);
-    DA_LAUNCH_CHECK();
-    if (dbias) {
-        char* cs = (char*)ws + da_align((size_t)parts * O * sizeof(float));
-        return da_colsum(dy, M, Cout, dbias, cs, da_bn_ws_bytes(0, Cout), stream);
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    if (da_pw_supported(Cin, Cout)) {
+        int rc = da_pw_wgrad(in, dy, dw_io, M, 1, 1, 1, Cin, Cout, 1, 0, ws, cs_off, st);
+        if (rc) return rc;
+    } else {
+        float* partial = (float*)ws;
+        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(parts), dim3(256), (size_t)kWgR * (Cin + Cout) * sizeof(float), st, in, dy, partial, M, Cin, Cout, per * kWgR);
+        DA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, partial, parts, O, dw_io);
+        DA_LAUNCH_CHECK();
     }
+    if (dbias)
+        return da_colsum(dy, M, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
     return 0;
 }

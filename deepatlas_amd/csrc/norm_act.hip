@@ -87,10 +87,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nbloc
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    float* mean, float* rstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wave per channel: lanes stride over the block partials, then a shuffle reduction
+    const int c = blockIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = threadIdx.x; b < nblocks; b += 64) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    s = da_wave_sum(s); ss = da_wave_sum(ss);
+    if (threadIdx.x != 0) return;
     const double m = s / (double)M;
     double var = ss / (double)M - m * m;
     if (var < 0.0) var = 0.0;
@@ -139,10 +141,11 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __re
 // finalize BN-backward sums: dgamma = s2, dbeta = s1, cm[0][c] = s1/M, cm[1][c] = s2/M
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long long M, int C,
                                        float* dgamma, float* dbeta, float* cm) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s1 += partial[((size_t)b * 2) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = threadIdx.x; b < nblocks; b += 64) { s1 += partial[((size_t)b * 2) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    s1 = da_wave_sum(s1); s2 = da_wave_sum(s2);
+    if (threadIdx.x != 0) return;
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     cm[c] = (float)(s1 / (double)M);
@@ -198,11 +201,11 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 }
 
 __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 2) * C + c];
-    out[c] = (float)s;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[((size_t)b * 2) * C + c];
+    s = da_wave_sum(s);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 template <int MODE>
@@ -234,7 +237,7 @@ extern "C" int da_bn_train_stats(const float* x, long long M, int C, const float
     double* partial = (double*)ws;
     int rc = launch_partial<0>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, da_stream(stream), partial, p.grid, M, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, M, C,
                        gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
     DA_LAUNCH_CHECK();
     return 0;
@@ -275,7 +278,7 @@ extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean,
     hipStream_t st = da_stream(stream);
     int rc = launch_partial<2>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm);
     DA_LAUNCH_CHECK();
     if (C % 4 == 0) {
         const long long nvec = M * C / 4;
@@ -302,7 +305,7 @@ extern "C" int da_colsum(const float* x, long long M, int C, float* out, void* w
     double* partial = (double*)ws;
     int rc = launch_partial<1>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(da_cdiv(C, 64)), dim3(64), 0, da_stream(stream), partial, p.grid, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, C, out);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,14 @@
+// Internal entry points of pointwise_mfma.hip (MFMA channel GEMMs for 1x1 conv and 2x2x2/s2 transposed conv).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+bool da_pw_supported(int K, int N);
+size_t da_pw_packed_bytes(int ntaps, int K, int N);
+// SCATTER (gather == 0): out[map(v,t)][N] = bias + A[v][K] * B_t ; GATHER: out[v][N] = sum_t A[map(v,t)][K] * B_t
+int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
+               long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
+               void* ws, size_t ws_bytes, hipStream_t st);
+size_t da_pw_wgrad_ws_bytes(long long M, int ntaps, int Cin, int Cout);
+int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
+                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1,0 +1,376 @@
+// Pointwise ("no spatial reuse") channel GEMMs on the matrix cores: 1x1x1 convolution and the 2x2x2 stride-2 transposed
+// convolution, forward / data-gradient / weight-gradient.  Rows a3, a5 of SURVEY.md §8 (unets.py:49,55,249-250).
+//
+// These are HBM-bound: the largest operand is the 32-channel full-resolution tensor (629 MB per volume) and every
+// element is used in one small dot product.  The VALU versions were bound by per-lane strided channel loads; here the
+// A operand is read straight from global memory in MFMA fragment order (16 lanes x 16 B = one voxel's 64-byte channel
+// run per instruction group), K is permuted so one 16-byte load feeds four v_mfma_f32_16x16x4_f32 (exact fp32), and the
+// packed weights (<= 128 KB) stay L1/L2 resident.  Algorithmic bytes: forward = read in + write out once; dgrad = read
+// dy + write dx once; wgrad = read in + dy once.
+//
+// map(v, tap): for the transposed conv the fine-grid voxel of coarse voxel v=(n,d,h,w) and tap (i,j,k) is
+//   ((n*2D + 2d+i)*2H + 2h+j)*2W + 2w+k = fine0(v) + (i*2H + j)*2W + k.   For 1x1 convs ntaps = 1 and map = identity.
+#include "common.h"
+#include "pointwise_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct PwP {
+    const float* a; const float* wp; const float* bias; float* out;
+    long long M;            // number of COARSE voxels (rows handled by the grid)
+    int D, H, W;            // coarse dims (used when up != 0)
+    int K, Nc;              // GEMM inner / output channel counts (multiples of 16)
+    int ntaps, up;
+};
+
+__device__ __forceinline__ long long fine0(long long v, int D, int H, int W) {
+    const int w = (int)(v % W); long long r = v / W;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D); const long long n = r / D;
+    return ((n * (2 * D) + 2 * d) * (2 * H) + 2 * h) * (long long)(2 * W) + 2 * w;
+}
+__device__ __forceinline__ long long tapoff(int t, int H, int W) {
+    return ((long long)(t >> 2) * (2 * H) + ((t >> 1) & 1)) * (2 * W) + (t & 1);
+}
+
+// SCATTER (GATHER == false): out[map(v,t)][n] = bias[n] + sum_k A[v][k] * B_t[k][n]      (conv1x1 fwd, deconv fwd)
+// GATHER  (GATHER == true) : out[v][n]        = sum_t sum_k A[map(v,t)][k] * B_t[k][n]   (conv1x1 dgrad, deconv dgrad)
+template <int KC, int NT, bool GATHER>
+__global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
+    constexpr int MT = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const long long vbase = ((long long)blockIdx.x * 4 + wave) * (MT * 16);
+    if (vbase >= p.M) return;
+    const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + lane;
+
+    long long arow[MT];            // A-row voxel (coarse; mapped to fine0 when the A side is the fine grid)
+    bool aval[MT];
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+        const long long v = vbase + r * 16 + i;
+        aval[r] = v < p.M;
+        const long long vv = aval[r] ? v : 0;
+        arow[r] = (GATHER && p.up) ? fine0(vv, p.D, p.H, p.W) : vv;
+    }
+    f32x4 acc[MT][NT];
+
+    if constexpr (!GATHER) {
+        float4 a[MT][KC];
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                a[r][c] = aval[r] ? *reinterpret_cast<const float4*>(p.a + arow[r] * p.K + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // output rows of this lane: voxel 4*g + reg of every M-tile
+        long long orow[MT][4];
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long long v = vbase + r * 16 + 4 * g + reg;
+                orow[r][reg] = (v < p.M) ? (p.up ? fine0(v, p.D, p.H, p.W) : v) : -1;
+            }
+        float bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = p.bias ? p.bias[16 * n + i] : 0.f;
+#pragma unroll 1
+        for (int t = 0; t < p.ntaps; ++t) {
+#pragma unroll
+            for (int r = 0; r < MT; ++r)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){bv[n], bv[n], bv[n], bv[n]};
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 b = wp4[(((size_t)t * NT + n) * KC + c) * 64];
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][c].x, b.x, acc[r][n], 0, 0, 0);
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][c].y, b.y, acc[r][n], 0, 0, 0);
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][c].z, b.z, acc[r][n], 0, 0, 0);
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][c].w, b.w, acc[r][n], 0, 0, 0);
+                    }
+                }
+            const long long toff = p.up ? tapoff(t, p.H, p.W) : 0;
+#pragma unroll
+            for (int r = 0; r < MT; ++r)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (orow[r][reg] < 0) continue;
+                    float* o = p.out + (orow[r][reg] + toff) * p.Nc + i;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
+                }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t = 0; t < p.ntaps; ++t) {
+            const long long toff = p.up ? tapoff(t, p.H, p.W) : 0;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                float4 a[MT];
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+                    a[r] = aval[r] ? *reinterpret_cast<const float4*>(p.a + (arow[r] + toff) * p.K + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 b = wp4[(((size_t)t * NT + n) * KC + c) * 64];
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, b.x, acc[r][n], 0, 0, 0);
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, b.y, acc[r][n], 0, 0, 0);
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, b.z, acc[r][n], 0, 0, 0);
+                        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, b.w, acc[r][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long long v = vbase + r * 16 + 4 * g + reg;
+                if (v >= p.M) continue;
+                float* o = p.out + v * p.Nc + i;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
+            }
+    }
+}
+
+// packed B: wp[t][n][c][lane][m] = B_t[k = 16c + 4(lane>>4) + m][j = 16n + (lane&15)]
+// transposed == 0: B_t[k][j] = w[(t*K + k)*N + j]    transposed != 0: B_t[k][j] = w[(t*N + j)*K + k]
+__global__ void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int ntaps, int K, int N, int transposed) {
+    const int KC = K / 16, NT = N / 16;
+    const long long total = (long long)ntaps * NT * KC * 256;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        long long rest = idx >> 8;
+        const int c = (int)(rest % KC); rest /= KC;
+        const int n = (int)(rest % NT); const int t = (int)(rest / NT);
+        const int k = 16 * c + 4 * (lane >> 4) + m, j = 16 * n + (lane & 15);
+        wp[idx] = transposed ? w[((size_t)t * N + j) * K + k] : w[((size_t)t * K + k) * N + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight gradient: dW[t][ci][co] = sum_v in[v][ci] * dy[map(v,t)][co]
+// Each wave walks its own voxel range (K split over waves and blocks); blockIdx.y selects a group of TPB taps.
+// ---------------------------------------------------------------------------------------------------
+struct PwWgP {
+    const float* in; const float* dy; float* partial;
+    long long M; int D, H, W, Cin, Cout, ntaps, up;
+    long long vox_per_wave;
+};
+
+template <int CIT, int COT, int TPB>
+__global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [CIT*TPB*COT][64][4] per-block reduction
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int t0 = blockIdx.y * TPB;
+    f32x4 acc[CIT][TPB][COT];
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+        for (int t = 0; t < TPB; ++t)
+#pragma unroll
+            for (int c = 0; c < COT; ++c) acc[a][t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long long toffs[TPB];
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) toffs[t] = p.up ? tapoff(t0 + t, p.H, p.W) : 0;
+
+    const long long v0 = ((long long)blockIdx.x * 4 + wave) * p.vox_per_wave;
+    long long v1 = v0 + p.vox_per_wave; if (v1 > p.M) v1 = p.M;
+#pragma unroll 2
+    for (long long vb = v0; vb < v1; vb += 4) {
+        const long long v = vb + g;
+        const bool ok = v < v1;
+        const long long vv = ok ? v : v0;
+        float av[CIT];
+#pragma unroll
+        for (int a = 0; a < CIT; ++a) av[a] = ok ? p.in[vv * p.Cin + 16 * a + i] : 0.f;
+        const long long fv = p.up ? fine0(vv, p.D, p.H, p.W) : vv;
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) {
+            float bv[COT];
+#pragma unroll
+            for (int c = 0; c < COT; ++c) bv[c] = ok ? p.dy[(fv + toffs[t]) * p.Cout + 16 * c + i] : 0.f;
+#pragma unroll
+            for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+                    acc[a][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[c], acc[a][t][c], 0, 0, 0);
+        }
+    }
+    // reduce the four waves through LDS, then write the block partial
+    constexpr int NACC = CIT * TPB * COT;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                for (int t = 0; t < TPB; ++t)
+#pragma unroll
+                    for (int c = 0; c < COT; ++c) {
+                        float4* slot = reinterpret_cast<float4*>(red) + ((a * TPB + t) * COT + c) * 64 + lane;
+                        float4 cur = (w == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
+                        cur.x += acc[a][t][c][0]; cur.y += acc[a][t][c][1]; cur.z += acc[a][t][c][2]; cur.w += acc[a][t][c][3];
+                        *slot = cur;
+                    }
+        }
+        __syncthreads();
+    }
+    // rows (M = ci) = 4*g + reg, cols (N = co) = i
+    float* part = p.partial + (size_t)blockIdx.x * p.ntaps * p.Cin * p.Cout;
+    for (int idx = threadIdx.x; idx < NACC * 64; idx += 256) {
+        const int ln = idx & 63; const int q = idx >> 6;
+        const int c = q % COT; const int t = (q / COT) % TPB; const int a = q / (COT * TPB);
+        const float4 val = reinterpret_cast<const float4*>(red)[idx];
+        const int gg = ln >> 4, jj = ln & 15;
+        const float vals[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ci = 16 * a + 4 * gg + reg, co = 16 * c + jj;
+            part[((size_t)(t0 + t) * p.Cin + ci) * p.Cout + co] = vals[reg];
+        }
+    }
+}
+
+__global__ void pw_reduce_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nparts; ++b) s += (double)partial[(size_t)b * O + o];
+        out[o] = (float)s;
+    }
+}
+
+template <int KC, int NT>
+int launch_pw(const PwP& p, bool gather, hipStream_t st) {
+    const unsigned grid = (unsigned)da_cdiv(p.M, 256);
+    if (gather) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, true>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false>), dim3(grid), dim3(256), 0, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+bool da_pw_supported(int K, int N) {
+    return K % 16 == 0 && N % 16 == 0 && K >= 16 && K <= 64 && N >= 16 && N <= 64;
+}
+
+size_t da_pw_packed_bytes(int ntaps, int K, int N) { return da_align((size_t)ntaps * K * N * sizeof(float)); }
+
+int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
+               long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
+               void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!da_pw_supported(K, N)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_pw_packed_bytes(ntaps, K, N)) return DA_ERR_WS_SMALL;
+    float* wp = (float*)ws;
+    const long long total = (long long)ntaps * K * N;
+    hipLaunchKernelGGL(pw_pack_kernel, dim3(da_grid(total, 256, 512)), dim3(256), 0, st, w, wp, ntaps, K, N, transposed);
+    DA_LAUNCH_CHECK();
+    PwP p;
+    p.a = a; p.wp = wp; p.bias = bias; p.out = out; p.M = M; p.D = D; p.H = H; p.W = W; p.K = K; p.Nc = N; p.ntaps = ntaps; p.up = up;
+    const int KC = K / 16, NT = N / 16;
+#define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) return launch_pw<kc, nt>(p, gather != 0, st)
+    DA_PW_CASE(1, 1); DA_PW_CASE(1, 2); DA_PW_CASE(2, 1); DA_PW_CASE(2, 2); DA_PW_CASE(4, 4);
+    DA_PW_CASE(1, 4); DA_PW_CASE(4, 1); DA_PW_CASE(2, 4); DA_PW_CASE(4, 2);
+    DA_PW_CASE(3, 3); DA_PW_CASE(1, 3); DA_PW_CASE(3, 1); DA_PW_CASE(2, 3); DA_PW_CASE(3, 2); DA_PW_CASE(3, 4); DA_PW_CASE(4, 3);
+#undef DA_PW_CASE
+    return DA_ERR_UNSUPPORTED;
+}
+
+static int wg_blocks(long long M, size_t O, long long* vox_per_wave) {
+    long long blocks = 1024;
+    const long long cap = (long long)((64ull << 20) / (O * 4)); if (blocks > cap) blocks = cap < 1 ? 1 : cap;
+    long long vpw = da_cdiv(M, blocks * 4);
+    vpw = da_cdiv(vpw, 4) * 4;
+    if (vpw < 4) vpw = 4;
+    *vox_per_wave = vpw;
+    return (int)da_cdiv(M, vpw * 4);
+}
+
+size_t da_pw_wgrad_ws_bytes(long long M, int ntaps, int Cin, int Cout) {
+    long long vpw;
+    const size_t O = (size_t)ntaps * Cin * Cout;
+    const int nb = wg_blocks(M, O, &vpw);
+    return da_align((size_t)nb * O * sizeof(float));
+}
+
+template <int CIT, int COT, int TPB>
+static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
+    const size_t shm = (size_t)CIT * TPB * COT * 64 * 4 * sizeof(float);
+    auto kern = pw_mfma_wgrad_kernel<CIT, COT, TPB>;
+    static bool attr_set = false;
+    if (!attr_set && shm > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks, p.ntaps / TPB), dim3(256), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
+                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!da_pw_supported(Cin, Cout) || (ntaps != 1 && ntaps != 8)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_pw_wgrad_ws_bytes(M, ntaps, Cin, Cout)) return DA_ERR_WS_SMALL;
+    PwWgP p;
+    p.in = in; p.dy = dy; p.partial = (float*)ws; p.M = M; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntaps = ntaps; p.up = up;
+    const size_t O = (size_t)ntaps * Cin * Cout;
+    const int nb = wg_blocks(M, O, &p.vox_per_wave);
+    const int CIT = Cin / 16, COT = Cout / 16;
+    int rc = DA_ERR_UNSUPPORTED;
+    // taps per block chosen so that CIT*COT*TPB*4 accumulator registers <= 128
+#define DA_WG_CASE(a, c, t) if (CIT == a && COT == c && ((ntaps == 8 && t > 0) || (ntaps == 1 && t == 0))) rc = launch_pw_wgrad<a, c, (t > 0 ? t : 1)>(p, nb, st)
+    if (ntaps == 8) {
+        if (CIT * COT <= 4) {
+            if (CIT == 1 && COT == 1) rc = launch_pw_wgrad<1, 1, 8>(p, nb, st);
+            else if (CIT == 1 && COT == 2) rc = launch_pw_wgrad<1, 2, 8>(p, nb, st);
+            else if (CIT == 2 && COT == 1) rc = launch_pw_wgrad<2, 1, 8>(p, nb, st);
+            else if (CIT == 2 && COT == 2) rc = launch_pw_wgrad<2, 2, 8>(p, nb, st);
+            else if (CIT == 1 && COT == 4) rc = launch_pw_wgrad<1, 4, 8>(p, nb, st);
+            else if (CIT == 4 && COT == 1) rc = launch_pw_wgrad<4, 1, 8>(p, nb, st);
+            else if (CIT == 1 && COT == 3) rc = launch_pw_wgrad<1, 3, 8>(p, nb, st);
+            else if (CIT == 3 && COT == 1) rc = launch_pw_wgrad<3, 1, 8>(p, nb, st);
+        } else if (CIT * COT <= 8) {
+            if (CIT == 2 && COT == 4) rc = launch_pw_wgrad<2, 4, 4>(p, nb, st);
+            else if (CIT == 4 && COT == 2) rc = launch_pw_wgrad<4, 2, 4>(p, nb, st);
+            else if (CIT == 2 && COT == 3) rc = launch_pw_wgrad<2, 3, 4>(p, nb, st);
+            else if (CIT == 3 && COT == 2) rc = launch_pw_wgrad<3, 2, 4>(p, nb, st);
+        } else {
+            if (CIT == 4 && COT == 4) rc = launch_pw_wgrad<4, 4, 2>(p, nb, st);
+            else if (CIT == 3 && COT == 3) rc = launch_pw_wgrad<3, 3, 2>(p, nb, st);
+            else if (CIT == 3 && COT == 4) rc = launch_pw_wgrad<3, 4, 2>(p, nb, st);
+            else if (CIT == 4 && COT == 3) rc = launch_pw_wgrad<4, 3, 2>(p, nb, st);
+        }
+    } else {
+        if (CIT == 1 && COT == 1) rc = launch_pw_wgrad<1, 1, 1>(p, nb, st);
+        else if (CIT == 1 && COT == 2) rc = launch_pw_wgrad<1, 2, 1>(p, nb, st);
+        else if (CIT == 2 && COT == 1) rc = launch_pw_wgrad<2, 1, 1>(p, nb, st);
+        else if (CIT == 2 && COT == 2) rc = launch_pw_wgrad<2, 2, 1>(p, nb, st);
+        else if (CIT == 4 && COT == 4) rc = launch_pw_wgrad<4, 4, 1>(p, nb, st);
+        else if (CIT == 2 && COT == 4) rc = launch_pw_wgrad<2, 4, 1>(p, nb, st);
+        else if (CIT == 4 && COT == 2) rc = launch_pw_wgrad<4, 2, 1>(p, nb, st);
+        else if (CIT == 1 && COT == 4) rc = launch_pw_wgrad<1, 4, 1>(p, nb, st);
+        else if (CIT == 4 && COT == 1) rc = launch_pw_wgrad<4, 1, 1>(p, nb, st);
+    }
+#undef DA_WG_CASE
+    if (rc) return rc;
+    hipLaunchKernelGGL(pw_reduce_kernel, dim3(da_grid((long long)O, 256)), dim3(256), 0, st, p.partial, nb, (int)O, dw);
+    DA_LAUNCH_CHECK();
+    return 0;
+}

@@ -120,7 +120,8 @@ class Conv1x1Fn(Function):
         out = _empty((N, D, H, W, Cout), a)
         M = N * D * H * W
         b = bias.detach().contiguous() if bias is not None else None
-        call('da_conv1x1_fwd', ptr(a), ptr(w_io), ptr(b), ptr(out), M, Cin, Cout, st)
+        wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(1, Cin, Cout), a)
+        call('da_conv1x1_fwd', ptr(a), ptr(w_io), ptr(b), ptr(out), M, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(a, w_io)
         return ncdhw(out)
@@ -135,7 +136,8 @@ class Conv1x1Fn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
-            call('da_conv1x1_dgrad', ptr(g), ptr(w_io), ptr(dx), M, Cin, Cout, st)
+            wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(1, Cin, Cout), a)
+            call('da_conv1x1_dgrad', ptr(g), ptr(w_io), ptr(dx), M, Cin, Cout, wp, wn, st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw_io = torch.empty_like(w_io)
             db = _empty((Cout,), a) if ctx.has_bias else None
@@ -161,7 +163,8 @@ class DeconvK2S2Fn(Function):
         call('da_w_iok_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 8, st)
         out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
         b = bias.detach().contiguous() if bias is not None else None
-        call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cin, Cout, st)
+        wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
+        call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(a, w_tio)
         return ncdhw(out)
@@ -176,7 +179,8 @@ class DeconvK2S2Fn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
-            call('da_deconv_k2s2_dgrad', ptr(g), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, st)
+            wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
+            call('da_deconv_k2s2_dgrad', ptr(g), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw_tio = torch.empty_like(w_tio)
             db = _empty((Cout,), a) if ctx.has_bias else None

@@ -71,9 +71,12 @@ int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, int C2, const
 int da_set_conv_direct(int on);
 
 /* ---- 1x1x1 convolution (segmentation head, row a5; unets.py:249-250) ------------------------- */
+/* scratch for the packed weights of the 1x1 / transposed-conv forward and data-gradient launchers */
+size_t da_pointwise_ws_bytes(int ntaps, int Cin, int Cout);
 int da_conv1x1_fwd(const float* in, const float* w_io, const float* bias, float* out,
-                   long long M, int Cin, int Cout, void* stream);
-int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout, void* stream);
+                   long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout,
+                     void* ws, size_t ws_bytes, void* stream);
 size_t da_conv1x1_wgrad_ws_bytes(long long M, int Cin, int Cout);
 int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, float* dbias,
                      long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
@@ -81,9 +84,9 @@ int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, float* dbia
 /* ---- 2x2x2 stride-2 transposed convolution (row a3; unets.py:49,55,240-241) ------------------ */
 /* out[N][2D][2H][2W][Cout] = bias + sum_ci in[N][D][H][W][ci] * w_tio[tap(i,j,k)][ci][co] */
 int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const float* bias, float* out,
-                       int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                       int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
-                         int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                         int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
 int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_tio, float* dbias,
                          int N, int D, int H, int W, int Cin, int Cout,
