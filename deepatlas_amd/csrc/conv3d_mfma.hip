@@ -34,22 +34,44 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + loc;
 }
 
-// stage an (HZ x HY x HX) halo tile of CK channels into LDS as [voxel][CK]; out-of-volume voxels are zero (padding 1)
-template <int CK, int HZ>
-__device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ src, int Cs, int choff,
+// Staging of an (HZ x HY x HX) halo tile of CK channels into LDS as [voxel][CK]; out-of-volume voxels are zero
+// (padding 1).  Split T14-style: stage_load issues the global loads into registers (one work item AHEAD, so their
+// latency hides under the current item's MFMAs), stage_write drops them into LDS after the barrier that retires the
+// previous tile.  The LDS image is linear in the flat (voxel, channel-quad) index, so the write is one ds_write_b128.
+template <int CK, int HZ> struct StageGeom {
+    static constexpr int Q = CK / 4;
+    static constexpr int TOTAL = HZ * HY * HX * Q;
+    static constexpr int NIT = (TOTAL + 255) / 256;
+};
+
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
+__device__ __forceinline__ void stage_load(float4* pre, const float* __restrict__ src, int Cs, int choff,
                                            int n, int z0, int y0, int x0, int D, int H, int W) {
-    constexpr int Q = CK / 4;
-    constexpr int TOTAL = HZ * HY * HX * Q;
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < TOTAL; idx += 256) {
+    constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        int idx = threadIdx.x + it * 256;
+        // opaque to the optimiser: otherwise LICM hoists all NIT voxel decompositions out of the persistent item loop
+        // and keeps ~3 VGPRs per staging iteration live across the MFMA phase (spills at two workgroups per CU)
+        asm volatile("" : "+v"(idx));
         const int c4 = idx % Q; const int hv = idx / Q;
         const int hx = hv % HX; const int t = hv / HX;
         const int hy = t % HY; const int hz = t / HY;
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+        if (idx < TOTAL && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
             v = *reinterpret_cast<const float4*>(src + ((((long long)n * D + z) * H + y) * W + x) * Cs + choff + c4 * 4);
-        *reinterpret_cast<float4*>(lds + hv * CK + c4 * 4) = v;
+        pre[it - IT0] = v;
+    }
+}
+
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
+__device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
+    constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        if (idx < TOTAL) reinterpret_cast<float4*>(lds)[idx] = pre[it - IT0];
     }
 }
 
@@ -57,7 +79,7 @@ struct FwdP {
     const float* in1; const float* in2; int C1, C2;
     const float* wp; const float* bias;
     float* out1; float* out2; int Cs1, Cs2;
-    int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles;
+    int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles, tiles_per_block;
     float slope;
 };
 
@@ -66,15 +88,49 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 4, HZ = TZ + 2;
     constexpr int NSTEPS = (27 * CK + 15) / 16;          // 27 (CK = 16) | 14 (CK = 8: two taps per K-step)
-    int t = xcd_remap(blockIdx.x, p.ntiles);
-    const int tx = t % p.ntx; t /= p.ntx;
-    const int ty = t % p.nty; t /= p.nty;
-    const int tz = t % p.ntz; const int n = t / p.ntz;
-    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+    constexpr int NIT = StageGeom<CK, HZ>::NIT;
+    // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
+    // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
+    constexpr int PRE = (NREP == 1) ? NIT : (NREP == 2 ? (NIT < 12 ? NIT : 12) : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NREP;
+    const int nchunks = (p.C1 + p.C2) / CK;
+    // persistent: this workgroup owns tiles [tile_begin, tile_end); work item = (tile, channel chunk)
+    const int tile_begin = blockIdx.x * p.tiles_per_block;
+    int tile_end = tile_begin + p.tiles_per_block; if (tile_end > p.ntiles) tile_end = p.ntiles;
+    const int nitems = (tile_end - tile_begin) * nchunks;
+    if (nitems <= 0) return;
+
+    auto item_coords = [&](int item, int& n, int& z0, int& y0, int& x0, int& ch) {
+        ch = item % nchunks;
+        int t = tile_begin + item / nchunks;
+        const int tx = t % p.ntx; t /= p.ntx;
+        const int ty = t % p.nty; t /= p.nty;
+        const int tz = t % p.ntz; n = t / p.ntz;
+        x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
+    };
+    auto issue_stage = [&](int item, float4* pre) {          // iterations [0, PRE)
+        int n, z0, y0, x0, ch;
+        item_coords(item, n, z0, y0, x0, ch);
+        const int cbase = ch * CK;
+        if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        else stage_load<CK, HZ, 0, PRE>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W);
+    };
+    auto stage_rest = [&](int item) {                         // iterations [PRE, NIT): global -> LDS, in <= 3 batches
+        if constexpr (PRE < NIT) {
+            int n, z0, y0, x0, ch;
+            item_coords(item, n, z0, y0, x0, ch);
+            const int cbase = ch * CK;
+            const float* src = (cbase < p.C1) ? p.in1 : p.in2;
+            const int Cs = (cbase < p.C1) ? p.C1 : p.C2, choff = (cbase < p.C1) ? cbase : cbase - p.C1;
+            constexpr int R = NIT - PRE, B1 = PRE + (R + 2) / 3, B2 = PRE + 2 * ((R + 2) / 3) < NIT ? PRE + 2 * ((R + 2) / 3) : NIT;
+            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1>(lds, tmp); }
+            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2>(lds, tmp); }
+            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT>(lds, tmp); }
+        }
+    };
 
     f32x4 acc[TY][NREP];
 #pragma unroll
@@ -82,100 +138,94 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
         for (int nn = 0; nn < NREP; ++nn) acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = (p.C1 + p.C2) / CK;
-    const float4* wp4 = reinterpret_cast<const float4*>(p.wp);
+    float4 pre[PRE > 0 ? PRE : 1];
+    issue_stage(0, pre);
+    stage_write<CK, HZ, 0, PRE>(lds, pre);
+    stage_rest(0);
+    __syncthreads();
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cbase = ch * CK;
-        const float* src; int Cs, choff;
-        if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
-        __syncthreads();
-        stage_tile<CK, HZ>(lds, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
-        __syncthreads();
-        const float4* wch = wp4 + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
-        float4 bcur[NREP];
+    // K-step s: lane group g supplies (tap, cin quad) = CK16: (s, g) | CK8: (2s + (g>>1), g&1).
+    const float* abase = (CK == 16) ? lds + ((wave * HY) * HX + i) * CK + g * 4
+                                    : lds + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
+    const bool hi = (g >> 1) != 0;
+    auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
+    auto a_off8 = [&](int s) -> int {                                                              // CK8: two taps per step
+        int tap = 2 * s + (hi ? 1 : 0); if (tap > 26) tap = 26;
+        return (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK;
+    };
+
+#pragma unroll 1
+    for (int item = 0; item < nitems; ++item) {
+        int n, z0, y0, x0, ch;
+        item_coords(item, n, z0, y0, x0, ch);
+        const bool has_next = item + 1 < nitems;
+        if (has_next) issue_stage(item + 1, pre);           // global loads in flight during this item's MFMAs
+
+        const f32x4* wch = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
+        // B fragments are fetched one K-step ahead (global, L1/L2 resident); A fragments come from LDS per step.
+        // MFMA order: component m outermost, M-tile r innermost -> 8*NREP independent accumulators between two uses
+        // of the same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
+        f32x4 bcur[NREP];
 #pragma unroll
         for (int nn = 0; nn < NREP; ++nn) bcur[nn] = wch[(size_t)nn * 64];
-
-        if constexpr (CK == 16) {
-            const float* abase = lds + ((wave * HY) * HX + i) * CK + g * 4;
+        // CK = 16: 3 x 9 K-steps (outer tap plane loop kept rolled: shorter scheduling regions, lower VGPR pressure);
+        // CK = 8: 14 K-steps, 2 x 7.
+        constexpr int SOUT = (CK == 16) ? 3 : 2, SIN = NSTEPS / SOUT;
 #pragma unroll 1
-            for (int dz = 0; dz < 3; ++dz) {
+        for (int so = 0; so < SOUT; ++so) {
+            const float* abase_o = abase + ((CK == 16) ? so * (HY * HX * CK) : 0);
 #pragma unroll
-                for (int dyx = 0; dyx < 9; ++dyx) {
-                    const int dy = dyx / 3, dx = dyx % 3;
-                    const int s = dz * 9 + dyx;
-                    const int sn = (s + 1 < 27) ? s + 1 : 26;
-                    float4 bnext[NREP];
-#pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn) bnext[nn] = wch[((size_t)sn * p.NT + nn) * 64];
-                    const float* ap = abase + ((dz * HY + dy) * HX + dx) * CK;
-#pragma unroll
-                    for (int r = 0; r < TY; ++r) {
-                        const float4 a = *reinterpret_cast<const float4*>(ap + r * (HX * CK));
-#pragma unroll
-                        for (int nn = 0; nn < NREP; ++nn) {
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bcur[nn].x, acc[r][nn], 0, 0, 0);
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bcur[nn].y, acc[r][nn], 0, 0, 0);
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bcur[nn].z, acc[r][nn], 0, 0, 0);
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bcur[nn].w, acc[r][nn], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn) bcur[nn] = bnext[nn];
-                }
-            }
-        } else {
-            // CK == 8: lane groups 0,1 take tap 2s (cin 0-3 / 4-7), groups 2,3 take tap 2s+1
-            const float* abase = lds + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
-            const bool hi = (g >> 1) != 0;
-#pragma unroll
-            for (int s = 0; s < NSTEPS; ++s) {
-                const int sn = (s + 1 < NSTEPS) ? s + 1 : NSTEPS - 1;
-                float4 bnext[NREP];
+            for (int si = 0; si < SIN; ++si) {
+                const int s = so * SIN + si;
+                int sn = s + 1; if (sn > NSTEPS - 1) sn = NSTEPS - 1;
+                f32x4 bnext[NREP], acur[TY];
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bnext[nn] = wch[((size_t)sn * p.NT + nn) * 64];
-                const int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
-                const int off0 = (((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3) * CK;
-                const int off1 = (((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3) * CK;
-                const float* ap = abase + (hi ? off1 : off0);
+                {
+                    // CK16: offset within the tap plane is compile-time (si); CK8: full offset from the (runtime) step
+                    const float* ap = (CK == 16) ? abase_o + a_off(si) : abase + a_off8(s);
 #pragma unroll
-                for (int r = 0; r < TY; ++r) {
-                    const float4 a = *reinterpret_cast<const float4*>(ap + r * (HX * CK));
-#pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn) {
-                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bcur[nn].x, acc[r][nn], 0, 0, 0);
-                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bcur[nn].y, acc[r][nn], 0, 0, 0);
-                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bcur[nn].z, acc[r][nn], 0, 0, 0);
-                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bcur[nn].w, acc[r][nn], 0, 0, 0);
-                    }
+                    for (int r = 0; r < TY; ++r) acur[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
                 }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                        for (int r = 0; r < TY; ++r)
+                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[r][m], bcur[nn][m], acc[r][nn], 0, 0, 0);
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bcur[nn] = bnext[nn];
             }
         }
-    }
 
-    // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg
-    const int z = z0 + wave;
-    if (z >= p.D) return;
+        if (ch == nchunks - 1) {
+            // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg
+            const int z = z0 + wave;
 #pragma unroll
-    for (int nn = 0; nn < NREP; ++nn) {
-        const int co = (nt0 + nn) * 16 + i;
-        if (co >= p.Cout) continue;
-        const float b = p.bias ? p.bias[co] : 0.f;
-        float* dst; int Cd, cd;
-        if (co < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co; } else { dst = p.out2; Cd = p.Cs2; cd = co - p.Cs1; }
+            for (int nn = 0; nn < NREP; ++nn) {
+                const int co = (nt0 + nn) * 16 + i;
+                const float b = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+                float* dst; int Cd, cd;
+                if (co < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co; } else { dst = p.out2; Cd = p.Cs2; cd = co - p.Cs1; }
 #pragma unroll
-        for (int r = 0; r < TY; ++r) {
-            const int y = y0 + r;
-            if (y >= p.H) continue;
-            const long long rowbase = (((long long)n * p.D + z) * p.H + y) * p.W;
+                for (int r = 0; r < TY; ++r) {
+                    const int y = y0 + r;
+                    const long long rowbase = (((long long)n * p.D + z) * p.H + y) * p.W;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int x = x0 + 4 * g + reg;
-                if (x < p.W) dst[(rowbase + x) * Cd + cd] = da_act(acc[r][nn][reg] + b, p.slope);
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int x = x0 + 4 * g + reg;
+                        if (co < p.Cout && z < p.D && y < p.H && x < p.W) dst[(rowbase + x) * Cd + cd] = da_act(acc[r][nn][reg] + b, p.slope);
+                    }
+                    acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
+        }
+        if (has_next) {
+            __syncthreads();                       // every wave is done reading this item's LDS tile
+            stage_write<CK, HZ, 0, PRE>(lds, pre);
+            stage_rest(item + 1);
+            __syncthreads();
         }
     }
 }
@@ -242,36 +292,55 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 
     const int tile_begin = blockIdx.x * p.tiles_per_slab;
     int tile_end = tile_begin + p.tiles_per_slab; if (tile_end > p.ntiles) tile_end = p.ntiles;
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
+    constexpr int NITA = StageGeom<CK, HZ>::NIT;
+    constexpr int QY = CG / 4, NITY = (TVOX * QY + 255) / 256;
+    float4 preA[NITA], preY[NITY];
+    auto tile_coords = [&](int tile, int& n, int& z0, int& y0, int& x0) {
         int t = tile;
         const int tx = t % p.ntx; t /= p.ntx;
         const int ty = t % p.nty; t /= p.nty;
-        const int tz = t % p.ntz; const int n = t / p.ntz;
-        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
-        __syncthreads();
-        stage_tile<CK, HZ>(ldsA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
-        // dY tile [TVOX][CG] (channel halves XOR-swizzled by voxel parity when CG % 32 == 0)
-        {
-            constexpr int Q = CG / 4;
-#pragma unroll 4
-            for (int idx = threadIdx.x; idx < TVOX * Q; idx += 256) {
-                const int c4 = idx % Q; const int v = idx / Q;
-                const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
-                const int co = cg * CG + c4 * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (z < p.D && y < p.H && x < p.W && co < p.Cout)
-                    val = *reinterpret_cast<const float4*>(p.dy + ((((long long)n * p.D + z) * p.H + y) * p.W + x) * p.Cout + co);
-                int c = c4 * 4;
-                if (SWZ) c ^= (v & 1) << 4;
-                *reinterpret_cast<float4*>(ldsY + v * CG + c) = val;
-            }
+        const int tz = t % p.ntz; n = t / p.ntz;
+        x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
+    };
+    auto issue_loads = [&](int tile) {
+        int n, z0, y0, x0;
+        tile_coords(tile, n, z0, y0, x0);
+        stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int c4 = idx % QY; const int v = idx / QY;
+            const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
+            const int co = cg * CG + c4 * 4;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TVOX * QY && z < p.D && y < p.H && x < p.W && co < p.Cout)
+                val = *reinterpret_cast<const float4*>(p.dy + ((((long long)n * p.D + z) * p.H + y) * p.W + x) * p.Cout + co);
+            preY[it] = val;
         }
-        __syncthreads();
-#pragma unroll 2
-        for (int s = 0; s < TVOX / 4; ++s) {
+    };
+    auto write_lds = [&]() {
+        stage_write<CK, HZ>(ldsA, preA);
+        // dY tile [TVOX][CG] (channel halves XOR-swizzled by voxel parity when CG % 32 == 0)
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int c4 = idx % QY; const int v = idx / QY;
+            int c = c4 * 4;
+            if (SWZ) c ^= (v & 1) << 4;
+            if (idx < TVOX * QY) *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
+        }
+    };
+    if (tile_begin < tile_end) { issue_loads(tile_begin); write_lds(); }
+    __syncthreads();
+#pragma unroll 1
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const bool has_next = tile + 1 < tile_end;
+        if (has_next) issue_loads(tile + 1);                 // next tile's global loads fly during this tile's MFMAs
+        // fragments for K-step s+1 are read from LDS while the MFMAs of step s issue (explicit double buffer: left to
+        // itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per MFMA, i.e. one exposed LDS latency each)
+        auto load_frag = [&](int s, float* a, float* b) {
             const int v = 4 * s + g;
             const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
-            float b[NREP];
 #pragma unroll
             for (int nn = 0; nn < NREP; ++nn) {
                 int c = nn * 16;
@@ -280,12 +349,28 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             }
             const float* ap = ldsA + ((vz * HY + vy) * HX + vx) * CK;
 #pragma unroll
-            for (int k = 0; k < TPW; ++k) {
-                const float a = ap[offA[k]];
+            for (int k = 0; k < TPW; ++k) a[k] = ap[offA[k]];
+        };
+        float a0[TPW], b0[NREP];
+        load_frag(0, a0, b0);
+#pragma unroll 2
+        for (int s = 0; s < TVOX / 4; ++s) {
+            float a1[TPW], b1[NREP];
+            load_frag(s + 1 < TVOX / 4 ? s + 1 : s, a1, b1);
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn)
-                    acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nn], acc[k][nn], 0, 0, 0);
-            }
+                    acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b0[nn], acc[k][nn], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) a0[k] = a1[k];
+#pragma unroll
+            for (int nn = 0; nn < NREP; ++nn) b0[nn] = b1[nn];
+        }
+        if (has_next) {
+            __syncthreads();
+            write_lds();
+            __syncthreads();
         }
     }
     // write this slab's partial dW[tap][cin][cout]; rows (M) = 4*g + reg, cols (N) = i
@@ -316,15 +401,106 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nparts
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// weight gradient for tiny Cin (first layers: seg 1 -> 8, reg 2 -> 16).  HBM-bound reduction over voxels:
+// GEMM M = (tap, ci) flattened (27*Cin <= 112 -> MT tiles of 16), N = Cout, K = voxels; both operands are read
+// straight from global memory in fragment order (the 27 shifted input reads hit L1/L2), one wave per output row.
+// ---------------------------------------------------------------------------------------------------
+struct ScP {
+    const float* in1; const float* in2; int C1, C2;
+    const float* dy; float* partial;
+    int N, D, H, W, Cout; long long nrows;
+};
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
+    __shared__ __attribute__((aligned(16))) float red[MT * NT * 64 * 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int Cin = p.C1 + p.C2;
+    // per-lane description of the A rows this lane feeds: m = 16*mt + i -> (tap, ci)
+    int dz[MT], dy_[MT], dx[MT], cs[MT], cc[MT]; bool mval[MT]; const float* src[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + i;
+        mval[mt] = m < 27 * Cin;
+        const int tap = mval[mt] ? m / Cin : 0, ci = mval[mt] ? m % Cin : 0;
+        dz[mt] = tap / 9 - 1; dy_[mt] = (tap / 3) % 3 - 1; dx[mt] = tap % 3 - 1;
+        if (ci < p.C1) { src[mt] = p.in1; cs[mt] = p.C1; cc[mt] = ci; } else { src[mt] = p.in2; cs[mt] = p.C2; cc[mt] = ci - p.C1; }
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long long wave_id = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
+    for (long long row = wave_id; row < p.nrows; row += nwaves) {
+        const int y = (int)(row % p.H); const int z = (int)((row / p.H) % p.D); const int n = (int)(row / ((long long)p.H * p.D));
+        long long rbase[MT]; bool rval[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int zz = z + dz[mt], yy = y + dy_[mt];
+            rval[mt] = mval[mt] && zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
+            rbase[mt] = ((((long long)n * p.D + (rval[mt] ? zz : 0)) * p.H + (rval[mt] ? yy : 0)) * p.W) * cs[mt] + cc[mt];
+        }
+        const float* grow = p.dy + (row * p.W) * p.Cout;
+#pragma unroll 2
+        for (int x0 = 0; x0 < p.W; x0 += 4) {
+            const int x = x0 + g;
+            float b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = (x < p.W && 16 * nt + i < p.Cout) ? grow[(long long)x * p.Cout + 16 * nt + i] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int xx = x + dx[mt];
+                const float a = (rval[mt] && x < p.W && xx >= 0 && xx < p.W) ? src[mt][rbase[mt] + (long long)xx * cs[mt]] : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float4* slot = reinterpret_cast<float4*>(red) + (mt * NT + nt) * 64 + lane;
+                    float4 cur = (w == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
+                    cur.x += acc[mt][nt][0]; cur.y += acc[mt][nt][1]; cur.z += acc[mt][nt][2]; cur.w += acc[mt][nt][3];
+                    *slot = cur;
+                }
+        }
+        __syncthreads();
+    }
+    const int O = 27 * Cin * p.Cout;
+    float* part = p.partial + (size_t)blockIdx.x * O;
+    for (int idx = threadIdx.x; idx < MT * NT * 64; idx += 256) {
+        const int ln = idx & 63, q = idx >> 6;
+        const int nt = q % NT, mt = q / NT;
+        const float4 v = reinterpret_cast<const float4*>(red)[idx];
+        const float vals[4] = {v.x, v.y, v.z, v.w};
+        const int co = 16 * nt + (ln & 15);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * mt + 4 * (ln >> 4) + reg;
+            if (m < 27 * Cin && co < p.Cout) part[(size_t)m * p.Cout + co] = vals[reg];
+        }
+    }
+}
+
 static int pick_ck(int C1, int C2) {
     const int Cin = C1 + C2;
     if (Cin % 16 == 0 && C1 % 16 == 0) return 16;
     if (Cin % 8 == 0 && C1 % 8 == 0) return 8;
     return 0;
 }
-// N-tiles per workgroup: 3 for Cout = 48 (dgrad of the 48->16 layer), otherwise <= 2 so that 8*NREP*4 accumulators +
-// fragments stay under 256 VGPRs (two workgroups per CU); more couts go to blockIdx.y.
-static int pick_nrep(int NT) { return NT <= 3 ? NT : (NT % 2 == 0 ? 2 : (NT % 3 == 0 ? 3 : 2)); }
+// N-tiles per workgroup: <= 2, so that 8*NREP*4 accumulators + fragments + the register-parked staging prefetch stay
+// under 256 VGPRs (two workgroups per CU); more couts go to blockIdx.y (the input tile is re-staged per group, which the
+// one-item-ahead prefetch hides).
+static int pick_nrep(int NT) { return NT <= 2 ? NT : (NT % 2 == 0 ? 2 : 1); }
 
 static size_t packed_bytes(int Cin, int Cout, int CK) {
     const int NT = (Cout + 15) / 16, NREP = pick_nrep(NT);
@@ -344,7 +520,7 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout) {
     q.ntz = (D + 1) / 2; q.nty = (H + TY - 1) / TY; q.ntx = (W + TX - 1) / TX;
     q.ntiles = N * q.ntz * q.nty * q.ntx;
     const size_t O = (size_t)27 * (C1 + C2) * Cout;
-    long long slabs = 1024 / (q.nchunks * q.ngroups); if (slabs < 1) slabs = 1;
+    long long slabs = 512 / (q.nchunks * q.ngroups); if (slabs < 1) slabs = 1;      // one resident round: 2 workgroups / CU
     const long long cap = (long long)((96ull << 20) / (O * 4)); if (slabs > cap) slabs = cap < 1 ? 1 : cap;
     if (slabs > q.ntiles) slabs = q.ntiles;
     q.tps = (int)da_cdiv(q.ntiles, slabs);
@@ -355,6 +531,7 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout) {
 
 }  // namespace
 
+static const int kScBlocksFwd = 1024;
 size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int stride) {
     if (stride != 1) return 0;
     size_t pk = 0;
@@ -362,6 +539,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
     if (Cout % 8 == 0) { const size_t a = packed_bytes(Cout, Cin, Cout % 16 == 0 ? 16 : 8); if (a > pk) pk = a; }
     size_t part = 0;
     if (Cin % 8 == 0) part = wgrad_plan(N, D, H, W, Cin, 0, Cout).partial_bytes;
+    if (Cin <= 4 && Cout <= 32) part = da_align((size_t)kScBlocksFwd * 27 * Cin * Cout * sizeof(float));
     return pk + part;
 }
 
@@ -382,7 +560,7 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles, gy), dim3(256), shm, st, p);
+    hipLaunchKernelGGL(kern, dim3((p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block, gy), dim3(256), shm, st, p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -410,6 +588,10 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.NT = NTpad;
     p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx; p.slope = slope;
+    {   // one resident round: 2 workgroups per CU x 256 CUs, split over the cout groups
+        int nblk = 512 / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
+        p.tiles_per_block = (p.ntiles + nblk - 1) / nblk;
+    }
 #define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return launch_fwd_mfma<ck, nr>(p, gy, st)
     DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3); DA_FWD_CASE(16, 4);
     DA_FWD_CASE(8, 1); DA_FWD_CASE(8, 2); DA_FWD_CASE(8, 3); DA_FWD_CASE(8, 4);
@@ -417,7 +599,11 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     return DA_ERR_UNSUPPORTED;
 }
 
+static bool smallcin_ok(int C1, int C2, int Cout, int stride) { return stride == 1 && C1 + C2 <= 4 && Cout <= 32; }
+static const int kScBlocks = 1024;
+
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride) {
+    if (smallcin_ok(C1, C2, Cout, stride)) return true;
     if (stride != 1) return false;
     if (pick_ck(C1, C2) == 0) return false;
     if (Cout % 4 != 0 || Cout < 8) return false;
@@ -441,7 +627,23 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
 
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st) {
-    (void)stride;
+    if (smallcin_ok(C1, C2, Cout, stride)) {
+        const int Cin = C1 + C2, O = 27 * Cin * Cout;
+        if (ws_bytes < (size_t)kScBlocks * O * sizeof(float)) return DA_ERR_WS_SMALL;
+        ScP sp;
+        sp.in1 = in1; sp.in2 = in2; sp.C1 = C1; sp.C2 = C2; sp.dy = dy; sp.partial = (float*)ws;
+        sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.Cout = Cout; sp.nrows = (long long)N * D * H;
+        int nb = (int)da_cdiv(sp.nrows, 4); if (nb > kScBlocks) nb = kScBlocks;
+        const int MT = (27 * Cin + 15) / 16, NT = (Cout + 15) / 16;
+#define DA_SC_CASE(mt, nt) if (MT == mt && NT == nt) hipLaunchKernelGGL((conv3_smallcin_wgrad_kernel<mt, nt>), dim3(nb), dim3(256), 0, st, sp)
+        DA_SC_CASE(2, 1); else DA_SC_CASE(2, 2); else DA_SC_CASE(4, 1); else DA_SC_CASE(4, 2); else DA_SC_CASE(6, 1); else DA_SC_CASE(6, 2);
+        else DA_SC_CASE(7, 1); else DA_SC_CASE(7, 2); else return DA_ERR_UNSUPPORTED;
+#undef DA_SC_CASE
+        DA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, sp.partial, nb, O, dw_tio);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < q.partial_bytes) return DA_ERR_WS_SMALL;
