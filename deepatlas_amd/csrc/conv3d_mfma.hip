@@ -44,24 +44,41 @@ template <int CK, int HZ> struct StageGeom {
     static constexpr int NIT = (TOTAL + 255) / 256;
 };
 
+// Global loads go through a buffer descriptor over ONE sample's tensor: an out-of-volume voxel gets byte offset
+// 0xFFFFFFFF, which the hardware range check turns into zeros -- no exec-mask branch per load, so the NIT loads issue
+// back to back.  The (hz, hy, hx) decomposition of the flat index is done once and then stepped by 256/Q voxels per
+// iteration with carries (two compares) instead of two magic-number divisions per iteration.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t da_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
 template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
 __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict__ src, int Cs, int choff,
                                            int n, int z0, int y0, int x0, int D, int H, int W) {
     constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
+    constexpr int STEP = 256 / Q;                        // voxels per iteration
+    constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
+    const long long sample = (long long)D * H * W * Cs;
+    const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+    int idx = threadIdx.x + IT0 * 256;
+    asm volatile("" : "+v"(idx));                       // keep the decomposition out of the persistent loop's invariants
+    const int c4 = idx % Q; int hv = idx / Q;
+    int hx = hv % HX; int t = hv / HX;
+    int hy = t % HY; int hz = t / HY;
+    const int cofs = choff + c4 * 4;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
-        int idx = threadIdx.x + it * 256;
-        // opaque to the optimiser: otherwise LICM hoists all NIT voxel decompositions out of the persistent item loop
-        // and keeps ~3 VGPRs per staging iteration live across the MFMA phase (spills at two workgroups per CU)
-        asm volatile("" : "+v"(idx));
-        const int c4 = idx % Q; const int hv = idx / Q;
-        const int hx = hv % HX; const int t = hv / HX;
-        const int hy = t % HY; const int hz = t / HY;
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < TOTAL && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-            v = *reinterpret_cast<const float4*>(src + ((((long long)n * D + z) * H + y) * W + x) * Cs + choff + c4 * 4);
-        pre[it - IT0] = v;
+        const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
+        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * 4);
+        pre[it - IT0] = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        hv += STEP;
+        hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
+        hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
+        hz += SZ + cy;
     }
 }
 
@@ -81,6 +98,7 @@ struct FwdP {
     float* out1; float* out2; int Cs1, Cs2;
     int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles, tiles_per_block;
     float slope;
+    int ablate;      // diagnostic only (env DA_ABLATE): 1 skip staging loads, 2 skip epilogue stores, 4 skip LDS writes+barriers, 8 skip MFMAs
 };
 
 template <int CK, int NREP>
@@ -91,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     constexpr int NIT = StageGeom<CK, HZ>::NIT;
     // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
     // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
-    constexpr int PRE = (NREP == 1) ? NIT : (NREP == 2 ? (NIT < 12 ? NIT : 12) : 0);
+    constexpr int PRE = (NREP == 1) ? NIT : (NREP == 2 ? (NIT < 8 ? NIT : 8) : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -138,6 +156,13 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
         for (int nn = 0; nn < NREP; ++nn) acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The two workgroups resident on a CU start together and every item costs the same, so their staging / barrier /
+    // epilogue phases would coincide for the whole launch and leave the matrix pipe idle.  Delay the second resident
+    // round (block ids >= half the grid) by roughly half an item so one workgroup's MFMAs cover the other's gaps.
+    if (blockIdx.x >= (gridDim.x + 1) / 2) {
+#pragma unroll 1
+        for (int d = 0; d < 3 * NREP; ++d) __builtin_amdgcn_s_sleep(127);
+    }
     float4 pre[PRE > 0 ? PRE : 1];
     issue_stage(0, pre);
     stage_write<CK, HZ, 0, PRE>(lds, pre);
@@ -159,20 +184,22 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         int n, z0, y0, x0, ch;
         item_coords(item, n, z0, y0, x0, ch);
         const bool has_next = item + 1 < nitems;
-        if (has_next) issue_stage(item + 1, pre);           // global loads in flight during this item's MFMAs
-
         const f32x4* wch = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
+        f32x4 bcur[NREP];
+        // step-0 weights are requested BEFORE the staging burst: vmcnt retires in order, so a B load issued behind the
+        // NIT staging loads could not be consumed until all of them have landed
+#pragma unroll
+        for (int nn = 0; nn < NREP; ++nn) bcur[nn] = wch[(size_t)nn * 64];
+        if (has_next && !(p.ablate & 1)) issue_stage(item + 1, pre);           // global loads in flight during this item's MFMAs
+
         // B fragments are fetched one K-step ahead (global, L1/L2 resident); A fragments come from LDS per step.
         // MFMA order: component m outermost, M-tile r innermost -> 8*NREP independent accumulators between two uses
         // of the same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
-        f32x4 bcur[NREP];
-#pragma unroll
-        for (int nn = 0; nn < NREP; ++nn) bcur[nn] = wch[(size_t)nn * 64];
         // CK = 16: 3 x 9 K-steps (outer tap plane loop kept rolled: shorter scheduling regions, lower VGPR pressure);
         // CK = 8: 14 K-steps, 2 x 7.
         constexpr int SOUT = (CK == 16) ? 3 : 2, SIN = NSTEPS / SOUT;
 #pragma unroll 1
-        for (int so = 0; so < SOUT; ++so) {
+        for (int so = 0; so < ((p.ablate & 8) ? 0 : SOUT); ++so) {
             const float* abase_o = abase + ((CK == 16) ? so * (HY * HX * CK) : 0);
 #pragma unroll
             for (int si = 0; si < SIN; ++si) {
@@ -199,29 +226,70 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             }
         }
 
-        if (ch == nchunks - 1) {
-            // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg
+        if (ch == nchunks - 1 && !(p.ablate & 2)) {
+            // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg.
             const int z = z0 + wave;
+            const bool full = (z0 + TZ <= p.D) && (y0 + TY <= p.H) && (x0 + TX <= p.W) && ((p.Cs1 & 3) == 0) && ((p.Cs2 & 3) == 0) && ((p.Cout & 3) == 0);
+            if (full) {
+                // Fast path (interior tiles): 4x4 transpose across each lane quad (2 DPP butterfly stages) turns the
+                // fragment (4 voxels x 1 cout per lane) into (1 voxel x 4 couts per lane) -> one 16-byte store per M-tile,
+                // 1 KiB contiguous per wave instruction for Cout = 16, and no per-element branches (hipcc puts an
+                // s_waitcnt vmcnt(0) in front of every store that sits in its own exec-mask branch).
+                const int q = lane & 3, a4 = (lane & 15) >> 2;
 #pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) {
-                const int co = (nt0 + nn) * 16 + i;
-                const float b = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
-                float* dst; int Cd, cd;
-                if (co < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co; } else { dst = p.out2; Cd = p.Cs2; cd = co - p.Cs1; }
+                for (int nn = 0; nn < NREP; ++nn) {
+                    const int co0 = (nt0 + nn) * 16 + 4 * a4;          // first of this lane's 4 couts after the transpose
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias && co0 + 3 < p.Cout) bv = *reinterpret_cast<const float4*>(p.bias + co0);
+                    float* dst; int Cd, cd;
+                    if (co0 < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co0; } else { dst = p.out2; Cd = p.Cs2; cd = co0 - p.Cs1; }
+                    const bool lane_ok = co0 + 3 < p.Cout;
 #pragma unroll
-                for (int r = 0; r < TY; ++r) {
-                    const int y = y0 + r;
-                    const long long rowbase = (((long long)n * p.D + z) * p.H + y) * p.W;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int x = x0 + 4 * g + reg;
-                        if (co < p.Cout && z < p.D && y < p.H && x < p.W) dst[(rowbase + x) * Cd + cd] = da_act(acc[r][nn][reg] + b, p.slope);
+                    for (int r = 0; r < TY; ++r) {
+                        float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];
+                        {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
+                            const bool odd = (q & 1) != 0;
+                            const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
+                            const float r01 = __shfl_xor(s01, 1), r23 = __shfl_xor(s23, 1);
+                            if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
+                        }
+                        {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
+                            const bool hi2 = (q & 2) != 0;
+                            const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
+                            const float r02 = __shfl_xor(s02, 2), r13 = __shfl_xor(s13, 2);
+                            if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
+                        }
+                        // now (t0..t3) = couts co0..co0+3 of voxel x = x0 + 4*g + q
+                        const long long vox = (((long long)n * p.D + z) * p.H + (y0 + r)) * p.W + x0 + 4 * g + q;
+                        float4 o;
+                        o.x = da_act(t0 + bv.x, p.slope); o.y = da_act(t1 + bv.y, p.slope);
+                        o.z = da_act(t2 + bv.z, p.slope); o.w = da_act(t3 + bv.w, p.slope);
+                        if (lane_ok) *reinterpret_cast<float4*>(dst + vox * Cd + cd) = o;
+                        acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
-                    acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn) {
+                    const int co = (nt0 + nn) * 16 + i;
+                    const float b = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+                    float* dst; int Cd, cd;
+                    if (co < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co; } else { dst = p.out2; Cd = p.Cs2; cd = co - p.Cs1; }
+#pragma unroll
+                    for (int r = 0; r < TY; ++r) {
+                        const int y = y0 + r;
+                        const long long rowbase = (((long long)n * p.D + z) * p.H + y) * p.W;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int x = x0 + 4 * g + reg;
+                            if (co < p.Cout && z < p.D && y < p.H && x < p.W) dst[(rowbase + x) * Cd + cd] = da_act(acc[r][nn][reg] + b, p.slope);
+                        }
+                        acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
         }
-        if (has_next) {
+        if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
             stage_write<CK, HZ, 0, PRE>(lds, pre);
             stage_rest(item + 1);
@@ -306,16 +374,18 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         int n, z0, y0, x0;
         tile_coords(tile, n, z0, y0, x0);
         stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
+        const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (long long)n * sampleY, (unsigned)(sampleY * sizeof(float)));
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
-            const int idx = threadIdx.x + it * 256;
+            int idx = threadIdx.x + it * 256;
+            asm volatile("" : "+v"(idx));
             const int c4 = idx % QY; const int v = idx / QY;
             const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
             const int co = cg * CG + c4 * 4;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < TVOX * QY && z < p.D && y < p.H && x < p.W && co < p.Cout)
-                val = *reinterpret_cast<const float4*>(p.dy + ((((long long)n * p.D + z) * p.H + y) * p.W + x) * p.Cout + co);
-            preY[it] = val;
+            const bool inb = idx < TVOX * QY && z < p.D && y < p.H && x < p.W && co < p.Cout;
+            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + co) * 4);
+            preY[it] = da_buf_load4(ry, inb ? off : 0xFFFFFFFFu);
         }
     };
     auto write_lds = [&]() {
@@ -330,42 +400,51 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             if (idx < TVOX * QY) *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
         }
     };
+    if (blockIdx.x >= (gridDim.x + 1) / 2) {                 // de-phase the two workgroups of a CU (see the forward kernel)
+#pragma unroll 1
+        for (int d = 0; d < NREP; ++d) __builtin_amdgcn_s_sleep(127);
+    }
     if (tile_begin < tile_end) { issue_loads(tile_begin); write_lds(); }
     __syncthreads();
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
         if (has_next) issue_loads(tile + 1);                 // next tile's global loads fly during this tile's MFMAs
-        // fragments for K-step s+1 are read from LDS while the MFMAs of step s issue (explicit double buffer: left to
-        // itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per MFMA, i.e. one exposed LDS latency each)
-        auto load_frag = [&](int s, float* a, float* b) {
-            const int v = 4 * s + g;
-            const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+        // K loop: 16 rows (vz, vy) x 4 K-steps (4 voxels along x each).  Per row one base address per operand; the four
+        // steps use compile-time offsets (ds_read immediates), so the VALU work per 28*NREP MFMAs is a handful of adds.
+        // Fragments of step j+1 are read while the MFMAs of step j issue (hipcc otherwise serialises read->wait->mfma).
+        const int swz = SWZ ? ((g & 1) << 4) : 0;             // voxel parity == g & 1 (row base and 4*j are even)
+#pragma unroll 1
+        for (int row = 0; row < TVOX / 16; ++row) {
+            const int vz = row >> 3, vy = row & 7;
+            const float* arow = ldsA + ((vz * HY + vy) * HX + g) * CK;
+            const float* yrow = ldsY + (row * 16 + g) * CG + i;
+            float a0[TPW], b0[NREP];
 #pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) {
-                int c = nn * 16;
-                if (SWZ) c ^= (v & 1) << 4;
-                b[nn] = ldsY[v * CG + c + i];
+            for (int nn = 0; nn < NREP; ++nn) b0[nn] = yrow[(nn * 16) ^ swz];
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) a0[k] = arow[offA[k]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a1[TPW], b1[NREP];
+                if (j < 3) {
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn) b1[nn] = yrow[(j + 1) * 4 * CG + ((nn * 16) ^ swz)];
+#pragma unroll
+                    for (int k = 0; k < TPW; ++k) a1[k] = arow[(j + 1) * 4 * CK + offA[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn)
+                        acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b0[nn], acc[k][nn], 0, 0, 0);
+                if (j < 3) {
+#pragma unroll
+                    for (int k = 0; k < TPW; ++k) a0[k] = a1[k];
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn) b0[nn] = b1[nn];
+                }
             }
-            const float* ap = ldsA + ((vz * HY + vy) * HX + vx) * CK;
-#pragma unroll
-            for (int k = 0; k < TPW; ++k) a[k] = ap[offA[k]];
-        };
-        float a0[TPW], b0[NREP];
-        load_frag(0, a0, b0);
-#pragma unroll 2
-        for (int s = 0; s < TVOX / 4; ++s) {
-            float a1[TPW], b1[NREP];
-            load_frag(s + 1 < TVOX / 4 ? s + 1 : s, a1, b1);
-#pragma unroll
-            for (int k = 0; k < TPW; ++k)
-#pragma unroll
-                for (int nn = 0; nn < NREP; ++nn)
-                    acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b0[nn], acc[k][nn], 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < TPW; ++k) a0[k] = a1[k];
-#pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) b0[nn] = b1[nn];
         }
         if (has_next) {
             __syncthreads();
@@ -588,6 +667,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.NT = NTpad;
     p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx; p.slope = slope;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("DA_ABLATE"); abl = e ? atoi(e) : 0; } p.ablate = abl; }
     {   // one resident round: 2 workgroups per CU x 256 CUs, split over the cout groups
         int nblk = 512 / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
         p.tiles_per_block = (p.ntiles + nblk - 1) / nblk;
