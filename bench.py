@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='volumes per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
+    ap.add_argument('--workload', default='seg', choices=['seg', 'reg', 'joint'],
+                    help="'seg' = BASELINE configs[1] (the headline metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -114,6 +116,28 @@ def main():
         opt.step()
         return loss
 
+    units_per_step = args.batch
+    workload_name = 'seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (BASELINE configs[1])' % (
+        args.batch, shape[0], shape[1], shape[2])
+    if args.workload in ('reg', 'joint'):
+        from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
+        reg = get_network('voxel_morph_cvpr')()
+        reg.weights_init()
+        reg.to(dev).train()
+        ropt = FlatAdam(reg.parameters(), lr=1e-3)
+        parallel.broadcast_parameters(ropt)
+        im_m, im_t = x[:1], torch.rand((1, 1) + shape, generator=g).to(dev)
+        sm, st_ = y[:1], torch.randint(0, n_classes, (1,) + shape, generator=g, dtype=torch.uint8).to(dev)
+        units_per_step = 1
+        if args.workload == 'reg':
+            rstep = RegistrationStep(reg, ropt)
+            step = lambda: rstep(im_m, im_t)[0]
+            workload_name = 'reg-only VoxelMorph + trilinear warp + NCC + bending + Adam, 1 pair/GPU, %dx%dx%d fp32 (BASELINE configs[2])' % shape
+        else:
+            jstep = DeepAtlasJointStep(model, opt, reg, ropt, n_classes)
+            step = lambda: jstep(im_m, im_t, sm, st_)['loss_seg']
+            workload_name = 'joint DeepAtlas alternating step (reg phase + seg phase, 32-ch seg warp), 1 pair/GPU, %dx%dx%d fp32 (BASELINE configs[3] per-GPU shape)' % shape
+
     for _ in range(args.warmup):
         step()
     prof = None
@@ -141,7 +165,7 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * args.batch * args.steps / dt
+        value = world * units_per_step * args.steps / dt
         roofline = None
         if prof is not None:
             summ = prof.summary()
@@ -159,12 +183,11 @@ def main():
         line = dict(metric='training volumes/sec at 160x192x160 fp32; Dice vs CPU ref', value=round(value, 4), unit='volumes/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                    config=dict(workload='seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (BASELINE configs[1])'
-                                         % (args.batch, shape[0], shape[1], shape[2]),
-                                global_batch=world * args.batch, volume=list(shape), n_classes=n_classes,
+                    config=dict(workload=workload_name,
+                                global_batch=world * units_per_step, volume=list(shape), n_classes=n_classes,
                                 parallelism='dp%d' % world, final_loss=round(final_loss, 6)),
                     roofline=roofline)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'seg':
             line['cpu_baseline'] = cpu_baseline(shape, args.batch, n_classes)
         else:
             line['cpu_baseline'] = None

@@ -326,7 +326,7 @@ struct WgP {
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, tiles_per_slab, O;
 };
 
-template <int CK, int NREP>
+template <int CK, int NREP, bool YS = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv)
 __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     constexpr int NITA = StageGeom<CK, HZ>::NIT;
     constexpr int QY = CG / 4, NITY = (TVOX * QY + 255) / 256;
     float4 preA[NITA], preY[NITY];
+    static_assert(!YS || NREP == 1, "scalar dY staging is only instantiated for one cout tile");
     auto tile_coords = [&](int tile, int& n, int& z0, int& y0, int& x0) {
         int t = tile;
         const int tx = t % p.ntx; t /= p.ntx;
@@ -383,9 +384,17 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             const int c4 = idx % QY; const int v = idx / QY;
             const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
             const int co = cg * CG + c4 * 4;
-            const bool inb = idx < TVOX * QY && z < p.D && y < p.H && x < p.W && co < p.Cout;
+            const bool vin = idx < TVOX * QY && z < p.D && y < p.H && x < p.W;
             const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + co) * 4);
-            preY[it] = da_buf_load4(ry, inb ? off : 0xFFFFFFFFu);
+            if constexpr (!YS) {
+                preY[it] = da_buf_load4(ry, (vin && co < p.Cout) ? off : 0xFFFFFFFFu);
+            } else {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    t[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (vin && co + j < p.Cout) ? off + 4 * j : 0xFFFFFFFFu, 0, 0));
+                preY[it] = make_float4(t[0], t[1], t[2], t[3]);
+            }
         }
     };
     auto write_lds = [&]() {
@@ -686,14 +695,14 @@ bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride) {
     if (smallcin_ok(C1, C2, Cout, stride)) return true;
     if (stride != 1) return false;
     if (pick_ck(C1, C2) == 0) return false;
-    if (Cout % 4 != 0 || Cout < 8) return false;
+    if (Cout % 4 != 0 && Cout > 16) return false;      // scalar dY staging covers one cout tile
     return true;
 }
 
-template <int CK, int NREP>
+template <int CK, int NREP, bool YS = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * sizeof(float);
-    auto kern = conv3_mfma_wgrad_kernel<CK, NREP>;
+    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -733,7 +742,9 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles; p.tiles_per_slab = q.tps;
     p.O = 27 * (C1 + C2) * Cout;
     int rc = DA_ERR_UNSUPPORTED;
-    if (q.CK == 16 && q.NREP == 1) rc = launch_wgrad_mfma<16, 1>(p, q, st);
+    if (Cout % 4 != 0 && q.CK == 16) rc = launch_wgrad_mfma<16, 1, true>(p, q, st);
+    else if (Cout % 4 != 0 && q.CK == 8) rc = launch_wgrad_mfma<8, 1, true>(p, q, st);
+    else if (q.CK == 16 && q.NREP == 1) rc = launch_wgrad_mfma<16, 1>(p, q, st);
     else if (q.CK == 16 && q.NREP == 2) rc = launch_wgrad_mfma<16, 2>(p, q, st);
     else if (q.CK == 8 && q.NREP == 1) rc = launch_wgrad_mfma<8, 1>(p, q, st);
     else if (q.CK == 8 && q.NREP == 2) rc = launch_wgrad_mfma<8, 2>(p, q, st);

@@ -1,0 +1,80 @@
+"""Registration and joint DeepAtlas training steps built from the reference's parts.
+
+The reference lists registration and joint training as TODO (README.md:15-19); only the components exist: the
+registration net (lib/network_factory/voxel_morph.py), the segmentation net, Dice with soft targets
+(lib/loss.py:435-436), NCC / bending losses and the one-hot transform.  The step definitions below are the
+build's composition of those parts, identical to oracle/steps.py (reg_step / joint_step), which the GPU tests
+compare against:
+
+  reg phase (seg net frozen):  L = l_sim*NCC(warp(Im), It) + l_reg*Bending(disp) + l_anat*Dice(warp(onehot(Sm)), onehot(St))
+  seg phase (reg net frozen):  L = l_sp*Dice(S(Im), Sm) + l_anat*Dice(warp(softmax(S(Im)), phi.detach()), onehot(St))
+"""
+import torch
+
+from .. import ops, parallel
+from ..lib.loss import DiceLossMultiClass, NormalizedCrossCorrelationLoss, BendingEnergyLoss
+
+
+class RegistrationStep:
+    """One registration optimisation step: VoxelMorph forward -> NCC + lambda * bending -> backward -> Adam."""
+
+    def __init__(self, reg_model, optimizer, lam_reg=1.0):
+        self.model, self.opt, self.lam_reg = reg_model, optimizer, lam_reg
+        self.ncc, self.bend = NormalizedCrossCorrelationLoss(), BendingEnergyLoss()
+
+    def __call__(self, source, target):
+        self.model.train()
+        self.opt.zero_grad()
+        disp, warped, deform = self.model(source, target)
+        l_sim = self.ncc(warped, target)
+        l_reg = self.bend(disp)
+        loss = l_sim + self.lam_reg * l_reg
+        loss.backward()
+        parallel.allreduce_gradients(self.opt)
+        self.opt.step()
+        return loss.detach(), (disp.detach(), warped.detach(), deform.detach()), (l_sim.detach(), l_reg.detach())
+
+
+class DeepAtlasJointStep:
+    """Alternating joint step (one reg phase + one seg phase per image pair)."""
+
+    def __init__(self, seg_model, seg_opt, reg_model, reg_opt, n_classes,
+                 lam_sim=1.0, lam_reg=1.0, lam_anat=1.0, lam_sp=1.0):
+        self.seg, self.seg_opt, self.reg, self.reg_opt = seg_model, seg_opt, reg_model, reg_opt
+        self.n_classes = n_classes
+        self.lam = dict(sim=lam_sim, reg=lam_reg, anat=lam_anat, sp=lam_sp)
+        self.ncc, self.bend = NormalizedCrossCorrelationLoss(), BendingEnergyLoss()
+        self.dice_logits = DiceLossMultiClass(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+        self.dice_prob = DiceLossMultiClass(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)
+
+    def __call__(self, im_m, im_t, seg_m, seg_t):
+        lam = self.lam
+        onehot_m = ops.one_hot(seg_m.unsqueeze(1), self.n_classes)
+        onehot_t = ops.one_hot(seg_t.unsqueeze(1), self.n_classes)
+        # ---- registration phase (segmentation net not involved: the moving segmentation is given)
+        self.reg.train()
+        self.reg_opt.zero_grad()
+        disp, warped, deform = self.reg(im_m, im_t)
+        warped_seg, _ = ops.WarpFn.apply(onehot_m, disp)
+        l_sim = self.ncc(warped, im_t)
+        l_reg = self.bend(disp)
+        l_anat = self.dice_prob(warped_seg, onehot_t)
+        loss_r = lam['sim'] * l_sim + lam['reg'] * l_reg + lam['anat'] * l_anat
+        loss_r.backward()
+        parallel.allreduce_gradients(self.reg_opt)
+        self.reg_opt.step()
+        disp = disp.detach()
+        # ---- segmentation phase (deformation fixed)
+        self.seg.train()
+        self.seg_opt.zero_grad()
+        logits = self.seg(im_m)
+        l_sp = self.dice_logits(logits, seg_m)
+        prob = ops.SoftmaxFn.apply(logits)
+        warped_prob, _ = ops.WarpFn.apply(prob, disp)
+        l_anat2 = self.dice_prob(warped_prob, onehot_t)
+        loss_s = lam['sp'] * l_sp + lam['anat'] * l_anat2
+        loss_s.backward()
+        parallel.allreduce_gradients(self.seg_opt)
+        self.seg_opt.step()
+        return dict(loss_reg=loss_r.detach(), loss_seg=loss_s.detach(), sim=l_sim.detach(), bend=l_reg.detach(),
+                    anat_reg=l_anat.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach())
