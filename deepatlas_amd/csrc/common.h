@@ -64,3 +64,7 @@ __device__ __forceinline__ float da_act_grad(float z, float slope) {
     // derivative wrt pre-activation z; PyTorch: grad * (z > 0 ? 1 : slope)
     return (slope < 0.f) ? 1.f : (z > 0.f ? 1.f : slope);
 }
+
+// out[o] = sum_b partial[b][o] in double.  256 threads = 64 consecutive outputs x 4 slices of the partial list
+// (coalesced 256-byte rows, 4x shorter serial chains, O/64 workgroups), combined through LDS.
+int da_reduce_partials(const float* partial, int nparts, int O, float* out, hipStream_t st);

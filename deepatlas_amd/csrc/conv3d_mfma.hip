@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     constexpr int NIT = StageGeom<CK, HZ>::NIT;
     // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
     // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
-    constexpr int PRE = (NREP == 1) ? NIT : (NREP == 2 ? (NIT < 8 ? NIT : 8) : 0);
+    constexpr int PRE = (NREP == 1) ? NIT : (NREP == 2 ? (NIT < 6 ? NIT : 6) : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -195,32 +195,52 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         // B fragments are fetched one K-step ahead (global, L1/L2 resident); A fragments come from LDS per step.
         // MFMA order: component m outermost, M-tile r innermost -> 8*NREP independent accumulators between two uses
         // of the same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
-        // CK = 16: 3 x 9 K-steps (outer tap plane loop kept rolled: shorter scheduling regions, lower VGPR pressure);
-        // CK = 8: 14 K-steps, 2 x 7.
-        constexpr int SOUT = (CK == 16) ? 3 : 2, SIN = NSTEPS / SOUT;
+        // CK = 16: 3 x 9 K-steps (outer tap-plane loop kept rolled: shorter scheduling regions, lower VGPR pressure);
+        // CK = 8: 14 K-steps, 2 x 7.  Each K-step is split into two half-steps of 4 M-tiles; the A fragments of the
+        // NEXT half-step are read from LDS while the current half-step's 16*NREP MFMAs issue (a 2 x 4-fragment double
+        // buffer = the same 32 VGPRs one full step of fragments needs), so no ds_read latency is exposed.
+        constexpr int SOUT = (CK == 16) ? 3 : 2, SIN = NSTEPS / SOUT, HALF = TY / 2;
+        auto step_ptr = [&](int so, int si) -> const float* {
+            if (CK == 16) return abase + so * (HY * HX * CK) + a_off(si);
+            return abase + a_off8(so * SIN + si);
+        };
+        f32x4 A0[HALF], A1[HALF];
+        {
+            const float* ap = step_ptr(0, 0);
+#pragma unroll
+            for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
+        }
 #pragma unroll 1
         for (int so = 0; so < ((p.ablate & 8) ? 0 : SOUT); ++so) {
-            const float* abase_o = abase + ((CK == 16) ? so * (HY * HX * CK) : 0);
 #pragma unroll
             for (int si = 0; si < SIN; ++si) {
                 const int s = so * SIN + si;
                 int sn = s + 1; if (sn > NSTEPS - 1) sn = NSTEPS - 1;
-                f32x4 bnext[NREP], acur[TY];
+                f32x4 bnext[NREP];
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bnext[nn] = wch[((size_t)sn * p.NT + nn) * 64];
-                {
-                    // CK16: offset within the tap plane is compile-time (si); CK8: full offset from the (runtime) step
-                    const float* ap = (CK == 16) ? abase_o + a_off(si) : abase + a_off8(s);
+                const float* ap = step_ptr(so, si);
 #pragma unroll
-                    for (int r = 0; r < TY; ++r) acur[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
+                for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const f32x4*>(ap + (HALF + r) * (HX * CK));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                        for (int r = 0; r < HALF; ++r)
+                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bcur[nn][m], acc[r][nn], 0, 0, 0);
+                {   // first half of the next K-step (the last step re-reads its own, harmlessly)
+                    const float* an = (si + 1 < SIN) ? step_ptr(so, si + 1) : ((so + 1 < SOUT) ? step_ptr(so + 1, 0) : ap);
+#pragma unroll
+                    for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(an + r * (HX * CK));
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                        for (int r = 0; r < TY; ++r)
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[r][m], bcur[nn][m], acc[r][nn], 0, 0, 0);
+                        for (int r = 0; r < HALF; ++r)
+                            acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bcur[nn][m], acc[HALF + r][nn], 0, 0, 0);
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bcur[nn] = bnext[nn];
             }
@@ -729,8 +749,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         else DA_SC_CASE(7, 1); else DA_SC_CASE(7, 2); else return DA_ERR_UNSUPPORTED;
 #undef DA_SC_CASE
         DA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(da_grid(O, 256)), dim3(256), 0, st, sp.partial, nb, O, dw_tio);
-        DA_LAUNCH_CHECK();
+        { const int rc2 = da_reduce_partials(sp.partial, nb, O, dw_tio, st); if (rc2) return rc2; }
         return 0;
     }
     const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout);
@@ -749,7 +768,6 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     else if (q.CK == 8 && q.NREP == 1) rc = launch_wgrad_mfma<8, 1>(p, q, st);
     else if (q.CK == 8 && q.NREP == 2) rc = launch_wgrad_mfma<8, 2>(p, q, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(da_grid(p.O, 256)), dim3(256), 0, st, p.partial, q.nslabs, p.O, dw_tio);
-    DA_LAUNCH_CHECK();
+    { const int rc2 = da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st); if (rc2) return rc2; }
     return 0;
 }

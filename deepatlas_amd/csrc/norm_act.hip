@@ -158,30 +158,46 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ cm, float slope, int train,
                                         float* __restrict__ dx, long long nvec, int cq, int C) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq);
-        float xv[VEC], gv[VEC], o[VEC];
-        if (VEC == 4) {
-            const float4 t = reinterpret_cast<const float4*>(x)[i];
-            const float4 g = reinterpret_cast<const float4*>(dy)[i];
-            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-            gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
-        } else { xv[0] = x[i]; gv[0] = dy[i]; }
+    // UNR independent 16-byte load pairs in flight per lane (three streams: dy, x -> dx); the per-channel constants
+    // are L1-resident
+    constexpr int UNR = (VEC == 4) ? 4 : 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += stride * UNR) {
+        float xv[UNR][VEC], gv[UNR][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int c = q * VEC + j;
-            const float sc = scale[c];
-            const float z = xv[j] * sc + shift[c];
-            const float dz = gv[j] * da_act_grad(z, slope);
-            if (train) {
-                const float xh = (xv[j] - mean[c]) * rstd[c];
-                o[j] = sc * (dz - cm[c] - xh * cm[C + c]);
-            } else {
-                o[j] = sc * dz;
+        for (int u = 0; u < UNR; ++u) {
+            const long long i = i0 + u * stride;
+            if (i < nvec) {
+                if (VEC == 4) {
+                    const float4 t = reinterpret_cast<const float4*>(x)[i];
+                    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+                    xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                    gv[u][0] = g.x; gv[u][1] = g.y; gv[u][2] = g.z; gv[u][3] = g.w;
+                } else { xv[u][0] = x[i]; gv[u][0] = dy[i]; }
             }
         }
-        if (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
-        else dx[i] = o[0];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long i = i0 + u * stride;
+            if (i >= nvec) continue;
+            const int q = (int)(i % cq);
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = q * VEC + j;
+                const float sc = scale[c];
+                const float z = xv[u][j] * sc + shift[c];
+                const float dz = gv[u][j] * da_act_grad(z, slope);
+                if (train) {
+                    const float xh = (xv[u][j] - mean[c]) * rstd[c];
+                    o[j] = sc * (dz - cm[c] - xh * cm[C + c]);
+                } else {
+                    o[j] = sc * dz;
+                }
+            }
+            if (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+            else dx[i] = o[0];
+        }
     }
 }
 

@@ -40,6 +40,27 @@ __global__ void tio_to_w_kernel(const float* __restrict__ src, float* __restrict
 
 }  // namespace
 
+__global__ void __launch_bounds__(256) da_reduce_partials_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
+    __shared__ double sh[4][64];
+    const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol;
+    double s0 = 0.0, s1 = 0.0;
+    if (o < O) {
+        int b = sl;
+        for (; b + 4 < nparts; b += 8) { s0 += (double)partial[(size_t)b * O + o]; s1 += (double)partial[(size_t)(b + 4) * O + o]; }
+        for (; b < nparts; b += 4) s0 += (double)partial[(size_t)b * O + o];
+    }
+    sh[sl][ol] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && o < O) out[o] = (float)(sh[0][ol] + sh[1][ol] + sh[2][ol] + sh[3][ol]);
+}
+
+int da_reduce_partials(const float* partial, int nparts, int O, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(da_reduce_partials_kernel, dim3((O + 63) / 64), dim3(256), 0, st, partial, nparts, O, out);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int da_version(void) { return 100; }
 
 extern "C" int da_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len) {

@@ -192,6 +192,14 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
 
     const long long v0 = ((long long)blockIdx.x * 4 + wave) * p.vox_per_wave;
     long long v1 = v0 + p.vox_per_wave; if (v1 > p.M) v1 = p.M;
+    // this lane's voxel (v0 + g, then += 4 per K-step) is tracked as (w, h, rest = n*D + d) with carries instead of
+    // three 64-bit divisions per step; fine-grid voxel = ((rest*2)*2H + 2h)*2W + 2w
+    int cw = 0, chh = 0; long long crest = 0;
+    if (p.up) {
+        const long long vs = v0 + g;
+        cw = (int)(vs % p.W); const long long r1 = vs / p.W;
+        chh = (int)(r1 % p.H); crest = r1 / p.H;
+    }
 #pragma unroll 2
     for (long long vb = v0; vb < v1; vb += 4) {
         const long long v = vb + g;
@@ -200,7 +208,13 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
         float av[CIT];
 #pragma unroll
         for (int a = 0; a < CIT; ++a) av[a] = ok ? p.in[vv * p.Cin + 16 * a + i] : 0.f;
-        const long long fv = p.up ? fine0(vv, p.D, p.H, p.W) : vv;
+        long long fv = vv;
+        if (p.up) {
+            fv = ((crest * 2) * (2 * p.H) + 2 * chh) * (long long)(2 * p.W) + 2 * cw;
+            cw += 4;
+            while (cw >= p.W) { cw -= p.W; if (++chh >= p.H) { chh = 0; ++crest; } }
+            if (!ok) fv = 0;
+        }
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
             float bv[COT];
@@ -293,7 +307,7 @@ int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias
 }
 
 static int wg_blocks(long long M, size_t O, long long* vox_per_wave) {
-    long long blocks = 1024;
+    long long blocks = 1024;                      // 4 workgroups per CU (accumulators <= 128 VGPRs)
     const long long cap = (long long)((64ull << 20) / (O * 4)); if (blocks > cap) blocks = cap < 1 ? 1 : cap;
     long long vpw = da_cdiv(M, blocks * 4);
     vpw = da_cdiv(vpw, 4) * 4;
@@ -370,7 +384,6 @@ int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D,
     }
 #undef DA_WG_CASE
     if (rc) return rc;
-    hipLaunchKernelGGL(pw_reduce_kernel, dim3(da_grid((long long)O, 256)), dim3(256), 0, st, p.partial, nb, (int)O, dw);
-    DA_LAUNCH_CHECK();
+    { const int rc2 = da_reduce_partials(p.partial, nb, (int)O, dw, st); if (rc2) return rc2; }
     return 0;
 }
