@@ -122,17 +122,23 @@ template <int VEC>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                   const float* __restrict__ shift, float slope, float* __restrict__ y,
                                   long long nvec, int cq) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq);
+    // cq divides the block size for every channel count on the path (C/4 in {1,2,4,8,16}), so a thread always sees
+    // the same channel quad: its constants are loaded once into registers
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool fixed_q = (VEC == 4) && (stride % cq == 0);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sf = sc;
+    if (fixed_q) { const int q = (int)(i0 % cq); sc = reinterpret_cast<const float4*>(scale)[q]; sf = reinterpret_cast<const float4*>(shift)[q]; }
+    for (long long i = i0; i < nvec; i += stride) {
         if (VEC == 4) {
+            if (!fixed_q) { const int q = (int)(i % cq); sc = reinterpret_cast<const float4*>(scale)[q]; sf = reinterpret_cast<const float4*>(shift)[q]; }
             const float4 t = reinterpret_cast<const float4*>(x)[i];
-            const float4 sc = reinterpret_cast<const float4*>(scale)[q];
-            const float4 sf = reinterpret_cast<const float4*>(shift)[q];
             float4 o;
             o.x = da_act(t.x * sc.x + sf.x, slope); o.y = da_act(t.y * sc.y + sf.y, slope);
             o.z = da_act(t.z * sc.z + sf.z, slope); o.w = da_act(t.w * sc.w + sf.w, slope);
             reinterpret_cast<float4*>(y)[i] = o;
         } else {
+            const int q = (int)(i % cq);
             y[i] = da_act(x[i] * scale[q] + shift[q], slope);
         }
     }
@@ -158,11 +164,22 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ cm, float slope, int train,
                                         float* __restrict__ dx, long long nvec, int cq, int C) {
-    // UNR independent 16-byte load pairs in flight per lane (three streams: dy, x -> dx); the per-channel constants
-    // are L1-resident
-    constexpr int UNR = (VEC == 4) ? 4 : 1;
+    // Three 16-byte streams (dy, x -> dx).  The six per-channel constants of this thread's channel quad are hoisted
+    // into registers (the grid stride is a multiple of cq, so the quad never changes); UNR load pairs in flight.
+    constexpr int UNR = (VEC == 4) ? 2 : 1;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += stride * UNR) {
+    const long long i00 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool fixed_q = (stride % cq == 0);
+    float k_sc[VEC], k_sf[VEC], k_mu[VEC], k_rs[VEC], k_c1[VEC], k_c2[VEC];
+    auto load_consts = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = q * VEC + j;
+            k_sc[j] = scale[c]; k_sf[j] = shift[c]; k_mu[j] = mean[c]; k_rs[j] = rstd[c]; k_c1[j] = cm[c]; k_c2[j] = cm[C + c];
+        }
+    };
+    if (fixed_q) load_consts((int)(i00 % cq));
+    for (long long i0 = i00; i0 < nvec; i0 += stride * UNR) {
         float xv[UNR][VEC], gv[UNR][VEC];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -180,19 +197,17 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
         for (int u = 0; u < UNR; ++u) {
             const long long i = i0 + u * stride;
             if (i >= nvec) continue;
-            const int q = (int)(i % cq);
+            if (!fixed_q) load_consts((int)(i % cq));
             float o[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const int c = q * VEC + j;
-                const float sc = scale[c];
-                const float z = xv[u][j] * sc + shift[c];
+                const float z = xv[u][j] * k_sc[j] + k_sf[j];
                 const float dz = gv[u][j] * da_act_grad(z, slope);
                 if (train) {
-                    const float xh = (xv[u][j] - mean[c]) * rstd[c];
-                    o[j] = sc * (dz - cm[c] - xh * cm[C + c]);
+                    const float xh = (xv[u][j] - k_mu[j]) * k_rs[j];
+                    o[j] = k_sc[j] * (dz - k_c1[j] - xh * k_c2[j]);
                 } else {
-                    o[j] = sc * dz;
+                    o[j] = k_sc[j] * dz;
                 }
             }
             if (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
