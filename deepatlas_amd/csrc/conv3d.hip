@@ -251,6 +251,7 @@ extern "C" size_t da_conv3d_k3_ws_bytes(int N, int D, int H, int W, int Cin, int
     const size_t parts = wgrad_direct_parts((long long)N * Do * Ho, O, &rpb);
     size_t direct = da_align(parts * (size_t)O * sizeof(float));
     size_t mfma = da_conv3_mfma_ws_bytes(N, D, H, W, Cin, Cout, stride);
+    if (stride == 2 && da_conv3_s2_supported(Cin, 0, Cout)) mfma = da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout);
     size_t packed = da_align((size_t)2 * O * sizeof(float) + 65536);
     const int Cm = Cin > Cout ? Cin : Cout;
     return packed + (direct > mfma ? direct : mfma) + da_bn_ws_bytes(0, Cm) + 4096;
@@ -270,6 +271,10 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
     if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
         return DA_ERR_BADARG;
     hipStream_t st = da_stream(stream);
+    if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout)) {
+        if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+        return da_conv3_s2_fwd(in1, C1, w_tio, bias, out, N, D, H, W, Cout, act_slope, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
+    }
     if (!force_direct() && da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) {
         if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
         return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
@@ -296,6 +301,8 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
         DA_LAUNCH_CHECK();
         return da_conv3_direct_fwd(dy, Cout, nullptr, 0, wf, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, 1, -1.f, st);
     }
+    if (!force_direct() && da_conv3_s2_supported(C1, C2, Cout))
+        return da_conv3_s2_dgrad(dy, w_tio, dx1, C1, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
     const int Do = (D - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long nvox = (long long)N * D * H * W;
     hipLaunchKernelGGL((conv3_s2_dgrad_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256), (unsigned)da_cdiv(Cin, 16)), dim3(256), 0, st,
@@ -315,7 +322,9 @@ extern "C" int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, in
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const int O = 27 * Cin * Cout;
     int rc = 0;
-    if (!force_direct() && da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) {
+    if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout)) {
+        rc = da_conv3_s2_wgrad(in1, C1, dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
+    } else if (!force_direct() && da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) {
         rc = da_conv3_mfma_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, st);
     } else {
         int rpb;

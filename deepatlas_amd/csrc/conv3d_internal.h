@@ -13,12 +13,22 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0);
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st);
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0);
 
 int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         float* out1, int Cs1, float* out2, int Cs2,
                         int N, int D, int H, int W, int Cout, int stride, float slope, hipStream_t st);
+
+// stride-2 via space-to-depth + tap-masked stride-1 MFMA kernels (conv3d_s2.hip)
+bool da_conv3_s2_supported(int C1, int C2, int Cout);
+size_t da_conv3_s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
+                    int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st);
+int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, int N, int D, int H, int W, int Cout,
+                      void* ws, size_t ws_bytes, hipStream_t st);
+int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
+                      void* ws, size_t ws_bytes, hipStream_t st);

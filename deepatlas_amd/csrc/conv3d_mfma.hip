@@ -98,10 +98,11 @@ struct FwdP {
     float* out1; float* out2; int Cs1, Cs2;
     int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles, tiles_per_block;
     float slope;
+    unsigned masks[16]; int maskmode;   // tap masks (stride-2 via space-to-depth): 0 none, 1 per channel chunk, 2 per blockIdx.y
     int ablate;      // diagnostic only (env DA_ABLATE): 1 skip staging loads, 2 skip epilogue stores, 4 skip LDS writes+barriers, 8 skip MFMAs
 };
 
-template <int CK, int NREP>
+template <int CK, int NREP, bool MASKED = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth), own instantiation
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 4, HZ = TZ + 2;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     constexpr int NIT = StageGeom<CK, HZ>::NIT;
     // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
     // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
-    constexpr int PRE = (NREP == 1) ? NIT : (NREP == 2 ? (NIT < 6 ? NIT : 6) : 0);
+    constexpr int PRE = MASKED ? (NREP == 1 ? NIT : 4) : ((NREP == 1) ? NIT : (NREP == 2 ? (NIT < 6 ? NIT : 6) : 0));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -195,6 +196,27 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         // B fragments are fetched one K-step ahead (global, L1/L2 resident); A fragments come from LDS per step.
         // MFMA order: component m outermost, M-tile r innermost -> 8*NREP independent accumulators between two uses
         // of the same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
+        if constexpr (MASKED) {
+            // sparse tap set (a stride-2 conv expressed as a stride-1 conv over the space-to-depth input: a channel chunk
+            // belongs to one input parity and only (1|2)^3 of the 27 taps are non-zero).  Staging-bound, so a plain loop.
+            unsigned msk = p.masks[p.maskmode == 1 ? ch : (int)blockIdx.y];
+            while (msk) {
+                const int sidx = __builtin_ctz(msk); msk &= msk - 1;
+                const float* ap = abase + (((sidx / 9) * HY + (sidx / 3) % 3) * HX + sidx % 3) * CK;
+                f32x4 bb[NREP], aa[TY];
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn) bb[nn] = wch[((size_t)sidx * p.NT + nn) * 64];
+#pragma unroll
+                for (int r = 0; r < TY; ++r) aa[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                        for (int r = 0; r < TY; ++r)
+                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r][m], bb[nn][m], acc[r][nn], 0, 0, 0);
+            }
+        } else {
         // CK = 16: 3 x 9 K-steps (outer tap-plane loop kept rolled: shorter scheduling regions, lower VGPR pressure);
         // CK = 8: 14 K-steps, 2 x 7.  Each K-step is split into two half-steps of 4 M-tiles; the A fragments of the
         // NEXT half-step are read from LDS while the current half-step's 16*NREP MFMAs issue (a 2 x 4-fragment double
@@ -244,6 +266,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bcur[nn] = bnext[nn];
             }
+        }
         }
 
         if (ch == nchunks - 1 && !(p.ablate & 2)) {
@@ -344,6 +367,7 @@ struct WgP {
     const float* in1; const float* in2; int C1, C2;
     const float* dy; float* partial;
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, tiles_per_slab, O;
+    unsigned masks[16]; int maskmode;   // per channel chunk tap masks (0 = all taps)
 };
 
 template <int CK, int NREP, bool YS = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv)
@@ -377,6 +401,13 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     for (int k = 0; k < TPW; ++k)
 #pragma unroll
         for (int nn = 0; nn < NREP; ++nn) acc[k][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // sparse tap sets (stride-2 via space-to-depth): this wave's tap slot k is live iff its tap is in the chunk's mask
+    bool live[TPW];
+    {
+        const unsigned msk = (CK == 16 && p.maskmode != 0) ? p.masks[ch] : 0x7FFFFFFu;
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) live[k] = (CK != 16) || (((msk >> (wave + 4 * k)) & 1u) != 0 && wave + 4 * k < 27);
+    }
 
     const int tile_begin = blockIdx.x * p.tiles_per_slab;
     int tile_end = tile_begin + p.tiles_per_slab; if (tile_end > p.ntiles) tile_end = p.ntiles;
@@ -452,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 #pragma unroll
             for (int nn = 0; nn < NREP; ++nn) b0[nn] = yrow[(nn * 16) ^ swz];
 #pragma unroll
-            for (int k = 0; k < TPW; ++k) a0[k] = arow[offA[k]];
+            for (int k = 0; k < TPW; ++k) a0[k] = live[k] ? arow[offA[k]] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float a1[TPW], b1[NREP];
@@ -460,13 +491,15 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 #pragma unroll
                     for (int nn = 0; nn < NREP; ++nn) b1[nn] = yrow[(j + 1) * 4 * CG + ((nn * 16) ^ swz)];
 #pragma unroll
-                    for (int k = 0; k < TPW; ++k) a1[k] = arow[(j + 1) * 4 * CK + offA[k]];
+                    for (int k = 0; k < TPW; ++k) a1[k] = live[k] ? arow[(j + 1) * 4 * CK + offA[k]] : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < TPW; ++k)
+                    if (live[k]) {
 #pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn)
-                        acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b0[nn], acc[k][nn], 0, 0, 0);
+                        for (int nn = 0; nn < NREP; ++nn)
+                            acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b0[nn], acc[k][nn], 0, 0, 0);
+                    }
                 if (j < 3) {
 #pragma unroll
                     for (int k = 0; k < TPW; ++k) a0[k] = a1[k];
@@ -599,6 +632,27 @@ __global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
     }
 }
 
+// Tap masks of the stride-1 conv over the space-to-depth tensor (channel = parity*Cin + ci, parity = (rz*2+ry)*2+rx).
+// Along an axis an even-parity (r=0) sub-volume only meets the original centre tap (offset index 1); an odd one meets
+// taps 0 and 2 at offset indices 0 and 1.  groups[g] covers channels [g*gsize, (g+1)*gsize); flipped: bit 26 - t.
+static void da_s2d_masks(unsigned* masks, int ngroups, int gsize, int cin, int flipped) {
+    for (int g = 0; g < 16; ++g) masks[g] = 0;
+    for (int g = 0; g < ngroups && g < 16; ++g) {
+        const int r0 = (g * gsize) / cin, r1 = ((g + 1) * gsize - 1) / cin;
+        unsigned m = 0;
+        for (int r = r0; r <= r1 && r < 8; ++r) {
+            const int rz = (r >> 2) & 1, ry = (r >> 1) & 1, rx = r & 1;
+            for (int oz = (rz ? 0 : 1); oz <= 1; ++oz)
+                for (int oy = (ry ? 0 : 1); oy <= 1; ++oy)
+                    for (int ox = (rx ? 0 : 1); ox <= 1; ++ox) {
+                        const int t = (oz * 3 + oy) * 3 + ox;
+                        m |= 1u << (flipped ? 26 - t : t);
+                    }
+        }
+        masks[g] = m;
+    }
+}
+
 static int pick_ck(int C1, int C2) {
     const int Cin = C1 + C2;
     if (Cin % 16 == 0 && C1 % 16 == 0) return 16;
@@ -658,10 +712,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride) {
     return true;
 }
 
-template <int CK, int NREP>
+template <int CK, int NREP, bool MASKED = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * sizeof(float);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP>;
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -676,7 +730,7 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin) {
     (void)stride;
     const int Cin = C1 + C2;
     const int CK = pick_ck(C1, C2);
@@ -696,10 +750,22 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.NT = NTpad;
     p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx; p.slope = slope;
+    p.maskmode = 0;
+    if (s2d_cin > 0) {
+        if (CK != 16) return DA_ERR_UNSUPPORTED;
+        if (!w_is_flipped_tr) { p.maskmode = 1; da_s2d_masks(p.masks, Cin / 16, 16, s2d_cin, 0); }
+        else { p.maskmode = 2; da_s2d_masks(p.masks, gy, NREP * 16, s2d_cin, 1); }
+    }
     { static int abl = -1; if (abl < 0) { const char* e = getenv("DA_ABLATE"); abl = e ? atoi(e) : 0; } p.ablate = abl; }
     {   // one resident round: 2 workgroups per CU x 256 CUs, split over the cout groups
-        int nblk = 512 / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
+        static int nres = -1; if (nres < 0) { const char* e = getenv("DA_FWD_BLOCKS"); nres = e ? atoi(e) : 512; }
+        int nblk = nres / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
         p.tiles_per_block = (p.ntiles + nblk - 1) / nblk;
+    }
+    if (p.maskmode != 0) {
+        if (NREP == 1) return launch_fwd_mfma<16, 1, true>(p, gy, st);
+        if (NREP == 2) return launch_fwd_mfma<16, 2, true>(p, gy, st);
+        return DA_ERR_UNSUPPORTED;
     }
 #define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return launch_fwd_mfma<ck, nr>(p, gy, st)
     DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3); DA_FWD_CASE(16, 4);
@@ -735,7 +801,7 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
 }
 
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin) {
     if (smallcin_ok(C1, C2, Cout, stride)) {
         const int Cin = C1 + C2, O = 27 * Cin * Cout;
         if (ws_bytes < (size_t)kScBlocks * O * sizeof(float)) return DA_ERR_WS_SMALL;
@@ -760,6 +826,11 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout;
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles; p.tiles_per_slab = q.tps;
     p.O = 27 * (C1 + C2) * Cout;
+    p.maskmode = 0;
+    if (s2d_cin > 0) {
+        if (q.CK != 16) return DA_ERR_UNSUPPORTED;
+        p.maskmode = 1; da_s2d_masks(p.masks, q.nchunks, 16, s2d_cin, 0);
+    }
     int rc = DA_ERR_UNSUPPORTED;
     if (Cout % 4 != 0 && q.CK == 16) rc = launch_wgrad_mfma<16, 1, true>(p, q, st);
     else if (Cout % 4 != 0 && q.CK == 8) rc = launch_wgrad_mfma<8, 1, true>(p, q, st);
