@@ -21,6 +21,9 @@
 #include "conv3d_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef DA_PIN
+#define DA_PIN 1   // pin the m-outer MFMA order (keeps hipcc from chaining 4 dependent MFMAs on one accumulator)
+#endif
 
 namespace {
 
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     constexpr int NIT = StageGeom<CK, HZ>::NIT;
     // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
     // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
-    constexpr int PRE = MASKED ? (NREP == 1 ? NIT : 4) : ((NREP == 1) ? NIT : (NREP == 2 ? (NIT < 6 ? NIT : 6) : 0));
+    constexpr int PRE = MASKED ? (NREP == 1 ? NIT : 4) : ((NREP <= 2) ? NIT : (NREP == 3 ? (NIT < 4 ? NIT : 4) : 0));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -245,24 +248,28 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                 for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const f32x4*>(ap + (HALF + r) * (HX * CK));
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
 #pragma unroll
                     for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                         for (int r = 0; r < HALF; ++r)
                             acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bcur[nn][m], acc[r][nn], 0, 0, 0);
+                    if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
+                }
                 {   // first half of the next K-step (the last step re-reads its own, harmlessly)
                     const float* an = (si + 1 < SIN) ? step_ptr(so, si + 1) : ((so + 1 < SOUT) ? step_ptr(so + 1, 0) : ap);
 #pragma unroll
                     for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(an + r * (HX * CK));
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
 #pragma unroll
                     for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                         for (int r = 0; r < HALF; ++r)
                             acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bcur[nn][m], acc[HALF + r][nn], 0, 0, 0);
+                    if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bcur[nn] = bnext[nn];
             }
@@ -662,7 +669,7 @@ static int pick_ck(int C1, int C2) {
 // N-tiles per workgroup: <= 2, so that 8*NREP*4 accumulators + fragments + the register-parked staging prefetch stay
 // under 256 VGPRs (two workgroups per CU); more couts go to blockIdx.y (the input tile is re-staged per group, which the
 // one-item-ahead prefetch hides).
-static int pick_nrep(int NT) { return NT <= 2 ? NT : (NT % 2 == 0 ? 2 : 1); }
+static int pick_nrep(int NT) { return NT <= 3 ? NT : (NT % 2 == 0 ? 2 : (NT % 3 == 0 ? 3 : 2)); }
 
 static size_t packed_bytes(int Cin, int Cout, int CK) {
     const int NT = (Cout + 15) / 16, NREP = pick_nrep(NT);

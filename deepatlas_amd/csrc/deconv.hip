@@ -244,10 +244,10 @@ extern "C" int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_
     const int O = 8 * Cin * Cout;
     const int parts = parts_for((long long)N * D * H * W, O, &per);
     const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
-    if (da_pw_supported(Cin, Cout)) {
-        int rc = da_pw_wgrad(in, dy, dw_tio, (long long)N * D * H * W, D, H, W, Cin, Cout, 8, 1, ws, cs_off, st);
-        if (rc) return rc;
-    } else {
+    int rc_pw = DA_ERR_UNSUPPORTED;
+    if (da_pw_supported(Cin, Cout)) rc_pw = da_pw_wgrad(in, dy, dw_tio, (long long)N * D * H * W, D, H, W, Cin, Cout, 8, 1, ws, cs_off, st);
+    if (rc_pw != 0 && rc_pw != DA_ERR_UNSUPPORTED) return rc_pw;
+    if (rc_pw == DA_ERR_UNSUPPORTED) {          // odd channel counts, or tensors beyond 32-bit byte offsets
         float* partial = (float*)ws;
         hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel, dim3(parts), dim3(256), 0, st, in, dy, partial, N, D, H, W, Cin, Cout, per);
         DA_LAUNCH_CHECK();
@@ -302,10 +302,10 @@ extern "C" int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, 
     long long per;
     const int parts = parts_for(da_cdiv(M, kWgR), O, &per);
     const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
-    if (da_pw_supported(Cin, Cout)) {
-        int rc = da_pw_wgrad(in, dy, dw_io, M, 1, 1, 1, Cin, Cout, 1, 0, ws, cs_off, st);
-        if (rc) return rc;
-    } else {
+    int rc_pw = DA_ERR_UNSUPPORTED;
+    if (da_pw_supported(Cin, Cout)) rc_pw = da_pw_wgrad(in, dy, dw_io, M, 1, 1, 1, Cin, Cout, 1, 0, ws, cs_off, st);
+    if (rc_pw != 0 && rc_pw != DA_ERR_UNSUPPORTED) return rc_pw;
+    if (rc_pw == DA_ERR_UNSUPPORTED) {
         float* partial = (float*)ws;
         hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(parts), dim3(256), (size_t)kWgR * (Cin + Cout) * sizeof(float), st, in, dy, partial, M, Cin, Cout, per * kWgR);
         DA_LAUNCH_CHECK();

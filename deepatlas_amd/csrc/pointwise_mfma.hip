@@ -192,40 +192,63 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
 
     const long long v0 = ((long long)blockIdx.x * 4 + wave) * p.vox_per_wave;
     long long v1 = v0 + p.vox_per_wave; if (v1 > p.M) v1 = p.M;
-    // this lane's voxel (v0 + g, then += 4 per K-step) is tracked as (w, h, rest = n*D + d) with carries instead of
-    // three 64-bit divisions per step; fine-grid voxel = ((rest*2)*2H + 2h)*2W + 2w
+    // Branch-free operand fetch: both tensors are addressed through buffer descriptors with 32-bit byte offsets; a lane
+    // past the end gets offset 0xFFFFFFFF (hardware returns 0).  All CIT + TPB*COT loads of a K-step are issued back to
+    // back and the NEXT step's loads are in flight while the current step's MFMAs issue (hipcc otherwise emits
+    // load -> s_waitcnt vmcnt(0) -> 4 MFMAs per tap, i.e. eight exposed memory round trips per step).
+    const unsigned fine_mult = p.up ? 8u : 1u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((unsigned long long)p.M * p.Cin * 4ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)((unsigned long long)p.M * fine_mult * p.Cout * 4ull), 0x00020000);
+    // this lane's voxel (v0 + g, then += 4 per K-step) tracked as (w, h, rest = n*D + d) with carries
     int cw = 0, chh = 0; long long crest = 0;
     if (p.up) {
         const long long vs = v0 + g;
         cw = (int)(vs % p.W); const long long r1 = vs / p.W;
         chh = (int)(r1 % p.H); crest = r1 / p.H;
     }
-#pragma unroll 2
-    for (long long vb = v0; vb < v1; vb += 4) {
+    unsigned toffb[TPB];
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) toffb[t] = (unsigned)(toffs[t] * p.Cout * 4);
+    auto fetch = [&](long long vb, float* av, float (*bv)[COT]) {
         const long long v = vb + g;
         const bool ok = v < v1;
-        const long long vv = ok ? v : v0;
-        float av[CIT];
+        const unsigned offa = ok ? (unsigned)((v * p.Cin + i) * 4) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int a = 0; a < CIT; ++a) av[a] = ok ? p.in[vv * p.Cin + 16 * a + i] : 0.f;
-        long long fv = vv;
+        for (int a = 0; a < CIT; ++a)
+            av[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? offa + 64u * a : 0xFFFFFFFFu, 0, 0));
+        long long fv = v;
         if (p.up) {
             fv = ((crest * 2) * (2 * p.H) + 2 * chh) * (long long)(2 * p.W) + 2 * cw;
             cw += 4;
             while (cw >= p.W) { cw -= p.W; if (++chh >= p.H) { chh = 0; ++crest; } }
-            if (!ok) fv = 0;
         }
+        const unsigned offb = (unsigned)((fv * p.Cout + i) * 4);
 #pragma unroll
-        for (int t = 0; t < TPB; ++t) {
-            float bv[COT];
+        for (int t = 0; t < TPB; ++t)
 #pragma unroll
-            for (int c = 0; c < COT; ++c) bv[c] = ok ? p.dy[(fv + toffs[t]) * p.Cout + 16 * c + i] : 0.f;
+            for (int c = 0; c < COT; ++c)
+                bv[t][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ok ? offb + toffb[t] + 64u * c : 0xFFFFFFFFu, 0, 0));
+    };
+    float avA[CIT], bvA[TPB][COT], avB[CIT], bvB[TPB][COT];
+    if (v0 < v1) fetch(v0, avA, bvA);
+#pragma unroll 1
+    for (long long vb = v0; vb < v1; vb += 8) {
+        fetch(vb + 4, avB, bvB);                    // past-the-end steps fetch zeros
+#pragma unroll
+        for (int t = 0; t < TPB; ++t)
 #pragma unroll
             for (int a = 0; a < CIT; ++a)
 #pragma unroll
                 for (int c = 0; c < COT; ++c)
-                    acc[a][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[c], acc[a][t][c], 0, 0, 0);
-        }
+                    acc[a][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[a], bvA[t][c], acc[a][t][c], 0, 0, 0);
+        fetch(vb + 8, avA, bvA);
+#pragma unroll
+        for (int t = 0; t < TPB; ++t)
+#pragma unroll
+            for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+                    acc[a][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[a], bvB[t][c], acc[a][t][c], 0, 0, 0);
     }
     // reduce the four waves through LDS, then write the block partial
     constexpr int NACC = CIT * TPB * COT;
@@ -341,6 +364,7 @@ static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
                 int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!da_pw_supported(Cin, Cout) || (ntaps != 1 && ntaps != 8)) return DA_ERR_UNSUPPORTED;
+    if ((unsigned long long)M * (up ? 8 : 1) * Cout * 4ull >= 0xFFFFFFF0ull || (unsigned long long)M * Cin * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_pw_wgrad_ws_bytes(M, ntaps, Cin, Cout)) return DA_ERR_WS_SMALL;
     PwWgP p;
     p.in = in; p.dy = dy; p.partial = (float*)ws; p.M = M; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntaps = ntaps; p.up = up;
