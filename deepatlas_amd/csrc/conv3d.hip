@@ -113,6 +113,63 @@ conv3_direct_fwd_kernel(const float* __restrict__ in1, int C1, const float* __re
     }
 }
 
+// Forward for Cin <= 2 (seg enc0.0: 1 -> 8, reg enc0: (source, target) -> 16): HBM-bound, 27*Cin input taps per voxel.
+// All taps are fetched through buffer descriptors (out-of-volume tap -> offset 0xFFFFFFFF -> 0) before any FMA, so the
+// loads issue back to back instead of one exec-mask branch + wait per tap; weights come through scalar loads.
+template <int CT>
+__global__ void __launch_bounds__(256)
+conv3_tinycin_fwd_kernel(const float* __restrict__ in1, int C1, const float* __restrict__ in2, int C2,
+                         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                         int N, int D, int H, int W, int Cout, float slope) {
+    const long long nvox = (long long)N * D * H * W;
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = v < nvox;
+    const long long vv = live ? v : 0;
+    long long r = vv;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D); const int n = (int)(r / D);
+    const int Cin = C1 + C2;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)in1, 0, (unsigned)((unsigned long long)nvox * C1 * 4ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(C2 > 0 ? in2 : in1), 0, (unsigned)((unsigned long long)nvox * (C2 > 0 ? C2 : C1) * 4ull), 0x00020000);
+    float xin[27][2];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xx = x + tap % 3 - 1;
+        const bool inb = live && (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const unsigned vox = (unsigned)(((n * D + zz) * H + yy) * W + xx);
+        if (C2 > 0) {          // one channel from each pointer
+            xin[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, inb ? vox * 4u : 0xFFFFFFFFu, 0, 0));
+            xin[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, inb ? vox * 4u : 0xFFFFFFFFu, 0, 0));
+        } else if (C1 == 2) {
+            xin[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, inb ? vox * 8u : 0xFFFFFFFFu, 0, 0));
+            xin[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, inb ? vox * 8u + 4u : 0xFFFFFFFFu, 0, 0));
+        } else {
+            xin[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, inb ? vox * 4u : 0xFFFFFFFFu, 0, 0));
+            xin[tap][1] = 0.f;
+        }
+    }
+    float acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = (bias && j < Cout) ? bias[j] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const float* wt = w + (size_t)tap * Cin * Cout;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if (j < Cout) {
+                acc[j] += xin[tap][0] * wt[j];
+                if (Cin == 2) acc[j] += xin[tap][1] * wt[Cout + j];
+            }
+        }
+    }
+    if (!live) return;
+    float* o = out + v * Cout;
+#pragma unroll
+    for (int j = 0; j < CT; j += 4)
+        if (j + 3 < Cout) *reinterpret_cast<float4*>(o + j) = make_float4(da_act(acc[j], slope), da_act(acc[j + 1], slope), da_act(acc[j + 2], slope), da_act(acc[j + 3], slope));
+}
+
 // w_tio [27][Cin][Cout] -> flipped + transposed [27][Cout][Cin]: stride-1 dgrad is a forward conv with it.
 __global__ void w_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cin, int Cout) {
     const int total = 27 * Cin * Cout;
@@ -280,6 +337,16 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
         return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
                                  N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
     }
+    // tiny Cin, full-quad Cout, single output pointer, 32-bit addressable
+    const bool tiny = !force_direct() && stride == 1 && ((C2 == 0 && (C1 == 1 || C1 == 2)) || (C1 == 1 && C2 == 1)) && (Cout == 8 || Cout == 16) &&
+                      (unsigned long long)N * D * H * W * 2ull * 4ull < 0xFFFFFFF0ull;
+    if (tiny) {
+        const long long nvox = (long long)N * D * H * W;
+        if (Cout == 8) hipLaunchKernelGGL((conv3_tinycin_fwd_kernel<8>), dim3((unsigned)da_cdiv(nvox, 256)), dim3(256), 0, st, in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, act_slope);
+        else hipLaunchKernelGGL((conv3_tinycin_fwd_kernel<16>), dim3((unsigned)da_cdiv(nvox, 256)), dim3(256), 0, st, in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, act_slope);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     return da_conv3_direct_fwd(in1, C1, in2, C2, w_tio, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, stride, act_slope, st);
 }
 
@@ -327,6 +394,10 @@ extern "C" int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, in
     } else if (!force_direct() && da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) {
         rc = da_conv3_mfma_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, st);
     } else {
+        rc = DA_ERR_UNSUPPORTED;
+    }
+    if (rc == DA_ERR_UNSUPPORTED) {
+        rc = 0;
         int rpb;
         const size_t parts = wgrad_direct_parts((long long)N * Do * Ho, O, &rpb);
         float* partial = (float*)ws;

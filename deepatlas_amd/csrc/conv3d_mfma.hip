@@ -583,30 +583,53 @@ __global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Operands come through buffer descriptors with 32-bit byte offsets (out-of-range lane -> 0xFFFFFFFF -> 0): no
+    // exec-mask branches, so the MT + NT loads of a K-step issue back to back, and the next step's loads are in flight
+    // while this step's MFMAs issue.
+    const unsigned long long vol = (unsigned long long)p.N * p.D * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t r1 = da_rsrc(p.in1, (unsigned)(vol * p.C1 * 4ull));
+    const __amdgpu_buffer_rsrc_t r2 = da_rsrc(p.C2 > 0 ? p.in2 : p.in1, (unsigned)(vol * (p.C2 > 0 ? p.C2 : p.C1) * 4ull));
+    const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy, (unsigned)(vol * p.Cout * 4ull));
+    bool from2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) from2[mt] = (src[mt] == p.in2) && p.C2 > 0;
     const long long wave_id = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
     for (long long row = wave_id; row < p.nrows; row += nwaves) {
         const int y = (int)(row % p.H); const int z = (int)((row / p.H) % p.D); const int n = (int)(row / ((long long)p.H * p.D));
-        long long rbase[MT]; bool rval[MT];
+        unsigned rbase[MT]; bool rval[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int zz = z + dz[mt], yy = y + dy_[mt];
             rval[mt] = mval[mt] && zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
-            rbase[mt] = ((((long long)n * p.D + (rval[mt] ? zz : 0)) * p.H + (rval[mt] ? yy : 0)) * p.W) * cs[mt] + cc[mt];
+            rbase[mt] = (unsigned)((((((long long)n * p.D + (rval[mt] ? zz : 0)) * p.H + (rval[mt] ? yy : 0)) * p.W) * cs[mt] + cc[mt]) * 4);
         }
-        const float* grow = p.dy + (row * p.W) * p.Cout;
-#pragma unroll 2
-        for (int x0 = 0; x0 < p.W; x0 += 4) {
+        const unsigned gbase = (unsigned)((row * p.W) * p.Cout * 4);
+        auto fetch = [&](int x0, float* a, float* b) {
             const int x = x0 + g;
-            float b[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = (x < p.W && 16 * nt + i < p.Cout) ? grow[(long long)x * p.Cout + 16 * nt + i] : 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (x < p.W && 16 * nt + i < p.Cout) ? gbase + (unsigned)((x * p.Cout + 16 * nt + i) * 4) : 0xFFFFFFFFu, 0, 0));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int xx = x + dx[mt];
-                const float a = (rval[mt] && x < p.W && xx >= 0 && xx < p.W) ? src[mt][rbase[mt] + (long long)xx * cs[mt]] : 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mt][nt], 0, 0, 0);
+                const unsigned off = (rval[mt] && x < p.W && xx >= 0 && xx < p.W) ? rbase[mt] + (unsigned)(xx * cs[mt] * 4) : 0xFFFFFFFFu;
+                a[mt] = __builtin_bit_cast(float, from2[mt] ? __builtin_amdgcn_raw_buffer_load_b32(r2, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(r1, off, 0, 0));
             }
+        };
+        float aA[MT], bA[NT], aB[MT], bB[NT];
+        fetch(0, aA, bA);
+#pragma unroll 1
+        for (int x0 = 0; x0 < p.W; x0 += 8) {
+            fetch(x0 + 4, aB, bB);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[mt], bA[nt], acc[mt][nt], 0, 0, 0);
+            fetch(x0 + 8, aA, bA);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[mt], bB[nt], acc[mt][nt], 0, 0, 0);
         }
     }
     for (int w = 0; w < 4; ++w) {
@@ -781,7 +804,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     return DA_ERR_UNSUPPORTED;
 }
 
-static bool smallcin_ok(int C1, int C2, int Cout, int stride) { return stride == 1 && C1 + C2 <= 4 && Cout <= 32; }
+static bool smallcin_ok(int C1, int C2, int Cout, int stride) { return stride == 1 && C1 + C2 <= 4 && Cout <= 32; }   // + 32-bit offsets, checked at launch
 static const int kScBlocks = 1024;
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride) {
@@ -812,6 +835,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (smallcin_ok(C1, C2, Cout, stride)) {
         const int Cin = C1 + C2, O = 27 * Cin * Cout;
         if (ws_bytes < (size_t)kScBlocks * O * sizeof(float)) return DA_ERR_WS_SMALL;
+        if ((unsigned long long)N * D * H * W * (Cout > Cin ? Cout : Cin) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
         ScP sp;
         sp.in1 = in1; sp.in2 = in2; sp.C1 = C1; sp.C2 = C2; sp.dy = dy; sp.partial = (float*)ws;
         sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.Cout = Cout; sp.nrows = (long long)N * D * H;
