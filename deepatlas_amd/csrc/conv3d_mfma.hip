@@ -377,7 +377,7 @@ struct WgP {
     unsigned masks[16]; int maskmode;   // per channel chunk tap masks (0 = all taps)
 };
 
-template <int CK, int NREP, bool YS = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv)
+template <int CK, int NREP, bool YS = false, bool MASKED = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets
 __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
@@ -411,9 +411,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     // sparse tap sets (stride-2 via space-to-depth): this wave's tap slot k is live iff its tap is in the chunk's mask
     bool live[TPW];
     {
-        const unsigned msk = (CK == 16 && p.maskmode != 0) ? p.masks[ch] : 0x7FFFFFFu;
+        const unsigned msk = MASKED ? p.masks[ch] : 0x7FFFFFFu;
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) live[k] = (CK != 16) || (((msk >> (wave + 4 * k)) & 1u) != 0 && wave + 4 * k < 27);
+        for (int k = 0; k < TPW; ++k) live[k] = !MASKED || (((msk >> (wave + 4 * k)) & 1u) != 0 && wave + 4 * k < 27);
     }
 
     const int tile_begin = blockIdx.x * p.tiles_per_slab;
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 #pragma unroll
             for (int nn = 0; nn < NREP; ++nn) b0[nn] = yrow[(nn * 16) ^ swz];
 #pragma unroll
-            for (int k = 0; k < TPW; ++k) a0[k] = live[k] ? arow[offA[k]] : 0.f;
+            for (int k = 0; k < TPW; ++k) a0[k] = (!MASKED || live[k]) ? arow[offA[k]] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float a1[TPW], b1[NREP];
@@ -498,11 +498,11 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 #pragma unroll
                     for (int nn = 0; nn < NREP; ++nn) b1[nn] = yrow[(j + 1) * 4 * CG + ((nn * 16) ^ swz)];
 #pragma unroll
-                    for (int k = 0; k < TPW; ++k) a1[k] = live[k] ? arow[(j + 1) * 4 * CK + offA[k]] : 0.f;
+                    for (int k = 0; k < TPW; ++k) a1[k] = (!MASKED || live[k]) ? arow[(j + 1) * 4 * CK + offA[k]] : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < TPW; ++k)
-                    if (live[k]) {
+                    if (!MASKED || live[k]) {
 #pragma unroll
                         for (int nn = 0; nn < NREP; ++nn)
                             acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[k], b0[nn], acc[k][nn], 0, 0, 0);
@@ -815,10 +815,10 @@ bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride) {
     return true;
 }
 
-template <int CK, int NREP, bool YS = false>
+template <int CK, int NREP, bool YS = false, bool MASKED = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * sizeof(float);
-    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS>;
+    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -863,7 +863,11 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.maskmode = 1; da_s2d_masks(p.masks, q.nchunks, 16, s2d_cin, 0);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (Cout % 4 != 0 && q.CK == 16) rc = launch_wgrad_mfma<16, 1, true>(p, q, st);
+    if (p.maskmode != 0) {
+        if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
+        rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true>(p, q, st);
+    }
+    else if (Cout % 4 != 0 && q.CK == 16) rc = launch_wgrad_mfma<16, 1, true>(p, q, st);
     else if (Cout % 4 != 0 && q.CK == 8) rc = launch_wgrad_mfma<8, 1, true>(p, q, st);
     else if (q.CK == 16 && q.NREP == 1) rc = launch_wgrad_mfma<16, 1>(p, q, st);
     else if (q.CK == 16 && q.NREP == 2) rc = launch_wgrad_mfma<16, 2>(p, q, st);
