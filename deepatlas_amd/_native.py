@@ -46,6 +46,7 @@ SIGNATURES = {
     'da_bn_eval_affine': (I, [P, P, P, P, F, I, P, P, P, P, P]),
     'da_bn_act_fwd': (I, [P, P, P, F, P, LL, I, P]),
     'da_bn_act_bwd': (I, [P, P, P, P, P, P, P, F, I, P, P, P, LL, I, P, SZ, P]),
+    'da_bn_act_bwd_dbias': (I, [P, P, P, P, P, P, F, I, P, P, P, P, LL, I, P, SZ, P]),
     'da_act_bwd': (I, [P, P, F, P, LL, P]),
     'da_colsum': (I, [P, LL, I, P, P, SZ, P]),
     'da_maxpool2_fwd': (I, [P, P, I, I, I, I, I, P]),

@@ -163,7 +163,7 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ cm, float slope, int train,
-                                        float* __restrict__ dx, long long nvec, int cq, int C) {
+                                        float* __restrict__ dx, long long nvec, int cq, int C, double* __restrict__ dxsum_partial) {
     // Three 16-byte streams (dy, x -> dx).  The six per-channel constants of this thread's channel quad are hoisted
     // into registers (the grid stride is a multiple of cq, so the quad never changes); UNR load pairs in flight.
     constexpr int UNR = (VEC == 4) ? 2 : 1;
@@ -179,6 +179,9 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
         }
     };
     if (fixed_q) load_consts((int)(i00 % cq));
+    float colacc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) colacc[j] = 0.f;
     for (long long i0 = i00; i0 < nvec; i0 += stride * UNR) {
         float xv[UNR][VEC], gv[UNR][VEC];
 #pragma unroll
@@ -212,6 +215,24 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
             }
             if (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
             else dx[i] = o[0];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) colacc[j] += o[j];
+        }
+    }
+    // optional: column sums of dx (= the bias gradient of the convolution that produced x), fused here so the conv's
+    // weight-gradient call needs no separate pass over dy.  Only valid when the channel quad is fixed per thread.
+    if (dxsum_partial != nullptr && fixed_q && VEC == 4) {
+        __shared__ float shs[256 * 4];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) shs[threadIdx.x * 4 + j] = colacc[j];
+        __syncthreads();
+        const int q0 = (int)(((long long)blockIdx.x * blockDim.x) % cq);
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            // threads t with (q0 + t) % cq == c / 4 own channel c's quad
+            const int want = c >> 2, j = c & 3;
+            double t = 0.0;
+            for (int th = ((want - q0) % cq + cq) % cq; th < (int)blockDim.x; th += cq) t += (double)shs[th * 4 + j];
+            dxsum_partial[((size_t)blockIdx.x * 2) * C + c] = t;
         }
     }
 }
@@ -296,11 +317,30 @@ extern "C" int da_bn_act_fwd(const float* x, const float* scale, const float* sh
     return 0;
 }
 
+static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, float act_slope, int train,
+                           float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                           void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                              const float* scale, const float* shift, float act_slope, int train,
                              float* dx, float* dgamma, float* dbeta, long long M, int C,
                              void* ws, size_t ws_bytes, void* stream) {
     (void)gamma;
+    return bn_act_bwd_impl(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, nullptr, M, C, ws, ws_bytes, stream);
+}
+
+extern "C" int da_bn_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd,
+                                   const float* scale, const float* shift, float act_slope, int train,
+                                   float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    return bn_act_bwd_impl(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, dxsum, M, C, ws, ws_bytes, stream);
+}
+
+static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, float act_slope, int train,
+                           float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                           void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !dx || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
     if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
     const RowPlan p = plan_rows(M, C);
@@ -313,12 +353,24 @@ extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean,
     DA_LAUNCH_CHECK();
     if (C % 4 == 0) {
         const long long nvec = M * C / 4;
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C / 4, C);
+        // fused bias-gradient column sums need a fixed channel quad per thread (256 % (C/4) == 0) and <= kMaxBlocks blocks
+        const int cq = C / 4;
+        const bool fuse = dxsum != nullptr && (256 % cq) == 0;
+        const int grid = fuse ? da_grid(nvec, 256, kMaxBlocks) : da_grid(nvec, 256);
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, cq, C, fuse ? partial : nullptr);
+        DA_LAUNCH_CHECK();
+        if (fuse) {
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, grid, C, dxsum);
+            DA_LAUNCH_CHECK();
+        } else if (dxsum != nullptr) {
+            return da_colsum(dx, M, C, dxsum, ws, ws_bytes, stream);
+        }
     } else {
         const long long nvec = M * C;
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<1>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C, C);
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<1>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C, C, nullptr);
+        DA_LAUNCH_CHECK();
+        if (dxsum != nullptr) return da_colsum(dx, M, C, dxsum, ws, ws_bytes, stream);
     }
-    DA_LAUNCH_CHECK();
     return 0;
 }
 

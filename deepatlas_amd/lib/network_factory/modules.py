@@ -53,10 +53,13 @@ class SegBlock(nn.Sequential):
     def forward(self, x, skip=None):
         conv = self.conv
         if self.batchnorm:
-            y = ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, -1.0)
             bn = self.BN
             if self.training and bn.track_running_stats:
                 bn.num_batches_tracked += 1
+            if self.stride == 1:          # conv + BN + act as one autograd node (BN backward also yields the conv bias gradient)
+                return ops.ConvBNActFn.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             self.training, bn.momentum, bn.eps, self.slope)
+            y = ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, -1.0)
             return ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      self.training, bn.momentum, bn.eps, self.slope)
         return ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, self.slope)
@@ -81,13 +84,13 @@ class SegUpBlock(nn.Sequential):
         self.batchnorm = batchnorm
 
     def forward(self, x):
-        y = ops.DeconvK2S2Fn.apply(x, self.deconv.weight, self.deconv.bias)
         if self.batchnorm:
             bn = self.BN
             if self.training and bn.track_running_stats:
                 bn.num_batches_tracked += 1
-            return ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     self.training, bn.momentum, bn.eps, self.slope)
+            return ops.DeconvBNActFn.apply(x, self.deconv.weight, self.deconv.bias, bn.weight, bn.bias, bn.running_mean,
+                                           bn.running_var, self.training, bn.momentum, bn.eps, self.slope)
+        y = ops.DeconvK2S2Fn.apply(x, self.deconv.weight, self.deconv.bias)
         return ops.ActFn.apply(y, self.slope)
 
 

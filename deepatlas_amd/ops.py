@@ -235,6 +235,131 @@ class BNActFn(Function):
         return ncdhw(dx), dgb[0], dgb[1], None, None, None, None, None, None
 
 
+def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st):
+    """stats (train: batch statistics + running-stat update, eval: running stats) and fused apply+activation."""
+    C = a.shape[-1]
+    M = a.numel() // C
+    stats = _empty((4, C), a)                     # mean, rstd, scale, shift
+    g = gamma.detach().contiguous() if gamma is not None else None
+    b = beta.detach().contiguous() if beta is not None else None
+    wsb = nat.lib().da_bn_ws_bytes(M, C)
+    train = bool(training or running_mean is None)
+    if train:
+        wp, wn = _ws(wsb, a)
+        call('da_bn_train_stats', ptr(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
+             ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
+    else:
+        call('da_bn_eval_affine', ptr(g), ptr(b), ptr(running_mean), ptr(running_var), float(eps), C,
+             ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
+    out = torch.empty_like(a)
+    call('da_bn_act_fwd', ptr(a), ptr(stats[2]), ptr(stats[3]), float(slope), ptr(out), M, C, st)
+    return out, stats, g, (M, C, float(slope), train, wsb)
+
+
+def _bn_backward(go, y, stats, cfg, want_dbias, st):
+    """BN+activation backward; returns (dy, dgamma, dbeta, dbias_of_producer or None) -- the producer's bias gradient is the
+    column sum of dy and is accumulated inside the apply pass."""
+    M, C, slope, train, wsb = cfg
+    dy = torch.empty_like(y)
+    dgb = _empty((3, C), y)
+    wp, wn = _ws(wsb, y)
+    call('da_bn_act_bwd_dbias', ptr(go), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+         slope, 1 if train else 0, ptr(dy), ptr(dgb[0]), ptr(dgb[1]), ptr(dgb[2]) if want_dbias else None, M, C, wp, wn, st)
+    return dy, dgb[0], dgb[1], (dgb[2] if want_dbias else None)
+
+
+class ConvBNActFn(Function):
+    """unets.convBlock with batchnorm=True as ONE autograd node: Conv3d(k3,p1) on concat(x1, x2) -> BatchNorm3d -> LeakyReLU
+    (unets.py:24-33).  Saves the raw conv output; the backward runs BN/act backward (which also yields the conv bias gradient),
+    then the conv data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        a1 = ndhwc(x1)
+        a2 = ndhwc(x2) if x2 is not None else None
+        N, D, H, W, C1 = a1.shape
+        C2 = a2.shape[-1] if a2 is not None else 0
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if Cin != C1 + C2 or tuple(weight.shape[2:]) != (3, 3, 3):
+            raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
+        st = stream()
+        w_tio = _empty((27, Cin, Cout), a1)
+        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
+        y = _empty((N, D, H, W, Cout), a1)
+        wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, 1)
+        wp, wn = _ws(wsb, a1)
+        b = bias.detach().contiguous() if bias is not None else None
+        call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
+        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st)
+        ctx.dims = (N, D, H, W, C1, C2, Cout, wsb)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a1, a2, w_tio, y, stats)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a1, a2, w_tio, y, stats = ctx.saved_tensors
+        N, D, H, W, C1, C2, Cout, wsb = ctx.dims
+        st = stream()
+        dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st)
+        wp, wn = _ws(wsb, a1)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
+            dx1 = _empty(a1.shape, a1)
+            dx2 = _empty(a2.shape, a1) if a2 is not None else None
+            call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
+        dw_tio = torch.empty_like(w_tio)
+        call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
+        dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
+        call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+        return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, dgamma, dbeta,
+                None, None, None, None, None, None)
+
+
+class DeconvBNActFn(Function):
+    """unets.deconvBlock with batchnorm=True as one autograd node: ConvTranspose3d(k2,s2) -> BatchNorm3d -> LeakyReLU (unets.py:42-52)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        a = ndhwc(x)
+        N, D, H, W, Cin = a.shape
+        Cout = weight.shape[1]
+        if weight.shape[0] != Cin or tuple(weight.shape[2:]) != (2, 2, 2):
+            raise ValueError('ConvTranspose3d weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
+        st = stream()
+        w_tio = _empty((8, Cin, Cout), a)
+        call('da_w_iok_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 8, st)
+        y = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
+        b = bias.detach().contiguous() if bias is not None else None
+        wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
+        call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, wp, wn, st)
+        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a, w_tio, y, stats)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, w_tio, y, stats = ctx.saved_tensors
+        N, D, H, W, Cin = a.shape
+        Cout = w_tio.shape[2]
+        st = stream()
+        dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(a)
+            wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
+            call('da_deconv_k2s2_dgrad', ptr(dy), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
+        dw_tio = torch.empty_like(w_tio)
+        wp, wn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
+        call('da_deconv_k2s2_wgrad', ptr(a), ptr(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, wp, wn, st)
+        dw = _empty((Cin, Cout, 2, 2, 2), a)
+        call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
+        return (ncdhw(dx) if dx is not None else None), dw, db, dgamma, dbeta, None, None, None, None, None, None
+
+
 class ActFn(Function):
     """Stand-alone ReLU / LeakyReLU (used when a block has no BatchNorm and the conv did not fuse it)."""
 

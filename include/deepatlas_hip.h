@@ -113,6 +113,12 @@ int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const floa
                   const float* scale, const float* shift, float act_slope, int train,
                   float* dx, float* dgamma, float* dbeta, long long M, int C,
                   void* ws, size_t ws_bytes, void* stream);
+/* Same, additionally writing dxsum[C] = per-channel column sums of dx: the bias gradient of the convolution (or transposed
+ * convolution) that produced x, fused into the apply pass so the conv weight-gradient call can skip its own pass over dy. */
+int da_bn_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd,
+                        const float* scale, const float* shift, float act_slope, int train,
+                        float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                        void* ws, size_t ws_bytes, void* stream);
 /* Backward of a bare activation from its OUTPUT y (ReLU / LeakyReLU): dx = dy * (y > 0 ? 1 : slope). */
 int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream);
 /* Per-channel column sum of x[M][C] -> out[C] (bias gradients). */
