@@ -29,6 +29,7 @@ SIGNATURES = {
     'da_w_tio_to_iok': (I, [P, P, I, I, I, P]),
     'da_conv3d_k3_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
     'da_conv3d_k3_fwd': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    'da_conv3d_k3_fwd_bnstats': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),
     'da_conv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, I, P, SZ, P]),
     'da_conv3d_k3_wgrad': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_set_conv_direct': (I, [I]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     'da_deconv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_bn_ws_bytes': (SZ, [LL, I]),
     'da_bn_train_stats': (I, [P, LL, I, P, P, F, F, P, P, P, P, P, P, P, SZ, P]),
+    'da_bn_train_stats_from_partials': (I, [P, I, LL, I, P, P, F, F, P, P, P, P, P, P, P]),
     'da_bn_eval_affine': (I, [P, P, P, P, F, I, P, P, P, P, P]),
     'da_bn_act_fwd': (I, [P, P, P, F, P, LL, I, P]),
     'da_bn_act_bwd': (I, [P, P, P, P, P, P, P, F, I, P, P, P, LL, I, P, SZ, P]),

@@ -350,6 +350,22 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
     return da_conv3_direct_fwd(in1, C1, in2, C2, w_tio, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, stride, act_slope, st);
 }
 
+extern "C" int da_conv3d_k3_fwd_bnstats(const float* in1, int C1, const float* in2, int C2,
+                                        const float* w_tio, const float* bias, float* out,
+                                        int N, int D, int H, int W, int Cout, int stride,
+                                        double* stats_partial, int stats_capacity, int* stats_nparts,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    if (stats_nparts) *stats_nparts = 0;
+    if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
+        return DA_ERR_BADARG;
+    if (stats_partial && stats_capacity >= 512 && !force_direct() && stride == 1 && da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) {
+        if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+        return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, stride, -1.f,
+                                 ws, ws_bytes, da_stream(stream), 0, stats_partial, stats_nparts);
+    }
+    return da_conv3d_k3_fwd(in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, stride, -1.f, ws, ws_bytes, stream);
+}
+
 extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
                                   int N, int D, int H, int W, int Cout, int stride,
                                   void* ws, size_t ws_bytes, void* stream) {

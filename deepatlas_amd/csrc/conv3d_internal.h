@@ -13,7 +13,7 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0);
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0, double* stats_partial = nullptr, int* stats_nparts = nullptr);
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,

@@ -102,10 +102,11 @@ struct FwdP {
     int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles, tiles_per_block;
     float slope;
     unsigned masks[16]; int maskmode;   // tap masks (stride-2 via space-to-depth): 0 none, 1 per channel chunk, 2 per blockIdx.y
+    double* stats_partial;              // optional [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the (pre-activation) output
     int ablate;      // diagnostic only (env DA_ABLATE): 1 skip staging loads, 2 skip epilogue stores, 4 skip LDS writes+barriers, 8 skip MFMAs
 };
 
-template <int CK, int NREP, bool MASKED = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth), own instantiation
+template <int CK, int NREP, bool MASKED = false, bool STATS = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 4, HZ = TZ + 2;
@@ -123,7 +124,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     const int tile_begin = blockIdx.x * p.tiles_per_block;
     int tile_end = tile_begin + p.tiles_per_block; if (tile_end > p.ntiles) tile_end = p.ntiles;
     const int nitems = (tile_end - tile_begin) * nchunks;
-    if (nitems <= 0) return;
+    if (nitems <= 0) {
+        if (STATS) for (int c = threadIdx.x; c < NREP * 16; c += 256) { const int co = blockIdx.y * NREP * 16 + c; if (co < p.Cout) { p.stats_partial[((size_t)blockIdx.x * 2) * p.Cout + co] = 0.0; p.stats_partial[((size_t)blockIdx.x * 2 + 1) * p.Cout + co] = 0.0; } }
+        return;
+    }
 
     auto item_coords = [&](int item, int& n, int& z0, int& y0, int& x0, int& ch) {
         ch = item % nchunks;
@@ -167,6 +171,44 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll 1
         for (int d = 0; d < 3 * NREP; ++d) __builtin_amdgcn_s_sleep(127);
     }
+    float st1[STATS ? NREP : 1][4], st2[STATS ? NREP : 1][4];   // per-lane BN partial sums of this lane's 4 couts (after the transpose)
+#pragma unroll
+    for (int nn = 0; nn < (STATS ? NREP : 1); ++nn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[nn][j] = 0.f; st2[nn][j] = 0.f; }
+    // BN partial sums: per-lane fp32 sums are folded every 2 tiles (<= 16 values per lane and channel) into per-channel
+    // DOUBLE accumulators held by the first NREP*16 threads (wave shuffles over q/g, then the 4 waves through a 2 KiB LDS
+    // strip behind the tile; everything past the per-lane sums is double), so E[x^2] - mean^2 keeps the accuracy of the stand-alone statistics pass.
+    double dsum1 = 0.0, dsum2 = 0.0;
+    double* sred = reinterpret_cast<double*>(lds + StageGeom<CK, HZ>::TOTAL * 4);      // [wave][2][NREP*16] doubles
+    int tiles_done = 0;
+    auto stats_flush = [&]() {
+        if constexpr (STATS) {
+#pragma unroll
+            for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double a = (double)st1[nn][j], b = (double)st2[nn][j];     // lane-to-lane tree in double
+                    a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+                    a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+                    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                    if ((lane & 3) == 0 && (lane >> 4) == 0) {
+                        const int c = nn * 16 + 4 * ((lane & 15) >> 2) + j;
+                        sred[(wave * 2 + 0) * (NREP * 16) + c] = a;
+                        sred[(wave * 2 + 1) * (NREP * 16) + c] = b;
+                    }
+                    st1[nn][j] = 0.f; st2[nn][j] = 0.f;
+                }
+            __syncthreads();
+            if ((int)threadIdx.x < NREP * 16) {
+                const int c = threadIdx.x;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { dsum1 += sred[(w * 2 + 0) * (NREP * 16) + c]; dsum2 += sred[(w * 2 + 1) * (NREP * 16) + c]; }
+            }
+            __syncthreads();
+        }
+    };
     float4 pre[PRE > 0 ? PRE : 1];
     issue_stage(0, pre);
     stage_write<CK, HZ, 0, PRE>(lds, pre);
@@ -278,72 +320,81 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 
         if (ch == nchunks - 1 && !(p.ablate & 2)) {
             // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg.
+            // A 4x4 transpose across each lane quad (2 DPP butterfly stages) turns the fragment (4 voxels x 1 cout per lane)
+            // into (1 voxel x 4 couts per lane): one 16-byte store per M-tile, 1 KiB contiguous per wave instruction for
+            // Cout = 16.  Interior tiles store unconditionally (hipcc puts an s_waitcnt vmcnt(0) in front of every store that
+            // sits in its own exec-mask branch); ragged tiles predicate per lane.
             const int z = z0 + wave;
-            const bool full = (z0 + TZ <= p.D) && (y0 + TY <= p.H) && (x0 + TX <= p.W) && ((p.Cs1 & 3) == 0) && ((p.Cs2 & 3) == 0) && ((p.Cout & 3) == 0);
-            if (full) {
-                // Fast path (interior tiles): 4x4 transpose across each lane quad (2 DPP butterfly stages) turns the
-                // fragment (4 voxels x 1 cout per lane) into (1 voxel x 4 couts per lane) -> one 16-byte store per M-tile,
-                // 1 KiB contiguous per wave instruction for Cout = 16, and no per-element branches (hipcc puts an
-                // s_waitcnt vmcnt(0) in front of every store that sits in its own exec-mask branch).
-                const int q = lane & 3, a4 = (lane & 15) >> 2;
+            const bool vec_ok = ((p.Cs1 & 3) == 0) && ((p.Cs2 & 3) == 0) && ((p.Cout & 3) == 0);
+            const bool full = (z0 + TZ <= p.D) && (y0 + TY <= p.H) && (x0 + TX <= p.W) && vec_ok;
+            const int q = lane & 3, a4 = (lane & 15) >> 2;
+            const int x = x0 + 4 * g + q;
 #pragma unroll
-                for (int nn = 0; nn < NREP; ++nn) {
-                    const int co0 = (nt0 + nn) * 16 + 4 * a4;          // first of this lane's 4 couts after the transpose
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.bias && co0 + 3 < p.Cout) bv = *reinterpret_cast<const float4*>(p.bias + co0);
-                    float* dst; int Cd, cd;
-                    if (co0 < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co0; } else { dst = p.out2; Cd = p.Cs2; cd = co0 - p.Cs1; }
-                    const bool lane_ok = co0 + 3 < p.Cout;
+            for (int nn = 0; nn < NREP; ++nn) {
+                const int co0 = (nt0 + nn) * 16 + 4 * a4;          // first of this lane's 4 couts after the transpose
+                float bvv[4];
 #pragma unroll
-                    for (int r = 0; r < TY; ++r) {
-                        float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];
-                        {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
-                            const bool odd = (q & 1) != 0;
-                            const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
-                            const float r01 = __shfl_xor(s01, 1), r23 = __shfl_xor(s23, 1);
-                            if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
-                        }
-                        {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
-                            const bool hi2 = (q & 2) != 0;
-                            const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
-                            const float r02 = __shfl_xor(s02, 2), r13 = __shfl_xor(s13, 2);
-                            if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
-                        }
-                        // now (t0..t3) = couts co0..co0+3 of voxel x = x0 + 4*g + q
-                        const long long vox = (((long long)n * p.D + z) * p.H + (y0 + r)) * p.W + x0 + 4 * g + q;
-                        float4 o;
-                        o.x = da_act(t0 + bv.x, p.slope); o.y = da_act(t1 + bv.y, p.slope);
-                        o.z = da_act(t2 + bv.z, p.slope); o.w = da_act(t3 + bv.w, p.slope);
-                        if (lane_ok) *reinterpret_cast<float4*>(dst + vox * Cd + cd) = o;
-                        acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) bvv[j] = (p.bias && co0 + j < p.Cout) ? p.bias[co0 + j] : 0.f;
+                float* dst; int Cd, cd;
+                if (co0 < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co0; } else { dst = p.out2; Cd = p.Cs2; cd = co0 - p.Cs1; }
+#pragma unroll
+                for (int r = 0; r < TY; ++r) {
+                    float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];
+                    {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
+                        const bool odd = (q & 1) != 0;
+                        const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
+                        const float r01 = __shfl_xor(s01, 1), r23 = __shfl_xor(s23, 1);
+                        if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
                     }
-                }
-            } else {
-#pragma unroll
-                for (int nn = 0; nn < NREP; ++nn) {
-                    const int co = (nt0 + nn) * 16 + i;
-                    const float b = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
-                    float* dst; int Cd, cd;
-                    if (co < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co; } else { dst = p.out2; Cd = p.Cs2; cd = co - p.Cs1; }
-#pragma unroll
-                    for (int r = 0; r < TY; ++r) {
-                        const int y = y0 + r;
-                        const long long rowbase = (((long long)n * p.D + z) * p.H + y) * p.W;
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int x = x0 + 4 * g + reg;
-                            if (co < p.Cout && z < p.D && y < p.H && x < p.W) dst[(rowbase + x) * Cd + cd] = da_act(acc[r][nn][reg] + b, p.slope);
-                        }
-                        acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
+                        const bool hi2 = (q & 2) != 0;
+                        const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
+                        const float r02 = __shfl_xor(s02, 2), r13 = __shfl_xor(s13, 2);
+                        if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
                     }
+                    // now (t0..t3) = couts co0..co0+3 of voxel (z, y0 + r, x)
+                    const float v0 = t0 + bvv[0], v1 = t1 + bvv[1], v2 = t2 + bvv[2], v3 = t3 + bvv[3];
+                    const long long vox = (((long long)n * p.D + z) * p.H + (y0 + r)) * p.W + x;
+                    const bool vin = full || (z < p.D && y0 + r < p.H && x < p.W);
+                    if (STATS) {
+                        const float m = vin ? 1.f : 0.f;
+                        st1[nn][0] += m * v0; st1[nn][1] += m * v1; st1[nn][2] += m * v2; st1[nn][3] += m * v3;
+                        st2[nn][0] += m * v0 * v0; st2[nn][1] += m * v1 * v1; st2[nn][2] += m * v2 * v2; st2[nn][3] += m * v3 * v3;
+                    }
+                    const float4 o = make_float4(da_act(v0, p.slope), da_act(v1, p.slope), da_act(v2, p.slope), da_act(v3, p.slope));
+                    if (full) {
+                        if (co0 + 3 < p.Cout) *reinterpret_cast<float4*>(dst + vox * Cd + cd) = o;
+                    } else if (vin) {
+                        if (vec_ok && co0 + 3 < p.Cout) *reinterpret_cast<float4*>(dst + vox * Cd + cd) = o;
+                        else {
+                            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int co = co0 + j;
+                                if (co < p.Cout) { if (co < p.Cs1) p.out1[vox * p.Cs1 + co] = ov[j]; else p.out2[vox * p.Cs2 + (co - p.Cs1)] = ov[j]; }
+                            }
+                        }
+                    }
+                    acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
+        if (STATS && ch == nchunks - 1 && ((++tiles_done) & 1) == 0) stats_flush();
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
             stage_write<CK, HZ, 0, PRE>(lds, pre);
             stage_rest(item + 1);
             __syncthreads();
+        }
+    }
+    if constexpr (STATS) {
+        stats_flush();
+        if ((int)threadIdx.x < NREP * 16) {
+            const int co = nt0 * 16 + (int)threadIdx.x;
+            if (co < p.Cout) {
+                p.stats_partial[((size_t)blockIdx.x * 2 + 0) * p.Cout + co] = dsum1;
+                p.stats_partial[((size_t)blockIdx.x * 2 + 1) * p.Cout + co] = dsum2;
+            }
         }
     }
 }
@@ -742,10 +793,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride) {
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
-    const size_t shm = (size_t)6 * HY * HX * CK * sizeof(float);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED>;
+    const size_t shm = (size_t)6 * HY * HX * CK * sizeof(float) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0);
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -760,7 +811,7 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts) {
     (void)stride;
     const int Cin = C1 + C2;
     const int CK = pick_ck(C1, C2);
@@ -791,6 +842,15 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         static int nres = -1; if (nres < 0) { const char* e = getenv("DA_FWD_BLOCKS"); nres = e ? atoi(e) : 512; }
         int nblk = nres / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
         p.tiles_per_block = (p.ntiles + nblk - 1) / nblk;
+    }
+    p.stats_partial = stats_partial;
+    if (stats_nparts) *stats_nparts = 0;
+    if (stats_partial && p.maskmode == 0 && (CK == 16 || CK == 8) && NREP <= 2) {
+        if (stats_nparts) *stats_nparts = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
+        if (CK == 16 && NREP == 1) return launch_fwd_mfma<16, 1, false, true>(p, gy, st);
+        if (CK == 16 && NREP == 2) return launch_fwd_mfma<16, 2, false, true>(p, gy, st);
+        if (CK == 8 && NREP == 1) return launch_fwd_mfma<8, 1, false, true>(p, gy, st);
+        if (CK == 8 && NREP == 2) return launch_fwd_mfma<8, 2, false, true>(p, gy, st);
     }
     if (p.maskmode != 0) {
         if (NREP == 1) return launch_fwd_mfma<16, 1, true>(p, gy, st);

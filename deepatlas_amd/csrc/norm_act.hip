@@ -295,6 +295,17 @@ extern "C" int da_bn_train_stats(const float* x, long long M, int C, const float
     return 0;
 }
 
+extern "C" int da_bn_train_stats_from_partials(const double* partial, int nparts, long long M, int C,
+                                               const float* gamma, const float* beta, float eps, float momentum,
+                                               float* running_mean, float* running_var,
+                                               float* mean, float* rstd, float* scale, float* shift, void* stream) {
+    if (!partial || nparts <= 0 || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, nparts, M, C,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int da_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                  float eps, int C, float* mean, float* rstd, float* scale, float* shift, void* stream) {
     if (!running_mean || !running_var || C <= 0) return DA_ERR_BADARG;

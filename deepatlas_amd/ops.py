@@ -7,6 +7,8 @@ their outputs as N x D x H x W x C and return the permuted N x C x D x H x W vie
 
 Every op is a HIP kernel launch on the current torch stream; there is no eager fallback.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -235,8 +237,9 @@ class BNActFn(Function):
         return ncdhw(dx), dgb[0], dgb[1], None, None, None, None, None, None
 
 
-def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st):
-    """stats (train: batch statistics + running-stat update, eval: running stats) and fused apply+activation."""
+def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials=None):
+    """stats (train: batch statistics + running-stat update, eval: running stats) and fused apply+activation.
+    partials = (double tensor [nparts][2][C], nparts) when the producing conv already accumulated the sums in its epilogue."""
     C = a.shape[-1]
     M = a.numel() // C
     stats = _empty((4, C), a)                     # mean, rstd, scale, shift
@@ -244,7 +247,10 @@ def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, e
     b = beta.detach().contiguous() if beta is not None else None
     wsb = nat.lib().da_bn_ws_bytes(M, C)
     train = bool(training or running_mean is None)
-    if train:
+    if train and partials is not None and partials[1] > 0:
+        call('da_bn_train_stats_from_partials', ptr(partials[0]), partials[1], M, C, ptr(g), ptr(b), float(eps), float(momentum),
+             ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
+    elif train:
         wp, wn = _ws(wsb, a)
         call('da_bn_train_stats', ptr(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
              ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
@@ -289,8 +295,18 @@ class ConvBNActFn(Function):
         wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, 1)
         wp, wn = _ws(wsb, a1)
         b = bias.detach().contiguous() if bias is not None else None
-        call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
-        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st)
+        partials = None
+        if training or running_mean is None:
+            # the MFMA epilogue accumulates the BatchNorm partial sums, so the statistics need no pass over y
+            import ctypes
+            pbuf = torch.empty((512, 2, Cout), dtype=torch.float64, device=a1.device)
+            npar = ctypes.c_int(0)
+            call('da_conv3d_k3_fwd_bnstats', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1,
+                 ptr(pbuf), 512 if os.environ.get('DA_NO_FUSED_STATS') != '1' else 0, ctypes.byref(npar), wp, wn, st)
+            partials = (pbuf, npar.value)
+        else:
+            call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
+        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials)
         ctx.dims = (N, D, H, W, C1, C2, Cout, wsb)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None

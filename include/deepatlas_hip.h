@@ -56,6 +56,15 @@ int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int C2,
                      const float* w_tio, const float* bias, float* out,
                      int N, int D, int H, int W, int Cout, int stride, float act_slope,
                      void* ws, size_t ws_bytes, void* stream);
+/* Forward of a conv that feeds a train-mode BatchNorm: same as da_conv3d_k3_fwd (no activation) and, when the MFMA path
+ * serves the layer, the epilogue also writes per-workgroup partial sums stats_partial[nparts][2][Cout] (double: sum, sum of
+ * squares of the output) so the BN statistics need no extra pass over the tensor.  *stats_nparts = 0 means "not fused":
+ * run da_bn_train_stats.  stats_capacity = number of [2][Cout] slots available (>= 512). */
+int da_conv3d_k3_fwd_bnstats(const float* in1, int C1, const float* in2, int C2,
+                             const float* w_tio, const float* bias, float* out,
+                             int N, int D, int H, int W, int Cout, int stride,
+                             double* stats_partial, int stats_capacity, int* stats_nparts,
+                             void* ws, size_t ws_bytes, void* stream);
 /* data gradient (autograd of the above): dx = concat(dx1[C1], dx2[C2]); D,H,W are the INPUT dims. */
 int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
                        int N, int D, int H, int W, int Cout, int stride,
@@ -101,6 +110,11 @@ int da_bn_train_stats(const float* x, long long M, int C, const float* gamma, co
                       float eps, float momentum, float* running_mean, float* running_var,
                       float* mean, float* rstd, float* scale, float* shift,
                       void* ws, size_t ws_bytes, void* stream);
+/* Same result from partial sums produced by da_conv3d_k3_fwd_bnstats. */
+int da_bn_train_stats_from_partials(const double* partial, int nparts, long long M, int C,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var,
+                                    float* mean, float* rstd, float* scale, float* shift, void* stream);
 /* Eval-mode affine from running statistics. */
 int da_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int C, float* mean, float* rstd, float* scale, float* shift, void* stream);
