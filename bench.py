@@ -82,12 +82,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
     assert world == max(args.gpus, 1) or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from deepatlas_amd import _native as nat, parallel
     from deepatlas_amd.lib.network_factory import get_network
