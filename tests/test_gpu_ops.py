@@ -378,3 +378,29 @@ def test_full_size_dice_of_identical_onehots_and_counts():
     counts, pred = ops.argmax_dice_counts(oh, lab)
     assert torch.equal(pred, lab)
     assert int(counts[0, :, 0].sum()) == lab.numel() and torch.equal(counts[0, :, 0], counts[0, :, 2])
+
+
+def test_full_size_conv_linearity_and_adjointness():
+    """Full BASELINE size (batch 1, 160x192x160), the dominant layer 48 -> 16 (two-pointer 32 + 16 input) on the MFMA path:
+    linearity conv(a x + b y) = a conv(x) + b conv(y) and the adjoint identities  <conv(x), g> = <x, dgrad(g)> = <w, wgrad(x, g)>
+    -- size-independent checks that tie forward, data gradient and weight gradient together without a CPU reference."""
+    from deepatlas_amd import ops
+    N, D, H, W = 1, 160, 192, 160
+    gen = torch.Generator().manual_seed(230)
+    def r(shape, scale=1.0):
+        return ((torch.rand(shape, generator=gen) * 2 - 1) * scale).to(dev())
+    x1, x2, y1, y2 = r((N, D, H, W, 32)).permute(0, 4, 1, 2, 3), r((N, D, H, W, 16)).permute(0, 4, 1, 2, 3), r((N, D, H, W, 32)).permute(0, 4, 1, 2, 3), r((N, D, H, W, 16)).permute(0, 4, 1, 2, 3)
+    w = r((16, 48, 3, 3, 3), 0.1)
+    f = lambda a, b: ops.Conv3dK3Fn.apply(a, b, w, None, 1, -1.0)
+    lhs = f(0.5 * x1 - 2.0 * y1, 0.5 * x2 - 2.0 * y2)
+    rhs = 0.5 * f(x1, x2) - 2.0 * f(y1, y2)
+    assert float((lhs - rhs).norm() / rhs.norm()) < 1e-5
+    xa, xb, wg = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    out = ops.Conv3dK3Fn.apply(xa, xb, wg, None, 1, -1.0)
+    g = r((N, D, H, W, 16)).permute(0, 4, 1, 2, 3)
+    out.backward(g)
+    inner = float((out.detach().double() * g.double()).sum())
+    via_dgrad = float((x1.double() * xa.grad.double()).sum() + (x2.double() * xb.grad.double()).sum())
+    via_wgrad = float((w.double() * wg.grad.double()).sum())
+    assert abs(inner - via_dgrad) <= 1e-4 * abs(inner) + 1e-2, (inner, via_dgrad)
+    assert abs(inner - via_wgrad) <= 1e-4 * abs(inner) + 1e-2, (inner, via_wgrad)
