@@ -337,6 +337,10 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
         return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
                                  N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
     }
+    if (!force_direct() && da_conv3_thin_supported(C1, C2, Cout, stride) && !(C1 + C2 <= 2 && (Cout == 8 || Cout == 16))) {
+        const int rc = da_conv3_thin_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope, st);
+        if (rc != DA_ERR_UNSUPPORTED) return rc;
+    }
     // tiny Cin, full-quad Cout, single output pointer, 32-bit addressable
     const bool tiny = !force_direct() && stride == 1 && ((C2 == 0 && (C1 == 1 || C1 == 2)) || (C1 == 1 && C2 == 1)) && (Cout == 8 || Cout == 16) &&
                       (unsigned long long)N * D * H * W * 2ull * 4ull < 0xFFFFFFF0ull;
@@ -378,6 +382,10 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
         if (!force_direct() && da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1)) {
             return da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, dx1, C1, dx2, C2,
                                      N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, st);
+        }
+        if (!force_direct() && da_conv3_thin_supported(Cout, 0, Cin, 1)) {
+            const int rc = da_conv3_thin_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, -1.f, st);
+            if (rc != DA_ERR_UNSUPPORTED) return rc;
         }
         float* wf = (float*)ws;
         hipLaunchKernelGGL(w_flip_transpose_kernel, dim3(da_grid(27 * Cin * Cout, 256)), dim3(256), 0, st, w_tio, wf, Cin, Cout);

@@ -32,3 +32,9 @@ int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, i
                       void* ws, size_t ws_bytes, hipStream_t st);
 int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
                       void* ws, size_t ws_bytes, hipStream_t st);
+
+// thin convs (Cout <= 4 or Cin <= 4) on the VALU from an LDS halo tile; flip_tr: `w` is the original layer's [27][Cout][Cin]
+// tensor and the data-gradient convolution is computed
+bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride);
+int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
+                      float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope, hipStream_t st);

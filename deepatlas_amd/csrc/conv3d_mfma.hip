@@ -399,6 +399,98 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Thin" 3x3x3 convolutions on the VALU from an LDS halo tile: very few output channels (the 24 -> 3 flow conv,
+// voxel_morph.py:57) or very few input channels (its data gradient, 3 -> 24).  An MFMA tile would be >= 13/16 padding; the
+// plain direct kernel is bound by per-lane strided global gathers.  Here the 6x10x18 halo tile is staged once per channel
+// chunk exactly like the MFMA kernel (buffer loads, zero padding in hardware), every thread owns two output voxels and CT
+// outputs, inputs come from LDS and the weights through wave-uniform (scalar) loads.
+// ---------------------------------------------------------------------------------------------------
+struct ThinP {
+    const float* in1; const float* in2; int C1, C2;      // C1 % CL == 0 when C2 > 0
+    const float* w;                                      // [27][Cin][Cout]  (flip_tr: original [27][Cout][Cin], taps flipped)
+    const float* bias; float* out1; float* out2; int Cs1, Cs2;
+    int N, D, H, W, Cout, ntz, nty, ntx, ntiles, flip_tr; float slope;
+};
+
+template <int CL, int CT>
+__global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TZ = 4, HZ = TZ + 2, HVOX = HZ * HY * HX;
+    int t = blockIdx.x;
+    const int tx = t % p.ntx; t /= p.ntx;
+    const int ty = t % p.nty; t /= p.nty;
+    const int tz = t % p.ntz; const int n = t / p.ntz;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+    const int Cin = p.C1 + p.C2;
+    const int nchunks = (Cin + CL - 1) / CL;
+    // this thread's two output voxels: (lz, ly, lx) and (lz + 2, ly, lx)
+    const int lx = threadIdx.x & 15, ly = (threadIdx.x >> 4) & 7, lz = threadIdx.x >> 7;
+    float acc[2][CT];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[v][j] = (p.bias && j < p.Cout) ? p.bias[j] : 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cbase = ch * CL;
+        const float* src; int Cs, choff;
+        if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
+        const int cvalid = (Cs - choff) < CL ? (Cs - choff) : CL;           // real channels in this chunk
+        const long long sample = (long long)p.D * p.H * p.W * Cs;
+        const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < HVOX * CL; idx += 256) {
+            const int c = idx % CL; const int hv = idx / CL;
+            const int hx = hv % HX; const int tt = hv / HX;
+            const int hy = tt % HY; const int hz = tt / HY;
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool inb = c < cvalid && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + c) * 4);
+            lds[idx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, inb ? off : 0xFFFFFFFFu, 0, 0));
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            const float* a0 = lds + (((lz + dz) * HY + (ly + dy)) * HX + (lx + dx)) * CL;
+            const float* a1 = a0 + 2 * HY * HX * CL;
+            float xa[CL], xb[CL];
+#pragma unroll
+            for (int c = 0; c < CL; c += 4) {
+                const float4 u = *reinterpret_cast<const float4*>(a0 + c), v = *reinterpret_cast<const float4*>(a1 + c);
+                xa[c] = u.x; xa[c + 1] = u.y; xa[c + 2] = u.z; xa[c + 3] = u.w;
+                xb[c] = v.x; xb[c + 1] = v.y; xb[c + 2] = v.z; xb[c + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                if (c < cvalid) {
+                    const int ci = cbase + c;
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) {
+                        if (j < p.Cout) {
+                            const float wv = p.flip_tr ? p.w[((size_t)(26 - tap) * p.Cout + j) * Cin + ci] : p.w[((size_t)tap * Cin + ci) * p.Cout + j];
+                            acc[0][j] += xa[c] * wv; acc[1][j] += xb[c] * wv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int z = z0 + lz + 2 * v, y = y0 + ly, x = x0 + lx;
+        if (z >= p.D || y >= p.H || x >= p.W) continue;
+        const long long vox = (((long long)n * p.D + z) * p.H + y) * p.W + x;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if (j < p.Cout) {
+                const float o = da_act(acc[v][j], p.slope);
+                if (j < p.Cs1) p.out1[vox * p.Cs1 + j] = o; else p.out2[vox * p.Cs2 + (j - p.Cs1)] = o;
+            }
+        }
+    }
+}
+
 // packed B operand: wp[chunk][step][ntile][lane][m]
 __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
                                         int CK, int NSTEPS, int NTpad, int flipped, long long total) {
@@ -866,6 +958,37 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
 
 static bool smallcin_ok(int C1, int C2, int Cout, int stride) { return stride == 1 && C1 + C2 <= 4 && Cout <= 32; }   // + 32-bit offsets, checked at launch
 static const int kScBlocks = 1024;
+
+bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride) {
+    const int Cin = C1 + C2;
+    if (stride != 1) return false;
+    if (Cout <= 4 && Cin >= 8 && Cin <= 64 && C1 % 8 == 0 && C2 % 8 == 0) return true;     // few outputs (flow forward)
+    if (Cin <= 4 && Cout >= 8 && Cout <= 32) return true;                                   // few inputs (flow data gradient)
+    return false;
+}
+
+int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
+                      float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope, hipStream_t st) {
+    if ((unsigned long long)D * H * W * (C1 > C2 ? C1 : C2) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+    ThinP p;
+    p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.Cs1 = Cs1; p.Cs2 = Cs2;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.flip_tr = flip_tr; p.slope = slope;
+    p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX; p.ntiles = N * p.ntz * p.nty * p.ntx;
+    const int Cin = C1 + C2;
+    if (Cout <= 4) {
+        hipLaunchKernelGGL((conv3_thin_kernel<8, 4>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 8 * sizeof(float), st, p);
+    } else if (Cin <= 4 && Cout <= 8) {
+        hipLaunchKernelGGL((conv3_thin_kernel<4, 8>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
+    } else if (Cin <= 4 && Cout <= 16) {
+        hipLaunchKernelGGL((conv3_thin_kernel<4, 16>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
+    } else if (Cin <= 4 && Cout <= 24) {
+        hipLaunchKernelGGL((conv3_thin_kernel<4, 24>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
+    } else if (Cin <= 4 && Cout <= 32) {
+        hipLaunchKernelGGL((conv3_thin_kernel<4, 32>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
+    } else return DA_ERR_UNSUPPORTED;
+    DA_LAUNCH_CHECK();
+    return 0;
+}
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride) {
     if (smallcin_ok(C1, C2, Cout, stride)) return true;

@@ -50,7 +50,8 @@ class DeepAtlasJointStep:
     def __call__(self, im_m, im_t, seg_m, seg_t):
         lam = self.lam
         onehot_m = ops.one_hot(seg_m.unsqueeze(1), self.n_classes)
-        onehot_t = ops.one_hot(seg_t.unsqueeze(1), self.n_classes)
+        # Dice against one-hot(seg_t): the fused kernel takes the index mask directly (t in {0,1} either way), so the target
+        # one-hot is never materialised
         # ---- registration phase (segmentation net not involved: the moving segmentation is given)
         self.reg.train()
         self.reg_opt.zero_grad()
@@ -58,7 +59,7 @@ class DeepAtlasJointStep:
         warped_seg, _ = ops.WarpFn.apply(onehot_m, disp)
         l_sim = self.ncc(warped, im_t)
         l_reg = self.bend(disp)
-        l_anat = self.dice_prob(warped_seg, onehot_t)
+        l_anat = self.dice_prob(warped_seg, seg_t)
         loss_r = lam['sim'] * l_sim + lam['reg'] * l_reg + lam['anat'] * l_anat
         loss_r.backward()
         parallel.allreduce_gradients(self.reg_opt)
@@ -71,7 +72,7 @@ class DeepAtlasJointStep:
         l_sp = self.dice_logits(logits, seg_m)
         prob = ops.SoftmaxFn.apply(logits)
         warped_prob, _ = ops.WarpFn.apply(prob, disp)
-        l_anat2 = self.dice_prob(warped_prob, onehot_t)
+        l_anat2 = self.dice_prob(warped_prob, seg_t)
         loss_s = lam['sp'] * l_sp + lam['anat'] * l_anat2
         loss_s.backward()
         parallel.allreduce_gradients(self.seg_opt)
