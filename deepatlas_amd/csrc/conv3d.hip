@@ -337,7 +337,7 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
         return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
                                  N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
     }
-    if (!force_direct() && da_conv3_thin_supported(C1, C2, Cout, stride) && !(C1 + C2 <= 2 && (Cout == 8 || Cout == 16))) {
+    if (!force_direct() && da_conv3_thin_supported(C1, C2, Cout, stride) && !getenv("DA_NO_THIN")) {
         const int rc = da_conv3_thin_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope, st);
         if (rc != DA_ERR_UNSUPPORTED) return rc;
     }

@@ -413,10 +413,10 @@ struct ThinP {
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, flip_tr; float slope;
 };
 
-template <int CL, int CT>
+template <int CL, int CT, int VPT>
 __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int TZ = 4, HZ = TZ + 2, HVOX = HZ * HY * HX;
+    constexpr int TZ = 2 * VPT, HZ = TZ + 2, HVOX = HZ * HY * HX;
     int t = blockIdx.x;
     const int tx = t % p.ntx; t /= p.ntx;
     const int ty = t % p.nty; t /= p.nty;
@@ -424,11 +424,21 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const int Cin = p.C1 + p.C2;
     const int nchunks = (Cin + CL - 1) / CL;
-    // this thread's two output voxels: (lz, ly, lx) and (lz + 2, ly, lx)
+    const int CinP = nchunks * CL;
+    // weights -> LDS once per workgroup, zero padded to [27][CinP][CT] so the inner loops carry no channel predicates
+    float* wl = lds + HVOX * CL;
+    for (int idx = threadIdx.x; idx < 27 * CinP * CT; idx += 256) {
+        const int j = idx % CT; const int r = idx / CT; const int ci = r % CinP; const int tap = r / CinP;
+        float v = 0.f;
+        if (ci < Cin && j < p.Cout)
+            v = p.flip_tr ? p.w[((size_t)(26 - tap) * p.Cout + j) * Cin + ci] : p.w[((size_t)tap * Cin + ci) * p.Cout + j];
+        wl[idx] = v;
+    }
+    // this thread's output voxels: (lz + 2 v, ly, lx), v < VPT
     const int lx = threadIdx.x & 15, ly = (threadIdx.x >> 4) & 7, lz = threadIdx.x >> 7;
-    float acc[2][CT];
+    float acc[VPT][CT];
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < VPT; ++v)
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[v][j] = (p.bias && j < p.Cout) ? p.bias[j] : 0.f;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -439,53 +449,89 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
         const long long sample = (long long)p.D * p.H * p.W * Cs;
         const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
         __syncthreads();
-        for (int idx = threadIdx.x; idx < HVOX * CL; idx += 256) {
-            const int c = idx % CL; const int hv = idx / CL;
-            const int hx = hv % HX; const int tt = hv / HX;
-            const int hy = tt % HY; const int hz = tt / HY;
-            const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool inb = c < cvalid && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + c) * 4);
-            lds[idx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, inb ? off : 0xFFFFFFFFu, 0, 0));
+        if (CL % 4 == 0 && cvalid == CL && Cs % 4 == 0) {                   // 16-byte staging
+            constexpr int Q = CL / 4 > 0 ? CL / 4 : 1;
+            for (int idx = threadIdx.x; idx < HVOX * Q; idx += 256) {
+                const int q = idx % Q; const int hv = idx / Q;
+                const int hx = hv % HX; const int tt = hv / HX;
+                const int hy = tt % HY; const int hz = tt / HY;
+                const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + q * 4) * 4);
+                *reinterpret_cast<float4*>(lds + idx * 4) = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < HVOX * CL; idx += 256) {
+                const int c = idx % CL; const int hv = idx / CL;
+                const int hx = hv % HX; const int tt = hv / HX;
+                const int hy = tt % HY; const int hz = tt / HY;
+                const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool inb = c < cvalid && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + c) * 4);
+                lds[idx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, inb ? off : 0xFFFFFFFFu, 0, 0));
+            }
         }
         __syncthreads();
 #pragma unroll 1
-        for (int tap = 0; tap < 27; ++tap) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const float* a0 = lds + (((lz + dz) * HY + (ly + dy)) * HX + (lx + dx)) * CL;
-            const float* a1 = a0 + 2 * HY * HX * CL;
-            float xa[CL], xb[CL];
+        for (int dz = 0; dz < 3; ++dz) {
 #pragma unroll
-            for (int c = 0; c < CL; c += 4) {
-                const float4 u = *reinterpret_cast<const float4*>(a0 + c), v = *reinterpret_cast<const float4*>(a1 + c);
-                xa[c] = u.x; xa[c + 1] = u.y; xa[c + 2] = u.z; xa[c + 3] = u.w;
-                xb[c] = v.x; xb[c + 1] = v.y; xb[c + 2] = v.z; xb[c + 3] = v.w;
-            }
+            for (int dyx = 0; dyx < 9; ++dyx) {
+                const int dy = dyx / 3, dx = dyx % 3;
+                const float* a0 = lds + (((lz + dz) * HY + (ly + dy)) * HX + (lx + dx)) * CL;
+                const float* wt = wl + ((dz * 9 + dyx) * CinP + cbase) * CT;
+                float xs[VPT][CL];
 #pragma unroll
-            for (int c = 0; c < CL; ++c) {
-                if (c < cvalid) {
-                    const int ci = cbase + c;
+                for (int v = 0; v < VPT; ++v) {
+                    const float* av = a0 + v * 2 * HY * HX * CL;
+                    if constexpr (CL % 4 == 0) {
 #pragma unroll
-                    for (int j = 0; j < CT; ++j) {
-                        if (j < p.Cout) {
-                            const float wv = p.flip_tr ? p.w[((size_t)(26 - tap) * p.Cout + j) * Cin + ci] : p.w[((size_t)tap * Cin + ci) * p.Cout + j];
-                            acc[0][j] += xa[c] * wv; acc[1][j] += xb[c] * wv;
+                        for (int c = 0; c < CL; c += 4) {
+                            const float4 u = *reinterpret_cast<const float4*>(av + c);
+                            xs[v][c] = u.x; xs[v][c + 1] = u.y; xs[v][c + 2] = u.z; xs[v][c + 3] = u.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CL; ++c) xs[v][c] = av[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CL; ++c) {
+#pragma unroll
+                    for (int j = 0; j < CT; j += 4) {
+                        const float4 wv = *reinterpret_cast<const float4*>(wt + c * CT + j);
+#pragma unroll
+                        for (int v = 0; v < VPT; ++v) {
+                            acc[v][j] += xs[v][c] * wv.x; acc[v][j + 1] += xs[v][c] * wv.y;
+                            acc[v][j + 2] += xs[v][c] * wv.z; acc[v][j + 3] += xs[v][c] * wv.w;
                         }
                     }
                 }
             }
         }
     }
+    const bool vec = (p.Cs1 % 4 == 0) && (p.Cs2 % 4 == 0) && (p.Cout % 4 == 0);
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < VPT; ++v) {
         const int z = z0 + lz + 2 * v, y = y0 + ly, x = x0 + lx;
         if (z >= p.D || y >= p.H || x >= p.W) continue;
         const long long vox = (((long long)n * p.D + z) * p.H + y) * p.W + x;
+        if (vec) {
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            if (j < p.Cout) {
-                const float o = da_act(acc[v][j], p.slope);
-                if (j < p.Cs1) p.out1[vox * p.Cs1 + j] = o; else p.out2[vox * p.Cs2 + (j - p.Cs1)] = o;
+            for (int j = 0; j < CT; j += 4) {
+                if (j < p.Cout) {
+                    const float4 o = make_float4(da_act(acc[v][j], p.slope), da_act(acc[v][j + 1], p.slope),
+                                                 da_act(acc[v][j + 2], p.slope), da_act(acc[v][j + 3], p.slope));
+                    float* dst = j < p.Cs1 ? p.out1 + vox * p.Cs1 + j : p.out2 + vox * p.Cs2 + (j - p.Cs1);
+                    *reinterpret_cast<float4*>(dst) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                if (j < p.Cout) {
+                    const float o = da_act(acc[v][j], p.slope);
+                    if (j < p.Cs1) p.out1[vox * p.Cs1 + j] = o; else p.out2[vox * p.Cs2 + (j - p.Cs1)] = o;
+                }
             }
         }
     }
@@ -963,8 +1009,28 @@ bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride) {
     const int Cin = C1 + C2;
     if (stride != 1) return false;
     if (Cout <= 4 && Cin >= 8 && Cin <= 64 && C1 % 8 == 0 && C2 % 8 == 0) return true;     // few outputs (flow forward)
-    if (Cin <= 4 && Cout >= 8 && Cout <= 32) return true;                                   // few inputs (flow data gradient)
+    if (Cin <= 4 && Cout >= 8 && Cout <= 32) return true;                        // few inputs (flow data gradient, first encoder)
     return false;
+}
+
+template <int CL, int CT, int VPT>
+static void thin_launch(ThinP& p, hipStream_t st) {
+    const int Cin = p.C1 + p.C2;
+    const int CinP = (Cin + CL - 1) / CL * CL;
+    const size_t ldsb = ((size_t)(2 * VPT + 2) * HY * HX * CL + (size_t)27 * CinP * CT) * sizeof(float);
+    p.ntz = (p.D + 2 * VPT - 1) / (2 * VPT);
+    p.ntiles = p.N * p.ntz * p.nty * p.ntx;
+    hipLaunchKernelGGL((conv3_thin_kernel<CL, CT, VPT>), dim3(p.ntiles), dim3(256), ldsb, st, p);
+}
+
+template <int CL>
+static int thin_few_inputs(ThinP& p, hipStream_t st) {
+    if (p.Cout <= 8) thin_launch<CL, 8, 4>(p, st);
+    else if (p.Cout <= 16) thin_launch<CL, 16, 4>(p, st);
+    else if (p.Cout <= 24) thin_launch<CL, 24, 4>(p, st);
+    else if (p.Cout <= 32) thin_launch<CL, 32, 2>(p, st);
+    else return DA_ERR_UNSUPPORTED;
+    return 0;
 }
 
 int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
@@ -973,19 +1039,15 @@ int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const 
     ThinP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.Cs1 = Cs1; p.Cs2 = Cs2;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.flip_tr = flip_tr; p.slope = slope;
-    p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX; p.ntiles = N * p.ntz * p.nty * p.ntx;
+    p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     const int Cin = C1 + C2;
-    if (Cout <= 4) {
-        hipLaunchKernelGGL((conv3_thin_kernel<8, 4>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 8 * sizeof(float), st, p);
-    } else if (Cin <= 4 && Cout <= 8) {
-        hipLaunchKernelGGL((conv3_thin_kernel<4, 8>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
-    } else if (Cin <= 4 && Cout <= 16) {
-        hipLaunchKernelGGL((conv3_thin_kernel<4, 16>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
-    } else if (Cin <= 4 && Cout <= 24) {
-        hipLaunchKernelGGL((conv3_thin_kernel<4, 24>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
-    } else if (Cin <= 4 && Cout <= 32) {
-        hipLaunchKernelGGL((conv3_thin_kernel<4, 32>), dim3(p.ntiles), dim3(256), (size_t)6 * HY * HX * 4 * sizeof(float), st, p);
-    } else return DA_ERR_UNSUPPORTED;
+    int rc = 0;
+    if (Cout <= 4) thin_launch<8, 4, 2>(p, st);
+    else if (Cin == 1 || (Cin <= 4 && C2 > 0)) rc = thin_few_inputs<1>(p, st);      // CL = 1 splits cleanly at the concat boundary
+    else if (Cin == 2 && (C2 == 0)) rc = thin_few_inputs<2>(p, st);
+    else if (Cin <= 4 && C2 == 0) rc = thin_few_inputs<4>(p, st);
+    else return DA_ERR_UNSUPPORTED;
+    if (rc) return rc;
     DA_LAUNCH_CHECK();
     return 0;
 }
