@@ -157,6 +157,38 @@ __global__ void warp_bwd_kernel(const float* __restrict__ dout, const float* __r
     }
 }
 
+// d_src only, one lane per channel: a wave instruction adds whole 4*C-byte voxel rows (64/C voxels per instruction), so the
+// atomic units see full lines instead of every fourth dword.  Trilinear weights are recomputed per lane (cheap next to the
+// 8 atomics); gOut is read fully coalesced.
+__global__ void warp_bwd_dsrc_lane_kernel(const float* __restrict__ dout, const float* __restrict__ disp, float* __restrict__ d_src,
+                                          int N, int D, int H, int W, int C) {
+    const long long total = (long long)N * D * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long v = i / C;
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int d = (int)(r % D); const int n = (int)(r / D);
+        const float gx = disp[v * 3 + 0] + id_coord(w, W);
+        const float gy = disp[v * 3 + 1] + id_coord(h, H);
+        const float gz = disp[v * 3 + 2] + id_coord(d, D);
+        if (!is_finite_coord(gx, gy, gz)) continue;
+        const Taps t = make_taps(gx, gy, gz, D, H, W);
+        const float g = dout[i];
+        float* base = d_src + (long long)n * D * H * W * C + c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                atomicAdd(base + (((long long)z * H + y) * W + x) * C, wgt * g);
+            }
+        }
+    }
+}
+
 __global__ void identity_grid_kernel(float* __restrict__ out, int D, int H, int W, int normalize) {
     const long long V = (long long)D * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long long)gridDim.x * blockDim.x) {
@@ -195,6 +227,12 @@ extern "C" int da_warp_bwd(const float* dout, const float* src, const float* dis
     if (!dout || !src || !disp || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
     if (!d_disp && !d_src) return 0;
     int lpv; const bool v4 = vec_ok(C, &lpv);
+    if (d_src && C >= 8 && C <= 64 && 64 % C == 0) {
+        const long long tot = (long long)N * D * H * W * C;
+        hipLaunchKernelGGL(warp_bwd_dsrc_lane_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, da_stream(stream), dout, disp, d_src, N, D, H, W, C);
+        d_src = nullptr;
+        if (!d_disp) { DA_LAUNCH_CHECK(); return 0; }
+    }
     const long long total = (long long)N * D * H * W * lpv;
     // block = 256 and gridDim*256 are multiples of lpv (<= 64), so the lanes of one voxel share a wave and a trip count
     if (v4) hipLaunchKernelGGL((warp_bwd_kernel<4>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), dout, src, disp, d_disp, d_src, N, D, H, W, C, lpv);
