@@ -179,8 +179,20 @@ def main():
                             frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                             kernel='%s%s' % (key[0], list(key[1][:8])), avg_ms=round(ms / ncalls, 4), launches=ncalls,
                             flops_per_launch=fl,
+                            traffic_source=None,
                             all_conv3d=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
                                             frac_of_step=round(tot_ms / args.steps / ms_per_step, 3)))
+        if roofline is not None:
+            # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_conv.sh -> tools/pmc_summary.py):
+            # FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape
+            try:
+                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+                rec = json.load(open(pj))['calls'].get(roofline['kernel'])
+                if rec:
+                    roofline['traffic'] = rec['traffic_bytes']
+                    roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json (algorithmic %d B)' % rec['algorithmic_bytes']
+            except (OSError, ValueError, KeyError):
+                pass
         line = dict(metric='training volumes/sec at 160x192x160 fp32; Dice vs CPU ref', value=round(value, 4), unit='volumes/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',

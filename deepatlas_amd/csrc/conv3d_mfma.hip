@@ -95,11 +95,47 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// XCD-aware tile walk.  Workgroup b lands on XCD b % 8 (round-robin dispatch) and each XCD has its own 4 MiB L2, so the tiles
+// that are resident at the same time on one XCD should be spatial neighbours: the halo voxels they share are then fetched from
+// HBM once instead of once per tile.  Tiles are therefore ordered brick by brick (BX x BY x BZ tiles, ragged at the volume
+// edge), every XCD owns one contiguous eighth of that order, and its J workgroups walk it interleaved (step k: positions
+// lo + k J + j), i.e. at any moment an XCD works on ~J consecutive positions = one or two bricks.
+// ---------------------------------------------------------------------------------------------------
+struct TileWalk { int lo, J, cnt; };
+
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+    const int G = gridDim.x, b = blockIdx.x;
+    const int X = (G % 8 == 0) ? 8 : 1;
+    const int J = G / X, xcd = b % X, j = b / X;
+    const int lo = (int)((long long)ntiles * xcd / X), hi = (int)((long long)ntiles * (xcd + 1) / X);
+    TileWalk w;
+    w.lo = lo + j; w.J = J;
+    w.cnt = (hi - lo > j) ? (hi - lo - j + J - 1) / J : 0;
+    return w;
+}
+
+template <int BX, int BY, int BZ>
+__device__ __forceinline__ void brick_tile(int pos, int ntx, int nty, int ntz, int& n, int& tx, int& ty, int& tz) {
+    const int per_sample = ntx * nty * ntz;
+    n = pos / per_sample; int r = pos - n * per_sample;
+    const int zb = r / (BZ * nty * ntx); r -= zb * (BZ * nty * ntx);
+    const int sz = min(BZ, ntz - zb * BZ);
+    const int yb = r / (sz * BY * ntx); r -= yb * (sz * BY * ntx);
+    const int sy = min(BY, nty - yb * BY);
+    const int xb = r / (sz * sy * BX); r -= xb * (sz * sy * BX);
+    const int sx = min(BX, ntx - xb * BX);
+    const int lx = r % sx; r /= sx;
+    const int ly = r % sy; const int lz = r / sy;
+    tx = xb * BX + lx; ty = yb * BY + ly; tz = zb * BZ + lz;
+}
+
 struct FwdP {
     const float* in1; const float* in2; int C1, C2;
     const float* wp; const float* bias;
     float* out1; float* out2; int Cs1, Cs2;
-    int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles, tiles_per_block;
+    int N, D, H, W, Cout, NT, ntz, nty, ntx, ntiles, nblocks;
     float slope;
     unsigned masks[16]; int maskmode;   // tap masks (stride-2 via space-to-depth): 0 none, 1 per channel chunk, 2 per blockIdx.y
     double* stats_partial;              // optional [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the (pre-activation) output
@@ -120,10 +156,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     const int i = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NREP;
     const int nchunks = (p.C1 + p.C2) / CK;
-    // persistent: this workgroup owns tiles [tile_begin, tile_end); work item = (tile, channel chunk)
-    const int tile_begin = blockIdx.x * p.tiles_per_block;
-    int tile_end = tile_begin + p.tiles_per_block; if (tile_end > p.ntiles) tile_end = p.ntiles;
-    const int nitems = (tile_end - tile_begin) * nchunks;
+    // persistent: this workgroup walks its share of the brick-ordered tile list; work item = (tile, channel chunk)
+    const TileWalk tw = tile_walk(p.ntiles);
+    const int nitems = tw.cnt * nchunks;
     if (nitems <= 0) {
         if (STATS) for (int c = threadIdx.x; c < NREP * 16; c += 256) { const int co = blockIdx.y * NREP * 16 + c; if (co < p.Cout) { p.stats_partial[((size_t)blockIdx.x * 2) * p.Cout + co] = 0.0; p.stats_partial[((size_t)blockIdx.x * 2 + 1) * p.Cout + co] = 0.0; } }
         return;
@@ -131,10 +166,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 
     auto item_coords = [&](int item, int& n, int& z0, int& y0, int& x0, int& ch) {
         ch = item % nchunks;
-        int t = tile_begin + item / nchunks;
-        const int tx = t % p.ntx; t /= p.ntx;
-        const int ty = t % p.nty; t /= p.nty;
-        const int tz = t % p.ntz; n = t / p.ntz;
+        int tx, ty, tz;
+        brick_tile<2, 4, 8>(tw.lo + (item / nchunks) * tw.J, p.ntx, p.nty, p.ntz, n, tx, ty, tz);   // brick = 32^3 voxels
         x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
     };
     auto issue_stage = [&](int item, float4* pre) {          // iterations [0, PRE)
@@ -605,17 +638,15 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         for (int k = 0; k < TPW; ++k) live[k] = !MASKED || (((msk >> (wave + 4 * k)) & 1u) != 0 && wave + 4 * k < 27);
     }
 
-    const int tile_begin = blockIdx.x * p.tiles_per_slab;
-    int tile_end = tile_begin + p.tiles_per_slab; if (tile_end > p.ntiles) tile_end = p.ntiles;
+    const TileWalk tw = tile_walk(p.ntiles);
+    const int tile_begin = 0, tile_end = tw.cnt;             // walk index k; tile = brick order position tw.lo + k * tw.J
     constexpr int NITA = StageGeom<CK, HZ>::NIT;
     constexpr int QY = CG / 4, NITY = (TVOX * QY + 255) / 256;
     float4 preA[NITA], preY[NITY];
     static_assert(!YS || NREP == 1, "scalar dY staging is only instantiated for one cout tile");
     auto tile_coords = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-        int t = tile;
-        const int tx = t % p.ntx; t /= p.ntx;
-        const int ty = t % p.nty; t /= p.nty;
-        const int tz = t % p.ntz; n = t / p.ntz;
+        int tx, ty, tz;
+        brick_tile<2, 4, 16>(tw.lo + tile * tw.J, p.ntx, p.nty, p.ntz, n, tx, ty, tz);               // brick = 32^3 voxels
         x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
     };
     auto issue_loads = [&](int tile) {
@@ -904,8 +935,9 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout) {
     long long slabs = 512 / (q.nchunks * q.ngroups); if (slabs < 1) slabs = 1;      // one resident round: 2 workgroups / CU
     const long long cap = (long long)((96ull << 20) / (O * 4)); if (slabs > cap) slabs = cap < 1 ? 1 : cap;
     if (slabs > q.ntiles) slabs = q.ntiles;
+    if (slabs >= 8) slabs &= ~7ll;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
     q.tps = (int)da_cdiv(q.ntiles, slabs);
-    q.nslabs = (int)da_cdiv(q.ntiles, q.tps);
+    q.nslabs = (int)slabs;
     q.partial_bytes = da_align((size_t)q.nslabs * O * sizeof(float));
     return q;
 }
@@ -941,7 +973,7 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block, gy), dim3(256), shm, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.nblocks, gy), dim3(256), shm, st, p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -979,12 +1011,13 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     {   // one resident round: 2 workgroups per CU x 256 CUs, split over the cout groups
         static int nres = -1; if (nres < 0) { const char* e = getenv("DA_FWD_BLOCKS"); nres = e ? atoi(e) : 512; }
         int nblk = nres / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
-        p.tiles_per_block = (p.ntiles + nblk - 1) / nblk;
+        if (nblk >= 8) nblk &= ~7;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
+        p.nblocks = nblk;
     }
     p.stats_partial = stats_partial;
     if (stats_nparts) *stats_nparts = 0;
     if (stats_partial && p.maskmode == 0 && (CK == 16 || CK == 8) && NREP <= 2) {
-        if (stats_nparts) *stats_nparts = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
+        if (stats_nparts) *stats_nparts = p.nblocks;
         if (CK == 16 && NREP == 1) return launch_fwd_mfma<16, 1, false, true>(p, gy, st);
         if (CK == 16 && NREP == 2) return launch_fwd_mfma<16, 2, false, true>(p, gy, st);
         if (CK == 8 && NREP == 1) return launch_fwd_mfma<8, 1, false, true>(p, gy, st);
