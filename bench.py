@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0
 def conv_flops(key):
     """Algorithmic FLOPs of one da_conv3d_k3_* call from its integer arguments (2*27*Cin*Cout per output voxel)."""
     name, a = key
-    if name == 'da_conv3d_k3_fwd':      # C1, C2, N, D, H, W, Cout, stride
+    if name in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'):      # C1, C2, N, D, H, W, Cout, stride
         C1, C2, N, D, H, W, Cout, stride = a[:8]
     elif name == 'da_conv3d_k3_dgrad':  # C1, C2, N, D, H, W, Cout, stride
         C1, C2, N, D, H, W, Cout, stride = a[:8]
@@ -143,7 +143,7 @@ def main():
         step()
     prof = None
     if not args.no_profile:
-        prof = nat.CallProfiler(['da_conv3d_k3_fwd', 'da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'])
+        prof = nat.CallProfiler(['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
