@@ -404,3 +404,61 @@ def test_full_size_conv_linearity_and_adjointness():
     via_wgrad = float((w.double() * wg.grad.double()).sum())
     assert abs(inner - via_dgrad) <= 1e-4 * abs(inner) + 1e-2, (inner, via_dgrad)
     assert abs(inner - via_wgrad) <= 1e-4 * abs(inner) + 1e-2, (inner, via_wgrad)
+
+
+def _prim():
+    """oracle/prim.c (plain C, double accumulation): an ATen-independent checker.  Prebuilt by __graft_entry__.build()."""
+    import ctypes, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so, src = os.path.join(root, 'oracle', 'libprim.so'), os.path.join(root, 'oracle', 'prim.c')
+    if not os.path.isfile(so):
+        subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-std=c99', src, '-lm', '-o', so])
+    lib = ctypes.CDLL(so)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.prim_conv3d_k3.argtypes = [P, P, P, P, I, I, I, I, I, I, I]; lib.prim_conv3d_k3.restype = None
+    lib.prim_deconv_k2s2.argtypes = [P, P, P, P, I, I, I, I, I, I]; lib.prim_deconv_k2s2.restype = None
+    lib.prim_grid_sample3d.argtypes = [P, P, P, I, I, I, I, I, I, I, I]; lib.prim_grid_sample3d.restype = None
+    return lib
+
+
+def _np_ptr(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize('case', [(32, 16, 16, 1, (1, 8, 9, 20)), (16, 0, 32, 2, (1, 9, 10, 11)), (8, 16, 3, 1, (1, 6, 8, 18)),
+                                  (1, 1, 16, 1, (1, 6, 8, 10)), (3, 0, 24, 1, (1, 5, 9, 17))],
+                         ids=lambda c: 'c%d+%d_o%d_s%d' % c[:4])
+def test_conv3d_vs_c_oracle(case):
+    """HIP forward against the plain-C double-accumulation conv (no ATen on either side)."""
+    from deepatlas_amd import ops
+    C1, C2, Cout, stride, (N, D, H, W) = case
+    x1 = rnd((N, C1, D, H, W), 11)
+    x2 = rnd((N, C2, D, H, W), 12) if C2 else None
+    w, b = rnd((Cout, C1 + C2, 3, 3, 3), 13, 0.2), rnd((Cout,), 14, 0.1)
+    xin = np.ascontiguousarray((torch.cat((x1, x2), 1) if C2 else x1).numpy())
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    yr = np.empty((N, Cout, Do, Ho, Wo), np.float32)
+    wn, bn = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(b.numpy())
+    _prim().prim_conv3d_k3(_np_ptr(xin), _np_ptr(wn), _np_ptr(bn), _np_ptr(yr), N, C1 + C2, D, H, W, Cout, stride)
+    yg = ops.Conv3dK3Fn.apply(cl(x1), cl(x2) if C2 else None, w.to(dev()), b.to(dev()), stride, -1.0)
+    check(yg, yr, tol=1e-5, what='fwd vs prim.c')
+
+
+def test_deconv_and_warp_vs_c_oracle():
+    from deepatlas_amd import ops
+    N, Cin, Cout, D, H, W = 1, 32, 32, 3, 4, 6
+    x, w, b = rnd((N, Cin, D, H, W), 21), rnd((Cin, Cout, 2, 2, 2), 22, 0.3), rnd((Cout,), 23, 0.1)
+    yr = np.empty((N, Cout, 2 * D, 2 * H, 2 * W), np.float32)
+    xn, wn, bn = (np.ascontiguousarray(t.numpy()) for t in (x, w, b))
+    _prim().prim_deconv_k2s2(_np_ptr(xn), _np_ptr(wn), _np_ptr(bn), _np_ptr(yr), N, Cin, D, H, W, Cout)
+    check(ops.DeconvK2S2Fn.apply(cl(x), w.to(dev()), b.to(dev())), yr, tol=1e-5, what='deconv vs prim.c')
+    # warp: identity + displacement, sampled by the C grid_sample
+    N, C, D, H, W = 1, 8, 6, 9, 11
+    src, disp = rnd((N, C, D, H, W), 24), rnd((N, 3, D, H, W), 25, 0.5)
+    out, deform = ops.WarpFn.apply(cl(src), cl(disp))
+    grid = np.ascontiguousarray(deform.detach().cpu().permute(0, 2, 3, 4, 1).contiguous().numpy())
+    sn = np.ascontiguousarray(src.numpy())
+    wr = np.empty_like(sn)
+    _prim().prim_grid_sample3d(_np_ptr(sn), _np_ptr(grid), _np_ptr(wr), N, C, D, H, W, D, H, W)
+    check(out, wr, tol=1e-5, what='warp vs prim.c')
