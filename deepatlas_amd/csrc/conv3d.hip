@@ -379,7 +379,7 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
     if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)) return DA_ERR_WS_SMALL;
     if (stride == 1) {
         // dX = conv(dY, flip/transpose(W)) : Cin' = Cout, Cout' = Cin, output split over (dx1, dx2)
-        if (!force_direct() && da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1)) {
+        if (!force_direct() && da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) {
             return da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, dx1, C1, dx2, C2,
                                      N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, st);
         }

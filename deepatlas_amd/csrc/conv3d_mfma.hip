@@ -95,6 +95,47 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
     }
 }
 
+// The same staging loads, one at a time: a cursor that carries the incremental (hz, hy, hx) decomposition so the loads of the
+// NEXT work item can be spread over the K-steps of the current one.  `valid` = false turns every offset out of range (zeros, no
+// memory traffic), so the loads are issued on every item without a branch around them and hipcc's vmcnt bookkeeping stays exact.
+template <int CK, int HZ> struct StageCursor {
+    __amdgpu_buffer_rsrc_t rs;
+    int hv, hx, hy, hz, cofs;
+    int z0, y0, x0, D, H, W, Cs;
+    bool valid;
+    __device__ __forceinline__ void init(const float* __restrict__ src, int Cs_, int choff, int n, int z0_, int y0_, int x0_,
+                                         int D_, int H_, int W_, bool valid_) {
+        constexpr int Q = StageGeom<CK, HZ>::Q;
+        const long long sample = (long long)D_ * H_ * W_ * Cs_;
+        rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+        int idx = threadIdx.x;
+        asm volatile("" : "+v"(idx));
+        const int c4 = idx % Q; hv = idx / Q;
+        hx = hv % HX; const int t = hv / HX;
+        hy = t % HY; hz = t / HY;
+        cofs = choff + c4 * 4;
+        z0 = z0_; y0 = y0_; x0 = x0_; D = D_; H = H_; W = W_; Cs = Cs_; valid = valid_;
+    }
+    __device__ __forceinline__ float4 next() {
+        constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
+        constexpr int STEP = 256 / Q;
+        constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
+        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool inb = valid && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
+        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * 4);
+        const float4 v = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        hv += STEP;
+        hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
+        hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
+        hz += SZ + cy;
+        return v;
+    }
+};
+__device__ __forceinline__ void da_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, byte_off, 0, 0);
+}
+template <bool B> struct BoolC { static constexpr bool value = B; };
+
 
 // ---------------------------------------------------------------------------------------------------
 // XCD-aware tile walk.  Workgroup b lands on XCD b % 8 (round-robin dispatch) and each XCD has its own 4 MiB L2, so the tiles
@@ -139,6 +180,7 @@ struct FwdP {
     float slope;
     unsigned masks[16]; int maskmode;   // tap masks (stride-2 via space-to-depth): 0 none, 1 per channel chunk, 2 per blockIdx.y
     double* stats_partial;              // optional [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the (pre-activation) output
+    unsigned long long* clk;
     int ablate;      // diagnostic only (env DA_ABLATE): 1 skip staging loads, 2 skip epilogue stores, 4 skip LDS writes+barriers, 8 skip MFMAs
 };
 
@@ -155,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NREP;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     const int nchunks = (p.C1 + p.C2) / CK;
     // persistent: this workgroup walks its share of the brick-ordered tile list; work item = (tile, channel chunk)
     const TileWalk tw = tile_walk(p.ntiles);
@@ -258,25 +301,49 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         return (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK;
     };
 
+    // ---- vector-memory scheduling.  vmcnt retires IN ORDER on gfx9 and counts stores as well as loads, and the CU's vector
+    // memory pipe is a FIFO shared by both resident workgroups.  A B fragment requested behind a 69 KB staging burst (or behind
+    // the epilogue's stores) is therefore unusable until all of that has completed, which stalled every item by a memory
+    // latency or two (ablation: staging loads +10 %, epilogue stores +9 % of the kernel time, not overlapped with anything).
+    // So: (1) B fragments come through a buffer descriptor (scalar step offset, no VGPR address math) and are requested
+    // LB K-steps ahead in a register ring that runs across item boundaries (the first LB steps of the next item are requested
+    // before this item's epilogue stores); (2) the next item's staging loads are spread over the K-steps, at most one per step;
+    // (3) nothing that touches vector memory sits inside a branch: invalid work (no next item, not the last chunk, ragged
+    // lanes) is expressed as out-of-range buffer offsets, so hipcc's s_waitcnt vmcnt(N) stay exact instead of collapsing to 0.
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * 1024), 0x00020000);
+    auto wb = [&](int chunk, int step, int nn) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
+    };
+    constexpr int LB = (NREP == 1) ? 4 : (NREP == 2 ? 2 : 1);   // B lookahead in K-steps
+    constexpr int RB = LB + 1;                          // ring slots
+    constexpr int TAIL = 5;                             // K-steps at the end of an item without staging loads (they must land before stage_write)
+    f32x4 bq[RB][NREP], nb[LB][NREP];
+    if constexpr (!MASKED) {
+#pragma unroll
+        for (int t = 0; t < LB; ++t)
+#pragma unroll
+            for (int nn = 0; nn < NREP; ++nn) nb[t][nn] = wb(0, t, nn);     // item 0 is chunk 0
+    }
+    // bias of this lane's 4 couts after the epilogue transpose (constant for the whole launch)
+    const int q = lane & 3, a4 = (lane & 15) >> 2;
+    float bvv[NREP][4];
+#pragma unroll
+    for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int co = (nt0 + nn) * 16 + 4 * a4 + j; bvv[nn][j] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
+
 #pragma unroll 1
     for (int item = 0; item < nitems; ++item) {
         int n, z0, y0, x0, ch;
         item_coords(item, n, z0, y0, x0, ch);
         const bool has_next = item + 1 < nitems;
-        const f32x4* wch = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
-        f32x4 bcur[NREP];
-        // step-0 weights are requested BEFORE the staging burst: vmcnt retires in order, so a B load issued behind the
-        // NIT staging loads could not be consumed until all of them have landed
-#pragma unroll
-        for (int nn = 0; nn < NREP; ++nn) bcur[nn] = wch[(size_t)nn * 64];
-        if (has_next && !(p.ablate & 1)) issue_stage(item + 1, pre);           // global loads in flight during this item's MFMAs
+        const bool last = (ch == nchunks - 1);
 
-        // B fragments are fetched one K-step ahead (global, L1/L2 resident); A fragments come from LDS per step.
-        // MFMA order: component m outermost, M-tile r innermost -> 8*NREP independent accumulators between two uses
-        // of the same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
         if constexpr (MASKED) {
             // sparse tap set (a stride-2 conv expressed as a stride-1 conv over the space-to-depth input: a channel chunk
             // belongs to one input parity and only (1|2)^3 of the 27 taps are non-zero).  Staging-bound, so a plain loop.
+            const f32x4* wch = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
+            if (has_next && !(p.ablate & 1)) issue_stage(item + 1, pre);
             unsigned msk = p.masks[p.maskmode == 1 ? ch : (int)blockIdx.y];
             while (msk) {
                 const int sidx = __builtin_ctz(msk); msk &= msk - 1;
@@ -295,124 +362,142 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                             acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r][m], bb[nn][m], acc[r][nn], 0, 0, 0);
             }
         } else {
-        // CK = 16: 3 x 9 K-steps (outer tap-plane loop kept rolled: shorter scheduling regions, lower VGPR pressure);
-        // CK = 8: 14 K-steps, 2 x 7.  Each K-step is split into two half-steps of 4 M-tiles; the A fragments of the
-        // NEXT half-step are read from LDS while the current half-step's 16*NREP MFMAs issue (a 2 x 4-fragment double
-        // buffer = the same 32 VGPRs one full step of fragments needs), so no ds_read latency is exposed.
-        constexpr int SOUT = (CK == 16) ? 3 : 2, SIN = NSTEPS / SOUT, HALF = TY / 2;
-        auto step_ptr = [&](int so, int si) -> const float* {
-            if (CK == 16) return abase + so * (HY * HX * CK) + a_off(si);
-            return abase + a_off8(so * SIN + si);
-        };
+        // CK = 16: 27 K-steps; CK = 8: 14 (two taps per step), fully unrolled.  Each K-step is split into two half-steps of 4
+        // M-tiles; the A fragments of the NEXT half-step are read from LDS while the current half-step's 16*NREP MFMAs issue (a
+        // 2 x 4-fragment double buffer = the same 32 VGPRs one full step of fragments needs), so no ds_read latency is exposed.
+        // MFMA order: component m outermost, M-tile r innermost -> 4*NREP independent accumulators between two uses of the
+        // same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
+        constexpr int HALF = TY / 2;
+        auto step_ptr = [&](int s) -> const float* { return (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
+        const int ch_next = (ch + 1 == nchunks) ? 0 : ch + 1;
+#pragma unroll
+        for (int t = 0; t < LB; ++t)
+#pragma unroll
+            for (int nn = 0; nn < NREP; ++nn) bq[t % RB][nn] = nb[t][nn];
+        StageCursor<CK, HZ> cur;
+        {
+            int n2, z2, y2, x2, ch2;
+            item_coords(item + 1, n2, z2, y2, x2, ch2);
+            const int cbase = ch2 * CK;
+            const bool first = cbase < p.C1;
+            cur.init(first ? p.in1 : p.in2, first ? p.C1 : p.C2, first ? cbase : cbase - p.C1, n2, z2, y2, x2, p.D, p.H, p.W,
+                     has_next && !(p.ablate & 1));
+        }
         f32x4 A0[HALF], A1[HALF];
         {
-            const float* ap = step_ptr(0, 0);
+            const float* ap = step_ptr(0);
 #pragma unroll
             for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
         }
-#pragma unroll 1
-        for (int so = 0; so < ((p.ablate & 8) ? 0 : SOUT); ++so) {
 #pragma unroll
-            for (int si = 0; si < SIN; ++si) {
-                const int s = so * SIN + si;
-                int sn = s + 1; if (sn > NSTEPS - 1) sn = NSTEPS - 1;
-                f32x4 bnext[NREP];
+        for (int s = 0; s < NSTEPS; ++s) {
+            // weights of K-step s + LB (of this chunk, or of the next item's chunk)
 #pragma unroll
-                for (int nn = 0; nn < NREP; ++nn) bnext[nn] = wch[((size_t)sn * p.NT + nn) * 64];
-                const float* ap = step_ptr(so, si);
+            for (int nn = 0; nn < NREP; ++nn) {
+                if (s + LB < NSTEPS) bq[(s + LB) % RB][nn] = wb(ch, s + LB, nn);
+                else nb[s + LB - NSTEPS][nn] = wb(ch_next, s + LB - NSTEPS, nn);
+            }
+            // next item's staging loads scheduled on this step
 #pragma unroll
-                for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const f32x4*>(ap + (HALF + r) * (HX * CK));
+            for (int j = 0; j < PRE; ++j)
+                if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) pre[j] = cur.next();
+            const float* ap = step_ptr(s);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+            for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const f32x4*>(ap + (HALF + r) * (HX * CK));
 #pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn)
+            for (int m = 0; m < 4; ++m) {
 #pragma unroll
-                        for (int r = 0; r < HALF; ++r)
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bcur[nn][m], acc[r][nn], 0, 0, 0);
-                    if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
-                }
-                {   // first half of the next K-step (the last step re-reads its own, harmlessly)
-                    const float* an = (si + 1 < SIN) ? step_ptr(so, si + 1) : ((so + 1 < SOUT) ? step_ptr(so + 1, 0) : ap);
+                for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                    for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(an + r * (HX * CK));
-                }
+                    for (int r = 0; r < HALF; ++r)
+                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bq[s % RB][nn][m], acc[r][nn], 0, 0, 0);
+                if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // first half of the next K-step (the last step re-reads its own, harmlessly)
+                const float* an = (s + 1 < NSTEPS) ? step_ptr(s + 1) : ap;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(an + r * (HX * CK));
+            }
 #pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn)
+            for (int m = 0; m < 4; ++m) {
 #pragma unroll
-                        for (int r = 0; r < HALF; ++r)
-                            acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bcur[nn][m], acc[HALF + r][nn], 0, 0, 0);
-                    if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                for (int nn = 0; nn < NREP; ++nn) bcur[nn] = bnext[nn];
+                    for (int r = 0; r < HALF; ++r)
+                        acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bq[s % RB][nn][m], acc[HALF + r][nn], 0, 0, 0);
+                if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
             }
         }
         }
 
-        if (ch == nchunks - 1 && !(p.ablate & 2)) {
-            // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg.
-            // A 4x4 transpose across each lane quad (2 DPP butterfly stages) turns the fragment (4 voxels x 1 cout per lane)
-            // into (1 voxel x 4 couts per lane): one 16-byte store per M-tile, 1 KiB contiguous per wave instruction for
-            // Cout = 16.  Interior tiles store unconditionally (hipcc puts an s_waitcnt vmcnt(0) in front of every store that
-            // sits in its own exec-mask branch); ragged tiles predicate per lane.
+        // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg.
+        // A 4x4 transpose across each lane quad (2 DPP butterfly stages) turns the fragment (4 voxels x 1 cout per lane)
+        // into (1 voxel x 4 couts per lane): one 16-byte store per M-tile, 1 KiB contiguous per wave instruction for
+        // Cout = 16.  The arithmetic runs on the last chunk only; the STORES are issued on every item through a buffer
+        // descriptor, with the offset out of range (dropped by the hardware) when this is not the last chunk or the lane is
+        // outside the volume -- no vector-memory instruction sits in a branch (see above).
+        {
             const int z = z0 + wave;
-            const bool vec_ok = ((p.Cs1 & 3) == 0) && ((p.Cs2 & 3) == 0) && ((p.Cout & 3) == 0);
-            const bool full = (z0 + TZ <= p.D) && (y0 + TY <= p.H) && (x0 + TX <= p.W) && vec_ok;
-            const int q = lane & 3, a4 = (lane & 15) >> 2;
             const int x = x0 + 4 * g + q;
+            const bool do_ep = last && !(p.ablate & 2);
+            if (do_ep) {
 #pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) {
-                const int co0 = (nt0 + nn) * 16 + 4 * a4;          // first of this lane's 4 couts after the transpose
-                float bvv[4];
+                for (int nn = 0; nn < NREP; ++nn) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bvv[j] = (p.bias && co0 + j < p.Cout) ? p.bias[co0 + j] : 0.f;
-                float* dst; int Cd, cd;
-                if (co0 < p.Cs1) { dst = p.out1; Cd = p.Cs1; cd = co0; } else { dst = p.out2; Cd = p.Cs2; cd = co0 - p.Cs1; }
-#pragma unroll
-                for (int r = 0; r < TY; ++r) {
-                    float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];
-                    {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
-                        const bool odd = (q & 1) != 0;
-                        const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
-                        const float r01 = __shfl_xor(s01, 1), r23 = __shfl_xor(s23, 1);
-                        if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
-                    }
-                    {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
-                        const bool hi2 = (q & 2) != 0;
-                        const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
-                        const float r02 = __shfl_xor(s02, 2), r13 = __shfl_xor(s13, 2);
-                        if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
-                    }
-                    // now (t0..t3) = couts co0..co0+3 of voxel (z, y0 + r, x)
-                    const float v0 = t0 + bvv[0], v1 = t1 + bvv[1], v2 = t2 + bvv[2], v3 = t3 + bvv[3];
-                    const long long vox = (((long long)n * p.D + z) * p.H + (y0 + r)) * p.W + x;
-                    const bool vin = full || (z < p.D && y0 + r < p.H && x < p.W);
-                    if (STATS) {
-                        const float m = vin ? 1.f : 0.f;
-                        st1[nn][0] += m * v0; st1[nn][1] += m * v1; st1[nn][2] += m * v2; st1[nn][3] += m * v3;
-                        st2[nn][0] += m * v0 * v0; st2[nn][1] += m * v1 * v1; st2[nn][2] += m * v2 * v2; st2[nn][3] += m * v3 * v3;
-                    }
-                    const float4 o = make_float4(da_act(v0, p.slope), da_act(v1, p.slope), da_act(v2, p.slope), da_act(v3, p.slope));
-                    if (full) {
-                        if (co0 + 3 < p.Cout) *reinterpret_cast<float4*>(dst + vox * Cd + cd) = o;
-                    } else if (vin) {
-                        if (vec_ok && co0 + 3 < p.Cout) *reinterpret_cast<float4*>(dst + vox * Cd + cd) = o;
-                        else {
-                            const float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int co = co0 + j;
-                                if (co < p.Cout) { if (co < p.Cs1) p.out1[vox * p.Cs1 + co] = ov[j]; else p.out2[vox * p.Cs2 + (co - p.Cs1)] = ov[j]; }
-                            }
+                    for (int r = 0; r < TY; ++r) {
+                        float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];
+                        {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
+                            const bool odd = (q & 1) != 0;
+                            const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
+                            const float r01 = __shfl_xor(s01, 1), r23 = __shfl_xor(s23, 1);
+                            if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
                         }
+                        {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
+                            const bool hi2 = (q & 2) != 0;
+                            const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
+                            const float r02 = __shfl_xor(s02, 2), r13 = __shfl_xor(s13, 2);
+                            if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
+                        }
+                        // now (t0..t3) = couts co0..co0+3 of voxel (z, y0 + r, x)
+                        const float v0 = t0 + bvv[nn][0], v1 = t1 + bvv[nn][1], v2 = t2 + bvv[nn][2], v3 = t3 + bvv[nn][3];
+                        if (STATS) {
+                            const float m = (z < p.D && y0 + r < p.H && x < p.W) ? 1.f : 0.f;
+                            st1[nn][0] += m * v0; st1[nn][1] += m * v1; st1[nn][2] += m * v2; st1[nn][3] += m * v3;
+                            st2[nn][0] += m * v0 * v0; st2[nn][1] += m * v1 * v1; st2[nn][2] += m * v2 * v2; st2[nn][3] += m * v3 * v3;
+                        }
+                        acc[r][nn] = (f32x4){da_act(v0, p.slope), da_act(v1, p.slope), da_act(v2, p.slope), da_act(v3, p.slope)};
                     }
-                    acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
+#pragma unroll
+            for (int nn = 0; nn < NREP; ++nn) {
+                const int cb = (nt0 + nn) * 16;                    // this N-tile lies entirely in out1 or in out2 (Cs1 % 16 == 0 when split)
+                const bool first = cb < p.Cs1;
+                float* dbase = first ? p.out1 : p.out2;
+                const int Cd = first ? p.Cs1 : p.Cs2;
+                const int cd = cb - (first ? 0 : p.Cs1) + 4 * a4;
+                const long long sample = (long long)p.D * p.H * p.W * Cd;
+                const __amdgpu_buffer_rsrc_t ro = da_rsrc(dbase + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+                const bool cok = do_ep && (cb + 4 * a4 + 3 < p.Cout) && z < p.D && x < p.W;
+#pragma unroll
+                for (int r = 0; r < TY; ++r) {
+                    const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * Cd + cd) * 4);
+                    da_buf_store4(ro, (cok && y0 + r < p.H) ? off : 0xFFFFFFFFu, acc[r][nn]);
+                }
+            }
+            if (do_ep) {
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                    for (int r = 0; r < TY; ++r) acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else if (last) {                                       // ablated epilogue: still reset
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                    for (int r = 0; r < TY; ++r) acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
-        if (STATS && ch == nchunks - 1 && ((++tiles_done) & 1) == 0) stats_flush();
+        if (STATS && last && ((++tiles_done) & 1) == 0) stats_flush();
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
             stage_write<CK, HZ, 0, PRE>(lds, pre);
@@ -420,6 +505,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             __syncthreads();
         }
     }
+    if (p.clk && blockIdx.x == 17 && blockIdx.y == 0 && threadIdx.x == 0) { p.clk[0] = __builtin_readcyclecounter() - clk0; p.clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
     if constexpr (STATS) {
         stats_flush();
         if ((int)threadIdx.x < NREP * 16) {
@@ -956,10 +1042,15 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
     return pk + part;
 }
 
-bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride) {
+bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, int Cs2) {
     if (stride != 1) return false;
     if (pick_ck(C1, C2) == 0) return false;
     if (Cout < 8) return false;            // Cout = 3 (flow) wastes 13/16 of every MFMA: direct kernel is faster
+    // 16-byte epilogue stores through one buffer descriptor per N-tile: couts in quads, a split output on a tile boundary
+    if (Cout % 4 != 0) return false;
+    if (Cs1 < 0) { Cs1 = Cout; Cs2 = 0; }
+    if (Cs2 > 0 && (Cs1 % 16 != 0 || Cs2 % 4 != 0)) return false;
+    if ((unsigned long long)Cs1 % 4 != 0) return false;
     return true;
 }
 
@@ -973,7 +1064,11 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.nblocks, gy), dim3(256), shm, st, p);
+    static unsigned long long* dclk = nullptr; static int want = -1;
+    if (want < 0) { want = getenv("DA_CLK") ? 1 : 0; if (want) (void)hipMalloc(&dclk, 16); }
+    FwdP q = p; q.clk = want ? dclk : nullptr;
+    hipLaunchKernelGGL(kern, dim3(p.nblocks, gy), dim3(256), shm, st, q);
+    if (want) { unsigned long long h[2]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, dclk, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[clk] cycles %llu realtime %llu -> %.0f MHz\n", h[0], h[1], (double)h[0] / (double)h[1] * 100.0); }
     DA_LAUNCH_CHECK();
     return 0;
 }
