@@ -71,6 +71,7 @@ SIGNATURES = {
     'da_bending_fwd': (I, [P, I, I, I, I, P, I, P, P, SZ, P]),
     'da_bending_bwd': (I, [P, P, P, I, I, I, I, P, I, P]),
     'da_argmax_dice_counts': (I, [P, P, I, I, LL, I, P, P, P]),
+    'da_label_overlap_counts': (I, [P, I, P, I, I, LL, I, P, P]),
     'da_adam_step': (I, [P, P, P, P, LL, F, F, F, F, I, F, P]),
 }
 

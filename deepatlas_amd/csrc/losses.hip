@@ -537,6 +537,46 @@ __global__ void argmax_counts_kernel(const float* __restrict__ logits, const voi
     }
 }
 
+
+// Overlap counts of two LABEL maps (lib/evalMetrics.py:103-217, lib/loss.py:348-391 -- every metric there
+// is a function of |P==c|, |T==c|, |P==c & T==c|).  Each thread walks RUN consecutive voxels and merges runs of equal
+// (pred, truth) pairs in registers before touching the per-wave LDS histograms: anatomical label maps are piecewise constant,
+// so this removes most of the same-address LDS atomic serialisation.  Exact integer arithmetic; 64-bit global atomics.
+__global__ void label_overlap_counts_kernel(const void* __restrict__ pred, int pred_bytes, const void* __restrict__ truth, int truth_bytes,
+                                            long long V, int C, unsigned long long* __restrict__ counts) {
+    extern __shared__ unsigned int shc[];   // [4 waves][3][C]
+    constexpr int RUN = 16;
+    const int n = blockIdx.y;
+    for (int c = threadIdx.x; c < 4 * 3 * C; c += blockDim.x) shc[c] = 0u;
+    __syncthreads();
+    unsigned int* h = shc + (threadIdx.x >> 6) * 3 * C;
+    auto flush = [&](int pl, int tl, unsigned int len) {
+        if (len == 0u) return;
+        if (pl >= 0 && pl < C) atomicAdd(&h[pl], len);
+        if (tl >= 0 && tl < C) atomicAdd(&h[C + tl], len);
+        if (pl == tl && pl >= 0 && pl < C) atomicAdd(&h[2 * C + pl], len);
+    };
+    const long long nruns = (V + RUN - 1) / RUN;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += (long long)gridDim.x * blockDim.x) {
+        const long long v0 = r * RUN;
+        const int cnt = (int)((V - v0) < RUN ? (V - v0) : RUN);
+        int pl = -1, tl = -1; unsigned int len = 0u;
+        for (int k = 0; k < cnt; ++k) {
+            const long long row = (long long)n * V + v0 + k;
+            const int a = (int)load_label(pred, pred_bytes, row), b = (int)load_label(truth, truth_bytes, row);
+            if (a != pl || b != tl) { flush(pl, tl, len); pl = a; tl = b; len = 0u; }
+            ++len;
+        }
+        flush(pl, tl, len);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * C; c += blockDim.x) {
+        const unsigned int t = shc[c] + shc[3 * C + c] + shc[6 * C + c] + shc[9 * C + c];
+        const int k = c / C, cc = c % C;
+        if (t) atomicAdd(&counts[((size_t)n * C + cc) * 3 + k], (unsigned long long)t);
+    }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -674,6 +714,16 @@ extern "C" int da_argmax_dice_counts(const float* logits, const void* truth, int
     const long long total = V * (lpv > 0 ? lpv : 1);
     hipLaunchKernelGGL(argmax_counts_kernel, dim3(da_grid(total, 256, 1024), N), dim3(256), (size_t)3 * C * sizeof(unsigned int), da_stream(stream),
                        logits, truth, label_bytes, V, C, lpv, counts, pred);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_label_overlap_counts(const void* pred, int pred_bytes, const void* truth, int truth_bytes, int N, long long V, int C,
+                                       unsigned long long* counts, void* stream) {
+    if (!pred || !truth || !counts || N <= 0 || V <= 0 || C <= 0 || C > 1024 || (pred_bytes != 1 && pred_bytes != 8) || (truth_bytes != 1 && truth_bytes != 8))
+        return DA_ERR_BADARG;
+    hipLaunchKernelGGL(label_overlap_counts_kernel, dim3(da_grid((V + 15) / 16, 256, 1024), N), dim3(256), (size_t)4 * 3 * C * sizeof(unsigned int),
+                       da_stream(stream), pred, pred_bytes, truth, truth_bytes, V, C, counts);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -42,6 +42,34 @@ class DiceLossMultiClass(nn.Module):
                                                                                          shape[:1] + [1, ] + shape[2:]))
 
 
+class DiceLossOnLabel(nn.Module):
+    """lib/loss.py:348-391: Dice loss between two segmentation MASKS B x 1 x D x M x N (no gradient: labels), background
+    dropped.  scores = 2|S&T| w / (w (|S| + |T|) + eps), loss = 1 - mean.  One pass over the two label maps
+    (`da_label_overlap_counts`) instead of two materialised one-hot tensors."""
+
+    def __init__(self, n_class=None, eps=10e-6):
+        super(DiceLossOnLabel, self).__init__()
+        self.n_class = n_class
+        self.eps = eps
+
+    def forward(self, source, target, weight_type='Uniform', average=True):
+        assert source.shape == target.shape
+        if self.n_class is None:
+            self.n_class = int(max(int(target.max().item()), int(source.max().item()))) + 1
+        B = target.shape[0]
+        c = ops.label_overlap_counts(source.reshape(B, -1), target.reshape(B, -1), self.n_class)[:, 1:, :].to(torch.float32)
+        source_volume, target_volume, inter = c[..., 0], c[..., 1], c[..., 2]
+        if weight_type == 'Simple':
+            weights = target_volume.reciprocal()
+            weights = torch.where(torch.isinf(weights), torch.ones_like(weights), weights)
+        elif weight_type == 'Uniform':
+            weights = torch.ones(B, target.shape[1], device=c.device)
+        else:
+            raise ValueError("Class weighting type {} does not exists!".format(weight_type))
+        scores = (2. * inter * weights) / (weights * (source_volume + target_volume) + self.eps)
+        return 1 - scores.mean()
+
+
 class NormalizedCrossCorrelationLoss(nn.Module):
     """1 - NCC (lib/loss.py:485-501)."""
 

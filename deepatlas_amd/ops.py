@@ -648,3 +648,16 @@ def argmax_dice_counts(logits, truth):
     pred = torch.empty((N, V), dtype=torch.uint8, device=a.device)
     call('da_argmax_dice_counts', ptr(a), ptr(lab), nbytes, N, V, C, ptr(counts), ptr(pred), stream())
     return counts, pred.reshape((N,) + tuple(a.shape[1:4]))
+
+
+def label_overlap_counts(pred, truth, n_class):
+    """integer overlap counts of two label maps (any shape with a leading batch axis).
+    Returns counts[N][n_class][3] int64 = (|pred==c|, |truth==c|, |both|); labels outside [0, n_class) are ignored."""
+    N = pred.shape[0]
+    pl, pb = _labels(pred.reshape(N, -1))
+    tl, tb = _labels(truth.reshape(N, -1))
+    if pl.shape != tl.shape:
+        raise ValueError('pred and truth must have the same number of voxels per sample')
+    counts = torch.zeros((N, n_class, 3), dtype=torch.int64, device=pl.device)
+    call('da_label_overlap_counts', ptr(pl), pb, ptr(tl), tb, N, pl.shape[1], n_class, ptr(counts), stream())
+    return counts

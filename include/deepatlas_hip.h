@@ -199,6 +199,12 @@ int da_bending_bwd(const float* disp, const float* dloss, float* d_disp, int N, 
 int da_argmax_dice_counts(const float* logits, const void* truth, int label_bytes, int N, long long V, int C,
                           unsigned long long* counts, unsigned char* pred, void* stream);
 
+/* ---- eval on label maps (lib/evalMetrics.py:103-217 get_multi_metric / cal_metric / get_multiclass_dice,
+ *      lib/loss.py:348-391 DiceLossOnLabel): every one of those metrics is a function of these integer counts ---------- */
+/* pred / truth: uint8 (1) or int64 (8) label maps [N][V]; labels outside [0, C) are ignored; counts as above, zero-filled. */
+int da_label_overlap_counts(const void* pred, int pred_bytes, const void* truth, int truth_bytes, int N, long long V, int C,
+                            unsigned long long* counts, void* stream);
+
 /* ---- optimiser (models/segmentation.py:91 torch.optim.Adam defaults) -------------------------- */
 int da_adam_step(float* p, const float* g, float* m, float* v, long long n,
                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);

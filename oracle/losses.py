@@ -117,3 +117,70 @@ def multiclass_dice(pred, truth, n_class, eps=1e-11):
     t1 = mask_to_one_hot(truth.reshape(B, 1, -1), n_class)[:, 1:, :]
     inter = (p1 * t1).sum(2)
     return (2. * inter) / ((p1.sum(2) + t1.sum(2)) + eps)
+
+
+def dice_loss_on_label(source, target, n_class=None, eps=10e-6, weight_type='Uniform'):
+    """lib/loss.py:348-391 DiceLossOnLabel.forward: masks B x 1 x D x M x N -> one-hot (background dropped), per (B, class)
+    scores = 2 I w / (w (S + T) + eps), loss = 1 - mean(scores)."""
+    assert source.shape == target.shape
+    if n_class is None:                                                         # :366-367
+        n_class = int(max(torch.unique(target).max(), torch.unique(source).max()).long().item()) + 1
+    ms = list(target.shape)
+    s1 = mask_to_one_hot(source.reshape(ms[0], ms[1], -1), n_class)[:, 1:, :]   # :370-375
+    t1 = mask_to_one_hot(target.reshape(ms[0], ms[1], -1), n_class)[:, 1:, :]
+    sv, tv = s1.sum(2), t1.sum(2)                                               # :378-379
+    if weight_type == 'Simple':                                                 # :381-383
+        w = tv.float().reciprocal()
+        w = torch.where(torch.isinf(w), torch.ones_like(w), w)
+    else:                                                                       # :384-385
+        w = torch.ones(ms[0], ms[1])
+    inter = s1 * t1
+    scores = (2. * inter.sum(2).float() * w) / (w * (sv.float() + tv.float()) + eps)   # :387-389
+    return 1 - scores.mean()
+
+
+def cal_metric(label_pred, label_gt):
+    """lib/evalMetrics.py:151-181 on two flat 0/1 arrays (counts instead of Python sets, same arithmetic)."""
+    eps = 1e-11
+    res = {'iou': -1, 'dice': -1, 'recall': -1, 'precision': -1}
+    n_gt = int(np.count_nonzero(label_gt == 1)); n_pred = int(np.count_nonzero(label_pred == 1))
+    n_both = int(np.count_nonzero((label_gt == 1) & (label_pred == 1)))
+    union = n_gt + n_pred - n_both
+    tp = float(n_both); fn = float(n_gt - n_both); fp = float(n_pred - n_both)
+    if n_gt != 0:
+        res['iou'] = tp / (float(union) + eps)
+        res['recall'] = tp / (tp + fn + eps)
+        res['precision'] = tp / (tp + fp + eps)
+        res['dice'] = 2 * tp / (2 * tp + fn + fp + eps)
+    return res
+
+
+def multi_metric(pred, gt, eval_label_list=None, rm_bg=False):
+    """lib/evalMetrics.py:103-148 get_multi_metric on numpy label maps B x ..."""
+    label_list = np.unique(gt).tolist()
+    if rm_bg:
+        label_list = label_list[1:]
+    if eval_label_list is not None:
+        for label in eval_label_list:
+            assert label in label_list
+        label_list = eval_label_list
+    nl, nb = len(label_list), pred.shape[0]
+    metrics = ['iou', 'dice', 'recall', 'precision']
+    mm = {m: np.zeros([nb, nl]) for m in metrics}
+    la = {m: np.zeros([nb, 1]) for m in metrics}
+    ba = {m: np.zeros([1, nl]) for m in metrics}
+    for l in range(nl):
+        lp = (pred == label_list[l]).astype(np.int32); lg = (gt == label_list[l]).astype(np.int32)
+        for b in range(nb):
+            r = cal_metric(lp[b].reshape(-1), lg[b].reshape(-1))
+            for m in metrics:
+                mm[m][b][l] = r[m]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        for m in metrics:
+            for s_ in range(nb):
+                la[m][s_] = float(np.mean(mm[m][s_][np.where(mm[m][s_] != -1)]))
+            for l in range(nl):
+                ba[m][:, l] = float(np.mean(mm[m][:, l][np.where(mm[m][:, l] != -1)]))
+    return {'multi_metric_res': mm, 'label_avg_res': la, 'batch_avg_res': ba, 'label_list': label_list}

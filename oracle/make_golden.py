@@ -225,12 +225,46 @@ def run_ops(ref, out):
     out['ops/evaldice/pred'], out['ops/evaldice/truth'], out['ops/evaldice/dice'] = np32(pred), np32(truth), dice
 
 
+def run_eval(ref, out):
+    """lib/evalMetrics.py:103-217 (get_multi_metric, cal_metric, get_multiclass_dice) and
+    lib/loss.py:348-391 (DiceLossOnLabel) on two small label maps; class 4 is absent from sample 0's ground truth
+    (the -1 / skip-in-average path) and class 3 from sample 1's prediction."""
+    from oracle import nets
+    D, H, W = 6, 10, 14
+    pred = nets.closed_form_labels((2, D, H, W), 5, seed=50).clone()
+    truth = nets.closed_form_labels((2, D, H, W), 5, seed=51).clone()
+    truth[0][truth[0] == 4] = 0
+    pred[1][pred[1] == 3] = 1
+    out['eval/pred'], out['eval/truth'] = np32(pred), np32(truth)
+    out['eval/multiclass_dice_n5'] = np32(ref.metrics.get_multiclass_dice(pred, truth, n_class=5))
+    out['eval/multiclass_dice_auto'] = np32(ref.metrics.get_multiclass_dice(pred, truth))
+    oh = ref.transforms.mask_to_one_hot(truth.view(2, 1, -1), 5).view(2, 5, D, H, W)
+    out['eval/multiclass_dice_onehot_truth'] = np32(ref.metrics.get_multiclass_dice(pred, oh, n_class=5))
+    for wt in ('Uniform', 'Simple'):
+        crit = ref.loss.DiceLossOnLabel(n_class=5)
+        out['eval/dice_on_label_%s' % wt] = np.float64(crit(pred[:, None], truth[:, None], weight_type=wt).item())
+    out['eval/dice_on_label_auto'] = np.float64(ref.loss.DiceLossOnLabel()(pred[:, None], truth[:, None]).item())
+    for tag, kw in (('all', {}), ('rm_bg', {'rm_bg': True}), ('sel', {'eval_label_list': [1, 3]})):
+        r = ref.metrics.get_multi_metric(pred.numpy(), truth.numpy(), **kw)
+        out['eval/multi_metric/%s/label_list' % tag] = np.asarray(r['label_list'], dtype=np.int64)
+        for grp in ('multi_metric_res', 'label_avg_res', 'batch_avg_res'):
+            for m, v in r[grp].items():
+                out['eval/multi_metric/%s/%s/%s' % (tag, grp, m)] = np.asarray(v, dtype=np.float64)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
     os.makedirs(OUT, exist_ok=True)
     from oracle import nets
+
+    out = {}
+    run_eval(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'eval.npz'), **out)
+    print('eval.npz', len(out))
+    if os.environ.get('GOLDEN_ONLY') == 'eval':
+        return
 
     out = {}
     run_ops(ref, out)

@@ -462,3 +462,59 @@ def test_deconv_and_warp_vs_c_oracle():
     wr = np.empty_like(sn)
     _prim().prim_grid_sample3d(_np_ptr(sn), _np_ptr(grid), _np_ptr(wr), N, C, D, H, W, D, H, W)
     check(out, wr, tol=1e-5, what='warp vs prim.c')
+
+
+# ---- label-map eval metrics on the device -----------------------------------------------------------------
+def test_label_metrics_golden(golden):
+    """get_multiclass_dice / DiceLossOnLabel / get_multi_metric through da_label_overlap_counts vs the reference's own outputs."""
+    from deepatlas_amd.lib import evalMetrics as em
+    from deepatlas_amd.lib.loss import DiceLossOnLabel
+    g = golden('eval')
+    pred, truth = T(g['eval/pred']).to(dev()), T(g['eval/truth']).to(dev())
+    np.testing.assert_allclose(em.get_multiclass_dice(pred, truth, n_class=5).cpu().numpy(), g['eval/multiclass_dice_n5'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(em.get_multiclass_dice(pred, truth).cpu().numpy(), g['eval/multiclass_dice_auto'], rtol=1e-6, atol=1e-7)
+    from deepatlas_amd import ops
+    oh = ops.one_hot(truth.reshape(2, 1, *truth.shape[1:]).long(), 5)
+    np.testing.assert_allclose(em.get_multiclass_dice(pred, oh, n_class=5).cpu().numpy(), g['eval/multiclass_dice_onehot_truth'], rtol=1e-6, atol=1e-7)
+    for wt in ('Uniform', 'Simple'):
+        v = DiceLossOnLabel(n_class=5)(pred[:, None], truth[:, None], weight_type=wt).item()
+        assert abs(v - float(g['eval/dice_on_label_%s' % wt])) < 1e-6, (wt, v)
+    assert abs(DiceLossOnLabel()(pred[:, None], truth[:, None]).item() - float(g['eval/dice_on_label_auto'])) < 1e-6
+    for tag, kw in (('all', {}), ('rm_bg', {'rm_bg': True}), ('sel', {'eval_label_list': [1, 3]})):
+        r = em.get_multi_metric(pred, truth, **kw)
+        assert list(r['label_list']) == list(g['eval/multi_metric/%s/label_list' % tag])
+        for grp in ('multi_metric_res', 'label_avg_res', 'batch_avg_res'):
+            for m, v in r[grp].items():
+                np.testing.assert_allclose(v, g['eval/multi_metric/%s/%s/%s' % (tag, grp, m)], rtol=1e-12, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.int64])
+def test_label_overlap_counts_bit_exact(dtype):
+    """ragged length (not a multiple of the 16-voxel run), 200 classes, out-of-range labels ignored; vs numpy, bit-exact."""
+    from deepatlas_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, V, C = 3, 16 * 1000 + 5, 200
+    pred = torch.randint(0, 220, (N, V), generator=g).to(dtype)
+    truth = torch.randint(0, 220, (N, V), generator=g).to(dtype)
+    truth[:, 1000:3000] = 7; pred[:, 1500:2500] = 7                   # long runs (merged in registers)
+    c = ops.label_overlap_counts(pred.to(dev()), truth.to(dev()), C).cpu().numpy()
+    p, t = pred.numpy().astype(np.int64), truth.numpy().astype(np.int64)
+    for n in range(N):
+        ref = np.stack([np.bincount(p[n][p[n] < C], minlength=C), np.bincount(t[n][t[n] < C], minlength=C),
+                        np.bincount(p[n][(p[n] == t[n]) & (p[n] < C)], minlength=C)], 1)
+        assert np.array_equal(c[n], ref)
+
+
+def test_full_size_label_metrics_properties():
+    """160x192x160: Dice(x, x) = 1 for every present class, counts conserve the voxel count, multi-metric of identical maps = 1."""
+    from deepatlas_amd.lib import evalMetrics as em
+    from deepatlas_amd.lib.datasets import structured_labels
+    from deepatlas_amd import ops
+    lab = structured_labels((160, 192, 160), 32).to(dev())[None]
+    c = ops.label_overlap_counts(lab, lab, 32)
+    assert int(c[0, :, 0].sum()) == 160 * 192 * 160 and torch.equal(c[..., 0], c[..., 2]) and torch.equal(c[..., 1], c[..., 2])
+    d = em.get_multiclass_dice(lab, lab, n_class=32)
+    present = c[0, 1:, 1] > 0
+    assert torch.allclose(d[0][present], torch.ones_like(d[0][present]), atol=1e-6)
+    r = em.get_multi_metric(lab, lab)
+    assert np.allclose(r['label_avg_res']['dice'], 1.0, atol=1e-9) and np.allclose(r['batch_avg_res']['iou'], 1.0, atol=1e-9)

@@ -194,3 +194,23 @@ def test_reg_three_steps(golden, tag, shape):
                     assert rel_l2(v.numpy(), ref) < 1e-5, (s, n)
                 else:
                     assert abs(summary_of(v)[2] - ref[2]) <= 1e-6 * ref[2], (s, n)
+
+
+# ---- label-map eval metrics ---------------------------------------------------------------------------
+def test_eval_label_metrics_oracle_vs_reference(golden):
+    """oracle.losses.{multiclass_dice, dice_loss_on_label, multi_metric} == lib/evalMetrics.py:103-217, lib/loss.py:348-391."""
+    import torch
+    from oracle import losses
+    g = golden('eval')
+    pred, truth = torch.from_numpy(g['eval/pred']), torch.from_numpy(g['eval/truth'])
+    np.testing.assert_allclose(losses.multiclass_dice(pred, truth, 5).numpy(), g['eval/multiclass_dice_n5'], rtol=1e-6, atol=1e-7)
+    for wt in ('Uniform', 'Simple'):
+        v = losses.dice_loss_on_label(pred[:, None], truth[:, None], n_class=5, weight_type=wt).item()
+        assert abs(v - float(g['eval/dice_on_label_%s' % wt])) < 1e-6
+    assert abs(losses.dice_loss_on_label(pred[:, None], truth[:, None]).item() - float(g['eval/dice_on_label_auto'])) < 1e-6
+    for tag, kw in (('all', {}), ('rm_bg', {'rm_bg': True}), ('sel', {'eval_label_list': [1, 3]})):
+        r = losses.multi_metric(pred.numpy(), truth.numpy(), **kw)
+        assert list(r['label_list']) == list(g['eval/multi_metric/%s/label_list' % tag])
+        for grp in ('multi_metric_res', 'label_avg_res', 'batch_avg_res'):
+            for m, v in r[grp].items():
+                np.testing.assert_allclose(v, g['eval/multi_metric/%s/%s/%s' % (tag, grp, m)], rtol=1e-12, atol=0, equal_nan=True)
