@@ -72,6 +72,12 @@ SIGNATURES = {
     'da_bending_bwd': (I, [P, P, P, I, I, I, I, P, I, P]),
     'da_argmax_dice_counts': (I, [P, P, I, I, LL, I, P, P, P]),
     'da_label_overlap_counts': (I, [P, I, P, I, I, LL, I, P, P]),
+    'da_lncc_ws_bytes': (SZ, [I, I, I, I, I]),
+    'da_lncc_fwd': (I, [P, P, I, I, I, I, I, F, P, P, P, SZ, P]),
+    'da_lncc_bwd': (I, [P, P, P, P, P, P, I, I, I, I, I, F, P, SZ, P]),
+    'da_gradloss_ws_bytes': (SZ, [I, I, I, I]),
+    'da_gradloss_fwd': (I, [P, I, I, I, I, P, I, I, P, P, SZ, P]),
+    'da_gradloss_bwd': (I, [P, P, P, I, I, I, I, P, I, I, P]),
     'da_adam_step': (I, [P, P, P, P, LL, F, F, F, F, I, F, P]),
 }
 

@@ -114,14 +114,28 @@ __global__ void dice_partial_gen_kernel(const float* __restrict__ src, const voi
 
 // one block; sums the partials, then thread 0 does the (N x C) epilogue in fp32 like the reference.
 // coef[0][n][c] = A (multiplies the target), coef[1][n][c] = B:  dL/dp = A*t + B
-__global__ void dice_finalize_kernel(const double* __restrict__ partial, int nblocks, int N, int C,
+// partial viewed as [N][nblocks][R]: one wave per (n, r) column sums its nblocks entries and leaves the total in slot b = 0
+// (only that wave touches that column, so in place).  The single-block finalize kernels then read one value per column
+// instead of walking nblocks entries serially per thread (that walk was 70-140 us of pure latency).
+__global__ void colreduce_inplace_kernel(double* __restrict__ partial, int N, int nblocks, int R) {
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wave >= N * R) return;
+    const int n = wave / R, r = wave % R;
+    double* col = partial + (size_t)n * nblocks * R + r;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += col[(size_t)b * R];
+    s = da_wave_sum(s);
+    if (lane == 0) col[0] = s;
+}
+
+__global__ void dice_finalize_kernel(const double* __restrict__ partial, int nblocks, int nsum, int N, int C,
                                      int weight_type, int no_bg, float eps, float* __restrict__ loss,
                                      float* __restrict__ coef, float* __restrict__ isc /* [3][N][C] scratch */) {
     const int NC = N * C;
     for (int i = threadIdx.x; i < 3 * NC; i += blockDim.x) {
         const int k = i / NC, nc = i % NC, n = nc / C, c = nc % C;
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[(((size_t)n * nblocks + b) * 3 + k) * C + c];
+        for (int b = 0; b < nsum; ++b) s += partial[(((size_t)n * nblocks + b) * 3 + k) * C + c];
         isc[i] = (float)s;
     }
     __syncthreads();
@@ -334,13 +348,13 @@ __global__ void ncc_partial_kernel(const float* __restrict__ x, const float* __r
 }
 
 // stats[n] = {mean_x, mean_y, cov, var_x, var_y, ncc, M, 0}
-__global__ void ncc_finalize_kernel(const double* __restrict__ partial, int nblocks, int N, long long V,
+__global__ void ncc_finalize_kernel(const double* __restrict__ partial, int nblocks, int nsum, int N, long long V,
                                     float* __restrict__ loss, double* __restrict__ stats) {
     __shared__ double sncc[64];
     const int n = threadIdx.x;
     if (n < N) {
         double s[5] = {0, 0, 0, 0, 0};
-        for (int b = 0; b < nblocks; ++b)
+        for (int b = 0; b < nsum; ++b)
             for (int k = 0; k < 5; ++k) s[k] += partial[((size_t)n * nblocks + b) * 5 + k];
         const double M = (double)V;
         const double mx = s[0] / M, my = s[1] / M;
@@ -605,7 +619,9 @@ extern "C" int da_dice_fwd(const float* src, const void* labels, int label_bytes
                            src, labels, label_bytes, soft_target, V, C, softmax, partial);
     }
     DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc);
+    hipLaunchKernelGGL(colreduce_inplace_kernel, dim3((unsigned)da_cdiv((long long)N * 3 * C * 64, 256)), dim3(256), 0, st, partial, N, nblocks, 3 * C);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, 1, N, C, weight_type, no_bg, eps, loss, coef, isc);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -663,7 +679,9 @@ extern "C" int da_ncc_fwd(const float* x, const float* y, int N, long long V, fl
     int nblocks = (int)da_cdiv(V / 4 + 1, 256 * 4); if (nblocks > kBlocks) nblocks = kBlocks; if (nblocks < 1) nblocks = 1;
     hipLaunchKernelGGL(ncc_partial_kernel, dim3(nblocks, N), dim3(256), 0, st, x, y, V, (double*)ws);
     DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ncc_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblocks, N, V, loss, stats);
+    hipLaunchKernelGGL(colreduce_inplace_kernel, dim3((unsigned)da_cdiv((long long)N * 5 * 64, 256)), dim3(256), 0, st, (double*)ws, N, nblocks, 5);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ncc_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblocks, 1, N, V, loss, stats);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -1,9 +1,9 @@
 """Loss registry: host-side mirror of lib/loss.py:739-761 with the hot-path losses as fused HIP kernels.
 
 Hot path: 'dice' -> DiceLossMultiClass, 'ncc' -> NormalizedCrossCorrelationLoss,
-'bendingEnergy' -> BendingEnergyLoss.  'mse' / 'L2' are one-line compositions; the remaining registry
-names (lncc, gradient, focal, cross_entropy, soft_cross_entropy) are outside this round's scope
- and raise NotImplementedError on construction instead of silently running elsewhere.
+'bendingEnergy' -> BendingEnergyLoss; SURVEY.md §8f f2: 'lncc' -> VoxelMorphLNCC, 'gradient' -> gradientLoss (reglosses.hip).
+'mse' / 'L2' are one-line compositions; the remaining registry names (focal, cross_entropy, soft_cross_entropy) are outside
+the volumetric hot path and raise NotImplementedError on construction instead of silently running elsewhere.
 """
 import torch
 import torch.nn as nn
@@ -97,6 +97,41 @@ class BendingEnergyLoss(nn.Module):
         return ops.BendingFn.apply(input, tuple(float(s) for s in self.spacing), self.normalize)
 
 
+class VoxelMorphLNCC(nn.Module):
+    """lib/loss.py:589-617 (registry name 'lncc'): local normalised cross-correlation over filter_size^3 windows.
+    `filter` is kept as the reference's all-ones nn.Parameter (state_dict key 'filter'); the kernel is the separable box
+    filter an all-ones window is, so a filter that is no longer all ones is refused instead of silently ignored."""
+
+    def __init__(self, filter_size=9, eps=1e-6):
+        super(VoxelMorphLNCC, self).__init__()
+        self.filter_size = filter_size
+        self.win_numel = self.filter_size ** 3
+        self.filter = nn.Parameter(torch.ones(1, 1, filter_size, filter_size, filter_size), requires_grad=False)
+        self.eps = eps
+
+    def forward(self, I, J):
+        if not bool((self.filter == 1).all()):
+            raise NotImplementedError('VoxelMorphLNCC.filter must stay all ones on the accelerated path')
+        return ops.LNCCFn.apply(I, J, self.filter_size, self.eps)
+
+
+class gradientLoss(nn.Module):
+    """lib/loss.py:625-671 (registry name 'gradient'): first-difference regulariser of a N x 3 x D x H x W field, with the
+    reference's `+` along H and W (loss.py:661,663) kept."""
+
+    def __init__(self, norm='L2', spacing=(1, 1, 1), normalize=True):
+        super(gradientLoss, self).__init__()
+        self.norm = norm
+        self.spacing = torch.tensor(spacing).float()
+        self.normalize = normalize
+        if self.normalize:
+            self.spacing /= self.spacing.min()
+
+    def forward(self, input):
+        # the launcher normalises `spacing` itself (idempotent for an already normalised vector) and the volume dims
+        return ops.GradLossFn.apply(input, tuple(self.spacing.tolist()), self.normalize, 2 if self.norm == 'L2' else 1)
+
+
 class MSELoss(nn.Module):
     def forward(self, input, target):
         return ((input - target) ** 2).mean()
@@ -118,9 +153,9 @@ def _out_of_scope(name, cite):
 
 loss_dict = {
     'ncc': NormalizedCrossCorrelationLoss,
-    'lncc': _out_of_scope('lncc', 'lib/loss.py:589-617'),
+    'lncc': VoxelMorphLNCC,
     'mse': MSELoss,
-    'gradient': _out_of_scope('gradient', 'lib/loss.py:625-671'),
+    'gradient': gradientLoss,
     'bendingEnergy': BendingEnergyLoss,
     'dice': DiceLossMultiClass,
     'L2': L2Loss,

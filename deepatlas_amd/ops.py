@@ -605,6 +605,68 @@ class BendingFn(Function):
         return ncdhw(du), None, None
 
 
+class LNCCFn(Function):
+    """VoxelMorphLNCC.forward (lib/loss.py:599-617): five F^3 box sums as three separable passes + fused cc reduction."""
+
+    @staticmethod
+    def forward(ctx, I, J, filter_size, eps):
+        if I.shape != J.shape or I.dim() != 5 or I.shape[1] != 1:
+            raise ValueError('LNCC expects two N x 1 x D x H x W volumes of the same shape')
+        nat.require_cuda(I); nat.require_cuda(J)
+        a, b = I.detach().contiguous().float(), J.detach().contiguous().float()
+        N, _, D, H, W = a.shape
+        F_ = int(filter_size)
+        if min(D, H, W) < F_:
+            raise RuntimeError('LNCC window %d larger than the volume %s' % (F_, (D, H, W)))
+        loss = _empty((1,), a)
+        sums = torch.empty((5, N, D - F_ + 1, H - F_ + 1, W - F_ + 1), dtype=torch.float32, device=a.device)
+        wsb = nat.lib().da_lncc_ws_bytes(N, D, H, W, F_)
+        wp, wn = _ws(wsb, a)
+        call('da_lncc_fwd', ptr(a), ptr(b), N, D, H, W, F_, float(eps), ptr(loss), ptr(sums), wp, wn, stream())
+        ctx.cfg = (F_, float(eps), wsb)
+        ctx.save_for_backward(a, b, sums)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        a, b, sums = ctx.saved_tensors
+        F_, eps, wsb = ctx.cfg
+        N, _, D, H, W = a.shape
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        dI = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        dJ = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        wp, wn = _ws(wsb, a)
+        call('da_lncc_bwd', ptr(a), ptr(b), ptr(sums), ptr(gl), ptr(dI), ptr(dJ), N, D, H, W, F_, eps, wp, wn, stream())
+        return dI, dJ, None, None
+
+
+class GradLossFn(Function):
+    """gradientLoss.forward (lib/loss.py:640-671), norm 'L2' or 'L1', with the reference's sign quirk along H and W."""
+
+    @staticmethod
+    def forward(ctx, disp, spacing, normalize, norm):
+        u = ndhwc(disp)
+        N, D, H, W, C = u.shape
+        if C != 3:
+            raise ValueError('gradientLoss expects a N x 3 x D x H x W displacement field')
+        loss = _empty((1,), u)
+        wp, wn = _ws(nat.lib().da_gradloss_ws_bytes(N, D, H, W), u)
+        call('da_gradloss_fwd', ptr(u), N, D, H, W, ctypes_float3(spacing), 1 if normalize else 0, int(norm), ptr(loss), wp, wn, stream())
+        ctx.cfg = (tuple(float(s) for s in spacing), bool(normalize), int(norm))
+        ctx.save_for_backward(u)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        u, = ctx.saved_tensors
+        N, D, H, W, _ = u.shape
+        spacing, normalize, norm = ctx.cfg
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        du = torch.empty_like(u)
+        call('da_gradloss_bwd', ptr(u), ptr(gl), ptr(du), N, D, H, W, ctypes_float3(spacing), 1 if normalize else 0, norm, stream())
+        return ncdhw(du), None, None, None
+
+
 def ctypes_float3(v):
     import ctypes
     arr = (ctypes.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))

@@ -194,6 +194,23 @@ int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* s
 int da_bending_bwd(const float* disp, const float* dloss, float* d_disp, int N, int D, int H, int W,
                    const float* spacing3, int normalize, void* stream);
 
+/* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC, registry 'lncc') ------------------------
+ * I, J: [N][D][H][W] fp32 (single channel); F^3 all-ones window, valid padding; loss = 1 - mean(cross^2 / (Ivar Jvar + eps)).
+ * sums: [5][N][D-F+1][H-F+1][W-F+1] window sums (I, J, I^2, J^2, IJ), written by fwd and consumed by bwd. */
+size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F);
+int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, int W, int F, float eps,
+                float* loss, float* sums, void* ws, size_t ws_bytes, void* stream);
+int da_lncc_bwd(const float* I, const float* J, const float* sums, const float* dloss, float* dI, float* dJ,
+                int N, int D, int H, int W, int F, float eps, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- displacement gradient regulariser (row f2; lib/loss.py:625-671 gradientLoss, registry 'gradient') ------------------
+ * disp [N][D][H][W][3]; norm = 2 ('L2') or 1; keeps the reference's +/- quirk along H and W (loss.py:661,663). */
+size_t da_gradloss_ws_bytes(int N, int D, int H, int W);
+int da_gradloss_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize, int norm,
+                    float* loss, void* ws, size_t ws_bytes, void* stream);
+int da_gradloss_bwd(const float* disp, const float* dloss, float* d_disp, int N, int D, int H, int W,
+                    const float* spacing3, int normalize, int norm, void* stream);
+
 /* ---- eval: argmax + per-class overlap counts (row a15; models/segmentation.py:188-194) -------- */
 /* counts[N][C][3] uint64 = (|pred==c|, |truth==c|, |pred==c & truth==c|), must be zero-filled; pred (may be NULL) uint8 [N][V]. */
 int da_argmax_dice_counts(const float* logits, const void* truth, int label_bytes, int N, long long V, int C,

@@ -184,3 +184,37 @@ def multi_metric(pred, gt, eval_label_list=None, rm_bg=False):
             for l in range(nl):
                 ba[m][:, l] = float(np.mean(mm[m][:, l][np.where(mm[m][:, l] != -1)]))
     return {'multi_metric_res': mm, 'label_avg_res': la, 'batch_avg_res': ba, 'label_list': label_list}
+
+
+def lncc_loss(I, J, filter_size=9, eps=1e-6):
+    """lib/loss.py:599-617 VoxelMorphLNCC.forward with its all-ones filter (same op order)."""
+    n = float(filter_size ** 3)
+    filt = torch.ones(1, 1, filter_size, filter_size, filter_size, dtype=I.dtype)
+    Is = F.conv3d(I, filt, padding=0); Js = F.conv3d(J, filt, padding=0)
+    I2s = F.conv3d(I ** 2, filt, padding=0); J2s = F.conv3d(J ** 2, filt, padding=0); IJs = F.conv3d(I * J, filt, padding=0)
+    Im, Jm = Is / n, Js / n
+    cross = IJs - Im * Js - Jm * Is + Im * Jm * n
+    Iv = I2s - 2 * Im * Is + Im ** 2 * n
+    Jv = J2s - 2 * Jm * Js + Jm ** 2 * n
+    cc = (cross ** 2) / (Iv * Jv + eps)
+    return 1 - cc.mean()
+
+
+def gradient_loss(u, norm='L2', spacing=(1, 1, 1), normalize=True):
+    """lib/loss.py:640-671 gradientLoss.forward: note `+` for the H and W differences (:661,:663) and the 3-vector
+    weights broadcast over the channel axis."""
+    sp = torch.tensor(spacing).to(u.dtype)
+    if normalize:
+        sp = sp / sp.min()
+    dims = torch.tensor(u.shape[2:]).to(u.dtype)
+    if normalize:
+        dims = dims / dims.min()
+    N, C = u.shape[0], u.shape[1]
+    dx = torch.abs(u[:, :, 2:, :, :] - u[:, :, :-2, :, :]).reshape(N, C, -1)
+    dy = torch.abs(u[:, :, :, 2:, :] + u[:, :, :, :-2, :]).reshape(N, C, -1)
+    dz = torch.abs(u[:, :, :, :, 2:] + u[:, :, :, :, :-2]).reshape(N, C, -1)
+    if norm == 'L2':
+        dx = (dx ** 2).mean(2) * (dims * sp / sp[0]) ** 2
+        dy = (dy ** 2).mean(2) * (dims * sp / sp[1]) ** 2
+        dz = (dz ** 2).mean(2) * (dims * sp / sp[2]) ** 2
+    return (dx.mean() + dy.mean() + dz.mean()) / 3.0

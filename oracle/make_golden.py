@@ -252,6 +252,29 @@ def run_eval(ref, out):
                 out['eval/multi_metric/%s/%s/%s' % (tag, grp, m)] = np.asarray(v, dtype=np.float64)
 
 
+def run_reglosses(ref, out):
+    """lib/loss.py:589-617 VoxelMorphLNCC and :625-671 gradientLoss (loss + input gradients)."""
+    from oracle import nets
+    shape = (2, 1, 12, 14, 16)
+    I = nets.closed_form_volume(shape, seed=60).clone().requires_grad_(True)
+    J = nets.closed_form_volume(shape, seed=61).clone().requires_grad_(True)
+    for fs in (9, 5):
+        crit = ref.loss.VoxelMorphLNCC(filter_size=fs)
+        l = crit(I, J)
+        gi, gj = torch.autograd.grad(l, (I, J))
+        out['lncc/f%d/loss' % fs] = np.float64(l.item())
+        out['lncc/f%d/grad_I' % fs], out['lncc/f%d/grad_J' % fs] = np32(gi), np32(gj)
+    out['lncc/I'], out['lncc/J'] = np32(I), np32(J)
+    u = (nets.closed_form_volume((2, 3, 6, 10, 14), seed=62) * 0.3).clone().requires_grad_(True)
+    out['gradloss/u'] = np32(u)
+    for tag, kw in (('L2', {}), ('L2_spacing', {'spacing': (1.0, 2.0, 1.5)}), ('L2_nonorm', {'spacing': (1.0, 2.0, 1.5), 'normalize': False}), ('L1', {'norm': 'L1'})):
+        crit = ref.loss.gradientLoss(**kw)
+        l = crit(u)
+        g, = torch.autograd.grad(l, u)
+        out['gradloss/%s/loss' % tag] = np.float64(l.item())
+        out['gradloss/%s/grad' % tag] = np32(g)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -263,7 +286,11 @@ def main():
     run_eval(ref, out)
     np.savez_compressed(os.path.join(OUT, 'eval.npz'), **out)
     print('eval.npz', len(out))
-    if os.environ.get('GOLDEN_ONLY') == 'eval':
+    out = {}
+    run_reglosses(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'reglosses.npz'), **out)
+    print('reglosses.npz', len(out))
+    if os.environ.get('GOLDEN_ONLY') in ('eval', 'f'):
         return
 
     out = {}

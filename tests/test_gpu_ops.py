@@ -518,3 +518,58 @@ def test_full_size_label_metrics_properties():
     assert torch.allclose(d[0][present], torch.ones_like(d[0][present]), atol=1e-6)
     r = em.get_multi_metric(lab, lab)
     assert np.allclose(r['label_avg_res']['dice'], 1.0, atol=1e-9) and np.allclose(r['batch_avg_res']['iou'], 1.0, atol=1e-9)
+
+
+# ---- LNCC / gradient losses ------------------------------------------------------------------------------------
+def test_lncc_golden(golden):
+    from deepatlas_amd.lib.loss import get_loss_function
+    g = golden('reglosses')
+    for fs in (9, 5):
+        I = T(g['lncc/I']).to(dev()).requires_grad_(True); J = T(g['lncc/J']).to(dev()).requires_grad_(True)
+        crit = get_loss_function('lncc')(filter_size=fs).to(dev())
+        assert list(crit.state_dict().keys()) == ['filter']
+        l = crit(I, J); l.backward()
+        ref = float(g['lncc/f%d/loss' % fs])
+        assert abs(l.item() - ref) < 1e-4 * max(1.0, abs(ref)), (fs, l.item(), ref)
+        check(I.grad, g['lncc/f%d/grad_I' % fs], tol=2e-4, what='lncc grad_I f%d' % fs)
+        check(J.grad, g['lncc/f%d/grad_J' % fs], tol=2e-4, what='lncc grad_J f%d' % fs)
+
+
+def test_lncc_vs_oracle_ragged_and_errors():
+    from deepatlas_amd.lib.loss import VoxelMorphLNCC
+    from oracle import losses
+    I, J = rnd((1, 1, 11, 13, 17), 1) * 0.5 + 0.5, rnd((1, 1, 11, 13, 17), 2) * 0.5 + 0.5
+    Ir, Jr = I.clone().requires_grad_(True), J.clone().requires_grad_(True)
+    lr = losses.lncc_loss(Ir, Jr, 9); lr.backward()
+    Ig, Jg = I.to(dev()).requires_grad_(True), J.to(dev()).requires_grad_(True)
+    lg = VoxelMorphLNCC()(Ig, Jg); lg.backward()
+    assert abs(lg.item() - lr.item()) < 1e-4
+    check(Ig.grad, Ir.grad, tol=2e-4, what='grad_I'); check(Jg.grad, Jr.grad, tol=2e-4, what='grad_J')
+    with pytest.raises(RuntimeError):
+        VoxelMorphLNCC()(rnd((1, 1, 8, 16, 16), 3).to(dev()), rnd((1, 1, 8, 16, 16), 4).to(dev()))     # window larger than D (F.conv3d raises too)
+    with pytest.raises(ValueError):
+        VoxelMorphLNCC()(rnd((1, 2, 12, 16, 16), 3).to(dev()), rnd((1, 2, 12, 16, 16), 4).to(dev()))
+
+
+def test_gradient_loss_golden(golden):
+    from deepatlas_amd.lib.loss import get_loss_function
+    g = golden('reglosses')
+    for tag, kw in (('L2', {}), ('L2_spacing', {'spacing': (1.0, 2.0, 1.5)}), ('L2_nonorm', {'spacing': (1.0, 2.0, 1.5), 'normalize': False}), ('L1', {'norm': 'L1'})):
+        u = cl(T(g['gradloss/u'])).requires_grad_(True)
+        l = get_loss_function('gradient')(**kw)(u); l.backward()
+        ref = float(g['gradloss/%s/loss' % tag])
+        assert abs(l.item() - ref) < 1e-5 * max(1.0, abs(ref)), (tag, l.item(), ref)
+        check(u.grad, g['gradloss/%s/grad' % tag], tol=1e-5, what='gradloss grad ' + tag)
+
+
+def test_full_size_lncc_and_gradient_loss_properties():
+    """160x192x160: LNCC(x, x) = 0 up to eps; gradientLoss of a constant field has the closed form of its +/- quirk."""
+    from deepatlas_amd.lib.loss import VoxelMorphLNCC, gradientLoss
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((1, 1, 160, 192, 160), generator=g).to(dev())
+    assert abs(VoxelMorphLNCC()(x, x).item()) < 1e-4
+    c = 0.25
+    u = torch.full((1, 3, 160, 192, 160), c).to(dev()).contiguous(memory_format=torch.channels_last_3d)
+    dims = torch.tensor([160., 192., 160.]) / 160.
+    expect = float((((dims ** 2) * (2 * c) ** 2).mean() * 2) / 3.0)          # dx = 0; dy = dz = |2c|, weights dims[c]^2
+    assert abs(gradientLoss()(u).item() - expect) < 1e-5 * expect

@@ -70,7 +70,10 @@ def test_out_of_scope_constructors_raise():
     with pytest.raises(NotImplementedError):
         get_network('UNet')(1, 2)
     with pytest.raises(NotImplementedError):
-        get_loss_function('lncc')()
+        get_loss_function('focal')()
+    # rows f1/f2 are on the accelerated path: constructible on the host, state_dict as the reference's
+    assert list(get_loss_function('lncc')().state_dict().keys()) == ['filter']
+    assert get_loss_function('gradient')(spacing=(1, 2, 4)).spacing.tolist() == [1.0, 2.0, 4.0]
 
 
 def test_train_seg_config_matches_reference_dict():

@@ -214,3 +214,23 @@ def test_eval_label_metrics_oracle_vs_reference(golden):
         for grp in ('multi_metric_res', 'label_avg_res', 'batch_avg_res'):
             for m, v in r[grp].items():
                 np.testing.assert_allclose(v, g['eval/multi_metric/%s/%s/%s' % (tag, grp, m)], rtol=1e-12, atol=0, equal_nan=True)
+
+
+# ---- LNCC and gradient losses ---------------------------------------------------------------------------------
+def test_reg_losses_f2_oracle_vs_reference(golden):
+    """oracle.losses.{lncc_loss, gradient_loss} == lib/loss.py:589-617, 625-671 (loss and input gradients)."""
+    import torch
+    from oracle import losses
+    g = golden('reglosses')
+    I = torch.from_numpy(g['lncc/I']).requires_grad_(True); J = torch.from_numpy(g['lncc/J']).requires_grad_(True)
+    for fs in (9, 5):
+        l = losses.lncc_loss(I, J, filter_size=fs)
+        gi, gj = torch.autograd.grad(l, (I, J))
+        assert abs(l.item() - float(g['lncc/f%d/loss' % fs])) < 1e-6
+        assert rel_l2(gi.numpy(), g['lncc/f%d/grad_I' % fs]) < 1e-5 and rel_l2(gj.numpy(), g['lncc/f%d/grad_J' % fs]) < 1e-5
+    u = torch.from_numpy(g['gradloss/u']).requires_grad_(True)
+    for tag, kw in (('L2', {}), ('L2_spacing', {'spacing': (1.0, 2.0, 1.5)}), ('L2_nonorm', {'spacing': (1.0, 2.0, 1.5), 'normalize': False}), ('L1', {'norm': 'L1'})):
+        l = losses.gradient_loss(u, **kw)
+        gu, = torch.autograd.grad(l, u)
+        assert abs(l.item() - float(g['gradloss/%s/loss' % tag])) < 1e-6 * max(1.0, abs(float(g['gradloss/%s/loss' % tag])))
+        assert rel_l2(gu.numpy(), g['gradloss/%s/grad' % tag]) < 1e-6
