@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='volumes per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
+    ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
+                    help="segmentation network of the 'seg' workload; 'UNet' = the fixed 19 M-parameter net (SURVEY.md row f3), not the headline config")
     ap.add_argument('--workload', default='seg', choices=['seg', 'reg', 'joint'],
                     help="'seg' = BASELINE configs[1] (the headline metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
     args = ap.parse_args()
@@ -98,7 +100,7 @@ def main():
     n_classes = 32
     shape = tuple(args.shape)
     torch.manual_seed(230)
-    model = get_network('UNet_light')(in_channel=1, n_classes=n_classes, bias=True, BN=True)
+    model = get_network(args.net)(in_channel=1, n_classes=n_classes, bias=True, BN=True)
     model.weights_init()
     model.to(dev).train()
     crit = get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
@@ -118,7 +120,8 @@ def main():
         return loss
 
     units_per_step = args.batch
-    workload_name = 'seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (BASELINE configs[1])' % (
+    workload_name = ('seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (BASELINE configs[1])' if args.net == 'UNet_light'
+                     else 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (SURVEY row f3, not a BASELINE config)') % (
         args.batch, shape[0], shape[1], shape[2])
     if args.workload in ('reg', 'joint'):
         from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep

@@ -22,19 +22,23 @@ __global__ void w_to_tio_kernel(const float* __restrict__ src, float* __restrict
     const long long total = (long long)A * B * K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(i % K); const int b = (int)((i / K) % B); const int a = (int)(i / ((long long)K * B));
-        // src[a][b][k]; dst[k][ci][co]
-        const int Cin = a_is_cout ? B : A, Cout = a_is_cout ? A : B;
-        const int ci = a_is_cout ? b : a, co = a_is_cout ? a : b;
-        dst[((size_t)k * Cin + ci) * Cout + co] = src[i];
+        // src[a][b][k]; dst[k][ci][co]   (flags bit 0: a is cout; bit 1: taps flipped, k -> K-1-k)
+        const bool aco = (a_is_cout & 1) != 0;
+        const int Cin = aco ? B : A, Cout = aco ? A : B;
+        const int ci = aco ? b : a, co = aco ? a : b;
+        const int kk = (a_is_cout & 2) ? K - 1 - k : k;
+        dst[((size_t)kk * Cin + ci) * Cout + co] = src[i];
     }
 }
 __global__ void tio_to_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B, int K, int a_is_cout) {
     const long long total = (long long)A * B * K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(i % K); const int b = (int)((i / K) % B); const int a = (int)(i / ((long long)K * B));
-        const int Cin = a_is_cout ? B : A, Cout = a_is_cout ? A : B;
-        const int ci = a_is_cout ? b : a, co = a_is_cout ? a : b;
-        dst[i] = src[((size_t)k * Cin + ci) * Cout + co];
+        const bool aco = (a_is_cout & 1) != 0;
+        const int Cin = aco ? B : A, Cout = aco ? A : B;
+        const int ci = aco ? b : a, co = aco ? a : b;
+        const int kk = (a_is_cout & 2) ? K - 1 - k : k;
+        dst[i] = src[((size_t)kk * Cin + ci) * Cout + co];
     }
 }
 
@@ -100,3 +104,6 @@ extern "C" int da_w_oik_to_tio(const float* src, float* dst, int Cout, int Cin, 
 extern "C" int da_w_tio_to_oik(const float* src, float* dst, int Cout, int Cin, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cout, Cin, K3, 1); }
 extern "C" int da_w_iok_to_tio(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(w_to_tio_kernel, Cin, Cout, K3, 0); }
 extern "C" int da_w_tio_to_iok(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cin, Cout, K3, 0); }
+// ConvTranspose3d(k, stride 1, padding (k-1)/2) == Conv3d with the taps flipped and the channel axes swapped
+extern "C" int da_w_iok_flip_to_tio(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(w_to_tio_kernel, Cin, Cout, K3, 2); }
+extern "C" int da_w_tio_to_iok_flip(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cin, Cout, K3, 2); }

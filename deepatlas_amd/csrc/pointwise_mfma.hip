@@ -21,7 +21,9 @@ struct PwP {
     const float* a; const float* wp; const float* bias; float* out;
     long long M;            // number of COARSE voxels (rows handled by the grid)
     int D, H, W;            // coarse dims (used when up != 0)
-    int K, Nc;              // GEMM inner / output channel counts (multiples of 16)
+    int K, Nc;              // GEMM inner / output channel counts of THIS launch (multiples of 16, <= 64)
+    int lda, ldo;           // row strides (floats) of A and out: the full channel counts when a launch covers a 64-wide slice
+    int accum;              // != 0: out += (a later K slice of the same output slice); bias is then not added again
     int ntaps, up;
 };
 
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
         for (int r = 0; r < MT; ++r)
 #pragma unroll
             for (int c = 0; c < KC; ++c)
-                a[r][c] = aval[r] ? *reinterpret_cast<const float4*>(p.a + arow[r] * p.K + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[r][c] = aval[r] ? *reinterpret_cast<const float4*>(p.a + arow[r] * p.lda + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
         // output rows of this lane: voxel 4*g + reg of every M-tile
         long long orow[MT][4];
 #pragma unroll
@@ -76,13 +78,25 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
             }
         float bv[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bv[n] = p.bias ? p.bias[16 * n + i] : 0.f;
+        for (int n = 0; n < NT; ++n) bv[n] = (p.bias && !p.accum) ? p.bias[16 * n + i] : 0.f;
 #pragma unroll 1
         for (int t = 0; t < p.ntaps; ++t) {
+            const long long toff = p.up ? tapoff(t, p.H, p.W) : 0;
 #pragma unroll
             for (int r = 0; r < MT; ++r)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){bv[n], bv[n], bv[n], bv[n]};
+            if (p.accum) {
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (orow[r][reg] < 0) continue;
+                        const float* o = p.out + (orow[r][reg] + toff) * p.ldo + i;
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc[r][n][reg] = o[16 * n];
+                    }
+            }
 #pragma unroll
             for (int c = 0; c < KC; ++c)
 #pragma unroll
@@ -96,13 +110,12 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                         acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][c].w, b.w, acc[r][n], 0, 0, 0);
                     }
                 }
-            const long long toff = p.up ? tapoff(t, p.H, p.W) : 0;
 #pragma unroll
             for (int r = 0; r < MT; ++r)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     if (orow[r][reg] < 0) continue;
-                    float* o = p.out + (orow[r][reg] + toff) * p.Nc + i;
+                    float* o = p.out + (orow[r][reg] + toff) * p.ldo + i;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
                 }
@@ -112,6 +125,18 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
         for (int r = 0; r < MT; ++r)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.accum) {
+#pragma unroll
+            for (int r = 0; r < MT; ++r)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long long v = vbase + r * 16 + 4 * g + reg;
+                    if (v >= p.M) continue;
+                    const float* o = p.out + v * p.ldo + i;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[r][n][reg] = o[16 * n];
+                }
+        }
 #pragma unroll 1
         for (int t = 0; t < p.ntaps; ++t) {
             const long long toff = p.up ? tapoff(t, p.H, p.W) : 0;
@@ -120,7 +145,7 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                 float4 a[MT];
 #pragma unroll
                 for (int r = 0; r < MT; ++r)
-                    a[r] = aval[r] ? *reinterpret_cast<const float4*>(p.a + (arow[r] + toff) * p.K + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    a[r] = aval[r] ? *reinterpret_cast<const float4*>(p.a + (arow[r] + toff) * p.lda + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const float4 b = wp4[(((size_t)t * NT + n) * KC + c) * 64];
@@ -140,7 +165,7 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
             for (int reg = 0; reg < 4; ++reg) {
                 const long long v = vbase + r * 16 + 4 * g + reg;
                 if (v >= p.M) continue;
-                float* o = p.out + v * p.Nc + i;
+                float* o = p.out + v * p.ldo + i;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
             }
@@ -149,7 +174,9 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
 
 // packed B: wp[t][n][c][lane][m] = B_t[k = 16c + 4(lane>>4) + m][j = 16n + (lane&15)]
 // transposed == 0: B_t[k][j] = w[(t*K + k)*N + j]    transposed != 0: B_t[k][j] = w[(t*N + j)*K + k]
-__global__ void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int ntaps, int K, int N, int transposed) {
+// (K, N) is the slice [k0, k0 + K) x [n0, n0 + N) of the full Kt x Nt weight matrices
+__global__ void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int ntaps, int K, int N, int transposed,
+                               int Kt, int Nt, int k0, int n0) {
     const int KC = K / 16, NT = N / 16;
     const long long total = (long long)ntaps * NT * KC * 256;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -158,7 +185,7 @@ __global__ void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
         const int c = (int)(rest % KC); rest /= KC;
         const int n = (int)(rest % NT); const int t = (int)(rest / NT);
         const int k = 16 * c + 4 * (lane >> 4) + m, j = 16 * n + (lane & 15);
-        wp[idx] = transposed ? w[((size_t)t * N + j) * K + k] : w[((size_t)t * K + k) * N + j];
+        wp[idx] = transposed ? w[((size_t)t * Nt + n0 + j) * Kt + k0 + k] : w[((size_t)t * Kt + k0 + k) * Nt + n0 + j];
     }
 }
 
@@ -168,7 +195,8 @@ __global__ void pw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------
 struct PwWgP {
     const float* in; const float* dy; float* partial;
-    long long M; int D, H, W, Cin, Cout, ntaps, up;
+    long long M; int D, H, W, Cin, Cout, ntaps, up;      // Cin / Cout: the (<= 64 wide) channel slices of this launch
+    int ldi, ldy;                                        // row strides (floats): the full channel counts
     long long vox_per_wave;
 };
 
@@ -197,8 +225,8 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     // back and the NEXT step's loads are in flight while the current step's MFMAs issue (hipcc otherwise emits
     // load -> s_waitcnt vmcnt(0) -> 4 MFMAs per tap, i.e. eight exposed memory round trips per step).
     const unsigned fine_mult = p.up ? 8u : 1u;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((unsigned long long)p.M * p.Cin * 4ull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)((unsigned long long)p.M * fine_mult * p.Cout * 4ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((unsigned long long)p.M * p.ldi * 4ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)((unsigned long long)p.M * fine_mult * p.ldy * 4ull), 0x00020000);
     // this lane's voxel (v0 + g, then += 4 per K-step) tracked as (w, h, rest = n*D + d) with carries
     int cw = 0, chh = 0; long long crest = 0;
     if (p.up) {
@@ -208,11 +236,11 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     }
     unsigned toffb[TPB];
 #pragma unroll
-    for (int t = 0; t < TPB; ++t) toffb[t] = (unsigned)(toffs[t] * p.Cout * 4);
+    for (int t = 0; t < TPB; ++t) toffb[t] = (unsigned)(toffs[t] * p.ldy * 4);
     auto fetch = [&](long long vb, float* av, float (*bv)[COT]) {
         const long long v = vb + g;
         const bool ok = v < v1;
-        const unsigned offa = ok ? (unsigned)((v * p.Cin + i) * 4) : 0xFFFFFFFFu;
+        const unsigned offa = ok ? (unsigned)((v * p.ldi + i) * 4) : 0xFFFFFFFFu;
 #pragma unroll
         for (int a = 0; a < CIT; ++a)
             av[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? offa + 64u * a : 0xFFFFFFFFu, 0, 0));
@@ -222,7 +250,7 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
             cw += 4;
             while (cw >= p.W) { cw -= p.W; if (++chh >= p.H) { chh = 0; ++crest; } }
         }
-        const unsigned offb = (unsigned)((fv * p.Cout + i) * 4);
+        const unsigned offb = (unsigned)((fv * p.ldy + i) * 4);
 #pragma unroll
         for (int t = 0; t < TPB; ++t)
 #pragma unroll
@@ -304,29 +332,41 @@ int launch_pw(const PwP& p, bool gather, hipStream_t st) {
 }  // namespace
 
 bool da_pw_supported(int K, int N) {
-    return K % 16 == 0 && N % 16 == 0 && K >= 16 && K <= 64 && N >= 16 && N <= 64;
+    return K % 16 == 0 && N % 16 == 0 && K >= 16 && K <= 1024 && N >= 16 && N <= 1024;
 }
 
-size_t da_pw_packed_bytes(int ntaps, int K, int N) { return da_align((size_t)ntaps * K * N * sizeof(float)); }
+size_t da_pw_packed_bytes(int ntaps, int K, int N) { return da_align((size_t)ntaps * (K < 64 ? K : 64) * (N < 64 ? N : 64) * sizeof(float)); }
 
+// One launch covers a K x N slice of at most 64 x 64 channels with everything in registers; wider layers (the full UNet's
+// 128 - 512 channel up-samplers, unets.py:88,91,94) are tiled on the host: for every 64-wide output slice the K slices are
+// accumulated into it in stream order (accum: the accumulators start from the current output instead of the bias).
 int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
                long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
                void* ws, size_t ws_bytes, hipStream_t st) {
     if (!da_pw_supported(K, N)) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_pw_packed_bytes(ntaps, K, N)) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
-    const long long total = (long long)ntaps * K * N;
-    hipLaunchKernelGGL(pw_pack_kernel, dim3(da_grid(total, 256, 512)), dim3(256), 0, st, w, wp, ntaps, K, N, transposed);
-    DA_LAUNCH_CHECK();
-    PwP p;
-    p.a = a; p.wp = wp; p.bias = bias; p.out = out; p.M = M; p.D = D; p.H = H; p.W = W; p.K = K; p.Nc = N; p.ntaps = ntaps; p.up = up;
-    const int KC = K / 16, NT = N / 16;
-#define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) return launch_pw<kc, nt>(p, gather != 0, st)
-    DA_PW_CASE(1, 1); DA_PW_CASE(1, 2); DA_PW_CASE(2, 1); DA_PW_CASE(2, 2); DA_PW_CASE(4, 4);
-    DA_PW_CASE(1, 4); DA_PW_CASE(4, 1); DA_PW_CASE(2, 4); DA_PW_CASE(4, 2);
-    DA_PW_CASE(3, 3); DA_PW_CASE(1, 3); DA_PW_CASE(3, 1); DA_PW_CASE(2, 3); DA_PW_CASE(3, 2); DA_PW_CASE(3, 4); DA_PW_CASE(4, 3);
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int nn = (N - n0) < 64 ? (N - n0) : 64;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int kk = (K - k0) < 64 ? (K - k0) : 64;
+            const long long total = (long long)ntaps * kk * nn;
+            hipLaunchKernelGGL(pw_pack_kernel, dim3(da_grid(total, 256, 512)), dim3(256), 0, st, w, wp, ntaps, kk, nn, transposed, K, N, k0, n0);
+            DA_LAUNCH_CHECK();
+            PwP p;
+            p.a = a + k0; p.wp = wp; p.bias = bias ? bias + n0 : nullptr; p.out = out + n0; p.M = M; p.D = D; p.H = H; p.W = W;
+            p.K = kk; p.Nc = nn; p.lda = K; p.ldo = N; p.accum = k0 > 0 ? 1 : 0; p.ntaps = ntaps; p.up = up;
+            const int KC = kk / 16, NT = nn / 16;
+            int rc = DA_ERR_UNSUPPORTED;
+#define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) rc = launch_pw<kc, nt>(p, gather != 0, st)
+            DA_PW_CASE(1, 1); DA_PW_CASE(1, 2); DA_PW_CASE(2, 1); DA_PW_CASE(2, 2); DA_PW_CASE(4, 4);
+            DA_PW_CASE(1, 4); DA_PW_CASE(4, 1); DA_PW_CASE(2, 4); DA_PW_CASE(4, 2);
+            DA_PW_CASE(3, 3); DA_PW_CASE(1, 3); DA_PW_CASE(3, 1); DA_PW_CASE(2, 3); DA_PW_CASE(3, 2); DA_PW_CASE(3, 4); DA_PW_CASE(4, 3);
 #undef DA_PW_CASE
-    return DA_ERR_UNSUPPORTED;
+            if (rc) return rc;
+        }
+    }
+    return 0;
 }
 
 static int wg_blocks(long long M, size_t O, long long* vox_per_wave) {
@@ -341,9 +381,17 @@ static int wg_blocks(long long M, size_t O, long long* vox_per_wave) {
 
 size_t da_pw_wgrad_ws_bytes(long long M, int ntaps, int Cin, int Cout) {
     long long vpw;
-    const size_t O = (size_t)ntaps * Cin * Cout;
+    const size_t O = (size_t)ntaps * (Cin < 64 ? Cin : 64) * (Cout < 64 ? Cout : 64);      // one 64 x 64 slice at a time
     const int nb = wg_blocks(M, O, &vpw);
-    return da_align((size_t)nb * O * sizeof(float));
+    return da_align((size_t)nb * O * sizeof(float)) + da_align(O * sizeof(float));
+}
+
+__global__ void pw_place_kernel(const float* __restrict__ src, float* __restrict__ dw, int ntaps, int cic, int coc, int Cin, int Cout, int ci0, int co0) {
+    const int total = ntaps * cic * coc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % coc; const int ci = (i / coc) % cic; const int t = i / (coc * cic);
+        dw[((size_t)t * Cin + ci0 + ci) * Cout + co0 + co] = src[i];
+    }
 }
 
 template <int CIT, int COT, int TPB>
@@ -361,13 +409,36 @@ static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
     return 0;
 }
 
+static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout, int ldi, int ldy,
+                          int ntaps, int up, void* ws, hipStream_t st);
+
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
                 int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!da_pw_supported(Cin, Cout) || (ntaps != 1 && ntaps != 8)) return DA_ERR_UNSUPPORTED;
     if ((unsigned long long)M * (up ? 8 : 1) * Cout * 4ull >= 0xFFFFFFF0ull || (unsigned long long)M * Cin * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_pw_wgrad_ws_bytes(M, ntaps, Cin, Cout)) return DA_ERR_WS_SMALL;
+    if (Cin <= 64 && Cout <= 64) return pw_wgrad_slice(in, dy, dw, M, D, H, W, Cin, Cout, Cin, Cout, ntaps, up, ws, st);
+    // wide layers: independent 64 x 64 channel slices, each reduced into a dense scratch and placed into dW
+    long long vpw;
+    const size_t Os = (size_t)ntaps * 64 * 64;
+    const int nbmax = wg_blocks(M, Os, &vpw);
+    float* tmp = (float*)((char*)ws + da_align((size_t)nbmax * Os * sizeof(float)));
+    for (int ci0 = 0; ci0 < Cin; ci0 += 64)
+        for (int co0 = 0; co0 < Cout; co0 += 64) {
+            const int cic = (Cin - ci0) < 64 ? (Cin - ci0) : 64, coc = (Cout - co0) < 64 ? (Cout - co0) : 64;
+            const int rc = pw_wgrad_slice(in + ci0, dy + co0, tmp, M, D, H, W, cic, coc, Cin, Cout, ntaps, up, ws, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(pw_place_kernel, dim3(da_grid((long long)ntaps * cic * coc, 256, 256)), dim3(256), 0, st, tmp, dw, ntaps, cic, coc, Cin, Cout, ci0, co0);
+            DA_LAUNCH_CHECK();
+        }
+    return 0;
+}
+
+static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout, int ldi, int ldy,
+                          int ntaps, int up, void* ws, hipStream_t st) {
     PwWgP p;
     p.in = in; p.dy = dy; p.partial = (float*)ws; p.M = M; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntaps = ntaps; p.up = up;
+    p.ldi = ldi; p.ldy = ldy;
     const size_t O = (size_t)ntaps * Cin * Cout;
     const int nb = wg_blocks(M, O, &p.vox_per_wave);
     const int CIT = Cin / 16, COT = Cout / 16;

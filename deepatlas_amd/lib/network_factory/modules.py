@@ -94,6 +94,69 @@ class SegUpBlock(nn.Sequential):
         return ops.ActFn.apply(y, self.slope)
 
 
+class UNetEncBlock(nn.Sequential):
+    """`UNet.encoder` (unets.py:113-124): nn.Sequential(Conv3d(k3,p1) [, BatchNorm3d], ReLU) with positional children, so the
+    state_dict keys are '<name>.0.weight', '<name>.1.running_mean', ... as in the reference."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True, batchnorm=False):
+        if kernel_size != 3 or padding != 1 or stride != 1:
+            raise NotImplementedError('HIP conv path covers kernel 3, padding 1')
+        mods = [nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)]
+        if batchnorm:
+            mods.append(nn.BatchNorm3d(out_channels))
+        mods.append(nn.ReLU())
+        super().__init__(*mods)
+        self.batchnorm = batchnorm
+
+    def forward(self, x, skip=None):
+        conv = self[0]
+        if self.batchnorm:
+            bn = self[1]
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            return ops.ConvBNActFn.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                         self.training, bn.momentum, bn.eps, 0.0)
+        return ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, 1, 0.0)
+
+
+class UNetDecBlock(nn.Sequential):
+    """`UNet.decoder` (unets.py:126-139): nn.Sequential(ConvTranspose3d [, BatchNorm3d], ReLU).  Two shapes occur
+    (unets.py:88-96): kernel 2 / stride 2 (the up-sampler, pointwise MFMA GEMM) and kernel 3 / stride 1 / padding 1, which is a
+    3x3x3 convolution with flipped taps and runs on the conv kernels (two-pointer concat input included)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True, batchnorm=False):
+        mods = [nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                   output_padding=output_padding, bias=bias)]
+        if batchnorm:
+            mods.append(nn.BatchNorm3d(out_channels))
+        mods.append(nn.ReLU())
+        super().__init__(*mods)
+        self.batchnorm = batchnorm
+        if (kernel_size, stride, padding, output_padding) == (2, 2, 0, 0):
+            self.kind = 'up'
+        elif (kernel_size, stride, padding, output_padding) == (3, 1, 1, 0):
+            self.kind = 'conv'
+        else:
+            raise NotImplementedError('HIP transposed-conv path covers (k2, s2) and (k3, s1, p1)')
+
+    def forward(self, x, skip=None):
+        dc = self[0]
+        bn = self[1] if self.batchnorm else None
+        if bn is not None and self.training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        if self.kind == 'up':
+            if skip is not None:
+                raise ValueError('the k2/s2 up-sampler takes a single input')
+            if bn is not None:
+                return ops.DeconvBNActFn.apply(x, dc.weight, dc.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                               self.training, bn.momentum, bn.eps, 0.0)
+            return ops.ActFn.apply(ops.DeconvK2S2Fn.apply(x, dc.weight, dc.bias), 0.0)
+        if bn is not None:
+            return ops.ConvBNActFn.apply(x, skip, dc.weight, dc.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                         self.training, bn.momentum, bn.eps, 0.0, True)
+        return ops.Conv3dK3Fn.apply(x, skip, dc.weight, dc.bias, 1, 0.0, True)
+
+
 class HeadConv(nn.Conv3d):
     """nn.Conv3d(C, n_classes, 1) output layer (unets.py:249-250) -- keys '<idx>.weight', '<idx>.bias'."""
 

@@ -2,13 +2,14 @@
 
 `UNet_generator(encoders, decoders, act, upsample, maxpool, res)` returns a class with the reference's
 constructor `(in_channel, n_classes, bias=False, BN=False)`, `forward(x) -> logits N x n_classes x D x H x W`,
-`weights_init()` and identical state_dict keys.  Implemented options: maxpool=True,
-upsample=False, res=False (the 'UNet_light' configuration, lib/network_factory/__init__.py:12-15).
+`weights_init()` and identical state_dict keys.  Implemented generator options: maxpool=True,
+upsample=False, res=False (the 'UNet_light' configuration, lib/network_factory/__init__.py:12-15); the fixed `UNet`
+(unets.py:70-179) is implemented in full.
 """
 import torch
 import torch.nn as nn
 
-from .modules import SegBlock as convBlock, SegUpBlock as deconvBlock, HeadConv, MaxPool2, get_activation_function
+from .modules import SegBlock as convBlock, SegUpBlock as deconvBlock, HeadConv, MaxPool2, UNetEncBlock, UNetDecBlock, get_activation_function
 
 
 def init_conv_weights(m):
@@ -84,9 +85,63 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
 
 
 class UNet(nn.Module):
-    """The fixed 19-layer `UNet` (unets.py:70-179) is registered for API parity; its ConvTranspose3d(k3,s1,p1)
-    decoder blocks have no HIP kernel yet, so construction raises loudly."""
+    """The fixed 8+9+1-layer `UNet` (unets.py:70-179): 32 -> 512 channels, ReLU, three max-pools, ConvTranspose3d(k2,s2)
+    up-samplers and ConvTranspose3d(k3,s1,p1) decoder "convs"; same attribute names, hence the same state_dict keys
+    (`ec0.0.weight`, `dc8.1.running_mean`, `dc0.bias`, ...).  SURVEY.md row f3."""
 
     def __init__(self, in_channel, n_classes, bias=False, BN=False):
+        self.in_channel = in_channel
+        self.n_classes = n_classes
         super(UNet, self).__init__()
-        raise NotImplementedError("'UNet' (unets.py:70-179) is outside the accelerated hot path this round; use 'UNet_light'")
+        self.ec0 = self.encoder(self.in_channel, 32, bias=bias, batchnorm=BN)
+        self.ec1 = self.encoder(32, 64, bias=bias, batchnorm=BN)
+        self.ec2 = self.encoder(64, 64, bias=bias, batchnorm=BN)
+        self.ec3 = self.encoder(64, 128, bias=bias, batchnorm=BN)
+        self.ec4 = self.encoder(128, 128, bias=bias, batchnorm=BN)
+        self.ec5 = self.encoder(128, 256, bias=bias, batchnorm=BN)
+        self.ec6 = self.encoder(256, 256, bias=bias, batchnorm=BN)
+        self.ec7 = self.encoder(256, 512, bias=bias, batchnorm=BN)
+
+        self.pool0 = MaxPool2(2)
+        self.pool1 = MaxPool2(2)
+        self.pool2 = MaxPool2(2)
+
+        self.dc9 = self.decoder(512, 512, kernel_size=2, stride=2, bias=bias, batchnorm=BN)
+        self.dc8 = self.decoder(256 + 512, 256, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
+        self.dc7 = self.decoder(256, 256, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
+        self.dc6 = self.decoder(256, 256, kernel_size=2, stride=2, bias=bias, batchnorm=BN)
+        self.dc5 = self.decoder(128 + 256, 128, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
+        self.dc4 = self.decoder(128, 128, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
+        self.dc3 = self.decoder(128, 128, kernel_size=2, stride=2, bias=bias, batchnorm=BN)
+        self.dc2 = self.decoder(64 + 128, 64, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
+        self.dc1 = self.decoder(64, 64, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
+        self.dc0 = HeadConv(64, n_classes, kernel_size=1, stride=1, padding=0, bias=bias)
+
+    def weights_init(self):
+        """unets.py:102-110: xavier-normal on every module whose class name contains 'Conv' (the nn.Conv3d / ConvTranspose3d
+        parameter holders and the head)."""
+        for m in self.modules():
+            classname = m.__class__.__name__
+            if classname.find('Conv') != -1:
+                if not m.weight is None:
+                    nn.init.xavier_normal_(m.weight.data)
+                if not m.bias is None:
+                    m.bias.data.zero_()
+
+    def encoder(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True, batchnorm=False):
+        return UNetEncBlock(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias, batchnorm=batchnorm)
+
+    def decoder(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True, batchnorm=False):
+        return UNetDecBlock(in_channels, out_channels, kernel_size, stride=stride, padding=padding, output_padding=output_padding,
+                            bias=bias, batchnorm=batchnorm)
+
+    def forward(self, x):
+        """unets.py:141-179; every torch.cat((up, syn), 1) is the two-pointer input of the following block."""
+        syn0 = self.ec1(self.ec0(x))
+        syn1 = self.ec3(self.ec2(self.pool0(syn0)))
+        syn2 = self.ec5(self.ec4(self.pool1(syn1)))
+        e7 = self.ec7(self.ec6(self.pool2(syn2)))
+        d7 = self.dc7(self.dc8(self.dc9(e7), syn2))
+        d4 = self.dc4(self.dc5(self.dc6(d7), syn1))
+        d1 = self.dc1(self.dc2(self.dc3(d4), syn0))
+        return self.dc0(d1)

@@ -59,17 +59,26 @@ class Conv3dK3Fn(Function):
     Reference call sites: unets.py:30,36; modules.py:48,56-58; voxel_morph.py:57,82."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, stride, act_slope):
+    def forward(ctx, x1, x2, weight, bias, stride, act_slope, *extra):
+        # extra[0] (optional): `weight` is a ConvTranspose3d(k=3, s=1, p=1) weight [Cin][Cout][3,3,3] (unets.py:88-96): the same
+        # operation as this convolution with flipped taps, so only the weight re-layout kernels differ
+        transposed = bool(extra[0]) if extra else False
+        ctx.n_extra, ctx.transposed = len(extra), transposed
         a1 = ndhwc(x1)
         a2 = ndhwc(x2) if x2 is not None else None
         N, D, H, W, C1 = a1.shape
         C2 = a2.shape[-1] if a2 is not None else 0
-        Cout, Cin = weight.shape[0], weight.shape[1]
+        Cout, Cin = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         if Cin != C1 + C2 or tuple(weight.shape[2:]) != (3, 3, 3):
             raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
+        if transposed and stride != 1:
+            raise NotImplementedError('transposed 3x3x3 conv: stride 1 only')
         st = stream()
         w_tio = _empty((27, Cin, Cout), a1)
-        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
+        if transposed:
+            call('da_w_iok_flip_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 27, st)
+        else:
+            call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
         Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
         out = _empty((N, Do, Ho, Wo, Cout), a1)
         wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
@@ -103,9 +112,13 @@ class Conv3dK3Fn(Function):
             dw_tio = torch.empty_like(w_tio)
             db = _empty((Cout,), a1) if ctx.has_bias else None
             call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(db), N, D, H, W, Cout, stride, wp, wn, st)
-            dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
-            call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
-        return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None)
+            if ctx.transposed:
+                dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
+                call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
+            else:
+                dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
+                call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+        return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None) + (None,) * ctx.n_extra
 
 
 class Conv1x1Fn(Function):
@@ -280,17 +293,22 @@ class ConvBNActFn(Function):
     then the conv data / weight gradients."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x1, x2, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, *extra):
+        transposed = bool(extra[0]) if extra else False        # ConvTranspose3d(k3,s1,p1) weight, see Conv3dK3Fn
+        ctx.n_extra, ctx.transposed = len(extra), transposed
         a1 = ndhwc(x1)
         a2 = ndhwc(x2) if x2 is not None else None
         N, D, H, W, C1 = a1.shape
         C2 = a2.shape[-1] if a2 is not None else 0
-        Cout, Cin = weight.shape[0], weight.shape[1]
+        Cout, Cin = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         if Cin != C1 + C2 or tuple(weight.shape[2:]) != (3, 3, 3):
             raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
         st = stream()
         w_tio = _empty((27, Cin, Cout), a1)
-        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
+        if transposed:
+            call('da_w_iok_flip_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 27, st)
+        else:
+            call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
         y = _empty((N, D, H, W, Cout), a1)
         wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, 1)
         wp, wn = _ws(wsb, a1)
@@ -327,10 +345,14 @@ class ConvBNActFn(Function):
             call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
         dw_tio = torch.empty_like(w_tio)
         call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
-        dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
-        call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+        if ctx.transposed:
+            dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
+            call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
+        else:
+            dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
+            call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, dgamma, dbeta,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None) + (None,) * ctx.n_extra
 
 
 class DeconvBNActFn(Function):

@@ -42,6 +42,10 @@ int da_w_tio_to_oik(const float* w_tio, float* w_oik, int Cout, int Cin, int K3,
 /* [Cin][Cout][k^3] (nn.ConvTranspose3d, unets.py:49,55) <-> [k^3][Cin][Cout] */
 int da_w_iok_to_tio(const float* w_iok, float* w_tio, int Cin, int Cout, int K3, void* stream);
 int da_w_tio_to_iok(const float* w_tio, float* w_iok, int Cin, int Cout, int K3, void* stream);
+/* ConvTranspose3d(k=3, s=1, p=1) weights [Cin][Cout][27] (unets.py:88-96 `UNet.decoder`): the same op as a 3x3x3 convolution with
+ * flipped taps, so it runs on the da_conv3d_k3_* entries after this re-layout. */
+int da_w_iok_flip_to_tio(const float* w_iok, float* w_tio, int Cin, int Cout, int K3, void* stream);
+int da_w_tio_to_iok_flip(const float* w_tio, float* w_iok, int Cin, int Cout, int K3, void* stream);
 
 /* ---- 3x3x3 convolution, padding 1, stride 1|2 (rows a1, a7, a9) ----------------------------- */
 /* replaces nn.Conv3d(k=3,p=1) forward: unets.py:30,36; modules.py:48,56; voxel_morph.py:57,82.

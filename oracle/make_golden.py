@@ -275,6 +275,38 @@ def run_reglosses(ref, out):
         out['gradloss/%s/grad' % tag] = np32(g)
 
 
+def run_unet_full(ref, out):
+    """the fixed `UNet` (unets.py:70-179) at 16^3, closed-form weights: forward, Dice loss, every gradient,
+    BN running stats after the step -- with and without BatchNorm; big tensors as summaries."""
+    from oracle import nets
+    shape, n_classes = (16, 16, 16), 3
+    x = nets.closed_form_volume((1, 1) + shape, seed=70)
+    y = nets.closed_form_labels((1,) + shape, n_classes, seed=71)
+    for BN in (False, True):
+        tag = 'unet_full/bn%d' % int(BN)
+        shapes = nets.unet_full_param_shapes(1, n_classes, bias=True, BN=BN)
+        sd0 = nets.closed_form_fill_positional(shapes, seed=4)
+        model = ref.nf.get_network('UNet')(1, n_classes, bias=True, BN=BN)
+        assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+        load_sd(model, sd0)
+        for dtype in (torch.float32, torch.float64):
+            m = copy.deepcopy(model).to(dtype)
+            m.train()
+            crit = ref.loss.get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+            logits = m(x.to(dtype))
+            loss = crit(logits, y.long())
+            loss.backward()
+            t = tag + ('' if dtype == torch.float32 else '_f64')
+            out[t + '/loss'] = np.float64(loss.item())
+            out[t + '/logits'] = summary(logits)
+            for n, p in m.named_parameters():
+                out[t + '/grad/' + n] = summary(p.grad)
+            if BN and dtype == torch.float32:
+                for n, v in m.state_dict().items():
+                    if 'running_' in n:
+                        out[t + '/after/' + n] = np32(v)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -290,6 +322,10 @@ def main():
     run_reglosses(ref, out)
     np.savez_compressed(os.path.join(OUT, 'reglosses.npz'), **out)
     print('reglosses.npz', len(out))
+    out = {}
+    run_unet_full(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'unet_full.npz'), **out)
+    print('unet_full.npz', len(out))
     if os.environ.get('GOLDEN_ONLY') in ('eval', 'f'):
         return
 

@@ -244,3 +244,82 @@ def voxelmorph_forward(sd, source, target):
     deform = disp + identity_transform(source.shape[2:], disp.dtype)
     warped = warp_trilinear(source, deform)
     return disp, warped, deform
+
+
+# ---- the fixed `UNet` (lib/network_factory/unets.py:70-179) -------------------------------------------------
+UNET_FULL_ENC = [('ec0', None, 32), ('ec1', 32, 64), ('ec2', 64, 64), ('ec3', 64, 128), ('ec4', 128, 128), ('ec5', 128, 256),
+                 ('ec6', 256, 256), ('ec7', 256, 512)]                                    # unets.py:75-82 (Conv3d k3 p1)
+UNET_FULL_DEC = [('dc9', 512, 512, 2), ('dc8', 256 + 512, 256, 3), ('dc7', 256, 256, 3), ('dc6', 256, 256, 2),
+                 ('dc5', 128 + 256, 128, 3), ('dc4', 128, 128, 3), ('dc3', 128, 128, 2), ('dc2', 64 + 128, 64, 3),
+                 ('dc1', 64, 64, 3)]                                                      # unets.py:88-96 (ConvTranspose3d)
+
+
+def unet_full_param_shapes(in_channel, n_classes, bias=True, BN=True):
+    """state_dict keys / shapes of `UNet(in_channel, n_classes, bias, BN)`: nn.Sequential children are positional
+    ('<name>.0' conv or transposed conv, '<name>.1' BatchNorm3d)."""
+    shapes = {}
+
+    def bn(prefix, c):
+        if BN:
+            shapes[prefix + '.1.weight'] = (c,); shapes[prefix + '.1.bias'] = (c,)
+            shapes[prefix + '.1.running_mean'] = (c,); shapes[prefix + '.1.running_var'] = (c,)
+            shapes[prefix + '.1.num_batches_tracked'] = ()
+    for name, cin, cout in UNET_FULL_ENC:
+        cin = in_channel if cin is None else cin
+        shapes[name + '.0.weight'] = (cout, cin, 3, 3, 3)
+        if bias:
+            shapes[name + '.0.bias'] = (cout,)
+        bn(name, cout)
+    for name, cin, cout, k in UNET_FULL_DEC:
+        shapes[name + '.0.weight'] = (cin, cout, k, k, k)                                  # ConvTranspose3d: [Cin][Cout][k^3]
+        if bias:
+            shapes[name + '.0.bias'] = (cout,)
+        bn(name, cout)
+    shapes['dc0.weight'] = (n_classes, 64, 1, 1, 1)                                          # unets.py:98
+    if bias:
+        shapes['dc0.bias'] = (n_classes,)
+    return shapes
+
+
+def closed_form_fill_positional(shapes, seed=0, dtype=torch.float32):
+    """closed_form_fill for positional nn.Sequential keys: a 1-D 'weight' is a BatchNorm weight, a 'bias' whose sibling
+    'running_mean' exists is a BatchNorm bias; everything else as in closed_form_fill."""
+    renamed = {}
+    for name, shp in shapes.items():
+        stem = name.rsplit('.', 1)[0]
+        is_bn = (stem + '.running_mean') in shapes
+        if is_bn and name.endswith(('.weight', '.bias')):
+            renamed[stem + '.BN.' + name.rsplit('.', 1)[1]] = (name, shp)
+        else:
+            renamed[name] = (name, shp)
+    filled = closed_form_fill({k: v[1] for k, v in renamed.items()}, seed=seed, dtype=dtype)
+    return {renamed[k][0]: v for k, v in filled.items()}
+
+
+def unet_full_forward(sd, x, training=True, momentum=0.1, eps=1e-5):
+    """UNet.forward, unets.py:141-179.  sd: reference state_dict keys; BN running stats updated in place when training."""
+    def block(x, name, transposed, k=3):
+        w, b = sd[name + '.0.weight'], sd.get(name + '.0.bias')
+        if not transposed:
+            y = F.conv3d(x, w, b, stride=1, padding=1)                                       # encoder :113-124
+        elif k == 2:
+            y = F.conv_transpose3d(x, w, b, stride=2)                                        # decoder k2 s2 :88,91,94
+        else:
+            y = F.conv_transpose3d(x, w, b, stride=1, padding=1)                             # decoder k3 s1 p1 :89-90,...
+        if (name + '.1.weight') in sd:
+            y = F.batch_norm(y, sd[name + '.1.running_mean'], sd[name + '.1.running_var'], sd[name + '.1.weight'],
+                             sd[name + '.1.bias'], training, momentum, eps)
+            if training:
+                sd[name + '.1.num_batches_tracked'] += 1
+        return F.relu(y)
+    syn0 = block(block(x, 'ec0', False), 'ec1', False)
+    syn1 = block(block(F.max_pool3d(syn0, 2), 'ec2', False), 'ec3', False)
+    syn2 = block(block(F.max_pool3d(syn1, 2), 'ec4', False), 'ec5', False)
+    e7 = block(block(F.max_pool3d(syn2, 2), 'ec6', False), 'ec7', False)
+    d9 = torch.cat((block(e7, 'dc9', True, 2), syn2), dim=1)
+    d7 = block(block(d9, 'dc8', True), 'dc7', True)
+    d6 = torch.cat((block(d7, 'dc6', True, 2), syn1), dim=1)
+    d4 = block(block(d6, 'dc5', True), 'dc4', True)
+    d3 = torch.cat((block(d4, 'dc3', True, 2), syn0), dim=1)
+    d1 = block(block(d3, 'dc2', True), 'dc1', True)
+    return F.conv3d(d1, sd['dc0.weight'], sd.get('dc0.bias'))

@@ -108,7 +108,8 @@ def test_conv3d_mfma_asymmetric_identity():
     check(y, F.conv3d(x, w, None, padding=1), tol=1e-6, what='impulse response')
 
 
-@pytest.mark.parametrize('Cin,Cout,dims', [(16, 16, (1, 3, 4, 5)), (64, 64, (1, 2, 3, 5)), (32, 32, (2, 4, 4, 6)), (6, 5, (1, 2, 3, 4))])
+@pytest.mark.parametrize('Cin,Cout,dims', [(16, 16, (1, 3, 4, 5)), (64, 64, (1, 2, 3, 5)), (32, 32, (2, 4, 4, 6)), (6, 5, (1, 2, 3, 4)),
+                                           (128, 128, (1, 3, 4, 5)), (256, 80, (1, 2, 3, 5)), (48, 192, (1, 2, 2, 3))])   # > 64: host-tiled 64 x 64 slices (full UNet)
 def test_deconv_k2s2(Cin, Cout, dims):
     from deepatlas_amd import ops
     N, D, H, W = dims
@@ -123,7 +124,7 @@ def test_deconv_k2s2(Cin, Cout, dims):
     check(yg, yr, what='fwd'); check(xg.grad, xr.grad, what='dgrad'); check(wg.grad, wr.grad, what='wgrad'); check(bg.grad, br.grad, what='bgrad')
 
 
-@pytest.mark.parametrize('Cin,Cout', [(16, 32), (8, 5), (16, 3)])
+@pytest.mark.parametrize('Cin,Cout', [(16, 32), (8, 5), (16, 3), (128, 32), (80, 144)])
 def test_conv1x1(Cin, Cout):
     from deepatlas_amd import ops
     x, w, b = rnd((2, Cin, 4, 6, 10), 1), rnd((Cout, Cin, 1, 1, 1), 2, 0.3), rnd((Cout,), 3, 0.1)

@@ -234,3 +234,31 @@ def test_reg_losses_f2_oracle_vs_reference(golden):
         gu, = torch.autograd.grad(l, u)
         assert abs(l.item() - float(g['gradloss/%s/loss' % tag])) < 1e-6 * max(1.0, abs(float(g['gradloss/%s/loss' % tag])))
         assert rel_l2(gu.numpy(), g['gradloss/%s/grad' % tag]) < 1e-6
+
+
+# ---- the fixed `UNet` ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('BN', [False, True])
+def test_unet_full_oracle_vs_reference(golden, BN):
+    """oracle.nets.unet_full_forward == UNet.forward (unets.py:141-179): logits, Dice loss, gradients (l2 of every tensor)."""
+    import torch
+    from oracle import nets, losses
+    g = golden('unet_full')
+    tag = 'unet_full/bn%d' % int(BN)
+    sd = nets.closed_form_fill_positional(nets.unet_full_param_shapes(1, 3, bias=True, BN=BN), seed=4)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+    state = dict(sd); state.update(params)
+    x = nets.closed_form_volume((1, 1, 16, 16, 16), seed=70)
+    y = nets.closed_form_labels((1, 16, 16, 16), 3, seed=71)
+    logits = nets.unet_full_forward(state, x, training=True)
+    loss = losses.dice_loss(logits, y.long(), n_class=3, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + '/loss'])) < 1e-6
+    assert rel_l2(summary_of(logits)[5:], g[tag + '/logits'][5:]) < 1e-5
+    for n, p in params.items():
+        ref = g[tag + '/grad/' + n]
+        if ref[2] > 1e-12:
+            assert abs(summary_of(p.grad)[2] - ref[2]) / ref[2] < 1e-4, n
+    if BN:
+        for n, v in state.items():
+            if 'running_' in n:
+                np.testing.assert_allclose(v.numpy(), g[tag + '/after/' + n], rtol=1e-5, atol=1e-7)
