@@ -67,8 +67,11 @@ def test_no_cpu_fallback():
 def test_out_of_scope_constructors_raise():
     from deepatlas_amd.lib.network_factory import get_network
     from deepatlas_amd.lib.loss import get_loss_function
-    with pytest.raises(NotImplementedError):
-        get_network('UNet')(1, 2)
+    from deepatlas_amd.lib.network_factory import unets
+    with pytest.raises(NotImplementedError):        # generator options still outside the accelerated path
+        unets.UNet_generator(encoders=[(8, 8)], decoders=[], upsample=True)
+    m = get_network('UNet')(1, 2, bias=True, BN=True)     # the fixed UNet is on the path: constructible on the host
+    assert 'dc8.1.running_mean' in m.state_dict() and tuple(m.state_dict()['dc8.0.weight'].shape) == (768, 256, 3, 3, 3)
     with pytest.raises(NotImplementedError):
         get_loss_function('focal')()
     # rows f1/f2 are on the accelerated path: constructible on the host, state_dict as the reference's
