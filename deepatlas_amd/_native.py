@@ -74,6 +74,12 @@ SIGNATURES = {
     'da_bending_bwd': (I, [P, P, P, I, I, I, I, P, I, P]),
     'da_argmax_dice_counts': (I, [P, P, I, I, LL, I, P, P, P]),
     'da_label_overlap_counts': (I, [P, I, P, I, I, LL, I, P, P]),
+    'da_conv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_conv_k2s2_dgrad': (I, [P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_conv_k2s2_wgrad_ws_bytes': (SZ, [I, I, I, I, I, I]),
+    'da_conv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_upsample_trilinear2_fwd': (I, [P, P, I, I, I, I, I, P]),
+    'da_upsample_trilinear2_bwd': (I, [P, P, I, I, I, I, I, P]),
     'da_lncc_ws_bytes': (SZ, [I, I, I, I, I]),
     'da_lncc_fwd': (I, [P, P, I, I, I, I, I, F, P, P, P, SZ, P]),
     'da_lncc_bwd': (I, [P, P, P, P, P, P, I, I, I, I, I, F, P, SZ, P]),

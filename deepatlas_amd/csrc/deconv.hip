@@ -316,3 +316,43 @@ extern "C" int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, 
         return da_colsum(dy, M, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// nn.Conv3d(kernel 2, stride 2, padding 0) -- the generator's maxpool=False down-sampler (unets.py:231-233).  It is the adjoint
+// of the k2/s2 transposed conv, so it runs on the same pointwise MFMA kernels with the roles swapped:
+//   fwd  = GATHER gemm (fine x -> coarse y, + bias)   dgrad = SCATTER gemm (coarse dy -> fine dx)   wgrad = pw wgrad with
+//   (in := dy coarse, dy := x fine), which yields dW as [tap][Cout][Cin].
+// Weights: w_tio [8][Cin][Cout] (da_w_oik_to_tio with K3 = 8).  D, H, W are the COARSE (output) dims; the fine input is exactly
+// 2D x 2H x 2W (even input sizes), channels multiples of 16.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int da_conv_k2s2_fwd(const float* x, const float* w_tio, const float* bias, float* y,
+                                int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w_tio || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm(x, w_tio, 0, bias, y, (long long)N * D * H * W, D, H, W, Cin, Cout, 8, 1, 1, ws, ws_bytes, da_stream(stream));
+}
+
+extern "C" int da_conv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
+                                  int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w_tio || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cout, Cin)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm(dy, w_tio, 1, nullptr, dx, (long long)N * D * H * W, D, H, W, Cout, Cin, 8, 1, 0, ws, ws_bytes, da_stream(stream));
+}
+
+extern "C" size_t da_conv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    return da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cout, Cin);
+}
+
+// dw_toi: [8][Cout][Cin] (convert with da_w_tio_to_iok(dw_toi, dw_oik, Cout, Cin, 8)); dbias [Cout] optional
+extern "C" int da_conv_k2s2_wgrad(const float* x, const float* dy, float* dw_toi, float* dbias,
+                                  int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw_toi || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cout, Cin)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    const int rc = da_pw_wgrad(dy, x, dw_toi, (long long)N * D * H * W, D, H, W, Cout, Cin, 8, 1, ws, cs_off, st);
+    if (rc) return rc;
+    if (dbias) return da_colsum(dy, (long long)N * D * H * W, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
+    return 0;
+}

@@ -122,9 +122,11 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < MT; ++r)
+        for (int n = 0; n < NT; ++n) {
+            const float bvn = (p.bias && !p.accum) ? p.bias[16 * n + i] : 0.f;       // only the strided conv (k2 s2) has a bias here
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < MT; ++r) acc[r][n] = (f32x4){bvn, bvn, bvn, bvn};
+        }
         if (p.accum) {
 #pragma unroll
             for (int r = 0; r < MT; ++r)

@@ -139,6 +139,83 @@ __global__ void upsample_nearest_bwd_kernel(const float* __restrict__ dy, float*
     }
 }
 
+// nn.Upsample(scale_factor=2, mode='trilinear') (align_corners=False; unets.py:236, the generator's upsample=True option):
+// src = max((dst + 0.5) / 2 - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, in - 1); lambda = src - i0.
+__device__ __forceinline__ void tri2_src(int dst, int in, int& i0, int& i1, float& l1) {
+    float s = ((float)dst + 0.5f) * 0.5f - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s; if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+    l1 = s - (float)i0;
+}
+
+template <int VEC>
+__global__ void upsample_tri2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int D, int H, int W, int C) {
+    const int cq = C / VEC, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * Do * Ho * Wo * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
+        tri2_src(od, D, d0, d1, ld); tri2_src(oh, H, h0, h1, lh); tri2_src(ow, W, w0, w1, lw);
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
+            // same association as ATen's upsample_trilinear3d: w-lerp, then h, then d
+            const float wgt = ((k & 4) ? ld : 1.f - ld) * (((k & 2) ? lh : 1.f - lh) * ((k & 1) ? lw : 1.f - lw));
+            const float* p = x + ((((long long)n * D + dd) * H + hh) * W + ww) * C + q * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += wgt * p[j];
+        }
+        float* o = y + i * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = acc[j];
+    }
+}
+
+// gather form of the backward: input voxel (d, h, w) collects from the outputs whose i0 or i1 is it (<= 5 candidates per axis)
+template <int VEC>
+__global__ void upsample_tri2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int D, int H, int W, int C) {
+    const int cq = C / VEC, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * D * H * W * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H); v /= H;
+        const int d = (int)(v % D); const int n = (int)(v / D);
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        for (int od = max(0, 2 * d - 2); od <= min(Do - 1, 2 * d + 2); ++od) {
+            int a0, a1; float la; tri2_src(od, D, a0, a1, la);
+            const float wd = (a0 == d ? 1.f - la : 0.f) + (a1 == d ? la : 0.f);
+            if (wd == 0.f) continue;
+            for (int oh = max(0, 2 * h - 2); oh <= min(Ho - 1, 2 * h + 2); ++oh) {
+                int b0, b1; float lb; tri2_src(oh, H, b0, b1, lb);
+                const float wh = (b0 == h ? 1.f - lb : 0.f) + (b1 == h ? lb : 0.f);
+                if (wh == 0.f) continue;
+                for (int ow = max(0, 2 * w - 2); ow <= min(Wo - 1, 2 * w + 2); ++ow) {
+                    int c0, c1; float lc; tri2_src(ow, W, c0, c1, lc);
+                    const float ww = (c0 == w ? 1.f - lc : 0.f) + (c1 == w ? lc : 0.f);
+                    if (ww == 0.f) continue;
+                    const float wgt = wd * (wh * ww);
+                    const float* p = dy + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] += wgt * p[j];
+                }
+            }
+        }
+        float* o = dx + i * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = acc[j];
+    }
+}
+
 }  // namespace
 
 #define DA_VEC_DISPATCH(KERNEL, total, ...)                                                                      \
@@ -179,5 +256,19 @@ extern "C" int da_upsample_nearest_bwd(const float* dy, float* dx, int N, int D,
     if (!dy || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return DA_ERR_BADARG;
     const long long total = (long long)N * D * H * W * C;
     DA_VEC_DISPATCH(upsample_nearest_bwd_kernel, total, dy, dx, N, D, H, W, C, Do, Ho, Wo);
+    return 0;
+}
+
+extern "C" int da_upsample_trilinear2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return DA_ERR_BADARG;
+    const long long total = (long long)N * D * H * W * 8 * C;
+    DA_VEC_DISPATCH(upsample_tri2_fwd_kernel, total, x, y, N, D, H, W, C);
+    return 0;
+}
+
+extern "C" int da_upsample_trilinear2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, void* stream) {
+    if (!dy || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return DA_ERR_BADARG;
+    const long long total = (long long)N * D * H * W * C;
+    DA_VEC_DISPATCH(upsample_tri2_bwd_kernel, total, dy, dx, N, D, H, W, C);
     return 0;
 }

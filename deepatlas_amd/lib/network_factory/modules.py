@@ -164,6 +164,21 @@ class HeadConv(nn.Conv3d):
         return ops.Conv1x1Fn.apply(x, self.weight, self.bias)
 
 
+class DownConv(nn.Conv3d):
+    """nn.Conv3d(C, C', kernel_size=2, stride=2, padding=0): the generator's maxpool=False down-sampler (unets.py:231-233);
+    keys 'down_samplers.<i>.weight' / '.bias'."""
+
+    def forward(self, x):
+        return ops.ConvK2S2Fn.apply(x, self.weight, self.bias)
+
+
+class UpsampleTrilinear2(nn.Upsample):
+    """nn.Upsample(scale_factor=2, mode="trilinear"): the generator's upsample=True up-sampler (unets.py:236), no parameters."""
+
+    def forward(self, x):
+        return ops.UpsampleTrilinear2Fn.apply(x)
+
+
 class MaxPool2(nn.MaxPool3d):
     """nn.MaxPool3d(2) (unets.py:230)."""
 

@@ -2,14 +2,15 @@
 
 `UNet_generator(encoders, decoders, act, upsample, maxpool, res)` returns a class with the reference's
 constructor `(in_channel, n_classes, bias=False, BN=False)`, `forward(x) -> logits N x n_classes x D x H x W`,
-`weights_init()` and identical state_dict keys.  Implemented generator options: maxpool=True,
-upsample=False, res=False (the 'UNet_light' configuration, lib/network_factory/__init__.py:12-15); the fixed `UNet`
-(unets.py:70-179) is implemented in full.
+`weights_init()` and identical state_dict keys.  All generator options are implemented: maxpool=False
+(strided k2/s2 conv down-sampler), upsample=True (trilinear x2), res=True (residual adds), besides the 'UNet_light'
+configuration (lib/network_factory/__init__.py:12-15); the fixed `UNet` (unets.py:70-179) is implemented in full.
 """
 import torch
 import torch.nn as nn
 
-from .modules import SegBlock as convBlock, SegUpBlock as deconvBlock, HeadConv, MaxPool2, UNetEncBlock, UNetDecBlock, get_activation_function
+from .modules import (SegBlock as convBlock, SegUpBlock as deconvBlock, HeadConv, MaxPool2, DownConv, UpsampleTrilinear2,
+                      UNetEncBlock, UNetDecBlock, get_activation_function)
 
 
 def init_conv_weights(m):
@@ -24,8 +25,6 @@ def init_conv_weights(m):
 
 def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True, res=False):
     """unets.py:182-280."""
-    if upsample or not maxpool or res:
-        raise NotImplementedError("HIP path implements maxpool=True, upsample=False, res=False (SURVEY.md §8f f3)")
 
     class UNetTemplate(nn.Module):
         def __init__(self, in_channel, n_classes, bias=False, BN=False):
@@ -47,11 +46,15 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
                 blocks = [convBlock(enc[k], enc[k + 1], bias=bias, batchnorm=BN, act=act) for k in range(len(enc) - 1)]
                 self.encoders.append(nn.Sequential(*blocks))
                 if i < len(encoders) - 1:
-                    self.down_samplers.append(MaxPool2(2))
+                    self.down_samplers.append(MaxPool2(2) if self.maxpool
+                                              else DownConv(enc[-1], encoders[i + 1][0], kernel_size=2, stride=2, padding=0, bias=bias))
 
             for i, dec in enumerate(decoders):
-                self.up_samplers.append(deconvBlock(encoders[-1][-1] if i == 0 else decoders[i - 1][-1], dec[0],
-                                                    kernel_size=2, stride=2, bias=bias, batchnorm=BN, act=act))
+                if self.upsample:
+                    self.up_samplers.append(UpsampleTrilinear2(scale_factor=2, mode="trilinear"))
+                else:
+                    self.up_samplers.append(deconvBlock(encoders[-1][-1] if i == 0 else decoders[i - 1][-1], dec[0],
+                                                        kernel_size=2, stride=2, bias=bias, batchnorm=BN, act=act))
                 dec = (encoders[-(i + 2)][-1] + dec[0],) + dec[1:]
                 # reference quirk kept: the block count comes from the leaked encoder loop variable (unets.py:247)
                 blocks = [convBlock(dec[k], dec[k + 1], kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN, act=act)
@@ -67,8 +70,10 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
             """unets.py:259-278.  The skip concat (up-sampled first, skip second) is a two-pointer conv input."""
             temp = []
             for i, enc in enumerate(self.encoders):
+                y = x
                 for blk in enc:
-                    x = blk(x)
+                    y = blk(y)
+                x = (y + x) if self.res else y            # res=True: `enc(x) + x` (unets.py:264; broadcasts a 1-channel input)
                 if i < self.levels - 1:
                     temp.append(x)
                     x = self.down_samplers[i](x)
@@ -76,9 +81,10 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
                 x = self.up_samplers[j](x)
                 skip = temp.pop()
                 blocks = list(dec)
-                x = blocks[0](x, skip)
+                y = blocks[0](x, skip)
                 for blk in blocks[1:]:
-                    x = blk(x)
+                    y = blk(y)
+                x = (y + x) if self.res else y            # res=True: `dec(cat(x, skip)) + x` (unets.py:275)
             return x
 
     return UNetTemplate

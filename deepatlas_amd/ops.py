@@ -206,6 +206,75 @@ class DeconvK2S2Fn(Function):
         return (ncdhw(dx) if dx is not None else None), dw, db
 
 
+class ConvK2S2Fn(Function):
+    """nn.Conv3d(kernel 2, stride 2, padding 0): UNet_generator(maxpool=False) down-sampler (unets.py:231-233).  The adjoint of
+    the k2/s2 transposed conv, on the same pointwise MFMA kernels.  Even spatial sizes, channels in multiples of 16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        a = ndhwc(x)
+        N, D2, H2, W2, Cin = a.shape
+        Cout = weight.shape[0]
+        if weight.shape[1] != Cin or tuple(weight.shape[2:]) != (2, 2, 2):
+            raise ValueError('Conv3d(k2,s2) weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
+        if (D2 | H2 | W2) & 1 or Cin % 16 or Cout % 16:
+            raise NotImplementedError('HIP strided-conv down-sampler: even spatial sizes and channels in multiples of 16')
+        D, H, W = D2 // 2, H2 // 2, W2 // 2
+        st = stream()
+        w_tio = _empty((8, Cin, Cout), a)
+        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 8, st)
+        out = _empty((N, D, H, W, Cout), a)
+        b = bias.detach().contiguous() if bias is not None else None
+        wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
+        call('da_conv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cin, Cout, wp, wn, st)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a, w_tio)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, w_tio = ctx.saved_tensors
+        N, D2, H2, W2, Cin = a.shape
+        D, H, W = D2 // 2, H2 // 2, W2 // 2
+        Cout = w_tio.shape[2]
+        st = stream()
+        g = ndhwc(gout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(a)
+            wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cout, Cin), a)
+            call('da_conv_k2s2_dgrad', ptr(g), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw_toi = _empty((8, Cout, Cin), a)
+            db = _empty((Cout,), a) if ctx.has_bias else None
+            wp, wn = _ws(nat.lib().da_conv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
+            call('da_conv_k2s2_wgrad', ptr(a), ptr(g), ptr(dw_toi), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
+            dw = _empty((Cout, Cin, 2, 2, 2), a)
+            call('da_w_tio_to_iok', ptr(dw_toi), ptr(dw), Cout, Cin, 8, st)          # [8][Cout][Cin] -> [Cout][Cin][8]
+        return (ncdhw(dx) if dx is not None else None), dw, db
+
+
+class UpsampleTrilinear2Fn(Function):
+    """nn.Upsample(scale_factor=2, mode='trilinear') (align_corners=False): UNet_generator(upsample=True), unets.py:236."""
+
+    @staticmethod
+    def forward(ctx, x):
+        a = ndhwc(x)
+        N, D, H, W, C = a.shape
+        out = _empty((N, 2 * D, 2 * H, 2 * W, C), a)
+        call('da_upsample_trilinear2_fwd', ptr(a), ptr(out), N, D, H, W, C, stream())
+        ctx.dims = (N, D, H, W, C)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        N, D, H, W, C = ctx.dims
+        g = ndhwc(gout)
+        dx = _empty((N, D, H, W, C), g)
+        call('da_upsample_trilinear2_bwd', ptr(g), ptr(dx), N, D, H, W, C, stream())
+        return ncdhw(dx)
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm3d + activation
 # ------------------------------------------------------------------------------------------------

@@ -198,6 +198,20 @@ int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* s
 int da_bending_bwd(const float* disp, const float* dloss, float* d_disp, int N, int D, int H, int W,
                    const float* spacing3, int normalize, void* stream);
 
+/* ---- UNet_generator options (unets.py:230-237) ---------------------------------------------------------------
+ * maxpool=False: nn.Conv3d(k2, s2, p0) down-sampler = the adjoint of the k2/s2 transposed conv (same pointwise MFMA kernels).
+ * D, H, W are the COARSE (output) dims, the input is 2D x 2H x 2W; w_tio [8][Cin][Cout]; dw_toi [8][Cout][Cin]. */
+int da_conv_k2s2_fwd(const float* x, const float* w_tio, const float* bias, float* y,
+                     int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
+                       int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+size_t da_conv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int da_conv_k2s2_wgrad(const float* x, const float* dy, float* dw_toi, float* dbias,
+                       int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* upsample=True: nn.Upsample(scale_factor=2, mode='trilinear') (align_corners=False); x [N][D][H][W][C] -> y [N][2D][2H][2W][C] */
+int da_upsample_trilinear2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
+int da_upsample_trilinear2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, void* stream);
+
 /* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC, registry 'lncc') ------------------------
  * I, J: [N][D][H][W] fp32 (single channel); F^3 all-ones window, valid padding; loss = 1 - mean(cross^2 / (Ivar Jvar + eps)).
  * sums: [5][N][D-F+1][H-F+1][W-F+1] window sums (I, J, I^2, J^2, IJ), written by fwd and consumed by bwd. */

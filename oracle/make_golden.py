@@ -307,6 +307,36 @@ def run_unet_full(ref, out):
                         out[t + '/after/' + n] = np32(v)
 
 
+def run_unet_options(ref, out):
+    """UNet_generator options (unets.py:230-237,264,275): UNET_OPT = maxpool=False (strided conv) +
+    upsample=True (trilinear), UNET_RES = res=True; first training step (logits, loss, every gradient), fp32 and fp64."""
+    from oracle import nets
+    shape, n_classes = (8, 8, 16), 16
+    x = nets.closed_form_volume((1, 1) + shape, seed=80)
+    y = nets.closed_form_labels((1,) + shape, n_classes, seed=81)
+    for name in ('UNET_OPT', 'UNET_RES'):
+        spec = getattr(nets, name)
+        cls = ref.unets.UNet_generator(encoders=spec['encoders'], decoders=spec['decoders'], act='ReLU', maxpool=spec['maxpool'],
+                                       upsample=spec['upsample'], res=spec['res'])
+        shapes = nets.unet_param_shapes(1, n_classes, spec['encoders'], spec['decoders'], maxpool=spec['maxpool'], upsample=spec['upsample'])
+        sd0 = nets.closed_form_fill(shapes, seed=5)
+        model = cls(1, n_classes, bias=True, BN=True)
+        assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+        load_sd(model, sd0)
+        for dtype in (torch.float32, torch.float64):
+            m = copy.deepcopy(model).to(dtype)
+            m.train()
+            crit = ref.loss.get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+            logits = m(x.to(dtype))
+            loss = crit(logits, y.long())
+            loss.backward()
+            t = 'unet_opt/' + name + ('' if dtype == torch.float32 else '_f64')
+            out[t + '/loss'] = np.float64(loss.item())
+            out[t + '/logits'] = np32(logits)
+            for n, p in m.named_parameters():
+                out[t + '/grad/' + n] = np32(p.grad)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -322,6 +352,13 @@ def main():
     run_reglosses(ref, out)
     np.savez_compressed(os.path.join(OUT, 'reglosses.npz'), **out)
     print('reglosses.npz', len(out))
+    out = {}
+    run_unet_options(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'unet_options.npz'), **out)
+    print('unet_options.npz', len(out))
+    if os.environ.get('GOLDEN_ONLY') == 'opt':
+        return
+
     out = {}
     run_unet_full(ref, out)
     np.savez_compressed(os.path.join(OUT, 'unet_full.npz'), **out)

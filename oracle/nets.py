@@ -18,6 +18,11 @@ UNET_LIGHT = dict(encoders=[(8, 16), (16, 16, 32), (32, 32, 64), (64, 64, 64)],
 UNET_TINY = dict(encoders=[(4, 8), (8, 8, 8), (8, 8, 16), (16, 16, 16)],
                  decoders=[(16, 16, 16), (16, 8, 8), (8, 8, 8)],
                  slope=0.01)
+# UNet_generator option fixtures (unets.py:230-237,264,275): strided-conv down-samplers + trilinear up-samplers,
+# and the residual variant (channel counts chosen so that `enc(x) + x` / `dec(.) + x` are well formed; the head maps to 16 classes)
+UNET_OPT = dict(encoders=[(16, 16), (16, 16, 16), (32, 32, 32)], decoders=[(32, 16, 16), (16, 16, 16)], slope=0.0,
+                maxpool=False, upsample=True, res=False)
+UNET_RES = dict(encoders=[(16, 16), (16, 16, 16)], decoders=[(16, 16, 16)], slope=0.0, maxpool=True, upsample=False, res=True)
 
 # lib/network_factory/voxel_morph.py:29-30
 VM_ENC = (16, 32, 32, 32, 32)
@@ -27,8 +32,9 @@ VM_DEC = (32, 32, 32, 8, 8)
 # ----------------------------------------------------------------------------------------
 # parameter construction (names/shapes follow the reference's state_dict [probed])
 # ----------------------------------------------------------------------------------------
-def unet_param_shapes(in_channel, n_classes, encoders, decoders, bias=True, BN=True):
-    """Ordered {name: shape} as produced by UNet_generator (unets.py:199-252)."""
+def unet_param_shapes(in_channel, n_classes, encoders, decoders, bias=True, BN=True, maxpool=True, upsample=False):
+    """Ordered {name: shape} as produced by UNet_generator (unets.py:199-252); maxpool=False adds the strided-conv
+    `down_samplers.<i>` (unets.py:231-233), upsample=True removes the `up_samplers` parameters (unets.py:235-237)."""
     shapes = {}
 
     def conv_block(prefix, cin, cout, conv_name='conv', transposed=False, k=3):
@@ -72,8 +78,13 @@ def unet_param_shapes(in_channel, n_classes, encoders, decoders, bias=True, BN=T
             shapes[f'decoders.decBlock{i}.{k}.weight'] = (cout, cin, 1, 1, 1)
             if bias:
                 shapes[f'decoders.decBlock{i}.{k}.bias'] = (cout,)
+    if not maxpool:
+        for i in range(len(encoders) - 1):
+            shapes[f'down_samplers.{i}.weight'] = (encoders[i + 1][0], encoders[i][-1], 2, 2, 2)
+            if bias:
+                shapes[f'down_samplers.{i}.bias'] = (encoders[i + 1][0],)
     for item in dec_shapes_order:
-        if item[0] == 'up':
+        if item[0] == 'up' and not upsample:
             _, i, cin, cout = item
             conv_block(f'up_samplers.{i}', cin, cout, conv_name='deconv', transposed=True, k=2)
     return shapes
@@ -185,24 +196,34 @@ def unet_forward(sd, x, spec, training=True):
     in place when training, like nn.BatchNorm3d).  Returns raw logits N x n_classes x D x H x W.
     """
     encoders, decoders, slope = spec['encoders'], spec['decoders'], spec['slope']
+    maxpool, upsample, res = spec.get('maxpool', True), spec.get('upsample', False), spec.get('res', False)
     levels = len(encoders)
     temp = []
     for i, enc in enumerate(encoders):
         nconv = len(enc) - (0 if i == 0 else 1)
+        y = x
         for k in range(nconv):
-            x = _conv_bn_act(x, sd, f'encoders.{i}.{k}', slope, training)
+            y = _conv_bn_act(y, sd, f'encoders.{i}.{k}', slope, training)
+        x = (y + x) if res else y                                    # unets.py:264
         if i < levels - 1:
             temp.append(x)
-            x = F.max_pool3d(x, 2)                                   # unets.py:230,267
+            if maxpool:
+                x = F.max_pool3d(x, 2)                               # unets.py:230,267
+            else:                                                    # strided conv k2 s2 p0, no BN / act (unets.py:231-233)
+                x = F.conv3d(x, sd[f'down_samplers.{i}.weight'], sd.get(f'down_samplers.{i}.bias'), stride=2)
     nconv_dec = len(encoders[-1]) - (0 if levels == 1 else 1)        # leaked `enc` quirk unets.py:247
     for j in range(len(decoders)):
-        x = _deconv_bn_act(x, sd, f'up_samplers.{j}', slope, training)
-        x = torch.cat((x, temp.pop()), dim=1)                         # up-sampled first, skip second (:275)
+        if upsample:                                                  # nn.Upsample(scale_factor=2, mode="trilinear") (:236)
+            x = F.interpolate(x, scale_factor=2, mode='trilinear', align_corners=False)
+        else:
+            x = _deconv_bn_act(x, sd, f'up_samplers.{j}', slope, training)
+        y = torch.cat((x, temp.pop()), dim=1)                         # up-sampled first, skip second (:275)
         for k in range(nconv_dec):
-            x = _conv_bn_act(x, sd, f'decoders.decBlock{j}.{k}', slope, training)
+            y = _conv_bn_act(y, sd, f'decoders.decBlock{j}.{k}', slope, training)
         if j == len(decoders) - 1:                                    # 1x1x1 head, no BN / act (:249-250)
-            x = F.conv3d(x, sd[f'decoders.decBlock{j}.{nconv_dec}.weight'],
+            y = F.conv3d(y, sd[f'decoders.decBlock{j}.{nconv_dec}.weight'],
                          sd.get(f'decoders.decBlock{j}.{nconv_dec}.bias'))
+        x = (y + x) if res else y                                     # (:275)
     return x
 
 

@@ -262,3 +262,27 @@ def test_unet_full_oracle_vs_reference(golden, BN):
         for n, v in state.items():
             if 'running_' in n:
                 np.testing.assert_allclose(v.numpy(), g[tag + '/after/' + n], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['UNET_OPT', 'UNET_RES'])
+def test_unet_generator_options_oracle_vs_reference(golden, name):
+    """oracle.nets.unet_forward with maxpool=False / upsample=True / res=True == UNetTemplate.forward (unets.py:259-278)."""
+    import torch
+    from oracle import nets, losses
+    g = golden('unet_options')
+    spec = getattr(nets, name)
+    sd = nets.closed_form_fill(nets.unet_param_shapes(1, 16, spec['encoders'], spec['decoders'], maxpool=spec['maxpool'], upsample=spec['upsample']), seed=5)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+    state = dict(sd); state.update(params)
+    x = nets.closed_form_volume((1, 1, 8, 8, 16), seed=80)
+    y = nets.closed_form_labels((1, 8, 8, 16), 16, seed=81)
+    logits = nets.unet_forward(state, x, spec, training=True)
+    loss = losses.dice_loss(logits, y.long(), n_class=16, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    loss.backward()
+    t = 'unet_opt/' + name
+    assert abs(loss.item() - float(g[t + '/loss'])) < 1e-6
+    assert rel_l2(logits.detach().numpy(), g[t + '/logits']) < 1e-5
+    for n, p in params.items():
+        ref = g[t + '/grad/' + n]
+        if np.linalg.norm(ref) > 1e-10 and not n.endswith('conv.bias'):
+            assert rel_l2(p.grad.numpy(), ref) < 1e-3, n
