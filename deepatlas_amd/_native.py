@@ -80,6 +80,10 @@ SIGNATURES = {
     'da_conv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_upsample_trilinear2_fwd': (I, [P, P, I, I, I, I, I, P]),
     'da_upsample_trilinear2_bwd': (I, [P, P, I, I, I, I, I, P]),
+    'da_clamp01_to_f32': (I, [P, I, P, LL, P]),
+    'da_crop3d': (I, [P, P, I, LL, I, I, I, I, I, I, I, I, I, P]),
+    'da_partition_tiles': (I, [P, P, I, I, I, I, P, P, P]),
+    'da_assemble_tiles': (I, [P, P, I, I, I, I, P, P, I, P]),
     'da_lncc_ws_bytes': (SZ, [I, I, I, I, I]),
     'da_lncc_fwd': (I, [P, P, I, I, I, I, I, F, P, P, P, SZ, P]),
     'da_lncc_bwd': (I, [P, P, P, P, P, P, I, I, I, I, I, F, P, SZ, P]),

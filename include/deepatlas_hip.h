@@ -212,6 +212,16 @@ int da_conv_k2s2_wgrad(const float* x, const float* dy, float* dw_toi, float* db
 int da_upsample_trilinear2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
 int da_upsample_trilinear2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, void* stream);
 
+/* ---- device data path (lib/transforms.py:71-92 SitkToTensor, :124-158 CropTensor, :508-649 Partition) ------
+ * src_dtype: 0 f32, 1 f64, 2 i16, 3 u8, 4 i32.  Volumes are [D][H][W] (numpy order z, y, x), tile3 / overlap3 likewise. */
+int da_clamp01_to_f32(const void* src, int src_dtype, float* dst, long long n, void* stream);
+int da_crop3d(const void* src, void* dst, int elem_bytes, long long C, int D, int H, int W,
+              int d0, int h0, int w0, int Do, int Ho, int Wo, void* stream);
+/* overlap tiling with numpy 'reflect' padding; tiles [ceil(D/ez)*ceil(H/ey)*ceil(W/ex)][tz][ty][tx], e = tile - 2*overlap */
+int da_partition_tiles(const void* vol, void* tiles, int elem_bytes, int D, int H, int W, const int* tile3, const int* overlap3, void* stream);
+/* vote == 0: copy the effective core of each tile; vote != 0 (uint8 labels): per-voxel majority over the covering tiles */
+int da_assemble_tiles(const void* tiles, void* vol, int elem_bytes, int D, int H, int W, const int* tile3, const int* overlap3, int vote, void* stream);
+
 /* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC, registry 'lncc') ------------------------
  * I, J: [N][D][H][W] fp32 (single channel); F^3 all-ones window, valid padding; loss = 1 - mean(cross^2 / (Ivar Jvar + eps)).
  * sums: [5][N][D-F+1][H-F+1][W-F+1] window sums (I, J, I^2, J^2, IJ), written by fwd and consumed by bwd. */

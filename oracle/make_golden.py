@@ -29,6 +29,7 @@ OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 def import_reference():
     sitk = types.ModuleType('SimpleITK')          # only default-arg attrs are touched (transforms.py:167,208,287)
     sitk.sitkLinear, sitk.sitkBSpline, sitk.sitkNearestNeighbor = 1, 2, 3
+    sitk.GetArrayFromImage = lambda a: np.array(a, copy=True)      # fixtures hand numpy arrays where the reference expects images
     sys.modules.setdefault('SimpleITK', sitk)
     if REF not in sys.path:
         sys.path.insert(0, REF)
@@ -337,6 +338,32 @@ def run_unet_options(ref, out):
                 out[t + '/grad/' + n] = np32(p.grad)
 
 
+def run_datapath(ref, out):
+    """lib/transforms.py SitkToTensor (:71-92), CropTensor (:124-158), Partition + assemble (:508-649), with
+    numpy arrays standing in for SimpleITK images (the stub's GetArrayFromImage is the identity)."""
+    from oracle import nets
+    T = ref.transforms
+    img = (nets.closed_form_volume((11, 13, 17), seed=90).double() * 1.6 - 0.3).numpy()          # values outside [0, 1]
+    seg = nets.closed_form_labels((1, 11, 13, 17), 4, seed=91)[0].numpy().astype(np.int16)
+    out['dp/img'], out['dp/seg'] = img, seg
+    s = T.SitkToTensor()({'image': img.copy(), 'segmentation': seg.copy()})
+    out['dp/totensor/image'], out['dp/totensor/seg'] = np32(s['image']), np32(s['segmentation'])
+    for tag, cs in (('c3', [1, 2, 3]), ('c6', [1, 0, 2, 3, 1, 0])):
+        c = T.CropTensor(cs)({'image': s['image'].clone(), 'segmentation': s['segmentation'].clone()})
+        out['dp/crop/%s/image' % tag], out['dp/crop/%s/seg' % tag] = np32(c['image']), np32(c['segmentation'])
+    for tag, tile, ov in (('a', (8, 8, 8), (2, 2, 2)), ('b', (9, 7, 6), (1, 2, 0))):
+        part = T.Partition(tile, ov, mode='eval')
+        p = part({'image': img.astype(np.float32), 'segmentation': seg.astype(np.uint8), 'name': 'x'})
+        out['dp/part/%s/image' % tag], out['dp/part/%s/seg' % tag] = np32(p['image']), np32(p['segmentation'])
+        tiles = p['segmentation'][:, 0]
+        out['dp/part/%s/assemble' % tag] = np.asarray(part.assemble(tiles, is_vote=False, if_itk=False))
+        # disagreeing tiles so that the vote matters: every odd tile predicts label + 1 (mod 4)
+        noisy = tiles.clone()
+        noisy[1::2] = (noisy[1::2] + 1) % 4
+        out['dp/part/%s/noisy' % tag] = np32(noisy)
+        out['dp/part/%s/assemble_vote' % tag] = np.asarray(part.assemble(noisy, is_vote=True, if_itk=False))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -352,6 +379,13 @@ def main():
     run_reglosses(ref, out)
     np.savez_compressed(os.path.join(OUT, 'reglosses.npz'), **out)
     print('reglosses.npz', len(out))
+    out = {}
+    run_datapath(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'datapath.npz'), **out)
+    print('datapath.npz', len(out))
+    if os.environ.get('GOLDEN_ONLY') == 'dp':
+        return
+
     out = {}
     run_unet_options(ref, out)
     np.savez_compressed(os.path.join(OUT, 'unet_options.npz'), **out)

@@ -574,3 +574,41 @@ def test_full_size_lncc_and_gradient_loss_properties():
     dims = torch.tensor([160., 192., 160.]) / 160.
     expect = float((((dims ** 2) * (2 * c) ** 2).mean() * 2) / 3.0)          # dx = 0; dy = dz = |2c|, weights dims[c]^2
     assert abs(gradientLoss()(u).item() - expect) < 1e-5 * expect
+
+
+# ---- device data path --------------------------------------------------------------------------------------------
+def test_datapath_golden_bit_exact(golden):
+    """SitkToTensor clamp/cast, CropTensor, Partition tiles (reflect padding) and both assemble modes: bit-equal to the reference."""
+    from deepatlas_amd.lib import transforms as TR
+    g = golden('datapath')
+    s = TR.SitkToTensor()({'image': g['dp/img'].copy(), 'segmentation': g['dp/seg'].copy()})
+    assert s['image'].is_cuda and s['image'].dtype == torch.float32 and s['segmentation'].dtype == torch.uint8
+    assert np.array_equal(s['image'].cpu().numpy(), g['dp/totensor/image']) and np.array_equal(s['segmentation'].cpu().numpy(), g['dp/totensor/seg'])
+    for tag, cs in (('c3', [1, 2, 3]), ('c6', [1, 0, 2, 3, 1, 0])):
+        c = TR.CropTensor(cs)({'image': s['image'].clone(), 'segmentation': s['segmentation'].clone()})
+        assert c['image'].is_contiguous()
+        assert np.array_equal(c['image'].cpu().numpy(), g['dp/crop/%s/image' % tag]) and np.array_equal(c['segmentation'].cpu().numpy(), g['dp/crop/%s/seg' % tag])
+    with pytest.raises(ValueError):
+        TR.CropTensor([1, 2])
+    for tag, tile, ov in (('a', (8, 8, 8), (2, 2, 2)), ('b', (9, 7, 6), (1, 2, 0))):
+        part = TR.Partition(tile, ov, mode='eval')
+        p = part({'image': g['dp/img'].astype(np.float32), 'segmentation': g['dp/seg'].astype(np.uint8), 'name': 'x'})
+        assert np.array_equal(p['image'].cpu().numpy(), g['dp/part/%s/image' % tag])
+        assert np.array_equal(p['segmentation'].cpu().numpy(), g['dp/part/%s/seg' % tag])
+        assert np.array_equal(part.assemble(p['segmentation'][:, 0]).cpu().numpy().astype(np.float64), g['dp/part/%s/assemble' % tag])
+        v = part.assemble(T(g['dp/part/%s/noisy' % tag]).to(dev()), is_vote=True)
+        assert np.array_equal(v.cpu().numpy(), g['dp/part/%s/assemble_vote' % tag])
+
+
+def test_datapath_full_size_round_trip():
+    """160x192x160: partition -> assemble is the identity for any tile / overlap, and the vote of consistent tiles too."""
+    from deepatlas_amd.lib import transforms as TR
+    from deepatlas_amd.lib.datasets import structured_labels
+    lab = structured_labels((160, 192, 160), 32).to(dev())
+    img = torch.rand((160, 192, 160), generator=torch.Generator().manual_seed(5)).to(dev())
+    part = TR.Partition((72, 72, 72), (4, 4, 4), mode='eval')
+    p = part({'image': img, 'segmentation': lab, 'name': 'x'})
+    assert p['image'].shape[1:] == (1, 72, 72, 72) and p['image'].shape[0] == 3 * 3 * 3
+    assert torch.equal(part.assemble(p['image'][:, 0]), img)
+    assert torch.equal(part.assemble(p['segmentation'][:, 0]), lab)
+    assert torch.equal(part.assemble(p['segmentation'][:, 0], is_vote=True), lab)

@@ -286,3 +286,21 @@ def test_unet_generator_options_oracle_vs_reference(golden, name):
         ref = g[t + '/grad/' + n]
         if np.linalg.norm(ref) > 1e-10 and not n.endswith('conv.bias'):
             assert rel_l2(p.grad.numpy(), ref) < 1e-3, n
+
+
+# ---- data path ---------------------------------------------------------------------------------------------------
+def test_datapath_oracle_vs_reference(golden):
+    from oracle import datapath as dp
+    g = golden('datapath')
+    img, seg = dp.sitk_to_tensor(g['dp/img'], g['dp/seg'])
+    assert np.array_equal(img, g['dp/totensor/image']) and np.array_equal(seg, g['dp/totensor/seg'])
+    for tag, cs in (('c3', [1, 2, 3]), ('c6', [1, 0, 2, 3, 1, 0])):
+        ci, cs_ = dp.crop_tensor(img, seg, cs)
+        assert np.array_equal(ci, g['dp/crop/%s/image' % tag]) and np.array_equal(cs_, g['dp/crop/%s/seg' % tag])
+    for tag, tile, ov in (('a', (8, 8, 8), (2, 2, 2)), ('b', (9, 7, 6), (1, 2, 0))):
+        part = dp.Partition(tile, ov)
+        assert np.array_equal(part.tiles(g['dp/img'].astype(np.float32))[:, None], g['dp/part/%s/image' % tag])
+        st = part.tiles(g['dp/seg'].astype(np.uint8))
+        assert np.array_equal(st[:, None], g['dp/part/%s/seg' % tag])
+        assert np.array_equal(part.assemble(st), g['dp/part/%s/assemble' % tag])
+        assert np.array_equal(part.assemble(g['dp/part/%s/noisy' % tag], is_vote=True), g['dp/part/%s/assemble_vote' % tag])
