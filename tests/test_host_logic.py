@@ -68,8 +68,9 @@ def test_out_of_scope_constructors_raise():
     from deepatlas_amd.lib.network_factory import get_network
     from deepatlas_amd.lib.loss import get_loss_function
     from deepatlas_amd.lib.network_factory import unets
-    with pytest.raises(NotImplementedError):        # generator options still outside the accelerated path
-        unets.UNet_generator(encoders=[(8, 8)], decoders=[], upsample=True)
+    # generator options are on the path: strided-conv down-samplers carry parameters, trilinear up-samplers none
+    g = unets.UNet_generator(encoders=[(16, 16), (16, 16, 16)], decoders=[(16, 16, 16)], maxpool=False, upsample=True)(1, 16, bias=True, BN=False)
+    assert 'down_samplers.0.weight' in g.state_dict() and not any(k.startswith('up_samplers') for k in g.state_dict())
     m = get_network('UNet')(1, 2, bias=True, BN=True)     # the fixed UNet is on the path: constructible on the host
     assert 'dc8.1.running_mean' in m.state_dict() and tuple(m.state_dict()['dc8.0.weight'].shape) == (768, 256, 3, 3, 3)
     with pytest.raises(NotImplementedError):
