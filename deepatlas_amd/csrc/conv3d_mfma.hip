@@ -181,7 +181,7 @@ struct FwdP {
     unsigned masks[16]; int maskmode;   // tap masks (stride-2 via space-to-depth): 0 none, 1 per channel chunk, 2 per blockIdx.y
     double* stats_partial;              // optional [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the (pre-activation) output
     unsigned long long* clk;
-    int ablate;      // diagnostic only (env DA_ABLATE): 1 skip staging loads, 2 skip epilogue stores, 4 skip LDS writes+barriers, 8 skip MFMAs
+    int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
 template <int CK, int NREP, bool MASKED = false, bool STATS = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums
@@ -240,13 +240,6 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
         for (int nn = 0; nn < NREP; ++nn) acc[r][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // The two workgroups resident on a CU start together and every item costs the same, so their staging / barrier /
-    // epilogue phases would coincide for the whole launch and leave the matrix pipe idle.  Delay the second resident
-    // round (block ids >= half the grid) by roughly half an item so one workgroup's MFMAs cover the other's gaps.
-    if (blockIdx.x >= (gridDim.x + 1) / 2) {
-#pragma unroll 1
-        for (int d = 0; d < 3 * NREP; ++d) __builtin_amdgcn_s_sleep(127);
-    }
     float st1[STATS ? NREP : 1][4], st2[STATS ? NREP : 1][4];   // per-lane BN partial sums of this lane's 4 couts (after the transpose)
 #pragma unroll
     for (int nn = 0; nn < (STATS ? NREP : 1); ++nn)
@@ -773,10 +766,6 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             if (idx < TVOX * QY) *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
         }
     };
-    if (blockIdx.x >= (gridDim.x + 1) / 2) {                 // de-phase the two workgroups of a CU (see the forward kernel)
-#pragma unroll 1
-        for (int d = 0; d < NREP; ++d) __builtin_amdgcn_s_sleep(127);
-    }
     if (tile_begin < tile_end) { issue_loads(tile_begin); write_lds(); }
     __syncthreads();
 #pragma unroll 1
