@@ -42,7 +42,7 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 // (floor mode) are zeroed by the caller's memset when D/H/W are odd.
 template <int VEC>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
-                                    int N, int D, int H, int W, int C) {
+                                    int N, int D, int H, int W, int C, const float* __restrict__ add) {
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -69,9 +69,15 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* _
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
-            float* p = dx + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
-            if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(am[0] == t ? g[0] : 0.f, am[1] == t ? g[1] : 0.f, am[2] == t ? g[2] : 0.f, am[3] == t ? g[3] : 0.f);
-            else *p = (am[0] == t) ? g[0] : 0.f;
+            const long long off = ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+            float* p = dx + off;
+            // `add`: the gradient that reaches x through its other consumer (the skip connection), fused here instead of a
+            // separate accumulation pass by autograd
+            if (VEC == 4) {
+                float4 o = make_float4(am[0] == t ? g[0] : 0.f, am[1] == t ? g[1] : 0.f, am[2] == t ? g[2] : 0.f, am[3] == t ? g[3] : 0.f);
+                if (add) { const float4 e = *reinterpret_cast<const float4*>(add + off); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+                *reinterpret_cast<float4*>(p) = o;
+            } else *p = ((am[0] == t) ? g[0] : 0.f) + (add ? add[off] : 0.f);
         }
     }
 }
@@ -239,7 +245,19 @@ extern "C" int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N
         if (e != hipSuccess) return (int)e;
     }
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    DA_VEC_DISPATCH(maxpool2_bwd_kernel, total, dy, x, dx, N, D, H, W, C);
+    DA_VEC_DISPATCH(maxpool2_bwd_kernel, total, dy, x, dx, N, D, H, W, C, (const float*)nullptr);
+    return 0;
+}
+
+// dx = gskip + maxpool_bwd(dy): x feeds both the pool and a skip connection (unets.py:266-267,275), so its gradient is the sum of the two
+extern "C" int da_maxpool2_bwd_add(const float* dy, const float* x, const float* gskip, float* dx, int N, int D, int H, int W, int C, void* stream) {
+    if (!dy || !x || !gskip || !dx || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
+    if ((D | H | W) & 1) {   // trailing planes are outside every pooling window: they only carry the skip gradient
+        hipError_t e = hipMemcpyAsync(dx, gskip, (size_t)N * D * H * W * C * sizeof(float), hipMemcpyDeviceToDevice, da_stream(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    DA_VEC_DISPATCH(maxpool2_bwd_kernel, total, dy, x, dx, N, D, H, W, C, gskip);
     return 0;
 }
 

@@ -9,6 +9,8 @@ configuration (lib/network_factory/__init__.py:12-15); the fixed `UNet` (unets.p
 import torch
 import torch.nn as nn
 
+from ... import ops
+
 from .modules import (SegBlock as convBlock, SegUpBlock as deconvBlock, HeadConv, MaxPool2, DownConv, UpsampleTrilinear2,
                       UNetEncBlock, UNetDecBlock, get_activation_function)
 
@@ -75,8 +77,12 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
                     y = blk(y)
                 x = (y + x) if self.res else y            # res=True: `enc(x) + x` (unets.py:264; broadcasts a 1-channel input)
                 if i < self.levels - 1:
-                    temp.append(x)
-                    x = self.down_samplers[i](x)
+                    if self.maxpool:          # skip tensor + pooled tensor from one node (gradients summed in the pool backward)
+                        skip, x = ops.MaxPool2SkipFn.apply(x)
+                        temp.append(skip)
+                    else:
+                        temp.append(x)
+                        x = self.down_samplers[i](x)
             for j, dec in enumerate(self.decoders):
                 x = self.up_samplers[j](x)
                 skip = temp.pop()
@@ -143,10 +149,10 @@ class UNet(nn.Module):
 
     def forward(self, x):
         """unets.py:141-179; every torch.cat((up, syn), 1) is the two-pointer input of the following block."""
-        syn0 = self.ec1(self.ec0(x))
-        syn1 = self.ec3(self.ec2(self.pool0(syn0)))
-        syn2 = self.ec5(self.ec4(self.pool1(syn1)))
-        e7 = self.ec7(self.ec6(self.pool2(syn2)))
+        syn0, p0 = ops.MaxPool2SkipFn.apply(self.ec1(self.ec0(x)))         # pool0/1/2 (parameter-free) fused with their skip branch
+        syn1, p1 = ops.MaxPool2SkipFn.apply(self.ec3(self.ec2(p0)))
+        syn2, p2 = ops.MaxPool2SkipFn.apply(self.ec5(self.ec4(p1)))
+        e7 = self.ec7(self.ec6(p2))
         d7 = self.dc7(self.dc8(self.dc9(e7), syn2))
         d4 = self.dc4(self.dc5(self.dc6(d7), syn1))
         d1 = self.dc1(self.dc2(self.dc3(d4), syn0))

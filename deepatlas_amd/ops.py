@@ -516,6 +516,34 @@ class MaxPool2Fn(Function):
         return ncdhw(dx)
 
 
+class MaxPool2SkipFn(Function):
+    """x -> (x as the skip tensor, MaxPool3d(2)(x)) as ONE autograd node (unets.py:266-267,275): the two gradients reaching x are
+    summed inside the max-pool backward kernel instead of by a separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        a = ndhwc(x)
+        N, D, H, W, C = a.shape
+        out = _empty((N, D // 2, H // 2, W // 2, C), a)
+        call('da_maxpool2_fwd', ptr(a), ptr(out), N, D, H, W, C, stream())
+        ctx.save_for_backward(a)
+        return ncdhw(a), ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gskip, gpool):
+        a, = ctx.saved_tensors
+        N, D, H, W, C = a.shape
+        if gpool is None:
+            return gskip
+        g = ndhwc(gpool)
+        dx = torch.empty_like(a)
+        if gskip is None:
+            call('da_maxpool2_bwd', ptr(g), ptr(a), ptr(dx), N, D, H, W, C, stream())
+        else:
+            call('da_maxpool2_bwd_add', ptr(g), ptr(a), ptr(ndhwc(gskip)), ptr(dx), N, D, H, W, C, stream())
+        return ncdhw(dx)
+
+
 class UpsampleNearestFn(Function):
     """F.interpolate(x, size=...) with the default 'nearest' mode (voxel_morph.py:72,74,76,80)."""
 

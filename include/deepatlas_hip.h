@@ -146,6 +146,8 @@ int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t w
 int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
 /* dx (input-sized) from dy and the saved input x; gradient goes to the first maximum in (d,h,w) scan order. */
 int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream);
+/* dx = gskip + maxpool_bwd(dy): the pooled tensor also feeds a skip connection (unets.py:266-267,275) */
+int da_maxpool2_bwd_add(const float* dy, const float* x, const float* gskip, float* dx, int N, int D, int H, int W, int C, void* stream);
 
 /* ---- nearest-neighbour up-sampling to a given size (row a8; voxel_morph.py:72,74,76,80) ------ */
 int da_upsample_nearest_fwd(const float* x, float* y, int N, int D, int H, int W, int C,
