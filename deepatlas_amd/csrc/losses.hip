@@ -9,6 +9,7 @@
 namespace {
 
 constexpr int kBlocks = 512;     // partial blocks per sample
+constexpr int kDiceBlocks = 2048; // Dice forward: 8 workgroups per CU per sample (softmax latency needs the occupancy)
 
 __device__ __forceinline__ long long load_label(const void* labels, int label_bytes, long long i) {
     return label_bytes == 1 ? (long long)((const unsigned char*)labels)[i] : ((const long long*)labels)[i];
@@ -43,23 +44,39 @@ __global__ void dice_partial_vec_kernel(const float* __restrict__ src, const voi
     const long long vpb = da_cdiv(V, (long long)gridDim.x);
     const long long v0 = (long long)blockIdx.x * vpb;
     long long v1 = v0 + vpb; if (v1 > V) v1 = V;
-    // every lane of a voxel group runs the same trip count (v depends on s only)
-    for (long long v = v0 + s; v < v1; v += slots) {
-        const long long row = (long long)n * V + v;
-        const float4 a = *reinterpret_cast<const float4*>(src + row * C + q * 4);
+    // every lane of a voxel group runs the same trip count (v depends on s only).  Two voxels per iteration: both 16-byte loads
+    // (and label bytes) are in flight before the first softmax's shuffles, which doubles the bytes in flight per wave.
+    auto accumulate = [&](float4 a, const float* tt) {
         float p[4] = {a.x, a.y, a.z, a.w};
         if (softmax) group_softmax4(p, lpv);
-        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { aI[j] += p[j] * tt[j]; aS[j] += p[j]; aT[j] += tt[j]; }
+    };
+    auto target = [&](long long row, float* tt) {
         if (soft) {
             const float4 b = *reinterpret_cast<const float4*>(soft + row * C + q * 4);
-            t[0] = b.x; t[1] = b.y; t[2] = b.z; t[3] = b.w;
+            tt[0] = b.x; tt[1] = b.y; tt[2] = b.z; tt[3] = b.w;
         } else {
             const int lab = (int)load_label(labels, label_bytes, row) - q * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = (lab == j) ? 1.f : 0.f;
+            for (int j = 0; j < 4; ++j) tt[j] = (lab == j) ? 1.f : 0.f;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { aI[j] += p[j] * t[j]; aS[j] += p[j]; aT[j] += t[j]; }
+    };
+    long long v = v0 + s;
+    for (; v + slots < v1; v += 2 * slots) {
+        const long long r0 = (long long)n * V + v, r1 = r0 + slots;
+        const float4 a0 = *reinterpret_cast<const float4*>(src + r0 * C + q * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(src + r1 * C + q * 4);
+        float t0[4], t1[4];
+        target(r0, t0); target(r1, t1);
+        accumulate(a0, t0); accumulate(a1, t1);
+    }
+    for (; v < v1; v += slots) {
+        const long long r0 = (long long)n * V + v;
+        const float4 a0 = *reinterpret_cast<const float4*>(src + r0 * C + q * 4);
+        float t0[4];
+        target(r0, t0);
+        accumulate(a0, t0);
     }
     float* sI = shf; float* sS = shf + (size_t)slots * C; float* sT = shf + (size_t)2 * slots * C;
 #pragma unroll
@@ -596,7 +613,7 @@ __global__ void label_overlap_counts_kernel(const void* __restrict__ pred, int p
 // ================================================================================================
 extern "C" size_t da_dice_ws_bytes(int N, long long V, int C) {
     (void)V;
-    return da_align((size_t)N * kBlocks * 3 * C * sizeof(double)) + da_align((size_t)3 * N * C * sizeof(float));
+    return da_align((size_t)N * kDiceBlocks * 3 * C * sizeof(double)) + da_align((size_t)3 * N * C * sizeof(float));
 }
 
 extern "C" int da_dice_fwd(const float* src, const void* labels, int label_bytes, const float* soft_target,
@@ -607,9 +624,9 @@ extern "C" int da_dice_fwd(const float* src, const void* labels, int label_bytes
     if (ws_bytes < da_dice_ws_bytes(N, V, C)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
     double* partial = (double*)ws;
-    float* isc = (float*)((char*)ws + da_align((size_t)N * kBlocks * 3 * C * sizeof(double)));
+    float* isc = (float*)((char*)ws + da_align((size_t)N * kDiceBlocks * 3 * C * sizeof(double)));
     const int lpv = lpv_for(C);
-    int nblocks = (int)da_cdiv(V, 256); if (nblocks > kBlocks) nblocks = kBlocks;
+    int nblocks = (int)da_cdiv(V, 256); if (nblocks > kDiceBlocks) nblocks = kDiceBlocks;
     if (lpv > 0) {
         const int slots = 256 / lpv;
         hipLaunchKernelGGL(dice_partial_vec_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
