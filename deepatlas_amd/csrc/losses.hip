@@ -9,6 +9,7 @@
 namespace {
 
 constexpr int kBlocks = 512;     // partial blocks per sample
+constexpr int kBendBlocks = 4096; // bending forward: 25-point stencil per element, latency-bound without occupancy
 constexpr int kDiceBlocks = 2048; // Dice forward: 8 workgroups per CU per sample (softmax latency needs the occupancy)
 
 __device__ __forceinline__ long long load_label(const void* labels, int label_bytes, long long i) {
@@ -714,7 +715,7 @@ extern "C" int da_ncc_bwd(const float* x, const float* y, const double* stats, c
 
 extern "C" size_t da_bending_ws_bytes(int N, int D, int H, int W) {
     (void)D; (void)H; (void)W;
-    return da_align((size_t)N * kBlocks * sizeof(double));
+    return da_align((size_t)N * kBendBlocks * sizeof(double));
 }
 
 extern "C" int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize,
@@ -724,7 +725,7 @@ extern "C" int da_bending_fwd(const float* disp, int N, int D, int H, int W, con
     hipStream_t st = da_stream(stream);
     const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize);
     const long long total = (long long)(D - 2) * (H - 2) * (W - 2) * 3;
-    int nblocks = (int)da_cdiv(total, 256 * 8); if (nblocks > kBlocks) nblocks = kBlocks; if (nblocks < 1) nblocks = 1;
+    int nblocks = (int)da_cdiv(total, 256 * 2); if (nblocks > kBendBlocks) nblocks = kBendBlocks; if (nblocks < 1) nblocks = 1;
     hipLaunchKernelGGL(bending_partial_kernel, dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
     DA_LAUNCH_CHECK();
     hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblocks * N, loss);

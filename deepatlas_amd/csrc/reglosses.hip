@@ -5,7 +5,7 @@
 
 namespace {
 
-constexpr int kBlocks = 1024;
+constexpr int kBlocks = 4096;
 
 __global__ void sum_partials_kernel(const double* __restrict__ partial, int count, double scale, double offset, float* __restrict__ out) {
     __shared__ double red[4];
@@ -272,7 +272,7 @@ extern "C" int da_gradloss_fwd(const float* disp, int N, int D, int H, int W, co
     hipStream_t st = da_stream(stream);
     const GradK K = gradloss_coeffs(N, D, H, W, spacing3, normalize, norm);
     const long long total = (long long)D * H * W * 3;
-    int nblocks = (int)da_cdiv(total, 256 * 8); if (nblocks > kBlocks) nblocks = kBlocks; if (nblocks < 1) nblocks = 1;
+    int nblocks = (int)da_cdiv(total, 256 * 2); if (nblocks > kBlocks) nblocks = kBlocks; if (nblocks < 1) nblocks = 1;
     hipLaunchKernelGGL(gradloss_partial_kernel, dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
     DA_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblocks * N, 1.0, 0.0, loss);
