@@ -85,9 +85,9 @@ SIGNATURES = {
     'da_crop3d': (I, [P, P, I, LL, I, I, I, I, I, I, I, I, I, P]),
     'da_partition_tiles': (I, [P, P, I, I, I, I, P, P, P]),
     'da_assemble_tiles': (I, [P, P, I, I, I, I, P, P, I, P]),
-    'da_lncc_ws_bytes': (SZ, [I, I, I, I, I]),
-    'da_lncc_fwd': (I, [P, P, I, I, I, I, I, F, P, P, P, SZ, P]),
-    'da_lncc_bwd': (I, [P, P, P, P, P, P, I, I, I, I, I, F, P, SZ, P]),
+    'da_lncc_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
+    'da_lncc_fwd': (I, [P, P, I, I, I, I, I, I, I, F, P, P, P, SZ, P]),
+    'da_lncc_bwd': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, SZ, P]),
     'da_gradloss_ws_bytes': (SZ, [I, I, I, I]),
     'da_gradloss_fwd': (I, [P, I, I, I, I, P, I, I, P, P, SZ, P]),
     'da_gradloss_bwd': (I, [P, P, P, I, I, I, I, P, I, I, P]),

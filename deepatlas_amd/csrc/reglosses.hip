@@ -23,14 +23,14 @@ __global__ void sum_partials_kernel(const double* __restrict__ partial, int coun
 // ------------------------------------------------------------------------------------------------
 // pass 1: products + box sum along W:  t1[k][n][z][y][xo], xo < Wo = W - F + 1
 __global__ void lncc_boxw_kernel(const float* __restrict__ I, const float* __restrict__ J, float* __restrict__ t1,
-                                 long long rows, int W, int Wo, int F, long long plane) {
+                                 long long rows, int W, int Wo, int F, long long plane, int dil, int stride) {
     const long long total = rows * Wo;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int xo = (int)(i % Wo); const long long r = i / Wo;
-        const float* a = I + r * W + xo; const float* b = J + r * W + xo;
+        const float* a = I + r * W + (long long)xo * stride; const float* b = J + r * W + (long long)xo * stride;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
         for (int t = 0; t < F; ++t) {
-            const float x = a[t], y = b[t];
+            const float x = a[t * dil], y = b[t * dil];
             s0 += x; s1 += y; s2 += x * x; s3 += y * y; s4 += x * y;
         }
         t1[i] = s0; t1[plane + i] = s1; t1[2 * plane + i] = s2; t1[3 * plane + i] = s3; t1[4 * plane + i] = s4;
@@ -38,8 +38,10 @@ __global__ void lncc_boxw_kernel(const float* __restrict__ I, const float* __res
 }
 
 // generic 1-D box sum of K planar fields along one axis of a [M][A][B] view (axis length A, inner stride B):
-// out[m][ao][b] = sum_{t<F} in[m][ao + t - pad][b] (zero outside), ao < Ao.  pad = 0: valid; pad = F - 1: full (transpose).
-__global__ void box_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long long M, int A, int Ao, long long B, int F, int pad) {
+// transposed == 0 (forward, valid):  out[m][ao][b] = sum_{t<F} in[m][ao*stride + t*dil][b],            ao < Ao
+// transposed != 0 (its adjoint):     out[m][a][b]  = sum_{t<F, (a - t*dil) % stride == 0} in[m][(a - t*dil)/stride][b],  a < Ao
+__global__ void box_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long long M, int A, int Ao, long long B, int F,
+                                int transposed, int dil, int stride) {
     const long long total = M * Ao * B;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i % B; long long r = i / B;
@@ -47,8 +49,10 @@ __global__ void box_axis_kernel(const float* __restrict__ in, float* __restrict_
         const float* src = in + (m * A) * B + b;
         float s = 0.f;
         for (int t = 0; t < F; ++t) {
-            const int a = ao + t - pad;
-            if (a >= 0 && a < A) s += src[(long long)a * B];
+            int a;
+            if (!transposed) a = ao * stride + t * dil;
+            else { const int rem = ao - t * dil; if (rem < 0 || rem % stride) continue; a = rem / stride; }
+            if (a < A) s += src[(long long)a * B];
         }
         out[i] = s;
     }
@@ -67,18 +71,18 @@ __device__ __forceinline__ void lncc_terms(float sI, float sJ, float sII, float 
 // pass 3: box sum along D of the 5 fields (in: [5][N][D][Ho*Wo]) fused with cc and its reduction; writes the window sums
 // (kept for the backward pass): sums[k][n][zo][yo*xo]
 __global__ void lncc_boxd_cc_kernel(const float* __restrict__ t2, float* __restrict__ sums, int N, int D, int Do, long long HW,
-                                    int F, float n, float eps, double* __restrict__ partial) {
+                                    int F, float n, float eps, double* __restrict__ partial, int dil, int stride) {
     __shared__ double red[4];
     const long long pin = (long long)N * D * HW, pout = (long long)N * Do * HW;
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pout; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i % HW; long long r = i / HW;
         const int zo = (int)(r % Do); const long long nn = r / Do;
-        const float* src = t2 + (nn * D + zo) * HW + b;
+        const float* src = t2 + (nn * D + (long long)zo * stride) * HW + b;
         float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < F; ++t)
 #pragma unroll
-            for (int k = 0; k < 5; ++k) s[k] += src[k * pin + (long long)t * HW];
+            for (int k = 0; k < 5; ++k) s[k] += src[k * pin + (long long)t * dil * HW];
 #pragma unroll
         for (int k = 0; k < 5; ++k) sums[k * pout + i] = s[k];
         float cross, ivar, jvar, den;
@@ -110,14 +114,17 @@ __global__ void lncc_bwd_fields_kernel(const float* __restrict__ sums, float* __
 
 // last backward pass: full box sum along W of the 7 fields (in: [7][rows][Wo]) fused with the combine
 __global__ void lncc_bwd_boxw_combine_kernel(const float* __restrict__ t, const float* __restrict__ I, const float* __restrict__ J,
-                                             float* __restrict__ dI, float* __restrict__ dJ, long long rows, int W, int Wo, int F) {
+                                             float* __restrict__ dI, float* __restrict__ dJ, long long rows, int W, int Wo, int F,
+                                             int dil, int stride) {
     const long long total = rows * W, plane = rows * Wo;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % W); const long long r = i / W;
         float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int tt = 0; tt < F; ++tt) {
-            const int xo = x - tt;
-            if (xo >= 0 && xo < Wo) {
+            const int rem = x - tt * dil;
+            if (rem < 0 || rem % stride) continue;
+            const int xo = rem / stride;
+            if (xo < Wo) {
 #pragma unroll
                 for (int k = 0; k < 7; ++k) s[k] += t[k * plane + r * Wo + xo];
             }
@@ -204,32 +211,36 @@ __global__ void gradloss_bwd_kernel(const float* __restrict__ disp, const float*
 }  // namespace
 
 // ================================================================================================
-extern "C" size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F) {
-    if (F < 1 || D < F || H < F || W < F) return 0;
-    const size_t Wo = W - F + 1, Ho = H - F + 1, Do = D - F + 1;
+static inline int lncc_out(int L, int F, int dil, int stride) { const int span = dil * (F - 1) + 1; return L < span ? 0 : (L - span) / stride + 1; }
+
+extern "C" size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F, int dil, int stride) {
+    if (F < 1 || dil < 1 || stride < 1) return 0;
+    const size_t Wo = lncc_out(W, F, dil, stride), Ho = lncc_out(H, F, dil, stride), Do = lncc_out(D, F, dil, stride);
+    if (!Wo || !Ho || !Do) return 0;
     // forward: t1 [5][N][D][H][Wo], t2 [5][N][D][Ho][Wo], partials; backward: G [7][N][Do][Ho][Wo], [7][N][D][Ho][Wo], [7][N][D][H][Wo]
     const size_t fwd = da_align((size_t)5 * N * D * H * Wo * 4) + da_align((size_t)5 * N * D * Ho * Wo * 4) + da_align((size_t)kBlocks * 8);
     const size_t bwd = da_align((size_t)7 * N * Do * Ho * Wo * 4) + da_align((size_t)7 * N * D * Ho * Wo * 4) + da_align((size_t)7 * N * D * H * Wo * 4);
     return fwd > bwd ? fwd : bwd;
 }
 
-extern "C" int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, int W, int F, float eps,
+extern "C" int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, int W, int F, int dil, int stride, float eps,
                            float* loss, float* sums, void* ws, size_t ws_bytes, void* stream) {
-    if (!I || !J || !loss || !sums || N <= 0 || F < 1 || D < F || H < F || W < F) return DA_ERR_BADARG;
-    if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F)) return DA_ERR_WS_SMALL;
+    if (!I || !J || !loss || !sums || N <= 0 || F < 1 || dil < 1 || stride < 1) return DA_ERR_BADARG;
+    const int Wo = lncc_out(W, F, dil, stride), Ho = lncc_out(H, F, dil, stride), Do = lncc_out(D, F, dil, stride);
+    if (!Wo || !Ho || !Do) return DA_ERR_BADARG;
+    if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F, dil, stride)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
-    const int Wo = W - F + 1, Ho = H - F + 1, Do = D - F + 1;
     float* t1 = (float*)ws;
     float* t2 = (float*)((char*)ws + da_align((size_t)5 * N * D * H * Wo * 4));
     double* partial = (double*)((char*)t2 + da_align((size_t)5 * N * D * Ho * Wo * 4));
     const long long rows = (long long)N * D * H;
-    hipLaunchKernelGGL(lncc_boxw_kernel, dim3(da_grid(rows * Wo, 256)), dim3(256), 0, st, I, J, t1, rows, W, Wo, F, rows * Wo);
+    hipLaunchKernelGGL(lncc_boxw_kernel, dim3(da_grid(rows * Wo, 256)), dim3(256), 0, st, I, J, t1, rows, W, Wo, F, rows * Wo, dil, stride);
     DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(box_axis_kernel, dim3(da_grid((long long)5 * N * D * Ho * Wo, 256)), dim3(256), 0, st, t1, t2, (long long)5 * N * D, H, Ho, (long long)Wo, F, 0);
+    hipLaunchKernelGGL(box_axis_kernel, dim3(da_grid((long long)5 * N * D * Ho * Wo, 256)), dim3(256), 0, st, t1, t2, (long long)5 * N * D, H, Ho, (long long)Wo, F, 0, dil, stride);
     DA_LAUNCH_CHECK();
     const long long pout = (long long)N * Do * Ho * Wo;
     int nblocks = (int)da_cdiv(pout, 256); if (nblocks > kBlocks) nblocks = kBlocks;
-    hipLaunchKernelGGL(lncc_boxd_cc_kernel, dim3(nblocks), dim3(256), 0, st, t2, sums, N, D, Do, (long long)Ho * Wo, F, (float)((double)F * F * F), eps, partial);
+    hipLaunchKernelGGL(lncc_boxd_cc_kernel, dim3(nblocks), dim3(256), 0, st, t2, sums, N, D, Do, (long long)Ho * Wo, F, (float)((double)F * F * F), eps, partial, dil, stride);
     DA_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, -1.0 / (double)pout, 1.0, loss);
     DA_LAUNCH_CHECK();
@@ -237,25 +248,26 @@ extern "C" int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, 
 }
 
 extern "C" int da_lncc_bwd(const float* I, const float* J, const float* sums, const float* dloss, float* dI, float* dJ,
-                           int N, int D, int H, int W, int F, float eps, void* ws, size_t ws_bytes, void* stream) {
-    if (!I || !J || !sums || !dloss || N <= 0 || F < 1 || D < F || H < F || W < F) return DA_ERR_BADARG;
+                           int N, int D, int H, int W, int F, int dil, int stride, float eps, void* ws, size_t ws_bytes, void* stream) {
+    if (!I || !J || !sums || !dloss || N <= 0 || F < 1 || dil < 1 || stride < 1) return DA_ERR_BADARG;
     if (!dI && !dJ) return 0;
-    if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F)) return DA_ERR_WS_SMALL;
+    const int Wo = lncc_out(W, F, dil, stride), Ho = lncc_out(H, F, dil, stride), Do = lncc_out(D, F, dil, stride);
+    if (!Wo || !Ho || !Do) return DA_ERR_BADARG;
+    if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F, dil, stride)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
-    const int Wo = W - F + 1, Ho = H - F + 1, Do = D - F + 1;
     float* G = (float*)ws;
     float* g1 = (float*)((char*)ws + da_align((size_t)7 * N * Do * Ho * Wo * 4));
     float* g2 = (float*)((char*)g1 + da_align((size_t)7 * N * D * Ho * Wo * 4));
     const long long P = (long long)N * Do * Ho * Wo;
     hipLaunchKernelGGL(lncc_bwd_fields_kernel, dim3(da_grid(P, 256)), dim3(256), 0, st, sums, G, P, (float)((double)F * F * F), eps, dloss, (float)(1.0 / (double)P));
     DA_LAUNCH_CHECK();
-    // transposed box filter: full sums along D, then H, then W (+ combine)
-    hipLaunchKernelGGL(box_axis_kernel, dim3(da_grid((long long)7 * N * D * Ho * Wo, 256)), dim3(256), 0, st, G, g1, (long long)7 * N, Do, D, (long long)Ho * Wo, F, F - 1);
+    // adjoint of the box filter along D, then H, then W (+ combine)
+    hipLaunchKernelGGL(box_axis_kernel, dim3(da_grid((long long)7 * N * D * Ho * Wo, 256)), dim3(256), 0, st, G, g1, (long long)7 * N, Do, D, (long long)Ho * Wo, F, 1, dil, stride);
     DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(box_axis_kernel, dim3(da_grid((long long)7 * N * D * H * Wo, 256)), dim3(256), 0, st, g1, g2, (long long)7 * N * D, Ho, H, (long long)Wo, F, F - 1);
+    hipLaunchKernelGGL(box_axis_kernel, dim3(da_grid((long long)7 * N * D * H * Wo, 256)), dim3(256), 0, st, g1, g2, (long long)7 * N * D, Ho, H, (long long)Wo, F, 1, dil, stride);
     DA_LAUNCH_CHECK();
     const long long rows = (long long)N * D * H;
-    hipLaunchKernelGGL(lncc_bwd_boxw_combine_kernel, dim3(da_grid(rows * W, 256)), dim3(256), 0, st, g2, I, J, dI, dJ, rows, W, Wo, F);
+    hipLaunchKernelGGL(lncc_bwd_boxw_combine_kernel, dim3(da_grid(rows * W, 256)), dim3(256), 0, st, g2, I, J, dI, dJ, rows, W, Wo, F, dil, stride);
     DA_LAUNCH_CHECK();
     return 0;
 }

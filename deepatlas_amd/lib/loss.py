@@ -115,6 +115,43 @@ class VoxelMorphLNCC(nn.Module):
         return ops.LNCCFn.apply(I, J, self.filter_size, self.eps)
 
 
+class LNCCLoss(nn.Module):
+    """lib/loss.py:512-586 (not in the registry): multi-scale LNCC.  Scales, weights, dilations and strides follow `__stepup`
+    (:516-540): min(img) > 128 -> windows ms/16, ms/8, ms/4 (weights .1/.3/.6, dilation 2); > 64 -> ms/4, ms/2 (.3/.7,
+    dilation 2); else ms/2 (1.0, dilation 1); stride max(int((k + 1) / 4), 1); eps 1e-5.  Each scale is one LNCCFn."""
+
+    def initialize(self, kernel_sz=[9, 9, 9], voxel_weights=None):
+        pass
+
+    def _stepup(self, img_sz, use_multi_scale=True):
+        max_scale = min(img_sz)
+        if not use_multi_scale:
+            raise NotImplementedError('the reference leaves self.scale undefined for use_multi_scale=False (loss.py:535-537)')
+        if max_scale > 128:
+            self.scale = [int(max_scale / 16), int(max_scale / 8), int(max_scale / 4)]
+            self.scale_weight = [0.1, 0.3, 0.6]
+            self.dilation = [2, 2, 2]
+        elif max_scale > 64:
+            self.scale = [int(max_scale / 4), int(max_scale / 2)]
+            self.scale_weight = [0.3, 0.7]
+            self.dilation = [2, 2]
+        else:
+            self.scale = [int(max_scale / 2)]
+            self.scale_weight = [1.0]
+            self.dilation = [1]
+        self.num_scale = len(self.scale)
+        self.kernel_sz = [[scale for _ in range(3)] for scale in self.scale]
+        self.step = [[max(int((ksz + 1) / 4), 1) for ksz in self.kernel_sz[scale_id]] for scale_id in range(self.num_scale)]
+
+    def forward(self, input, target, inst_weights=None, train=None):
+        self._stepup(img_sz=list(input.shape[2:]))
+        lncc_total = 0.
+        for scale_id in range(self.num_scale):
+            lncc = ops.LNCCFn.apply(input, target, self.scale[scale_id], 1e-5, self.dilation[scale_id], self.step[scale_id][0])
+            lncc_total = lncc_total + lncc * self.scale_weight[scale_id]
+        return lncc_total
+
+
 class gradientLoss(nn.Module):
     """lib/loss.py:625-671 (registry name 'gradient'): first-difference regulariser of a N x 3 x D x H x W field, with the
     reference's `+` along H and W (loss.py:661,663) kept."""

@@ -725,38 +725,42 @@ class BendingFn(Function):
 
 
 class LNCCFn(Function):
-    """VoxelMorphLNCC.forward (lib/loss.py:599-617): five F^3 box sums as three separable passes + fused cc reduction."""
+    """Local normalised cross-correlation over all-ones k^3 windows (dilation d, stride s): VoxelMorphLNCC.forward
+    (lib/loss.py:599-617: k = filter_size, d = s = 1) and one scale of LNCCLoss.forward (:541-584).  Five box sums as three
+    separable passes + fused cc reduction; backward through the adjoint box filter."""
 
     @staticmethod
-    def forward(ctx, I, J, filter_size, eps):
+    def forward(ctx, I, J, filter_size, eps, dilation=1, stride=1):
         if I.shape != J.shape or I.dim() != 5 or I.shape[1] != 1:
             raise ValueError('LNCC expects two N x 1 x D x H x W volumes of the same shape')
         nat.require_cuda(I); nat.require_cuda(J)
         a, b = I.detach().contiguous().float(), J.detach().contiguous().float()
         N, _, D, H, W = a.shape
-        F_ = int(filter_size)
-        if min(D, H, W) < F_:
-            raise RuntimeError('LNCC window %d larger than the volume %s' % (F_, (D, H, W)))
+        F_, d_, s_ = int(filter_size), int(dilation), int(stride)
+        span = d_ * (F_ - 1) + 1
+        if min(D, H, W) < span:
+            raise RuntimeError('LNCC window %d (dilation %d) larger than the volume %s' % (F_, d_, (D, H, W)))
+        od = tuple((L - span) // s_ + 1 for L in (D, H, W))
         loss = _empty((1,), a)
-        sums = torch.empty((5, N, D - F_ + 1, H - F_ + 1, W - F_ + 1), dtype=torch.float32, device=a.device)
-        wsb = nat.lib().da_lncc_ws_bytes(N, D, H, W, F_)
+        sums = torch.empty((5, N) + od, dtype=torch.float32, device=a.device)
+        wsb = nat.lib().da_lncc_ws_bytes(N, D, H, W, F_, d_, s_)
         wp, wn = _ws(wsb, a)
-        call('da_lncc_fwd', ptr(a), ptr(b), N, D, H, W, F_, float(eps), ptr(loss), ptr(sums), wp, wn, stream())
-        ctx.cfg = (F_, float(eps), wsb)
+        call('da_lncc_fwd', ptr(a), ptr(b), N, D, H, W, F_, d_, s_, float(eps), ptr(loss), ptr(sums), wp, wn, stream())
+        ctx.cfg = (F_, d_, s_, float(eps), wsb)
         ctx.save_for_backward(a, b, sums)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gloss):
         a, b, sums = ctx.saved_tensors
-        F_, eps, wsb = ctx.cfg
+        F_, d_, s_, eps, wsb = ctx.cfg
         N, _, D, H, W = a.shape
         gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
         dI = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         dJ = torch.empty_like(a) if ctx.needs_input_grad[1] else None
         wp, wn = _ws(wsb, a)
-        call('da_lncc_bwd', ptr(a), ptr(b), ptr(sums), ptr(gl), ptr(dI), ptr(dJ), N, D, H, W, F_, eps, wp, wn, stream())
-        return dI, dJ, None, None
+        call('da_lncc_bwd', ptr(a), ptr(b), ptr(sums), ptr(gl), ptr(dI), ptr(dJ), N, D, H, W, F_, d_, s_, eps, wp, wn, stream())
+        return dI, dJ, None, None, None, None
 
 
 class GradLossFn(Function):

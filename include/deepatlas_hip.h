@@ -224,14 +224,15 @@ int da_partition_tiles(const void* vol, void* tiles, int elem_bytes, int D, int 
 /* vote == 0: copy the effective core of each tile; vote != 0 (uint8 labels): per-voxel majority over the covering tiles */
 int da_assemble_tiles(const void* tiles, void* vol, int elem_bytes, int D, int H, int W, const int* tile3, const int* overlap3, int vote, void* stream);
 
-/* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC, registry 'lncc') ------------------------
- * I, J: [N][D][H][W] fp32 (single channel); F^3 all-ones window, valid padding; loss = 1 - mean(cross^2 / (Ivar Jvar + eps)).
- * sums: [5][N][D-F+1][H-F+1][W-F+1] window sums (I, J, I^2, J^2, IJ), written by fwd and consumed by bwd. */
-size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F);
-int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, int W, int F, float eps,
+/* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC = registry 'lncc', and :512-586 LNCCLoss) -----
+ * I, J: [N][D][H][W] fp32 (single channel); all-ones F^3 window with dilation `dil` and stride `stride` (1, 1 for VoxelMorphLNCC),
+ * valid padding; loss = 1 - mean(cross^2 / (Ivar Jvar + eps)).  Output extent per axis: (L - dil (F-1) - 1) / stride + 1.
+ * sums: [5][N][Do][Ho][Wo] window sums (I, J, I^2, J^2, IJ), written by fwd and consumed by bwd. */
+size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F, int dil, int stride);
+int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, int W, int F, int dil, int stride, float eps,
                 float* loss, float* sums, void* ws, size_t ws_bytes, void* stream);
 int da_lncc_bwd(const float* I, const float* J, const float* sums, const float* dloss, float* dI, float* dJ,
-                int N, int D, int H, int W, int F, float eps, void* ws, size_t ws_bytes, void* stream);
+                int N, int D, int H, int W, int F, int dil, int stride, float eps, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- displacement gradient regulariser (row f2; lib/loss.py:625-671 gradientLoss, registry 'gradient') ------------------
  * disp [N][D][H][W][3]; norm = 2 ('L2') or 1; keeps the reference's +/- quirk along H and W (loss.py:661,663). */

@@ -218,3 +218,29 @@ def gradient_loss(u, norm='L2', spacing=(1, 1, 1), normalize=True):
         dy = (dy ** 2).mean(2) * (dims * sp / sp[1]) ** 2
         dz = (dz ** 2).mean(2) * (dims * sp / sp[2]) ** 2
     return (dx.mean() + dy.mean() + dz.mean()) / 3.0
+
+
+def lncc_multiscale_loss(I, J):
+    """lib/loss.py:512-586 LNCCLoss.forward (+ __stepup :516-540), filters on the CPU instead of .cuda()."""
+    img_sz = list(I.shape[2:])
+    ms = min(img_sz)
+    if ms > 128:
+        scale, weight, dil = [int(ms / 16), int(ms / 8), int(ms / 4)], [0.1, 0.3, 0.6], [2, 2, 2]
+    elif ms > 64:
+        scale, weight, dil = [int(ms / 4), int(ms / 2)], [0.3, 0.7], [2, 2]
+    else:
+        scale, weight, dil = [int(ms / 2)], [1.0], [1]
+    total = 0.
+    for k, w, d in zip(scale, weight, dil):
+        step = max(int((k + 1) / 4), 1)
+        filt = torch.ones([1, 1, k, k, k], dtype=I.dtype)
+        conv = lambda t: F.conv3d(t, filt, padding=0, dilation=d, stride=step).view(I.shape[0], -1)
+        Is, Js, I2s, J2s, IJs = conv(I), conv(J), conv(I ** 2), conv(J ** 2), conv(I * J)
+        numel = float(k ** 3)
+        Im, Jm = Is / numel, Js / numel
+        cross = IJs - Jm * Is - Im * Js + Jm * Im * numel
+        Iv = I2s - 2 * Im * Is + Im ** 2 * numel
+        Jv = J2s - 2 * Jm * Js + Jm ** 2 * numel
+        lncc = cross * cross / (Iv * Jv + 1e-5)
+        total = total + (1 - lncc.mean()) * w
+    return total

@@ -266,6 +266,26 @@ def run_reglosses(ref, out):
         out['lncc/f%d/loss' % fs] = np.float64(l.item())
         out['lncc/f%d/grad_I' % fs], out['lncc/f%d/grad_J' % fs] = np32(gi), np32(gj)
     out['lncc/I'], out['lncc/J'] = np32(I), np32(J)
+    # multi-scale LNCCLoss (:512-586, builds its filters with .cuda(): run on the CPU by making .cuda() the identity for this call)
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, shp in (('s1', (1, 1, 20, 24, 28)), ('s2', (1, 1, 66, 68, 70)), ('s3', (1, 1, 130, 132, 134))):
+            A = nets.closed_form_volume(shp, seed=63).clone().requires_grad_(True)
+            B = nets.closed_form_volume(shp, seed=64).clone().requires_grad_(True)
+            l = ref.loss.LNCCLoss()(A, B)
+            ga, gb = torch.autograd.grad(l, (A, B))
+            out['lncc_ms/%s/loss' % tag] = np.float64(l.item())
+            out['lncc_ms/%s/grad_I' % tag], out['lncc_ms/%s/grad_J' % tag] = summary(ga), summary(gb)
+            # fp64 twin: the window variances are differences of large sums, so fp32 gradients carry visible rounding noise
+            A64, B64 = A.detach().double().requires_grad_(True), B.detach().double().requires_grad_(True)
+            from oracle import losses as _ol          # the reference builds fp32 filters; its restatement (pinned above in fp32) takes the input dtype
+            l64 = _ol.lncc_multiscale_loss(A64, B64)
+            ga64, gb64 = torch.autograd.grad(l64, (A64, B64))
+            out['lncc_ms/%s_f64/loss' % tag] = np.float64(l64.item())
+            out['lncc_ms/%s_f64/grad_I' % tag], out['lncc_ms/%s_f64/grad_J' % tag] = summary(ga64), summary(gb64)
+    finally:
+        torch.Tensor.cuda = _cuda
     u = (nets.closed_form_volume((2, 3, 6, 10, 14), seed=62) * 0.3).clone().requires_grad_(True)
     out['gradloss/u'] = np32(u)
     for tag, kw in (('L2', {}), ('L2_spacing', {'spacing': (1.0, 2.0, 1.5)}), ('L2_nonorm', {'spacing': (1.0, 2.0, 1.5), 'normalize': False}), ('L1', {'norm': 'L1'})):

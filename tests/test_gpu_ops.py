@@ -612,3 +612,24 @@ def test_datapath_full_size_round_trip():
     assert torch.equal(part.assemble(p['image'][:, 0]), img)
     assert torch.equal(part.assemble(p['segmentation'][:, 0]), lab)
     assert torch.equal(part.assemble(p['segmentation'][:, 0], is_vote=True), lab)
+
+
+def test_lncc_multiscale_golden(golden):
+    """LNCCLoss (lib/loss.py:512-586): dilated / strided box windows at 1, 2 and 3 scales vs the reference's outputs.  The window
+    variances are differences of large sums (up to 33^3 terms), so the reference's own fp32 gradients deviate from fp64 by up to
+    1.4e-3 on the two-scale case; the device is compared with the fp64 twin within 3 x that deviation (never tighter than 5e-4)."""
+    from deepatlas_amd.lib.loss import LNCCLoss
+    from oracle import nets
+    from conftest import summary_of
+    g = golden('reglosses')
+    for tag, shp in (('s1', (1, 1, 20, 24, 28)), ('s2', (1, 1, 66, 68, 70)), ('s3', (1, 1, 130, 132, 134))):
+        A = nets.closed_form_volume(shp, seed=63).to(dev()).requires_grad_(True)
+        B = nets.closed_form_volume(shp, seed=64).to(dev()).requires_grad_(True)
+        l = LNCCLoss()(A, B); l.backward()
+        ref = float(g['lncc_ms/%s_f64/loss' % tag])
+        assert abs(l.item() - ref) < max(1e-5, 10 * abs(float(g['lncc_ms/%s/loss' % tag]) - ref)), (tag, l.item(), ref)
+        for t, key in ((A, 'grad_I'), (B, 'grad_J')):
+            s_, r32, r64 = summary_of(t.grad), g['lncc_ms/%s/%s' % (tag, key)], g['lncc_ms/%s_f64/%s' % (tag, key)]
+            floor = max(abs(r32[2] - r64[2]) / r64[2], rel_l2(r32[5:], r64[5:]))
+            assert abs(s_[2] - r64[2]) / r64[2] < max(5e-4, 3 * floor), (tag, key, s_[2], r64[2], floor)
+            assert rel_l2(s_[5:], r64[5:]) < max(5e-4, 3 * floor), (tag, key, floor)

@@ -304,3 +304,17 @@ def test_datapath_oracle_vs_reference(golden):
         assert np.array_equal(st[:, None], g['dp/part/%s/seg' % tag])
         assert np.array_equal(part.assemble(st), g['dp/part/%s/assemble' % tag])
         assert np.array_equal(part.assemble(g['dp/part/%s/noisy' % tag], is_vote=True), g['dp/part/%s/assemble_vote' % tag])
+
+
+def test_lncc_multiscale_oracle_vs_reference(golden):
+    """oracle.losses.lncc_multiscale_loss == LNCCLoss.forward (lib/loss.py:512-586) at one, two and three scales."""
+    import torch
+    from oracle import nets, losses
+    g = golden('reglosses')
+    for tag, shp in (('s1', (1, 1, 20, 24, 28)), ('s2', (1, 1, 66, 68, 70))):            # the 3-scale case runs in the GPU suite
+        A = nets.closed_form_volume(shp, seed=63).clone().requires_grad_(True)
+        B = nets.closed_form_volume(shp, seed=64).clone().requires_grad_(True)
+        l = losses.lncc_multiscale_loss(A, B)
+        ga, gb = torch.autograd.grad(l, (A, B))
+        assert abs(l.item() - float(g['lncc_ms/%s/loss' % tag])) < 1e-6
+        assert rel_l2(summary_of(ga)[5:], g['lncc_ms/%s/grad_I' % tag][5:]) < 1e-5 and rel_l2(summary_of(gb)[5:], g['lncc_ms/%s/grad_J' % tag][5:]) < 1e-5
