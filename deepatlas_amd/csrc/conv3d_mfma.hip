@@ -135,6 +135,9 @@ __device__ __forceinline__ void da_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, byte_off, 0, 0);
 }
 template <bool B> struct BoolC { static constexpr bool value = B; };
+// lane ^ 1 / lane ^ 2 exchanges inside a lane quad as DPP quad_perm moves (VALU, no trip through the LDS crossbar like __shfl_xor)
+__device__ __forceinline__ float da_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float da_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -442,13 +445,13 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                         {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
                             const bool odd = (q & 1) != 0;
                             const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
-                            const float r01 = __shfl_xor(s01, 1), r23 = __shfl_xor(s23, 1);
+                            const float r01 = da_quad_xor1(s01), r23 = da_quad_xor1(s23);
                             if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
                         }
                         {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
                             const bool hi2 = (q & 2) != 0;
                             const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
-                            const float r02 = __shfl_xor(s02, 2), r13 = __shfl_xor(s13, 2);
+                            const float r02 = da_quad_xor2(s02), r13 = da_quad_xor2(s13);
                             if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
                         }
                         // now (t0..t3) = couts co0..co0+3 of voxel (z, y0 + r, x)
