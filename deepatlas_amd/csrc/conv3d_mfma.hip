@@ -1073,7 +1073,14 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     const int Cin = C1 + C2;
     const int CK = pick_ck(C1, C2);
     if (!CK) return DA_ERR_UNSUPPORTED;
-    const int NT = (Cout + 15) / 16, NREP = pick_nrep(NT);
+    const int NT = (Cout + 15) / 16;
+    int NREP = pick_nrep(NT);
+    {   // coarse levels have few tiles (30 per volume at 20x24x20): give every N-tile its own workgroup there, so that
+        // tiles x cout-groups covers more of the 256 CUs (the extra input re-staging is irrelevant at that size)
+        static int adapt = -1; if (adapt < 0) { const char* e = getenv("DA_NREP_ADAPT"); adapt = e ? atoi(e) : 1; }
+        const long long tiles = (long long)N * ((D + 3) / 4) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+        if (adapt && s2d_cin == 0 && NREP > 1 && tiles * ((NT + NREP - 1) / NREP) < 256) NREP = 1;
+    }
     const int gy = (NT + NREP - 1) / NREP, NTpad = gy * NREP;
     const int NSTEPS = (27 * CK + 15) / 16;
     const size_t pk = packed_bytes(Cin, Cout, CK);
