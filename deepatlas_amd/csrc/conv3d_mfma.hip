@@ -1075,11 +1075,19 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     if (!CK) return DA_ERR_UNSUPPORTED;
     const int NT = (Cout + 15) / 16;
     int NREP = pick_nrep(NT);
-    {   // coarse levels have few tiles (30 per volume at 20x24x20): give every N-tile its own workgroup there, so that
-        // tiles x cout-groups covers more of the 256 CUs (the extra input re-staging is irrelevant at that size)
+    {   // Coarse levels have few tiles (30 per volume at 20x24x20, 180 at 40x48x40): the persistent grid then runs one or two
+        // uneven rounds.  Makespan model: a workgroup walks ceil(tiles / nblk) tiles, each costing ~NREP (one N-tile per
+        // workgroup is ~8 % less efficient per FLOP but quadruples / doubles the number of work items); take the cheaper.
         static int adapt = -1; if (adapt < 0) { const char* e = getenv("DA_NREP_ADAPT"); adapt = e ? atoi(e) : 1; }
         const long long tiles = (long long)N * ((D + 3) / 4) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
-        if (adapt && s2d_cin == 0 && NREP > 1 && tiles * ((NT + NREP - 1) / NREP) < 256) NREP = 1;
+        if (adapt && s2d_cin == 0 && NREP > 1) {
+            auto cost = [&](int nrep) {
+                const int g = (NT + nrep - 1) / nrep;
+                long long nb = 512 / g; if (nb < 1) nb = 1; if (nb > tiles) nb = tiles;
+                return (double)((tiles + nb - 1) / nb) * nrep * (nrep == 1 ? 1.08 : 1.0);
+            };
+            if (cost(1) < cost(NREP)) NREP = 1;
+        }
     }
     const int gy = (NT + NREP - 1) / NREP, NTpad = gy * NREP;
     const int NSTEPS = (27 * CK + 15) / 16;
