@@ -77,8 +77,7 @@ class SitkToTensor(object):
 
 class CropTensor(object):
     """lib/transforms.py:124-158: crop_size [z, y, x] (both sides) or [z_lo, y_lo, x_lo, z_hi, y_hi, x_hi] voxels off a C x D x H x W
-    image and its D x H x W segmentation.  Device tensors are cropped into fresh contiguous tensors by one copy kernel; host
-    tensors are sliced exactly as the reference does."""
+    image and its D x H x W segmentation, as fresh contiguous device tensors from one copy kernel."""
 
     def __init__(self, crop_size):
         crop_size = list(crop_size)
@@ -93,8 +92,9 @@ class CropTensor(object):
         c = self.crop_size
         D, H, W = size
         Do, Ho, Wo = D - c[0] - c[3], H - c[1] - c[4], W - c[2] - c[5]
-        if not t.is_cuda or t.element_size() not in (1, 4):
-            return t[..., c[0]:D - c[3], c[1]:H - c[4], c[2]:W - c[5]]
+        t = t.to(_device())                       # host tensors are uploaded: there is no host implementation of this path
+        if t.element_size() not in (1, 4):
+            t = t.float() if t.dtype.is_floating_point else t.to(torch.int32)
         t = t.contiguous()
         out = torch.empty(tuple(t.shape[:-3]) + (Do, Ho, Wo), dtype=t.dtype, device=t.device)
         call('da_crop3d', ptr(t), ptr(out), t.element_size(), lead, D, H, W, c[0], c[1], c[2], Do, Ho, Wo, stream())
