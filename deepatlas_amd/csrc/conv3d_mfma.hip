@@ -856,6 +856,8 @@ struct ScP {
     const float* in1; const float* in2; int C1, C2;
     const float* dy; float* partial;
     int N, D, H, W, Cout; long long nrows;
+    const float* dyb; int Cd1;      // optional second half of the B operand: channels [Cd1, Cout) come from dyb (stride Cout - Cd1);
+                                    // Cd1 == Cout when the B operand is one tensor
 };
 
 template <int MT, int NT>
@@ -887,7 +889,9 @@ __global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
     const unsigned long long vol = (unsigned long long)p.N * p.D * p.H * p.W;
     const __amdgpu_buffer_rsrc_t r1 = da_rsrc(p.in1, (unsigned)(vol * p.C1 * 4ull));
     const __amdgpu_buffer_rsrc_t r2 = da_rsrc(p.C2 > 0 ? p.in2 : p.in1, (unsigned)(vol * (p.C2 > 0 ? p.C2 : p.C1) * 4ull));
-    const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy, (unsigned)(vol * p.Cout * 4ull));
+    const int Cd2 = p.Cout - p.Cd1;
+    const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy, (unsigned)(vol * p.Cd1 * 4ull));
+    const __amdgpu_buffer_rsrc_t ry2 = da_rsrc(Cd2 > 0 ? p.dyb : p.dy, (unsigned)(vol * (Cd2 > 0 ? Cd2 : p.Cd1) * 4ull));
     bool from2[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) from2[mt] = (src[mt] == p.in2) && p.C2 > 0;
@@ -901,12 +905,16 @@ __global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
             rval[mt] = mval[mt] && zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
             rbase[mt] = (unsigned)((((((long long)n * p.D + (rval[mt] ? zz : 0)) * p.H + (rval[mt] ? yy : 0)) * p.W) * cs[mt] + cc[mt]) * 4);
         }
-        const unsigned gbase = (unsigned)((row * p.W) * p.Cout * 4);
+        const unsigned gbase = (unsigned)((row * p.W) * p.Cd1 * 4), gbase2 = (unsigned)((row * p.W) * Cd2 * 4);
         auto fetch = [&](int x0, float* a, float* b) {
             const int x = x0 + g;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (x < p.W && 16 * nt + i < p.Cout) ? gbase + (unsigned)((x * p.Cout + 16 * nt + i) * 4) : 0xFFFFFFFFu, 0, 0));
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = 16 * nt + i;
+                const bool ok = x < p.W && c < p.Cout;
+                if (c < p.Cd1) b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? gbase + (unsigned)((x * p.Cd1 + c) * 4) : 0xFFFFFFFFu, 0, 0));
+                else b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry2, ok ? gbase2 + (unsigned)((x * Cd2 + c - p.Cd1) * 4) : 0xFFFFFFFFu, 0, 0));
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int xx = x + dx[mt];
@@ -1031,6 +1039,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
     size_t part = 0;
     if (Cin % 8 == 0) part = wgrad_plan(N, D, H, W, Cin, 0, Cout).partial_bytes;
     if (Cin <= 4 && Cout <= 32) part = da_align((size_t)kScBlocksFwd * 27 * Cin * Cout * sizeof(float));
+    if (Cout <= 4 && Cin <= 32) { const size_t sw = da_align((size_t)(kScBlocksFwd + 1) * 27 * Cin * Cout * sizeof(float)); if (sw > part) part = sw; }   // swapped-operand weight gradient
     return pk + part;
 }
 
@@ -1195,6 +1204,15 @@ bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride) {
     return true;
 }
 
+// tmp[(t' * Cout + co) * Cin + ci] (t' = mirrored tap) -> dw_tio[((26 - t') * Cin + ci) * Cout + co]
+__global__ void swapped_wgrad_place_kernel(const float* __restrict__ tmp, float* __restrict__ dw, int Cin, int Cout) {
+    const int O = 27 * Cin * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < O; i += gridDim.x * blockDim.x) {
+        const int ci = i % Cin; const int r = i / Cin; const int co = r % Cout; const int t = r / Cout;
+        dw[((size_t)(26 - t) * Cin + ci) * Cout + co] = tmp[i];
+    }
+}
+
 template <int CK, int NREP, bool YS = false, bool MASKED = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * sizeof(float);
@@ -1218,7 +1236,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         if ((unsigned long long)N * D * H * W * (Cout > Cin ? Cout : Cin) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
         ScP sp;
         sp.in1 = in1; sp.in2 = in2; sp.C1 = C1; sp.C2 = C2; sp.dy = dy; sp.partial = (float*)ws;
-        sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.Cout = Cout; sp.nrows = (long long)N * D * H;
+        sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.Cout = Cout; sp.nrows = (long long)N * D * H; sp.dyb = nullptr; sp.Cd1 = Cout;
         int nb = (int)da_cdiv(sp.nrows, 4); if (nb > kScBlocks) nb = kScBlocks;
         const int MT = (27 * Cin + 15) / 16, NT = (Cout + 15) / 16;
 #define DA_SC_CASE(mt, nt) if (MT == mt && NT == nt) hipLaunchKernelGGL((conv3_smallcin_wgrad_kernel<mt, nt>), dim3(nb), dim3(256), 0, st, sp)
@@ -1227,6 +1245,29 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
 #undef DA_SC_CASE
         DA_LAUNCH_CHECK();
         { const int rc2 = da_reduce_partials(sp.partial, nb, O, dw_tio, st); if (rc2) return rc2; }
+        return 0;
+    }
+    if (stride == 1 && s2d_cin == 0 && Cout <= 4 && C1 + C2 <= 32 && (unsigned long long)N * D * H * W * (C1 > C2 ? C1 : C2) * 4ull < 0xFFFFFFF0ull) {
+        // Very few OUTPUT channels (the 24 -> 3 flow conv, voxel_morph.py:57): swap the operands.  dW[tap][ci][co] =
+        // sum_u dy[u - tap][co] x[u][ci] is the small-Cin weight gradient of a conv with "input" dy (Cout channels), "output
+        // gradient" x (Cin channels, possibly two tensors) and the taps mirrored; 27*Cout <= 108 rows instead of an MFMA N-tile
+        // that is 13/16 padding.  The result [27][Cout][Cin] (mirrored) is permuted into dw_tio by a tiny kernel.
+        const int Cin = C1 + C2, O = 27 * Cin * Cout;
+        if (ws_bytes < (size_t)(kScBlocks + 1) * O * sizeof(float)) return DA_ERR_WS_SMALL;
+        ScP sp;
+        sp.in1 = dy; sp.in2 = nullptr; sp.C1 = Cout; sp.C2 = 0; sp.dy = in1; sp.dyb = in2; sp.Cd1 = C1; sp.Cout = Cin;
+        sp.partial = (float*)ws; sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.nrows = (long long)N * D * H;
+        int nb = (int)da_cdiv(sp.nrows, 4); if (nb > kScBlocks) nb = kScBlocks;
+        const int MT = (27 * Cout + 15) / 16, NT = (Cin + 15) / 16;
+#define DA_SC_CASE(mt, nt) if (MT == mt && NT == nt) hipLaunchKernelGGL((conv3_smallcin_wgrad_kernel<mt, nt>), dim3(nb), dim3(256), 0, st, sp)
+        DA_SC_CASE(2, 1); else DA_SC_CASE(2, 2); else DA_SC_CASE(4, 1); else DA_SC_CASE(4, 2); else DA_SC_CASE(6, 1); else DA_SC_CASE(6, 2);
+        else DA_SC_CASE(7, 1); else DA_SC_CASE(7, 2); else return DA_ERR_UNSUPPORTED;
+#undef DA_SC_CASE
+        DA_LAUNCH_CHECK();
+        float* tmp = (float*)ws + (size_t)kScBlocks * O;
+        { const int rc2 = da_reduce_partials(sp.partial, nb, O, tmp, st); if (rc2) return rc2; }
+        hipLaunchKernelGGL(swapped_wgrad_place_kernel, dim3(da_grid(O, 256, 64)), dim3(256), 0, st, tmp, dw_tio, Cin, Cout);
+        DA_LAUNCH_CHECK();
         return 0;
     }
     const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout);
