@@ -334,8 +334,9 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
     }
     if (!force_direct() && da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) {
         if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
-        return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
-                                 N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
+        const int rc = da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, /*w_is_flipped_tr=*/0, bias, out, Cout, nullptr, 0,
+                                         N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
+        if (rc != DA_ERR_UNSUPPORTED) return rc;           // e.g. a per-sample tensor beyond 32-bit byte offsets: direct kernels below
     }
     if (!force_direct() && da_conv3_thin_supported(C1, C2, Cout, stride) && !getenv("DA_NO_THIN")) {
         const int rc = da_conv3_thin_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope, st);
@@ -364,8 +365,10 @@ extern "C" int da_conv3d_k3_fwd_bnstats(const float* in1, int C1, const float* i
         return DA_ERR_BADARG;
     if (stats_partial && stats_capacity >= 512 && !force_direct() && stride == 1 && da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) {
         if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
-        return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, stride, -1.f,
-                                 ws, ws_bytes, da_stream(stream), 0, stats_partial, stats_nparts);
+        const int rc = da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, stride, -1.f,
+                                         ws, ws_bytes, da_stream(stream), 0, stats_partial, stats_nparts);
+        if (rc != DA_ERR_UNSUPPORTED) return rc;
+        if (stats_nparts) *stats_nparts = 0;
     }
     return da_conv3d_k3_fwd(in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, stride, -1.f, ws, ws_bytes, stream);
 }
@@ -380,8 +383,9 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
     if (stride == 1) {
         // dX = conv(dY, flip/transpose(W)) : Cin' = Cout, Cout' = Cin, output split over (dx1, dx2)
         if (!force_direct() && da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) {
-            return da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, dx1, C1, dx2, C2,
-                                     N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, st);
+            const int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, dx1, C1, dx2, C2,
+                                             N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, st);
+            if (rc != DA_ERR_UNSUPPORTED) return rc;
         }
         if (!force_direct() && da_conv3_thin_supported(Cout, 0, Cin, 1)) {
             const int rc = da_conv3_thin_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, -1.f, st);

@@ -1082,6 +1082,11 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     const int Cin = C1 + C2;
     const int CK = pick_ck(C1, C2);
     if (!CK) return DA_ERR_UNSUPPORTED;
+    {   // every tensor is addressed per sample through a buffer descriptor with 32-bit byte offsets
+        const unsigned long long vox4 = (unsigned long long)D * H * W * 4ull;
+        const int cmax = (C1 > C2 ? C1 : C2) > (Cs1 > Cs2 ? Cs1 : Cs2) ? (C1 > C2 ? C1 : C2) : (Cs1 > Cs2 ? Cs1 : Cs2);
+        if (vox4 * (unsigned long long)cmax >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+    }
     const int NT = (Cout + 15) / 16;
     int NREP = pick_nrep(NT);
     {   // Coarse levels have few tiles (30 per volume at 20x24x20, 180 at 40x48x40): the persistent grid then runs one or two
@@ -1272,6 +1277,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     }
     const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
+    if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < q.partial_bytes) return DA_ERR_WS_SMALL;
     WgP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.dy = dy; p.partial = (float*)ws;
