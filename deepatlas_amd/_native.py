@@ -61,6 +61,8 @@ SIGNATURES = {
     'da_warp_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
     'da_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, I, P]),
     'da_identity_grid': (I, [P, I, I, I, I, P]),
+    'da_warp_labels_fwd': (I, [P, I, P, P, I, I, I, I, I, P]),
+    'da_warp_labels_bwd': (I, [P, P, I, P, P, I, I, I, I, I, P]),
     'da_dice_ws_bytes': (SZ, [I, LL, I]),
     'da_dice_fwd': (I, [P, P, I, P, I, LL, I, I, I, I, F, P, P, P, SZ, P]),
     'da_dice_bwd': (I, [P, P, I, P, P, P, P, I, LL, I, I, P]),

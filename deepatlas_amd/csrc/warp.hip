@@ -189,6 +189,78 @@ __global__ void warp_bwd_dsrc_lane_kernel(const float* __restrict__ dout, const 
     }
 }
 
+// Warp of a LABEL map as if it were its one-hot encoding (the joint step's registration phase warps one-hot(seg_m) with the
+// predicted field): out[v][c] = sum_k w_k [label[corner_k] == c].  The 32-channel one-hot tensor (629 MB per
+// volume) is never materialised: 8 label bytes are read per voxel instead of 8 x 128 bytes.  One lane per channel.
+__device__ __forceinline__ int warp_label_at(const void* lab, int label_bytes, long long i) {
+    return label_bytes == 1 ? (int)((const unsigned char*)lab)[i] : (int)((const long long*)lab)[i];
+}
+
+__global__ void warp_labels_fwd_kernel(const void* __restrict__ labels, int label_bytes, const float* __restrict__ disp,
+                                       float* __restrict__ out, int N, int D, int H, int W, int C) {
+    const long long total = (long long)N * D * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long v = i / C;
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int d = (int)(r % D); const int n = (int)(r / D);
+        const float gx = disp[v * 3 + 0] + id_coord(w, W);
+        const float gy = disp[v * 3 + 1] + id_coord(h, H);
+        const float gz = disp[v * 3 + 2] + id_coord(d, D);
+        const bool fin = is_finite_coord(gx, gy, gz);
+        const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
+        const long long sbase = (long long)n * D * H * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                if (warp_label_at(labels, label_bytes, sbase + ((long long)z * H + y) * W + x) == c) acc += wgt;
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+// d loss / d disp for the label warp: the same grid gradient as warp_bwd_kernel with sum_c src[corner][c] gOut[c] = gOut[label[corner]]
+__global__ void warp_labels_bwd_kernel(const float* __restrict__ dout, const void* __restrict__ labels, int label_bytes,
+                                       const float* __restrict__ disp, float* __restrict__ d_disp, int N, int D, int H, int W, int C) {
+    const long long nvox = (long long)N * D * H * W;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int d = (int)(r % D); const int n = (int)(r / D);
+        const float gx = disp[v * 3 + 0] + id_coord(w, W);
+        const float gy = disp[v * 3 + 1] + id_coord(h, H);
+        const float gz = disp[v * 3 + 2] + id_coord(d, D);
+        const bool fin = is_finite_coord(gx, gy, gz);
+        const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
+        const long long sbase = (long long)n * D * H * W;
+        float gix = 0.f, giy = 0.f, giz = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wx = cx ? t.fx0 : t.fx1, wy = cy ? t.fy0 : t.fy1, wz = cz ? t.fz0 : t.fz1;
+                const int lab = warp_label_at(labels, label_bytes, sbase + ((long long)z * H + y) * W + x);
+                const float dot = (lab >= 0 && lab < C) ? dout[v * C + lab] : 0.f;
+                gix += (cx ? dot : -dot) * wy * wz;
+                giy += (cy ? dot : -dot) * wx * wz;
+                giz += (cz ? dot : -dot) * wx * wy;
+            }
+        }
+        d_disp[v * 3 + 0] = gix * ((float)(W - 1) / 2.f);
+        d_disp[v * 3 + 1] = giy * ((float)(H - 1) / 2.f);
+        d_disp[v * 3 + 2] = giz * ((float)(D - 1) / 2.f);
+    }
+}
+
 __global__ void identity_grid_kernel(float* __restrict__ out, int D, int H, int W, int normalize) {
     const long long V = (long long)D * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long long)gridDim.x * blockDim.x) {
@@ -245,6 +317,24 @@ extern "C" int da_identity_grid(float* out, int D, int H, int W, int normalize, 
     if (!out || D < 1 || H < 1 || W < 1) return DA_ERR_BADARG;
     const long long V = (long long)D * H * W;
     hipLaunchKernelGGL(identity_grid_kernel, dim3(da_grid(V, 256)), dim3(256), 0, da_stream(stream), out, D, H, W, normalize);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_warp_labels_fwd(const void* labels, int label_bytes, const float* disp, float* out,
+                                  int N, int D, int H, int W, int C, void* stream) {
+    if (!labels || !disp || !out || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (label_bytes != 1 && label_bytes != 8)) return DA_ERR_BADARG;
+    const long long total = (long long)N * D * H * W * C;
+    hipLaunchKernelGGL(warp_labels_fwd_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), labels, label_bytes, disp, out, N, D, H, W, C);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_warp_labels_bwd(const float* dout, const void* labels, int label_bytes, const float* disp, float* d_disp,
+                                  int N, int D, int H, int W, int C, void* stream) {
+    if (!dout || !labels || !disp || !d_disp || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (label_bytes != 1 && label_bytes != 8)) return DA_ERR_BADARG;
+    const long long nvox = (long long)N * D * H * W;
+    hipLaunchKernelGGL(warp_labels_bwd_kernel, dim3(da_grid(nvox, 256)), dim3(256), 0, da_stream(stream), dout, labels, label_bytes, disp, d_disp, N, D, H, W, C);
     DA_LAUNCH_CHECK();
     return 0;
 }

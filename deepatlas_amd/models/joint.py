@@ -49,14 +49,13 @@ class DeepAtlasJointStep:
 
     def __call__(self, im_m, im_t, seg_m, seg_t):
         lam = self.lam
-        onehot_m = ops.one_hot(seg_m.unsqueeze(1), self.n_classes)
         # Dice against one-hot(seg_t): the fused kernel takes the index mask directly (t in {0,1} either way), so the target
         # one-hot is never materialised
         # ---- registration phase (segmentation net not involved: the moving segmentation is given)
         self.reg.train()
         self.reg_opt.zero_grad()
         disp, warped, deform = self.reg(im_m, im_t)
-        warped_seg, _ = ops.WarpFn.apply(onehot_m, disp)
+        warped_seg = ops.WarpLabelsFn.apply(seg_m, disp, self.n_classes)      # = warp(one_hot(seg_m)), one-hot never materialised
         l_sim = self.ncc(warped, im_t)
         l_reg = self.bend(disp)
         l_anat = self.dice_prob(warped_seg, seg_t)

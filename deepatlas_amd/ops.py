@@ -606,6 +606,31 @@ class WarpFn(Function):
 _WEIGHT_TYPES = {'Uniform': 0, 'Simple': 1, 'Volume': 2}
 
 
+class WarpLabelsFn(Function):
+    """warp(one_hot(labels), identity + disp) without the one-hot tensor (joint step, registration phase): N x C x D x H x W."""
+
+    @staticmethod
+    def forward(ctx, labels, disp, n_classes):
+        u = ndhwc(disp)
+        N, D, H, W, _ = u.shape
+        lab, nbytes = _labels(labels.reshape(N, -1))
+        if lab.shape[1] != D * H * W:
+            raise ValueError('label map and displacement field must cover the same volume')
+        out = _empty((N, D, H, W, int(n_classes)), u)
+        call('da_warp_labels_fwd', ptr(lab), nbytes, ptr(u), ptr(out), N, D, H, W, int(n_classes), stream())
+        ctx.cfg = (N, D, H, W, int(n_classes), nbytes)
+        ctx.save_for_backward(lab, u)
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lab, u = ctx.saved_tensors
+        N, D, H, W, C, nbytes = ctx.cfg
+        d_disp = torch.empty_like(u)
+        call('da_warp_labels_bwd', ptr(ndhwc(gout)), ptr(lab), nbytes, ptr(u), ptr(d_disp), N, D, H, W, C, stream())
+        return None, ncdhw(d_disp), None
+
+
 class DiceFn(Function):
     """DiceLossMultiClass.forward (lib/loss.py:410-476) with the softmax and the one-hot fused in."""
 

@@ -166,6 +166,12 @@ int da_warp_fwd(const float* src, const float* disp, float* deform, float* out,
 int da_warp_bwd(const float* dout, const float* src, const float* disp, float* d_disp, float* d_src,
                 int N, int D, int H, int W, int C, void* stream);
 /* lib/utils.py:78-102 get_identity_transform(_batch): out[3][D][H][W] (reference layout, channel-first) */
+/* warp of one-hot(labels) without materialising the one-hot tensor (joint step): out [N][D][H][W][C];
+ * labels uint8 (1) / int64 (8) [N][D][H][W]; backward w.r.t. the displacement only (labels carry no gradient). */
+int da_warp_labels_fwd(const void* labels, int label_bytes, const float* disp, float* out,
+                       int N, int D, int H, int W, int C, void* stream);
+int da_warp_labels_bwd(const float* dout, const void* labels, int label_bytes, const float* disp, float* d_disp,
+                       int N, int D, int H, int W, int C, void* stream);
 int da_identity_grid(float* out, int D, int H, int W, int normalize, void* stream);
 
 /* ---- fused softmax + Dice loss (row a11; lib/loss.py:410-476, lib/transforms.py:675-689) ------ */

@@ -633,3 +633,20 @@ def test_lncc_multiscale_golden(golden):
             floor = max(abs(r32[2] - r64[2]) / r64[2], rel_l2(r32[5:], r64[5:]))
             assert abs(s_[2] - r64[2]) / r64[2] < max(5e-4, 3 * floor), (tag, key, s_[2], r64[2], floor)
             assert rel_l2(s_[5:], r64[5:]) < max(5e-4, 3 * floor), (tag, key, floor)
+
+
+def test_warp_labels_equals_warp_of_onehot():
+    """da_warp_labels_{fwd,bwd} == warp(one_hot(labels)) and its displacement gradient (uint8 and int64 labels, out-of-volume taps)."""
+    from deepatlas_amd import ops
+    N, C, D, H, W = 2, 8, 6, 10, 12
+    g = torch.Generator().manual_seed(9)
+    lab = torch.randint(0, C, (N, D, H, W), generator=g)
+    disp = rnd((N, 3, D, H, W), 2, 0.6)
+    go = rnd((N, C, D, H, W), 3)
+    for dt in (torch.uint8, torch.int64):
+        l = lab.to(dt).to(dev())
+        d1 = cl(disp).requires_grad_(True)
+        w1, _ = ops.WarpFn.apply(ops.one_hot(l.unsqueeze(1), C), d1); (w1 * cl(go)).sum().backward()
+        d2 = cl(disp).requires_grad_(True)
+        w2 = ops.WarpLabelsFn.apply(l, d2, C); (w2 * cl(go)).sum().backward()
+        check(w2, w1, tol=1e-6, what='label warp fwd'); check(d2.grad, d1.grad, tol=1e-5, what='label warp grad_disp')
