@@ -196,12 +196,14 @@ __device__ __forceinline__ int warp_label_at(const void* lab, int label_bytes, l
     return label_bytes == 1 ? (int)((const unsigned char*)lab)[i] : (int)((const long long*)lab)[i];
 }
 
+template <int VEC>
 __global__ void warp_labels_fwd_kernel(const void* __restrict__ labels, int label_bytes, const float* __restrict__ disp,
                                        float* __restrict__ out, int N, int D, int H, int W, int C) {
-    const long long total = (long long)N * D * H * W * C;
+    const int cq = C / VEC;                                    // lanes per voxel, VEC channels each (16-byte stores for VEC = 4)
+    const long long total = (long long)N * D * H * W * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long long v = i / C;
+        const int c0 = (int)(i % cq) * VEC;
+        const long long v = i / cq;
         long long r = v;
         const int w = (int)(r % W); r /= W;
         const int h = (int)(r % H); r /= H;
@@ -212,17 +214,23 @@ __global__ void warp_labels_fwd_kernel(const void* __restrict__ labels, int labe
         const bool fin = is_finite_coord(gx, gy, gz);
         const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
         const long long sbase = (long long)n * D * H * W;
-        float acc = 0.f;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
             const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
             if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
                 const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
-                if (warp_label_at(labels, label_bytes, sbase + ((long long)z * H + y) * W + x) == c) acc += wgt;
+                const int rel = warp_label_at(labels, label_bytes, sbase + ((long long)z * H + y) * W + x) - c0;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += (rel == j) ? wgt : 0.f;
             }
         }
-        out[i] = acc;
+        float* o = out + v * C + c0;
+        if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else o[0] = acc[0];
     }
 }
 
@@ -325,7 +333,8 @@ extern "C" int da_warp_labels_fwd(const void* labels, int label_bytes, const flo
                                   int N, int D, int H, int W, int C, void* stream) {
     if (!labels || !disp || !out || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (label_bytes != 1 && label_bytes != 8)) return DA_ERR_BADARG;
     const long long total = (long long)N * D * H * W * C;
-    hipLaunchKernelGGL(warp_labels_fwd_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), labels, label_bytes, disp, out, N, D, H, W, C);
+    if (C % 4 == 0) hipLaunchKernelGGL((warp_labels_fwd_kernel<4>), dim3(da_grid(total / 4, 256)), dim3(256), 0, da_stream(stream), labels, label_bytes, disp, out, N, D, H, W, C);
+    else hipLaunchKernelGGL((warp_labels_fwd_kernel<1>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), labels, label_bytes, disp, out, N, D, H, W, C);
     DA_LAUNCH_CHECK();
     return 0;
 }
