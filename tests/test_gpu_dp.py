@@ -1,0 +1,85 @@
+"""GPU, world_size 2 on ONE device (gloo carries the device tensors): the product's data-parallel step -- HIP model, FlatAdam's
+flat gradient bucket, parallel.broadcast_parameters / allreduce_gradients -- against a single-process run that accumulates the two
+per-sample gradients (per-replica BatchNorm statistics).  On the 8-GPU node the same code runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _model_and_data(rank_slice):
+    from oracle import nets
+    from deepatlas_amd.lib.network_factory import unets
+    spec = nets.UNET_TINY
+    sd = nets.closed_form_fill(nets.unet_param_shapes(1, 5, spec['encoders'], spec['decoders']), seed=1)
+    cls = unets.UNet_generator(encoders=spec['encoders'], decoders=spec['decoders'], act='LeakyReLU', maxpool=True, upsample=False, res=False)
+    model = cls(in_channel=1, n_classes=5, bias=True, BN=True)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.to('cuda:0').train()
+    x = nets.closed_form_volume((2, 1, 16, 16, 16), seed=2)[rank_slice].to('cuda:0')
+    y = nets.closed_form_labels((2, 16, 16, 16), 5, seed=3)[rank_slice].to('cuda:0')
+    return model, x, y
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from deepatlas_amd import parallel
+    from deepatlas_amd.optim import FlatAdam
+    from deepatlas_amd.lib.loss import get_loss_function
+    model, x, y = _model_and_data(slice(rank, rank + 1))
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    if rank == 1:                                       # replicas must end up with rank 0's weights
+        opt.flat_p.mul_(1.5)
+    parallel.broadcast_parameters(opt, src=0)
+    crit = get_loss_function('dice')(n_class=5, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    for it in range(2):
+        opt.zero_grad()
+        loss = crit(model(x), y.long())
+        loss.backward()
+        parallel.allreduce_gradients(opt)               # THE collective: one flat fp32 bucket
+        if it == 0:
+            np.save(os.path.join(out_dir, 'g_%d.npy' % rank), opt.flat_g.detach().cpu().numpy())
+        opt.step()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'p_%d.npy' % rank), opt.flat_p.detach().cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_one_gpu_matches_gradient_accumulation(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / 'p_0.npy'), np.load(tmp_path / 'p_1.npy')
+    assert np.array_equal(p0, p1)                       # replicas stay bit-identical
+    g0, g1 = np.load(tmp_path / 'g_0.npy'), np.load(tmp_path / 'g_1.npy')
+    assert np.array_equal(g0, g1)                       # ... and hold the same averaged gradient
+    # single process: the two batch-1 passes (own BatchNorm statistics each), gradients averaged.  Compared on the gradient
+    # bucket: Adam divides by sqrt(v), which turns the rounding noise of analytically-zero gradients (conv biases in front of a
+    # BatchNorm) into lr-sized steps, so parameters after a step are not a meaningful yardstick for the collective.
+    from deepatlas_amd.optim import FlatAdam
+    from deepatlas_amd.lib.loss import get_loss_function
+    model, x, y = _model_and_data(slice(0, 2))
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    crit = get_loss_function('dice')(n_class=5, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    acc = torch.zeros_like(opt.flat_g)
+    bn_state = {k: v.clone() for k, v in model.state_dict().items() if 'running_' in k or 'num_batches' in k}
+    for r in range(world):
+        model.load_state_dict(bn_state, strict=False)                # every replica starts the step from the same BN buffers
+        opt.zero_grad()
+        crit(model(x[r:r + 1]), y[r:r + 1].long()).backward()
+        opt._gather_stray_grads()
+        acc += opt.flat_g
+    ref = (acc / world).detach().cpu().numpy()
+    assert np.max(np.abs(g0 - ref)) <= 1e-6 * np.max(np.abs(ref)), (float(np.max(np.abs(g0 - ref))), float(np.max(np.abs(ref))))
