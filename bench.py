@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='volumes per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
+    ap.add_argument('--profile-all', action='store_true', help='HIP-event timing of dgrad / wgrad calls too (perturbs the two-stream overlap)')
+    ap.add_argument('--sync-wgrad', action='store_true', help='weight gradients on the main stream (default: side stream, overlapped with the HBM-bound backward kernels)')
     ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
                     help="segmentation network of the 'seg' workload; 'UNet' = the fixed 19 M-parameter net (SURVEY.md row f3), not the headline config")
     ap.add_argument('--workload', default='seg', choices=['seg', 'reg', 'joint'],
@@ -92,7 +94,8 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from deepatlas_amd import _native as nat, parallel
+    from deepatlas_amd import _native as nat, parallel, ops
+    ops.enable_async_wgrad(not args.sync_wgrad)
     from deepatlas_amd.lib.network_factory import get_network
     from deepatlas_amd.lib.loss import get_loss_function
     from deepatlas_amd.optim import FlatAdam
@@ -146,7 +149,12 @@ def main():
         step()
     prof = None
     if not args.no_profile:
-        prof = nat.CallProfiler(['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'])
+        # HIP-event timing of the conv calls of the FORWARD pass.  The backward pass runs its weight gradients on a second stream
+        # (ops.ASYNC_WGRAD): timing events recorded on that stream serialise it against the main one (measured: the overlap gain
+        # disappears), and kernels that do overlap time each other's slowdown, so the roofline call is taken where nothing else is
+        # in flight.  --profile-all times all four conv entry points (and costs ~5 % of `value`).
+        names = ['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'] + (['da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'] if args.profile_all else [])
+        prof = nat.CallProfiler(names)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,14 +191,15 @@ def main():
                             kernel='%s%s' % (key[0], list(key[1][:8])), avg_ms=round(ms / ncalls, 4), launches=ncalls,
                             flops_per_launch=fl,
                             traffic_source=None,
-                            all_conv3d=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
-                                            frac_of_step=round(tot_ms / args.steps / ms_per_step, 3)))
+                            profiled_calls=names,
+                            all_profiled=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
+                                              frac_of_step=round(tot_ms / args.steps / ms_per_step, 3)))
         if roofline is not None:
             # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_conv.sh -> tools/pmc_summary.py):
             # FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape
             try:
                 pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-                rec = json.load(open(pj))['calls'].get(roofline['kernel'])
+                rec = json.load(open(pj))['calls'].get(roofline['kernel'].replace('da_conv3d_k3_fwd_bnstats[', 'da_conv3d_k3_fwd['))   # same kernel + per-workgroup BN partials
                 if rec:
                     roofline['traffic'] = rec['traffic_bytes']
                     roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json (algorithmic %d B)' % rec['algorithmic_bytes']

@@ -179,14 +179,15 @@ def require_cuda(*tensors):
 
 
 class _Workspace:
-    """One growing scratch buffer per device; kernels on one stream are ordered, so it is shared by all ops."""
+    """One growing scratch buffer per device and stream; kernels on one stream are ordered, so it is shared by all ops on it."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes, device):
         nbytes = int(nbytes) + 256
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        # one buffer per (device, stream): kernels on one stream are ordered, kernels on different streams are not
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

@@ -95,10 +95,11 @@ __global__ void dice_partial_vec_kernel(const float* __restrict__ src, const voi
 __global__ void dice_partial_gen_kernel(const float* __restrict__ src, const void* __restrict__ labels, int label_bytes,
                                         const float* __restrict__ soft, long long V, int C, int softmax,
                                         double* __restrict__ partial) {
-    extern __shared__ float shf[];   // [3][C] accumulators (LDS float atomics within the block)
+    extern __shared__ float shf[];   // [4 waves][3][C]: every wave owns its accumulators, combined in wave order (deterministic)
     const int n = blockIdx.y;
-    for (int c = threadIdx.x; c < 3 * C; c += blockDim.x) shf[c] = 0.f;
+    for (int c = threadIdx.x; c < 4 * 3 * C; c += blockDim.x) shf[c] = 0.f;
     __syncthreads();
+    float* mine = shf + (threadIdx.x >> 6) * 3 * C;
     const long long vpb = da_cdiv(V, (long long)gridDim.x);
     const long long v0 = (long long)blockIdx.x * vpb;
     long long v1 = v0 + vpb; if (v1 > V) v1 = V;
@@ -120,13 +121,15 @@ __global__ void dice_partial_gen_kernel(const float* __restrict__ src, const voi
             float t = soft ? soft[row * C + c] : (lab == c ? 1.f : 0.f);
             if (!live) { p = 0.f; t = 0.f; }
             const float wI = da_wave_sum(p * t), wS = da_wave_sum(p), wT = da_wave_sum(t);
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&shf[c], wI); atomicAdd(&shf[C + c], wS); atomicAdd(&shf[2 * C + c], wT); }
+            if ((threadIdx.x & 63) == 0) { mine[c] += wI; mine[C + c] += wS; mine[2 * C + c] += wT; }
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double* o = partial + (((size_t)n * gridDim.x + blockIdx.x) * 3) * C;
-        o[c] = shf[c]; o[C + c] = shf[C + c]; o[2 * C + c] = shf[2 * C + c];
+        double a = 0.0, b = 0.0, t = 0.0;
+        for (int w = 0; w < 4; ++w) { a += shf[w * 3 * C + c]; b += shf[w * 3 * C + C + c]; t += shf[w * 3 * C + 2 * C + c]; }
+        o[c] = a; o[C + c] = b; o[2 * C + c] = t;
     }
 }
 
@@ -633,7 +636,7 @@ extern "C" int da_dice_fwd(const float* src, const void* labels, int label_bytes
         hipLaunchKernelGGL(dice_partial_vec_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
                            src, labels, label_bytes, soft_target, V, C, lpv, softmax, partial);
     } else {
-        hipLaunchKernelGGL(dice_partial_gen_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * C * sizeof(float), st,
+        hipLaunchKernelGGL(dice_partial_gen_kernel, dim3(nblocks, N), dim3(256), (size_t)4 * 3 * C * sizeof(float), st,
                            src, labels, label_bytes, soft_target, V, C, softmax, partial);
     }
     DA_LAUNCH_CHECK();

@@ -24,6 +24,7 @@ from ..lib.loss import get_loss_function
 from ..lib.network_factory import get_network
 from ..lib.param_dict import save_dict_to_json
 from ..optim import FlatAdam
+from .. import ops
 from .. import parallel
 
 try:
@@ -94,6 +95,8 @@ class SegmentationExperiment(BaseExperiment):
     def setup_optimizer(self):
         """models/segmentation.py:90-111: Adam + plateau / multiStep / const."""
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.config['learning_rate'])
+        # conv weight gradients on a second stream, accumulated into the optimiser's flat bucket (joined in zero_grad / step)
+        ops.enable_async_wgrad(bool(self.config.get('async_wgrad', True)))
         if self.config['lr_mode'] == 'plateau':
             self.scheduler = lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='max',
                                                             patience=100 // self.config['valid_epoch_period'],

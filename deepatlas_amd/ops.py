@@ -52,6 +52,46 @@ def _labels(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# weight gradients on a side stream
+# ------------------------------------------------------------------------------------------------
+# The 3x3x3 weight-gradient kernels are MFMA-bound and off the critical path of the backward pass: nothing downstream needs dW
+# before the optimiser step.  With ASYNC_WGRAD they run on a second HIP stream and ACCUMULATE straight into `weight.grad` (FlatAdam's
+# flat bucket), so the HBM-bound BatchNorm / activation / pooling backward kernels of the following layers overlap with them
+# instead of queueing behind them.  The consumer of the gradients (FlatAdam.zero_grad / step, parallel.allreduce_gradients) joins
+# the side stream first.  Off by default: plain autograd semantics (p.grad valid on the current stream right after backward()).
+ASYNC_WGRAD = False
+_side_stream = None
+
+
+def enable_async_wgrad(flag=True):
+    global ASYNC_WGRAD
+    ASYNC_WGRAD = bool(flag)
+
+
+def side_stream():
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight gradient issued on the side stream."""
+    if _side_stream is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+
+
+def _async_target(param):
+    """The tensor to accumulate an asynchronous gradient into, or None for the synchronous autograd path."""
+    if not ASYNC_WGRAD or param is None or not isinstance(param, torch.nn.Parameter):
+        return None
+    g = param.grad
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
 # convolutions
 # ------------------------------------------------------------------------------------------------
 class Conv3dK3Fn(Function):
@@ -88,6 +128,7 @@ class Conv3dK3Fn(Function):
              N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
         ctx.dims = (N, D, H, W, C1, C2, Cout, stride, float(act_slope), wsb)
         ctx.has_bias = bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(a1, a2, w_tio, out if act_slope >= 0 else None)
         return ncdhw(out)
 
@@ -108,7 +149,28 @@ class Conv3dK3Fn(Function):
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
             call('da_conv3d_k3_dgrad', ptr(g), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, stride, wp, wn, st)
         dw = db = None
-        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+        gw, gb = _async_target(ctx.wparam), (_async_target(ctx.bparam) if ctx.has_bias else None)
+        if ctx.needs_input_grad[2] and gw is not None and (not ctx.has_bias or gb is not None):
+            side = side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                sst = stream()
+                dw_tio = torch.empty_like(w_tio)
+                dbs = _empty((Cout,), a1) if ctx.has_bias else None
+                swp, swn = _ws(wsb, a1)
+                call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(dbs), N, D, H, W, Cout, stride, swp, swn, sst)
+                dws = torch.empty_like(gw)
+                if ctx.transposed:
+                    call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dws), C1 + C2, Cout, 27, sst)
+                else:
+                    call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
+                gw.add_(dws)
+                if dbs is not None:
+                    gb.add_(dbs)
+            for t in (a1, a2, g, w_tio):
+                if t is not None:
+                    t.record_stream(side)
+        elif ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw_tio = torch.empty_like(w_tio)
             db = _empty((Cout,), a1) if ctx.has_bias else None
             call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(db), N, D, H, W, Cout, stride, wp, wn, st)
@@ -397,6 +459,7 @@ class ConvBNActFn(Function):
         ctx.dims = (N, D, H, W, C1, C2, Cout, wsb)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.wparam = weight
         ctx.save_for_backward(a1, a2, w_tio, y, stats)
         return ncdhw(out)
 
@@ -412,14 +475,34 @@ class ConvBNActFn(Function):
             dx1 = _empty(a1.shape, a1)
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
             call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
-        dw_tio = torch.empty_like(w_tio)
-        call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
-        if ctx.transposed:
-            dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
-            call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
+        gw = _async_target(ctx.wparam)
+        if gw is not None:
+            side = side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                sst = stream()
+                dw_tio = torch.empty_like(w_tio)
+                swp, swn = _ws(wsb, a1)
+                call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, swp, swn, sst)
+                dws = torch.empty_like(gw)
+                if ctx.transposed:
+                    call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dws), C1 + C2, Cout, 27, sst)
+                else:
+                    call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
+                gw.add_(dws)
+            for t in (a1, a2, dy, w_tio):
+                if t is not None:
+                    t.record_stream(side)
+            dw = None
         else:
-            dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
-            call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+            dw_tio = torch.empty_like(w_tio)
+            call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
+            if ctx.transposed:
+                dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
+                call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
+            else:
+                dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
+                call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, dgamma, dbeta,
                 None, None, None, None, None, None) + (None,) * ctx.n_extra
 

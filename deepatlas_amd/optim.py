@@ -8,6 +8,8 @@ state_dict()/load_state_dict() keep torch.optim.Adam's format (per-parameter ste
 """
 import torch
 
+from . import ops
+
 from . import _native as nat
 from ._native import call, ptr, stream
 
@@ -43,12 +45,14 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         """Gradients live in the flat bucket: zero it in one memset and keep the views attached."""
+        ops.join_side_stream()                      # asynchronous weight gradients of the previous step have landed
         self.flat_g.zero_()
         for p, off, k in self._slices:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + k].view(p.shape)
 
     def _gather_stray_grads(self):
+        ops.join_side_stream()                      # weight gradients accumulated on the side stream (ops.ASYNC_WGRAD)
         # autograd may have replaced a .grad view (e.g. first backward after set_to_none); fold it back
         for p, off, k in self._slices:
             if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
