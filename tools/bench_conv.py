@@ -14,7 +14,7 @@ from deepatlas_amd._native import call, ptr, stream, workspace
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--layer', default='32,16,16,2,160,192,160')
-    ap.add_argument('--what', default='fwd,dgrad,wgrad')
+    ap.add_argument('--what', default='fwd,fwdstats,dgrad,wgrad')
     ap.add_argument('--iters', type=int, default=5)
     a = ap.parse_args()
     C1, C2, Cout, N, D, H, W = [int(v) for v in a.layer.split(',')]
@@ -27,6 +27,7 @@ def main():
     out = torch.empty_like(dy)
     dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
     dw = torch.empty_like(w)
+    pbuf = torch.empty((512, 2, Cout), dtype=torch.float64, device=dev)
     wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)
     wp, wn = workspace.get(wsb, dev)
     st = stream()
@@ -35,6 +36,11 @@ def main():
         def run():
             if what == 'fwd':
                 call('da_conv3d_k3_fwd', ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
+            elif what == 'fwdstats':
+                import ctypes
+                npar = ctypes.c_int(0)
+                call('da_conv3d_k3_fwd_bnstats', ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1,
+                     ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st)
             elif what == 'dgrad':
                 call('da_conv3d_k3_dgrad', ptr(dy), ptr(w), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
             else:

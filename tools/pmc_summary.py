@@ -32,6 +32,7 @@ def main():
             v = v[1:] if len(v) > 1 else v          # first launch includes cold allocation effects
             per.setdefault(k, {})[c] = sum(v) / len(v)
     sig = {'conv3_mfma_fwd_kernel<16, 1, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+           'conv3_mfma_fwd_kernel<16, 1, false, true>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
            'conv3_mfma_fwd_kernel<16, 3, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
            'conv3_mfma_wgrad_kernel<16, 1, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     vox = 2 * 160 * 192 * 160
@@ -42,7 +43,7 @@ def main():
         if k not in per:
             continue
         f, w = per[k].get('FETCH_SIZE', 0.0), per[k].get('WRITE_SIZE', 0.0)
-        a = alg[name.split('_')[3].split('[')[0]]
+        a = alg[name.split('_')[3].split('[')[0]]            # 'fwd' also for da_conv3d_k3_fwd_bnstats
         res['calls'][name] = {'kernel': k, 'fetch_bytes': f, 'write_bytes': w, 'traffic_bytes': f + w,
                               'algorithmic_bytes': a, 'traffic_over_algorithmic': (f + w) / a}
     with open(os.path.join(dst, '%s_pmc_traffic.json' % tag), 'w') as fh:
