@@ -61,6 +61,8 @@ def _labels(t):
 # the side stream first.  Off by default: plain autograd semantics (p.grad valid on the current stream right after backward()).
 ASYNC_WGRAD = False
 _side_stream = None
+_side_keep = []          # tensors the side stream still reads: referenced until the join instead of Tensor.record_stream(), whose
+                         # event-polled frees made the caching allocator fall back to hipMalloc on random steps (40 -> 64 ms)
 
 
 def enable_async_wgrad(flag=True):
@@ -79,6 +81,7 @@ def join_side_stream():
     """Make the current stream wait for every weight gradient issued on the side stream."""
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
+        _side_keep.clear()
 
 
 def _async_target(param):
@@ -167,9 +170,7 @@ class Conv3dK3Fn(Function):
                 gw.add_(dws)
                 if dbs is not None:
                     gb.add_(dbs)
-            for t in (a1, a2, g, w_tio):
-                if t is not None:
-                    t.record_stream(side)
+            _side_keep.extend(t for t in (a1, a2, g) if t is not None)
         elif ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw_tio = torch.empty_like(w_tio)
             db = _empty((Cout,), a1) if ctx.has_bias else None
@@ -490,9 +491,7 @@ class ConvBNActFn(Function):
                 else:
                     call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
                 gw.add_(dws)
-            for t in (a1, a2, dy, w_tio):
-                if t is not None:
-                    t.record_stream(side)
+            _side_keep.extend(t for t in (a1, a2, dy) if t is not None)
             dw = None
         else:
             dw_tio = torch.empty_like(w_tio)
