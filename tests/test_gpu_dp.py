@@ -36,9 +36,10 @@ def _worker(rank, world, port, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from deepatlas_amd import parallel
+    from deepatlas_amd import parallel, ops
     from deepatlas_amd.optim import FlatAdam
     from deepatlas_amd.lib.loss import get_loss_function
+    ops.enable_async_wgrad(True)                        # as in bench.py: weight gradients on the side stream, joined before the all-reduce
     model, x, y = _model_and_data(slice(rank, rank + 1))
     opt = FlatAdam(model.parameters(), lr=1e-3)
     if rank == 1:                                       # replicas must end up with rank 0's weights
