@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     auto wb = [&](int chunk, int step, int nn) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
     };
-    constexpr int LB = (NREP == 1) ? 4 : (NREP == 2 ? 2 : 1);   // B lookahead in K-steps
+    constexpr int LB = (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2)
     constexpr int RB = LB + 1;                          // ring slots
     constexpr int TAIL = 5;                             // K-steps at the end of an item without staging loads (they must land before stage_write)
     f32x4 bq[RB][NREP], nb[LB][NREP];
@@ -1145,8 +1145,8 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         return DA_ERR_UNSUPPORTED;
     }
 #define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return launch_fwd_mfma<ck, nr>(p, gy, st)
-    DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3); DA_FWD_CASE(16, 4);
-    DA_FWD_CASE(8, 1); DA_FWD_CASE(8, 2); DA_FWD_CASE(8, 3); DA_FWD_CASE(8, 4);
+    DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3);          // pick_nrep never asks for more than 3 N-tiles
+    DA_FWD_CASE(8, 1); DA_FWD_CASE(8, 2); DA_FWD_CASE(8, 3);
 #undef DA_FWD_CASE
     return DA_ERR_UNSUPPORTED;
 }
