@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Timeline view of a rocprofv3 (rocpd sqlite) kernel trace of a two-stream training step: how much of the wall time has a
+matrix (MFMA conv) kernel in flight, how much only HBM-bound kernels, how much nothing, and which kernels account for the time
+that no matrix kernel covers ("exposed" time).
+Usage: python tools/rocpd_timeline.py x_results.db [--skip-frac 0.3] [--top 25]"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([A-Za-z0-9_:]+(<[^(]*>)?)', name)
+    return (m.group(1) if m else name)[:80]
+
+
+def is_matrix(name):
+    return name.startswith('conv3_mfma_')
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    skip = float(sys.argv[sys.argv.index('--skip-frac') + 1]) if '--skip-frac' in sys.argv else 0.3
+    top = int(sys.argv[sys.argv.index('--top') + 1]) if '--top' in sys.argv else 25
+    rows = db.execute("select name, start, end, queue_id from kernels order by start").fetchall()
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo = t0 + (t1 - t0) * skip                      # drop warm-up at the head of the trace
+    adam = [e for n, s, e, q in rows if 'adam_kernel' in n]
+    nsteps = 0
+    if len(adam) >= 3:                               # steady state: from the end of an optimiser launch to the end of the last one
+        k = max(1, len(adam) // 2)
+        lo, t1, nsteps = adam[-k - 1], adam[-1], k
+    rows = [(short(n), max(s, lo), min(e, t1), q) for n, s, e, q in rows if e > lo and s < t1]
+    ev = []                                          # sweep line over [start, end) of every kernel
+    for i, (n, s, e, q) in enumerate(rows):
+        ev.append((s, 1, i)); ev.append((e, 0, i))
+    ev.sort()
+    active = set(); nm = 0
+    prev = lo
+    tm = tn = ti = 0
+    exposed = defaultdict(float)
+    for t, kind, i in ev:
+        dt = t - prev
+        if dt > 0:
+            if nm > 0: tm += dt
+            elif active:
+                tn += dt
+                for j in active: exposed[rows[j][0]] += dt / len(active)
+            else: ti += dt
+        prev = t
+        if kind == 1:
+            active.add(i); nm += is_matrix(rows[i][0])
+        else:
+            active.discard(i); nm -= is_matrix(rows[i][0])
+    wall = prev - lo
+    print('# %s: window %.3f ms = %d steps, queues %s' % (sys.argv[1], wall / 1e6, nsteps, sorted(set(r[3] for r in rows))))
+    if nsteps:
+        wall_step = wall / nsteps
+        print('per step: %.3f ms' % (wall_step / 1e6))
+    print('matrix kernel in flight      %8.3f ms  %5.1f %%' % (tm / 1e6, 100 * tm / wall))
+    print('only other kernels in flight %8.3f ms  %5.1f %%' % (tn / 1e6, 100 * tn / wall))
+    print('nothing in flight            %8.3f ms  %5.1f %%' % (ti / 1e6, 100 * ti / wall))
+    print('exposed time by kernel (no matrix kernel running beside it):')
+    for k, v in sorted(exposed.items(), key=lambda kv: -kv[1])[:top]:
+        print('  %-80s %8.3f ms  %5.1f %%' % (k, v / 1e6, 100 * v / wall))
+
+
+if __name__ == '__main__':
+    main()
