@@ -886,26 +886,29 @@ __global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
     // Operands come through buffer descriptors with 32-bit byte offsets (out-of-range lane -> 0xFFFFFFFF -> 0): no
     // exec-mask branches, so the MT + NT loads of a K-step issue back to back, and the next step's loads are in flight
     // while this step's MFMAs issue.
-    const unsigned long long vol = (unsigned long long)p.N * p.D * p.H * p.W;
-    const __amdgpu_buffer_rsrc_t r1 = da_rsrc(p.in1, (unsigned)(vol * p.C1 * 4ull));
-    const __amdgpu_buffer_rsrc_t r2 = da_rsrc(p.C2 > 0 ? p.in2 : p.in1, (unsigned)(vol * (p.C2 > 0 ? p.C2 : p.C1) * 4ull));
+    // Descriptors are per SAMPLE (rebuilt when the wave's row moves to another sample), so only one sample has to fit 32 bits.
+    const unsigned long long vol = (unsigned long long)p.D * p.H * p.W;
     const int Cd2 = p.Cout - p.Cd1;
-    const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy, (unsigned)(vol * p.Cd1 * 4ull));
-    const __amdgpu_buffer_rsrc_t ry2 = da_rsrc(Cd2 > 0 ? p.dyb : p.dy, (unsigned)(vol * (Cd2 > 0 ? Cd2 : p.Cd1) * 4ull));
     bool from2[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) from2[mt] = (src[mt] == p.in2) && p.C2 > 0;
     const long long wave_id = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
     for (long long row = wave_id; row < p.nrows; row += nwaves) {
-        const int y = (int)(row % p.H); const int z = (int)((row / p.H) % p.D); const int n = (int)(row / ((long long)p.H * p.D));
+        const int y = (int)(row % p.H); const int z = (int)((row / p.H) % p.D);
+        const int n = __builtin_amdgcn_readfirstlane((int)(row / ((long long)p.H * p.D)));
+        const __amdgpu_buffer_rsrc_t r1 = da_rsrc(p.in1 + (size_t)n * vol * p.C1, (unsigned)(vol * p.C1 * 4ull));
+        const __amdgpu_buffer_rsrc_t r2 = da_rsrc(p.C2 > 0 ? p.in2 + (size_t)n * vol * p.C2 : p.in1, (unsigned)(vol * (p.C2 > 0 ? p.C2 : p.C1) * 4ull));
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (size_t)n * vol * p.Cd1, (unsigned)(vol * p.Cd1 * 4ull));
+        const __amdgpu_buffer_rsrc_t ry2 = da_rsrc(Cd2 > 0 ? p.dyb + (size_t)n * vol * Cd2 : p.dy, (unsigned)(vol * (Cd2 > 0 ? Cd2 : p.Cd1) * 4ull));
         unsigned rbase[MT]; bool rval[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int zz = z + dz[mt], yy = y + dy_[mt];
             rval[mt] = mval[mt] && zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
-            rbase[mt] = (unsigned)((((((long long)n * p.D + (rval[mt] ? zz : 0)) * p.H + (rval[mt] ? yy : 0)) * p.W) * cs[mt] + cc[mt]) * 4);
+            rbase[mt] = (unsigned)((((((long long)(rval[mt] ? zz : 0)) * p.H + (rval[mt] ? yy : 0)) * p.W) * cs[mt] + cc[mt]) * 4);
         }
-        const unsigned gbase = (unsigned)((row * p.W) * p.Cd1 * 4), gbase2 = (unsigned)((row * p.W) * Cd2 * 4);
+        const long long srow = (long long)z * p.H + y;                 // row within the sample
+        const unsigned gbase = (unsigned)((srow * p.W) * p.Cd1 * 4), gbase2 = (unsigned)((srow * p.W) * Cd2 * 4);
         auto fetch = [&](int x0, float* a, float* b) {
             const int x = x0 + g;
 #pragma unroll
@@ -1238,7 +1241,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (smallcin_ok(C1, C2, Cout, stride)) {
         const int Cin = C1 + C2, O = 27 * Cin * Cout;
         if (ws_bytes < (size_t)kScBlocks * O * sizeof(float)) return DA_ERR_WS_SMALL;
-        if ((unsigned long long)N * D * H * W * (Cout > Cin ? Cout : Cin) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+        if ((unsigned long long)D * H * W * (Cout > Cin ? Cout : Cin) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
         ScP sp;
         sp.in1 = in1; sp.in2 = in2; sp.C1 = C1; sp.C2 = C2; sp.dy = dy; sp.partial = (float*)ws;
         sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.Cout = Cout; sp.nrows = (long long)N * D * H; sp.dyb = nullptr; sp.Cd1 = Cout;
@@ -1252,7 +1255,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         { const int rc2 = da_reduce_partials(sp.partial, nb, O, dw_tio, st); if (rc2) return rc2; }
         return 0;
     }
-    if (stride == 1 && s2d_cin == 0 && Cout <= 4 && C1 + C2 <= 32 && (unsigned long long)N * D * H * W * (C1 > C2 ? C1 : C2) * 4ull < 0xFFFFFFF0ull) {
+    if (stride == 1 && s2d_cin == 0 && Cout <= 4 && C1 + C2 <= 32 && (unsigned long long)D * H * W * (C1 > C2 ? C1 : C2) * 4ull < 0xFFFFFFF0ull) {
         // Very few OUTPUT channels (the 24 -> 3 flow conv, voxel_morph.py:57): swap the operands.  dW[tap][ci][co] =
         // sum_u dy[u - tap][co] x[u][ci] is the small-Cin weight gradient of a conv with "input" dy (Cout channels), "output
         // gradient" x (Cin channels, possibly two tensors) and the taps mirrored; 27*Cout <= 108 rows instead of an MFMA N-tile

@@ -220,21 +220,29 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
 #pragma unroll
     for (int t = 0; t < TPB; ++t) toffs[t] = p.up ? tapoff(t0 + t, p.H, p.W) : 0;
 
-    const long long v0 = ((long long)blockIdx.x * 4 + wave) * p.vox_per_wave;
+    const long long vblk = (long long)blockIdx.x * 4 * p.vox_per_wave;      // first voxel of this workgroup
+    const long long v0 = vblk + (long long)wave * p.vox_per_wave;
     long long v1 = v0 + p.vox_per_wave; if (v1 > p.M) v1 = p.M;
     // Branch-free operand fetch: both tensors are addressed through buffer descriptors with 32-bit byte offsets; a lane
     // past the end gets offset 0xFFFFFFFF (hardware returns 0).  All CIT + TPB*COT loads of a K-step are issued back to
     // back and the NEXT step's loads are in flight while the current step's MFMAs issue (hipcc otherwise emits
     // load -> s_waitcnt vmcnt(0) -> 4 MFMAs per tap, i.e. eight exposed memory round trips per step).
+    // The descriptors are based at this WORKGROUP's first voxel (for the up-sampler's dy: at the first fine voxel of the
+    // coarse d-slice that voxel lies in), so the 32-bit offsets only span one workgroup's share and tensors of any size work.
     const unsigned fine_mult = p.up ? 8u : 1u;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((unsigned long long)p.M * p.ldi * 4ull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)((unsigned long long)p.M * fine_mult * p.ldy * 4ull), 0x00020000);
-    // this lane's voxel (v0 + g, then += 4 per K-step) tracked as (w, h, rest = n*D + d) with carries
+    const long long slice0 = p.up ? vblk / ((long long)p.H * p.W) : 0;          // n*D + d of the first voxel
+    const long long fbase = p.up ? slice0 * 2 * (2ll * p.H) * (2ll * p.W) : vblk;   // first dy voxel the descriptor covers
+    auto clip32 = [](unsigned long long b) -> unsigned { return b > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)b; };
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + vblk * p.ldi), 0,
+                                           clip32((unsigned long long)(p.M - vblk) * p.ldi * 4ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + fbase * p.ldy), 0,
+                                           clip32((unsigned long long)(p.M * fine_mult - fbase) * p.ldy * 4ull), 0x00020000);
+    // this lane's voxel (v0 + g, then += 4 per K-step) tracked as (w, h, rest = n*D + d - slice0) with carries
     int cw = 0, chh = 0; long long crest = 0;
     if (p.up) {
         const long long vs = v0 + g;
         cw = (int)(vs % p.W); const long long r1 = vs / p.W;
-        chh = (int)(r1 % p.H); crest = r1 / p.H;
+        chh = (int)(r1 % p.H); crest = r1 / p.H - slice0;
     }
     unsigned toffb[TPB];
 #pragma unroll
@@ -242,11 +250,11 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     auto fetch = [&](long long vb, float* av, float (*bv)[COT]) {
         const long long v = vb + g;
         const bool ok = v < v1;
-        const unsigned offa = ok ? (unsigned)((v * p.ldi + i) * 4) : 0xFFFFFFFFu;
+        const unsigned offa = ok ? (unsigned)(((v - vblk) * p.ldi + i) * 4) : 0xFFFFFFFFu;
 #pragma unroll
         for (int a = 0; a < CIT; ++a)
             av[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? offa + 64u * a : 0xFFFFFFFFu, 0, 0));
-        long long fv = v;
+        long long fv = v - vblk;
         if (p.up) {
             fv = ((crest * 2) * (2 * p.H) + 2 * chh) * (long long)(2 * p.W) + 2 * cw;
             cw += 4;
@@ -417,7 +425,6 @@ static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
                 int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!da_pw_supported(Cin, Cout) || (ntaps != 1 && ntaps != 8)) return DA_ERR_UNSUPPORTED;
-    if ((unsigned long long)M * (up ? 8 : 1) * Cout * 4ull >= 0xFFFFFFF0ull || (unsigned long long)M * Cin * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_pw_wgrad_ws_bytes(M, ntaps, Cin, Cout)) return DA_ERR_WS_SMALL;
     if (Cin <= 64 && Cout <= 64) return pw_wgrad_slice(in, dy, dw, M, D, H, W, Cin, Cout, Cin, Cout, ntaps, up, ws, st);
     // wide layers: independent 64 x 64 channel slices, each reduced into a dense scratch and placed into dW

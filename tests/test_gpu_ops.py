@@ -381,6 +381,38 @@ def test_full_size_dice_of_identical_onehots_and_counts():
     assert int(counts[0, :, 0].sum()) == lab.numel() and torch.equal(counts[0, :, 0], counts[0, :, 2])
 
 
+def test_large_batch_transposed_conv_and_head_beyond_4gib():
+    """Batch 8 at 160x192x160: the 32 -> 32 up-sampler's output and the 32-class logits are 5 GB each, past 32-bit byte offsets.
+    Additivity over the batch axis: weight / bias gradients of the whole batch = sum over the two half batches, and the forward /
+    data gradient of a half equals the matching half of the whole (same kernels, no CPU reference needed at this size)."""
+    from deepatlas_amd import ops
+    gen = torch.Generator().manual_seed(7)
+    def r(shape, scale=1.0):
+        return ((torch.rand(shape, generator=gen) * 2 - 1) * scale).to(dev())
+    def run(fn, x, w, b, go):
+        xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = fn(xg, wg, bg)
+        y.backward(go)
+        return y.detach(), xg.grad, wg.grad, bg.grad
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    for name, fn, xs, ws, gs in [
+            ('deconv', ops.DeconvK2S2Fn.apply, (8, 80, 96, 80, 32), (32, 32, 2, 2, 2), (8, 160, 192, 160, 32)),
+            ('head', ops.Conv1x1Fn.apply, (8, 160, 192, 160, 16), (32, 16, 1, 1, 1), (8, 160, 192, 160, 32))]:
+        x, w, b = r(xs).permute(0, 4, 1, 2, 3), r(ws, 0.2), r((32,), 0.1)
+        go = r(gs).permute(0, 4, 1, 2, 3)
+        assert go.numel() * 4 > 2 ** 32
+        y, dx, dw, db = run(fn, x, w, b, go)
+        ya, dxa, dwa, dba = run(fn, x[:4], w, b, go[:4])
+        yb, dxb, dwb, dbb = run(fn, x[4:], w, b, go[4:])
+        assert torch.equal(y[:4], ya) and torch.equal(y[4:], yb), name
+        assert torch.equal(dx[:4], dxa) and torch.equal(dx[4:], dxb), name
+        assert rel(dw, dwa + dwb) < 1e-5, (name, rel(dw, dwa + dwb))
+        assert rel(db, dba + dbb) < 1e-5, (name, rel(db, dba + dbb))
+        del x, go, y, dx, ya, yb, dxa, dxb
+        torch.cuda.empty_cache()
+
+
 def test_full_size_conv_linearity_and_adjointness():
     """Full BASELINE size (batch 1, 160x192x160), the dominant layer 48 -> 16 (two-pointer 32 + 16 input) on the MFMA path:
     linearity conv(a x + b y) = a conv(x) + b conv(y) and the adjoint identities  <conv(x), g> = <x, dgrad(g)> = <w, wgrad(x, g)>
