@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -39,6 +40,16 @@ def conv_flops(key):
         return 0
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     return 2.0 * 27 * (C1 + C2) * Cout * N * Do * Ho * Wo
+
+
+def conv_bytes(key):
+    """Algorithmic HBM bytes of one da_conv3d_k3_fwd* call: the input read once + the output written once, fp32 (weights are KBs)."""
+    name, a = key
+    if name not in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'):
+        return 0
+    C1, C2, N, D, H, W, Cout, stride = a[:8]
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    return 4.0 * N * ((C1 + C2) * D * H * W + Cout * Do * Ho * Wo)
 
 
 def cpu_baseline(shape, batch, n_classes, budget_s=20.0):
@@ -76,6 +87,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
     ap.add_argument('--profile-all', action='store_true', help='HIP-event timing of dgrad / wgrad calls too (perturbs the two-stream overlap)')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help="matrix arithmetic of the 3x3x3 convolutions: 'fp32' = the reference's arithmetic (the headline metric); 'bf16' = "
+                         "bf16 operands, fp32 accumulate, fp32 tensors (BASELINE configs[4]'s mixed precision; not the headline)")
     ap.add_argument('--sync-wgrad', action='store_true', help='weight gradients on the main stream (default: side stream, overlapped with the HBM-bound backward kernels)')
     ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
                     help="segmentation network of the 'seg' workload; 'UNet' = the fixed 19 M-parameter net (SURVEY.md row f3), not the headline config")
@@ -96,6 +110,7 @@ def main():
 
     from deepatlas_amd import _native as nat, parallel, ops
     ops.enable_async_wgrad(not args.sync_wgrad)
+    ops.set_matrix_precision(args.precision)
     from deepatlas_amd.lib.network_factory import get_network
     from deepatlas_amd.lib.loss import get_loss_function
     from deepatlas_amd.optim import FlatAdam
@@ -126,6 +141,8 @@ def main():
     workload_name = ('seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (BASELINE configs[1])' if args.net == 'UNet_light'
                      else 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (SURVEY row f3, not a BASELINE config)') % (
         args.batch, shape[0], shape[1], shape[2])
+    if args.precision == 'bf16':
+        workload_name = workload_name.replace('fp32 (', 'bf16 matrix mode (').replace('BASELINE configs[1]', "BASELINE configs[1] shape with configs[4]'s precision")
     if args.workload in ('reg', 'joint'):
         from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
         reg = get_network('voxel_morph_cvpr')()
@@ -186,15 +203,20 @@ def main():
             achieved = fl * ncalls / (ms * 1e-3) / 1e12
             tot_fl = sum(conv_flops(k) * v[0] for k, v in summ.items())
             tot_ms = sum(v[1] for v in summ.values())
-            roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+            if args.precision == 'bf16':     # bf16 matrix mode: the convolutions are no longer matrix-bound -> price the call against HBM
+                gbs = conv_bytes(key) * ncalls / (ms * 1e-3) / 1e9
+                rl_head = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
+            else:
+                rl_head = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                               frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None)
+            roofline = dict(rl_head,
                             kernel='%s%s' % (key[0], list(key[1][:8])), avg_ms=round(ms / ncalls, 4), launches=ncalls,
                             flops_per_launch=fl,
                             traffic_source=None,
                             profiled_calls=names,
                             all_profiled=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
                                               frac_of_step=round(tot_ms / args.steps / ms_per_step, 3)))
-        if roofline is not None:
+        if roofline is not None and args.precision == 'fp32':
             # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_conv.sh -> tools/pmc_summary.py):
             # FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape
             try:
@@ -207,10 +229,10 @@ def main():
                 pass
         line = dict(metric='training volumes/sec at 160x192x160 fp32; Dice vs CPU ref', value=round(value, 4), unit='volumes/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32' if args.precision == 'fp32' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
                     config=dict(workload=workload_name,
                                 global_batch=world * units_per_step, volume=list(shape), n_classes=n_classes,
-                                parallelism='dp%d' % world, final_loss=round(final_loss, 6)),
+                                parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision),
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'seg':
             line['cpu_baseline'] = cpu_baseline(shape, args.batch, n_classes)

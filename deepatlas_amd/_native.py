@@ -35,6 +35,7 @@ SIGNATURES = {
     'da_conv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, I, P, SZ, P]),
     'da_conv3d_k3_wgrad': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_set_conv_direct': (I, [I]),
+    'da_set_matrix_bf16': (I, [I]),
     'da_pointwise_ws_bytes': (SZ, [I, I, I]),
     'da_conv1x1_fwd': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
     'da_conv1x1_dgrad': (I, [P, P, P, LL, I, I, P, SZ, P]),

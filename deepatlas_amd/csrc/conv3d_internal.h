@@ -9,6 +9,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
 // forward-shaped implicit GEMM.  in = concat(in1[C1], in2[C2]); output channels [0,Cs1) -> out1, rest -> out2.
 // w_is_flipped_tr != 0: `w_tio` is the ORIGINAL layer's [27][Cout][C1] tensor and the kernel runs the data-gradient
 // convolution (taps flipped, channels transposed) -- i.e. logical Cin = C1, logical Cout = `Cout`.
+bool da_matrix_bf16();                 // bf16 matrix mode switch (da_set_matrix_bf16)
 bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1 = -1, int Cs2 = 0);   // Cs1/Cs2: output split (dgrad of a concat conv)
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,

@@ -21,6 +21,8 @@
 #include "conv3d_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));      // four bf16 (the A / B fragment of v_mfma_f32_16x16x16_bf16)
+#include <type_traits>
 #ifndef DA_PIN
 #define DA_PIN 1   // pin the m-outer MFMA order (keeps hipcc from chaining 4 dependent MFMAs on one accumulator)
 #endif
@@ -85,13 +87,22 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
     }
 }
 
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
+__device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+// BF: the LDS image holds bf16 (same [voxel][CK] order, 8 bytes per channel quad): converted once here instead of at every tap
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false>
 __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
     constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
         const int idx = threadIdx.x + it * 256;
-        if (idx < TOTAL) reinterpret_cast<float4*>(lds)[idx] = pre[it - IT0];
+        if (idx < TOTAL) {
+            if constexpr (BF) {
+                const float4 v = pre[it - IT0];
+                reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
+            } else reinterpret_cast<float4*>(lds)[idx] = pre[it - IT0];
+        }
     }
 }
 
@@ -187,9 +198,15 @@ struct FwdP {
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums
+// BF: bf16 matrix mode (da_set_matrix_bf16): tensors stay fp32 in HBM, the staged tile and the packed weights are bf16 and one
+// v_mfma_f32_16x16x16_bf16 (fp32 accumulate) replaces the four v_mfma_f32_16x16x4_f32 of a K-step -- same lane <-> (voxel, cin)
+// mapping, so everything around the K loop is shared.  The kernel is then bound by HBM / LDS instead of the matrix pipe.
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    using AElem = std::conditional_t<BF, short, float>;
+    using Frag = std::conditional_t<BF, s16x4, f32x4>;          // A / B fragment: 4 consecutive cin of one voxel / one cout
+    constexpr int EB = BF ? 2 : 4;                               // bytes per staged element
     constexpr int TZ = 4, HZ = TZ + 2;
     constexpr int NSTEPS = (27 * CK + 15) / 16;          // 27 (CK = 16) | 14 (CK = 8: two taps per K-step)
     constexpr int NIT = StageGeom<CK, HZ>::NIT;
@@ -231,9 +248,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const float* src = (cbase < p.C1) ? p.in1 : p.in2;
             const int Cs = (cbase < p.C1) ? p.C1 : p.C2, choff = (cbase < p.C1) ? cbase : cbase - p.C1;
             constexpr int R = NIT - PRE, B1 = PRE + (R + 2) / 3, B2 = PRE + 2 * ((R + 2) / 3) < NIT ? PRE + 2 * ((R + 2) / 3) : NIT;
-            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1>(lds, tmp); }
-            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2>(lds, tmp); }
-            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT>(lds, tmp); }
+            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF>(lds, tmp); }
+            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF>(lds, tmp); }
+            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF>(lds, tmp); }
         }
     };
 
@@ -252,7 +269,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // DOUBLE accumulators held by the first NREP*16 threads (wave shuffles over q/g, then the 4 waves through a 2 KiB LDS
     // strip behind the tile; everything past the per-lane sums is double), so E[x^2] - mean^2 keeps the accuracy of the stand-alone statistics pass.
     double dsum1 = 0.0, dsum2 = 0.0;
-    double* sred = reinterpret_cast<double*>(lds + StageGeom<CK, HZ>::TOTAL * 4);      // [wave][2][NREP*16] doubles
+    double* sred = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB);      // [wave][2][NREP*16] doubles
     int tiles_done = 0;
     auto stats_flush = [&]() {
         if constexpr (STATS) {
@@ -283,13 +300,13 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     };
     float4 pre[PRE > 0 ? PRE : 1];
     issue_stage(0, pre);
-    stage_write<CK, HZ, 0, PRE>(lds, pre);
+    stage_write<CK, HZ, 0, PRE, BF>(lds, pre);
     stage_rest(0);
     __syncthreads();
 
     // K-step s: lane group g supplies (tap, cin quad) = CK16: (s, g) | CK8: (2s + (g>>1), g&1).
-    const float* abase = (CK == 16) ? lds + ((wave * HY) * HX + i) * CK + g * 4
-                                    : lds + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
+    const AElem* abase = (CK == 16) ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + g * 4
+                                    : reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
     const bool hi = (g >> 1) != 0;
     auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
     auto a_off8 = [&](int s) -> int {                                                              // CK8: two taps per step
@@ -306,14 +323,20 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // before this item's epilogue stores); (2) the next item's staging loads are spread over the K-steps, at most one per step;
     // (3) nothing that touches vector memory sits inside a branch: invalid work (no next item, not the last chunk, ragged
     // lanes) is expressed as out-of-range buffer offsets, so hipcc's s_waitcnt vmcnt(N) stay exact instead of collapsing to 0.
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * 1024), 0x00020000);
-    auto wb = [&](int chunk, int step, int nn) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * 256 * EB), 0x00020000);
+    auto wb = [&](int chunk, int step, int nn) -> Frag {
+        if constexpr (BF) return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rsw, (unsigned)lane * 8u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 512), 0));
+        else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
+    };
+    // one K-step of one (M-tile, N-tile) pair
+    auto mma_bf = [&](f32x4 c, const Frag& a, const Frag& b) -> f32x4 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+        else return c;
     };
     constexpr int LB = (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2)
     constexpr int RB = LB + 1;                          // ring slots
     constexpr int TAIL = 5;                             // K-steps at the end of an item without staging loads (they must land before stage_write)
-    f32x4 bq[RB][NREP], nb[LB][NREP];
+    Frag bq[RB][NREP], nb[LB][NREP];
     if constexpr (!MASKED) {
 #pragma unroll
         for (int t = 0; t < LB; ++t)
@@ -338,17 +361,23 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         if constexpr (MASKED) {
             // sparse tap set (a stride-2 conv expressed as a stride-1 conv over the space-to-depth input: a channel chunk
             // belongs to one input parity and only (1|2)^3 of the 27 taps are non-zero).  Staging-bound, so a plain loop.
-            const f32x4* wch = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
+            const Frag* wch = reinterpret_cast<const Frag*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
             if (has_next && !(p.ablate & 1)) issue_stage(item + 1, pre);
             unsigned msk = p.masks[p.maskmode == 1 ? ch : (int)blockIdx.y];
             while (msk) {
                 const int sidx = __builtin_ctz(msk); msk &= msk - 1;
-                const float* ap = abase + (((sidx / 9) * HY + (sidx / 3) % 3) * HX + sidx % 3) * CK;
-                f32x4 bb[NREP], aa[TY];
+                const AElem* ap = abase + (((sidx / 9) * HY + (sidx / 3) % 3) * HX + sidx % 3) * CK;
+                Frag bb[NREP], aa[TY];
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bb[nn] = wch[((size_t)sidx * p.NT + nn) * 64];
 #pragma unroll
-                for (int r = 0; r < TY; ++r) aa[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
+                for (int r = 0; r < TY; ++r) aa[r] = *reinterpret_cast<const Frag*>(ap + r * (HX * CK));
+                if constexpr (BF) {
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                        for (int r = 0; r < TY; ++r) acc[r][nn] = mma_bf(acc[r][nn], aa[r], bb[nn]);
+                } else {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -356,6 +385,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                         for (int r = 0; r < TY; ++r)
                             acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r][m], bb[nn][m], acc[r][nn], 0, 0, 0);
+                }
             }
         } else {
         // CK = 16: 27 K-steps; CK = 8: 14 (two taps per step), fully unrolled.  Each K-step is split into two half-steps of 4
@@ -364,7 +394,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         // MFMA order: component m outermost, M-tile r innermost -> 4*NREP independent accumulators between two uses of the
         // same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
         constexpr int HALF = TY / 2;
-        auto step_ptr = [&](int s) -> const float* { return (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
+        auto step_ptr = [&](int s) -> const AElem* { return (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
         const int ch_next = (ch + 1 == nchunks) ? 0 : ch + 1;
 #pragma unroll
         for (int t = 0; t < LB; ++t)
@@ -379,11 +409,11 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             cur.init(first ? p.in1 : p.in2, first ? p.C1 : p.C2, first ? cbase : cbase - p.C1, n2, z2, y2, x2, p.D, p.H, p.W,
                      has_next && !(p.ablate & 1));
         }
-        f32x4 A0[HALF], A1[HALF];
+        Frag A0[HALF], A1[HALF];
         {
-            const float* ap = step_ptr(0);
+            const AElem* ap = step_ptr(0);
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(ap + r * (HX * CK));
+            for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const Frag*>(ap + r * (HX * CK));
         }
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
@@ -397,9 +427,15 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
             for (int j = 0; j < PRE; ++j)
                 if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) pre[j] = cur.next();
-            const float* ap = step_ptr(s);
+            const AElem* ap = step_ptr(s);
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const f32x4*>(ap + (HALF + r) * (HX * CK));
+            for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const Frag*>(ap + (HALF + r) * (HX * CK));
+            if constexpr (BF) {
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                    for (int r = 0; r < HALF; ++r) acc[r][nn] = mma_bf(acc[r][nn], A0[r], bq[s % RB][nn]);
+            } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -409,11 +445,18 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                         acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bq[s % RB][nn][m], acc[r][nn], 0, 0, 0);
                 if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
             }
-            {   // first half of the next K-step (the last step re-reads its own, harmlessly)
-                const float* an = (s + 1 < NSTEPS) ? step_ptr(s + 1) : ap;
-#pragma unroll
-                for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const f32x4*>(an + r * (HX * CK));
             }
+            {   // first half of the next K-step (the last step re-reads its own, harmlessly)
+                const AElem* an = (s + 1 < NSTEPS) ? step_ptr(s + 1) : ap;
+#pragma unroll
+                for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const Frag*>(an + r * (HX * CK));
+            }
+            if constexpr (BF) {
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                    for (int r = 0; r < HALF; ++r) acc[HALF + r][nn] = mma_bf(acc[HALF + r][nn], A1[r], bq[s % RB][nn]);
+            } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -422,6 +465,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                     for (int r = 0; r < HALF; ++r)
                         acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bq[s % RB][nn][m], acc[HALF + r][nn], 0, 0, 0);
                 if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
+            }
             }
         }
         }
@@ -496,7 +540,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         if (STATS && last && ((++tiles_done) & 1) == 0) stats_flush();
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
-            stage_write<CK, HZ, 0, PRE>(lds, pre);
+            stage_write<CK, HZ, 0, PRE, BF>(lds, pre);
             stage_rest(item + 1);
             __syncthreads();
         }
@@ -654,7 +698,7 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
 
 // packed B operand: wp[chunk][step][ntile][lane][m]
 __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
-                                        int CK, int NSTEPS, int NTpad, int flipped, long long total) {
+                                        int CK, int NSTEPS, int NTpad, int flipped, long long total, int bf) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx & 3); const int lane = (int)((idx >> 2) & 63);
         long long rest = idx >> 8;
@@ -667,7 +711,8 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
         float v = 0.f;
         if (tap < 27 && cout < Cout && cin < Cin)
             v = flipped ? w[((size_t)(26 - tap) * Cout + cout) * Cin + cin] : w[((size_t)tap * Cin + cin) * Cout + cout];
-        wp[idx] = v;
+        if (bf) reinterpret_cast<unsigned short*>(wp)[idx] = __builtin_bit_cast(unsigned short, (__bf16)v);      // same [..][lane][m] order, 2 bytes each
+        else wp[idx] = v;
     }
 }
 
@@ -681,15 +726,20 @@ struct WgP {
     unsigned masks[16]; int maskmode;   // per channel chunk tap masks (0 = all taps)
 };
 
-template <int CK, int NREP, bool YS = false, bool MASKED = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets
+// BF (bf16 matrix mode): both LDS tiles hold bf16 and one v_mfma_f32_16x16x16_bf16 consumes a whole row of 16 voxels (K = 16).
+// Its fragments need 4 consecutive VOXELS of one channel per lane while the tiles are channel-contiguous, which is exactly
+// what ds_read_b64_tr_b16 delivers: in each 16-lane group lane s supplies the address of (voxel 4g + s/4, channel quad s%4)
+// and receives (voxels 4g .. 4g+3, channel s) -- checked in tools/ubench/ds_read_tr16.hip.
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets
 __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(!(BF && YS), "bf16 mode stages dY in channel quads");
     constexpr int TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
     constexpr int CG = NREP * 16;
     constexpr int TPW = (CK == 16) ? 7 : 4;                     // tap slots per wave (CK = 8: tap PAIRS, 14 in total)
-    constexpr bool SWZ = (CG % 32) == 0;
+    constexpr bool SWZ = !BF && (CG % 32) == 0;
     float* ldsA = lds;
-    float* ldsY = lds + HZ * HY * HX * CK;
+    float* ldsY = BF ? lds + HZ * HY * HX * CK / 2 : lds + HZ * HY * HX * CK;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -704,8 +754,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     for (int k = 0; k < TPW; ++k) {
         int tap;
         if (CK == 16) tap = wave + 4 * k; else tap = 2 * (wave + 4 * k) + (i >> 3);
+        if (BF && CK == 8) tap = 2 * (wave + 4 * k) + ((i & 3) >> 1);      // transpose-read source lane: channel quad i & 3 of the 16 (tap, ci) rows
         if (tap > 26) tap = 26;                               // garbage slot, never written out
-        offA[k] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK + ((CK == 16) ? i : (i & 7));
+        if (BF) offA[k] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK + ((CK == 16) ? (i & 3) * 4 : (i & 1) * 4);
+        else offA[k] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK + ((CK == 16) ? i : (i & 7));
     }
     f32x4 acc[TPW][NREP];
 #pragma unroll
@@ -758,7 +810,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         }
     };
     auto write_lds = [&]() {
-        stage_write<CK, HZ>(ldsA, preA);
+        stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA);
         // dY tile [TVOX][CG] (channel halves XOR-swizzled by voxel parity when CG % 32 == 0)
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
@@ -766,7 +818,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             const int c4 = idx % QY; const int v = idx / QY;
             int c = c4 * 4;
             if (SWZ) c ^= (v & 1) << 4;
-            if (idx < TVOX * QY) *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
+            if (idx < TVOX * QY) {
+                if constexpr (BF) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));   // linear [v][CG] in bf16
+                else *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
+            }
         }
     };
     if (tile_begin < tile_end) { issue_loads(tile_begin); write_lds(); }
@@ -779,6 +834,30 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         // steps use compile-time offsets (ds_read immediates), so the VALU work per 28*NREP MFMAs is a handful of adds.
         // Fragments of step j+1 are read while the MFMAs of step j issue (hipcc otherwise serialises read->wait->mfma).
         const int swz = SWZ ? ((g & 1) << 4) : 0;             // voxel parity == g & 1 (row base and 4*j are even)
+        if constexpr (BF) {
+            typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+            const short* ldsAh = reinterpret_cast<const short*>(ldsA);
+            const short* ldsYh = reinterpret_cast<const short*>(ldsY);
+#pragma unroll 2
+            for (int row = 0; row < TVOX / 16; ++row) {
+                const int vz = row >> 3, vy = row & 7;
+                const short* arow = ldsAh + ((vz * HY + vy) * HX + 4 * g + (i >> 2)) * CK;
+                const short* yrow = ldsYh + (row * 16 + 4 * g + (i >> 2)) * CG + (i & 3) * 4;
+                s16x4 a[TPW], b[NREP];
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn) b[nn] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(yrow + nn * 16));
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+                    if (!MASKED || live[k]) a[k] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(arow + offA[k]));
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+                    if (!MASKED || live[k]) {
+#pragma unroll
+                        for (int nn = 0; nn < NREP; ++nn)
+                            acc[k][nn] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[k], b[nn], acc[k][nn], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll 1
         for (int row = 0; row < TVOX / 16; ++row) {
             const int vz = row >> 3, vy = row & 7;
@@ -1058,10 +1137,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
-    const size_t shm = (size_t)6 * HY * HX * CK * sizeof(float) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS>;
+    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0);
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1085,6 +1164,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     const int Cin = C1 + C2;
     const int CK = pick_ck(C1, C2);
     if (!CK) return DA_ERR_UNSUPPORTED;
+    const bool bf = da_matrix_bf16();
     {   // every tensor is addressed per sample through a buffer descriptor with 32-bit byte offsets
         const unsigned long long vox4 = (unsigned long long)D * H * W * 4ull;
         const int cmax = (C1 > C2 ? C1 : C2) > (Cs1 > Cs2 ? Cs1 : Cs2) ? (C1 > C2 ? C1 : C2) : (Cs1 > Cs2 ? Cs1 : Cs2);
@@ -1092,6 +1172,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     const int NT = (Cout + 15) / 16;
     int NREP = pick_nrep(NT);
+    if (bf && NREP > 2) NREP = 2;                 // bf16 mode is not matrix-bound; three N-tiles would spill
     {   // Coarse levels have few tiles (30 per volume at 20x24x20, 180 at 40x48x40): the persistent grid then runs one or two
         // uneven rounds.  Makespan model: a workgroup walks ceil(tiles / nblk) tiles, each costing ~NREP (one N-tile per
         // workgroup is ~8 % less efficient per FLOP but quadruples / doubles the number of work items); take the cheaper.
@@ -1112,7 +1193,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     if (ws_bytes < pk) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
     const long long total = (long long)(Cin / CK) * NSTEPS * NTpad * 256;
-    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total);
+    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, bf ? 1 : 0);
     DA_LAUNCH_CHECK();
     FwdP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.wp = wp; p.bias = bias;
@@ -1137,22 +1218,29 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     if (stats_nparts) *stats_nparts = 0;
     if (stats_partial && p.maskmode == 0 && (CK == 16 || CK == 8) && NREP <= 2) {
         if (stats_nparts) *stats_nparts = p.nblocks;
-        if (CK == 16 && NREP == 1) return launch_fwd_mfma<16, 1, false, true>(p, gy, st);
-        if (CK == 16 && NREP == 2) return launch_fwd_mfma<16, 2, false, true>(p, gy, st);
-        if (CK == 8 && NREP == 1) return launch_fwd_mfma<8, 1, false, true>(p, gy, st);
-        if (CK == 8 && NREP == 2) return launch_fwd_mfma<8, 2, false, true>(p, gy, st);
+#define DA_ST_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true>(p, gy, st)
+        DA_ST_CASE(16, 1); DA_ST_CASE(16, 2); DA_ST_CASE(8, 1); DA_ST_CASE(8, 2);
+#undef DA_ST_CASE
     }
     if (p.maskmode != 0) {
-        if (NREP == 1) return launch_fwd_mfma<16, 1, true>(p, gy, st);
-        if (NREP == 2) return launch_fwd_mfma<16, 2, true>(p, gy, st);
+        if (NREP == 1) return bf ? launch_fwd_mfma<16, 1, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 1, true>(p, gy, st);
+        if (NREP == 2) return bf ? launch_fwd_mfma<16, 2, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 2, true>(p, gy, st);
         return DA_ERR_UNSUPPORTED;
     }
-#define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return launch_fwd_mfma<ck, nr>(p, gy, st)
+#define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, false, true>(p, gy, st) : launch_fwd_mfma<ck, nr>(p, gy, st)
     DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3);          // pick_nrep never asks for more than 3 N-tiles
     DA_FWD_CASE(8, 1); DA_FWD_CASE(8, 2); DA_FWD_CASE(8, 3);
 #undef DA_FWD_CASE
     return DA_ERR_UNSUPPORTED;
 }
+
+// bf16 matrix mode: process-wide switch (like da_set_conv_direct); returns the previous setting
+static int g_matrix_bf16 = -1;          // -1: not decided yet (env DA_MATRIX_BF16=1 turns it on for tools)
+bool da_matrix_bf16() {
+    if (g_matrix_bf16 < 0) { const char* e = getenv("DA_MATRIX_BF16"); g_matrix_bf16 = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_matrix_bf16 != 0;
+}
+extern "C" int da_set_matrix_bf16(int on) { const int prev = da_matrix_bf16() ? 1 : 0; g_matrix_bf16 = on ? 1 : 0; return prev; }
 
 static bool smallcin_ok(int C1, int C2, int Cout, int stride) { return stride == 1 && C1 + C2 <= 4 && Cout <= 32; }   // + 32-bit offsets, checked at launch
 static const int kScBlocks = 1024;
@@ -1221,10 +1309,10 @@ __global__ void swapped_wgrad_place_kernel(const float* __restrict__ tmp, float*
     }
 }
 
-template <int CK, int NREP, bool YS = false, bool MASKED = false>
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
-    const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * sizeof(float);
-    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED>;
+    const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4);
+    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1280,6 +1368,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     }
     const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
+    const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < q.partial_bytes) return DA_ERR_WS_SMALL;
     WgP p;
@@ -1295,14 +1384,15 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     int rc = DA_ERR_UNSUPPORTED;
     if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
-        rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true>(p, q, st);
+        if (bf) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true>(p, q, st);
+        else rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true>(p, q, st);
     }
     else if (Cout % 4 != 0 && q.CK == 16) rc = launch_wgrad_mfma<16, 1, true>(p, q, st);
     else if (Cout % 4 != 0 && q.CK == 8) rc = launch_wgrad_mfma<8, 1, true>(p, q, st);
-    else if (q.CK == 16 && q.NREP == 1) rc = launch_wgrad_mfma<16, 1>(p, q, st);
-    else if (q.CK == 16 && q.NREP == 2) rc = launch_wgrad_mfma<16, 2>(p, q, st);
-    else if (q.CK == 8 && q.NREP == 1) rc = launch_wgrad_mfma<8, 1>(p, q, st);
-    else if (q.CK == 8 && q.NREP == 2) rc = launch_wgrad_mfma<8, 2>(p, q, st);
+    else if (q.CK == 16 && q.NREP == 1) rc = bf ? launch_wgrad_mfma<16, 1, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 1>(p, q, st);
+    else if (q.CK == 16 && q.NREP == 2) rc = bf ? launch_wgrad_mfma<16, 2, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2>(p, q, st);
+    else if (q.CK == 8 && q.NREP == 1) rc = bf ? launch_wgrad_mfma<8, 1, false, false, true>(p, q, st) : launch_wgrad_mfma<8, 1>(p, q, st);
+    else if (q.CK == 8 && q.NREP == 2) rc = bf ? launch_wgrad_mfma<8, 2, false, false, true>(p, q, st) : launch_wgrad_mfma<8, 2>(p, q, st);
     if (rc) return rc;
     { const int rc2 = da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st); if (rc2) return rc2; }
     return 0;

@@ -65,6 +65,17 @@ _side_keep = []          # tensors the side stream still reads: referenced until
                          # event-polled frees made the caching allocator fall back to hipMalloc on random steps (40 -> 64 ms)
 
 
+def set_matrix_precision(mode):
+    """'fp32' (default: exact fp32 MFMA, the reference's arithmetic) or 'bf16': the 3x3x3 convolutions round their operands to bf16
+    while staging them and accumulate in fp32 on the bf16 matrix pipe (BASELINE config 5); everything else stays fp32.
+    Process-wide; returns the previous mode."""
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError("matrix precision must be 'fp32' or 'bf16', got %r" % (mode,))
+    from ._native import lib
+    prev = lib().da_set_matrix_bf16(1 if mode == 'bf16' else 0)
+    return 'bf16' if prev else 'fp32'
+
+
 def enable_async_wgrad(flag=True):
     global ASYNC_WGRAD
     ASYNC_WGRAD = bool(flag)

@@ -83,6 +83,12 @@ int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, int C2, const
  * DA_CONV_DIRECT=1); returns the previous setting.  Used by the GPU tests to A/B the two implementations. */
 int da_set_conv_direct(int on);
 
+/* bf16 matrix mode (BASELINE config 5; the reference itself is fp32-only, train_seg.py has no autocast): when on, the 3x3x3
+ * convolutions (forward, data gradient, weight gradient) round their operands to bf16 while staging them and run on
+ * v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm, losses and the optimiser stay fp32.
+ * Off by default (exact fp32 v_mfma_f32_16x16x4_f32); returns the previous setting. */
+int da_set_matrix_bf16(int on);
+
 /* ---- 1x1x1 convolution (segmentation head, row a5; unets.py:249-250) ------------------------- */
 /* scratch for the packed weights of the 1x1 / transposed-conv forward and data-gradient launchers */
 size_t da_pointwise_ws_bytes(int ntaps, int Cin, int Cout);

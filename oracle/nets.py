@@ -163,10 +163,18 @@ def closed_form_labels(shape, n_classes, seed=0):
 # ----------------------------------------------------------------------------------------
 # forward restatements
 # ----------------------------------------------------------------------------------------
+# Optional emulation of the product's bf16 matrix mode (not a reference feature: train_seg.py is fp32-only).  When set to a
+# callable, the input and the weight of every 3x3x3 convolution that the product runs on the matrix cores (Cin % 8 == 0,
+# Cout >= 8, Cout % 4 == 0) are passed through it before the fp32 convolution, e.g. lambda t: t.bfloat16().float().
+K3_OPERAND_ROUND = None
+
+
 def _conv_bn_act(x, sd, prefix, slope, training, conv_name='conv', stride=1, padding=1, momentum=0.1, eps=1e-5):
     """unets.py:24-39 convBlock: Conv3d -> BatchNorm3d -> LeakyReLU(0.01)."""
     w = sd[f'{prefix}.{conv_name}.weight']
     b = sd.get(f'{prefix}.{conv_name}.bias')
+    if K3_OPERAND_ROUND is not None and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[1] % 8 == 0 and w.shape[0] >= 8 and w.shape[0] % 4 == 0:
+        x, w = K3_OPERAND_ROUND(x), K3_OPERAND_ROUND(w)
     y = F.conv3d(x, w, b, stride=stride, padding=padding)
     if f'{prefix}.BN.weight' in sd:
         y = F.batch_norm(y, sd[f'{prefix}.BN.running_mean'], sd[f'{prefix}.BN.running_var'],

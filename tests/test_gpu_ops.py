@@ -381,6 +381,40 @@ def test_full_size_dice_of_identical_onehots_and_counts():
     assert int(counts[0, :, 0].sum()) == lab.numel() and torch.equal(counts[0, :, 0], counts[0, :, 2])
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize('C1,C2,Cout,dims,stride', [(16, 0, 16, (1, 9, 11, 21), 1), (32, 16, 16, (2, 8, 16, 32), 1), (8, 0, 16, (1, 6, 9, 17), 1),
+                                                     (16, 16, 32, (1, 5, 8, 16), 1), (32, 0, 48, (1, 4, 8, 16), 1), (16, 0, 32, (1, 8, 12, 20), 2),
+                                                     (64, 0, 64, (1, 4, 9, 18), 1)])
+def test_conv3d_bf16_matrix_mode(C1, C2, Cout, dims, stride):
+    """BASELINE config 5's arithmetic: operands rounded to bf16 (round-to-nearest-even), products and sums in fp32.  bf16 x bf16
+    products are exact in fp32, so the bf16 mode must equal the fp32 reference run on pre-rounded operands up to summation order."""
+    from deepatlas_amd import ops
+    N, D, H, W = dims
+    Cin = C1 + C2
+    x, w, b = rnd((N, Cin, D, H, W), 1), rnd((Cout, Cin, 3, 3, 3), 2, 0.2), rnd((Cout,), 3, 0.1)
+    xr, wr = _bf16_round(x).requires_grad_(True), _bf16_round(w).requires_grad_(True)
+    yr = F.conv3d(xr, wr, b, stride=stride, padding=1)
+    go = rnd(tuple(yr.shape), 4)
+    (yr * _bf16_round(go)).sum().backward()                # data gradient of the reference with dy pre-rounded
+    prev = ops.set_matrix_precision('bf16')
+    try:
+        x1 = cl(x[:, :C1]).requires_grad_(True)
+        x2 = cl(x[:, C1:]).requires_grad_(True) if C2 else None
+        wg = w.to(dev()).requires_grad_(True)
+        yg = ops.Conv3dK3Fn.apply(x1, x2, wg, b.to(dev()), stride, -1.0)
+        yg.backward(cl(go))
+    finally:
+        ops.set_matrix_precision(prev)
+    check(yg, yr, tol=2e-5, what='bf16 fwd')
+    check(x1.grad, xr.grad[:, :C1], tol=2e-5, what='bf16 dgrad')
+    if C2:
+        check(x2.grad, xr.grad[:, C1:], tol=2e-5, what='bf16 dgrad (second input)')
+    check(wg.grad, wr.grad, tol=2e-5, what='bf16 wgrad')
+
+
 def test_large_batch_transposed_conv_and_head_beyond_4gib():
     """Batch 8 at 160x192x160: the 32 -> 32 up-sampler's output and the 32-class logits are 5 GB each, past 32-bit byte offsets.
     Additivity over the batch axis: weight / bias gradients of the whole batch = sum over the two half batches, and the forward /

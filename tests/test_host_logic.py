@@ -91,3 +91,17 @@ def test_train_seg_config_matches_reference_dict():
     assert c['loss_settings'] == {'n_class': 32, 'weight_type': 'Uniform', 'no_bg': False, 'softmax': True, 'eps': 1e-6}
     assert c['lr_mode'] == 'multiStep' and c['milestones'] == [0.5, 1] and c['gamma'] == 0.2
     assert c['samples_per_epoch'] == 42 and c['crop_size'] == [0, 10, 7, 14, 8, 7]
+
+
+def test_matrix_precision_switch_round_trip():
+    """ops.set_matrix_precision: process-wide switch in the C library (no GPU needed to flip it); unknown modes raise."""
+    from deepatlas_amd import ops
+    prev = ops.set_matrix_precision('bf16')
+    try:
+        assert prev in ('fp32', 'bf16')
+        assert ops.set_matrix_precision('fp32') == 'bf16'
+        assert ops.set_matrix_precision('fp32') == 'fp32'
+        with pytest.raises(ValueError):
+            ops.set_matrix_precision('fp16')
+    finally:
+        ops.set_matrix_precision(prev)
