@@ -227,7 +227,10 @@ def main():
                     roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json (algorithmic %d B)' % rec['algorithmic_bytes']
             except (OSError, ValueError, KeyError):
                 pass
-        line = dict(metric='training volumes/sec at 160x192x160 fp32; Dice vs CPU ref', value=round(value, 4), unit='volumes/s',
+        metric = 'training volumes/sec at 160x192x160 fp32; Dice vs CPU ref'          # BASELINE.json's metric (the default invocation)
+        if shape != (160, 192, 160) or args.precision != 'fp32':
+            metric = 'training volumes/sec at %dx%dx%d %s' % (shape[0], shape[1], shape[2], 'fp32' if args.precision == 'fp32' else 'bf16 matrix mode')
+        line = dict(metric=metric, value=round(value, 4), unit='volumes/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32' if args.precision == 'fp32' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
                     config=dict(workload=workload_name,

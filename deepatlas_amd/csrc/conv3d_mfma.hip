@@ -22,6 +22,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));      // four bf16 (the A / B fragment of v_mfma_f32_16x16x16_bf16)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));    // eight bf16 (the A / B fragment of v_mfma_f32_16x16x32_bf16)
 #include <type_traits>
 #ifndef DA_PIN
 #define DA_PIN 1   // pin the m-outer MFMA order (keeps hipcc from chaining 4 dependent MFMAs on one accumulator)
@@ -204,11 +205,14 @@ struct FwdP {
 template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // K32: the dense bf16 kernels use v_mfma_f32_16x16x32_bf16 (K = 32 = two taps x 16 cin, or four taps x 8 cin; 16 cycles per
+    // SIMD for twice the K of the 16x16x16 form, which gfx950 issues at ~32 cycles); the sparse-tap variant keeps one tap per step.
+    constexpr bool K32 = BF && !MASKED;
     using AElem = std::conditional_t<BF, short, float>;
-    using Frag = std::conditional_t<BF, s16x4, f32x4>;          // A / B fragment: 4 consecutive cin of one voxel / one cout
+    using Frag = std::conditional_t<K32, bf16x8, std::conditional_t<BF, s16x4, f32x4>>;   // A / B fragment: 4 (8) consecutive cin of one voxel / one cout
     constexpr int EB = BF ? 2 : 4;                               // bytes per staged element
     constexpr int TZ = 4, HZ = TZ + 2;
-    constexpr int NSTEPS = (27 * CK + 15) / 16;          // 27 (CK = 16) | 14 (CK = 8: two taps per K-step)
+    constexpr int NSTEPS = K32 ? (CK == 16 ? 14 : 7) : (27 * CK + 15) / 16;          // 27 (CK = 16) | 14 (CK = 8: two taps per K-step); K32: 14 | 7
     constexpr int NIT = StageGeom<CK, HZ>::NIT;
     // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
     // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
@@ -305,12 +309,17 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     __syncthreads();
 
     // K-step s: lane group g supplies (tap, cin quad) = CK16: (s, g) | CK8: (2s + (g>>1), g&1).
-    const AElem* abase = (CK == 16) ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + g * 4
+    const AElem* abase = K32 ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + ((CK == 16) ? (g & 1) * 8 : 0)
+                       : (CK == 16) ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + g * 4
                                     : reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
     const bool hi = (g >> 1) != 0;
     auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
     auto a_off8 = [&](int s) -> int {                                                              // CK8: two taps per step
         int tap = 2 * s + (hi ? 1 : 0); if (tap > 26) tap = 26;
+        return (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK;
+    };
+    auto a_off32 = [&](int s) -> int {                                                             // K32: lane group g -> tap 2s + (g>>1) | 4s + g
+        int tap = (CK == 16) ? 2 * s + (g >> 1) : 4 * s + g; if (tap > 26) tap = 26;             // (taps past 26 carry zero weights)
         return (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK;
     };
 
@@ -323,14 +332,16 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // before this item's epilogue stores); (2) the next item's staging loads are spread over the K-steps, at most one per step;
     // (3) nothing that touches vector memory sits inside a branch: invalid work (no next item, not the last chunk, ragged
     // lanes) is expressed as out-of-range buffer offsets, so hipcc's s_waitcnt vmcnt(N) stay exact instead of collapsing to 0.
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * 256 * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * (K32 ? 1024 : 256 * EB)), 0x00020000);
     auto wb = [&](int chunk, int step, int nn) -> Frag {
-        if constexpr (BF) return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rsw, (unsigned)lane * 8u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 512), 0));
+        if constexpr (K32) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
+        else if constexpr (BF) return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rsw, (unsigned)lane * 8u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 512), 0));
         else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
     };
     // one K-step of one (M-tile, N-tile) pair
     auto mma_bf = [&](f32x4 c, const Frag& a, const Frag& b) -> f32x4 {
-        if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+        if constexpr (K32) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        else if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
         else return c;
     };
     constexpr int LB = (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2)
@@ -394,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         // MFMA order: component m outermost, M-tile r innermost -> 4*NREP independent accumulators between two uses of the
         // same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
         constexpr int HALF = TY / 2;
-        auto step_ptr = [&](int s) -> const AElem* { return (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
+        auto step_ptr = [&](int s) -> const AElem* { return K32 ? abase + a_off32(s) : (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
         const int ch_next = (ch + 1 == nchunks) ? 0 : ch + 1;
 #pragma unroll
         for (int t = 0; t < LB; ++t)
@@ -708,6 +719,19 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
         int tap, c4;
         if (CK == 16) { tap = s; c4 = g; } else { const int qd = s * 4 + g; tap = qd >> 1; c4 = qd & 1; }
         const int cin = ch * CK + c4 * 4 + m, cout = nt * 16 + j;
+        if (bf == 2) {      // v_mfma_f32_16x16x32_bf16: 8 bf16 per lane, lane group g = tap 2s + (g>>1), cin half g&1 (CK 16) | tap 4s + g (CK 8)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * m + h;
+                const int tp = (CK == 16) ? 2 * s + (g >> 1) : 4 * s + g;
+                const int ci = ch * CK + ((CK == 16) ? (g & 1) * 8 : 0) + e;
+                float v2 = 0.f;
+                if (tp < 27 && cout < Cout && ci < Cin)
+                    v2 = flipped ? w[((size_t)(26 - tp) * Cout + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * Cout + cout];
+                reinterpret_cast<unsigned short*>(wp)[idx * 2 + h] = __builtin_bit_cast(unsigned short, (__bf16)v2);
+            }
+            continue;
+        }
         float v = 0.f;
         if (tap < 27 && cout < Cout && cin < Cin)
             v = flipped ? w[((size_t)(26 - tap) * Cout + cout) * Cin + cin] : w[((size_t)tap * Cin + cin) * Cout + cout];
@@ -1188,12 +1212,13 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         }
     }
     const int gy = (NT + NREP - 1) / NREP, NTpad = gy * NREP;
-    const int NSTEPS = (27 * CK + 15) / 16;
+    const int pkmode = bf ? (s2d_cin > 0 ? 1 : 2) : 0;       // 0 fp32 | 1 bf16, one tap per K-step (sparse taps) | 2 bf16, K = 32 per step
+    const int NSTEPS = pkmode == 2 ? (CK == 16 ? 14 : 7) : (27 * CK + 15) / 16;
     const size_t pk = packed_bytes(Cin, Cout, CK);
     if (ws_bytes < pk) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
     const long long total = (long long)(Cin / CK) * NSTEPS * NTpad * 256;
-    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, bf ? 1 : 0);
+    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode);
     DA_LAUNCH_CHECK();
     FwdP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.wp = wp; p.bias = bias;
