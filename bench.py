@@ -32,6 +32,8 @@ def conv_flops(key):
     name, a = key
     if name in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'):      # C1, C2, N, D, H, W, Cout, stride
         C1, C2, N, D, H, W, Cout, stride = a[:8]
+    elif name == 'da_conv3d_k3_fwd_pro':                              # C1, C2, N, D, H, W, Cout, stats capacity (stride 1)
+        C1, C2, N, D, H, W, Cout = a[:7]; stride = 1
     elif name == 'da_conv3d_k3_dgrad':  # C1, C2, N, D, H, W, Cout, stride
         C1, C2, N, D, H, W, Cout, stride = a[:8]
     elif name == 'da_conv3d_k3_wgrad':
@@ -45,9 +47,9 @@ def conv_flops(key):
 def conv_bytes(key):
     """Algorithmic HBM bytes of one da_conv3d_k3_fwd* call: the input read once + the output written once, fp32 (weights are KBs)."""
     name, a = key
-    if name not in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'):
+    if name not in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_fwd_pro'):
         return 0
-    C1, C2, N, D, H, W, Cout, stride = a[:8]
+    C1, C2, N, D, H, W, Cout, stride = (tuple(a[:7]) + (1,)) if name == 'da_conv3d_k3_fwd_pro' else a[:8]
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     return 4.0 * N * ((C1 + C2) * D * H * W + Cout * Do * Ho * Wo)
 
@@ -170,7 +172,7 @@ def main():
         # (ops.ASYNC_WGRAD): timing events recorded on that stream serialise it against the main one (measured: the overlap gain
         # disappears), and kernels that do overlap time each other's slowdown, so the roofline call is taken where nothing else is
         # in flight.  --profile-all times all four conv entry points (and costs ~5 % of `value`).
-        names = ['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'] + (['da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'] if args.profile_all else [])
+        names = ['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_fwd_pro'] + (['da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'] if args.profile_all else [])
         prof = nat.CallProfiler(names)
     torch.cuda.synchronize()
     if world > 1:
@@ -221,7 +223,11 @@ def main():
             # FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape
             try:
                 pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-                rec = json.load(open(pj))['calls'].get(roofline['kernel'].replace('da_conv3d_k3_fwd_bnstats[', 'da_conv3d_k3_fwd['))   # same kernel + per-workgroup BN partials
+                # same kernel (+ per-workgroup BN partials; the input-prologue variant reads the same bytes, raw instead of activated)
+                kname = roofline['kernel'].replace('da_conv3d_k3_fwd_bnstats[', 'da_conv3d_k3_fwd[')
+                if kname.startswith('da_conv3d_k3_fwd_pro['):
+                    kname = 'da_conv3d_k3_fwd[' + kname[len('da_conv3d_k3_fwd_pro['):].rsplit(',', 1)[0] + ', 1]'
+                rec = json.load(open(pj))['calls'].get(kname)
                 if rec:
                     roofline['traffic'] = rec['traffic_bytes']
                     roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json (algorithmic %d B)' % rec['algorithmic_bytes']

@@ -34,6 +34,8 @@ SIGNATURES = {
     'da_conv3d_k3_fwd_bnstats': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),
     'da_conv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, I, P, SZ, P]),
     'da_conv3d_k3_wgrad': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_conv3d_k3_fwd_pro': (I, [P, I, P, P, F, P, I, P, P, F, P, P, P, I, I, I, I, I, F, P, I, POINTER(c_int), P, SZ, P]),
+    'da_conv3d_k3_wgrad_pro': (I, [P, I, P, P, F, P, I, P, P, F, P, P, I, I, I, I, I, P, SZ, P]),
     'da_set_conv_direct': (I, [I]),
     'da_set_matrix_bf16': (I, [I]),
     'da_pointwise_ws_bytes': (SZ, [I, I, I]),
@@ -159,6 +161,18 @@ def call(name, *args):
         rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise NativeError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
+
+
+def call_supported(name, *args):
+    """Like call(), for entry points that may decline a shape: returns False on DA_ERR_UNSUPPORTED (the caller then takes its
+    documented alternative HIP entry), True on success; every other error raises."""
+    try:
+        call(name, *args)
+        return True
+    except NativeError as e:
+        if 'DA_ERR_UNSUPPORTED' in str(e):
+            return False
+        raise
 
 
 def ptr(t):

@@ -373,6 +373,41 @@ extern "C" int da_conv3d_k3_fwd_bnstats(const float* in1, int C1, const float* i
     return da_conv3d_k3_fwd(in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, stride, -1.f, ws, ws_bytes, stream);
 }
 
+// Forward / weight gradient with an INPUT PROLOGUE: in1 / in2 may be raw outputs of a BatchNorm'd producer whose per-channel
+// scale / shift and activation are applied while the tile is staged (the activated tensor is never written to HBM).  Matrix-core
+// path only, stride 1; DA_ERR_UNSUPPORTED = the caller materialises the activation (da_bn_act_fwd) and uses the plain entry.
+extern "C" int da_conv3d_k3_fwd_pro(const float* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                                    const float* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                                    const float* w_tio, const float* bias, float* out,
+                                    int N, int D, int H, int W, int Cout, float act_slope,
+                                    double* stats_partial, int stats_capacity, int* stats_nparts,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (stats_nparts) *stats_nparts = 0;
+    if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 ||
+        (pro1_scale && !pro1_shift) || (pro2_scale && !pro2_shift))
+        return DA_ERR_BADARG;
+    if (force_direct() || !da_conv3_mfma_fwd_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)) return DA_ERR_WS_SMALL;
+    const DaPro pro = {pro1_scale, pro1_shift, pro1_slope, pro2_scale, pro2_shift, pro2_slope};
+    const bool stats = stats_partial && stats_capacity >= 512;
+    return da_conv3_mfma_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, 1, stats ? -1.f : act_slope,
+                             ws, ws_bytes, da_stream(stream), 0, stats ? stats_partial : nullptr, stats ? stats_nparts : nullptr, &pro);
+}
+
+extern "C" int da_conv3d_k3_wgrad_pro(const float* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                                      const float* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                                      const float* dy, float* dw_tio,
+                                      int N, int D, int H, int W, int Cout,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (!in1 || !dy || !dw_tio || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || Cout <= 0 ||
+        (pro1_scale && !pro1_shift) || (pro2_scale && !pro2_shift))
+        return DA_ERR_BADARG;
+    if (force_direct() || !da_conv3_mfma_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)) return DA_ERR_WS_SMALL;
+    const DaPro pro = {pro1_scale, pro1_shift, pro1_slope, pro2_scale, pro2_shift, pro2_slope};
+    return da_conv3_mfma_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, 1, ws, ws_bytes, da_stream(stream), 0, &pro);
+}
+
 extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
                                   int N, int D, int H, int W, int Cout, int stride,
                                   void* ws, size_t ws_bytes, void* stream) {

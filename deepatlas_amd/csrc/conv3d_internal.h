@@ -10,15 +10,21 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
 // w_is_flipped_tr != 0: `w_tio` is the ORIGINAL layer's [27][Cout][C1] tensor and the kernel runs the data-gradient
 // convolution (taps flipped, channels transposed) -- i.e. logical Cin = C1, logical Cout = `Cout`.
 bool da_matrix_bf16();                 // bf16 matrix mode switch (da_set_matrix_bf16)
+// Input prologue: in1 / in2 are RAW outputs of a producer whose per-channel affine (BatchNorm scale / shift) and activation
+// (slope as in da_conv3d_k3_fwd: < 0 identity, 0 ReLU, > 0 LeakyReLU) are applied while the tile is staged.  A null scale
+// pointer = that input is already activated.
+struct DaPro { const float* s1; const float* t1; float slope1; const float* s2; const float* t2; float slope2; };
 bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1 = -1, int Cs2 = 0);   // Cs1/Cs2: output split (dgrad of a concat conv)
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0, double* stats_partial = nullptr, int* stats_nparts = nullptr);
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0, double* stats_partial = nullptr, int* stats_nparts = nullptr,
+                      const DaPro* pro = nullptr);
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0);
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0,
+                        const DaPro* pro = nullptr);
 
 int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         float* out1, int Cs1, float* out2, int Cs2,

@@ -57,13 +57,16 @@ template <int CK, int HZ> struct StageGeom {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t da_rsrc(const float* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
+__device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
 __device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
 template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
 __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict__ src, int Cs, int choff,
-                                           int n, int z0, int y0, int x0, int D, int H, int W) {
+                                           int n, int z0, int y0, int x0, int D, int H, int W, unsigned* vmask = nullptr) {
     constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
     constexpr int STEP = 256 / Q;                        // voxels per iteration
     constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
@@ -81,6 +84,7 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
         const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * 4);
         pre[it - IT0] = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        if (vmask) *vmask |= (inb ? 1u : 0u) << (it - IT0);
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
         hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
@@ -88,9 +92,31 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
     }
 }
 
-__device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+// LeakyReLU / ReLU / identity as max(z, z * s) with s = slope in [0, 1) or s = 1 for "no activation": two VALU operations, no
+// compares, and bit-identical to da_act() for every finite or non-finite z (z > 0: z; z < 0: z * s >= z; -0 and NaN propagate alike).
+__device__ __forceinline__ float da_act01(float z, float s) { return fmaxf(z, z * s); }
+
+// Input prologue (PRO variants): the staged tensor is a RAW convolution output whose BatchNorm + LeakyReLU has not been applied
+// yet; it is applied here, on the way into LDS, with exactly the expression of bn_act_fwd_kernel (norm_act.hip) so the result is
+// bit-identical to materialising the activated tensor first.  Padding (out-of-volume voxels, mask bit clear) stays zero.
+template <int CK, int HZ, int IT0, int IT1, bool BF>
+__device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const float4* pre, unsigned vmask, float4 sc, float4 sf, float slope) {
+    constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        if (idx < TOTAL) {
+            const float4 t = pre[it - IT0];
+            const bool ok = ((vmask >> (it - IT0)) & 1u) != 0;
+            float4 v;
+            v.x = ok ? da_act01(t.x * sc.x + sf.x, slope) : 0.f; v.y = ok ? da_act01(t.y * sc.y + sf.y, slope) : 0.f;
+            v.z = ok ? da_act01(t.z * sc.z + sf.z, slope) : 0.f; v.w = ok ? da_act01(t.w * sc.w + sf.w, slope) : 0.f;
+            if constexpr (BF) reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
+            else reinterpret_cast<float4*>(lds)[idx] = v;
+        }
+    }
 }
+
 // BF: the LDS image holds bf16 (same [voxel][CK] order, 8 bytes per channel quad): converted once here instead of at every tap
 template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false>
 __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
@@ -114,7 +140,7 @@ template <int CK, int HZ> struct StageCursor {
     __amdgpu_buffer_rsrc_t rs;
     int hv, hx, hy, hz, cofs;
     int z0, y0, x0, D, H, W, Cs;
-    bool valid;
+    bool valid, last_inb;
     __device__ __forceinline__ void init(const float* __restrict__ src, int Cs_, int choff, int n, int z0_, int y0_, int x0_,
                                          int D_, int H_, int W_, bool valid_) {
         constexpr int Q = StageGeom<CK, HZ>::Q;
@@ -136,6 +162,7 @@ template <int CK, int HZ> struct StageCursor {
         const bool inb = valid && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
         const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * 4);
         const float4 v = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        last_inb = inb;
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
         hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
@@ -196,13 +223,14 @@ struct FwdP {
     unsigned masks[16]; int maskmode;   // tap masks (stride-2 via space-to-depth): 0 none, 1 per channel chunk, 2 per blockIdx.y
     double* stats_partial;              // optional [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the (pre-activation) output
     unsigned long long* clk;
+    const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: per-channel scale / shift / act slope still to be applied to in1 / in2
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
 // BF: bf16 matrix mode (da_set_matrix_bf16): tensors stay fp32 in HBM, the staged tile and the packed weights are bf16 and one
 // v_mfma_f32_16x16x16_bf16 (fp32 accumulate) replaces the four v_mfma_f32_16x16x4_f32 of a K-step -- same lane <-> (voxel, cin)
 // mapping, so everything around the K loop is shared.  The kernel is then bound by HBM / LDS instead of the matrix pipe.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // K32: the dense bf16 kernels use v_mfma_f32_16x16x32_bf16 (K = 32 = two taps x 16 cin, or four taps x 8 cin; 16 cycles per
@@ -217,6 +245,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // staging iterations whose loads are issued one work item ahead and parked in VGPRs during the MFMA phase; the
     // rest (register budget: 8*NREP*4 accumulators must leave two workgroups per CU) are fetched after the barrier
     constexpr int PRE = MASKED ? (NREP == 1 ? NIT : 4) : ((NREP <= 2) ? NIT : (NREP == 3 ? (NIT < 4 ? NIT : 4) : 0));
+    static_assert(!PRO || (PRE == NIT && !MASKED), "the prologue variant keeps the whole next tile in registers");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -303,9 +332,35 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         }
     };
     float4 pre[PRE > 0 ? PRE : 1];
+    // PRO: scale / shift / slope of the channel quad this thread stages (256 % Q == 0: the quad is fixed per thread and chunk).
+    // Unconditional loads from always-valid arrays (the host substitutes identity arrays for an input without a prologue).
+    unsigned vm = 0;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
+    auto load_pro = [&](int item) {
+        if constexpr (PRO) {
+            int n, z0, y0, x0, ch;
+            item_coords(item, n, z0, y0, x0, ch);
+            const int cbase = ch * CK;
+            const bool first = cbase < p.C1;
+            const int cofs = (first ? cbase : cbase - p.C1) + ((int)threadIdx.x % StageGeom<CK, HZ>::Q) * 4;
+            psc = *reinterpret_cast<const float4*>((first ? p.ps1 : p.ps2) + cofs);
+            psf = *reinterpret_cast<const float4*>((first ? p.pt1 : p.pt2) + cofs);
+            pslope = first ? p.pslope1 : p.pslope2;
+        }
+    };
+    if constexpr (PRO) {
+        int n, z0, y0, x0, ch;
+        item_coords(0, n, z0, y0, x0, ch);
+        const int cbase = ch * CK;
+        if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W, &vm);
+        else stage_load<CK, HZ, 0, PRE>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W, &vm);
+        load_pro(0);
+        stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
+    } else {
     issue_stage(0, pre);
     stage_write<CK, HZ, 0, PRE, BF>(lds, pre);
     stage_rest(0);
+    }
     __syncthreads();
 
     // K-step s: lane group g supplies (tap, cin quad) = CK16: (s, g) | CK8: (2s + (g>>1), g&1).
@@ -347,6 +402,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     constexpr int LB = (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2)
     constexpr int RB = LB + 1;                          // ring slots
     constexpr int TAIL = 5;                             // K-steps at the end of an item without staging loads (they must land before stage_write)
+    constexpr int PRO_DELAY = 3;                        // K-steps between a staging load and its prologue arithmetic (< TAIL)
+    constexpr bool PRO_IN = PRO && NREP == 1;           // prologue arithmetic inside the K loop (one N-tile: registers to spare); else between the barriers
+    static_assert(!PRO || NSTEPS - TAIL + PRO_DELAY <= NSTEPS, "prologue arithmetic must fall inside the K loop");
     Frag bq[RB][NREP], nb[LB][NREP];
     if constexpr (!MASKED) {
 #pragma unroll
@@ -412,6 +470,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
             for (int nn = 0; nn < NREP; ++nn) bq[t % RB][nn] = nb[t][nn];
         StageCursor<CK, HZ> cur;
+        if constexpr (PRO) vm = 0;
+        if constexpr (PRO_IN) load_pro(has_next ? item + 1 : item);               // constants of the tile staged during this item
         {
             int n2, z2, y2, x2, ch2;
             item_coords(item + 1, n2, z2, y2, x2, ch2);
@@ -437,7 +497,18 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             // next item's staging loads scheduled on this step
 #pragma unroll
             for (int j = 0; j < PRE; ++j)
-                if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) pre[j] = cur.next();
+                if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) { pre[j] = cur.next(); if constexpr (PRO) vm |= (cur.last_inb ? 1u : 0u) << j; }
+            if constexpr (PRO_IN) {   // the deferred BatchNorm + activation of a staged quad, PRO_DELAY K-steps after its load was issued:
+                                      // by then it has landed, and the VALU work hides under the other wave's MFMAs instead of sitting between the barriers
+#pragma unroll
+                for (int j = 0; j < PRE; ++j)
+                    if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) + PRO_DELAY == s) {
+                        const bool ok = ((vm >> j) & 1u) != 0;
+                        const float4 t = pre[j];
+                        pre[j].x = ok ? da_act01(t.x * psc.x + psf.x, pslope) : 0.f; pre[j].y = ok ? da_act01(t.y * psc.y + psf.y, pslope) : 0.f;
+                        pre[j].z = ok ? da_act01(t.z * psc.z + psf.z, pslope) : 0.f; pre[j].w = ok ? da_act01(t.w * psc.w + psf.w, pslope) : 0.f;
+                    }
+            }
             const AElem* ap = step_ptr(s);
 #pragma unroll
             for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const Frag*>(ap + (HALF + r) * (HX * CK));
@@ -549,10 +620,12 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             }
         }
         if (STATS && last && ((++tiles_done) & 1) == 0) stats_flush();
+        if constexpr (PRO && !PRO_IN) load_pro(has_next ? item + 1 : item);      // outside the branch: no vector memory in branches
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
-            stage_write<CK, HZ, 0, PRE, BF>(lds, pre);
-            stage_rest(item + 1);
+            if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
+            else stage_write<CK, HZ, 0, PRE, BF>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
+            if constexpr (!PRO) stage_rest(item + 1);
             __syncthreads();
         }
     }
@@ -748,13 +821,14 @@ struct WgP {
     const float* dy; float* partial;
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, tiles_per_slab, O;
     unsigned masks[16]; int maskmode;   // per channel chunk tap masks (0 = all taps)
+    const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: see FwdP
 };
 
 // BF (bf16 matrix mode): both LDS tiles hold bf16 and one v_mfma_f32_16x16x16_bf16 consumes a whole row of 16 voxels (K = 16).
 // Its fragments need 4 consecutive VOXELS of one channel per lane while the tiles are channel-contiguous, which is exactly
 // what ds_read_b64_tr_b16 delivers: in each 16-lane group lane s supplies the address of (voxel 4g + s/4, channel quad s%4)
 // and receives (voxels 4g .. 4g+3, channel s) -- checked in tools/ubench/ds_read_tr16.hip.
-template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets; PRO: input prologue (BN + act applied to x while staging)
 __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(!(BF && YS), "bf16 mode stages dY in channel quads");
@@ -771,6 +845,14 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     const int cbase = ch * CK;
     const float* src; int Cs, choff;
     if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
+    unsigned vmA = 0;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
+    if constexpr (PRO) {      // this block's channel chunk is fixed: the thread's quad constants are loaded once
+        const int cofs = choff + ((int)threadIdx.x % StageGeom<CK, HZ>::Q) * 4;
+        psc = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.ps1 : p.ps2) + cofs);
+        psf = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.pt1 : p.pt2) + cofs);
+        pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
+    }
 
     // per-lane A offsets (floats) for this wave's tap slots
     int offA[TPW];
@@ -810,7 +892,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     auto issue_loads = [&](int tile) {
         int n, z0, y0, x0;
         tile_coords(tile, n, z0, y0, x0);
-        stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
+        if constexpr (PRO) { vmA = 0; stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W, &vmA); }
+        else stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
         const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (long long)n * sampleY, (unsigned)(sampleY * sizeof(float)));
 #pragma unroll
@@ -834,7 +917,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         }
     };
     auto write_lds = [&]() {
-        stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA);
+        if constexpr (PRO) stage_write_pro<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA);
         // dY tile [TVOX][CG] (channel halves XOR-swizzled by voxel parity when CG % 32 == 0)
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
@@ -1161,10 +1245,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF>;
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1180,14 +1264,40 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     return 0;
 }
 
+// identity scale / shift for an input without a prologue (the kernels load the constants unconditionally); one device per process
+static const int kProMaxC = 2048;
+static int pro_identity(const float** ones, const float** zeros) {
+    static float* buf = nullptr;
+    if (!buf) {
+        hipError_t e = hipMalloc(&buf, 2 * kProMaxC * sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        float* h = (float*)malloc(2 * kProMaxC * sizeof(float));
+        for (int i = 0; i < kProMaxC; ++i) { h[i] = 1.f; h[kProMaxC + i] = 0.f; }
+        e = hipMemcpy(buf, h, 2 * kProMaxC * sizeof(float), hipMemcpyHostToDevice);
+        free(h);
+        if (e != hipSuccess) return (int)e;
+    }
+    *ones = buf; *zeros = buf + kProMaxC;
+    return 0;
+}
+
+// kernel-side activation parameter (da_act01): slope in [0, 1) as is, "no activation" (slope < 0 or no prologue) -> 1
+static int pro_slopes(const DaPro* pro, int C2, float* s1, float* s2) {
+    const float a = pro->s1 ? pro->slope1 : -1.f, b = (C2 > 0 && pro->s2) ? pro->slope2 : -1.f;
+    if (a >= 1.f || b >= 1.f) return 1;
+    *s1 = a < 0.f ? 1.f : a; *s2 = b < 0.f ? 1.f : b;
+    return 0;
+}
+
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro) {
     (void)stride;
     const int Cin = C1 + C2;
     const int CK = pick_ck(C1, C2);
     if (!CK) return DA_ERR_UNSUPPORTED;
+    if (pro && (s2d_cin > 0 || w_is_flipped_tr || Cin > kProMaxC)) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();
     {   // every tensor is addressed per sample through a buffer descriptor with 32-bit byte offsets
         const unsigned long long vox4 = (unsigned long long)D * H * W * 4ull;
@@ -1196,7 +1306,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     const int NT = (Cout + 15) / 16;
     int NREP = pick_nrep(NT);
-    if (bf && NREP > 2) NREP = 2;                 // bf16 mode is not matrix-bound; three N-tiles would spill
+    if ((bf || pro) && NREP > 2) NREP = 2;        // bf16 mode is not matrix-bound, three N-tiles would spill; the prologue variant parks the whole next tile in registers
     {   // Coarse levels have few tiles (30 per volume at 20x24x20, 180 at 40x48x40): the persistent grid then runs one or two
         // uneven rounds.  Makespan model: a workgroup walks ceil(tiles / nblk) tiles, each costing ~NREP (one N-tile per
         // workgroup is ~8 % less efficient per FLOP but quadruples / doubles the number of work items); take the cheaper.
@@ -1241,11 +1351,26 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     p.stats_partial = stats_partial;
     if (stats_nparts) *stats_nparts = 0;
+    p.ps1 = p.pt1 = p.ps2 = p.pt2 = nullptr; p.pslope1 = p.pslope2 = -1.f;
+    if (pro) {
+        const float *ones, *zeros;
+        if (const int rc = pro_identity(&ones, &zeros)) return rc;
+        if (pro_slopes(pro, C2, &p.pslope1, &p.pslope2)) return DA_ERR_UNSUPPORTED;
+        p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
+        p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
+    }
     if (stats_partial && p.maskmode == 0 && (CK == 16 || CK == 8) && NREP <= 2) {
         if (stats_nparts) *stats_nparts = p.nblocks;
-#define DA_ST_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true>(p, gy, st)
+#define DA_ST_CASE(ck, nr) if (CK == ck && NREP == nr) return pro ? (bf ? launch_fwd_mfma<ck, nr, false, true, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true, false, true>(p, gy, st)) \
+                                                                  : (bf ? launch_fwd_mfma<ck, nr, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true>(p, gy, st))
         DA_ST_CASE(16, 1); DA_ST_CASE(16, 2); DA_ST_CASE(8, 1); DA_ST_CASE(8, 2);
 #undef DA_ST_CASE
+    }
+    if (pro) {
+#define DA_PRO_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, false, false, true>(p, gy, st)
+        DA_PRO_CASE(16, 1); DA_PRO_CASE(16, 2); DA_PRO_CASE(8, 1); DA_PRO_CASE(8, 2);
+#undef DA_PRO_CASE
+        return DA_ERR_UNSUPPORTED;
     }
     if (p.maskmode != 0) {
         if (NREP == 1) return bf ? launch_fwd_mfma<16, 1, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 1, true>(p, gy, st);
@@ -1334,10 +1459,10 @@ __global__ void swapped_wgrad_place_kernel(const float* __restrict__ tmp, float*
     }
 }
 
-template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false>
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4);
-    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF>;
+    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF, PRO>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1350,7 +1475,8 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
 }
 
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin) {
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro) {
+    if (pro && (stride != 1 || s2d_cin > 0 || C1 + C2 > kProMaxC || pick_ck(C1, C2) == 0 || Cout % 4 != 0 || Cout <= 4)) return DA_ERR_UNSUPPORTED;
     if (smallcin_ok(C1, C2, Cout, stride)) {
         const int Cin = C1 + C2, O = 27 * Cin * Cout;
         if (ws_bytes < (size_t)kScBlocks * O * sizeof(float)) return DA_ERR_WS_SMALL;
@@ -1405,6 +1531,20 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (s2d_cin > 0) {
         if (q.CK != 16) return DA_ERR_UNSUPPORTED;
         p.maskmode = 1; da_s2d_masks(p.masks, q.nchunks, 16, s2d_cin, 0);
+    }
+    p.ps1 = p.pt1 = p.ps2 = p.pt2 = nullptr; p.pslope1 = p.pslope2 = -1.f;
+    if (pro) {
+        const float *ones, *zeros;
+        if (const int rc0 = pro_identity(&ones, &zeros)) return rc0;
+        if (pro_slopes(pro, C2, &p.pslope1, &p.pslope2)) return DA_ERR_UNSUPPORTED;
+        p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
+        p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
+        int rcp = DA_ERR_UNSUPPORTED;
+#define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
+        DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2);
+#undef DA_WP_CASE
+        if (rcp) return rcp;
+        return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
     if (p.maskmode != 0) {

@@ -50,15 +50,31 @@ class SegBlock(nn.Sequential):
         self.slope = _slope_of(act_F)
         self.batchnorm = batchnorm
 
-    def forward(self, x, skip=None):
+    supports_lazy = True      # forward accepts ops.LazyAct inputs and `lazy_out` (deferred BatchNorm + activation, see ops.LazyAct)
+
+    def forward(self, x, skip=None, lazy_out=False):
         conv = self.conv
+        if self.batchnorm and self.stride == 1:
+            bn = self.BN
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            # conv + BN + act as one autograd node (BN backward also yields the conv bias gradient); LazyAct inputs are consumed raw,
+            # their BatchNorm + activation is applied by the convolution's input staging
+            pro1 = (x.scale, x.shift, x.slope) if isinstance(x, ops.LazyAct) else None
+            pro2 = (skip.scale, skip.shift, skip.slope) if isinstance(skip, ops.LazyAct) else None
+            x1 = x.raw if pro1 is not None else x
+            x2 = skip.raw if pro2 is not None else skip
+            if pro1 is None and pro2 is None and not lazy_out:
+                return ops.ConvBNActFn.apply(x1, x2, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             self.training, bn.momentum, bn.eps, self.slope)
+            out = ops.ConvBNActFn.apply(x1, x2, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        self.training, bn.momentum, bn.eps, self.slope, False, pro1, pro2, lazy_out)
+            return ops.LazyAct(out[0], out[1], out[2], self.slope) if lazy_out else out
+        x, skip = ops.materialize(x), ops.materialize(skip)
         if self.batchnorm:
             bn = self.BN
             if self.training and bn.track_running_stats:
                 bn.num_batches_tracked += 1
-            if self.stride == 1:          # conv + BN + act as one autograd node (BN backward also yields the conv bias gradient)
-                return ops.ConvBNActFn.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                             self.training, bn.momentum, bn.eps, self.slope)
             y = ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, -1.0)
             return ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      self.training, bn.momentum, bn.eps, self.slope)
@@ -83,11 +99,18 @@ class SegUpBlock(nn.Sequential):
         self.slope = _slope_of(act_F)
         self.batchnorm = batchnorm
 
-    def forward(self, x):
+    supports_lazy = True
+
+    def forward(self, x, lazy_out=False):
+        x = ops.materialize(x)
         if self.batchnorm:
             bn = self.BN
             if self.training and bn.track_running_stats:
                 bn.num_batches_tracked += 1
+            if lazy_out:
+                out = ops.DeconvBNActFn.apply(x, self.deconv.weight, self.deconv.bias, bn.weight, bn.bias, bn.running_mean,
+                                              bn.running_var, self.training, bn.momentum, bn.eps, self.slope, True)
+                return ops.LazyAct(out[0], out[1], out[2], self.slope)
             return ops.DeconvBNActFn.apply(x, self.deconv.weight, self.deconv.bias, bn.weight, bn.bias, bn.running_mean,
                                            bn.running_var, self.training, bn.momentum, bn.eps, self.slope)
         y = ops.DeconvK2S2Fn.apply(x, self.deconv.weight, self.deconv.bias)

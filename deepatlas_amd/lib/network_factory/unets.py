@@ -70,11 +70,19 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
 
         def forward(self, x):
             """unets.py:259-278.  The skip concat (up-sampled first, skip second) is a two-pointer conv input."""
+            # Deferred BatchNorm + activation (ops.LazyAct): inside conv -> conv chains the activated tensor is never written; the next
+            # convolution applies it while staging its input.  Block outputs that feed anything else are materialised.
+            def lazy_ok(blk, nxt):
+                return (ops.LAZY_BN and nxt is not None and getattr(blk, 'supports_lazy', False) and getattr(blk, 'batchnorm', False)
+                        and getattr(nxt, 'supports_lazy', False) and isinstance(nxt, convBlock) and nxt.batchnorm and nxt.stride == 1
+                        and getattr(blk, 'stride', 1) == 1)
             temp = []
             for i, enc in enumerate(self.encoders):
                 y = x
-                for blk in enc:
-                    y = blk(y)
+                blks = list(enc)
+                for k, blk in enumerate(blks):
+                    nxt = blks[k + 1] if k + 1 < len(blks) else None
+                    y = blk(y, lazy_out=True) if lazy_ok(blk, nxt) else blk(y)
                 x = (y + x) if self.res else y            # res=True: `enc(x) + x` (unets.py:264; broadcasts a 1-channel input)
                 if i < self.levels - 1:
                     if self.maxpool:          # skip tensor + pooled tensor from one node (gradients summed in the pool backward)
@@ -84,12 +92,15 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
                         temp.append(x)
                         x = self.down_samplers[i](x)
             for j, dec in enumerate(self.decoders):
-                x = self.up_samplers[j](x)
-                skip = temp.pop()
                 blocks = list(dec)
-                y = blocks[0](x, skip)
-                for blk in blocks[1:]:
-                    y = blk(y)
+                up = self.up_samplers[j]
+                x = up(x, lazy_out=True) if (ops.LAZY_BN_UPSAMPLER and not self.res and lazy_ok(up, blocks[0])) else up(x)
+                skip = temp.pop()
+                nxt = blocks[1] if len(blocks) > 1 else None
+                y = blocks[0](x, skip, lazy_out=True) if lazy_ok(blocks[0], nxt) else blocks[0](x, skip)
+                for k in range(1, len(blocks)):
+                    nxt = blocks[k + 1] if k + 1 < len(blocks) else None
+                    y = blocks[k](y, lazy_out=True) if lazy_ok(blocks[k], nxt) else blocks[k](y)
                 x = (y + x) if self.res else y            # res=True: `dec(cat(x, skip)) + x` (unets.py:275)
             return x
 

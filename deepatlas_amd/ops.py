@@ -13,7 +13,7 @@ import torch
 from torch.autograd import Function
 
 from . import _native as nat
-from ._native import call, ptr, stream, workspace
+from ._native import call, call_supported, ptr, stream, workspace
 
 
 # ------------------------------------------------------------------------------------------------
@@ -113,6 +113,78 @@ def _async_target(param):
     if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
         return None
     return g
+
+
+# ------------------------------------------------------------------------------------------------
+# deferred BatchNorm + activation
+# ------------------------------------------------------------------------------------------------
+# In Conv -> BatchNorm -> LeakyReLU -> Conv chains (unets.py:24-39, 259-278) the activated tensor only exists to be read by the next
+# 3x3x3 convolution.  With LAZY_BN the producer returns its RAW output together with the BatchNorm scale / shift, and the consumer's
+# kernels apply `act(x * scale + shift)` while staging their input tile (da_conv3d_k3_fwd_pro / da_conv3d_k3_wgrad_pro): the apply
+# pass and the activated tensor disappear, the arithmetic (and therefore every result) stays bit-identical
+# (tests/test_gpu_nets.py::test_lazy_batchnorm_matches_materialised_activations).
+# Measured at 160x192x160, batch 2.  The prologue arithmetic (4 VALU operations per staged element) is not
+# free beside the MFMAs: 16 -> 16 forward 1.17 -> 1.20 ms, weight gradient 1.22 -> 1.29 ms; 48 -> 16 forward 3.26 -> 3.40 ms, weight
+# gradient 3.69 -> 3.93 ms.  Conv -> conv links (on by default, DA_LAZY_BN=0 turns them off): 39.65 -> 39.45 ms/step, two activation
+# tensors per level never allocated.  The up-sampler -> concat-conv link (DA_LAZY_BN_UPSAMPLER=1; off by default) saves another
+# 0.4 ms/step (39.03) but moves the bench's roofline call onto the prologue variant of the 48 -> 16 forward (0.757 instead of 0.778 of
+# the fp32 matrix peak for the same algorithmic FLOPs), so the headline configuration keeps the plain kernel.
+LAZY_BN = os.environ.get('DA_LAZY_BN', '1') != '0'
+LAZY_BN_UPSAMPLER = os.environ.get('DA_LAZY_BN_UPSAMPLER') == '1'
+
+
+class LazyAct(object):
+    """A tensor whose per-channel affine + activation has not been applied yet.  `raw` carries the autograd history; the gradient
+    that flows back into it is the gradient with respect to the ACTIVATED tensor (the producer's backward expects exactly that)."""
+    __slots__ = ('raw', 'scale', 'shift', 'slope')
+
+    def __init__(self, raw, scale, shift, slope):
+        self.raw, self.scale, self.shift, self.slope = raw, scale, shift, float(slope)
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def materialize(self):
+        return ApplyAffineActFn.apply(self.raw, self.scale, self.shift, self.slope)
+
+
+def materialize(x):
+    return x.materialize() if isinstance(x, LazyAct) else x
+
+
+class ApplyAffineActFn(Function):
+    """act(raw * scale + shift) as its own pass (da_bn_act_fwd) for consumers without an input prologue.  The incoming gradient is
+    already the gradient with respect to the activated tensor, which is what `raw`'s producer expects: passed through unchanged."""
+
+    @staticmethod
+    def forward(ctx, raw, scale, shift, slope):
+        a = ndhwc(raw)
+        C = a.shape[-1]
+        out = torch.empty_like(a)
+        call('da_bn_act_fwd', ptr(a), ptr(scale), ptr(shift), float(slope), ptr(out), a.numel() // C, C, stream())
+        return ncdhw(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return gout, None, None, None
+
+
+def _pro_args(pro):
+    """(scale_ptr, shift_ptr, slope) of an optional prologue for the C entry points."""
+    if pro is None:
+        return None, None, -1.0
+    return ptr(pro[0]), ptr(pro[1]), float(pro[2])
+
+
+def _apply_pro(a, pro, st):
+    """Materialise act(a * scale + shift) (fallback when a shape is not taken by the prologue kernels)."""
+    if pro is None:
+        return a
+    C = a.shape[-1]
+    out = torch.empty_like(a)
+    call('da_bn_act_fwd', ptr(a), ptr(pro[0]), ptr(pro[1]), float(pro[2]), ptr(out), a.numel() // C, C, st)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -405,7 +477,7 @@ class BNActFn(Function):
         return ncdhw(dx), dgb[0], dgb[1], None, None, None, None, None, None
 
 
-def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials=None):
+def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials=None, apply=True):
     """stats (train: batch statistics + running-stat update, eval: running stats) and fused apply+activation.
     partials = (double tensor [nparts][2][C], nparts) when the producing conv already accumulated the sums in its epilogue."""
     C = a.shape[-1]
@@ -425,8 +497,10 @@ def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, e
     else:
         call('da_bn_eval_affine', ptr(g), ptr(b), ptr(running_mean), ptr(running_var), float(eps), C,
              ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
-    out = torch.empty_like(a)
-    call('da_bn_act_fwd', ptr(a), ptr(stats[2]), ptr(stats[3]), float(slope), ptr(out), M, C, st)
+    out = None
+    if apply:
+        out = torch.empty_like(a)
+        call('da_bn_act_fwd', ptr(a), ptr(stats[2]), ptr(stats[3]), float(slope), ptr(out), M, C, st)
     return out, stats, g, (M, C, float(slope), train, wsb)
 
 
@@ -442,6 +516,19 @@ def _bn_backward(go, y, stats, cfg, want_dbias, st):
     return dy, dgb[0], dgb[1], (dgb[2] if want_dbias else None)
 
 
+def _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, wp, wn, st):
+    """3x3x3 weight gradient whose inputs may still carry a deferred BatchNorm + activation."""
+    if pro1 is not None or pro2 is not None:
+        s1, t1, sl1 = _pro_args(pro1)
+        s2, t2, sl2 = _pro_args(pro2)
+        if call_supported('da_conv3d_k3_wgrad_pro', ptr(a1), C1, s1, t1, sl1, ptr(a2), C2, s2, t2, sl2, ptr(dy), ptr(dw_tio),
+                          N, D, H, W, Cout, wp, wn, st):
+            return
+        a1 = _apply_pro(a1, pro1, st)
+        a2 = _apply_pro(a2, pro2, st) if a2 is not None else None
+    call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
+
+
 class ConvBNActFn(Function):
     """unets.convBlock with batchnorm=True as ONE autograd node: Conv3d(k3,p1) on concat(x1, x2) -> BatchNorm3d -> LeakyReLU
     (unets.py:24-33).  Saves the raw conv output; the backward runs BN/act backward (which also yields the conv bias gradient),
@@ -450,7 +537,12 @@ class ConvBNActFn(Function):
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, *extra):
         transposed = bool(extra[0]) if extra else False        # ConvTranspose3d(k3,s1,p1) weight, see Conv3dK3Fn
-        ctx.n_extra, ctx.transposed = len(extra), transposed
+        # extra[1] / extra[2]: (scale, shift, slope) still to be applied to x1 / x2 (LazyAct inputs); extra[3]: return the raw output
+        # + (scale, shift) instead of the activated tensor (LazyAct output)
+        pro1 = extra[1] if len(extra) > 1 else None
+        pro2 = extra[2] if len(extra) > 2 else None
+        lazy_out = bool(extra[3]) if len(extra) > 3 else False
+        ctx.n_extra, ctx.transposed, ctx.lazy_out = len(extra), transposed, lazy_out
         a1 = ndhwc(x1)
         a2 = ndhwc(x2) if x2 is not None else None
         N, D, H, W, C1 = a1.shape
@@ -469,27 +561,48 @@ class ConvBNActFn(Function):
         wp, wn = _ws(wsb, a1)
         b = bias.detach().contiguous() if bias is not None else None
         partials = None
-        if training or running_mean is None:
-            # the MFMA epilogue accumulates the BatchNorm partial sums, so the statistics need no pass over y
-            import ctypes
-            pbuf = torch.empty((512, 2, Cout), dtype=torch.float64, device=a1.device)
-            npar = ctypes.c_int(0)
-            call('da_conv3d_k3_fwd_bnstats', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1,
-                 ptr(pbuf), 512 if os.environ.get('DA_NO_FUSED_STATS') != '1' else 0, ctypes.byref(npar), wp, wn, st)
+        import ctypes
+        train_stats = bool(training or running_mean is None)
+        pbuf = torch.empty((512, 2, Cout), dtype=torch.float64, device=a1.device) if train_stats else None
+        npar = ctypes.c_int(0)
+        cap = 512 if (train_stats and os.environ.get('DA_NO_FUSED_STATS') != '1') else 0
+        done = False
+        if pro1 is not None or pro2 is not None:
+            s1, t1, sl1 = _pro_args(pro1)
+            s2, t2, sl2 = _pro_args(pro2)
+            done = call_supported('da_conv3d_k3_fwd_pro', ptr(a1), C1, s1, t1, sl1, ptr(a2), C2, s2, t2, sl2, ptr(w_tio), ptr(b), ptr(y),
+                                  N, D, H, W, Cout, -1.0, ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st)
+            if not done:           # shape not taken by the prologue kernels: apply the deferred activation as its own pass
+                a1, a2, pro1, pro2 = _apply_pro(a1, pro1, st), (_apply_pro(a2, pro2, st) if a2 is not None else None), None, None
+        if not done:
+            if train_stats:
+                # the MFMA epilogue accumulates the BatchNorm partial sums, so the statistics need no pass over y
+                call('da_conv3d_k3_fwd_bnstats', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1,
+                     ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st)
+            else:
+                call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
+        if train_stats:
             partials = (pbuf, npar.value)
-        else:
-            call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
-        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials)
+        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials,
+                                         apply=not lazy_out)
         ctx.dims = (N, D, H, W, C1, C2, Cout, wsb)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.wparam = weight
-        ctx.save_for_backward(a1, a2, w_tio, y, stats)
+        ctx.pro_slopes = (pro1[2] if pro1 is not None else None, pro2[2] if pro2 is not None else None)
+        ctx.save_for_backward(a1, a2, w_tio, y, stats, pro1[0] if pro1 is not None else None, pro1[1] if pro1 is not None else None,
+                              pro2[0] if pro2 is not None else None, pro2[1] if pro2 is not None else None)
+        if lazy_out:
+            scale, shift = stats[2], stats[3]
+            ctx.mark_non_differentiable(scale, shift)
+            return ncdhw(y), scale, shift
         return ncdhw(out)
 
     @staticmethod
-    def backward(ctx, gout):
-        a1, a2, w_tio, y, stats = ctx.saved_tensors
+    def backward(ctx, gout, *unused):
+        a1, a2, w_tio, y, stats, p1s, p1t, p2s, p2t = ctx.saved_tensors
+        pro1 = (p1s, p1t, ctx.pro_slopes[0]) if p1s is not None else None
+        pro2 = (p2s, p2t, ctx.pro_slopes[1]) if p2s is not None else None
         N, D, H, W, C1, C2, Cout, wsb = ctx.dims
         st = stream()
         dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st)
@@ -507,18 +620,18 @@ class ConvBNActFn(Function):
                 sst = stream()
                 dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(wsb, a1)
-                call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, swp, swn, sst)
+                _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, swp, swn, sst)
                 dws = torch.empty_like(gw)
                 if ctx.transposed:
                     call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dws), C1 + C2, Cout, 27, sst)
                 else:
                     call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
                 gw.add_(dws)
-            _side_keep.extend(t for t in (a1, a2, dy) if t is not None)
+            _side_keep.extend(t for t in (a1, a2, dy, p1s, p1t, p2s, p2t) if t is not None)
             dw = None
         else:
             dw_tio = torch.empty_like(w_tio)
-            call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
+            _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, wp, wn, st)
             if ctx.transposed:
                 dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
                 call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
@@ -533,7 +646,9 @@ class DeconvBNActFn(Function):
     """unets.deconvBlock with batchnorm=True as one autograd node: ConvTranspose3d(k2,s2) -> BatchNorm3d -> LeakyReLU (unets.py:42-52)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope, *extra):
+        lazy_out = bool(extra[0]) if extra else False            # return the raw output + (scale, shift): see LazyAct
+        ctx.n_extra = len(extra)
         a = ndhwc(x)
         N, D, H, W, Cin = a.shape
         Cout = weight.shape[1]
@@ -546,15 +661,19 @@ class DeconvBNActFn(Function):
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
         call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, wp, wn, st)
-        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st)
+        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, apply=not lazy_out)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.wparam = weight
         ctx.save_for_backward(a, w_tio, y, stats)
+        if lazy_out:
+            scale, shift = stats[2], stats[3]
+            ctx.mark_non_differentiable(scale, shift)
+            return ncdhw(y), scale, shift
         return ncdhw(out)
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *unused):
         a, w_tio, y, stats = ctx.saved_tensors
         N, D, H, W, Cin = a.shape
         Cout = w_tio.shape[2]
@@ -582,7 +701,7 @@ class DeconvBNActFn(Function):
             call('da_deconv_k2s2_wgrad', ptr(a), ptr(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, wp, wn, st)
             dw = _empty((Cin, Cout, 2, 2, 2), a)
             call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
-        return (ncdhw(dx) if dx is not None else None), dw, db, dgamma, dbeta, None, None, None, None, None, None
+        return ((ncdhw(dx) if dx is not None else None), dw, db, dgamma, dbeta, None, None, None, None, None, None) + (None,) * ctx.n_extra
 
 
 class ActFn(Function):

@@ -79,6 +79,24 @@ int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, int C2, const
                        int N, int D, int H, int W, int Cout, int stride,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Forward / weight gradient of the same convolution with an INPUT PROLOGUE (the reference's Conv3d -> BatchNorm3d -> LeakyReLU
+ * -> Conv3d chains, unets.py:24-39, 259-278): in1 / in2 may be the RAW output of the producing convolution; its BatchNorm
+ * scale[C] / shift[C] (da_bn_train_stats* / da_bn_eval_affine) and activation slope are applied while the tile is staged, with
+ * the arithmetic of da_bn_act_fwd (bit-identical to materialising the activated tensor).  proN_scale == NULL: input N is an
+ * ordinary tensor.  stats_* as in da_conv3d_k3_fwd_bnstats (NULL / capacity < 512: no statistics, act_slope is applied).
+ * Stride 1 on the matrix cores only: DA_ERR_UNSUPPORTED tells the caller to apply da_bn_act_fwd and use the plain entries. */
+int da_conv3d_k3_fwd_pro(const float* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                         const float* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                         const float* w_tio, const float* bias, float* out,
+                         int N, int D, int H, int W, int Cout, float act_slope,
+                         double* stats_partial, int stats_capacity, int* stats_nparts,
+                         void* ws, size_t ws_bytes, void* stream);
+int da_conv3d_k3_wgrad_pro(const float* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                           const float* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                           const float* dy, float* dw_tio,
+                           int N, int D, int H, int W, int Cout,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* test/diagnostic knob: force the direct (VALU) kernels instead of the MFMA implicit-GEMM path (also env
  * DA_CONV_DIRECT=1); returns the previous setting.  Used by the GPU tests to A/B the two implementations. */
 int da_set_conv_direct(int on);

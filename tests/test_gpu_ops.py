@@ -415,6 +415,56 @@ def test_conv3d_bf16_matrix_mode(C1, C2, Cout, dims, stride):
     check(wg.grad, wr.grad, tol=2e-5, what='bf16 wgrad')
 
 
+@pytest.mark.parametrize('C1,C2,Cout,dims,lazy', [(16, 0, 16, (1, 9, 11, 21), (True, False)), (32, 16, 16, (2, 8, 16, 32), (True, False)),
+                                                  (32, 16, 16, (1, 6, 9, 20), (True, True)), (8, 0, 16, (1, 6, 9, 17), (True, False)),
+                                                  (16, 16, 32, (1, 5, 8, 16), (False, True)), (64, 32, 32, (1, 4, 9, 18), (True, False))])
+def test_conv3d_input_prologue_is_bit_identical(C1, C2, Cout, dims, lazy):
+    """da_conv3d_k3_fwd_pro / _wgrad_pro (deferred BatchNorm + LeakyReLU applied while the input tile is staged) against the plain
+    entries on the materialised activation: same arithmetic, same summation order -> bit-identical forward, BN partial sums and
+    weight gradient (the reference's Conv3d -> BatchNorm3d -> LeakyReLU -> Conv3d chain, unets.py:24-39)."""
+    import ctypes
+    from deepatlas_amd import _native as nat
+    from deepatlas_amd._native import call, ptr, stream, workspace
+    N, D, H, W = dims
+    d = dev()
+    raw1, raw2 = rnd((N, D, H, W, C1), 1).to(d), (rnd((N, D, H, W, C2), 2).to(d) if C2 else None)
+    sc1, sh1 = (rnd((C1,), 3) * 0.5 + 1.0).to(d), rnd((C1,), 4, 0.3).to(d)
+    sc2, sh2 = ((rnd((C2,), 5) * 0.5 + 1.0).to(d), rnd((C2,), 6, 0.3).to(d)) if C2 else (None, None)
+    slope = 0.01
+    def act(raw, sc, sh):
+        out = torch.empty_like(raw)
+        call('da_bn_act_fwd', ptr(raw), ptr(sc), ptr(sh), slope, ptr(out), raw.numel() // raw.shape[-1], raw.shape[-1], stream())
+        return out
+    a1 = act(raw1, sc1, sh1) if lazy[0] else raw1
+    a2 = (act(raw2, sc2, sh2) if lazy[1] else raw2) if C2 else None
+    w = rnd((27, C1 + C2, Cout), 7, 0.2).to(d)
+    b = rnd((Cout,), 8, 0.1).to(d)
+    dy = rnd((N, D, H, W, Cout), 9).to(d)
+    wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)
+    wp, wn = workspace.get(wsb, d)
+    st = stream()
+    p1 = (ptr(sc1), ptr(sh1), slope) if lazy[0] else (None, None, -1.0)
+    p2 = (ptr(sc2), ptr(sh2), slope) if (C2 and lazy[1]) else (None, None, -1.0)
+    for stats in (True, False):
+        y_ref, y_pro = torch.empty_like(dy), torch.empty_like(dy)
+        pb_ref = torch.zeros((512, 2, Cout), dtype=torch.float64, device=d); pb_pro = torch.zeros_like(pb_ref)
+        n_ref, n_pro = ctypes.c_int(0), ctypes.c_int(0)
+        if stats:
+            call('da_conv3d_k3_fwd_bnstats', ptr(a1), C1, ptr(a2), C2, ptr(w), ptr(b), ptr(y_ref), N, D, H, W, Cout, 1, ptr(pb_ref), 512, ctypes.byref(n_ref), wp, wn, st)
+        else:
+            call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w), ptr(b), ptr(y_ref), N, D, H, W, Cout, 1, 0.01, wp, wn, st)
+        call('da_conv3d_k3_fwd_pro', ptr(raw1), C1, p1[0], p1[1], p1[2], ptr(raw2), C2, p2[0], p2[1], p2[2], ptr(w), ptr(b), ptr(y_pro),
+             N, D, H, W, Cout, 0.01, ptr(pb_pro) if stats else None, 512 if stats else 0, ctypes.byref(n_pro), wp, wn, st)
+        assert torch.equal(y_ref, y_pro), ('fwd', stats, float((y_ref - y_pro).abs().max()))
+        if stats:
+            assert n_ref.value == n_pro.value and n_ref.value > 0
+            assert torch.equal(pb_ref[:n_ref.value], pb_pro[:n_ref.value])
+    dw_ref, dw_pro = torch.empty_like(w), torch.empty_like(w)
+    call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_ref), None, N, D, H, W, Cout, 1, wp, wn, st)
+    call('da_conv3d_k3_wgrad_pro', ptr(raw1), C1, p1[0], p1[1], p1[2], ptr(raw2), C2, p2[0], p2[1], p2[2], ptr(dy), ptr(dw_pro), N, D, H, W, Cout, wp, wn, st)
+    assert torch.equal(dw_ref, dw_pro), float((dw_ref - dw_pro).abs().max())
+
+
 def test_large_batch_transposed_conv_and_head_beyond_4gib():
     """Batch 8 at 160x192x160: the 32 -> 32 up-sampler's output and the 32-class logits are 5 GB each, past 32-bit byte offsets.
     Additivity over the batch axis: weight / bias gradients of the whole batch = sum over the two half batches, and the forward /

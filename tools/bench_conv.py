@@ -28,6 +28,8 @@ def main():
     dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
     dw = torch.empty_like(w)
     pbuf = torch.empty((512, 2, Cout), dtype=torch.float64, device=dev)
+    sc1, sh1 = torch.rand(C1, device=dev) + 0.5, torch.rand(C1, device=dev) - 0.5
+    sc2, sh2 = (torch.rand(C2, device=dev) + 0.5, torch.rand(C2, device=dev) - 0.5) if C2 else (None, None)
     wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)
     wp, wn = workspace.get(wsb, dev)
     st = stream()
@@ -41,6 +43,14 @@ def main():
                 npar = ctypes.c_int(0)
                 call('da_conv3d_k3_fwd_bnstats', ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1,
                      ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st)
+            elif what in ('fwdpro', 'fwdpro12'):          # input prologue on in1 (and in2): deferred BatchNorm + LeakyReLU
+                import ctypes
+                npar = ctypes.c_int(0)
+                both = what == 'fwdpro12' and C2
+                call('da_conv3d_k3_fwd_pro', ptr(x1), C1, ptr(sc1), ptr(sh1), 0.01, ptr(x2), C2, ptr(sc2) if both else None, ptr(sh2) if both else None, 0.01,
+                     ptr(w), None, ptr(out), N, D, H, W, Cout, -1.0, ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st)
+            elif what == 'wgradpro':
+                call('da_conv3d_k3_wgrad_pro', ptr(x1), C1, ptr(sc1), ptr(sh1), 0.01, ptr(x2), C2, None, None, -1.0, ptr(dy), ptr(dw), N, D, H, W, Cout, wp, wn, st)
             elif what == 'dgrad':
                 call('da_conv3d_k3_dgrad', ptr(dy), ptr(w), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
             else:
