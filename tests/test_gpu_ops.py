@@ -418,10 +418,22 @@ def test_conv3d_bf16_matrix_mode(C1, C2, Cout, dims, stride):
 @pytest.mark.parametrize('C1,C2,Cout,dims,lazy', [(16, 0, 16, (1, 9, 11, 21), (True, False)), (32, 16, 16, (2, 8, 16, 32), (True, False)),
                                                   (32, 16, 16, (1, 6, 9, 20), (True, True)), (8, 0, 16, (1, 6, 9, 17), (True, False)),
                                                   (16, 16, 32, (1, 5, 8, 16), (False, True)), (64, 32, 32, (1, 4, 9, 18), (True, False))])
-def test_conv3d_input_prologue_is_bit_identical(C1, C2, Cout, dims, lazy):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_conv3d_input_prologue_is_bit_identical(C1, C2, Cout, dims, lazy, precision):
     """da_conv3d_k3_fwd_pro / _wgrad_pro (deferred BatchNorm + LeakyReLU applied while the input tile is staged) against the plain
     entries on the materialised activation: same arithmetic, same summation order -> bit-identical forward, BN partial sums and
     weight gradient (the reference's Conv3d -> BatchNorm3d -> LeakyReLU -> Conv3d chain, unets.py:24-39)."""
+    import ctypes
+    from deepatlas_amd import _native as nat, ops
+    from deepatlas_amd._native import call, ptr, stream, workspace
+    prev_precision = ops.set_matrix_precision(precision)      # bf16 mode: the rounding happens after the prologue, on identical values
+    try:
+        _prologue_case(C1, C2, Cout, dims, lazy)
+    finally:
+        ops.set_matrix_precision(prev_precision)
+
+
+def _prologue_case(C1, C2, Cout, dims, lazy):
     import ctypes
     from deepatlas_amd import _native as nat
     from deepatlas_amd._native import call, ptr, stream, workspace
