@@ -44,23 +44,34 @@ __global__ void tio_to_w_kernel(const float* __restrict__ src, float* __restrict
 
 }  // namespace
 
+// out[o] = sum over partial sets b of partial[b][o], in double, in a fixed order (deterministic).  16 outputs x 16 set-groups per
+// block: a thread walks nparts / 16 sets (four loads in flight), the 16 group sums of an output meet in LDS.  The partial sets of
+// a weight gradient are a few MB and L2-resident; what matters is the length of the per-thread dependent chain, not bandwidth.
 __global__ void __launch_bounds__(256) da_reduce_partials_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
-    __shared__ double sh[4][64];
-    const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + ol;
-    double s0 = 0.0, s1 = 0.0;
+    __shared__ double sh[16][17];
+    const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + ol;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (o < O) {
         int b = sl;
-        for (; b + 4 < nparts; b += 8) { s0 += (double)partial[(size_t)b * O + o]; s1 += (double)partial[(size_t)(b + 4) * O + o]; }
-        for (; b < nparts; b += 4) s0 += (double)partial[(size_t)b * O + o];
+        for (; b + 48 < nparts; b += 64) {
+            s0 += (double)partial[(size_t)b * O + o]; s1 += (double)partial[(size_t)(b + 16) * O + o];
+            s2 += (double)partial[(size_t)(b + 32) * O + o]; s3 += (double)partial[(size_t)(b + 48) * O + o];
+        }
+        for (; b < nparts; b += 16) s0 += (double)partial[(size_t)b * O + o];
     }
-    sh[sl][ol] = s0 + s1;
+    sh[sl][ol] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sl == 0 && o < O) out[o] = (float)(sh[0][ol] + sh[1][ol] + sh[2][ol] + sh[3][ol]);
+    if (sl == 0 && o < O) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][ol];
+        out[o] = (float)t;
+    }
 }
 
 int da_reduce_partials(const float* partial, int nparts, int O, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(da_reduce_partials_kernel, dim3((O + 63) / 64), dim3(256), 0, st, partial, nparts, O, out);
+    hipLaunchKernelGGL(da_reduce_partials_kernel, dim3((O + 15) / 16), dim3(256), 0, st, partial, nparts, O, out);
     DA_LAUNCH_CHECK();
     return 0;
 }
