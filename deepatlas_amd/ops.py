@@ -509,11 +509,31 @@ def _bn_backward(go, y, stats, cfg, want_dbias, st):
     column sum of dy and is accumulated inside the apply pass."""
     M, C, slope, train, wsb = cfg
     dy = torch.empty_like(y)
-    dgb = _empty((3, C), y)
+    dgb = _empty((3, C), y)                   # rows: producer bias, gamma, beta -- the order the parameters have in a block
     wp, wn = _ws(wsb, y)
     call('da_bn_act_bwd_dbias', ptr(go), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-         slope, 1 if train else 0, ptr(dy), ptr(dgb[0]), ptr(dgb[1]), ptr(dgb[2]) if want_dbias else None, M, C, wp, wn, st)
-    return dy, dgb[0], dgb[1], (dgb[2] if want_dbias else None)
+         slope, 1 if train else 0, ptr(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, wp, wn, st)
+    return dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None)
+
+
+def _accumulate_small_grads(bias, gamma, beta, db, dgamma, dbeta):
+    """With ASYNC_WGRAD (gradients may be accumulated straight into FlatAdam's bucket): if bias / gamma / beta of a block sit next to
+    each other in the bucket (they do: conv.bias, BN.weight, BN.bias are consecutive parameters) their three gradients -- one (3, C)
+    tensor, see _bn_backward -- are added with ONE kernel instead of three autograd accumulations.  Returns the gradients still to
+    be handed to autograd (None where already accumulated)."""
+    if db is None or dgamma is None or dbeta is None or os.environ.get('DA_NO_SMALL_GRAD_FUSE') == '1':
+        return db, dgamma, dbeta
+    gb, gg, gbt = _async_target(bias), _async_target(gamma), _async_target(beta)
+    if gb is None or gg is None or gbt is None:
+        return db, dgamma, dbeta
+    C = db.numel()
+    if not (gb.numel() == gg.numel() == gbt.numel() == C and gg.data_ptr() == gb.data_ptr() + 4 * C and gbt.data_ptr() == gg.data_ptr() + 4 * C
+            and dgamma.data_ptr() == db.data_ptr() + 4 * C and dbeta.data_ptr() == dgamma.data_ptr() + 4 * C):
+        return db, dgamma, dbeta
+    dst = torch.as_strided(gb, (3 * C,), (1,))
+    src = torch.as_strided(db, (3 * C,), (1,))
+    dst.add_(src)
+    return None, None, None
 
 
 def _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, wp, wn, st):
@@ -589,6 +609,7 @@ class ConvBNActFn(Function):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.wparam = weight
+        ctx.small_params = (bias, gamma, beta)
         ctx.pro_slopes = (pro1[2] if pro1 is not None else None, pro2[2] if pro2 is not None else None)
         ctx.save_for_backward(a1, a2, w_tio, y, stats, pro1[0] if pro1 is not None else None, pro1[1] if pro1 is not None else None,
                               pro2[0] if pro2 is not None else None, pro2[1] if pro2 is not None else None)
@@ -638,6 +659,7 @@ class ConvBNActFn(Function):
             else:
                 dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
                 call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+        db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, db, dgamma, dbeta)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, dgamma, dbeta,
                 None, None, None, None, None, None) + (None,) * ctx.n_extra
 
@@ -665,6 +687,7 @@ class DeconvBNActFn(Function):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.wparam = weight
+        ctx.small_params = (bias, gamma, beta)
         ctx.save_for_backward(a, w_tio, y, stats)
         if lazy_out:
             scale, shift = stats[2], stats[3]
@@ -701,6 +724,7 @@ class DeconvBNActFn(Function):
             call('da_deconv_k2s2_wgrad', ptr(a), ptr(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, wp, wn, st)
             dw = _empty((Cin, Cout, 2, 2, 2), a)
             call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
+        db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, db, dgamma, dbeta)
         return ((ncdhw(dx) if dx is not None else None), dw, db, dgamma, dbeta, None, None, None, None, None, None) + (None,) * ctx.n_extra
 
 
