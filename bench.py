@@ -224,13 +224,16 @@ def main():
             try:
                 pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
                 # same kernel (+ per-workgroup BN partials; the input-prologue variant reads the same bytes, raw instead of activated)
-                kname = roofline['kernel'].replace('da_conv3d_k3_fwd_bnstats[', 'da_conv3d_k3_fwd[')
+                calls = json.load(open(pj))['calls']
+                kname = roofline['kernel']
                 if kname.startswith('da_conv3d_k3_fwd_pro['):
-                    kname = 'da_conv3d_k3_fwd[' + kname[len('da_conv3d_k3_fwd_pro['):].rsplit(',', 1)[0] + ', 1]'
-                rec = json.load(open(pj))['calls'].get(kname)
+                    kname = 'da_conv3d_k3_fwd_bnstats[' + kname[len('da_conv3d_k3_fwd_pro['):].rsplit(',', 1)[0] + ', 1]'
+                rec = calls.get(kname) or calls.get(kname.replace('da_conv3d_k3_fwd_bnstats[', 'da_conv3d_k3_fwd['))
                 if rec:
                     roofline['traffic'] = rec['traffic_bytes']
                     roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json (algorithmic %d B)' % rec['algorithmic_bytes']
+                    if 'sq' in rec:      # SQ_VALU_MFMA_BUSY_CYCLES of the same call: matrix-pipe busy rate per SIMD, against the 2.4 GHz peak clock
+                        roofline['mfma_busy_vs_peak_clock'] = round(rec['sq']['mfma_util_vs_2p4ghz_peak'], 4)
             except (OSError, ValueError, KeyError):
                 pass
         metric = 'training volumes/sec at 160x192x160 fp32; Dice vs CPU ref'          # BASELINE.json's metric (the default invocation)
