@@ -44,6 +44,7 @@ SIGNATURES = {
     'da_conv1x1_wgrad_ws_bytes': (SZ, [LL, I, I]),
     'da_conv1x1_wgrad': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
     'da_deconv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_deconv_k2s2_fwd_bnstats': (I, [P, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),
     'da_deconv_k2s2_dgrad': (I, [P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_deconv_k2s2_wgrad_ws_bytes': (SZ, [I, I, I, I, I, I]),
     'da_deconv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),

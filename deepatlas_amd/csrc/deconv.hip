@@ -211,6 +211,25 @@ extern "C" int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const flo
     return 0;
 }
 
+// Same, also producing the BatchNorm partial sums of the output in the epilogue ([stats_nparts][2][Cout] doubles for
+// da_bn_train_stats_from_partials).  *stats_nparts = 0 when the shape is not taken by the matrix-core kernel or the capacity is
+// too small: the output is still computed and the caller runs da_bn_train_stats over it.
+extern "C" int da_deconv_k2s2_fwd_bnstats(const float* in, const float* w_tio, const float* bias, float* out,
+                                          int N, int D, int H, int W, int Cin, int Cout,
+                                          double* stats_partial, int stats_capacity, int* stats_nparts,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (stats_nparts) *stats_nparts = 0;
+    if (!in || !w_tio || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    const long long nvox = (long long)N * D * H * W;
+    const long long nblk = da_cdiv(nvox, 256);
+    if (stats_partial && stats_nparts && da_pw_supported(Cin, Cout) && nblk <= stats_capacity) {
+        const int rc = da_pw_gemm(in, w_tio, 0, bias, out, nvox, D, H, W, Cin, Cout, 8, 1, 0, ws, ws_bytes, da_stream(stream), stats_partial);
+        if (rc == 0) *stats_nparts = (int)nblk;
+        return rc;
+    }
+    return da_deconv_k2s2_fwd(in, w_tio, bias, out, N, D, H, W, Cin, Cout, ws, ws_bytes, stream);
+}
+
 extern "C" int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
                                     int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w_tio || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;

@@ -25,6 +25,7 @@ struct PwP {
     int lda, ldo;           // row strides (floats) of A and out: the full channel counts when a launch covers a 64-wide slice
     int accum;              // != 0: out += (a later K slice of the same output slice); bias is then not added again
     int ntaps, up;
+    double* stats; int stats_ld;   // STATS: per-workgroup BatchNorm partial sums [gridDim.x][2][stats_ld] of this launch's Nc output columns
 };
 
 __device__ __forceinline__ long long fine0(long long v, int D, int H, int W) {
@@ -39,14 +40,20 @@ __device__ __forceinline__ long long tapoff(int t, int H, int W) {
 
 // SCATTER (GATHER == false): out[map(v,t)][n] = bias[n] + sum_k A[v][k] * B_t[k][n]      (conv1x1 fwd, deconv fwd)
 // GATHER  (GATHER == true) : out[v][n]        = sum_t sum_k A[map(v,t)][k] * B_t[k][n]   (conv1x1 dgrad, deconv dgrad)
-template <int KC, int NT, bool GATHER>
+// STATS (SCATTER only): the epilogue also accumulates the BatchNorm sums of everything this workgroup writes (per-lane fp32 over
+// the <= 16 values of a tap, then double), so the transposed conv + BatchNorm3d of unets.py:49-51 needs no statistics pass over y.
+template <int KC, int NT, bool GATHER, bool STATS = false>
 __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
+    static_assert(!(STATS && GATHER), "statistics are an epilogue of the scatter form");
     constexpr int MT = 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const long long vbase = ((long long)blockIdx.x * 4 + wave) * (MT * 16);
-    if (vbase >= p.M) return;
+    if (!STATS && vbase >= p.M) return;         // (STATS: every wave reaches the workgroup reduction; its rows are simply all invalid)
+    double d1[STATS ? NT : 1], d2[STATS ? NT : 1];
+#pragma unroll
+    for (int n = 0; n < (STATS ? NT : 1); ++n) { d1[n] = 0.0; d2[n] = 0.0; }
     const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + lane;
 
     long long arow[MT];            // A-row voxel (coarse; mapped to fine0 when the A side is the fine grid)
@@ -119,6 +126,37 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
                 }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < MT; ++r)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const float v = (orow[r][reg] >= 0) ? acc[r][n][reg] : 0.f;
+                            t1 += v; t2 += v * v;
+                        }
+                    d1[n] += (double)t1; d2[n] += (double)t2;
+                }
+            }
+        }
+        if constexpr (STATS) {
+            // lanes i, i+16, i+32, i+48 hold the same channel (16n + i): fold the four voxel groups, then the four waves through LDS
+            __shared__ double sred[4][2][NT * 16];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                double a = d1[n], b = d2[n];
+                a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                if (g == 0) { sred[wave][0][n * 16 + i] = a; sred[wave][1][n * 16 + i] = b; }
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < NT * 16) {
+                const int c = threadIdx.x;
+                p.stats[((size_t)blockIdx.x * 2 + 0) * p.stats_ld + c] = (sred[0][0][c] + sred[1][0][c]) + (sred[2][0][c] + sred[3][0][c]);
+                p.stats[((size_t)blockIdx.x * 2 + 1) * p.stats_ld + c] = (sred[0][1][c] + sred[1][1][c]) + (sred[2][1][c] + sred[3][1][c]);
+            }
         }
     } else {
 #pragma unroll
@@ -334,6 +372,7 @@ template <int KC, int NT>
 int launch_pw(const PwP& p, bool gather, hipStream_t st) {
     const unsigned grid = (unsigned)da_cdiv(p.M, 256);
     if (gather) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, true>), dim3(grid), dim3(256), 0, st, p);
+    else if (p.stats) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false, true>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false>), dim3(grid), dim3(256), 0, st, p);
     DA_LAUNCH_CHECK();
     return 0;
@@ -352,8 +391,9 @@ size_t da_pw_packed_bytes(int ntaps, int K, int N) { return da_align((size_t)nta
 // accumulated into it in stream order (accum: the accumulators start from the current output instead of the bias).
 int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
                long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
-               void* ws, size_t ws_bytes, hipStream_t st) {
+               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial) {
     if (!da_pw_supported(K, N)) return DA_ERR_UNSUPPORTED;
+    if (stats_partial && gather) return DA_ERR_BADARG;
     if (ws_bytes < da_pw_packed_bytes(ntaps, K, N)) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
     for (int n0 = 0; n0 < N; n0 += 64) {
@@ -366,6 +406,7 @@ int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias
             PwP p;
             p.a = a + k0; p.wp = wp; p.bias = bias ? bias + n0 : nullptr; p.out = out + n0; p.M = M; p.D = D; p.H = H; p.W = W;
             p.K = kk; p.Nc = nn; p.lda = K; p.ldo = N; p.accum = k0 > 0 ? 1 : 0; p.ntaps = ntaps; p.up = up;
+            p.stats = (stats_partial && k0 + 64 >= K) ? stats_partial + n0 : nullptr; p.stats_ld = N;      // statistics of the FINAL values: last K slice
             const int KC = kk / 16, NT = nn / 16;
             int rc = DA_ERR_UNSUPPORTED;
 #define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) rc = launch_pw<kc, nt>(p, gather != 0, st)

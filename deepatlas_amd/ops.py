@@ -682,8 +682,18 @@ class DeconvBNActFn(Function):
         y = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
-        call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, wp, wn, st)
-        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, apply=not lazy_out)
+        partials = None
+        if (training or running_mean is None) and os.environ.get('DA_NO_FUSED_STATS') != '1' and os.environ.get('DA_NO_FUSED_DECONV_STATS') != '1':
+            # the matrix-core epilogue accumulates the BatchNorm partial sums (one set per 256 coarse voxels): no statistics pass over y
+            import ctypes
+            nblk = (N * D * H * W + 255) // 256
+            pbuf = torch.empty((nblk, 2, Cout), dtype=torch.float64, device=a.device)
+            npar = ctypes.c_int(0)
+            call('da_deconv_k2s2_fwd_bnstats', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, ptr(pbuf), nblk, ctypes.byref(npar), wp, wn, st)
+            partials = (pbuf, npar.value)
+        else:
+            call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, wp, wn, st)
+        out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials, apply=not lazy_out)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.wparam = weight

@@ -122,6 +122,14 @@ int da_conv1x1_wgrad(const float* in, const float* dy, float* dw_io, float* dbia
 /* out[N][2D][2H][2W][Cout] = bias + sum_ci in[N][D][H][W][ci] * w_tio[tap(i,j,k)][ci][co] */
 int da_deconv_k2s2_fwd(const float* in, const float* w_tio, const float* bias, float* out,
                        int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* Same, with the BatchNorm3d partial sums of the output accumulated in the epilogue (unets.py:49-51: ConvTranspose3d ->
+ * BatchNorm3d): stats_partial[stats_nparts][2][Cout] doubles for da_bn_train_stats_from_partials; needs
+ * stats_capacity >= ceil(N*D*H*W / 256).  *stats_nparts == 0 on return: no statistics were produced (shape / capacity), run
+ * da_bn_train_stats over the output instead. */
+int da_deconv_k2s2_fwd_bnstats(const float* in, const float* w_tio, const float* bias, float* out,
+                               int N, int D, int H, int W, int Cin, int Cout,
+                               double* stats_partial, int stats_capacity, int* stats_nparts,
+                               void* ws, size_t ws_bytes, void* stream);
 int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
                          int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);

@@ -477,6 +477,39 @@ def _prologue_case(C1, C2, Cout, dims, lazy):
     assert torch.equal(dw_ref, dw_pro), float((dw_ref - dw_pro).abs().max())
 
 
+@pytest.mark.parametrize('Cin,Cout,dims', [(32, 32, (2, 8, 12, 10)), (16, 16, (1, 3, 5, 7)), (64, 32, (1, 5, 6, 9)), (128, 128, (1, 3, 4, 5)), (48, 80, (1, 2, 3, 17))])
+def test_deconv_fused_batchnorm_statistics(Cin, Cout, dims):
+    """da_deconv_k2s2_fwd_bnstats: same output as the plain entry (bit for bit) and per-channel sums / sums of squares of that output
+    in the epilogue partials (ragged last workgroup, 64-wide channel slices and K slices included)."""
+    import ctypes
+    from deepatlas_amd import _native as nat
+    from deepatlas_amd._native import call, ptr, stream, workspace
+    N, D, H, W = dims
+    d = dev()
+    x = rnd((N, D, H, W, Cin), 1).to(d)
+    w = rnd((8, Cin, Cout), 2, 0.3).to(d)
+    b = rnd((Cout,), 3, 0.1).to(d)
+    y0 = torch.empty((N, 2 * D, 2 * H, 2 * W, Cout), device=d)
+    y1 = torch.empty_like(y0)
+    wp, wn = workspace.get(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), d)
+    call('da_deconv_k2s2_fwd', ptr(x), ptr(w), ptr(b), ptr(y0), N, D, H, W, Cin, Cout, wp, wn, stream())
+    nblk = (N * D * H * W + 255) // 256
+    pbuf = torch.full((nblk, 2, Cout), float('nan'), dtype=torch.float64, device=d)
+    npar = ctypes.c_int(0)
+    call('da_deconv_k2s2_fwd_bnstats', ptr(x), ptr(w), ptr(b), ptr(y1), N, D, H, W, Cin, Cout, ptr(pbuf), nblk, ctypes.byref(npar), wp, wn, stream())
+    assert npar.value == nblk
+    assert torch.equal(y0, y1)
+    s = pbuf.sum(0).cpu()
+    ref = y0.double().reshape(-1, Cout).cpu()
+    # per-lane fp32 sums of <= 16 values, everything above in double: error bounded by 1e-6 of the sum of magnitudes
+    assert bool(((s[0] - ref.sum(0)).abs() <= 1e-6 * ref.abs().sum(0)).all())
+    assert bool(((s[1] - (ref * ref).sum(0)).abs() <= 1e-6 * (ref * ref).sum(0)).all())
+    # too small a capacity: output still produced, no statistics claimed
+    npar2 = ctypes.c_int(7)
+    call('da_deconv_k2s2_fwd_bnstats', ptr(x), ptr(w), ptr(b), ptr(y1), N, D, H, W, Cin, Cout, ptr(pbuf), nblk - 1, ctypes.byref(npar2), wp, wn, stream())
+    assert npar2.value == 0 and torch.equal(y0, y1)
+
+
 def test_large_batch_transposed_conv_and_head_beyond_4gib():
     """Batch 8 at 160x192x160: the 32 -> 32 up-sampler's output and the 32-class logits are 5 GB each, past 32-bit byte offsets.
     Additivity over the batch axis: weight / bias gradients of the whole batch = sum over the two half batches, and the forward /
