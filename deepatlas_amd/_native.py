@@ -40,6 +40,8 @@ SIGNATURES = {
     'da_set_matrix_bf16': (I, [I]),
     'da_pointwise_ws_bytes': (SZ, [I, I, I]),
     'da_conv1x1_fwd': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
+    'da_conv1x1_fwd_pro': (I, [P, P, P, F, P, P, P, LL, I, I, P, SZ, P]),
+    'da_conv1x1_wgrad_pro': (I, [P, P, P, F, P, P, P, LL, I, I, P, SZ, P]),
     'da_conv1x1_dgrad': (I, [P, P, P, LL, I, I, P, SZ, P]),
     'da_conv1x1_wgrad_ws_bytes': (SZ, [LL, I, I]),
     'da_conv1x1_wgrad': (I, [P, P, P, P, LL, I, I, P, SZ, P]),

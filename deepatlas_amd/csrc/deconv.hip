@@ -289,6 +289,29 @@ extern "C" int da_conv1x1_fwd(const float* in, const float* w_io, const float* b
     return 0;
 }
 
+// 1x1x1 convolution whose input is a RAW producer output: act(in * pro_scale + pro_shift) is what gets convolved (the deferred
+// BatchNorm + LeakyReLU of the last decoder block in front of the head, unets.py:249-250).  Matrix-core path only.
+extern "C" int da_conv1x1_fwd_pro(const float* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                  const float* w_io, const float* bias, float* out,
+                                  long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !pro_scale || !pro_shift || !w_io || !out || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm(in, w_io, 0, bias, out, M, 1, 1, 1, Cin, Cout, 1, 0, 0, ws, ws_bytes, da_stream(stream), nullptr, pro_scale, pro_shift, pro_slope);
+}
+
+extern "C" int da_conv1x1_wgrad_pro(const float* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                    const float* dy, float* dw_io, float* dbias,
+                                    long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !pro_scale || !pro_shift || !dy || !dw_io || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv1x1_wgrad_ws_bytes(M, Cin, Cout)) return DA_ERR_WS_SMALL;
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    const int rc = da_pw_wgrad(in, dy, dw_io, M, 1, 1, 1, Cin, Cout, 1, 0, ws, cs_off, da_stream(stream), pro_scale, pro_shift, pro_slope);
+    if (rc) return rc;
+    if (dbias) return da_colsum(dy, M, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
+    return 0;
+}
+
 extern "C" int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout,
                                 void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w_io || !dx || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;

@@ -8,7 +8,9 @@ size_t da_pw_packed_bytes(int ntaps, int K, int N);
 // SCATTER (gather == 0): out[map(v,t)][N] = bias + A[v][K] * B_t ; GATHER: out[v][N] = sum_t A[map(v,t)][K] * B_t
 int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
                long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
-               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial = nullptr);   // stats_partial: [cdiv(M,256)][2][N] BatchNorm sums (scatter form)
+               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial = nullptr,   // stats_partial: [cdiv(M,256)][2][N] BatchNorm sums (scatter form)
+               const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f);   // input prologue: act(a * scale + shift) is consumed
 size_t da_pw_wgrad_ws_bytes(long long M, int ntaps, int Cin, int Cout);
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
-                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st);
+                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st,
+                const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f);

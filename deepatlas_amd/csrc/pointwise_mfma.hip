@@ -26,7 +26,11 @@ struct PwP {
     int accum;              // != 0: out += (a later K slice of the same output slice); bias is then not added again
     int ntaps, up;
     double* stats; int stats_ld;   // STATS: per-workgroup BatchNorm partial sums [gridDim.x][2][stats_ld] of this launch's Nc output columns
+    const float* ps; const float* pt; float pslope;   // optional input prologue (scatter form): A is a raw tensor, act(A * ps + pt) is consumed
 };
+
+// max(z, z * s): LeakyReLU / ReLU for s in [0, 1), identity for s = 1 (same expression as the 3x3x3 kernels' prologue)
+__device__ __forceinline__ float pw_act01(float z, float s) { return fmaxf(z, z * s); }
 
 __device__ __forceinline__ long long fine0(long long v, int D, int H, int W) {
     const int w = (int)(v % W); long long r = v / W;
@@ -74,6 +78,17 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
 #pragma unroll
             for (int c = 0; c < KC; ++c)
                 a[r][c] = aval[r] ? *reinterpret_cast<const float4*>(p.a + arow[r] * p.lda + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.ps) {      // deferred BatchNorm + activation of the producer (rows past M are never stored, so they need no mask)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.ps + 16 * c + 4 * g), sf = *reinterpret_cast<const float4*>(p.pt + 16 * c + 4 * g);
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    a[r][c].x = pw_act01(a[r][c].x * sc.x + sf.x, p.pslope); a[r][c].y = pw_act01(a[r][c].y * sc.y + sf.y, p.pslope);
+                    a[r][c].z = pw_act01(a[r][c].z * sc.z + sf.z, p.pslope); a[r][c].w = pw_act01(a[r][c].w * sc.w + sf.w, p.pslope);
+                }
+            }
+        }
         // output rows of this lane: voxel 4*g + reg of every M-tile
         long long orow[MT][4];
 #pragma unroll
@@ -238,6 +253,7 @@ struct PwWgP {
     long long M; int D, H, W, Cin, Cout, ntaps, up;      // Cin / Cout: the (<= 64 wide) channel slices of this launch
     int ldi, ldy;                                        // row strides (floats): the full channel counts
     long long vox_per_wave;
+    const float* ps; const float* pt; float pslope;      // optional input prologue on `in` (see PwP)
 };
 
 template <int CIT, int COT, int TPB>
@@ -285,9 +301,14 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     unsigned toffb[TPB];
 #pragma unroll
     for (int t = 0; t < TPB; ++t) toffb[t] = (unsigned)(toffs[t] * p.ldy * 4);
-    auto fetch = [&](long long vb, float* av, float (*bv)[COT]) {
+    float psc[CIT], psf[CIT];
+#pragma unroll
+    for (int a = 0; a < CIT; ++a) { psc[a] = p.ps ? p.ps[i + 16 * a] : 1.f; psf[a] = p.ps ? p.pt[i + 16 * a] : 0.f; }
+    const bool pro = p.ps != nullptr;
+    auto fetch = [&](long long vb, float* av, float (*bv)[COT], bool& okout) {
         const long long v = vb + g;
         const bool ok = v < v1;
+        okout = ok;
         const unsigned offa = ok ? (unsigned)(((v - vblk) * p.ldi + i) * 4) : 0xFFFFFFFFu;
 #pragma unroll
         for (int a = 0; a < CIT; ++a)
@@ -305,11 +326,20 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
             for (int c = 0; c < COT; ++c)
                 bv[t][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ok ? offb + toffb[t] + 64u * c : 0xFFFFFFFFu, 0, 0));
     };
+    // the deferred activation is applied when a fragment is USED (one K-step after its loads were issued), never at fetch time
+    auto apply_pro = [&](float* av, bool ok) {
+        if (pro) {
+#pragma unroll
+            for (int a = 0; a < CIT; ++a) av[a] = ok ? pw_act01(av[a] * psc[a] + psf[a], p.pslope) : 0.f;
+        }
+    };
     float avA[CIT], bvA[TPB][COT], avB[CIT], bvB[TPB][COT];
-    if (v0 < v1) fetch(v0, avA, bvA);
+    bool okA = false, okB = false;
+    if (v0 < v1) fetch(v0, avA, bvA, okA);
 #pragma unroll 1
     for (long long vb = v0; vb < v1; vb += 8) {
-        fetch(vb + 4, avB, bvB);                    // past-the-end steps fetch zeros
+        fetch(vb + 4, avB, bvB, okB);               // past-the-end steps fetch zeros
+        apply_pro(avA, okA);
 #pragma unroll
         for (int t = 0; t < TPB; ++t)
 #pragma unroll
@@ -317,7 +347,8 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
 #pragma unroll
                 for (int c = 0; c < COT; ++c)
                     acc[a][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[a], bvA[t][c], acc[a][t][c], 0, 0, 0);
-        fetch(vb + 8, avA, bvA);
+        fetch(vb + 8, avA, bvA, okA);
+        apply_pro(avB, okB);
 #pragma unroll
         for (int t = 0; t < TPB; ++t)
 #pragma unroll
@@ -391,9 +422,10 @@ size_t da_pw_packed_bytes(int ntaps, int K, int N) { return da_align((size_t)nta
 // accumulated into it in stream order (accum: the accumulators start from the current output instead of the bias).
 int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
                long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
-               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial) {
+               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial, const float* pro_scale, const float* pro_shift, float pro_slope) {
     if (!da_pw_supported(K, N)) return DA_ERR_UNSUPPORTED;
-    if (stats_partial && gather) return DA_ERR_BADARG;
+    if ((stats_partial || pro_scale) && gather) return DA_ERR_BADARG;
+    if (pro_scale && (!pro_shift || pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_pw_packed_bytes(ntaps, K, N)) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
     for (int n0 = 0; n0 < N; n0 += 64) {
@@ -407,6 +439,7 @@ int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias
             p.a = a + k0; p.wp = wp; p.bias = bias ? bias + n0 : nullptr; p.out = out + n0; p.M = M; p.D = D; p.H = H; p.W = W;
             p.K = kk; p.Nc = nn; p.lda = K; p.ldo = N; p.accum = k0 > 0 ? 1 : 0; p.ntaps = ntaps; p.up = up;
             p.stats = (stats_partial && k0 + 64 >= K) ? stats_partial + n0 : nullptr; p.stats_ld = N;      // statistics of the FINAL values: last K slice
+            p.ps = pro_scale ? pro_scale + k0 : nullptr; p.pt = pro_scale ? pro_shift + k0 : nullptr; p.pslope = pro_slope < 0.f ? 1.f : pro_slope;
             const int KC = kk / 16, NT = nn / 16;
             int rc = DA_ERR_UNSUPPORTED;
 #define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) rc = launch_pw<kc, nt>(p, gather != 0, st)
@@ -460,14 +493,17 @@ static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
     return 0;
 }
 
+struct PwPro { const float* s; const float* t; float slope; };
 static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout, int ldi, int ldy,
-                          int ntaps, int up, void* ws, hipStream_t st);
+                          int ntaps, int up, void* ws, hipStream_t st, const PwPro& pro, int ci0);
 
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
-                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st, const float* pro_scale, const float* pro_shift, float pro_slope) {
     if (!da_pw_supported(Cin, Cout) || (ntaps != 1 && ntaps != 8)) return DA_ERR_UNSUPPORTED;
+    if (pro_scale && (!pro_shift || pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
+    const PwPro pro = {pro_scale, pro_shift, pro_slope < 0.f ? 1.f : pro_slope};
     if (ws_bytes < da_pw_wgrad_ws_bytes(M, ntaps, Cin, Cout)) return DA_ERR_WS_SMALL;
-    if (Cin <= 64 && Cout <= 64) return pw_wgrad_slice(in, dy, dw, M, D, H, W, Cin, Cout, Cin, Cout, ntaps, up, ws, st);
+    if (Cin <= 64 && Cout <= 64) return pw_wgrad_slice(in, dy, dw, M, D, H, W, Cin, Cout, Cin, Cout, ntaps, up, ws, st, pro, 0);
     // wide layers: independent 64 x 64 channel slices, each reduced into a dense scratch and placed into dW
     long long vpw;
     const size_t Os = (size_t)ntaps * 64 * 64;
@@ -476,7 +512,7 @@ int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D,
     for (int ci0 = 0; ci0 < Cin; ci0 += 64)
         for (int co0 = 0; co0 < Cout; co0 += 64) {
             const int cic = (Cin - ci0) < 64 ? (Cin - ci0) : 64, coc = (Cout - co0) < 64 ? (Cout - co0) : 64;
-            const int rc = pw_wgrad_slice(in + ci0, dy + co0, tmp, M, D, H, W, cic, coc, Cin, Cout, ntaps, up, ws, st);
+            const int rc = pw_wgrad_slice(in + ci0, dy + co0, tmp, M, D, H, W, cic, coc, Cin, Cout, ntaps, up, ws, st, pro, ci0);
             if (rc) return rc;
             hipLaunchKernelGGL(pw_place_kernel, dim3(da_grid((long long)ntaps * cic * coc, 256, 256)), dim3(256), 0, st, tmp, dw, ntaps, cic, coc, Cin, Cout, ci0, co0);
             DA_LAUNCH_CHECK();
@@ -485,8 +521,9 @@ int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D,
 }
 
 static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout, int ldi, int ldy,
-                          int ntaps, int up, void* ws, hipStream_t st) {
+                          int ntaps, int up, void* ws, hipStream_t st, const PwPro& pro, int ci0) {
     PwWgP p;
+    p.ps = pro.s ? pro.s + ci0 : nullptr; p.pt = pro.s ? pro.t + ci0 : nullptr; p.pslope = pro.slope;
     p.in = in; p.dy = dy; p.partial = (float*)ws; p.M = M; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ntaps = ntaps; p.up = up;
     p.ldi = ldi; p.ldy = ldy;
     const size_t O = (size_t)ntaps * Cin * Cout;

@@ -183,7 +183,11 @@ class UNetDecBlock(nn.Sequential):
 class HeadConv(nn.Conv3d):
     """nn.Conv3d(C, n_classes, 1) output layer (unets.py:249-250) -- keys '<idx>.weight', '<idx>.bias'."""
 
+    supports_lazy = True      # accepts an ops.LazyAct input (deferred BatchNorm + activation of the last decoder block)
+
     def forward(self, x):
+        if isinstance(x, ops.LazyAct):
+            return ops.Conv1x1Fn.apply(x.raw, self.weight, self.bias, (x.scale, x.shift, x.slope))
         return ops.Conv1x1Fn.apply(x, self.weight, self.bias)
 
 

@@ -74,8 +74,8 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
             # convolution applies it while staging its input.  Block outputs that feed anything else are materialised.
             def lazy_ok(blk, nxt):
                 return (ops.LAZY_BN and nxt is not None and getattr(blk, 'supports_lazy', False) and getattr(blk, 'batchnorm', False)
-                        and getattr(nxt, 'supports_lazy', False) and isinstance(nxt, convBlock) and nxt.batchnorm and nxt.stride == 1
-                        and getattr(blk, 'stride', 1) == 1)
+                        and getattr(nxt, 'supports_lazy', False) and getattr(blk, 'stride', 1) == 1
+                        and ((isinstance(nxt, convBlock) and nxt.batchnorm and nxt.stride == 1) or isinstance(nxt, HeadConv)))
             temp = []
             for i, enc in enumerate(self.encoders):
                 y = x

@@ -95,6 +95,20 @@ def join_side_stream():
         _side_keep.clear()
 
 
+def _serialize_matrix_kernels(flops):
+    """Called right before a LARGE matrix-bound data-gradient kernel is queued on the main stream: wait for the weight gradients
+    already queued on the side stream.  The conv kernels are persistent with a static tile partition, so one that starts while
+    another still holds half of every CU's LDS finishes as late as its last-started workgroup (the 48 <- 16 data gradient: 3.3 ms
+    alone, 4.9 ms when it starts 0.7 ms before the previous layer's weight gradient ends).  The side stream exists to overlap weight
+    gradients with the HBM-bound BatchNorm / pooling kernels in between, not with other MFMA kernels.  Only for kernels of >= 1 ms
+    (a cross-stream wait costs tens of microseconds)."""
+    if ASYNC_WGRAD and _side_stream is not None and flops >= _SERIALIZE_MIN_FLOPS:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+
+
+_SERIALIZE_MIN_FLOPS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_FLOPS', '1.2e11'))
+
+
 def _run_on_side(fn, keep_alive):
     """Run `fn()` on the side stream after everything queued so far on the current stream; `keep_alive` tensors stay referenced
     until the join."""
@@ -123,12 +137,12 @@ def _async_target(param):
 # kernels apply `act(x * scale + shift)` while staging their input tile (da_conv3d_k3_fwd_pro / da_conv3d_k3_wgrad_pro): the apply
 # pass and the activated tensor disappear, the arithmetic (and therefore every result) stays bit-identical
 # (tests/test_gpu_nets.py::test_lazy_batchnorm_matches_materialised_activations).
-# Measured at 160x192x160, batch 2.  The prologue arithmetic (4 VALU operations per staged element) is not
-# free beside the MFMAs: 16 -> 16 forward 1.17 -> 1.20 ms, weight gradient 1.22 -> 1.29 ms; 48 -> 16 forward 3.26 -> 3.40 ms, weight
-# gradient 3.69 -> 3.93 ms.  Conv -> conv links (on by default, DA_LAZY_BN=0 turns them off): 39.65 -> 39.45 ms/step, two activation
-# tensors per level never allocated.  The up-sampler -> concat-conv link (DA_LAZY_BN_UPSAMPLER=1; off by default) saves another
-# 0.4 ms/step (39.03) but moves the bench's roofline call onto the prologue variant of the 48 -> 16 forward (0.757 instead of 0.778 of
-# the fp32 matrix peak for the same algorithmic FLOPs), so the headline configuration keeps the plain kernel.
+# Measured at 160x192x160, batch 2.  In the HBM-bound head kernels the prologue is free; in the MFMA-bound 3x3x3
+# kernels its 4 VALU operations per staged element are not: 16 -> 16 forward 1.17 -> 1.20 ms, weight gradient 1.22 -> 1.29 ms; 48 -> 16
+# forward 3.26 -> 3.40 ms, weight gradient 3.69 -> 3.93 ms.  Conv -> conv and conv -> head links (on by default, DA_LAZY_BN=0 turns them
+# off): 39.15 -> 38.6 ms/step, and the activated tensors of those links are never allocated.  The up-sampler -> concat-conv link
+# (DA_LAZY_BN_UPSAMPLER=1; off by default) saves another 0.2 ms/step but moves the bench's roofline call onto the prologue variant of
+# the 48 -> 16 forward (0.757 instead of 0.778 of the fp32 matrix peak for the same algorithmic FLOPs).
 LAZY_BN = os.environ.get('DA_LAZY_BN', '1') != '0'
 LAZY_BN_UPSAMPLER = os.environ.get('DA_LAZY_BN_UPSAMPLER') == '1'
 
@@ -243,6 +257,7 @@ class Conv3dK3Fn(Function):
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
             dx1 = _empty(a1.shape, a1)
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
+            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3))
             call('da_conv3d_k3_dgrad', ptr(g), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, stride, wp, wn, st)
         dw = db = None
         gw, gb = _async_target(ctx.wparam), (_async_target(ctx.bparam) if ctx.has_bias else None)
@@ -281,7 +296,9 @@ class Conv1x1Fn(Function):
     """nn.Conv3d(Cin, Cout, 1): the segmentation head (unets.py:249-250)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, *extra):
+        pro = extra[0] if extra else None          # (scale, shift, slope) still to be applied to x (LazyAct input)
+        ctx.n_extra = len(extra)
         a = ndhwc(x)
         N, D, H, W, Cin = a.shape
         Cout = weight.shape[0]
@@ -292,14 +309,19 @@ class Conv1x1Fn(Function):
         M = N * D * H * W
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(1, Cin, Cout), a)
-        call('da_conv1x1_fwd', ptr(a), ptr(w_io), ptr(b), ptr(out), M, Cin, Cout, wp, wn, st)
+        if pro is not None and not call_supported('da_conv1x1_fwd_pro', ptr(a), ptr(pro[0]), ptr(pro[1]), float(pro[2]), ptr(w_io), ptr(b), ptr(out),
+                                                  M, Cin, Cout, wp, wn, st):
+            a, pro = _apply_pro(a, pro, st), None
+        if pro is None:
+            call('da_conv1x1_fwd', ptr(a), ptr(w_io), ptr(b), ptr(out), M, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(a, w_io)
+        ctx.pro_slope = pro[2] if pro is not None else None
+        ctx.save_for_backward(a, w_io, pro[0] if pro is not None else None, pro[1] if pro is not None else None)
         return ncdhw(out)
 
     @staticmethod
     def backward(ctx, gout):
-        a, w_io = ctx.saved_tensors
+        a, w_io, ps, pt = ctx.saved_tensors
         Cin, Cout = w_io.shape
         M = a.numel() // Cin
         st = stream()
@@ -315,10 +337,15 @@ class Conv1x1Fn(Function):
             dw_io = torch.empty_like(w_io)
             db = _empty((Cout,), a) if ctx.has_bias else None
             wp, wn = _ws(nat.lib().da_conv1x1_wgrad_ws_bytes(M, Cin, Cout), a)
-            call('da_conv1x1_wgrad', ptr(a), ptr(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
+            if ps is not None:
+                if not call_supported('da_conv1x1_wgrad_pro', ptr(a), ptr(ps), ptr(pt), float(ctx.pro_slope), ptr(g), ptr(dw_io), ptr(db),
+                                      M, Cin, Cout, wp, wn, st):
+                    call('da_conv1x1_wgrad', ptr(_apply_pro(a, (ps, pt, ctx.pro_slope), st)), ptr(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
+            else:
+                call('da_conv1x1_wgrad', ptr(a), ptr(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
             dw = _empty((Cout, Cin, 1, 1, 1), a)
             call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), Cout, Cin, 1, st)
-        return (ncdhw(dx) if dx is not None else None), dw, db
+        return ((ncdhw(dx) if dx is not None else None), dw, db) + (None,) * ctx.n_extra
 
 
 class DeconvK2S2Fn(Function):
@@ -632,6 +659,7 @@ class ConvBNActFn(Function):
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
             dx1 = _empty(a1.shape, a1)
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
+            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W)
             call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
         gw = _async_target(ctx.wparam)
         if gw is not None:

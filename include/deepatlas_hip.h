@@ -112,6 +112,15 @@ int da_set_matrix_bf16(int on);
 size_t da_pointwise_ws_bytes(int ntaps, int Cin, int Cout);
 int da_conv1x1_fwd(const float* in, const float* w_io, const float* bias, float* out,
                    long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* Head with an INPUT PROLOGUE (see da_conv3d_k3_fwd_pro): `in` is the raw output of the last decoder convolution and
+ * act(in * pro_scale + pro_shift) is what the 1x1x1 convolution consumes; same arithmetic as da_bn_act_fwd followed by the plain
+ * entries.  Channel counts in multiples of 16 (matrix-core kernels), else DA_ERR_UNSUPPORTED. */
+int da_conv1x1_fwd_pro(const float* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                       const float* w_io, const float* bias, float* out,
+                       long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_wgrad_pro(const float* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                         const float* dy, float* dw_io, float* dbias,
+                         long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int da_conv1x1_dgrad(const float* dy, const float* w_io, float* dx, long long M, int Cin, int Cout,
                      void* ws, size_t ws_bytes, void* stream);
 size_t da_conv1x1_wgrad_ws_bytes(long long M, int Cin, int Cout);

@@ -67,5 +67,21 @@ def main():
         print('  %-80s %8.3f ms  %5.1f %%' % (k, v / 1e6, 100 * v / wall))
 
 
+def dump_last_step(path, min_us=150.0):
+    """--dump: start / end / queue / duration of every kernel longer than min_us in the last optimiser step of the trace."""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end, queue_id from kernels order by start").fetchall()
+    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    seg = rows[adam[-2] + 1:adam[-1] + 1]
+    t0 = seg[0][1]
+    for n, s_, e, q in seg:
+        d = (e - s_) / 1e3
+        if d > min_us:
+            print('%7.3f -> %7.3f  q%d  %8.1f us  %s' % ((s_ - t0) / 1e6, (e - t0) / 1e6, q, d, short(n)[:60]))
+
+
 if __name__ == '__main__':
+    if '--dump' in sys.argv:
+        dump_last_step(sys.argv[1])
+        sys.exit(0)
     main()
