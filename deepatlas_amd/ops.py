@@ -95,18 +95,24 @@ def join_side_stream():
         _side_keep.clear()
 
 
+_last_side_flops = 0.0          # FLOPs of the weight gradient most recently queued on the side stream
+
+
 def _serialize_matrix_kernels(flops):
-    """Called right before a LARGE matrix-bound data-gradient kernel is queued on the main stream: wait for the weight gradients
-    already queued on the side stream.  The conv kernels are persistent with a static tile partition, so one that starts while
-    another still holds half of every CU's LDS finishes as late as its last-started workgroup (the 48 <- 16 data gradient: 3.3 ms
-    alone, 4.9 ms when it starts 0.7 ms before the previous layer's weight gradient ends).  The side stream exists to overlap weight
-    gradients with the HBM-bound BatchNorm / pooling kernels in between, not with other MFMA kernels.  Only for kernels of >= 1 ms
-    (a cross-stream wait costs tens of microseconds)."""
-    if ASYNC_WGRAD and _side_stream is not None and flops >= _SERIALIZE_MIN_FLOPS:
+    """Experiment switch, OFF by default (DA_MFMA_SERIALIZE_MIN_FLOPS=1.2e11 turns it on): before a matrix-bound data gradient of
+    at least that many FLOPs is queued on the main stream, wait for the side stream if the weight gradient queued there is much
+    shorter (<= DA_MFMA_SERIALIZE_MAX_RATIO of the FLOPs).  The conv kernels are persistent with a static tile partition, and a
+    long data gradient that starts while a short weight gradient drains its last workgroups can finish late (seen with
+    DA_LAZY_BN=0: the 48 <- 16 data gradient 3.3 -> 4.9 ms, 41.0 vs 39.1 ms per step with the wait).  But on the coarse, few-tile
+    layers of the full UNet overlapping MFMA kernels fill each other's tails and any waiting costs (268 ms per step without, 301 -
+    316 ms with), and the default schedule does not show the problem (38.6 ms with or without) -- so the streams are left alone."""
+    if (ASYNC_WGRAD and _side_stream is not None and flops >= _SERIALIZE_MIN_FLOPS
+            and _last_side_flops <= _SERIALIZE_MAX_RATIO * flops):
         torch.cuda.current_stream().wait_stream(_side_stream)
 
 
-_SERIALIZE_MIN_FLOPS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_FLOPS', '1.2e11'))
+_SERIALIZE_MIN_FLOPS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_FLOPS', 'inf'))
+_SERIALIZE_MAX_RATIO = float(os.environ.get('DA_MFMA_SERIALIZE_MAX_RATIO', '0.6'))
 
 
 def _run_on_side(fn, keep_alive):
@@ -262,6 +268,8 @@ class Conv3dK3Fn(Function):
         dw = db = None
         gw, gb = _async_target(ctx.wparam), (_async_target(ctx.bparam) if ctx.has_bias else None)
         if ctx.needs_input_grad[2] and gw is not None and (not ctx.has_bias or gb is not None):
+            global _last_side_flops
+            _last_side_flops = 54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3)
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -663,6 +671,8 @@ class ConvBNActFn(Function):
             call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
         gw = _async_target(ctx.wparam)
         if gw is not None:
+            global _last_side_flops
+            _last_side_flops = 54.0 * (C1 + C2) * Cout * N * D * H * W
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
