@@ -510,6 +510,43 @@ def test_deconv_fused_batchnorm_statistics(Cin, Cout, dims):
     assert npar2.value == 0 and torch.equal(y0, y1)
 
 
+@pytest.mark.parametrize('Cin,Cout,M', [(16, 32, 5000), (64, 16, 777), (128, 48, 1300), (128, 64, 900), (16, 16, 64)])
+def test_conv1x1_input_prologue_is_bit_identical(Cin, Cout, M):
+    """da_conv1x1_fwd_pro / _wgrad_pro (the head consuming the raw output of the last decoder block, unets.py:249-250) against
+    da_bn_act_fwd followed by the plain entries: same arithmetic, same order -> bit-identical output, weight and bias gradients
+    (ragged row counts, 64-wide channel slices included)."""
+    from deepatlas_amd import _native as nat
+    from deepatlas_amd._native import call, call_supported, ptr, stream, workspace
+    d = dev()
+    raw = rnd((M, Cin), 1).to(d)
+    sc, sh = (rnd((Cin,), 2) * 0.5 + 1.0).to(d), rnd((Cin,), 3, 0.3).to(d)
+    w = rnd((Cin, Cout), 4, 0.3).to(d)
+    b = rnd((Cout,), 5, 0.1).to(d)
+    dy = rnd((M, Cout), 6).to(d)
+    st = stream()
+    for slope in (0.01, 0.0):
+        a = torch.empty_like(raw)
+        call('da_bn_act_fwd', ptr(raw), ptr(sc), ptr(sh), slope, ptr(a), M, Cin, st)
+        wp, wn = workspace.get(max(nat.lib().da_pointwise_ws_bytes(1, Cin, Cout), nat.lib().da_conv1x1_wgrad_ws_bytes(M, Cin, Cout)), d)
+        y0, y1 = torch.empty((M, Cout), device=d), torch.empty((M, Cout), device=d)
+        call('da_conv1x1_fwd', ptr(a), ptr(w), ptr(b), ptr(y0), M, Cin, Cout, wp, wn, st)
+        call('da_conv1x1_fwd_pro', ptr(raw), ptr(sc), ptr(sh), slope, ptr(w), ptr(b), ptr(y1), M, Cin, Cout, wp, wn, st)
+        assert torch.equal(y0, y1), ('fwd', slope, float((y0 - y1).abs().max()))
+        dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
+        db0, db1 = torch.empty_like(b), torch.empty_like(b)
+        call('da_conv1x1_wgrad', ptr(a), ptr(dy), ptr(dw0), ptr(db0), M, Cin, Cout, wp, wn, st)
+        if not call_supported('da_conv1x1_wgrad_pro', ptr(raw), ptr(sc), ptr(sh), slope, ptr(dy), ptr(dw1), ptr(db1), M, Cin, Cout, wp, wn, st):
+            assert (Cin, Cout) == (128, 48)      # a 64 x 48 channel slice has no single-tap weight-gradient instantiation: declined, the caller materialises
+            check(y1, a.cpu() @ w.cpu() + b.cpu(), what='head fwd with prologue')
+            continue
+        assert torch.equal(dw0, dw1), ('wgrad', slope, float((dw0 - dw1).abs().max()))
+        assert torch.equal(db0, db1)
+        # and against torch on the activated input (not only self-consistency)
+        ref = a.cpu() @ w.cpu() + b.cpu()
+        check(y1, ref, what='head fwd with prologue')
+        check(dw1, a.cpu().t() @ dy.cpu(), what='head wgrad with prologue')
+
+
 def test_large_batch_transposed_conv_and_head_beyond_4gib():
     """Batch 8 at 160x192x160: the 32 -> 32 up-sampler's output and the 32-class logits are 5 GB each, past 32-bit byte offsets.
     Additivity over the batch axis: weight / bias gradients of the whole batch = sum over the two half batches, and the forward /
