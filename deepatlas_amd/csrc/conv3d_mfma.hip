@@ -1,4 +1,7 @@
 // Implicit-GEMM 3x3x3 convolution on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32).
+// Template switches on the same kernels: BF = opt-in bf16 matrix mode (bf16 LDS tiles / packed weights, v_mfma_f32_16x16x32_bf16 or
+// 16x16x16 + ds_read_b64_tr_b16 for the weight gradient, fp32 accumulate; da_set_matrix_bf16), PRO = input prologue (the staged
+// tensor is a raw producer output whose BatchNorm + activation is applied on the way into LDS; da_conv3d_k3_fwd_pro / _wgrad_pro).
 //
 // Forward / data-gradient  (da_conv3_mfma_fwd):
 //   GEMM view  M = output voxels, N = Cout, K = 27 taps x Cin.   One workgroup (4 waves) owns a 4x8x16 output tile;
