@@ -105,3 +105,29 @@ def test_matrix_precision_switch_round_trip():
             ops.set_matrix_precision('fp16')
     finally:
         ops.set_matrix_precision(prev)
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_device():
+    """Empty / null / undersized arguments are refused with DA_ERR_BADARG (-1) / DA_ERR_WS_SMALL (-2) by the entry points themselves
+    (no HIP call has happened yet, so this runs without a GPU): empty batch, empty volume, missing second input, scratch too small."""
+    from ctypes import c_void_p, c_int, byref
+    from deepatlas_amd import _native
+    L = _native.lib()
+    fake = c_void_p(0x1000)          # never dereferenced on the host
+    BAD, SMALL = -1, -2
+    assert L.da_conv3d_k3_fwd(fake, 16, None, 0, fake, None, fake, 0, 8, 8, 8, 16, 1, -1.0, fake, 1 << 20, None) == BAD          # N = 0
+    assert L.da_conv3d_k3_fwd(fake, 16, None, 0, fake, None, fake, 1, 0, 8, 8, 16, 1, -1.0, fake, 1 << 20, None) == BAD          # D = 0
+    assert L.da_conv3d_k3_fwd(None, 16, None, 0, fake, None, fake, 1, 8, 8, 8, 16, 1, -1.0, fake, 1 << 20, None) == BAD          # null input
+    assert L.da_conv3d_k3_fwd(fake, 16, None, 8, fake, None, fake, 1, 8, 8, 8, 16, 1, -1.0, fake, 1 << 20, None) == BAD          # C2 > 0 without in2
+    assert L.da_conv3d_k3_fwd(fake, 16, None, 0, fake, None, fake, 1, 8, 8, 8, 16, 3, -1.0, fake, 1 << 20, None) == BAD          # stride 3
+    n = c_int(5)
+    assert L.da_conv3d_k3_fwd_pro(fake, 16, fake, None, 0.01, None, 0, None, None, -1.0, fake, None, fake, 1, 8, 8, 8, 16, -1.0,
+                                  None, 0, byref(n), fake, 1 << 20, None) == BAD and n.value == 0                                  # scale without shift
+    need = L.da_conv3d_k3_ws_bytes(1, 8, 8, 8, 16, 16, 1)
+    assert need > 0
+    assert L.da_conv3d_k3_wgrad(fake, 16, None, 0, fake, fake, None, 1, 8, 8, 8, 16, 1, fake, need - 1, None) == SMALL
+    assert L.da_conv3d_k3_wgrad(fake, 16, None, 0, None, fake, None, 1, 8, 8, 8, 16, 1, fake, need, None) == BAD                  # null dy
+    assert L.da_deconv_k2s2_fwd_bnstats(fake, fake, None, None, 1, 4, 4, 4, 16, 16, None, 0, byref(n), fake, 1 << 20, None) == BAD   # null output
+    assert L.da_conv1x1_fwd_pro(fake, None, None, 0.01, fake, None, fake, 100, 16, 32, fake, 1 << 20, None) == BAD                # prologue entry without a prologue
+    assert L.da_bn_act_fwd(None, fake, fake, 0.01, fake, 10, 16, None) == BAD
+    assert L.da_maxpool2_fwd(fake, fake, 0, 8, 8, 8, 16, None) == BAD
