@@ -339,7 +339,7 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
         if (rc != DA_ERR_UNSUPPORTED) return rc;           // e.g. a per-sample tensor beyond 32-bit byte offsets: direct kernels below
     }
     if (!force_direct() && da_conv3_thin_supported(C1, C2, Cout, stride) && !getenv("DA_NO_THIN")) {
-        const int rc = da_conv3_thin_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope, st);
+        const int rc = da_conv3_thin_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope, ws, ws_bytes, st);
         if (rc != DA_ERR_UNSUPPORTED) return rc;
     }
     // tiny Cin, full-quad Cout, single output pointer, 32-bit addressable
@@ -423,7 +423,7 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
             if (rc != DA_ERR_UNSUPPORTED) return rc;
         }
         if (!force_direct() && da_conv3_thin_supported(Cout, 0, Cin, 1)) {
-            const int rc = da_conv3_thin_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, -1.f, st);
+            const int rc = da_conv3_thin_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, -1.f, ws, ws_bytes, st);
             if (rc != DA_ERR_UNSUPPORTED) return rc;
         }
         float* wf = (float*)ws;

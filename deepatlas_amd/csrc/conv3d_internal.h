@@ -44,4 +44,5 @@ int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, 
 // tensor and the data-gradient convolution is computed
 bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
-                      float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope, hipStream_t st);
+                      float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope,
+                      void* ws, size_t ws_bytes, hipStream_t st);

@@ -654,13 +654,27 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 // ---------------------------------------------------------------------------------------------------
 struct ThinP {
     const float* in1; const float* in2; int C1, C2;      // C1 % CL == 0 when C2 > 0
-    const float* w;                                      // [27][Cin][Cout]  (flip_tr: original [27][Cout][Cin], taps flipped)
+    const float* w;                                      // zero-padded [27][CinP][CT] (thin_pack_kernel), read through the scalar cache
     const float* bias; float* out1; float* out2; int Cs1, Cs2;
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, flip_tr; float slope;
 };
 
+// weights [27][Cin][Cout] (flip_tr: original [27][Cout][Cin], taps flipped) -> zero-padded [27][CinP][CT]: the thin kernel's inner loops
+// then carry no channel predicates, and every weight address is wave-uniform
+__global__ void thin_pack_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cin, int CinP, int Cout, int CT, int flip_tr) {
+    const int total = 27 * CinP * CT;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int j = idx % CT; const int r = idx / CT; const int ci = r % CinP; const int tap = r / CinP;
+        float v = 0.f;
+        if (ci < Cin && j < Cout)
+            v = flip_tr ? w[((size_t)(26 - tap) * Cout + j) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cout + j];
+        wq[idx] = v;
+    }
+}
+
 template <int CL, int CT, int VPT>
 __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
+    constexpr bool WSCAL = CT <= 16;      // weights through the scalar cache (few outputs per thread) or staged in LDS (CT >= 24: too many SGPR loads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 2 * VPT, HZ = TZ + 2, HVOX = HZ * HY * HX;
     int t = blockIdx.x;
@@ -671,14 +685,15 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
     const int Cin = p.C1 + p.C2;
     const int nchunks = (Cin + CL - 1) / CL;
     const int CinP = nchunks * CL;
-    // weights -> LDS once per workgroup, zero padded to [27][CinP][CT] so the inner loops carry no channel predicates
-    float* wl = lds + HVOX * CL;
-    for (int idx = threadIdx.x; idx < 27 * CinP * CT; idx += 256) {
-        const int j = idx % CT; const int r = idx / CT; const int ci = r % CinP; const int tap = r / CinP;
-        float v = 0.f;
-        if (ci < Cin && j < p.Cout)
-            v = p.flip_tr ? p.w[((size_t)(26 - tap) * p.Cout + j) * Cin + ci] : p.w[((size_t)tap * Cin + ci) * p.Cout + j];
-        wl[idx] = v;
+    // weights, zero padded to [27][CinP][CT] so the inner loops carry no channel predicates.  WSCAL: wave-uniform addresses into the padded
+    // global copy -> s_load_dwordx4 through the scalar cache and SGPR operands in the FMAs, no LDS traffic (with the LDS copy 8 of
+    // every 10 ds_reads of the 24 -> 3 flow conv were weights: 0.54 -> 0.45 ms).  With many outputs per thread (CT >= 24, the 3 -> 24 data
+    // gradient) the scalar loads themselves become the bottleneck (0.50 -> 0.66 ms), so those keep a copy in LDS.
+    const float* __restrict__ wl = p.w;
+    if constexpr (!WSCAL) {
+        float* wlds = lds + HVOX * CL;
+        for (int idx = threadIdx.x; idx < 27 * CinP * CT; idx += 256) wlds[idx] = p.w[idx];
+        wl = wlds;
     }
     // this thread's output voxels: (lz + 2 v, ly, lx), v < VPT
     const int lx = threadIdx.x & 15, ly = (threadIdx.x >> 4) & 7, lz = threadIdx.x >> 7;
@@ -1406,39 +1421,47 @@ bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride) {
     return false;
 }
 
+static const size_t kThinPackBytes = 65536;        // padded weights [27][CinP][CT]: <= 27.6 KB (Cin <= 64, CT = 4) / 13.8 KB (Cin <= 4, CT <= 32)
+
 template <int CL, int CT, int VPT>
-static void thin_launch(ThinP& p, hipStream_t st) {
+static int thin_launch(ThinP& p, const float* w_src, float* wq, hipStream_t st) {
     const int Cin = p.C1 + p.C2;
     const int CinP = (Cin + CL - 1) / CL * CL;
-    const size_t ldsb = ((size_t)(2 * VPT + 2) * HY * HX * CL + (size_t)27 * CinP * CT) * sizeof(float);
+    if ((size_t)27 * CinP * CT * sizeof(float) > kThinPackBytes) return DA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(thin_pack_kernel, dim3(da_grid(27 * CinP * CT, 256, 64)), dim3(256), 0, st, w_src, wq, Cin, CinP, p.Cout, CT, p.flip_tr);
+    p.w = wq;
+    const size_t ldsb = ((size_t)(2 * VPT + 2) * HY * HX * CL + (CT <= 16 ? 0 : (size_t)27 * CinP * CT)) * sizeof(float);
     p.ntz = (p.D + 2 * VPT - 1) / (2 * VPT);
     p.ntiles = p.N * p.ntz * p.nty * p.ntx;
     hipLaunchKernelGGL((conv3_thin_kernel<CL, CT, VPT>), dim3(p.ntiles), dim3(256), ldsb, st, p);
-}
-
-template <int CL>
-static int thin_few_inputs(ThinP& p, hipStream_t st) {
-    if (p.Cout <= 8) thin_launch<CL, 8, 4>(p, st);
-    else if (p.Cout <= 16) thin_launch<CL, 16, 4>(p, st);
-    else if (p.Cout <= 24) thin_launch<CL, 24, 4>(p, st);
-    else if (p.Cout <= 32) thin_launch<CL, 32, 2>(p, st);
-    else return DA_ERR_UNSUPPORTED;
     return 0;
 }
 
+template <int CL>
+static int thin_few_inputs(ThinP& p, const float* w_src, float* wq, hipStream_t st) {
+    if (p.Cout <= 8) return thin_launch<CL, 8, 4>(p, w_src, wq, st);
+    if (p.Cout <= 16) return thin_launch<CL, 16, 4>(p, w_src, wq, st);
+    if (p.Cout <= 24) return thin_launch<CL, 24, 4>(p, w_src, wq, st);
+    if (p.Cout <= 32) return thin_launch<CL, 32, 2>(p, w_src, wq, st);
+    return DA_ERR_UNSUPPORTED;
+}
+
 int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
-                      float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope, hipStream_t st) {
+                      float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
     if ((unsigned long long)D * H * W * (C1 > C2 ? C1 : C2) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < kThinPackBytes) return DA_ERR_WS_SMALL;
+    float* wq = (float*)ws;
     ThinP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.Cs1 = Cs1; p.Cs2 = Cs2;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.flip_tr = flip_tr; p.slope = slope;
     p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     const int Cin = C1 + C2;
     int rc = 0;
-    if (Cout <= 4) thin_launch<8, 4, 2>(p, st);
-    else if (Cin == 1 || (Cin <= 4 && C2 > 0)) rc = thin_few_inputs<1>(p, st);      // CL = 1 splits cleanly at the concat boundary
-    else if (Cin == 2 && (C2 == 0)) rc = thin_few_inputs<2>(p, st);
-    else if (Cin <= 4 && C2 == 0) rc = thin_few_inputs<4>(p, st);
+    if (Cout <= 4) rc = thin_launch<8, 4, 2>(p, w, wq, st);
+    else if (Cin == 1 || (Cin <= 4 && C2 > 0)) rc = thin_few_inputs<1>(p, w, wq, st);      // CL = 1 splits cleanly at the concat boundary
+    else if (Cin == 2 && (C2 == 0)) rc = thin_few_inputs<2>(p, w, wq, st);
+    else if (Cin <= 4 && C2 == 0) rc = thin_few_inputs<4>(p, w, wq, st);
     else return DA_ERR_UNSUPPORTED;
     if (rc) return rc;
     DA_LAUNCH_CHECK();
