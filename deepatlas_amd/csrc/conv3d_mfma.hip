@@ -661,13 +661,14 @@ struct ThinP {
 
 // weights [27][Cin][Cout] (flip_tr: original [27][Cout][Cin], taps flipped) -> zero-padded [27][CinP][CT]: the thin kernel's inner loops
 // then carry no channel predicates, and every weight address is wave-uniform
-__global__ void thin_pack_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cin, int CinP, int Cout, int CT, int flip_tr) {
+// (j0, Cw: this launch covers output channels [j0, j0 + Cout) of a layer with Cw output channels)
+__global__ void thin_pack_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cin, int CinP, int Cout, int CT, int flip_tr, int j0, int Cw) {
     const int total = 27 * CinP * CT;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int j = idx % CT; const int r = idx / CT; const int ci = r % CinP; const int tap = r / CinP;
         float v = 0.f;
         if (ci < Cin && j < Cout)
-            v = flip_tr ? w[((size_t)(26 - tap) * Cout + j) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cout + j];
+            v = flip_tr ? w[((size_t)(26 - tap) * Cw + j0 + j) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cw + j0 + j];
         wq[idx] = v;
     }
 }
@@ -1424,11 +1425,11 @@ bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride) {
 static const size_t kThinPackBytes = 65536;        // padded weights [27][CinP][CT]: <= 27.6 KB (Cin <= 64, CT = 4) / 13.8 KB (Cin <= 4, CT <= 32)
 
 template <int CL, int CT, int VPT>
-static int thin_launch(ThinP& p, const float* w_src, float* wq, hipStream_t st) {
+static int thin_launch(ThinP& p, const float* w_src, float* wq, hipStream_t st, int j0 = 0, int Cw = -1) {
     const int Cin = p.C1 + p.C2;
     const int CinP = (Cin + CL - 1) / CL * CL;
-    if ((size_t)27 * CinP * CT * sizeof(float) > kThinPackBytes) return DA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(thin_pack_kernel, dim3(da_grid(27 * CinP * CT, 256, 64)), dim3(256), 0, st, w_src, wq, Cin, CinP, p.Cout, CT, p.flip_tr);
+    if ((size_t)27 * CinP * CT * sizeof(float) > kThinPackBytes / 2) return DA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(thin_pack_kernel, dim3(da_grid(27 * CinP * CT, 256, 64)), dim3(256), 0, st, w_src, wq, Cin, CinP, p.Cout, CT, p.flip_tr, j0, Cw < 0 ? p.Cout : Cw);
     p.w = wq;
     const size_t ldsb = ((size_t)(2 * VPT + 2) * HY * HX * CL + (CT <= 16 ? 0 : (size_t)27 * CinP * CT)) * sizeof(float);
     p.ntz = (p.D + 2 * VPT - 1) / (2 * VPT);
@@ -1441,6 +1442,18 @@ template <int CL>
 static int thin_few_inputs(ThinP& p, const float* w_src, float* wq, hipStream_t st) {
     if (p.Cout <= 8) return thin_launch<CL, 8, 4>(p, w_src, wq, st);
     if (p.Cout <= 16) return thin_launch<CL, 16, 4>(p, w_src, wq, st);
+    static int split = -1; if (split < 0) { const char* e = getenv("DA_NO_THIN_SPLIT"); split = (e && atoi(e)) ? 0 : 1; }
+    if (split && p.Cs2 > 0 && p.Cs1 <= 16 && p.Cs2 <= 16 && p.Cs1 % 4 == 0 && p.Cs2 % 4 == 0) {
+        // split output (data gradient of a concat conv, e.g. the flow conv's 3 -> 16 + 8): one launch per output tensor, each with few
+        // enough outputs per thread for scalar-cache weights; the (tiny) input is simply read twice
+        ThinP a = p, b = p;
+        a.Cout = p.Cs1; a.Cs2 = 0; a.out2 = nullptr;
+        b.Cout = p.Cs2; b.out1 = p.out2; b.Cs1 = p.Cs2; b.Cs2 = 0; b.out2 = nullptr;
+        float* wq2 = wq + kThinPackBytes / 2 / sizeof(float);
+        int rc = (a.Cout <= 8) ? thin_launch<CL, 8, 4>(a, w_src, wq, st, 0, p.Cout) : thin_launch<CL, 16, 4>(a, w_src, wq, st, 0, p.Cout);
+        if (rc) return rc;
+        return (b.Cout <= 8) ? thin_launch<CL, 8, 4>(b, w_src, wq2, st, p.Cs1, p.Cout) : thin_launch<CL, 16, 4>(b, w_src, wq2, st, p.Cs1, p.Cout);
+    }
     if (p.Cout <= 24) return thin_launch<CL, 24, 4>(p, w_src, wq, st);
     if (p.Cout <= 32) return thin_launch<CL, 32, 2>(p, w_src, wq, st);
     return DA_ERR_UNSUPPORTED;
