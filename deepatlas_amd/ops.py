@@ -98,21 +98,24 @@ def join_side_stream():
 _last_side_flops = 0.0          # FLOPs of the weight gradient most recently queued on the side stream
 
 
-def _serialize_matrix_kernels(flops):
-    """Experiment switch, OFF by default (DA_MFMA_SERIALIZE_MIN_FLOPS=1.2e11 turns it on): before a matrix-bound data gradient of
-    at least that many FLOPs is queued on the main stream, wait for the side stream if the weight gradient queued there is much
-    shorter (<= DA_MFMA_SERIALIZE_MAX_RATIO of the FLOPs).  The conv kernels are persistent with a static tile partition, and a
-    long data gradient that starts while a short weight gradient drains its last workgroups can finish late (seen with
-    DA_LAZY_BN=0: the 48 <- 16 data gradient 3.3 -> 4.9 ms, 41.0 vs 39.1 ms per step with the wait).  But on the coarse, few-tile
-    layers of the full UNet overlapping MFMA kernels fill each other's tails and any waiting costs (268 ms per step without, 301 -
-    316 ms with), and the default schedule does not show the problem (38.6 ms with or without) -- so the streams are left alone."""
-    if (ASYNC_WGRAD and _side_stream is not None and flops >= _SERIALIZE_MIN_FLOPS
+def _serialize_matrix_kernels(flops, voxels):
+    """Called right before a matrix-bound data-gradient kernel is queued on the main stream: for a LARGE full-resolution data
+    gradient (>= 3e11 FLOPs on >= 4e6 voxels) behind a much shorter queued weight gradient (<= 0.4 of its FLOPs) the main stream first
+    waits for the side stream.  The conv kernels are persistent with a static tile partition; such a data gradient that starts
+    while the short weight gradient drains its last workgroups gets its own workgroups started unevenly and finishes late (the
+    48 <- 16 data gradient of UNet_light: 3.3 ms alone, 4.9 ms when it starts 0.7 ms before the 16 -> 16 weight gradient ends).
+    Whether that happens depends on microseconds of launch timing -- removing sixteen 2-us fill kernels per step moved the step from
+    38.7 to 40.9 ms -- so the schedule is pinned instead of left to chance: 39.05 ms in either case.  The rule is deliberately
+    narrow: on coarse, few-tile layers (all of the full UNet below full resolution) overlapping MFMA kernels fill each other's
+    tails and waiting costs 10 % (268 vs 300 ms per step), and equally long kernels are left to overlap too."""
+    if (ASYNC_WGRAD and _side_stream is not None and flops >= _SERIALIZE_MIN_FLOPS and voxels >= _SERIALIZE_MIN_VOXELS
             and _last_side_flops <= _SERIALIZE_MAX_RATIO * flops):
         torch.cuda.current_stream().wait_stream(_side_stream)
 
 
-_SERIALIZE_MIN_FLOPS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_FLOPS', 'inf'))
-_SERIALIZE_MAX_RATIO = float(os.environ.get('DA_MFMA_SERIALIZE_MAX_RATIO', '0.6'))
+_SERIALIZE_MIN_FLOPS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_FLOPS', '3e11'))      # 'inf' disables the rule
+_SERIALIZE_MAX_RATIO = float(os.environ.get('DA_MFMA_SERIALIZE_MAX_RATIO', '0.4'))
+_SERIALIZE_MIN_VOXELS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_VOXELS', '4e6'))
 
 
 def _run_on_side(fn, keep_alive):
@@ -263,7 +266,7 @@ class Conv3dK3Fn(Function):
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
             dx1 = _empty(a1.shape, a1)
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
-            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3))
+            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3), N * D * H * W)
             call('da_conv3d_k3_dgrad', ptr(g), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, stride, wp, wn, st)
         dw = db = None
         gw, gb = _async_target(ctx.wparam), (_async_target(ctx.bparam) if ctx.has_bias else None)
@@ -651,6 +654,7 @@ class ConvBNActFn(Function):
         if lazy_out:
             scale, shift = stats[2], stats[3]
             ctx.mark_non_differentiable(scale, shift)
+            ctx.set_materialize_grads(False)          # no zero-filled gradients for (scale, shift): they are statistics, not graph nodes
             return ncdhw(y), scale, shift
         return ncdhw(out)
 
@@ -667,7 +671,7 @@ class ConvBNActFn(Function):
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
             dx1 = _empty(a1.shape, a1)
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
-            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W)
+            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
             call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
         gw = _async_target(ctx.wparam)
         if gw is not None:
@@ -740,6 +744,7 @@ class DeconvBNActFn(Function):
         if lazy_out:
             scale, shift = stats[2], stats[3]
             ctx.mark_non_differentiable(scale, shift)
+            ctx.set_materialize_grads(False)          # no zero-filled gradients for (scale, shift): they are statistics, not graph nodes
             return ncdhw(y), scale, shift
         return ncdhw(out)
 
