@@ -227,14 +227,20 @@ struct FwdP {
     double* stats_partial;              // optional [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the (pre-activation) output
     unsigned long long* clk;
     const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: per-channel scale / shift / act slope still to be applied to in1 / in2
+    int* dyn_ctr;    // DYN: tile counters [gridDim.y][8 XCDs], zeroed by the pack kernel of the same call
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
 // BF: bf16 matrix mode (da_set_matrix_bf16): tensors stay fp32 in HBM, the staged tile and the packed weights are bf16 and one
 // v_mfma_f32_16x16x16_bf16 (fp32 accumulate) replaces the four v_mfma_f32_16x16x4_f32 of a K-step -- same lane <-> (voxel, cin)
 // mapping, so everything around the K loop is shared.  The kernel is then bound by HBM / LDS instead of the matrix pipe.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue
+// DYN (experiment, DA_DYN_TILES=1): work-stealing tile walk.  Instead of a static share of its XCD's tile range a workgroup draws the
+// next position from that XCD's counter (one atomic per tile by thread 0, two tiles ahead, handed to the other waves through a
+// 4-entry LDS ring), so a kernel whose workgroups start at different times -- behind another persistent kernel on the other stream
+// -- still finishes together.  Not for the STATS variant: its per-workgroup partial sums would then depend on the draw order.
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
+    static_assert(!DYN || (!STATS && !MASKED && !PRO), "dynamic tile walk: plain forward / data-gradient variants only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // K32: the dense bf16 kernels use v_mfma_f32_16x16x32_bf16 (K = 32 = two taps x 16 cin, or four taps x 8 cin; 16 cycles per
     // SIMD for twice the K of the 16x16x16 form, which gfx950 issues at ~32 cycles); the sparse-tap variant keeps one tap per step.
@@ -257,16 +263,33 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     const int nchunks = (p.C1 + p.C2) / CK;
     // persistent: this workgroup walks its share of the brick-ordered tile list; work item = (tile, channel chunk)
     const TileWalk tw = tile_walk(p.ntiles);
-    const int nitems = tw.cnt * nchunks;
-    if (nitems <= 0) {
+    const int nitems = DYN ? 0x7FFFFFFF : tw.cnt * nchunks;
+    if (!DYN && nitems <= 0) {
         if (STATS) for (int c = threadIdx.x; c < NREP * 16; c += 256) { const int co = blockIdx.y * NREP * 16 + c; if (co < p.Cout) { p.stats_partial[((size_t)blockIdx.x * 2) * p.Cout + co] = 0.0; p.stats_partial[((size_t)blockIdx.x * 2 + 1) * p.Cout + co] = 0.0; } }
         return;
     }
+    // DYN: this workgroup's XCD range [xlo, xhi) of the brick order, its counter, and the ring of drawn positions.  (Out-of-range
+    // buffer ATOMICS fault on gfx950 -- tools/ubench/buffer_atomic_oob.hip -- so the draw sits in an exec-mask branch of thread 0.)
+    int xlo = 0, xhi = 0;
+    int* sp = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB);
+    int* ctr = nullptr;
+    if constexpr (DYN) {
+        const int G = gridDim.x, X = (G % 8 == 0) ? 8 : 1, xcd = blockIdx.x % X;
+        xlo = (int)((long long)p.ntiles * xcd / X); xhi = (int)((long long)p.ntiles * (xcd + 1) / X);
+        ctr = p.dyn_ctr + blockIdx.y * 8 + xcd;
+        if (threadIdx.x == 0) { sp[0] = xlo + atomicAdd(ctr, 1); sp[1] = xlo + atomicAdd(ctr, 1); }
+        __syncthreads();
+        if (sp[0] >= xhi) return;
+    }
+    auto tile_pos = [&](int k) -> int {
+        if constexpr (DYN) return __builtin_amdgcn_readfirstlane(sp[k & 3]);
+        else return tw.lo + k * tw.J;
+    };
 
     auto item_coords = [&](int item, int& n, int& z0, int& y0, int& x0, int& ch) {
         ch = item % nchunks;
         int tx, ty, tz;
-        brick_tile<2, 4, 8>(tw.lo + (item / nchunks) * tw.J, p.ntx, p.nty, p.ntz, n, tx, ty, tz);   // brick = 32^3 voxels
+        brick_tile<2, 4, 8>(tile_pos(item / nchunks), p.ntx, p.nty, p.ntz, n, tx, ty, tz);   // brick = 32^3 voxels
         x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
     };
     auto issue_stage = [&](int item, float4* pre) {          // iterations [0, PRE)
@@ -427,8 +450,11 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     for (int item = 0; item < nitems; ++item) {
         int n, z0, y0, x0, ch;
         item_coords(item, n, z0, y0, x0, ch);
-        const bool has_next = item + 1 < nitems;
+        const bool has_next = DYN ? ((ch + 1 < nchunks) || tile_pos(item / nchunks + 1) < xhi) : (item + 1 < nitems);
         const bool last = (ch == nchunks - 1);
+        if constexpr (DYN) {       // on a tile's first chunk: draw the position of the tile after next; published below, before the barriers
+            if (threadIdx.x == 0 && ch == 0) sp[(item / nchunks + 2) & 3] = xlo + atomicAdd(ctr, 1);
+        }
 
         if constexpr (MASKED) {
             // sparse tap set (a stride-2 conv expressed as a stride-1 conv over the space-to-depth input: a channel chunk
@@ -624,6 +650,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         }
         if (STATS && last && ((++tiles_done) & 1) == 0) stats_flush();
         if constexpr (PRO && !PRO_IN) load_pro(has_next ? item + 1 : item);      // outside the branch: no vector memory in branches
+        if constexpr (DYN) { if (!has_next) break; }
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
             if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
@@ -801,7 +828,8 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
 
 // packed B operand: wp[chunk][step][ntile][lane][m]
 __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
-                                        int CK, int NSTEPS, int NTpad, int flipped, long long total, int bf) {
+                                        int CK, int NSTEPS, int NTpad, int flipped, long long total, int bf, int* zero_ctr, int nctr) {
+    if (zero_ctr && blockIdx.x == 0 && (int)threadIdx.x < nctr) zero_ctr[threadIdx.x] = 0;      // DYN tile counters of the launch that follows
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx & 3); const int lane = (int)((idx >> 2) & 63);
         long long rest = idx >> 8;
@@ -1209,11 +1237,12 @@ static int pick_ck(int C1, int C2) {
 // one-item-ahead prefetch hides).
 static int pick_nrep(int NT) { return NT <= 3 ? NT : (NT % 2 == 0 ? 2 : (NT % 3 == 0 ? 3 : 2)); }
 
+static const int kDynCtrInts = 256;          // tile counters [<= 32 cout groups][8 XCDs] behind the packed weights
 static size_t packed_bytes(int Cin, int Cout, int CK) {
     const int NT = (Cout + 15) / 16, NREP = pick_nrep(NT);
     const int NTpad = (NT + NREP - 1) / NREP * NREP;
     const int NSTEPS = (27 * CK + 15) / 16;
-    return da_align((size_t)(Cin / CK) * NSTEPS * NTpad * 256 * sizeof(float));
+    return da_align((size_t)(Cin / CK) * NSTEPS * NTpad * 256 * sizeof(float)) + da_align(kDynCtrInts * sizeof(int));
 }
 
 struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; };
@@ -1264,10 +1293,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
-    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO>;
+    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1347,7 +1376,11 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     if (ws_bytes < pk) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
     const long long total = (long long)(Cin / CK) * NSTEPS * NTpad * 256;
-    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode);
+    int* dyn_ctr = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pk - da_align(kDynCtrInts * sizeof(int)));
+    static int dyn_env = -1; if (dyn_env < 0) { const char* e = getenv("DA_DYN_TILES"); dyn_env = (e && atoi(e)) ? 1 : 0; }
+    const bool dyn = dyn_env && !bf && !pro && s2d_cin == 0 && !stats_partial && gy * 8 <= kDynCtrInts;
+    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode,
+                       dyn ? dyn_ctr : nullptr, gy * 8);
     DA_LAUNCH_CHECK();
     FwdP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.wp = wp; p.bias = bias;
@@ -1371,6 +1404,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     p.stats_partial = stats_partial;
     if (stats_nparts) *stats_nparts = 0;
     p.ps1 = p.pt1 = p.ps2 = p.pt2 = nullptr; p.pslope1 = p.pslope2 = -1.f;
+    p.dyn_ctr = dyn_ctr;
     if (pro) {
         const float *ones, *zeros;
         if (const int rc = pro_identity(&ones, &zeros)) return rc;
@@ -1395,6 +1429,11 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         if (NREP == 1) return bf ? launch_fwd_mfma<16, 1, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 1, true>(p, gy, st);
         if (NREP == 2) return bf ? launch_fwd_mfma<16, 2, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 2, true>(p, gy, st);
         return DA_ERR_UNSUPPORTED;
+    }
+    if (dyn) {       // experiment (DA_DYN_TILES=1): work-stealing tile walk for the plain fp32 forward / data-gradient kernels
+#define DA_DYN_CASE(ck, nr) if (CK == ck && NREP == nr) return launch_fwd_mfma<ck, nr, false, false, false, false, true>(p, gy, st)
+        DA_DYN_CASE(16, 1); DA_DYN_CASE(16, 2); DA_DYN_CASE(16, 3); DA_DYN_CASE(8, 1); DA_DYN_CASE(8, 2);
+#undef DA_DYN_CASE
     }
 #define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, false, true>(p, gy, st) : launch_fwd_mfma<ck, nr>(p, gy, st)
     DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3);          // pick_nrep never asks for more than 3 N-tiles
