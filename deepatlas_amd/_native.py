@@ -60,6 +60,7 @@ SIGNATURES = {
     'da_act_bwd': (I, [P, P, F, P, LL, P]),
     'da_colsum': (I, [P, LL, I, P, P, SZ, P]),
     'da_maxpool2_fwd': (I, [P, P, I, I, I, I, I, P]),
+    'da_maxpool2_fwd_pro': (I, [P, P, P, F, P, P, I, I, I, I, I, P]),
     'da_maxpool2_bwd': (I, [P, P, P, I, I, I, I, I, P]),
     'da_maxpool2_bwd_add': (I, [P, P, P, P, I, I, I, I, I, P]),
     'da_upsample_nearest_fwd': (I, [P, P, I, I, I, I, I, I, I, I, P]),

@@ -37,6 +37,40 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// MaxPool3d(2) whose input is a RAW producer output (deferred BatchNorm + activation, ops.LazyAct): one pass reads the raw window,
+// writes the activated voxels (the skip tensor of unets.py:266, which has to exist anyway) and their maximum.  Same arithmetic as
+// bn_act_fwd_kernel followed by maxpool2_fwd_kernel: act(z) = max(z, z * s) with s in [0, 1) (s = 1: no activation).  Even D, H, W.
+__global__ void maxpool2_fwd_pro_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, float s,
+                                        float* __restrict__ act, float* __restrict__ y, int N, int D, int H, int W, int C) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / 4;
+    const long long total = (long long)N * Do * Ho * Wo * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq); long long v = i / cq;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        const float4 sc = reinterpret_cast<const float4*>(scale)[q], sf = reinterpret_cast<const float4*>(shift)[q];
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float4 a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            a[t] = *reinterpret_cast<const float4*>(x + ((((long long)n * D + d) * H + h) * W + w) * C + q * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            float4 z;
+            z.x = a[t].x * sc.x + sf.x; z.y = a[t].y * sc.y + sf.y; z.z = a[t].z * sc.z + sf.z; z.w = a[t].w * sc.w + sf.w;
+            z.x = fmaxf(z.x, z.x * s); z.y = fmaxf(z.y, z.y * s); z.z = fmaxf(z.z, z.z * s); z.w = fmaxf(z.w, z.w * s);
+            *reinterpret_cast<float4*>(act + ((((long long)n * D + d) * H + h) * W + w) * C + q * 4) = z;
+            m[0] = (z.x > m[0] || z.x != z.x) ? z.x : m[0]; m[1] = (z.y > m[1] || z.y != z.y) ? z.y : m[1];
+            m[2] = (z.z > m[2] || z.z != z.z) ? z.z : m[2]; m[3] = (z.w > m[3] || z.w != z.w) ? z.w : m[3];
+        }
+        *reinterpret_cast<float4*>(y + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * 4) = make_float4(m[0], m[1], m[2], m[3]);
+    }
+}
+
 // One thread per OUTPUT window and channel group: recompute the arg-max (first maximum in scan order),
 // write all eight input-gradient positions (dense stores, no atomics).  Voxels of odd trailing planes
 // (floor mode) are zeroed by the caller's memset when D/H/W are odd.
@@ -235,6 +269,17 @@ extern "C" int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, in
     if (!x || !y || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
     DA_VEC_DISPATCH(maxpool2_fwd_kernel, total, x, y, N, D, H, W, C);
+    return 0;
+}
+
+extern "C" int da_maxpool2_fwd_pro(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope, float* act, float* y,
+                                   int N, int D, int H, int W, int C, void* stream) {
+    if (!x || !pro_scale || !pro_shift || !act || !y || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
+    if (((D | H | W) & 1) || C % 4 != 0 || pro_slope >= 1.f) return DA_ERR_UNSUPPORTED;       // odd trailing planes / odd channel counts: materialise + da_maxpool2_fwd
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_pro_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), x, pro_scale, pro_shift,
+                       pro_slope < 0.f ? 1.f : pro_slope, act, y, N, D, H, W, C);
+    DA_LAUNCH_CHECK();
     return 0;
 }
 

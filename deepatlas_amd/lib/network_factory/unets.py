@@ -80,13 +80,20 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
             for i, enc in enumerate(self.encoders):
                 y = x
                 blks = list(enc)
+                # the level's last block may also stay lazy when its only consumer is the max-pool: the pool pass applies BatchNorm +
+                # activation itself and writes the activated tensor as the skip connection
+                into_pool = (ops.LAZY_BN and self.maxpool and not self.res and i < self.levels - 1 and getattr(blks[-1], 'supports_lazy', False)
+                             and getattr(blks[-1], 'batchnorm', False) and getattr(blks[-1], 'stride', 1) == 1 and isinstance(blks[-1], convBlock))
                 for k, blk in enumerate(blks):
                     nxt = blks[k + 1] if k + 1 < len(blks) else None
-                    y = blk(y, lazy_out=True) if lazy_ok(blk, nxt) else blk(y)
+                    y = blk(y, lazy_out=True) if (lazy_ok(blk, nxt) or (nxt is None and into_pool)) else blk(y)
                 x = (y + x) if self.res else y            # res=True: `enc(x) + x` (unets.py:264; broadcasts a 1-channel input)
                 if i < self.levels - 1:
                     if self.maxpool:          # skip tensor + pooled tensor from one node (gradients summed in the pool backward)
-                        skip, x = ops.MaxPool2SkipFn.apply(x)
+                        if isinstance(x, ops.LazyAct):
+                            skip, x = ops.MaxPool2SkipFn.apply(x.raw, x.scale, x.shift, x.slope)
+                        else:
+                            skip, x = ops.MaxPool2SkipFn.apply(x)
                         temp.append(skip)
                     else:
                         temp.append(x)

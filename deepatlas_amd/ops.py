@@ -835,11 +835,22 @@ class MaxPool2SkipFn(Function):
     summed inside the max-pool backward kernel instead of by a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, *extra):
+        # extra = (scale, shift, slope): x is a RAW producer output (LazyAct); its BatchNorm + activation is applied in the same pass that
+        # pools it, and the activated tensor written by that pass is the skip tensor
+        ctx.n_extra = len(extra)
         a = ndhwc(x)
         N, D, H, W, C = a.shape
         out = _empty((N, D // 2, H // 2, W // 2, C), a)
-        call('da_maxpool2_fwd', ptr(a), ptr(out), N, D, H, W, C, stream())
+        st = stream()
+        if extra:
+            act = torch.empty_like(a)
+            if not call_supported('da_maxpool2_fwd_pro', ptr(a), ptr(extra[0]), ptr(extra[1]), float(extra[2]), ptr(act), ptr(out), N, D, H, W, C, st):
+                act = _apply_pro(a, extra, st)
+                call('da_maxpool2_fwd', ptr(act), ptr(out), N, D, H, W, C, st)
+            a = act
+        else:
+            call('da_maxpool2_fwd', ptr(a), ptr(out), N, D, H, W, C, st)
         ctx.save_for_backward(a)
         return ncdhw(a), ncdhw(out)
 
@@ -848,14 +859,14 @@ class MaxPool2SkipFn(Function):
         a, = ctx.saved_tensors
         N, D, H, W, C = a.shape
         if gpool is None:
-            return gskip
+            return (gskip,) + (None,) * ctx.n_extra
         g = ndhwc(gpool)
         dx = torch.empty_like(a)
         if gskip is None:
             call('da_maxpool2_bwd', ptr(g), ptr(a), ptr(dx), N, D, H, W, C, stream())
         else:
             call('da_maxpool2_bwd_add', ptr(g), ptr(a), ptr(ndhwc(gskip)), ptr(dx), N, D, H, W, C, stream())
-        return ncdhw(dx)
+        return (ncdhw(dx),) + (None,) * ctx.n_extra
 
 
 class UpsampleNearestFn(Function):

@@ -185,6 +185,11 @@ int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t w
 
 /* ---- MaxPool3d(2) (row a2; unets.py:230,267) ------------------------------------------------- */
 int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
+/* MaxPool3d(2) of a tensor whose BatchNorm + activation is still pending (see da_conv3d_k3_fwd_pro): one pass writes the activated
+ * tensor `act` (the skip connection of unets.py:266-267) and its pooled version `y`; arithmetic of da_bn_act_fwd + da_maxpool2_fwd.
+ * Even D, H, W and C % 4 == 0, else DA_ERR_UNSUPPORTED. */
+int da_maxpool2_fwd_pro(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope, float* act, float* y,
+                        int N, int D, int H, int W, int C, void* stream);
 /* dx (input-sized) from dy and the saved input x; gradient goes to the first maximum in (d,h,w) scan order. */
 int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream);
 /* dx = gskip + maxpool_bwd(dy): the pooled tensor also feeds a skip connection (unets.py:266-267,275) */

@@ -547,6 +547,28 @@ def test_conv1x1_input_prologue_is_bit_identical(Cin, Cout, M):
         check(dw1, a.cpu().t() @ dy.cpu(), what='head wgrad with prologue')
 
 
+@pytest.mark.parametrize('C,dims', [(16, (2, 8, 12, 10)), (8, (1, 4, 6, 8)), (32, (1, 2, 4, 6))])
+def test_maxpool_input_prologue_is_bit_identical(C, dims):
+    """da_maxpool2_fwd_pro (deferred BatchNorm + LeakyReLU applied in the pooling pass, which also writes the activated skip tensor)
+    against da_bn_act_fwd + da_maxpool2_fwd; odd sizes are declined (the caller materialises)."""
+    from deepatlas_amd._native import call, call_supported, ptr, stream
+    N, D, H, W = dims
+    d = dev()
+    raw = rnd((N, D, H, W, C), 1).to(d)
+    sc, sh = (rnd((C,), 2) * 0.5 + 1.0).to(d), rnd((C,), 3, 0.3).to(d)
+    for slope in (0.01, 0.0):
+        a0 = torch.empty_like(raw)
+        call('da_bn_act_fwd', ptr(raw), ptr(sc), ptr(sh), slope, ptr(a0), raw.numel() // C, C, stream())
+        y0 = torch.empty((N, D // 2, H // 2, W // 2, C), device=d)
+        call('da_maxpool2_fwd', ptr(a0), ptr(y0), N, D, H, W, C, stream())
+        a1, y1 = torch.empty_like(raw), torch.empty_like(y0)
+        call('da_maxpool2_fwd_pro', ptr(raw), ptr(sc), ptr(sh), slope, ptr(a1), ptr(y1), N, D, H, W, C, stream())
+        assert torch.equal(a0, a1) and torch.equal(y0, y1)
+    odd = rnd((1, 5, 6, 8, C), 4).to(d)
+    assert not call_supported('da_maxpool2_fwd_pro', ptr(odd), ptr(sc), ptr(sh), 0.01, ptr(torch.empty_like(odd)),
+                              ptr(torch.empty((1, 2, 3, 4, C), device=d)), 1, 5, 6, 8, C, stream())
+
+
 def test_large_batch_transposed_conv_and_head_beyond_4gib():
     """Batch 8 at 160x192x160: the 32 -> 32 up-sampler's output and the 32-class logits are 5 GB each, past 32-bit byte offsets.
     Additivity over the batch axis: weight / bias gradients of the whole batch = sum over the two half batches, and the forward /
