@@ -1,17 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json metric: training volumes/sec at 160x192x160 fp32.
 
-Workload (config.workload): BASELINE.json configs[1] "Seg-only 3D U-Net, batch=2, 160x192x160 fp32, 1xMI355X":
+Headline workload (config.workload): BASELINE.json configs[1] "Seg-only 3D U-Net, batch=2, 160x192x160 fp32, 1xMI355X":
 UNet_light (874 864 params) + fused softmax-Dice + Adam, one step = zero_grad / forward / loss / backward /
 [flat-bucket gradient all-reduce] / Adam over a batch of 2 synthetic volumes per GPU (weak scaling: per-GPU batch fixed).
 Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
 
-  python bench.py --gpus N --steps K --warmup W
+After the headline the default run also times configs[2] (reg-only) and configs[3]'s per-GPU shape (joint alternating step,
+1 pair per GPU) for the same --steps / --warmup and reports them under "extra" (north_star's target is quoted on the joint step).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,32 +30,42 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
-HBM_PEAK_GBS = 8000.0
+
+# algorithmic conv FLOPs per voxel of one TRAINING pass (forward + data gradient + weight gradient = 3 x forward)
+SEG_TRAIN_FLOP_PER_VOXEL = 3 * 113520.0          # UNet_light: 1 673.9 GFLOP per 160x192x160 volume
+REG_TRAIN_FLOP_PER_VOXEL = 3 * 32630.0           # VoxelMorph: 481.1 GFLOP per pair
+FULL_UNET_NOTE = 'full UNet: step FLOPs not tabulated in SURVEY.md'
+
+CONV_FWD_CALLS = ['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_fwd_pro']
+CONV_BWD_CALLS = ['da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad', 'da_conv3d_k3_wgrad_pro']
+
+
+def conv_dims(key):
+    """(C1, C2, N, D, H, W, Cout, stride) of a da_conv3d_k3_* call from its integer arguments, or None."""
+    name, a = key
+    if name in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'):
+        return tuple(a[:8])
+    if name in ('da_conv3d_k3_fwd_pro', 'da_conv3d_k3_wgrad_pro'):          # stride 1 only; no stride argument
+        return tuple(a[:7]) + (1,)
+    return None
 
 
 def conv_flops(key):
-    """Algorithmic FLOPs of one da_conv3d_k3_* call from its integer arguments (2*27*Cin*Cout per output voxel)."""
-    name, a = key
-    if name in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats'):      # C1, C2, N, D, H, W, Cout, stride
-        C1, C2, N, D, H, W, Cout, stride = a[:8]
-    elif name == 'da_conv3d_k3_fwd_pro':                              # C1, C2, N, D, H, W, Cout, stats capacity (stride 1)
-        C1, C2, N, D, H, W, Cout = a[:7]; stride = 1
-    elif name == 'da_conv3d_k3_dgrad':  # C1, C2, N, D, H, W, Cout, stride
-        C1, C2, N, D, H, W, Cout, stride = a[:8]
-    elif name == 'da_conv3d_k3_wgrad':
-        C1, C2, N, D, H, W, Cout, stride = a[:8]
-    else:
+    """Algorithmic FLOPs of one da_conv3d_k3_* call (2*27*Cin*Cout per output voxel; forward = data gradient = weight gradient)."""
+    d = conv_dims(key)
+    if d is None:
         return 0
+    C1, C2, N, D, H, W, Cout, stride = d
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     return 2.0 * 27 * (C1 + C2) * Cout * N * Do * Ho * Wo
 
 
 def conv_bytes(key):
     """Algorithmic HBM bytes of one da_conv3d_k3_fwd* call: the input read once + the output written once, fp32 (weights are KBs)."""
-    name, a = key
-    if name not in ('da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_fwd_pro'):
+    d = conv_dims(key)
+    if d is None or key[0] not in CONV_FWD_CALLS:
         return 0
-    C1, C2, N, D, H, W, Cout, stride = (tuple(a[:7]) + (1,)) if name == 'da_conv3d_k3_fwd_pro' else a[:8]
+    C1, C2, N, D, H, W, Cout, stride = d
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     return 4.0 * N * ((C1 + C2) * D * H * W + Cout * Do * Ho * Wo)
 
@@ -79,6 +95,188 @@ def cpu_baseline(shape, batch, n_classes, budget_s=20.0):
                        % (n, batch, shape[0], shape[1], shape[2], warm, dt))
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: check the devices, then run N ranks of this script under torch.distributed.run."""
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; refusing to run fewer ranks '
+                         'and label them as %d\n' % (n, have, n))
+        sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Workload:
+    """One timed configuration: step() closure + what one step amounts to."""
+
+    def __init__(self, name, step, units, unit, flops_per_step, loss_of):
+        self.name, self.step, self.units, self.unit, self.flops_per_step, self.loss_of = name, step, units, unit, flops_per_step, loss_of
+
+
+def make_workloads(args, dev, rank, which):
+    """Build the models / optimisers / resident inputs of the requested workloads ('seg', 'reg', 'joint')."""
+    from deepatlas_amd import parallel
+    from deepatlas_amd.lib.network_factory import get_network
+    from deepatlas_amd.lib.loss import get_loss_function
+    from deepatlas_amd.optim import FlatAdam
+    n_classes = 32
+    shape = tuple(args.shape)
+    V = shape[0] * shape[1] * shape[2]
+    torch.manual_seed(230)
+    model = get_network(args.net)(in_channel=1, n_classes=n_classes, bias=True, BN=True)
+    model.weights_init()
+    model.to(dev).train()
+    crit = get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    parallel.broadcast_parameters(opt)
+    from deepatlas_amd.lib.datasets import synthetic_batch_on_device
+    x, y = synthetic_batch_on_device(args.batch, shape, n_classes, seed=230 + rank, device=dev)
+
+    def seg_step():
+        opt.zero_grad()
+        out = model(x)
+        loss = crit(out, y)
+        loss.backward()
+        parallel.allreduce_gradients(opt)
+        opt.step()
+        return loss
+
+    prec = 'fp32' if args.precision == 'fp32' else 'bf16 matrix mode'
+    out = {}
+    if 'seg' in which:
+        if args.net == 'UNet_light':
+            nm = 'seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (BASELINE configs[1]%s)' % (
+                args.batch, shape[0], shape[1], shape[2], prec, '' if args.precision == 'fp32' else " shape with configs[4]'s precision")
+            fl = SEG_TRAIN_FLOP_PER_VOXEL * V * args.batch
+        else:
+            nm = 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (SURVEY row f3, not a BASELINE config)' % (
+                args.batch, shape[0], shape[1], shape[2], prec)
+            fl = None
+        out['seg'] = Workload(nm, seg_step, args.batch, 'volumes/s', fl, lambda r: r)
+    if 'reg' in which or 'joint' in which:
+        from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
+        reg = get_network('voxel_morph_cvpr')()
+        reg.weights_init()
+        reg.to(dev).train()
+        ropt = FlatAdam(reg.parameters(), lr=1e-3)
+        parallel.broadcast_parameters(ropt)
+        x2, y2 = synthetic_batch_on_device(1, shape, n_classes, seed=1230 + rank, device=dev)
+        im_m, im_t, sm, st_ = x[:1], x2, y[:1], y2
+        if 'reg' in which:
+            rstep = RegistrationStep(reg, ropt)
+            out['reg'] = Workload('reg-only VoxelMorph + trilinear warp + NCC + bending + Adam, 1 pair/GPU, %dx%dx%d %s (BASELINE configs[2])'
+                                  % (shape + (prec,)), lambda: rstep(im_m, im_t)[0], 1, 'pairs/s', REG_TRAIN_FLOP_PER_VOXEL * V, lambda r: r)
+        if 'joint' in which:
+            jstep = DeepAtlasJointStep(model, opt, reg, ropt, n_classes)
+            out['joint'] = Workload('joint DeepAtlas alternating step (reg phase + seg phase, 32-ch seg warp), 1 pair/GPU, %dx%dx%d %s '
+                                    '(BASELINE configs[3] per-GPU shape)' % (shape + (prec,)),
+                                    lambda: jstep(im_m, im_t, sm, st_)['loss_seg'], 1, 'pairs/s',
+                                    (SEG_TRAIN_FLOP_PER_VOXEL + REG_TRAIN_FLOP_PER_VOXEL) * V if args.net == 'UNet_light' else None, lambda r: r)
+    return out, n_classes
+
+
+def time_workload(wl, args, world, dev, prof_names=None):
+    """W warm-up steps, then EXACTLY K steps between barrier + synchronize; returns (max-over-ranks seconds, per-rank seconds, final loss,
+    call profiler, C-ABI launches per step)."""
+    from deepatlas_amd import _native as nat
+    for _ in range(args.warmup):
+        wl.step()
+    prof = nat.CallProfiler(prof_names) if prof_names else None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    nat.profiler = prof
+    n0 = nat.n_calls
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nat.profiler = None
+    launches = (nat.n_calls - n0) / max(args.steps, 1)
+    per_rank = [dt]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(v.item()) for v in allt]
+        dt = max(per_rank)
+    return dt, per_rank, float(loss.item()), prof, launches
+
+
+def result_of(wl, dt, per_rank, world, args, launches):
+    ms = dt / args.steps * 1e3
+    r = dict(value=round(world * wl.units * args.steps / dt, 4), unit=wl.unit, ms_per_step=round(ms, 3), workload=wl.name,
+             c_abi_launches_per_step=round(launches, 1))
+    if wl.flops_per_step:
+        r['step_tflops'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12, 2)
+        if args.precision == 'fp32':
+            r['step_frac_of_fp32_mfma_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+    if world > 1:
+        r['ms_per_step_per_rank'] = [round(t / args.steps * 1e3, 3) for t in per_rank]
+    return r
+
+
+def call_table(summ):
+    """{(name, ints): (n, ms)} -> list of per-call records sorted by total time."""
+    rows = []
+    for k, (n, ms) in summ.items():
+        fl = conv_flops(k)
+        if not fl or not n:
+            continue
+        tf = fl * n / (ms * 1e-3) / 1e12
+        rows.append(dict(call='%s%s' % (k[0], list(conv_dims(k))), launches=n, avg_ms=round(ms / n, 4), total_ms=round(ms, 3),
+                         tflops=round(tf, 2), frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), _key=k, _fl=fl))
+    rows.sort(key=lambda r: -r['total_ms'])
+    return rows
+
+
+def pmc_traffic_for(kname):
+    """HBM bytes per launch of a call from the newest committed PMC passes at this round (tools/pmc_conv.sh -> tools/pmc_summary.py):
+    FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape.  A separate rocprofv3 run, not
+    a measurement of this process -- `traffic_source` says so."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        calls = doc['calls']
+    except (OSError, ValueError, KeyError):
+        return None
+    cands = [kname]
+    if kname.startswith('da_conv3d_k3_fwd_pro['):
+        body = kname[len('da_conv3d_k3_fwd_pro['):]
+        cands.append('da_conv3d_k3_fwd_bnstats[' + body)
+    if kname.startswith('da_conv3d_k3_wgrad_pro['):
+        cands.append('da_conv3d_k3_wgrad[' + kname[len('da_conv3d_k3_wgrad_pro['):])
+    for c in cands:
+        rec = calls.get(c)
+        if rec:
+            out = dict(traffic=rec['traffic_bytes'],
+                       traffic_source='%s (separate rocprofv3 --pmc passes of this call at commit %s; algorithmic %d B)'
+                                      % (os.path.relpath(files[-1], ROOT), doc.get('commit', '?'), rec['algorithmic_bytes']))
+            if 'sq' in rec:
+                out['mfma_busy_vs_peak_clock'] = round(rec['sq']['mfma_util_vs_2p4ghz_peak'], 4)
+            return out
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -88,170 +286,134 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='volumes per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
-    ap.add_argument('--profile-all', action='store_true', help='HIP-event timing of dgrad / wgrad calls too (perturbs the two-stream overlap)')
+    ap.add_argument('--no-extra', action='store_true', help="skip the reg / joint legs and the post-run backward-kernel timing pass")
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="matrix arithmetic of the 3x3x3 convolutions: 'fp32' = the reference's arithmetic (the headline metric); 'bf16' = "
-                         "bf16 operands, fp32 accumulate, fp32 tensors (BASELINE configs[4]'s mixed precision; not the headline)")
+                         "bf16 operands, fp32 accumulate (BASELINE configs[4]'s mixed precision; not the headline)")
     ap.add_argument('--sync-wgrad', action='store_true', help='weight gradients on the main stream (default: side stream, overlapped with the HBM-bound backward kernels)')
     ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
                     help="segmentation network of the 'seg' workload; 'UNet' = the fixed 19 M-parameter net (SURVEY.md row f3), not the headline config")
     ap.add_argument('--workload', default='seg', choices=['seg', 'reg', 'joint'],
-                    help="'seg' = BASELINE configs[1] (the headline metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
+                    help="headline leg: 'seg' = BASELINE configs[1] (the metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
     args = ap.parse_args()
 
+    want = max(args.gpus, 1)
+    if 'WORLD_SIZE' not in os.environ and want > 1:
+        self_spawn(want)                                   # never returns
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == max(args.gpus, 1) or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
+    if world != want:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (want, world))
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write('bench.py: rank %d needs device %d but only %d GPU(s) are visible\n' % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    rccl = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        try:
+            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = 'unknown'
 
-    from deepatlas_amd import _native as nat, parallel, ops
+    from deepatlas_amd import _native as nat, ops
     ops.enable_async_wgrad(not args.sync_wgrad)
     ops.set_matrix_precision(args.precision)
-    from deepatlas_amd.lib.network_factory import get_network
-    from deepatlas_amd.lib.loss import get_loss_function
-    from deepatlas_amd.optim import FlatAdam
-
-    n_classes = 32
     shape = tuple(args.shape)
-    torch.manual_seed(230)
-    model = get_network(args.net)(in_channel=1, n_classes=n_classes, bias=True, BN=True)
-    model.weights_init()
-    model.to(dev).train()
-    crit = get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
-    opt = FlatAdam(model.parameters(), lr=1e-3)
-    parallel.broadcast_parameters(opt)
-    g = torch.Generator().manual_seed(230 + rank)
-    x = torch.rand((args.batch, 1) + shape, generator=g).to(dev)
-    y = torch.randint(0, n_classes, (args.batch,) + shape, generator=g, dtype=torch.uint8).to(dev)
+    extra_legs = [] if (args.no_extra or args.workload != 'seg' or args.net != 'UNet_light') else ['reg', 'joint']
+    wls, n_classes = make_workloads(args, dev, rank, [args.workload] + extra_legs)
 
-    def step():
-        opt.zero_grad()
-        out = model(x)
-        loss = crit(out, y)
-        loss.backward()
-        parallel.allreduce_gradients(opt)
-        opt.step()
-        return loss
+    # ---- headline: the timed region carries HIP-event timing of the FORWARD conv calls only.  The backward pass runs its weight
+    # gradients on a second stream (ops.ASYNC_WGRAD): timing events recorded there serialise it against the main stream and
+    # overlapping kernels time each other's slowdown, so backward kernels are timed in a separate short pass after the timed region.
+    head = wls[args.workload]
+    dt, per_rank, final_loss, prof, launches = time_workload(head, args, world, dev, None if args.no_profile else CONV_FWD_CALLS)
+    head_res = result_of(head, dt, per_rank, world, args, launches)
 
-    units_per_step = args.batch
-    workload_name = ('seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (BASELINE configs[1])' if args.net == 'UNet_light'
-                     else 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d fp32 (SURVEY row f3, not a BASELINE config)') % (
-        args.batch, shape[0], shape[1], shape[2])
-    if args.precision == 'bf16':
-        workload_name = workload_name.replace('fp32 (', 'bf16 matrix mode (').replace('BASELINE configs[1]', "BASELINE configs[1] shape with configs[4]'s precision")
-    if args.workload in ('reg', 'joint'):
-        from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
-        reg = get_network('voxel_morph_cvpr')()
-        reg.weights_init()
-        reg.to(dev).train()
-        ropt = FlatAdam(reg.parameters(), lr=1e-3)
-        parallel.broadcast_parameters(ropt)
-        im_m, im_t = x[:1], torch.rand((1, 1) + shape, generator=g).to(dev)
-        sm, st_ = y[:1], torch.randint(0, n_classes, (1,) + shape, generator=g, dtype=torch.uint8).to(dev)
-        units_per_step = 1
-        if args.workload == 'reg':
-            rstep = RegistrationStep(reg, ropt)
-            step = lambda: rstep(im_m, im_t)[0]
-            workload_name = 'reg-only VoxelMorph + trilinear warp + NCC + bending + Adam, 1 pair/GPU, %dx%dx%d fp32 (BASELINE configs[2])' % shape
-        else:
-            jstep = DeepAtlasJointStep(model, opt, reg, ropt, n_classes)
-            step = lambda: jstep(im_m, im_t, sm, st_)['loss_seg']
-            workload_name = 'joint DeepAtlas alternating step (reg phase + seg phase, 32-ch seg warp), 1 pair/GPU, %dx%dx%d fp32 (BASELINE configs[3] per-GPU shape)' % shape
+    bwd_rows = []
+    if prof is not None and not args.no_extra and args.precision == 'fp32':
+        # post-run pass: 3 steps with every conv call timed and the weight gradients on the MAIN stream (nothing overlaps: clean
+        # per-kernel durations of the data / weight gradients).  Not part of `value`.
+        ops.enable_async_wgrad(False)
+        p2 = nat.CallProfiler(CONV_FWD_CALLS + CONV_BWD_CALLS)
+        head.step()
+        torch.cuda.synchronize()
+        nat.profiler = p2
+        for _ in range(3):
+            head.step()
+        torch.cuda.synchronize()
+        nat.profiler = None
+        ops.enable_async_wgrad(not args.sync_wgrad)
+        bwd_rows = call_table(p2.summary())
 
-    for _ in range(args.warmup):
-        step()
-    prof = None
-    if not args.no_profile:
-        # HIP-event timing of the conv calls of the FORWARD pass.  The backward pass runs its weight gradients on a second stream
-        # (ops.ASYNC_WGRAD): timing events recorded on that stream serialise it against the main one (measured: the overlap gain
-        # disappears), and kernels that do overlap time each other's slowdown, so the roofline call is taken where nothing else is
-        # in flight.  --profile-all times all four conv entry points (and costs ~5 % of `value`).
-        names = ['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_fwd_pro'] + (['da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad'] if args.profile_all else [])
-        prof = nat.CallProfiler(names)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    nat.profiler = prof
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    nat.profiler = None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss.item())
+    extra = {}
+    for leg in extra_legs:
+        edt, eper, eloss, _, elaunch = time_workload(wls[leg], args, world, dev, None)
+        extra[leg] = dict(result_of(wls[leg], edt, eper, world, args, elaunch), final_loss=round(eloss, 6))
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = world * units_per_step * args.steps / dt
         roofline = None
         if prof is not None:
-            summ = prof.summary()
-            key, (ncalls, ms) = max(summ.items(), key=lambda kv: kv[1][1])
-            fl = conv_flops(key)
-            achieved = fl * ncalls / (ms * 1e-3) / 1e12
-            tot_fl = sum(conv_flops(k) * v[0] for k, v in summ.items())
-            tot_ms = sum(v[1] for v in summ.values())
+            rows = call_table(prof.summary())
+            tot_fl = sum(r['_fl'] * r['launches'] for r in rows)
+            tot_ms = sum(r['total_ms'] for r in rows)
+            top = rows[0]                                                       # forward call with the most time in the timed region
             if args.precision == 'bf16':     # bf16 matrix mode: the convolutions are no longer matrix-bound -> price the call against HBM
-                gbs = conv_bytes(key) * ncalls / (ms * 1e-3) / 1e9
+                gbs = conv_bytes(top['_key']) * top['launches'] / (top['total_ms'] * 1e-3) / 1e9
                 rl_head = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
             else:
-                rl_head = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                               frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None)
-            roofline = dict(rl_head,
-                            kernel='%s%s' % (key[0], list(key[1][:8])), avg_ms=round(ms / ncalls, 4), launches=ncalls,
-                            flops_per_launch=fl,
-                            traffic_source=None,
-                            profiled_calls=names,
+                rl_head = dict(bound='mfma', achieved=top['tflops'], peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=top['frac'], traffic=None)
+            roofline = dict(rl_head, kernel=top['call'], avg_ms=top['avg_ms'], launches=top['launches'], flops_per_launch=top['_fl'],
+                            measured='HIP events on the launch stream inside the timed region (forward pass: nothing else in flight)',
+                            traffic_source=None, profiled_calls=CONV_FWD_CALLS,
                             all_profiled=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
-                                              frac_of_step=round(tot_ms / args.steps / ms_per_step, 3)))
-        if roofline is not None and args.precision == 'fp32':
-            # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_conv.sh -> tools/pmc_summary.py):
-            # FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape
-            try:
-                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-                # same kernel (+ per-workgroup BN partials; the input-prologue variant reads the same bytes, raw instead of activated)
-                calls = json.load(open(pj))['calls']
-                kname = roofline['kernel']
-                if kname.startswith('da_conv3d_k3_fwd_pro['):
-                    kname = 'da_conv3d_k3_fwd_bnstats[' + kname[len('da_conv3d_k3_fwd_pro['):].rsplit(',', 1)[0] + ', 1]'
-                rec = calls.get(kname) or calls.get(kname.replace('da_conv3d_k3_fwd_bnstats[', 'da_conv3d_k3_fwd['))
-                if rec:
-                    roofline['traffic'] = rec['traffic_bytes']
-                    roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json (algorithmic %d B)' % rec['algorithmic_bytes']
-                    if 'sq' in rec:      # SQ_VALU_MFMA_BUSY_CYCLES of the same call: matrix-pipe busy rate per SIMD, against the 2.4 GHz peak clock
-                        roofline['mfma_busy_vs_peak_clock'] = round(rec['sq']['mfma_util_vs_2p4ghz_peak'], 4)
-            except (OSError, ValueError, KeyError):
-                pass
+                                              frac_of_step=round(tot_ms / args.steps / head_res['ms_per_step'], 3)))
+            if args.precision == 'fp32':
+                pm = pmc_traffic_for(top['call'])
+                if pm:
+                    roofline.update(pm)
+            if head.flops_per_step and args.precision == 'fp32':
+                roofline['step_frac'] = head_res['step_frac_of_fp32_mfma_peak']       # algorithmic conv FLOPs per step / ms_per_step / peak
+                roofline['step_tflops'] = head_res['step_tflops']
+            if bwd_rows:
+                # the same layer's three kernels (forward / data gradient / weight gradient) without overlap, and the slowest training
+                # kernel overall = the call with the most time in the post-run pass
+                lay = conv_dims(top['_key'])
+                same = [r for r in bwd_rows if conv_dims(r['_key']) == lay]
+                slow = bwd_rows[0]
+                strip = lambda r: {k: v for k, v in r.items() if not k.startswith('_')}
+                roofline['post_run_pass'] = dict(
+                    note='3 extra steps after the timed region, weight gradients on the main stream, every conv call timed with HIP events',
+                    roofline_layer=[strip(r) for r in same],
+                    slowest_training_kernel=strip(slow),
+                    lowest_frac_heavy_kernel=strip(min((r for r in bwd_rows if r['total_ms'] >= 0.05 * sum(q['total_ms'] for q in bwd_rows)),
+                                                       key=lambda r: r['frac'], default=slow)),
+                    all_conv_calls=dict(tflops=round(sum(r['_fl'] * r['launches'] for r in bwd_rows) / (sum(r['total_ms'] for r in bwd_rows) * 1e-3) / 1e12, 2),
+                                        ms_per_step=round(sum(r['total_ms'] for r in bwd_rows) / 3, 3)))
         metric = 'training volumes/sec at 160x192x160 fp32; Dice vs CPU ref'          # BASELINE.json's metric (the default invocation)
         if shape != (160, 192, 160) or args.precision != 'fp32':
             metric = 'training volumes/sec at %dx%dx%d %s' % (shape[0], shape[1], shape[2], 'fp32' if args.precision == 'fp32' else 'bf16 matrix mode')
-        line = dict(metric=metric, value=round(value, 4), unit='volumes/s',
-                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32' if args.precision == 'fp32' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
-                    config=dict(workload=workload_name,
-                                global_batch=world * units_per_step, volume=list(shape), n_classes=n_classes,
-                                parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision),
-                    roofline=roofline)
+        line = dict(metric=metric, value=head_res['value'], unit='volumes/s',
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head_res['ms_per_step'],
+                    higher_is_better=True, scaling='weak', vs_baseline=None,
+                    dtype='f32' if args.precision == 'fp32' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
+                    config=dict(workload=head.name, global_batch=world * head.units, volume=list(shape), n_classes=n_classes,
+                                parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision,
+                                c_abi_launches_per_step=head_res['c_abi_launches_per_step'], rccl=rccl,
+                                ms_per_step_per_rank=head_res.get('ms_per_step_per_rank')),
+                    roofline=roofline, extra=extra or None)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'seg':
             line['cpu_baseline'] = cpu_baseline(shape, args.batch, n_classes)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -80,8 +80,11 @@ SIGNATURES = {
     'da_ncc_fwd': (I, [P, P, I, LL, P, P, P, SZ, P]),
     'da_ncc_bwd': (I, [P, P, P, P, P, P, I, LL, P]),
     'da_bending_ws_bytes': (SZ, [I, I, I, I]),
-    'da_bending_fwd': (I, [P, I, I, I, I, P, I, P, P, SZ, P]),
-    'da_bending_bwd': (I, [P, P, P, I, I, I, I, P, I, P]),
+    'da_bending_fwd': (I, [P, I, I, I, I, P, I, I, P, P, SZ, P]),
+    'da_bending_bwd': (I, [P, P, P, I, I, I, I, P, I, I, P]),
+    'da_xent_ws_bytes': (SZ, []),
+    'da_xent_fwd': (I, [P, P, I, P, P, LL, I, I, I, F, LL, I, P, P, P, SZ, P]),
+    'da_xent_bwd': (I, [P, P, I, P, P, P, P, P, LL, I, I, I, F, LL, P]),
     'da_argmax_dice_counts': (I, [P, P, I, I, LL, I, P, P, P]),
     'da_label_overlap_counts': (I, [P, I, P, I, I, LL, I, P, P]),
     'da_conv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
@@ -94,6 +97,7 @@ SIGNATURES = {
     'da_crop3d': (I, [P, P, I, LL, I, I, I, I, I, I, I, I, I, P]),
     'da_partition_tiles': (I, [P, P, I, I, I, I, P, P, P]),
     'da_assemble_tiles': (I, [P, P, I, I, I, I, P, P, I, P]),
+    'da_synth_volume': (I, [P, P, I, I, I, I, I, I, F, ctypes.c_uint, I, P]),
     'da_lncc_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
     'da_lncc_fwd': (I, [P, P, I, I, I, I, I, I, I, F, P, P, P, SZ, P]),
     'da_lncc_bwd': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, SZ, P]),
@@ -150,9 +154,12 @@ class CallProfiler:
 
 
 profiler = None          # set to a CallProfiler to time calls
+n_calls = 0              # C-ABI calls issued by this process (bench.py reports launches per step)
 
 
 def call(name, *args):
+    global n_calls
+    n_calls += 1
     prof = profiler
     if prof is not None and prof.wants(name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -110,6 +110,52 @@ __global__ void assemble_vote_kernel(const unsigned char* __restrict__ tiles, un
     }
 }
 
+// ---- synthetic volumes (SURVEY.md row f4 "synthetic-volume generator on device"; BASELINE configs are all synthetic) ----------
+// Counter-based: every element is a pure function of (seed, sample, voxel index), so the numpy restatement (oracle/datapath.py
+// synth_volume) reproduces it bit for bit and ranks / batch sizes do not change what a given sample looks like.
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned int synth_bits(unsigned int seed, unsigned long long i, unsigned int stream_id) {
+    const unsigned int hi = (unsigned int)(i >> 32), lo = (unsigned int)i;
+    return mix32(mix32(lo ^ mix32(seed + 0x9e3779b9u * hi)) + stream_id);
+}
+
+// mode 0 (throughput inputs): img ~ U[0,1), lab ~ U{0..C-1}, iid.
+// mode 1 (Dice-parity inputs): blocky label map lab = ((z / bz) * 5 + (y / by) * 3 + x / bx + sample) % C with b = max(dim / 8, 1),
+//         img = clamp(lab / (C - 1) + noise * U, 0, 1)   -- the structure lib/datasets.py's synthetic dataset uses.
+__global__ void synth_volume_kernel(float* __restrict__ img, unsigned char* __restrict__ lab, int N, int D, int H, int W, int C,
+                                    int mode, float noise, unsigned int seed, int sample0) {
+    const long long V = (long long)D * H * W, total = V * N;
+    const int bz = max(D / 8, 1), by = max(H / 8, 1), bx = max(W / 8, 1);
+    const float inv24 = 1.0f / 16777216.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / V, v = i - n * V;
+        const unsigned long long ctr = (unsigned long long)(sample0 + n) * (unsigned long long)V + (unsigned long long)v;
+        const float u = (float)(synth_bits(seed, ctr, 0u) >> 8) * inv24;
+        if (mode == 0) {
+            if (img) img[i] = u;
+            if (lab) lab[i] = (unsigned char)(synth_bits(seed, ctr, 1u) % (unsigned int)C);
+        } else {
+            const int x = (int)(v % W); const long long r = v / W;
+            const int y = (int)(r % H), z = (int)(r / H);
+            const int l = (int)(((long long)(z / bz) * 5 + (y / by) * 3 + (x / bx) + sample0 + n) % C);
+            if (lab) lab[i] = (unsigned char)l;
+            if (img) {
+                float val;
+                {
+#pragma clang fp contract(off)                                   // numpy order: round the quotient, the product and the sum separately
+                    const float q = (float)l / (float)max(C - 1, 1);
+                    const float pn = noise * u;
+                    val = q + pn;
+                }
+                img[i] = fminf(fmaxf(val, 0.f), 1.f);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int da_clamp01_to_f32(const void* src, int src_dtype, float* dst, long long n, void* stream) {
@@ -162,6 +208,15 @@ extern "C" int da_assemble_tiles(const void* tiles, void* vol, int elem_bytes, i
     } else if (elem_bytes == 4) hipLaunchKernelGGL((assemble_kernel<float>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), (const float*)tiles, (float*)vol, g);
     else if (elem_bytes == 1) hipLaunchKernelGGL((assemble_kernel<unsigned char>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), (const unsigned char*)tiles, (unsigned char*)vol, g);
     else return DA_ERR_BADARG;
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_synth_volume(float* img, unsigned char* labels, int N, int D, int H, int W, int n_classes, int mode, float noise,
+                               unsigned int seed, int sample0, void* stream) {
+    if ((!img && !labels) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || n_classes < 1 || n_classes > 256 || (mode != 0 && mode != 1) || sample0 < 0) return DA_ERR_BADARG;
+    const long long total = (long long)N * D * H * W;
+    hipLaunchKernelGGL(synth_volume_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), img, labels, N, D, H, W, n_classes, mode, noise, seed, sample0);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -419,7 +419,7 @@ __global__ void ncc_bwd_kernel(const float* __restrict__ x, const float* __restr
 // ------------------------------------------------------------------------------------------------
 struct BendK { float k[3][6]; };
 
-static BendK bending_coeffs(int N, int D, int H, int W, const float* spacing3, int normalize) {
+static BendK bending_coeffs(int N, int D, int H, int W, const float* spacing3, int normalize, int norm) {
     float sp[3] = {1.f, 1.f, 1.f};
     if (spacing3) { sp[0] = spacing3[0]; sp[1] = spacing3[1]; sp[2] = spacing3[2]; }
     if (normalize) { const float m = fminf(sp[0], fminf(sp[1], sp[2])); sp[0] /= m; sp[1] /= m; sp[2] /= m; }
@@ -430,7 +430,8 @@ static BendK bending_coeffs(int N, int D, int H, int W, const float* spacing3, i
     BendK K;
     for (int c = 0; c < 3; ++c)
         for (int t = 0; t < 6; ++t) {
-            const float w = dims[c] * sp[c] / den[t];            // loss.py:722-727 (vector over the channel axis)
+            // loss.py:722-727 (vector over the channel axis); any norm other than 'L2' skips that block: plain means of the |differences| (:729)
+            const float w = norm == 2 ? dims[c] * sp[c] / den[t] : 1.f;
             const double mult = (t < 3 ? 1.0 : 2.0) / (9.0 * 3.0 * (double)N * Mint);   // .mean(2), .mean(), /9, 2x mixed
             K.k[c][t] = (float)((double)(w * w) * mult);
         }
@@ -439,6 +440,7 @@ static BendK bending_coeffs(int N, int D, int H, int W, const float* spacing3, i
 
 #define BU(dd, hh, ww) u[((((long long)(dd)) * H + (hh)) * W + (ww)) * 3 + c]
 
+template <bool L1>
 __global__ void bending_partial_kernel(const float* __restrict__ disp, int D, int H, int W, BendK K,
                                        double* __restrict__ partial) {
     __shared__ double red[4];
@@ -458,7 +460,8 @@ __global__ void bending_partial_kernel(const float* __restrict__ disp, int D, in
         const float t3 = BU(d + 1, h + 1, w) + BU(d - 1, h - 1, w) - BU(d + 1, h - 1, w) - BU(d - 1, h + 1, w);
         const float t4 = BU(d, h + 1, w + 1) + BU(d, h - 1, w - 1) - BU(d, h + 1, w - 1) - BU(d, h - 1, w + 1);
         const float t5 = BU(d + 1, h, w + 1) + BU(d - 1, h, w - 1) - BU(d + 1, h, w - 1) - BU(d - 1, h, w + 1);
-        acc += K.k[c][0] * t0 * t0 + K.k[c][1] * t1 * t1 + K.k[c][2] * t2 * t2 + K.k[c][3] * t3 * t3 + K.k[c][4] * t4 * t4 + K.k[c][5] * t5 * t5;
+        if (L1) acc += K.k[c][0] * fabsf(t0) + K.k[c][1] * fabsf(t1) + K.k[c][2] * fabsf(t2) + K.k[c][3] * fabsf(t3) + K.k[c][4] * fabsf(t4) + K.k[c][5] * fabsf(t5);
+        else acc += K.k[c][0] * t0 * t0 + K.k[c][1] * t1 * t1 + K.k[c][2] * t2 * t2 + K.k[c][3] * t3 * t3 + K.k[c][4] * t4 * t4 + K.k[c][5] * t5 * t5;
         if (++cnt == 32) { dacc += (double)acc; acc = 0.f; cnt = 0; }
     }
     dacc += (double)acc;
@@ -474,15 +477,17 @@ __global__ void scalar_finalize_kernel(const double* __restrict__ partial, int c
     if (threadIdx.x == 0) loss[0] = (float)s;
 }
 
-// gather-form backward: d loss / d u[p] = 2 * sum_terms K * sum_{centres q containing p} term(q) * coef
+// gather-form backward: d loss / d u[p] = 2 * sum_terms K * sum_{centres q containing p} term(q) * coef  (L1: sign(term(q)) and no 2)
+template <bool L1>
 __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ dloss,
                                    float* __restrict__ d_disp, int D, int H, int W, BendK K) {
     const int n = blockIdx.y;
     const float* u = disp + (long long)n * D * H * W * 3;
     float* du = d_disp + (long long)n * D * H * W * 3;
     const long long total = (long long)D * H * W * 3;
-    const float gl = 2.f * dloss[0];
+    const float gl = (L1 ? 1.f : 2.f) * dloss[0];
     auto interior = [&](int d, int h, int w) { return d >= 1 && d < D - 1 && h >= 1 && h < H - 1 && w >= 1 && w < W - 1; };
+    auto f = [](float t) { return L1 ? (t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f)) : t; };      // d|t|/dt = sign(t) (0 at 0, torch.abs)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % 3); long long r = i / 3;
         const int w = (int)(r % W); r /= W;
@@ -493,15 +498,15 @@ __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* 
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
             if (interior(d, h, w)) {
                 const float u0 = BU(d, h, w);
-                s0 -= 2.f * (BU(d + 1, h, w) + BU(d - 1, h, w) - 2.f * u0);
-                s1 -= 2.f * (BU(d, h + 1, w) + BU(d, h - 1, w) - 2.f * u0);
-                s2 -= 2.f * (BU(d, h, w + 1) + BU(d, h, w - 1) - 2.f * u0);
+                s0 -= 2.f * f(BU(d + 1, h, w) + BU(d - 1, h, w) - 2.f * u0);
+                s1 -= 2.f * f(BU(d, h + 1, w) + BU(d, h - 1, w) - 2.f * u0);
+                s2 -= 2.f * f(BU(d, h, w + 1) + BU(d, h, w - 1) - 2.f * u0);
             }
 #pragma unroll
             for (int sgn = -1; sgn <= 1; sgn += 2) {
-                if (interior(d + sgn, h, w)) s0 += BU(d + 2 * sgn, h, w) + BU(d, h, w) - 2.f * BU(d + sgn, h, w);
-                if (interior(d, h + sgn, w)) s1 += BU(d, h + 2 * sgn, w) + BU(d, h, w) - 2.f * BU(d, h + sgn, w);
-                if (interior(d, h, w + sgn)) s2 += BU(d, h, w + 2 * sgn) + BU(d, h, w) - 2.f * BU(d, h, w + sgn);
+                if (interior(d + sgn, h, w)) s0 += f(BU(d + 2 * sgn, h, w) + BU(d, h, w) - 2.f * BU(d + sgn, h, w));
+                if (interior(d, h + sgn, w)) s1 += f(BU(d, h + 2 * sgn, w) + BU(d, h, w) - 2.f * BU(d, h + sgn, w));
+                if (interior(d, h, w + sgn)) s2 += f(BU(d, h, w + 2 * sgn) + BU(d, h, w) - 2.f * BU(d, h, w + sgn));
             }
             g += K.k[c][0] * s0 + K.k[c][1] * s1 + K.k[c][2] * s2;
         }
@@ -514,11 +519,11 @@ __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* 
                 for (int sb = -1; sb <= 1; sb += 2) {
                     const float cf = (float)(sa * sb);
                     { const int qd = d - sa, qh = h - sb;   // (D,H)
-                      if (interior(qd, qh, w)) s3 += cf * (BU(qd + 1, qh + 1, w) + BU(qd - 1, qh - 1, w) - BU(qd + 1, qh - 1, w) - BU(qd - 1, qh + 1, w)); }
+                      if (interior(qd, qh, w)) s3 += cf * f(BU(qd + 1, qh + 1, w) + BU(qd - 1, qh - 1, w) - BU(qd + 1, qh - 1, w) - BU(qd - 1, qh + 1, w)); }
                     { const int qh = h - sa, qw = w - sb;   // (H,W)
-                      if (interior(d, qh, qw)) s4 += cf * (BU(d, qh + 1, qw + 1) + BU(d, qh - 1, qw - 1) - BU(d, qh + 1, qw - 1) - BU(d, qh - 1, qw + 1)); }
+                      if (interior(d, qh, qw)) s4 += cf * f(BU(d, qh + 1, qw + 1) + BU(d, qh - 1, qw - 1) - BU(d, qh + 1, qw - 1) - BU(d, qh - 1, qw + 1)); }
                     { const int qd = d - sa, qw = w - sb;   // (D,W)
-                      if (interior(qd, h, qw)) s5 += cf * (BU(qd + 1, h, qw + 1) + BU(qd - 1, h, qw - 1) - BU(qd + 1, h, qw - 1) - BU(qd - 1, h, qw + 1)); }
+                      if (interior(qd, h, qw)) s5 += cf * f(BU(qd + 1, h, qw + 1) + BU(qd - 1, h, qw - 1) - BU(qd + 1, h, qw - 1) - BU(qd - 1, h, qw + 1)); }
                 }
             g += K.k[c][3] * s3 + K.k[c][4] * s4 + K.k[c][5] * s5;
         }
@@ -721,15 +726,16 @@ extern "C" size_t da_bending_ws_bytes(int N, int D, int H, int W) {
     return da_align((size_t)N * kBendBlocks * sizeof(double));
 }
 
-extern "C" int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize,
+extern "C" int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize, int norm,
                               float* loss, void* ws, size_t ws_bytes, void* stream) {
-    if (!disp || !loss || N <= 0 || D < 3 || H < 3 || W < 3) return DA_ERR_BADARG;
+    if (!disp || !loss || N <= 0 || D < 3 || H < 3 || W < 3 || (norm != 1 && norm != 2)) return DA_ERR_BADARG;
     if (ws_bytes < da_bending_ws_bytes(N, D, H, W)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
-    const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize);
+    const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize, norm);
     const long long total = (long long)(D - 2) * (H - 2) * (W - 2) * 3;
     int nblocks = (int)da_cdiv(total, 256 * 2); if (nblocks > kBendBlocks) nblocks = kBendBlocks; if (nblocks < 1) nblocks = 1;
-    hipLaunchKernelGGL(bending_partial_kernel, dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
+    if (norm == 2) hipLaunchKernelGGL((bending_partial_kernel<false>), dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
+    else hipLaunchKernelGGL((bending_partial_kernel<true>), dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
     DA_LAUNCH_CHECK();
     hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nblocks * N, loss);
     DA_LAUNCH_CHECK();
@@ -737,11 +743,12 @@ extern "C" int da_bending_fwd(const float* disp, int N, int D, int H, int W, con
 }
 
 extern "C" int da_bending_bwd(const float* disp, const float* dloss, float* d_disp, int N, int D, int H, int W,
-                              const float* spacing3, int normalize, void* stream) {
-    if (!disp || !dloss || !d_disp || N <= 0 || D < 3 || H < 3 || W < 3) return DA_ERR_BADARG;
-    const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize);
+                              const float* spacing3, int normalize, int norm, void* stream) {
+    if (!disp || !dloss || !d_disp || N <= 0 || D < 3 || H < 3 || W < 3 || (norm != 1 && norm != 2)) return DA_ERR_BADARG;
+    const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize, norm);
     const long long total = (long long)D * H * W * 3;
-    hipLaunchKernelGGL(bending_bwd_kernel, dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
+    if (norm == 2) hipLaunchKernelGGL((bending_bwd_kernel<false>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
+    else hipLaunchKernelGGL((bending_bwd_kernel<true>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -50,6 +50,21 @@ class SyntheticPairDataset(Dataset):
         return im, it, sm, st_
 
 
+def synthetic_batch_on_device(n, shape, n_classes, seed=230, device='cuda', structured=False, noise=0.1, sample0=0):
+    """synthetic volumes generated in HBM by the HIP kernel da_synth_volume (no host tensor, no PCIe copy).
+    Returns (image n x 1 x D x H x W float32 in [0,1], labels n x D x H x W uint8).  structured=False: iid throughput inputs
+    (SURVEY.md 8d); structured=True: the blocky label / noisy image volumes of SyntheticSegDataset's kind (Dice-parity inputs)."""
+    from .. import _native as nat
+    D, H, W = (int(s) for s in shape)
+    img = torch.empty((n, 1, D, H, W), dtype=torch.float32, device=device)
+    lab = torch.empty((n, D, H, W), dtype=torch.uint8, device=device)
+    nat.require_cuda(img)
+    with torch.cuda.device(img.device):
+        nat.call('da_synth_volume', nat.ptr(img), nat.ptr(lab), n, D, H, W, int(n_classes), 1 if structured else 0, float(noise),
+                 int(seed) & 0xffffffff, int(sample0), nat.stream())
+    return img, lab
+
+
 def get_seg_dataset(name):
     if name == 'synthetic':
         return SyntheticSegDataset

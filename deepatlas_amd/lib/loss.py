@@ -2,8 +2,7 @@
 
 Hot path: 'dice' -> DiceLossMultiClass, 'ncc' -> NormalizedCrossCorrelationLoss,
 'bendingEnergy' -> BendingEnergyLoss; SURVEY.md §8f f2: 'lncc' -> VoxelMorphLNCC, 'gradient' -> gradientLoss (reglosses.hip).
-'mse' / 'L2' are one-line compositions; the remaining registry names (focal, cross_entropy, soft_cross_entropy) are outside
-the volumetric hot path and raise NotImplementedError on construction instead of silently running elsewhere.
+'mse' / 'L2' are one-line compositions; 'focal' / 'cross_entropy' / 'soft_cross_entropy' share one voxelwise HIP kernel pair (xent.hip).
 """
 import torch
 import torch.nn as nn
@@ -81,12 +80,11 @@ class NormalizedCrossCorrelationLoss(nn.Module):
 
 
 class BendingEnergyLoss(nn.Module):
-    """Bending energy of a 3D displacement field (lib/loss.py:674-730), norm='L2'."""
+    """Bending energy of a 3D displacement field (lib/loss.py:674-730).  norm='L2': weighted squared differences (:721-727); any
+    other value skips that block in the reference, leaving the plain mean of the absolute differences (:729) -- same here."""
 
     def __init__(self, norm='L2', spacing=(1, 1, 1), normalize=True):
         super(BendingEnergyLoss, self).__init__()
-        if norm != 'L2':
-            raise NotImplementedError("only norm='L2' does anything in the reference (lib/loss.py:721)")
         self.norm = norm
         self.spacing = torch.tensor(spacing).float()
         self.normalize = normalize
@@ -94,7 +92,7 @@ class BendingEnergyLoss(nn.Module):
             self.spacing /= self.spacing.min()
 
     def forward(self, input):
-        return ops.BendingFn.apply(input, tuple(float(s) for s in self.spacing), self.normalize)
+        return ops.BendingFn.apply(input, tuple(float(s) for s in self.spacing), self.normalize, 2 if self.norm == 'L2' else 1)
 
 
 class VoxelMorphLNCC(nn.Module):
@@ -179,13 +177,58 @@ class L2Loss(nn.Module):
         return (input ** 2).mean()
 
 
-def _out_of_scope(name, cite):
-    class _Unavailable(nn.Module):
-        def __init__(self, *a, **k):
-            super().__init__()
-            raise NotImplementedError("loss '%s' (%s) has no HIP kernel yet (SURVEY.md §8f)" % (name, cite))
-    _Unavailable.__name__ = name
-    return _Unavailable
+class SoftCrossEntropy(nn.Module):
+    """lib/loss.py:100-154 (registry 'soft_cross_entropy'): cross entropy against a class-probability target B x C x D x M x N.
+    The reference's index-target branch multiplies the un-flattened B x D x M x N mask into B x C x D x M x N log-probabilities
+    (`target`, not `target_flat`, :151-153) and fails to broadcast; that call raises here too."""
+
+    def __init__(self, n_class=None, weight_type='Simple', no_bg=False, softmax=False):
+        super(SoftCrossEntropy, self).__init__()
+        self.weight_type = weight_type
+        self.n_class = n_class
+        self.no_bg = no_bg
+        self.softmax = softmax
+
+    def forward(self, pred, target):
+        shape = list(pred.shape)
+        if len(target.shape) == len(shape) - 1:
+            raise RuntimeError("SoftCrossEntropy: an index target does not broadcast against the predictions in the reference "
+                               "(lib/loss.py:151-153 use `target`, not the one-hot `target_flat`); pass class probabilities B x C x ...")
+        if target.shape[1] != shape[1]:
+            raise ValueError("Incorrect size of target tensor: {}, should be {} or []".format(target.shape, shape,
+                                                                                             shape[:1] + [1, ] + shape[2:]))
+        return ops.XentFn.apply(pred, None, target, None, 2, self.softmax, 0.0, -100, 0)
+
+
+class FocalLoss(nn.Module):
+    """lib/loss.py:157-213 (registry 'focal'): -alpha[t] (1 - probs)^gamma log_p with log_p = -F.cross_entropy(inputs, t) and
+    probs = F.nll_loss(P, t) = -P[t] -- so the modulating factor is (1 + P[t])^gamma, as in the reference."""
+
+    def __init__(self, class_num, alpha=None, gamma=2, size_average=True, soft_max=True):
+        super(FocalLoss, self).__init__()
+        self.alpha = torch.ones(class_num, 1) if alpha is None else alpha
+        self.gamma = gamma
+        self.class_num = class_num
+        self.size_average = size_average
+        self.soft_max = soft_max
+
+    def forward(self, inputs, targets):
+        return ops.XentFn.apply(inputs, targets, None, self.alpha, 1, self.soft_max, float(self.gamma), -100, 0 if self.size_average else 1)
+
+
+class CrossEntropyLoss(nn.Module):
+    """torch.nn.CrossEntropyLoss as registered under 'cross_entropy' (lib/loss.py:749): index targets B x D x M x N, `ignore_index`,
+    reduction 'mean' | 'sum'.  Class weights / label smoothing are not part of the reference's use and raise."""
+
+    def __init__(self, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction='mean', label_smoothing=0.0):
+        super(CrossEntropyLoss, self).__init__()
+        if weight is not None or label_smoothing != 0.0 or reduction not in ('mean', 'sum'):
+            raise NotImplementedError("HIP cross entropy: weight=None, label_smoothing=0, reduction 'mean' or 'sum'")
+        self.ignore_index = ignore_index
+        self.reduction = reduction
+
+    def forward(self, input, target):
+        return ops.XentFn.apply(input, target, None, None, 0, True, 0.0, self.ignore_index, 0 if self.reduction == 'mean' else 1)
 
 
 loss_dict = {
@@ -196,9 +239,9 @@ loss_dict = {
     'bendingEnergy': BendingEnergyLoss,
     'dice': DiceLossMultiClass,
     'L2': L2Loss,
-    'focal': _out_of_scope('focal', 'lib/loss.py:157-213'),
-    'cross_entropy': _out_of_scope('cross_entropy', 'torch.nn.CrossEntropyLoss'),
-    'soft_cross_entropy': _out_of_scope('soft_cross_entropy', 'lib/loss.py:100-154'),
+    'focal': FocalLoss,
+    'cross_entropy': CrossEntropyLoss,
+    'soft_cross_entropy': SoftCrossEntropy,
 }
 
 

@@ -8,6 +8,8 @@ compare against:
 
   reg phase (seg net frozen):  L = l_sim*NCC(warp(Im), It) + l_reg*Bending(disp) + l_anat*Dice(warp(onehot(Sm)), onehot(St))
   seg phase (reg net frozen):  L = l_sp*Dice(S(Im), Sm) + l_anat*Dice(warp(softmax(S(Im)), phi.detach()), onehot(St))
+  Sm = None (moving image without a manual segmentation): the reg phase warps softmax(S(Im)).detach() (segmentation net in eval
+  mode under no_grad: no state change) instead of onehot(Sm), and the seg phase drops its supervised term.
 """
 import torch
 
@@ -54,8 +56,15 @@ class DeepAtlasJointStep:
         # ---- registration phase (segmentation net not involved: the moving segmentation is given)
         self.reg.train()
         self.reg_opt.zero_grad()
+        if seg_m is None:
+            with torch.no_grad():
+                self.seg.eval()
+                prob_m = ops.SoftmaxFn.apply(self.seg(im_m))
         disp, warped, deform = self.reg(im_m, im_t)
-        warped_seg = ops.WarpLabelsFn.apply(seg_m, disp, self.n_classes)      # = warp(one_hot(seg_m)), one-hot never materialised
+        if seg_m is not None:
+            warped_seg = ops.WarpLabelsFn.apply(seg_m, disp, self.n_classes)      # = warp(one_hot(seg_m)), one-hot never materialised
+        else:
+            warped_seg, _ = ops.WarpFn.apply(prob_m, disp)                          # gradient flows to disp only (prob_m is a constant)
         l_sim = self.ncc(warped, im_t)
         l_reg = self.bend(disp)
         l_anat = self.dice_prob(warped_seg, seg_t)
@@ -68,7 +77,7 @@ class DeepAtlasJointStep:
         self.seg.train()
         self.seg_opt.zero_grad()
         logits = self.seg(im_m)
-        l_sp = self.dice_logits(logits, seg_m)
+        l_sp = self.dice_logits(logits, seg_m) if seg_m is not None else torch.zeros((), device=logits.device)
         prob = ops.SoftmaxFn.apply(logits)
         warped_prob, _ = ops.WarpFn.apply(prob, disp)
         l_anat2 = self.dice_prob(warped_prob, seg_t)

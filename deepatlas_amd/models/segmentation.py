@@ -114,7 +114,7 @@ class SegmentationExperiment(BaseExperiment):
         self.setup_train()
         print("Training {}".format(self.exp_name))
         finished_epoch, self.best_score = self.initialize_model(self.model, self.optimizer, self.config['resume_dir'])
-        parallel.broadcast_parameters(self.optimizer)
+        parallel.broadcast_parameters(self.optimizer, model=self.model)
         self.current_epoch = finished_epoch + 1
         for epoch in range(self.current_epoch, self.config['n_epochs'] + 1):
             self.train_one_epoch()
@@ -164,13 +164,14 @@ class SegmentationExperiment(BaseExperiment):
         with torch.no_grad():
             self.model.eval()
             dice_per_class = torch.zeros(self.config["n_classes"] - 1, dtype=torch.float64)
-            j = -1
+            n_vol = 0
             pred = images = truths = None
             for j, (images, truths, name) in enumerate(dataloader):
                 pred = self.model(images.to(self.device))
                 d = metrics.metricEval('dice', pred, truths.to(self.device))       # [N][C-1]
                 dice_per_class += torch.from_numpy(d.sum(0))
-            dice_per_class = (dice_per_class / (j + 1)).float()
+                n_vol += d.shape[0]                                                # average over VOLUMES (loaders may batch > 1)
+            dice_per_class = (dice_per_class / max(n_vol, 1)).float()
             dice_avg = dice_per_class.mean()
             sample_for_vis = {'img': images, 'truth': truths, 'pred': pred}
         return dice_per_class, dice_avg, sample_for_vis

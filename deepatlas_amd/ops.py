@@ -128,12 +128,25 @@ def _run_on_side(fn, keep_alive):
     _side_keep.extend(t for t in keep_alive if t is not None)
 
 
+_flat_buckets = []       # (device index, first byte, one-past-last byte) of every FlatAdam gradient bucket alive in this process
+
+
+def register_flat_bucket(flat_g):
+    """FlatAdam announces its gradient bucket: only gradients that live inside such a bucket are accumulated asynchronously (their
+    consumer -- FlatAdam.zero_grad / step, parallel.allreduce_gradients -- joins the side stream; any other optimiser would not)."""
+    _flat_buckets.append((flat_g.device.index, flat_g.data_ptr(), flat_g.data_ptr() + 4 * flat_g.numel()))
+
+
 def _async_target(param):
-    """The tensor to accumulate an asynchronous gradient into, or None for the synchronous autograd path."""
-    if not ASYNC_WGRAD or param is None or not isinstance(param, torch.nn.Parameter):
+    """The tensor to accumulate an asynchronous gradient into, or None for the synchronous autograd path (frozen parameters,
+    gradients that are not views of a registered FlatAdam bucket, ASYNC_WGRAD off)."""
+    if not ASYNC_WGRAD or param is None or not isinstance(param, torch.nn.Parameter) or not param.requires_grad:
         return None
     g = param.grad
     if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    a = g.data_ptr()
+    if not any(dev == g.device.index and lo <= a and a + 4 * g.numel() <= hi for dev, lo, hi in _flat_buckets):
         return None
     return g
 
@@ -673,8 +686,10 @@ class ConvBNActFn(Function):
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
             call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
-        gw = _async_target(ctx.wparam)
-        if gw is not None:
+        gw = _async_target(ctx.wparam) if ctx.needs_input_grad[2] else None
+        if not ctx.needs_input_grad[2]:
+            dw = None                                  # frozen weight: no weight-gradient kernel at all
+        elif gw is not None:
             global _last_side_flops
             _last_side_flops = 54.0 * (C1 + C2) * Cout * N * D * H * W
             side = side_stream()
@@ -760,8 +775,10 @@ class DeconvBNActFn(Function):
             dx = torch.empty_like(a)
             wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
             call('da_deconv_k2s2_dgrad', ptr(dy), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
-        gw = _async_target(ctx.wparam)
-        if gw is not None:
+        gw = _async_target(ctx.wparam) if ctx.needs_input_grad[1] else None
+        if not ctx.needs_input_grad[1]:
+            dw = None                                  # frozen weight
+        elif gw is not None:
             def side_work():                        # HBM-bound: overlaps the MFMA-bound conv data gradients on the main stream
                 dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
@@ -1050,7 +1067,7 @@ class BendingFn(Function):
     """BendingEnergyLoss.forward, norm='L2' (lib/loss.py:687-730)."""
 
     @staticmethod
-    def forward(ctx, disp, spacing, normalize):
+    def forward(ctx, disp, spacing, normalize, norm=2):
         u = ndhwc(disp)
         N, D, H, W, C = u.shape
         if C != 3:
@@ -1058,8 +1075,8 @@ class BendingFn(Function):
         sp = (ctypes_float3(spacing))
         loss = _empty((1,), u)
         wp, wn = _ws(nat.lib().da_bending_ws_bytes(N, D, H, W), u)
-        call('da_bending_fwd', ptr(u), N, D, H, W, sp, 1 if normalize else 0, ptr(loss), wp, wn, stream())
-        ctx.cfg = (tuple(float(s) for s in spacing), bool(normalize))
+        call('da_bending_fwd', ptr(u), N, D, H, W, sp, 1 if normalize else 0, int(norm), ptr(loss), wp, wn, stream())
+        ctx.cfg = (tuple(float(s) for s in spacing), bool(normalize), int(norm))
         ctx.save_for_backward(u)
         return loss.reshape(())
 
@@ -1067,11 +1084,48 @@ class BendingFn(Function):
     def backward(ctx, gloss):
         u, = ctx.saved_tensors
         N, D, H, W, _ = u.shape
-        spacing, normalize = ctx.cfg
+        spacing, normalize, norm = ctx.cfg
         gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
         du = torch.empty_like(u)
-        call('da_bending_bwd', ptr(u), ptr(gl), ptr(du), N, D, H, W, ctypes_float3(spacing), 1 if normalize else 0, stream())
-        return ncdhw(du), None, None
+        call('da_bending_bwd', ptr(u), ptr(gl), ptr(du), N, D, H, W, ctypes_float3(spacing), 1 if normalize else 0, norm, stream())
+        return ncdhw(du), None, None, None
+
+
+class XentFn(Function):
+    """Cross-entropy family of the loss registry (lib/loss.py:739-761) on N x C x D x H x W logits: mode 0 nn.CrossEntropyLoss,
+    1 FocalLoss.forward (lib/loss.py:181-213), 2 SoftCrossEntropy.forward with a probability target (:115-154)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, soft_target, alpha, mode, softmax, gamma, ignore_index, reduction):
+        a = ndhwc(logits) if logits.dim() == 5 else logits.contiguous()
+        nat.require_cuda(a)
+        C = a.shape[-1]
+        M = a.numel() // C
+        lab = soft = None
+        lab_bytes = 0
+        if soft_target is not None:
+            soft = ndhwc(soft_target) if soft_target.dim() == 5 else soft_target.contiguous()
+        else:
+            lab, lab_bytes = _labels(labels.reshape(-1))
+            if lab.numel() != M:
+                raise ValueError('target has %d elements for %d voxels' % (lab.numel(), M))
+        al = alpha.detach().to(a.device, torch.float32).reshape(-1).contiguous() if alpha is not None else None
+        loss, denom = _empty((1,), a), _empty((1,), a)
+        wp, wn = _ws(nat.lib().da_xent_ws_bytes(), a)
+        call('da_xent_fwd', ptr(a), ptr(lab), lab_bytes, ptr(soft), ptr(al), M, C, int(mode), 1 if softmax else 0, float(gamma),
+             int(ignore_index), int(reduction), ptr(loss), ptr(denom), wp, wn, stream())
+        ctx.cfg = (M, C, int(mode), 1 if softmax else 0, float(gamma), int(ignore_index), lab_bytes, logits.dim() == 5)
+        ctx.save_for_backward(a, lab, soft, al, denom)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        a, lab, soft, al, denom = ctx.saved_tensors
+        M, C, mode, softmax, gamma, ignore, lab_bytes, five = ctx.cfg
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        dx = torch.empty_like(a)
+        call('da_xent_bwd', ptr(a), ptr(lab), lab_bytes, ptr(soft), ptr(al), ptr(gl), ptr(denom), ptr(dx), M, C, mode, softmax, gamma, ignore, stream())
+        return (ncdhw(dx) if five else dx), None, None, None, None, None, None, None, None
 
 
 class LNCCFn(Function):

@@ -15,10 +15,15 @@ from ._native import call, ptr, stream
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError('FlatAdam implements torch.optim.Adam as the reference uses it (models/segmentation.py:91): '
+                                      'no weight decay, no amsgrad')
         params = [p for p in params]
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
         super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise NotImplementedError('FlatAdam updates ONE flat bucket with one (lr, betas, eps): pass a single parameter group')
         ps = [p for g in self.param_groups for p in g['params']]
         if not ps:
             raise ValueError('no parameters')
@@ -29,6 +34,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        ops.register_flat_bucket(self.flat_g)
         self._steps = 0
         self._slices = []
         off = 0
@@ -43,8 +49,19 @@ class FlatAdam(torch.optim.Optimizer):
             self._slices.append((p, off, k))
             off += k
 
+    def _set_step_count(self, n):
+        self._steps = int(n)
+        for p, _, _ in self._slices:
+            self.state[p]['step'] = torch.tensor(float(n))
+
+    def add_param_group(self, param_group):
+        if getattr(self, 'flat_p', None) is not None:
+            raise NotImplementedError('FlatAdam: parameters are fixed at construction (they live in one flat bucket)')
+        super().add_param_group(param_group)
+
     def zero_grad(self, set_to_none=False):
-        """Gradients live in the flat bucket: zero it in one memset and keep the views attached."""
+        """Gradients live in the flat bucket: zero it in one memset and keep the views attached (`set_to_none` would detach them
+        from the bucket the all-reduce and the Adam kernel work on, so it is ignored)."""
         ops.join_side_stream()                      # asynchronous weight gradients of the previous step have landed
         self.flat_g.zero_()
         for p, off, k in self._slices:
@@ -59,16 +76,39 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
                 p.grad = self.flat_g[off:off + k].view(p.shape)
 
+    def _frozen_mask(self):
+        """1.0 for elements whose parameter takes part in the update, 0.0 for frozen ones (requires_grad=False or no gradient this
+        step: torch.optim.Adam skips those entirely, moments included).  None when every parameter is live (the usual case)."""
+        frozen = [(off, k) for p, off, k in self._slices if (not p.requires_grad) or p.grad is None]
+        if not frozen:
+            return None
+        mask = torch.ones_like(self.flat_p)
+        for off, k in frozen:
+            mask[off:off + k] = 0
+        return mask
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
         self._gather_stray_grads()
         g = self.param_groups[0]
+        for p, off, k in self._slices:
+            if p.data_ptr() != self.flat_p.data_ptr() + 4 * off:
+                raise RuntimeError('FlatAdam: a parameter no longer lives in the flat bucket (model.to()/.half() after constructing the '
+                                   'optimiser?); build the optimiser after moving the model')
+        mask = self._frozen_mask()
+        if mask is not None:                        # frozen slices: keep p, m, v exactly as they are
+            keep = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone())
         self._steps += 1
         call('da_adam_step', ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), self.flat_p.numel(),
              float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self._steps, float(grad_scale), stream())
+        if mask is not None:
+            live = mask.bool()
+            for cur, old in zip((self.flat_p, self.flat_m, self.flat_v), keep):
+                cur.copy_(torch.where(live, cur, old))
         for p, _, _ in self._slices:
-            self.state[p]['step'] += 1
+            if p.requires_grad and p.grad is not None:
+                self.state[p]['step'] += 1
         return loss
 
     def load_state_dict(self, state_dict):

@@ -3,8 +3,9 @@
 The reference is single-process.  Volumes shard on the batch axis; BatchNorm stays
 per-replica (= the reference's batch-1 statistics); the only exchange is the mean of the gradients, which
 FlatAdam keeps in ONE contiguous fp32 buffer (seg 3.5 MB / reg 1.0 MB): a single torch.distributed all-reduce
-(backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests).  The 1/world_size scale is folded
-into the Adam kernel (grad_scale) rather than a separate pass.
+(backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests).  allreduce_gradients(average=True) (the default, what
+every caller in this package uses) divides the reduced bucket by world_size in place; callers that prefer to fold the scale into
+the Adam kernel call allreduce_gradients(average=False) and optimizer.step(grad_scale=1/world_size) -- never both.
 """
 import torch
 import torch.distributed as dist
@@ -41,11 +42,22 @@ def allreduce_gradients(optimizer, average=True):
     allreduce_flat_(optimizer.flat_g, average=average)
 
 
-def broadcast_parameters(optimizer, src=0):
-    """Make every replica start from rank `src`'s weights (one broadcast of the flat parameter bucket)."""
+def broadcast_parameters(optimizer, src=0, model=None):
+    """Make every replica start from rank `src`'s state: the flat parameter bucket, the Adam moments and step count (a resumed
+    checkpoint is loaded on every rank, but only rank `src`'s copy is authoritative) and, when `model` is given, its buffers
+    (BatchNorm running statistics)."""
     if not is_dist() or dist.get_world_size() == 1:
         return
     dist.broadcast(optimizer.flat_p, src=src)
+    if hasattr(optimizer, 'flat_m'):
+        dist.broadcast(optimizer.flat_m, src=src)
+        dist.broadcast(optimizer.flat_v, src=src)
+        steps = torch.tensor([float(optimizer._steps)], dtype=torch.float64, device=optimizer.flat_p.device)
+        dist.broadcast(steps, src=src)
+        optimizer._set_step_count(int(steps.item()))
+    if model is not None:
+        for b in model.buffers():
+            dist.broadcast(b, src=src)
 
 
 def distributed_sampler(dataset, shuffle=True, seed=0):

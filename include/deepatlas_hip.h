@@ -247,10 +247,26 @@ int da_ncc_bwd(const float* x, const float* y, const double* stats, const float*
 
 /* ---- bending-energy loss (row a13; lib/loss.py:687-730) --------------------------------------- */
 size_t da_bending_ws_bytes(int N, int D, int H, int W);
-int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize,
+/* norm: 2 = 'L2' (the weighted squared differences, :721-727); 1 = any other value of the reference's `norm`: the block at :721-727
+ * is skipped and the loss is the plain mean of the |differences| (:729). */
+int da_bending_fwd(const float* disp, int N, int D, int H, int W, const float* spacing3, int normalize, int norm,
                    float* loss, void* ws, size_t ws_bytes, void* stream);
 int da_bending_bwd(const float* disp, const float* dloss, float* d_disp, int N, int D, int H, int W,
-                   const float* spacing3, int normalize, void* stream);
+                   const float* spacing3, int normalize, int norm, void* stream);
+
+/* ---- cross-entropy family of the loss registry (lib/loss.py:739-761) ------------------------------------------------------
+ * logits [M][C] (channels-last voxels), C <= 64.  mode 0: 'cross_entropy' = torch.nn.CrossEntropyLoss(ignore_index, reduction);
+ * mode 1: 'focal' = FocalLoss.forward (lib/loss.py:181-213): -alpha[t] (1 + P[t])^gamma log_softmax(x)[t] with P = softmax(x) when
+ * `softmax` else x -- the reference's `1 - F.nll_loss(P, t)` is 1 PLUS p_t, kept; mode 2: 'soft_cross_entropy' = SoftCrossEntropy.forward
+ * (:115-154) with a class-probability target [M][C]: mean over voxels of sum_c -t_c log_softmax(x)_c (softmax) or -t_c log(max(x_c, 1e-8)).
+ * reduction: 0 mean (cross_entropy: over the non-ignored voxels), 1 sum.  denom (1 float, device) is written by fwd and read by bwd. */
+size_t da_xent_ws_bytes(void);
+int da_xent_fwd(const float* logits, const void* labels, int label_bytes, const float* soft_target, const float* alpha,
+                long long M, int C, int mode, int softmax, float gamma, long long ignore_index, int reduction,
+                float* loss, float* denom, void* ws, size_t ws_bytes, void* stream);
+int da_xent_bwd(const float* logits, const void* labels, int label_bytes, const float* soft_target, const float* alpha,
+                const float* dloss, const float* denom, float* dlogits, long long M, int C, int mode, int softmax, float gamma,
+                long long ignore_index, void* stream);
 
 /* ---- UNet_generator options (unets.py:230-237) ---------------------------------------------------------------
  * maxpool=False: nn.Conv3d(k2, s2, p0) down-sampler = the adjoint of the k2/s2 transposed conv (same pointwise MFMA kernels).
@@ -275,6 +291,13 @@ int da_crop3d(const void* src, void* dst, int elem_bytes, long long C, int D, in
 int da_partition_tiles(const void* vol, void* tiles, int elem_bytes, int D, int H, int W, const int* tile3, const int* overlap3, void* stream);
 /* vote == 0: copy the effective core of each tile; vote != 0 (uint8 labels): per-voxel majority over the covering tiles */
 int da_assemble_tiles(const void* tiles, void* vol, int elem_bytes, int D, int H, int W, const int* tile3, const int* overlap3, int vote, void* stream);
+
+/* synthetic volumes generated on the device (row f4; the structure of the BASELINE configs' synthetic data, the reference's sample
+ * convention lib/datasets.py:150-166: image [N][D][H][W] fp32 in [0,1], segmentation uint8).  Counter-based hash: element = f(seed,
+ * sample0 + n, voxel), restated bit-exactly in oracle/datapath.py.  mode 0: iid image ~ U[0,1), labels ~ U{0..C-1};
+ * mode 1: blocky coordinate-function labels, image = clamp(label / (C-1) + noise U, 0, 1).  img or labels may be NULL. */
+int da_synth_volume(float* img, unsigned char* labels, int N, int D, int H, int W, int n_classes, int mode, float noise,
+                    unsigned int seed, int sample0, void* stream);
 
 /* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC = registry 'lncc', and :512-586 LNCCLoss) -----
  * I, J: [N][D][H][W] fp32 (single channel); all-ones F^3 window with dilation `dil` and stride `stride` (1, 1 for VoxelMorphLNCC),

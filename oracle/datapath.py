@@ -61,3 +61,38 @@ class Partition:
                     out[i * self.eff[0]:(i + 1) * self.eff[0], j * self.eff[1]:(j + 1) * self.eff[1], k * self.eff[2]:(k + 1) * self.eff[2]] = \
                         tiles[ind][self.ov[0]:self.tile[0] - self.ov[0], self.ov[1]:self.tile[1] - self.ov[1], self.ov[2]:self.tile[2] - self.ov[2]]
         return out[:self.size[0], :self.size[1], :self.size[2]]
+
+
+# ---- synthetic volumes (restates deepatlas_amd/csrc/datapath.hip synth_volume_kernel; the reference has no synthetic data: the
+#      sample convention (image [D][H][W] fp32 in [0,1], segmentation uint8) is lib/datasets.py:150-166) ----------------------------
+def _mix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+    return x
+
+
+def _synth_bits(seed, ctr, stream_id):
+    hi = (ctr >> np.uint64(32)).astype(np.uint32)
+    lo = (ctr & np.uint64(0xffffffff)).astype(np.uint32)
+    with np.errstate(over='ignore'):
+        return _mix32(_mix32(lo ^ _mix32(np.uint32(seed) + np.uint32(0x9e3779b9) * hi)) + np.uint32(stream_id))
+
+
+def synth_volume(N, shape, n_classes, mode, noise, seed, sample0=0):
+    """-> (img [N][D][H][W] float32, labels [N][D][H][W] uint8), bit-equal to da_synth_volume."""
+    D, H, W = shape
+    V = D * H * W
+    n = np.arange(N, dtype=np.uint64)[:, None]
+    v = np.arange(V, dtype=np.uint64)[None, :]
+    ctr = (np.uint64(sample0) + n) * np.uint64(V) + v
+    u = (_synth_bits(seed, ctr, 0) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    if mode == 0:
+        lab = (_synth_bits(seed, ctr, 1) % np.uint32(n_classes)).astype(np.uint8)
+        return u.reshape(N, D, H, W), lab.reshape(N, D, H, W)
+    bz, by, bx = max(D // 8, 1), max(H // 8, 1), max(W // 8, 1)
+    z, y, x = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing='ij')
+    base = (z // bz) * 5 + (y // by) * 3 + (x // bx)
+    lab = np.stack([(base + sample0 + k) % n_classes for k in range(N)], 0)
+    q = lab.astype(np.float32) / np.float32(max(n_classes - 1, 1))
+    img = np.clip(q + np.float32(noise) * u.reshape(N, D, H, W), np.float32(0), np.float32(1)).astype(np.float32)
+    return img, lab.astype(np.uint8)

@@ -59,8 +59,9 @@ def ncc_loss(inp, tgt):
     return 1 - ncc.mean()
 
 
-def bending_energy_loss(disp, spacing=(1., 1., 1.), normalize=True):
-    """BendingEnergyLoss.forward (norm='L2'), lib/loss.py:687-730.
+def bending_energy_loss(disp, spacing=(1., 1., 1.), normalize=True, norm='L2'):
+    """BendingEnergyLoss.forward, lib/loss.py:687-730 (norm != 'L2' skips the weighting block :721-727: plain means of the
+    absolute differences).
 
     Keeps the reference's quirks: mixed differences are not divided by 4; the per-axis
     weight vector spatial_dims=(D,H,W)/min is broadcast over the CHANNEL axis (:694-696,
@@ -82,12 +83,13 @@ def bending_energy_loss(disp, spacing=(1., 1., 1.), normalize=True):
     dxdy = (u[:, :, 2:, 2:, 1:-1] + u[:, :, :-2, :-2, 1:-1] - u[:, :, 2:, :-2, 1:-1] - u[:, :, :-2, 2:, 1:-1]).abs().reshape(B, C, -1)
     dydz = (u[:, :, 1:-1, 2:, 2:] + u[:, :, 1:-1, :-2, :-2] - u[:, :, 1:-1, 2:, :-2] - u[:, :, 1:-1, :-2, 2:]).abs().reshape(B, C, -1)
     dxdz = (u[:, :, 2:, 1:-1, 2:] + u[:, :, :-2, 1:-1, :-2] - u[:, :, 2:, 1:-1, :-2] - u[:, :, :-2, 1:-1, 2:]).abs().reshape(B, C, -1)
-    ddx = (ddx ** 2).mean(2) * (dims * sp / (sp[0] ** 2)) ** 2
-    ddy = (ddy ** 2).mean(2) * (dims * sp / (sp[1] ** 2)) ** 2
-    ddz = (ddz ** 2).mean(2) * (dims * sp / (sp[2] ** 2)) ** 2
-    dxdy = (dxdy ** 2).mean(2) * (dims * sp / (sp[0] * sp[1])) ** 2
-    dydz = (dydz ** 2).mean(2) * (dims * sp / (sp[1] * sp[2])) ** 2
-    dxdz = (dxdz ** 2).mean(2) * (dims * sp / (sp[2] * sp[0])) ** 2
+    if norm == 'L2':                                                        # :721-727
+        ddx = (ddx ** 2).mean(2) * (dims * sp / (sp[0] ** 2)) ** 2
+        ddy = (ddy ** 2).mean(2) * (dims * sp / (sp[1] ** 2)) ** 2
+        ddz = (ddz ** 2).mean(2) * (dims * sp / (sp[2] ** 2)) ** 2
+        dxdy = (dxdy ** 2).mean(2) * (dims * sp / (sp[0] * sp[1])) ** 2
+        dydz = (dydz ** 2).mean(2) * (dims * sp / (sp[1] * sp[2])) ** 2
+        dxdz = (dxdz ** 2).mean(2) * (dims * sp / (sp[2] * sp[0])) ** 2
     return (ddx.mean() + ddy.mean() + ddz.mean() + 2 * dxdy.mean() + 2 * dydz.mean() + 2 * dxdz.mean()) / 9.0
 
 
@@ -244,3 +246,42 @@ def lncc_multiscale_loss(I, J):
         lncc = cross * cross / (Iv * Jv + 1e-5)
         total = total + (1 - lncc.mean()) * w
     return total
+
+
+def cross_entropy_loss(logits, target, ignore_index=-100, reduction='mean'):
+    """Registry 'cross_entropy' = torch.nn.CrossEntropyLoss (lib/loss.py:749), restated from its definition: -log_softmax(x)[t]
+    over the voxels whose target is not `ignore_index`, mean over those voxels or sum."""
+    C = logits.shape[1]
+    lp = F.log_softmax(logits, 1).movedim(1, -1).reshape(-1, C)
+    t = target.reshape(-1).long()
+    keep = t != ignore_index
+    picked = -lp[keep].gather(1, t[keep].unsqueeze(1)).squeeze(1)
+    return picked.sum() if reduction == 'sum' else picked.sum() / keep.sum()
+
+
+def focal_loss(inputs, targets, class_num, alpha=None, gamma=2, size_average=True, soft_max=True):
+    """FocalLoss.forward, lib/loss.py:181-213.  Quirks kept: log_p is the log-softmax of `inputs` even when soft_max=False (:200), and
+    probs = F.nll_loss(P, t) = -P[t] (:201), so the modulating factor (1 - probs)^gamma is (1 + P[t])^gamma."""
+    C = inputs.shape[1]
+    x = inputs.movedim(1, -1).reshape(-1, C)                                # :187-189
+    t = targets.reshape(-1).long()
+    P = F.softmax(x, dim=1) if soft_max else x                              # :193-196
+    a = (torch.ones(class_num, 1) if alpha is None else alpha).to(x.dtype)[t].reshape(-1)   # :198
+    log_p = F.log_softmax(x, 1).gather(1, t.unsqueeze(1)).squeeze(1)        # :200  (= -cross_entropy)
+    probs = -P.gather(1, t.unsqueeze(1)).squeeze(1)                         # :201  (= nll_loss)
+    batch_loss = -a * torch.pow(1 - probs, gamma) * log_p                   # :203
+    return batch_loss.mean() if size_average else batch_loss.sum()          # :205-208
+
+
+def soft_cross_entropy_loss(pred, target, softmax=True):
+    """SoftCrossEntropy.forward with a class-probability target, lib/loss.py:151-154."""
+    if softmax:
+        return torch.mean(torch.sum(-target * F.log_softmax(pred, 1), 1))
+    return torch.mean(torch.sum(-target * torch.log(pred.clamp(min=1e-8)), 1))
+
+
+def seg_mask_to_one_hot(mask, n_classes):
+    """transforms.SegMaskToOneHot.one_mask_to_one_hot, lib/transforms.py:663-673: D x M x N mask -> C x D x M x N float."""
+    one_hot = torch.zeros([n_classes] + list(mask.shape), dtype=torch.float32)
+    one_hot.scatter_(0, mask.unsqueeze(0).long(), 1)
+    return one_hot

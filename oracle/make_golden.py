@@ -384,6 +384,65 @@ def run_datapath(ref, out):
         out['dp/part/%s/assemble_vote' % tag] = np.asarray(part.assemble(noisy, is_vote=True, if_itk=False))
 
 
+def run_registry_losses(ref, out):
+    """Round-2 additions: the registry's cross-entropy family (lib/loss.py:100-154 SoftCrossEntropy, :157-213 FocalLoss, :749
+    nn.CrossEntropyLoss), BendingEnergyLoss with norm != 'L2' (:721-729) and transforms.SegMaskToOneHot (lib/transforms.py:652-673)."""
+    from oracle import nets
+    import warnings
+    warnings.simplefilter('ignore')
+    N, C, shape = 2, 5, (6, 10, 12)
+    x = (nets.closed_form_volume((N, C) + shape, seed=70) * 4 - 2).clone().requires_grad_(True)
+    y = nets.closed_form_labels((N,) + shape, C, seed=71)
+    out['xent/logits'], out['xent/labels'] = np32(x), np32(y).astype(np.uint8)
+    # cross_entropy (registry entry is torch.nn.CrossEntropyLoss itself)
+    for tag, kw, tgt in (('mean', {}, y.long()), ('sum', {'reduction': 'sum'}, y.long()),
+                         ('ignore', {'ignore_index': 2}, y.long())):
+        l = ref.loss.get_loss_function('cross_entropy')(**kw)(x, tgt)
+        g, = torch.autograd.grad(l, x)
+        out['xent/ce_%s/loss' % tag], out['xent/ce_%s/grad' % tag] = np.float64(l.item()), np32(g)
+    # focal: default alpha (ones), gamma 2; per-class alpha, gamma 1.5, sum reduction; soft_max=False on probabilities
+    alpha = torch.linspace(0.5, 1.5, C).reshape(C, 1)
+    out['xent/alpha'] = np32(alpha)
+    for tag, kw in (('default', {}), ('alpha_g15_sum', {'alpha': alpha, 'gamma': 1.5, 'size_average': False})):
+        l = ref.loss.get_loss_function('focal')(C, **kw)(x, y.long())
+        g, = torch.autograd.grad(l, x)
+        out['xent/focal_%s/loss' % tag], out['xent/focal_%s/grad' % tag] = np.float64(l.item()), np32(g)
+    p = torch.softmax(x.detach() * 0.7, 1).clone().requires_grad_(True)
+    out['xent/prob'] = np32(p)
+    l = ref.loss.get_loss_function('focal')(C, soft_max=False)(p, y.long())
+    g, = torch.autograd.grad(l, p)
+    out['xent/focal_nosoftmax/loss'], out['xent/focal_nosoftmax/grad'] = np.float64(l.item()), np32(g)
+    # soft cross entropy with a probability target; softmax=True on logits, softmax=False on probabilities (clamp_ is in place: clone)
+    t = torch.softmax(nets.closed_form_volume((N, C) + shape, seed=72) * 3, 1)
+    out['xent/soft_target'] = np32(t)
+    l = ref.loss.get_loss_function('soft_cross_entropy')(n_class=C, softmax=True)(x, t)
+    g, = torch.autograd.grad(l, x)
+    out['xent/soft_softmax/loss'], out['xent/soft_softmax/grad'] = np.float64(l.item()), np32(g)
+    p2 = p.detach().clone()
+    p2[0, 1, 0, 0, :4] = 0.0                                         # exercises the 1e-8 clamp
+    out['xent/prob_clamped_in'] = np32(p2)
+    p2.requires_grad_(True)
+    l = ref.loss.get_loss_function('soft_cross_entropy')(n_class=C, softmax=False)(p2 * 1.0, t)
+    g, = torch.autograd.grad(l, p2)
+    out['xent/soft_nosoftmax/loss'], out['xent/soft_nosoftmax/grad'] = np.float64(l.item()), np32(g)
+    try:
+        ref.loss.get_loss_function('soft_cross_entropy')(n_class=C, softmax=True)(x, y.long())
+        out['xent/soft_index_target_raises'] = np.int64(0)
+    except Exception:
+        out['xent/soft_index_target_raises'] = np.int64(1)
+    # bending energy, norm other than 'L2' (D != H != W as in ops.npz)
+    u = (nets.closed_form_volume((2, 3, 6, 10, 14), seed=62) * 0.3).clone().requires_grad_(True)
+    out['bendL1/u'] = np32(u)
+    for tag, kw in (('L1', {'norm': 'L1'}), ('L1_spacing', {'norm': 'L1', 'spacing': (1.0, 2.0, 1.5)})):
+        l = ref.loss.BendingEnergyLoss(**kw)(u)
+        g, = torch.autograd.grad(l, u)
+        out['bendL1/%s/loss' % tag], out['bendL1/%s/grad' % tag] = np.float64(l.item()), np32(g)
+    # SegMaskToOneHot on a D x M x N uint8 mask
+    seg = nets.closed_form_labels((1, 5, 6, 7), 4, seed=73)[0].to(torch.uint8)
+    smp = ref.transforms.SegMaskToOneHot(4)({'segmentation': seg.clone()})
+    out['onehot/seg'], out['onehot/segmentation_onehot'] = np32(seg), np32(smp['segmentation_onehot'])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -391,6 +450,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     from oracle import nets
 
+    out = {}
+    run_registry_losses(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'registry_losses.npz'), **out)
+    print('registry_losses.npz', len(out))
+    if os.environ.get('GOLDEN_ONLY') == 'xent':
+        return
     out = {}
     run_eval(ref, out)
     np.savez_compressed(os.path.join(OUT, 'eval.npz'), **out)

@@ -85,10 +85,16 @@ def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec,
     reg phase (seg net frozen): L = lam_sim*NCC(warp(Im), It) + lam_reg*Bending(disp)
                                     + lam_anat*Dice(warp(onehot(seg_m)), onehot(seg_t))   [soft 5-D target path]
     seg phase (reg net frozen): L = lam_sp*Dice(S(Im), seg_m) + lam_anat*Dice(warp(softmax(S(Im)), phi.detach()), onehot(seg_t))
-    Returns dict of losses.
+    seg_m=None (the moving image has no manual segmentation): the reg phase warps softmax(S(Im)).detach() -- the segmentation net in
+    eval mode, no state change -- instead of onehot(seg_m), and the seg phase has no supervised term.
+    Returns dict of losses (+ 'grads_reg' / 'grads_seg': the gradients each optimiser step consumed).
     """
-    onehot_m = losses.mask_to_one_hot(seg_m.long().unsqueeze(1), n_classes)
     onehot_t = losses.mask_to_one_hot(seg_t.long().unsqueeze(1), n_classes)
+    if seg_m is not None:
+        onehot_m = losses.mask_to_one_hot(seg_m.long().unsqueeze(1), n_classes)
+    else:
+        with torch.no_grad():
+            onehot_m = F.softmax(nets.unet_forward(seg_sd, im_m, spec, training=False), dim=1)
     # ---- reg phase
     rn = reg_opt.names
     for n in rn:
@@ -109,7 +115,8 @@ def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec,
     for n in sn:
         seg_sd[n].requires_grad_(True)
     logits = nets.unet_forward(seg_sd, im_m, spec, training=True)
-    l_sp = losses.dice_loss(logits, seg_m.long(), n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    l_sp = (losses.dice_loss(logits, seg_m.long(), n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+            if seg_m is not None else torch.zeros((), dtype=logits.dtype))
     prob = F.softmax(logits, dim=1)
     l_anat2 = losses.dice_loss(nets.warp_trilinear(prob, deform), onehot_t, n_classes,
                                weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)
@@ -119,4 +126,4 @@ def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec,
         seg_sd[n].requires_grad_(False)
     seg_opt.step(seg_sd, g2)
     return dict(loss_reg=loss_r.detach(), loss_seg=loss_s.detach(), sim=l_sim.detach(), bend=l_reg.detach(),
-                anat_reg=l_anat.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach())
+                anat_reg=l_anat.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach(), grads_reg=g, grads_seg=g2)

@@ -38,3 +38,11 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def max_abs_rel(a, b):
+    """Element-wise criterion next to rel_l2: the largest single-element error, in units of the reference tensor's largest magnitude.
+    A handful of wrong boundary voxels in a large tensor moves this, not the l2 norm."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)) if a.size else 0.0

@@ -84,3 +84,29 @@ def test_dp_two_ranks_one_gpu_matches_gradient_accumulation(tmp_path):
         acc += opt.flat_g
     ref = (acc / world).detach().cpu().numpy()
     assert np.max(np.abs(g0 - ref)) <= 1e-6 * np.max(np.abs(ref)), (float(np.max(np.abs(g0 - ref))), float(np.max(np.abs(ref))))
+
+
+def test_rccl_two_ranks_on_two_devices():
+    """RCCL with more than one rank (the collectives bench.py / parallel.py issue): skipped on the one-GPU box, runs
+    tools/rccl_smoke.py at world size 2 wherever two devices are visible (the 8-GPU node)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 visible GPUs (one-GPU box: RCCL world size 1 only)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(_free_port()), os.path.join(root, 'tools', 'rccl_smoke.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'rccl ok: world 2' in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` must not silently run fewer ranks: with N > visible devices it exits non-zero with a clear message."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and ('only %d GPU' % torch.cuda.device_count()) in out.stderr, out.stderr

@@ -1,0 +1,235 @@
+"""GPU parity at BASELINE's FULL size (2 x 160 x 192 x 160): crop equivalence against torch-CPU.
+
+Convolutions are local: a brick of the full-size HIP output depends only on the input brick + halo, so it can be compared with
+torch-CPU (the reference's arithmetic provider) run on the cropped input in milliseconds.  That exercises what the small-shape
+parity tests cannot: the XCD-aware brick walk, the persistent-grid tile partition, ragged edge tiles of the real volume, the sample
+boundary and the > 4 GiB addressing -- at the layer shapes of the headline step.  Bricks: the 8 volume corners' worth of edge
+cases (first / last voxel of every axis), the seams of the 32^3 brick order and of the XCD partition, the sample boundary.
+Criteria: rel-l2 <= 1e-5 AND max-abs <= 1e-5 of the brick's largest magnitude (element-wise).
+Weight gradients: dy is non-zero only inside the bricks, so the full-size kernel's dW must equal the sum of torch-CPU's dW over
+the cropped bricks (volume additivity)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2, max_abs_rel
+
+pytestmark = pytest.mark.gpu
+FULL = (160, 192, 160)
+TOL = 1e-5
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def gpu_rand(shape, seed, scale=1.0):
+    """uniform [-scale, scale) generated on the device, logical N x C x D x H x W with channels-last strides"""
+    g = torch.Generator(device=dev()).manual_seed(seed)
+    N, C, D, H, W = shape
+    t = torch.empty((N, D, H, W, C), device=dev())
+    t.uniform_(-scale, scale, generator=g)
+    return t.permute(0, 4, 1, 2, 3)
+
+
+def bricks(D, H, W, size=(10, 12, 14)):
+    """>= 8 output bricks (origin triples): the two opposite volume corners, every face's far edge, the 32-voxel brick seams, a seam of
+    the XCD partition of the tile order (middle of the volume), and ragged far corners."""
+    bd, bh, bw = size
+    o = [(0, 0, 0), (D - bd, H - bh, W - bw), (0, H - bh, 0), (D - bd, 0, W - bw), (0, 0, W - bw), (D - bd, H - bh, 0),
+         (32 - bd // 2, 32 - bh // 2, 32 - bw // 2), (D // 2 - bd // 2, H // 2 - bh // 2, W // 2 - bw // 2),
+         (64 - 3, 96 - 5, 128 - 7), (D - bd, 64 - bh // 2, 32 - 3)]
+    return [(max(0, min(d, D - bd)), max(0, min(h, H - bh)), max(0, min(w, W - bw))) + size for d, h, w in o]
+
+
+def crop_zero_halo(x, n, lo, hi):
+    """x: N x C x D x H x W device tensor; returns the CPU crop x[n, :, lo:hi] with indices outside the volume zero-filled
+    (= the convolution's zero padding)."""
+    C = x.shape[1]
+    dims = x.shape[2:]
+    out = torch.zeros((1, C) + tuple(h - l for l, h in zip(lo, hi)))
+    src = tuple(slice(max(l, 0), min(h, s)) for l, h, s in zip(lo, hi, dims))
+    dst = tuple(slice(max(l, 0) - l, min(h, s) - l) for l, h, s in zip(lo, hi, dims))
+    out[(0, slice(None)) + dst] = x[(n, slice(None)) + src].cpu()
+    return out
+
+
+def assert_close(a, b, what):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    e, m = rel_l2(a, b), max_abs_rel(a, b)
+    assert e <= TOL and m <= TOL, '%s: rel-l2 %.2e, max-abs %.2e of max|ref|' % (what, e, m)
+
+
+CONV_LAYERS = [
+    # name, C1, C2, Cout, stride            (SURVEY.md section 8 a1 / a7 layer table)
+    ('dec 48->16 concat', 32, 16, 16, 1),
+    ('dec 16->16', 16, 0, 16, 1),
+    ('enc0 1->8', 1, 0, 8, 1),
+    ('enc 8->16', 8, 0, 16, 1),
+    ('reg enc1 16->32 stride 2', 16, 0, 32, 2),
+    ('reg flow 24->3', 8, 16, 3, 1),
+]
+
+
+@pytest.mark.parametrize('name,C1,C2,Cout,stride', CONV_LAYERS, ids=[c[0].replace(' ', '_') for c in CONV_LAYERS])
+def test_full_size_conv_crops_vs_torch_cpu(name, C1, C2, Cout, stride):
+    from deepatlas_amd import ops
+    N = 2
+    D, H, W = FULL
+    x1 = gpu_rand((N, C1, D, H, W), 11)
+    x2 = gpu_rand((N, C2, D, H, W), 12) if C2 else None
+    g = torch.Generator().manual_seed(13)
+    w = (torch.rand((Cout, C1 + C2, 3, 3, 3), generator=g) * 2 - 1) * 0.2
+    b = (torch.rand((Cout,), generator=g) * 2 - 1) * 0.1
+    Do, Ho, Wo = ((D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
+    x1r, x2r = x1.detach().requires_grad_(True), (x2.detach().requires_grad_(True) if C2 else None)
+    wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.Conv3dK3Fn.apply(x1r, x2r, wg, bg, stride, -1.0)
+    assert tuple(y.shape) == (N, Cout, Do, Ho, Wo)
+    bl = bricks(Do, Ho, Wo)
+    # ---- forward: every brick of both samples' far ends (sample 0 start, sample 1 end = the sample boundary in memory)
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bl):
+        n = bi % N
+        lo = (d0 * stride - 1, h0 * stride - 1, w0 * stride - 1)
+        hi = ((d0 + bd - 1) * stride + 2, (h0 + bh - 1) * stride + 2, (w0 + bw - 1) * stride + 2)
+        xin = crop_zero_halo(x1, n, lo, hi)
+        if C2:
+            xin = torch.cat((xin, crop_zero_halo(x2, n, lo, hi)), 1)
+        ref = F.conv3d(xin, w, b, stride=stride, padding=0)
+        assert_close(y[n:n + 1, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw], ref, '%s fwd brick %d' % (name, bi))
+    # ---- backward: dy non-zero only inside the bricks (disjoint by construction of the list? no: overlapping bricks are merged by
+    # writing the same random field), so dx crops and the full dW follow from the bricks alone
+    dy = torch.zeros((N, Do, Ho, Wo, Cout), device=dev()).permute(0, 4, 1, 2, 3)
+    field = gpu_rand((N, Cout, Do, Ho, Wo), 14)
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bl):
+        n = bi % N
+        dy[n, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw] = field[n, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw]
+    y.backward(dy)
+    torch.cuda.synchronize()
+    # CPU: one autograd pass per sample over the bounding crops of each brick (input crop + halo covers everything dy touches)
+    dw_ref = torch.zeros_like(w, dtype=torch.float64)
+    db_ref = torch.zeros(Cout, dtype=torch.float64)
+    done = set()
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bl):
+        n = bi % N
+        if (n, d0, h0, w0) in done:
+            continue
+        done.add((n, d0, h0, w0))
+        # a brick enlarged by 2 output voxels on every side: every dy value that can reach the brick's input region is inside
+        e0 = (max(d0 - 2, 0), max(h0 - 2, 0), max(w0 - 2, 0))
+        e1 = (min(d0 + bd + 2, Do), min(h0 + bh + 2, Ho), min(w0 + bw + 2, Wo))
+        lo = tuple(a * stride - 1 for a in e0)
+        hi = tuple((c - 1) * stride + 2 for c in e1)
+        xin = crop_zero_halo(x1, n, lo, hi)
+        if C2:
+            xin = torch.cat((xin, crop_zero_halo(x2, n, lo, hi)), 1)
+        xin.requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        yr = F.conv3d(xin, wr, br, stride=stride, padding=0)
+        dyc = dy[n:n + 1, :, e0[0]:e1[0], e0[1]:e1[1], e0[2]:e1[2]].cpu()
+        yr.backward(dyc)
+        # dx of the input voxels under the brick proper (all their contributing outputs lie inside the enlarged brick)
+        i0 = tuple(a * stride for a in (d0, h0, w0))
+        i1 = tuple(min((a + s - 1) * stride + 1, dim) for a, s, dim in zip((d0, h0, w0), (bd, bh, bw), (D, H, W)))
+        sl = tuple(slice(a - l, c - l) for a, c, l in zip(i0, i1, lo))
+        gx = xin.grad[(0, slice(None)) + sl]
+        assert_close(x1r.grad[n, :, i0[0]:i1[0], i0[1]:i1[1], i0[2]:i1[2]], gx[:C1], '%s dgrad brick %d' % (name, bi))
+        if C2:
+            assert_close(x2r.grad[n, :, i0[0]:i1[0], i0[1]:i1[1], i0[2]:i1[2]], gx[C1:], '%s dgrad (skip half) brick %d' % (name, bi))
+    # weight / bias gradient: additivity over the bricks.  Overlapping enlarged crops would double count, so dW is accumulated from
+    # DISJOINT pieces: each brick proper with the dy values written into it (dy outside the bricks is zero).
+    written = torch.zeros((N, Do, Ho, Wo), dtype=torch.bool)
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bl):
+        n = bi % N
+        fresh = ~written[n, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw]
+        if not fresh.any():
+            continue
+        written[n, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw] = True
+        lo = (d0 * stride - 1, h0 * stride - 1, w0 * stride - 1)
+        hi = ((d0 + bd - 1) * stride + 2, (h0 + bh - 1) * stride + 2, (w0 + bw - 1) * stride + 2)
+        xin = crop_zero_halo(x1, n, lo, hi)
+        if C2:
+            xin = torch.cat((xin, crop_zero_halo(x2, n, lo, hi)), 1)
+        wr = w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        yr = F.conv3d(xin, wr, br, stride=stride, padding=0)
+        dyc = dy[n:n + 1, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw].cpu() * fresh.to(torch.float32)
+        yr.backward(dyc)
+        dw_ref += wr.grad.double()
+        db_ref += br.grad.double()
+    assert_close(wg.grad, dw_ref.float(), '%s wgrad (sum over bricks)' % name)
+    assert_close(bg.grad, db_ref.float(), '%s bias grad' % name)
+
+
+def test_full_size_transposed_conv_and_head_crops_vs_torch_cpu():
+    """ConvTranspose3d(32, 32, k2, s2) 80x96x80 -> 160x192x160 (the 1.26 GB up-sampler output) and the 1x1x1 head 16 -> 32 at full size."""
+    from deepatlas_amd import ops
+    N = 2
+    D, H, W = FULL
+    g = torch.Generator().manual_seed(21)
+    # --- transposed conv
+    x = gpu_rand((N, 32, D // 2, H // 2, W // 2), 22).detach().requires_grad_(True)
+    w = (torch.rand((32, 32, 2, 2, 2), generator=g) * 2 - 1) * 0.3
+    b = (torch.rand((32,), generator=g) * 2 - 1) * 0.1
+    y = ops.DeconvK2S2Fn.apply(x, w.to(dev()), b.to(dev()))
+    dy = gpu_rand((N, 32, D, H, W), 23)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bricks(D // 2, H // 2, W // 2, (6, 6, 8))):
+        n = bi % N
+        xc = x.detach()[n:n + 1, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw].cpu().requires_grad_(True)
+        yr = F.conv_transpose3d(xc, w, b, stride=2)
+        assert_close(y[n:n + 1, :, 2 * d0:2 * (d0 + bd), 2 * h0:2 * (h0 + bh), 2 * w0:2 * (w0 + bw)], yr, 'deconv fwd brick %d' % bi)
+        yr.backward(dy[n:n + 1, :, 2 * d0:2 * (d0 + bd), 2 * h0:2 * (h0 + bh), 2 * w0:2 * (w0 + bw)].cpu())
+        assert_close(x.grad[n:n + 1, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw], xc.grad, 'deconv dgrad brick %d' % bi)
+    del x, y, dy
+    # --- head
+    x = gpu_rand((N, 16, D, H, W), 24).detach().requires_grad_(True)
+    w = (torch.rand((32, 16, 1, 1, 1), generator=g) * 2 - 1) * 0.3
+    b = (torch.rand((32,), generator=g) * 2 - 1) * 0.1
+    y = ops.Conv1x1Fn.apply(x, w.to(dev()), b.to(dev()))
+    dy = gpu_rand((N, 32, D, H, W), 25)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bricks(D, H, W)):
+        n = bi % N
+        sl = (slice(n, n + 1), slice(None), slice(d0, d0 + bd), slice(h0, h0 + bh), slice(w0, w0 + bw))
+        xc = x.detach()[sl].cpu().requires_grad_(True)
+        yr = F.conv3d(xc, w, b)
+        assert_close(y[sl], yr, 'head fwd brick %d' % bi)
+        yr.backward(dy[sl].cpu())
+        assert_close(x.grad[sl], xc.grad, 'head dgrad brick %d' % bi)
+
+
+def test_full_size_fused_bn_block_crops_vs_torch_cpu():
+    """conv -> BatchNorm(train) -> LeakyReLU as ONE node at full size (the fused-statistics epilogue over 512 persistent workgroups):
+    per-channel batch statistics against a double-precision reduction of the HIP conv output itself, and the activated bricks against
+    torch-CPU's conv on the crop followed by the affine + LeakyReLU with those statistics."""
+    from deepatlas_amd import ops
+    N, C1, Cout = 2, 16, 16
+    D, H, W = FULL
+    x = gpu_rand((N, C1, D, H, W), 31)
+    g = torch.Generator().manual_seed(32)
+    w = (torch.rand((Cout, C1, 3, 3, 3), generator=g) * 2 - 1) * 0.2
+    b = (torch.rand((Cout,), generator=g) * 2 - 1) * 0.1
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.rand(Cout, generator=g) - 0.5
+    rm, rv = torch.zeros(Cout, device=dev()), torch.ones(Cout, device=dev())
+    out = ops.ConvBNActFn.apply(x, None, w.to(dev()), b.to(dev()), gamma.to(dev()), beta.to(dev()), rm, rv, True, 0.1, 1e-5, 0.01)
+    raw = ops.Conv3dK3Fn.apply(x, None, w.to(dev()), b.to(dev()), 1, -1.0)
+    r = raw.permute(0, 2, 3, 4, 1).reshape(-1, Cout).double()
+    mean, var = r.mean(0), r.var(0, unbiased=False)
+    M = r.shape[0]
+    # running stats: momentum 0.1, unbiased variance
+    assert torch.allclose(rm.double(), 0.1 * mean, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * var * M / (M - 1), rtol=1e-5, atol=1e-7)
+    scale = (gamma.double() / torch.sqrt(var.cpu() + 1e-5))
+    shift = beta.double() - mean.cpu() * scale
+    for bi, (d0, h0, w0, bd, bh, bw) in enumerate(bricks(D, H, W)):
+        n = bi % N
+        xin = crop_zero_halo(x, n, (d0 - 1, h0 - 1, w0 - 1), (d0 + bd + 1, h0 + bh + 1, w0 + bw + 1))
+        yr = F.conv3d(xin, w, b, padding=0).double()
+        ref = F.leaky_relu(yr * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), 0.01).float()
+        assert_close(out[n:n + 1, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw], ref, 'conv+BN+act brick %d' % bi)

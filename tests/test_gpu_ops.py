@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import rel_l2, max_abs_rel
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -36,6 +36,8 @@ def check(a, b, tol=TOL, what=''):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     e = rel_l2(a, b)
     assert e < tol, '%s rel-l2 %.3e' % (what, e)
+    m = max_abs_rel(a, b)                       # element-wise: no single element off by more than `tol` of the tensor's largest magnitude
+    assert m < tol, '%s max-abs %.3e of max|ref|' % (what, m)
 
 
 CONV_CASES = [
@@ -870,3 +872,100 @@ def test_warp_labels_equals_warp_of_onehot():
         d2 = cl(disp).requires_grad_(True)
         w2 = ops.WarpLabelsFn.apply(l, d2, C); (w2 * cl(go)).sum().backward()
         check(w2, w1, tol=1e-6, what='label warp fwd'); check(d2.grad, d1.grad, tol=1e-5, what='label warp grad_disp')
+
+
+# ---- round 2: registry cross-entropy family, bending norm != 'L2', SegMaskToOneHot, device synthetic generator -------------
+def test_registry_cross_entropy_family_golden(golden):
+    """'cross_entropy' / 'focal' / 'soft_cross_entropy' of the loss registry (lib/loss.py:739-761) on xent.hip against the
+    reference's own outputs (tests/golden/registry_losses.npz): loss and the gradient with respect to the predictions."""
+    from deepatlas_amd.lib.loss import get_loss_function
+    g = golden('registry_losses')
+    y = T(g['xent/labels']).to(dev())
+
+    def run(tag, crit, pred, target):
+        p = cl(T(pred)).requires_grad_(True)
+        l = crit(p, target)
+        l.backward()
+        ref = float(g[f'xent/{tag}/loss'])
+        assert abs(l.item() - ref) < 1e-5 * max(1.0, abs(ref)), (tag, l.item(), ref)
+        check(p.grad, g[f'xent/{tag}/grad'], what=tag + ' grad')
+
+    CE, FL, SCE = get_loss_function('cross_entropy'), get_loss_function('focal'), get_loss_function('soft_cross_entropy')
+    run('ce_mean', CE(), g['xent/logits'], y)
+    run('ce_mean', CE(), g['xent/logits'], y.long())                       # int64 targets (models/segmentation.py:154) as well as uint8
+    run('ce_sum', CE(reduction='sum'), g['xent/logits'], y)
+    run('ce_ignore', CE(ignore_index=2), g['xent/logits'], y)
+    run('focal_default', FL(5), g['xent/logits'], y)
+    run('focal_alpha_g15_sum', FL(5, alpha=T(g['xent/alpha']), gamma=1.5, size_average=False), g['xent/logits'], y)
+    run('focal_nosoftmax', FL(5, soft_max=False), g['xent/prob'], y)
+    t = cl(T(g['xent/soft_target']))
+    run('soft_softmax', SCE(n_class=5, softmax=True), g['xent/logits'], t)
+    run('soft_nosoftmax', SCE(n_class=5, softmax=False), g['xent/prob_clamped_in'], t)
+    with pytest.raises(RuntimeError):                                       # the reference's index-target branch fails to broadcast
+        SCE(n_class=5, softmax=True)(cl(T(g['xent/logits'])), y.long())
+
+
+def test_cross_entropy_c32_vs_torch():
+    """32 classes (the headline head), ragged voxel count, against torch-CPU's own CrossEntropyLoss and the oracle's focal restatement."""
+    from oracle import losses
+    from deepatlas_amd.lib.loss import get_loss_function
+    x = rnd((2, 32, 5, 7, 9), 1, 3.0)
+    y = torch.randint(0, 32, (2, 5, 7, 9), generator=torch.Generator().manual_seed(2))
+    xr = x.clone().requires_grad_(True)
+    lr_ = torch.nn.CrossEntropyLoss()(xr, y)
+    lr_.backward()
+    xg = cl(x).requires_grad_(True)
+    lg = get_loss_function('cross_entropy')()(xg, y.to(dev()))
+    lg.backward()
+    assert abs(lg.item() - lr_.item()) < 1e-5
+    check(xg.grad, xr.grad, what='CE C=32 grad')
+    xr2 = x.clone().requires_grad_(True)
+    lf = losses.focal_loss(xr2, y, 32)
+    lf.backward()
+    xg2 = cl(x).requires_grad_(True)
+    lg2 = get_loss_function('focal')(32)(xg2, y.to(dev()))
+    lg2.backward()
+    assert abs(lg2.item() - lf.item()) < 1e-5 * max(1.0, abs(lf.item()))
+    check(xg2.grad, xr2.grad, what='focal C=32 grad')
+
+
+def test_bending_energy_other_norm_golden(golden):
+    """BendingEnergyLoss(norm != 'L2') (lib/loss.py:721-729: the weighting block is skipped, plain mean of |differences|)."""
+    from deepatlas_amd.lib.loss import BendingEnergyLoss
+    g = golden('registry_losses')
+    for tag, kw in (('L1', {}), ('L1_spacing', {'spacing': (1.0, 2.0, 1.5)})):
+        u = cl(T(g['bendL1/u'])).requires_grad_(True)
+        l = BendingEnergyLoss(norm='L1', **kw)(u)
+        l.backward()
+        assert abs(l.item() - g[f'bendL1/{tag}/loss']) < 1e-5 * abs(g[f'bendL1/{tag}/loss']), tag
+        check(u.grad, g[f'bendL1/{tag}/grad'], what='bending L1 grad ' + tag)
+
+
+def test_seg_mask_to_one_hot_golden_bit_exact(golden):
+    """transforms.SegMaskToOneHot (lib/transforms.py:652-673) on the device, bit-equal to the reference's output."""
+    from deepatlas_amd.lib.transforms import SegMaskToOneHot
+    g = golden('registry_losses')
+    seg = T(g['onehot/seg']).to(dev())
+    out = SegMaskToOneHot(4)({'segmentation': seg})
+    assert out['segmentation'] is seg
+    oh = out['segmentation_onehot']
+    assert oh.dtype == torch.float32 and tuple(oh.shape) == (4,) + tuple(seg.shape)
+    assert np.array_equal(oh.cpu().numpy(), g['onehot/segmentation_onehot'])
+
+
+@pytest.mark.parametrize('structured', [False, True])
+def test_synthetic_volume_generator_bit_exact_vs_oracle(structured):
+    """SURVEY.md row f4 "synthetic-volume generator on device": da_synth_volume against its numpy restatement, bit for bit, including a
+    sample offset (rank r draws samples r*n ...), plus the full-size volume's value ranges."""
+    from oracle import datapath as dp
+    from deepatlas_amd.lib.datasets import synthetic_batch_on_device
+    shape = (9, 16, 23)
+    img, lab = synthetic_batch_on_device(3, shape, 32, seed=230, device=dev(), structured=structured, sample0=2)
+    ri, rl = dp.synth_volume(3, shape, 32, 1 if structured else 0, 0.1, 230, sample0=2)
+    assert np.array_equal(lab.cpu().numpy(), rl)
+    assert np.array_equal(img.cpu().numpy()[:, 0], ri)
+    big, bl = synthetic_batch_on_device(2, (160, 192, 160), 32, seed=7, device=dev(), structured=structured)
+    assert float(big.min()) >= 0.0 and float(big.max()) <= 1.0 and int(bl.max()) == 31 and int(bl.min()) == 0
+    if not structured:
+        assert abs(float(big.mean()) - 0.5) < 1e-3
+        assert np.array_equal(big[1, 0, :2, :3].cpu().numpy(), dp.synth_volume(2, (160, 192, 160), 32, 0, 0.1, 7)[0][1, :2, :3])

@@ -73,8 +73,12 @@ def test_out_of_scope_constructors_raise():
     assert 'down_samplers.0.weight' in g.state_dict() and not any(k.startswith('up_samplers') for k in g.state_dict())
     m = get_network('UNet')(1, 2, bias=True, BN=True)     # the fixed UNet is on the path: constructible on the host
     assert 'dc8.1.running_mean' in m.state_dict() and tuple(m.state_dict()['dc8.0.weight'].shape) == (768, 256, 3, 3, 3)
+    # the whole registry is constructible (round 2: 'focal' / 'cross_entropy' / 'soft_cross_entropy' run on xent.hip)
+    assert get_loss_function('focal')(5).class_num == 5 and get_loss_function('cross_entropy')().ignore_index == -100
+    assert get_loss_function('soft_cross_entropy')(n_class=5, softmax=True).softmax is True
+    assert get_loss_function('bendingEnergy')(norm='L1').norm == 'L1'
     with pytest.raises(NotImplementedError):
-        get_loss_function('focal')()
+        get_loss_function('cross_entropy')(label_smoothing=0.1)
     # rows f1/f2 are on the accelerated path: constructible on the host, state_dict as the reference's
     assert list(get_loss_function('lncc')().state_dict().keys()) == ['filter']
     assert get_loss_function('gradient')(spacing=(1, 2, 4)).spacing.tolist() == [1.0, 2.0, 4.0]

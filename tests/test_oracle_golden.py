@@ -318,3 +318,50 @@ def test_lncc_multiscale_oracle_vs_reference(golden):
         ga, gb = torch.autograd.grad(l, (A, B))
         assert abs(l.item() - float(g['lncc_ms/%s/loss' % tag])) < 1e-6
         assert rel_l2(summary_of(ga)[5:], g['lncc_ms/%s/grad_I' % tag][5:]) < 1e-5 and rel_l2(summary_of(gb)[5:], g['lncc_ms/%s/grad_J' % tag][5:]) < 1e-5
+
+
+def test_registry_losses_oracle_vs_reference(golden):
+    """Round-2 fixtures (tests/golden/registry_losses.npz, generated from the reference by oracle/make_golden.py): the registry's
+    cross-entropy family, BendingEnergyLoss with norm != 'L2', SegMaskToOneHot, and the device synthetic generator's restatement."""
+    from oracle import losses
+    g = golden('registry_losses')
+    x = T(g['xent/logits']).requires_grad_(True)
+    y = T(g['xent/labels'])
+
+    def check(tag, l, wrt):
+        gr, = torch.autograd.grad(l, wrt)
+        assert abs(l.item() - g[f'xent/{tag}/loss']) < 1e-6 * max(1.0, abs(g[f'xent/{tag}/loss'])), tag
+        assert rel_l2(gr.numpy(), g[f'xent/{tag}/grad']) < 1e-6, tag
+
+    check('ce_mean', losses.cross_entropy_loss(x, y), x)
+    check('ce_sum', losses.cross_entropy_loss(x, y, reduction='sum'), x)
+    check('ce_ignore', losses.cross_entropy_loss(x, y, ignore_index=2), x)
+    check('focal_default', losses.focal_loss(x, y, 5), x)
+    check('focal_alpha_g15_sum', losses.focal_loss(x, y, 5, alpha=T(g['xent/alpha']), gamma=1.5, size_average=False), x)
+    p = T(g['xent/prob']).requires_grad_(True)
+    check('focal_nosoftmax', losses.focal_loss(p, y, 5, soft_max=False), p)
+    t = T(g['xent/soft_target'])
+    check('soft_softmax', losses.soft_cross_entropy_loss(x, t, softmax=True), x)
+    p2 = T(g['xent/prob_clamped_in']).requires_grad_(True)
+    check('soft_nosoftmax', losses.soft_cross_entropy_loss(p2, t, softmax=False), p2)
+    assert int(g['xent/soft_index_target_raises']) == 1            # the reference's index-target branch fails; the product raises too
+    u = T(g['bendL1/u']).requires_grad_(True)
+    for tag, kw in (('L1', {}), ('L1_spacing', {'spacing': (1.0, 2.0, 1.5)})):
+        l = losses.bending_energy_loss(u, norm='L1', **kw)
+        gr, = torch.autograd.grad(l, u)
+        assert abs(l.item() - g[f'bendL1/{tag}/loss']) < 1e-7
+        assert rel_l2(gr.numpy(), g[f'bendL1/{tag}/grad']) < 1e-6
+    assert np.array_equal(losses.seg_mask_to_one_hot(T(g['onehot/seg']), 4).numpy(), g['onehot/segmentation_onehot'])
+
+
+def test_synth_volume_restatement_properties():
+    """oracle/datapath.py synth_volume (the bit-exact restatement of da_synth_volume): value ranges, determinism, sample offset."""
+    from oracle import datapath as dp
+    img, lab = dp.synth_volume(3, (8, 16, 24), 32, 0, 0.1, 230)
+    assert img.dtype == np.float32 and lab.dtype == np.uint8 and img.min() >= 0 and img.max() < 1 and lab.max() < 32
+    assert abs(img.mean() - 0.5) < 0.02 and len(np.unique(lab)) == 32
+    img2, lab2 = dp.synth_volume(1, (8, 16, 24), 32, 0, 0.1, 230, sample0=2)          # sample k is the same whatever batch it is drawn in
+    assert np.array_equal(img2[0], img[2]) and np.array_equal(lab2[0], lab[2])
+    simg, slab = dp.synth_volume(2, (16, 16, 24), 32, 1, 0.1, 230)
+    assert np.array_equal(slab[1], (slab[0].astype(int) + 1) % 32) and simg.max() <= 1.0
+    assert np.abs(simg - slab / np.float32(31)).max() <= 0.1 + 1e-6
