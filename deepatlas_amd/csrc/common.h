@@ -68,3 +68,6 @@ __device__ __forceinline__ float da_act_grad(float z, float slope) {
 // out[o] = sum_b partial[b][o] in double.  256 threads = 64 consecutive outputs x 4 slices of the partial list
 // (coalesced 256-byte rows, 4x shorter serial chains, O/64 workgroups), combined through LDS.
 int da_reduce_partials(const float* partial, int nparts, int O, float* out, hipStream_t st);
+// losses.hip: Dice loss / coefficients from per-block partial sums (shared with the fused label-warp Dice in warp.hip)
+int da_dice_finish(double* partial, int nblocks, int N, int C, int weight_type, int no_bg, float eps,
+                   float* loss, float* coef, float* isc, hipStream_t st);

@@ -652,6 +652,17 @@ extern "C" int da_dice_fwd(const float* src, const void* labels, int label_bytes
     return 0;
 }
 
+// Dice from per-block partial sums [N][nblocks][3][C] (I, S, T) produced by another kernel (the fused label-warp Dice, warp.hip):
+// reduce over the blocks, then weights / loss / backward coefficients exactly as da_dice_fwd.  isc: 3*N*C floats of scratch.
+int da_dice_finish(double* partial, int nblocks, int N, int C, int weight_type, int no_bg, float eps,
+                   float* loss, float* coef, float* isc, hipStream_t st) {
+    hipLaunchKernelGGL(colreduce_inplace_kernel, dim3((unsigned)da_cdiv((long long)N * 3 * C * 64, 256)), dim3(256), 0, st, partial, N, nblocks, 3 * C);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, 1, N, C, weight_type, no_bg, eps, loss, coef, isc);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int da_dice_bwd(const float* src, const void* labels, int label_bytes, const float* soft_target,
                            const float* coef, const float* dloss, float* d_src,
                            int N, long long V, int C, int softmax, void* stream) {

@@ -189,6 +189,67 @@ __global__ void warp_bwd_dsrc_lane_kernel(const float* __restrict__ dout, const 
     }
 }
 
+// ---- deterministic d_src (parity runs).  Float atomics add in arrival order, so two runs of the same step differ in the last bits
+// (and, through Adam, drift apart).  Integer addition is associative: every contribution w * g is converted to a 64-bit fixed-point
+// number with a power-of-two scale derived from max|gOut| (itself order-independent) and accumulated with 64-bit integer atomics
+// -- the sum is bit-identical whatever the order -- then converted back.  Resolution 2^-38 of max|gOut| per contribution (fp32 keeps
+// 2^-24 of each term), headroom for 2^24 contributions per element.  Costs an 8-byte scratch element + two extra passes: a switch,
+// not the default.
+__global__ void absmax_kernel(const float* __restrict__ x, long long n, unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float a = fabsf(x[i]);
+        m = (a == a && a <= 3.0e38f) ? fmaxf(m, a) : m;              // ignore NaN / inf
+    }
+    m = da_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+
+__device__ __forceinline__ float fixed_scale_from_max(unsigned int max_bits) {
+    const float m = __uint_as_float(max_bits);
+    if (!(m > 0.f)) return 1.f;
+    int e; frexpf(m, &e);                                             // m = f * 2^e, f in [0.5, 1)  ->  m < 2^e
+    return ldexpf(1.f, 38 - e);                                       // |w * g| * scale < 2^38
+}
+
+__global__ void warp_bwd_dsrc_fixed_kernel(const float* __restrict__ dout, const float* __restrict__ disp, unsigned long long* __restrict__ acc,
+                                           const unsigned int* __restrict__ max_bits, int N, int D, int H, int W, int C) {
+    const float scale = fixed_scale_from_max(max_bits[0]);
+    const long long total = (long long)N * D * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long v = i / C;
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int d = (int)(r % D); const int n = (int)(r / D);
+        const float gx = disp[v * 3 + 0] + id_coord(w, W);
+        const float gy = disp[v * 3 + 1] + id_coord(h, H);
+        const float gz = disp[v * 3 + 2] + id_coord(d, D);
+        if (!is_finite_coord(gx, gy, gz)) continue;
+        const Taps t = make_taps(gx, gy, gz, D, H, W);
+        const float g = dout[i];
+        unsigned long long* base = acc + (long long)n * D * H * W * C + c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                const long long q = __double2ll_rn((double)(wgt * g) * (double)scale);
+                atomicAdd(base + (((long long)z * H + y) * W + x) * C, (unsigned long long)q);      // two's complement wrap-around add
+            }
+        }
+    }
+}
+
+__global__ void fixed_to_float_kernel(const unsigned long long* __restrict__ acc, const unsigned int* __restrict__ max_bits,
+                                      float* __restrict__ out, long long n) {
+    const double inv = 1.0 / (double)fixed_scale_from_max(max_bits[0]);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (float)((double)(long long)acc[i] * inv);
+}
+
 // Warp of a LABEL map as if it were its one-hot encoding (the joint step's registration phase warps one-hot(seg_m) with the
 // predicted field): out[v][c] = sum_k w_k [label[corner_k] == c].  The 32-channel one-hot tensor (629 MB per
 // volume) is never materialised: 8 label bytes are read per voxel instead of 8 x 128 bytes.  One lane per channel.
@@ -281,6 +342,189 @@ __global__ void identity_grid_kernel(float* __restrict__ out, int D, int H, int 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused anatomy losses of the joint step: Dice of a WARPED segmentation against a label map.
+// Dice's gradient with respect to its input is g[v][c] = a[c] * [St[v] == c] + b[c] (a, b = `coef` of da_dice_fwd): rank-structured.
+//  * registration phase, Dice(warp(onehot(Sm), phi), onehot(St)): the warped 32-channel tensor (629 MB) is never built.  The three
+//    per-class sums Dice needs follow from the 8 (weight, label) pairs of every voxel, and the gradient reaching the displacement
+//    only needs g at the 8 corner labels -- computed from a, b on the fly.
+//  * segmentation phase, Dice(warp(softmax(S(Im)), phi), onehot(St)): the adjoint warp (a scatter of 8 x 32 float atomics per voxel)
+//    collapses to  W^T g = b[c] * A[u] + a[c] * B[u][c]  with  A = W^T 1  (one channel) and  B = W^T onehot(St)  (8 atomics per
+//    voxel land in channel St[v] only): 16 atomics per voxel instead of 256.
+// ------------------------------------------------------------------------------------------------
+template <int CPL>   // classes per lane; lpv = C / CPL lanes share a voxel
+__global__ void label_warp_dice_partial_kernel(const void* __restrict__ lab_m, int bm, const void* __restrict__ lab_t, int bt,
+                                               const float* __restrict__ disp, int D, int H, int W, int C, int lpv,
+                                               double* __restrict__ partial /* [N][gridDim.x][3][C] : I, S, T */) {
+    __shared__ double sred[4][3 * 64];
+    const int n = blockIdx.y;
+    const long long V = (long long)D * H * W;
+    const long long total = V * lpv;
+    float aS[CPL], aI[CPL], aT[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { aS[j] = 0.f; aI[j] = 0.f; aT[j] = 0.f; }
+    double dS[CPL], dI[CPL], dT[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { dS[j] = 0.0; dI[j] = 0.0; dT[j] = 0.0; }
+    int cnt = 0;
+    const long long sb = (long long)n * V;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % lpv);
+        const long long v = i / lpv;
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); const int d = (int)(r / H);
+        const float* u = disp + (sb + v) * 3;
+        const float gx = u[0] + id_coord(w, W), gy = u[1] + id_coord(h, H), gz = u[2] + id_coord(d, D);
+        const bool fin = is_finite_coord(gx, gy, gz);
+        const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
+        const int c0 = q * CPL;
+        const int tl = warp_label_at(lab_t, bt, sb + v) - c0;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) aT[j] += (tl == j) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                const int rel = warp_label_at(lab_m, bm, sb + ((long long)z * H + y) * W + x) - c0;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const float hit = (rel == j) ? wgt : 0.f;
+                    aS[j] += hit;
+                    aI[j] += (tl == j) ? hit : 0.f;
+                }
+            }
+        }
+        if (++cnt == 16) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { dS[j] += (double)aS[j]; dI[j] += (double)aI[j]; dT[j] += (double)aT[j]; aS[j] = aI[j] = aT[j] = 0.f; }
+            cnt = 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { dS[j] += (double)aS[j]; dI[j] += (double)aI[j]; dT[j] += (double)aT[j]; }
+    // lanes with the same q (= lane % lpv; 256 and 64 are multiples of lpv) hold the same classes: fixed-order xor tree over the others
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        double a = dI[j], b = dS[j], c = dT[j];
+        for (int o = lpv; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+        if (lane < lpv) { const int cls = lane * CPL + j; sred[wave][cls] = a; sred[wave][64 + cls] = b; sred[wave][128 + cls] = c; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * C; idx += blockDim.x) {
+        const int k = idx / C, c = idx % C;
+        const double s = sred[0][k * 64 + c] + sred[1][k * 64 + c] + sred[2][k * 64 + c] + sred[3][k * 64 + c];
+        partial[(((size_t)n * gridDim.x + blockIdx.x) * 3 + k) * C + c] = s;
+    }
+}
+
+// d loss / d disp of Dice(warp(onehot(lab_m))): the grid gradient of warp_labels_bwd_kernel with g[corner label] formed from coef
+__global__ void label_warp_dice_bwd_kernel(const void* __restrict__ lab_m, int bm, const void* __restrict__ lab_t, int bt,
+                                           const float* __restrict__ disp, const float* __restrict__ coef, const float* __restrict__ dloss,
+                                           float* __restrict__ d_disp, int N, int D, int H, int W, int C) {
+    const long long V = (long long)D * H * W, nvox = V * N;
+    const float gl = dloss[0];
+    const int NC = N * C;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int d = (int)(r % D); const int n = (int)(r / D);
+        const float gx = disp[v * 3 + 0] + id_coord(w, W);
+        const float gy = disp[v * 3 + 1] + id_coord(h, H);
+        const float gz = disp[v * 3 + 2] + id_coord(d, D);
+        const bool fin = is_finite_coord(gx, gy, gz);
+        const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
+        const long long sbase = (long long)n * V;
+        const int tl = warp_label_at(lab_t, bt, v);
+        float gix = 0.f, giy = 0.f, giz = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wx = cx ? t.fx0 : t.fx1, wy = cy ? t.fy0 : t.fy1, wz = cz ? t.fz0 : t.fz1;
+                const int lab = warp_label_at(lab_m, bm, sbase + ((long long)z * H + y) * W + x);
+                float dot = 0.f;
+                if (lab >= 0 && lab < C) dot = gl * (coef[n * C + lab] * (lab == tl ? 1.f : 0.f) + coef[NC + n * C + lab]);
+                gix += (cx ? dot : -dot) * wy * wz;
+                giy += (cy ? dot : -dot) * wx * wz;
+                giz += (cz ? dot : -dot) * wx * wy;
+            }
+        }
+        d_disp[v * 3 + 0] = gix * ((float)(W - 1) / 2.f);
+        d_disp[v * 3 + 1] = giy * ((float)(H - 1) / 2.f);
+        d_disp[v * 3 + 2] = giz * ((float)(D - 1) / 2.f);
+    }
+}
+
+// A[n][u] += w, B[n][u][St[v]] += w over the 8 taps of every voxel v  (A, B zero-filled by the launcher)
+__global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int bt, const float* __restrict__ disp,
+                                           float* __restrict__ A, float* __restrict__ B, int N, int D, int H, int W, int C) {
+    const long long V = (long long)D * H * W, nvox = V * N;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+        long long r = v;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int d = (int)(r % D); const int n = (int)(r / D);
+        const float gx = disp[v * 3 + 0] + id_coord(w, W);
+        const float gy = disp[v * 3 + 1] + id_coord(h, H);
+        const float gz = disp[v * 3 + 2] + id_coord(d, D);
+        if (!is_finite_coord(gx, gy, gz)) continue;
+        const Taps t = make_taps(gx, gy, gz, D, H, W);
+        const int lab = warp_label_at(lab_t, bt, v);
+        const bool lok = lab >= 0 && lab < C;
+        const long long sbase = (long long)n * V;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                const long long uu = sbase + ((long long)z * H + y) * W + x;
+                atomicAdd(A + uu, wgt);
+                if (lok) atomicAdd(B + uu * C + lab, wgt);
+            }
+        }
+    }
+}
+
+// dlogits[u][j] = p[u][j] (g[u][j] - sum_c g[u][c] p[u][c]),  g = gl_a (b_a[c] A[u] + a_a[c] B[u][c]) + gl_s (a_s[c] [Sm[u] == c] + b_s[c]),
+// p = softmax(logits) given as `prob`; written IN PLACE over B.  lpv = C / 4 lanes per voxel.
+__global__ void seg_anat_dlogits_kernel(const float* __restrict__ prob, const void* __restrict__ lab_m, int bm,
+                                        const float* __restrict__ A, float* __restrict__ B,
+                                        const float* __restrict__ coef_s, const float* __restrict__ coef_a,
+                                        const float* __restrict__ gl_s, const float* __restrict__ gl_a,
+                                        int N, long long V, int C, int lpv) {
+    const long long total = (long long)N * V * lpv;
+    const int NC = N * C;
+    const float gs = (coef_s && gl_s) ? gl_s[0] : 0.f, ga = gl_a ? gl_a[0] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % lpv);
+        const long long row = i / lpv;
+        const int n = (int)(row / V);
+        const float4 pv = *reinterpret_cast<const float4*>(prob + row * C + q * 4);
+        const float4 bv = *reinterpret_cast<const float4*>(B + row * C + q * 4);
+        const float a = A[row];
+        const float p[4] = {pv.x, pv.y, pv.z, pv.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
+        const int lab = (coef_s && lab_m) ? warp_label_at(lab_m, bm, row) - q * 4 : -1;
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = n * C + q * 4 + j;
+            g[j] = ga * (coef_a[NC + c] * a + coef_a[c] * b[j]);
+            if (coef_s) g[j] += gs * (coef_s[c] * (lab == j ? 1.f : 0.f) + coef_s[NC + c]);
+        }
+        float dot = g[0] * p[0] + g[1] * p[1] + g[2] * p[2] + g[3] * p[3];
+        for (int k = 1; k < lpv; k <<= 1) dot += __shfl_xor(dot, k);
+        *reinterpret_cast<float4*>(B + row * C + q * 4) = make_float4(p[0] * (g[0] - dot), p[1] * (g[1] - dot), p[2] * (g[2] - dot), p[3] * (g[3] - dot));
+    }
+}
+
 static bool vec_ok(int C, int* lpv) {
     if (C % 4 != 0) { *lpv = 1; return false; }
     const int q = C / 4;
@@ -344,6 +588,98 @@ extern "C" int da_warp_labels_bwd(const float* dout, const void* labels, int lab
     if (!dout || !labels || !disp || !d_disp || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (label_bytes != 1 && label_bytes != 8)) return DA_ERR_BADARG;
     const long long nvox = (long long)N * D * H * W;
     hipLaunchKernelGGL(warp_labels_bwd_kernel, dim3(da_grid(nvox, 256)), dim3(256), 0, da_stream(stream), dout, labels, label_bytes, disp, d_disp, N, D, H, W, C);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t da_warp_bwd_dsrc_det_ws_bytes(int N, int D, int H, int W, int C) {
+    return da_align((size_t)N * D * H * W * C * sizeof(unsigned long long)) + 256;
+}
+
+extern "C" int da_warp_bwd_dsrc_det(const float* dout, const float* disp, float* d_src, int N, int D, int H, int W, int C,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!dout || !disp || !d_src || !ws || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
+    if (ws_bytes < da_warp_bwd_dsrc_det_ws_bytes(N, D, H, W, C)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    const long long tot = (long long)N * D * H * W * C;
+    const size_t acc_bytes = da_align((size_t)tot * sizeof(unsigned long long));
+    unsigned long long* acc = (unsigned long long*)ws;
+    unsigned int* max_bits = (unsigned int*)((char*)ws + acc_bytes);
+    hipError_t e = hipMemsetAsync(ws, 0, acc_bytes + 256, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(absmax_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, dout, tot, max_bits);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(warp_bwd_dsrc_fixed_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, dout, disp, acc, (const unsigned int*)max_bits, N, D, H, W, C);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, (const unsigned long long*)acc, (const unsigned int*)max_bits, d_src, tot);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused anatomy losses (joint step) -------------------------------------------------------------------------------------
+static const int kLwdBlocks = 1024;
+
+extern "C" size_t da_label_warp_dice_ws_bytes(int N, int C) {
+    return da_align((size_t)N * kLwdBlocks * 3 * C * sizeof(double)) + da_align((size_t)3 * N * C * sizeof(float));
+}
+
+extern "C" int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,
+                                      int N, int D, int H, int W, int C, int weight_type, int no_bg, float eps,
+                                      float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+    if (!lab_m || !lab_t || !disp || !loss || !coef || N <= 0 || N > 64 || D < 2 || H < 2 || W < 2 || C <= 0 ||
+        (lab_m_bytes != 1 && lab_m_bytes != 8) || (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
+    if (C > 64 || C % 4 != 0) return DA_ERR_UNSUPPORTED;                 // callers fall back to warp(one-hot) + Dice
+    if (ws_bytes < da_label_warp_dice_ws_bytes(N, C)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    double* partial = (double*)ws;
+    float* isc = (float*)((char*)ws + da_align((size_t)N * kLwdBlocks * 3 * C * sizeof(double)));
+    const long long V = (long long)D * H * W;
+    // classes per lane: 8 when that leaves a power-of-two number of lanes per voxel, else 4
+    int cpl = 4;
+    if (C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0) cpl = 8;
+    const int lpv = C / cpl;
+    if (lpv > 64 || (lpv & (lpv - 1)) != 0) return DA_ERR_UNSUPPORTED;
+    int nblocks = (int)da_cdiv(V * lpv, 256 * 4); if (nblocks > kLwdBlocks) nblocks = kLwdBlocks; if (nblocks < 1) nblocks = 1;
+    if (cpl == 8) hipLaunchKernelGGL((label_warp_dice_partial_kernel<8>), dim3(nblocks, N), dim3(256), 0, st, lab_m, lab_m_bytes, lab_t, lab_t_bytes, disp, D, H, W, C, lpv, partial);
+    else hipLaunchKernelGGL((label_warp_dice_partial_kernel<4>), dim3(nblocks, N), dim3(256), 0, st, lab_m, lab_m_bytes, lab_t, lab_t_bytes, disp, D, H, W, C, lpv, partial);
+    DA_LAUNCH_CHECK();
+    return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
+}
+
+extern "C" int da_label_warp_dice_bwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,
+                                      const float* coef, const float* dloss, float* d_disp, int N, int D, int H, int W, int C, void* stream) {
+    if (!lab_m || !lab_t || !disp || !coef || !dloss || !d_disp || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 ||
+        (lab_m_bytes != 1 && lab_m_bytes != 8) || (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
+    const long long nvox = (long long)N * D * H * W;
+    hipLaunchKernelGGL(label_warp_dice_bwd_kernel, dim3(da_grid(nvox, 256)), dim3(256), 0, da_stream(stream), lab_m, lab_m_bytes, lab_t, lab_t_bytes,
+                       disp, coef, dloss, d_disp, N, D, H, W, C);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const float* disp, float* A, float* B,
+                                      int N, int D, int H, int W, int C, void* stream) {
+    if (!lab_t || !disp || !A || !B || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
+    hipStream_t st = da_stream(stream);
+    const long long nvox = (long long)N * D * H * W;
+    hipError_t e = hipMemsetAsync(A, 0, (size_t)nvox * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(B, 0, (size_t)nvox * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(warp_adjoint_labels_kernel, dim3(da_grid(nvox, 256)), dim3(256), 0, st, lab_t, lab_t_bytes, disp, A, B, N, D, H, W, C);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, float* B_dlogits,
+                                   const float* coef_sup, const float* coef_anat, const float* dloss_sup, const float* dloss_anat,
+                                   int N, long long V, int C, void* stream) {
+    if (!prob || !A || !B_dlogits || !coef_anat || !dloss_anat || N <= 0 || V <= 0 || C <= 0) return DA_ERR_BADARG;
+    if (coef_sup && (!lab_m || !dloss_sup || (lab_m_bytes != 1 && lab_m_bytes != 8))) return DA_ERR_BADARG;
+    int lpv; if (!vec_ok(C, &lpv)) return DA_ERR_UNSUPPORTED;
+    const long long total = (long long)N * V * lpv;
+    hipLaunchKernelGGL(seg_anat_dlogits_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), prob, lab_m, lab_m_bytes, A, B_dlogits,
+                       coef_sup, coef_anat, dloss_sup, dloss_anat, N, V, C, lpv);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -41,7 +41,8 @@ class DeepAtlasJointStep:
     """Alternating joint step (one reg phase + one seg phase per image pair)."""
 
     def __init__(self, seg_model, seg_opt, reg_model, reg_opt, n_classes,
-                 lam_sim=1.0, lam_reg=1.0, lam_anat=1.0, lam_sp=1.0):
+                 lam_sim=1.0, lam_reg=1.0, lam_anat=1.0, lam_sp=1.0, fused=True):
+        self.fused = fused             # fused anatomy losses (ops.LabelWarpDiceFn / ops.SegPhaseLossFn); False: the op-by-op composition
         self.seg, self.seg_opt, self.reg, self.reg_opt = seg_model, seg_opt, reg_model, reg_opt
         self.n_classes = n_classes
         self.lam = dict(sim=lam_sim, reg=lam_reg, anat=lam_anat, sp=lam_sp)
@@ -61,13 +62,18 @@ class DeepAtlasJointStep:
                 self.seg.eval()
                 prob_m = ops.SoftmaxFn.apply(self.seg(im_m))
         disp, warped, deform = self.reg(im_m, im_t)
-        if seg_m is not None:
-            warped_seg = ops.WarpLabelsFn.apply(seg_m, disp, self.n_classes)      # = warp(one_hot(seg_m)), one-hot never materialised
-        else:
-            warped_seg, _ = ops.WarpFn.apply(prob_m, disp)                          # gradient flows to disp only (prob_m is a constant)
+        fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
         l_sim = self.ncc(warped, im_t)
         l_reg = self.bend(disp)
-        l_anat = self.dice_prob(warped_seg, seg_t)
+        if seg_m is not None and fused:
+            # Dice(warp(one_hot(seg_m)), one_hot(seg_t)) straight from the two label maps: no 32-channel tensor in either direction
+            l_anat = ops.LabelWarpDiceFn.apply(seg_m, seg_t, disp, self.n_classes, 'Uniform', False, 1e-6)
+        else:
+            if seg_m is not None:
+                warped_seg = ops.WarpLabelsFn.apply(seg_m, disp, self.n_classes)      # = warp(one_hot(seg_m)), one-hot never materialised
+            else:
+                warped_seg, _ = ops.WarpFn.apply(prob_m, disp)                          # gradient flows to disp only (prob_m is a constant)
+            l_anat = self.dice_prob(warped_seg, seg_t)
         loss_r = lam['sim'] * l_sim + lam['reg'] * l_reg + lam['anat'] * l_anat
         loss_r.backward()
         parallel.allreduce_gradients(self.reg_opt)
@@ -77,10 +83,15 @@ class DeepAtlasJointStep:
         self.seg.train()
         self.seg_opt.zero_grad()
         logits = self.seg(im_m)
-        l_sp = self.dice_logits(logits, seg_m) if seg_m is not None else torch.zeros((), device=logits.device)
-        prob = ops.SoftmaxFn.apply(logits)
-        warped_prob, _ = ops.WarpFn.apply(prob, disp)
-        l_anat2 = self.dice_prob(warped_prob, seg_t)
+        if fused and not ops.DETERMINISTIC:
+            # both Dice terms as one node: structured adjoint warp + one pass to the logit gradient (ops.SegPhaseLossFn); its scatter
+            # uses float atomics, so deterministic runs take the composed path below (fixed-point accumulation in WarpFn)
+            l_sp, l_anat2 = ops.SegPhaseLossFn.apply(logits, seg_m, disp, seg_t, 'Uniform', False, 1e-6)
+        else:
+            l_sp = self.dice_logits(logits, seg_m) if seg_m is not None else torch.zeros((), device=logits.device)
+            prob = ops.SoftmaxFn.apply(logits)
+            warped_prob, _ = ops.WarpFn.apply(prob, disp)
+            l_anat2 = self.dice_prob(warped_prob, seg_t)
         loss_s = lam['sp'] * l_sp + lam['anat'] * l_anat2
         loss_s.backward()
         parallel.allreduce_gradients(self.seg_opt)

@@ -76,6 +76,18 @@ def set_matrix_precision(mode):
     return 'bf16' if prev else 'fp32'
 
 
+# Every kernel of the package reduces in a fixed order (per-block partials + a second launch) except ONE: the scatter of the trilinear
+# warp's gradient with respect to its SOURCE (only the joint step's 32-channel probability warp needs it), which uses float atomics.
+# DETERMINISTIC switches that one to an order-independent fixed-point accumulation, making whole training steps run-to-run bit-identical.
+DETERMINISTIC = os.environ.get('DA_DETERMINISTIC') == '1'
+
+
+def set_deterministic(flag=True):
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(flag)
+    return prev
+
+
 def enable_async_wgrad(flag=True):
     global ASYNC_WGRAD
     ASYNC_WGRAD = bool(flag)
@@ -128,13 +140,24 @@ def _run_on_side(fn, keep_alive):
     _side_keep.extend(t for t in keep_alive if t is not None)
 
 
-_flat_buckets = []       # (device index, first byte, one-past-last byte) of every FlatAdam gradient bucket alive in this process
+_flat_buckets = []       # weak references to every FlatAdam gradient bucket alive in this process
 
 
 def register_flat_bucket(flat_g):
     """FlatAdam announces its gradient bucket: only gradients that live inside such a bucket are accumulated asynchronously (their
     consumer -- FlatAdam.zero_grad / step, parallel.allreduce_gradients -- joins the side stream; any other optimiser would not)."""
-    _flat_buckets.append((flat_g.device.index, flat_g.data_ptr(), flat_g.data_ptr() + 4 * flat_g.numel()))
+    import weakref
+    _flat_buckets[:] = [r for r in _flat_buckets if r() is not None]
+    _flat_buckets.append(weakref.ref(flat_g))
+
+
+def _in_flat_bucket(g):
+    a = g.data_ptr()
+    for r in _flat_buckets:
+        b = r()
+        if b is not None and b.device == g.device and b.data_ptr() <= a and a + 4 * g.numel() <= b.data_ptr() + 4 * b.numel():
+            return True
+    return False
 
 
 def _async_target(param):
@@ -145,8 +168,7 @@ def _async_target(param):
     g = param.grad
     if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
         return None
-    a = g.data_ptr()
-    if not any(dev == g.device.index and lo <= a and a + 4 * g.numel() <= hi for dev, lo, hi in _flat_buckets):
+    if not _in_flat_bucket(g):
         return None
     return g
 
@@ -934,9 +956,17 @@ class WarpFn(Function):
         go = ndhwc(g_out) if g_out is not None else torch.zeros_like(s)
         if ctx.needs_input_grad[1]:
             d_disp = torch.empty_like(u)
-        if ctx.needs_input_grad[0]:
-            d_src = torch.zeros_like(s)
-        call('da_warp_bwd', ptr(go), ptr(s), ptr(u), ptr(d_disp), ptr(d_src), N, D, H, W, C, st)
+        if ctx.needs_input_grad[0] and DETERMINISTIC:
+            # parity runs: order-independent fixed-point accumulation instead of float atomics (da_warp_bwd_dsrc_det)
+            d_src = torch.empty_like(s)
+            wp, wn = _ws(nat.lib().da_warp_bwd_dsrc_det_ws_bytes(N, D, H, W, C), s)
+            call('da_warp_bwd_dsrc_det', ptr(go), ptr(u), ptr(d_src), N, D, H, W, C, wp, wn, st)
+            if d_disp is not None:
+                call('da_warp_bwd', ptr(go), ptr(s), ptr(u), ptr(d_disp), None, N, D, H, W, C, st)
+        else:
+            if ctx.needs_input_grad[0]:
+                d_src = torch.zeros_like(s)
+            call('da_warp_bwd', ptr(go), ptr(s), ptr(u), ptr(d_disp), ptr(d_src), N, D, H, W, C, st)
         if d_disp is not None and g_deform is not None:
             d_disp = d_disp + ndhwc(g_deform)
         return (ncdhw(d_src) if d_src is not None else None), (ncdhw(d_disp) if d_disp is not None else None)
@@ -971,6 +1001,100 @@ class WarpLabelsFn(Function):
         d_disp = torch.empty_like(u)
         call('da_warp_labels_bwd', ptr(ndhwc(gout)), ptr(lab), nbytes, ptr(u), ptr(d_disp), N, D, H, W, C, stream())
         return None, ncdhw(d_disp), None
+
+
+def fused_anatomy_supported(n_classes):
+    """The fused anatomy-loss kernels take class counts whose 4-channel lane groups are a power of two (4, 8, 16, 32, 64)."""
+    q = n_classes // 4
+    return n_classes % 4 == 0 and 1 <= q <= 16 and (q & (q - 1)) == 0
+
+
+class LabelWarpDiceFn(Function):
+    """Dice(warp(one_hot(labels_m), identity + disp), one_hot(labels_t)) -- the registration phase's anatomy loss (models/joint.py) --
+    straight from the two label maps: neither the warped one-hot tensor nor Dice's gradient tensor is materialised
+    (da_label_warp_dice_fwd / _bwd).  Same value and d loss / d disp as WarpLabelsFn followed by DiceFn(softmax=False)."""
+
+    @staticmethod
+    def forward(ctx, labels_m, labels_t, disp, n_classes, weight_type, no_bg, eps):
+        u = ndhwc(disp)
+        N, D, H, W, _ = u.shape
+        lm, bm = _labels(labels_m.reshape(N, -1))
+        lt, bt = _labels(labels_t.reshape(N, -1))
+        if lm.shape[1] != D * H * W or lt.shape[1] != D * H * W:
+            raise ValueError('label maps and displacement field must cover the same volume')
+        C = int(n_classes)
+        loss = _empty((1,), u)
+        coef = _empty((2, N, C), u)
+        wp, wn = _ws(nat.lib().da_label_warp_dice_ws_bytes(N, C), u)
+        call('da_label_warp_dice_fwd', ptr(lm), bm, ptr(lt), bt, ptr(u), N, D, H, W, C, _WEIGHT_TYPES[weight_type], 1 if no_bg else 0,
+             float(eps), ptr(loss), ptr(coef), wp, wn, stream())
+        ctx.cfg = (N, D, H, W, C, bm, bt)
+        ctx.save_for_backward(lm, lt, u, coef)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        lm, lt, u, coef = ctx.saved_tensors
+        N, D, H, W, C, bm, bt = ctx.cfg
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        d_disp = torch.empty_like(u)
+        call('da_label_warp_dice_bwd', ptr(lm), bm, ptr(lt), bt, ptr(u), ptr(coef), ptr(gl), ptr(d_disp), N, D, H, W, C, stream())
+        return None, None, ncdhw(d_disp), None, None, None, None
+
+
+class SegPhaseLossFn(Function):
+    """The segmentation phase's two Dice terms as ONE node (models/joint.py):
+        l_sup  = Dice(softmax(logits), labels_m)                                   (None labels_m: 0)
+        l_anat = Dice(warp(softmax(logits), identity + disp), one_hot(labels_t))    with disp a constant.
+    Forward runs the existing kernels (Dice, softmax, warp, Dice).  Backward: Dice's gradient is rank-structured, so the adjoint
+    warp collapses to two scatters of 8 atomics per voxel (da_warp_adjoint_labels) and ONE dense pass forms the gradient with respect
+    to the logits through the softmax Jacobian for both terms (da_seg_anat_dlogits) -- instead of Dice backward x 2, a 256-atomics-per-
+    voxel scatter, softmax backward and the sum of the two logit gradients."""
+
+    @staticmethod
+    def forward(ctx, logits, labels_m, disp, labels_t, weight_type, no_bg, eps):
+        a = ndhwc(logits)
+        u = ndhwc(disp.detach())
+        N, D, H, W, C = a.shape
+        V = D * H * W
+        st = stream()
+        wt, nb = _WEIGHT_TYPES[weight_type], 1 if no_bg else 0
+        lt, bt = _labels(labels_t.reshape(N, -1))
+        lm = coef_s = None
+        bm = 0
+        loss_s = torch.zeros((1,), dtype=torch.float32, device=a.device)
+        wp, wn = _ws(nat.lib().da_dice_ws_bytes(N, V, C), a)
+        if labels_m is not None:
+            lm, bm = _labels(labels_m.reshape(N, -1))
+            coef_s = _empty((2, N, C), a)
+            call('da_dice_fwd', ptr(a), ptr(lm), bm, None, N, V, C, 1, wt, nb, float(eps), ptr(loss_s), ptr(coef_s), wp, wn, st)
+        prob = torch.empty_like(a)
+        call('da_softmax_fwd', ptr(a), ptr(prob), N * V, C, st)
+        warped = torch.empty_like(a)
+        call('da_warp_fwd', ptr(prob), ptr(u), None, ptr(warped), N, D, H, W, C, st)
+        loss_a = _empty((1,), a)
+        coef_a = _empty((2, N, C), a)
+        call('da_dice_fwd', ptr(warped), ptr(lt), bt, None, N, V, C, 0, wt, nb, float(eps), ptr(loss_a), ptr(coef_a), wp, wn, st)
+        ctx.cfg = (N, D, H, W, C, bm, bt)
+        ctx.scratch = warped                       # dead after the Dice sums: reused as B / the logit gradient in backward
+        ctx.save_for_backward(prob, u, lm, lt, coef_s, coef_a)
+        return loss_s.reshape(()), loss_a.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_s, g_a):
+        prob, u, lm, lt, coef_s, coef_a = ctx.saved_tensors
+        N, D, H, W, C, bm, bt = ctx.cfg
+        st = stream()
+        zero = lambda: torch.zeros((1,), dtype=torch.float32, device=prob.device)
+        gs = g_s.detach().reshape(1).to(torch.float32).contiguous() if g_s is not None else zero()
+        ga = g_a.detach().reshape(1).to(torch.float32).contiguous() if g_a is not None else zero()
+        B = ctx.scratch if ctx.scratch is not None else torch.empty_like(prob)
+        ctx.scratch = None
+        A = _empty((N, D * H * W), prob)
+        call('da_warp_adjoint_labels', ptr(lt), bt, ptr(u), ptr(A), ptr(B), N, D, H, W, C, st)
+        call('da_seg_anat_dlogits', ptr(prob), ptr(lm), bm, ptr(A), ptr(B), ptr(coef_s), ptr(coef_a), ptr(gs) if coef_s is not None else None,
+             ptr(ga), N, D * H * W, C, st)
+        return ncdhw(B), None, None, None, None, None, None
 
 
 class DiceFn(Function):

@@ -219,6 +219,31 @@ int da_warp_labels_fwd(const void* labels, int label_bytes, const float* disp, f
 int da_warp_labels_bwd(const float* dout, const void* labels, int label_bytes, const float* disp, float* d_disp,
                        int N, int D, int H, int W, int C, void* stream);
 int da_identity_grid(float* out, int D, int H, int W, int normalize, void* stream);
+/* ---- fused anatomy losses of the joint step (parts: lib/loss.py:410-476 Dice, voxel_morph.py:90-91 warp) ------
+ * Dice's input gradient is g[v][c] = coef[0][n][c] [St[v] == c] + coef[1][n][c] (coef as written by da_dice_fwd), which lets both
+ * anatomy terms skip their 32-channel intermediate tensors:
+ *  registration phase: loss = Dice(warp(onehot(lab_m), id + disp), onehot(lab_t)) straight from the two label maps (no warped
+ *    one-hot, no gradient tensor); bwd writes d loss / d disp.
+ *  segmentation phase: the adjoint warp of g is coef[1][c] A[u] + coef[0][c] B[u][c] with A = W^T 1 ([N][V]) and
+ *    B = W^T onehot(lab_t) ([N][V][C]) -- da_warp_adjoint_labels zero-fills and scatters both (16 float atomics per voxel instead of
+ *    8 C) -- and da_seg_anat_dlogits turns B IN PLACE into d(loss_sup + loss_anat) / d logits through the softmax Jacobian
+ *    (prob = softmax(logits); coef_sup / lab_m / dloss_sup NULL when there is no supervised Dice term). */
+size_t da_label_warp_dice_ws_bytes(int N, int C);
+int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,
+                           int N, int D, int H, int W, int C, int weight_type, int no_bg, float eps,
+                           float* loss, float* coef /*[2][N][C]*/, void* ws, size_t ws_bytes, void* stream);
+int da_label_warp_dice_bwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,
+                           const float* coef, const float* dloss, float* d_disp, int N, int D, int H, int W, int C, void* stream);
+int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const float* disp, float* A, float* B,
+                           int N, int D, int H, int W, int C, void* stream);
+int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, float* B_dlogits,
+                        const float* coef_sup, const float* coef_anat, const float* dloss_sup, const float* dloss_anat,
+                        int N, long long V, int C, void* stream);
+/* deterministic d_src (parity runs): the same scatter as da_warp_bwd's d_src, accumulated in 64-bit fixed point with integer atomics
+ * (order-independent, hence run-to-run bit-identical), scale = power of two from max|dout|.  d_src is OVERWRITTEN (no pre-zeroing). */
+size_t da_warp_bwd_dsrc_det_ws_bytes(int N, int D, int H, int W, int C);
+int da_warp_bwd_dsrc_det(const float* dout, const float* disp, float* d_src, int N, int D, int H, int W, int C,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- fused softmax + Dice loss (row a11; lib/loss.py:410-476, lib/transforms.py:675-689) ------ */
 /* src[N][V][C] logits (softmax != 0) or probabilities; target: labels (label_bytes = 1 uint8 | 8 int64,

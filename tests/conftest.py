@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(autouse=True)
+def _reset_process_wide_switches():
+    """SegmentationExperiment / bench enable process-wide modes (side-stream weight gradients, bf16 matrix mode, deterministic warp):
+    every test starts from the defaults."""
+    yield
+    mod = sys.modules.get('deepatlas_amd.ops')
+    if mod is not None:
+        mod.enable_async_wgrad(False)
+        mod.set_deterministic(False)
+
+
 @pytest.fixture(scope='session')
 def golden():
     cache = {}
