@@ -58,6 +58,7 @@ SIGNATURES = {
     'da_bn_act_bwd': (I, [P, P, P, P, P, P, P, F, I, P, P, P, LL, I, P, SZ, P]),
     'da_bn_act_bwd_dbias': (I, [P, P, P, P, P, P, F, I, P, P, P, P, LL, I, P, SZ, P]),
     'da_act_bwd': (I, [P, P, F, P, LL, P]),
+    'da_act_bwd_add_dbias': (I, [P, P, P, F, P, P, LL, I, P, SZ, P]),
     'da_colsum': (I, [P, LL, I, P, P, SZ, P]),
     'da_maxpool2_fwd': (I, [P, P, I, I, I, I, I, P]),
     'da_maxpool2_fwd_pro': (I, [P, P, P, F, P, P, I, I, I, I, I, P]),

@@ -1,0 +1,227 @@
+// Weight gradient of a 3x3x3 convolution with VERY FEW output channels: the registration net's flow conv 24 -> 3
+// (voxel_morph.py:57, input = concat(dec5 [8 ch], enc1 [16 ch]) at full resolution).
+//
+//   dW[tap][ci][co] = sum_p x[p][ci] * dy[p - (tap - 1)][co]          (p over input voxels; dy zero outside the volume)
+//
+// As a GEMM:  M = (tap, co) = 27 * Cout <= 81 rows (6 M-tiles of 16),  N = ci (one 16-wide N-tile per input tensor),  K = voxels.
+// An N-tile over Cout would be 13/16 padding and the operand-swapped small-Cin kernel (conv3_smallcin_wgrad_kernel) feeds both
+// operands with per-lane dword loads from global memory: 1.16 ms for 0.16 ms of HBM traffic.  Here both operands are staged in LDS
+// once per 4 x 8 x 16 voxel tile -- x tiles as [voxel][16] (conflict-free fragment reads), the dy tile with a one-voxel halo
+// (6 x 10 x 18 x Cout floats) read through 27 shifted windows -- the next tile's global loads fly under the current tile's MFMAs,
+// and persistent workgroups keep dW in accumulators (v_mfma_f32_16x16x4_f32, exact fp32) until one partial per workgroup is written;
+// da_reduce_partials sums them in double, in a fixed order.  Algorithmic bytes: (Cin + Cout) * 4 per voxel, read once.
+#include "common.h"
+#include "conv3d_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TZ = 4, TY = 8, TX = 16, TVOX = TZ * TY * TX;
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;
+constexpr int MT = 6;                     // M-tiles: 27 * Cout <= 96
+constexpr int kFlowBlocks = 512;          // 2 workgroups per CU
+
+struct FlowWgP {
+    const float* in1; const float* in2; int C1, C2;        // x = concat(in1, in2); C1, C2 in {0, 4, 8, 12, 16}
+    const float* dy; float* partial;
+    int N, D, H, W, Cout, ntz, nty, ntx, ntiles;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+template <int S1>      // LDS row stride (floats) of the in1 tile: 8 or 16
+__global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xa = lds;                               // in2 tile  [TVOX][16]
+    float* xb = xa + TVOX * 16;                    // in1 tile  [TVOX][S1]
+    float* dyl = xb + TVOX * S1;                   // dy halo tile [HVOX][Cout]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4;
+    const int Cout = p.Cout, Cin = p.C1 + p.C2;
+    const int Q2 = p.C2 / 4, Q1 = p.C1 / 4;
+
+    // A rows of this lane: m = 16 mt + i -> (tap, co); window offset into the dy halo tile for  p - (tap - 1)  = local + 2 - t per axis
+    int offA[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + i;
+        const bool ok = m < 27 * Cout;
+        const int tap = ok ? m / Cout : 13, co = ok ? m % Cout : 0;
+        const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+        offA[mt] = (((2 - tz) * HY + (2 - ty)) * HX + (2 - tx)) * Cout + co;
+    }
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // static share of the tile list (contiguous range per workgroup: neighbouring tiles share dy halo rows in L2)
+    const int per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(p.ntiles, t_begin + per);
+
+    constexpr int NX2 = TVOX * 4 / 256;            // float4 loads per thread for a 16-channel tile (8)
+    constexpr int NDY = (HVOX * 3 + 255) / 256;    // dword loads per thread for the dy halo tile, Cout <= 3 (13)
+    float4 pa[NX2], pb[NX2];
+    float pd[NDY];
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.ntx; t /= p.ntx;
+        const int ty = t % p.nty; t /= p.nty;
+        const int tz = t % p.ntz; const int n = t / p.ntz;
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        const unsigned long long vol = (unsigned long long)p.D * p.H * p.W;
+        const __amdgpu_buffer_rsrc_t r2 = flow_rsrc(p.C2 > 0 ? p.in2 + (size_t)n * vol * p.C2 : p.dy, p.C2 > 0 ? (unsigned)(vol * p.C2 * 4ull) : 0u);
+        const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p.C1 > 0 ? p.in1 + (size_t)n * vol * p.C1 : p.dy, p.C1 > 0 ? (unsigned)(vol * p.C1 * 4ull) : 0u);
+        const __amdgpu_buffer_rsrc_t ry = flow_rsrc(p.dy + (size_t)n * vol * Cout, (unsigned)(vol * Cout * 4ull));
+#pragma unroll
+        for (int it = 0; it < NX2; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            {   // in2: Q2 quads per voxel
+                const int c4 = Q2 > 0 ? idx % Q2 : 0, v = Q2 > 0 ? idx / Q2 : TVOX;
+                const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
+                const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
+                pa[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * 4) : 0xFFFFFFFFu, 0, 0));
+            }
+            {   // in1: Q1 quads per voxel
+                const int c4 = Q1 > 0 ? idx % Q1 : 0, v = Q1 > 0 ? idx / Q1 : TVOX;
+                const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
+                const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
+                pb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C1 + c4 * 4) * 4) : 0xFFFFFFFFu, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int co = idx % Cout, hv = idx / Cout;
+            const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = hv < HVOX && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            pd[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? (unsigned)((((z * p.H + y) * p.W + x) * Cout + co) * 4) : 0xFFFFFFFFu, 0, 0));
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < NX2; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (Q2 > 0 && idx < TVOX * Q2) *reinterpret_cast<float4*>(xa + (idx / Q2) * 16 + (idx % Q2) * 4) = pa[it];
+            if (Q1 > 0 && idx < TVOX * Q1) *reinterpret_cast<float4*>(xb + (idx / Q1) * S1 + (idx % Q1) * 4) = pb[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < HVOX * Cout) dyl[idx] = pd[it];
+        }
+    };
+    // channels a tensor does not have stay zero for the whole launch (written once, never overwritten)
+    for (int idx = threadIdx.x; idx < TVOX * 16; idx += 256) xa[idx] = 0.f;
+    for (int idx = threadIdx.x; idx < TVOX * S1; idx += 256) xb[idx] = 0.f;
+    __syncthreads();
+    if (t_begin < t_end) { issue(t_begin); write_lds(); }
+    __syncthreads();
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool has_next = tile + 1 < t_end;
+        if (has_next) issue(tile + 1);
+        // wave w: z-slab w; 8 rows x 4 K-steps (4 voxels along x each)
+#pragma unroll 1
+        for (int yl = 0; yl < TY; ++yl) {
+            const float* arow = dyl + ((wave * HY + yl) * HX + g) * Cout;
+            const float* b2row = xa + ((wave * TY + yl) * TX + g) * 16 + i;
+            const float* b1row = xb + ((wave * TY + yl) * TX + g) * S1 + (i & (S1 - 1));
+#pragma unroll
+            for (int xs = 0; xs < 4; ++xs) {
+                float a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = arow[xs * 4 * Cout + offA[mt]];
+                const float b0 = b2row[xs * 4 * 16], b1 = b1row[xs * 4 * S1];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+        if (has_next) {
+            __syncthreads();
+            write_lds();
+            __syncthreads();
+        }
+    }
+    // cross-wave reduction through LDS (the tiles are dead), fixed order; then this workgroup's partial dW[tap][ci][co]
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float4* slot = red + (mt * 2 + nt) * 64 + lane;
+                    float4 cur = (w == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
+                    cur.x += acc[mt][nt][0]; cur.y += acc[mt][nt][1]; cur.z += acc[mt][nt][2]; cur.w += acc[mt][nt][3];
+                    *slot = cur;
+                }
+        }
+        __syncthreads();
+    }
+    const int O = 27 * Cin * Cout;
+    float* part = p.partial + (size_t)blockIdx.x * O;
+    for (int idx = threadIdx.x; idx < MT * 2 * 64; idx += 256) {
+        const int ln = idx & 63, q = idx >> 6;
+        const int nt = q & 1, mt = q >> 1;
+        const float4 v = red[idx];
+        const float vals[4] = {v.x, v.y, v.z, v.w};
+        const int col = ln & 15;                                 // C / D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + reg
+        const int ci = nt == 0 ? p.C1 + col : col;               // N-tile 0 = in2's channels, N-tile 1 = in1's
+        const bool cok = nt == 0 ? col < p.C2 : col < p.C1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * mt + 4 * (ln >> 4) + reg;
+            if (cok && m < 27 * Cout) part[((size_t)(m / Cout) * Cin + ci) * Cout + (m % Cout)] = vals[reg];
+        }
+    }
+}
+
+}  // namespace
+
+bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride) {
+    return stride == 1 && Cout >= 1 && Cout <= 3 && C1 % 4 == 0 && C2 % 4 == 0 && C1 <= 16 && C2 <= 16 && C1 + C2 >= 4;
+}
+
+size_t da_conv3_flow_wgrad_ws_bytes(int Cin, int Cout) { return da_align((size_t)kFlowBlocks * 27 * Cin * Cout * sizeof(float)); }
+
+int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
+                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!da_conv3_flow_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
+    const int Cin = C1 + C2, O = 27 * Cin * Cout;
+    if (ws_bytes < da_conv3_flow_wgrad_ws_bytes(Cin, Cout)) return DA_ERR_WS_SMALL;
+    if ((unsigned long long)D * H * W * 16ull * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+    FlowWgP p;
+    // N-tile 0 takes the tensor called in2; a single-tensor input is passed as in2 so that it lands in the full-width tile
+    if (C2 == 0) { p.in1 = nullptr; p.C1 = 0; p.in2 = in1; p.C2 = C1; }
+    else { p.in1 = in1; p.C1 = C1; p.in2 = in2; p.C2 = C2; }
+    p.dy = dy; p.partial = (float*)ws;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout;
+    p.ntz = (D + TZ - 1) / TZ; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
+    p.ntiles = N * p.ntz * p.nty * p.ntx;
+    int nb = p.ntiles < kFlowBlocks ? p.ntiles : kFlowBlocks;
+    const int S1 = p.C1 <= 8 ? 8 : 16;
+    const size_t red_bytes = (size_t)MT * 2 * 64 * sizeof(float4);
+    size_t shm = ((size_t)TVOX * 16 + (size_t)TVOX * S1 + (size_t)HVOX * Cout) * sizeof(float);
+    if (shm < red_bytes) shm = red_bytes;
+    if (S1 == 8) {
+        static bool set8 = false;
+        if (!set8) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return (int)e; set8 = true; }
+        hipLaunchKernelGGL(flow_wgrad_kernel<8>, dim3(nb), dim3(256), shm, st, p);
+    } else {
+        static bool set16 = false;
+        if (!set16) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return (int)e; set16 = true; }
+        hipLaunchKernelGGL(flow_wgrad_kernel<16>, dim3(nb), dim3(256), shm, st, p);
+    }
+    DA_LAUNCH_CHECK();
+    // the kernel's ci order is the conv's own (in1's channels first); with the single-tensor swap above C1 == 0 keeps it that way
+    return da_reduce_partials(p.partial, nb, O, dw_tio, st);
+}

@@ -46,3 +46,10 @@ bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
                       float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope,
                       void* ws, size_t ws_bytes, hipStream_t st);
+
+// weight gradient of a conv with <= 3 output channels and <= 16 + 16 input channels (the 24 -> 3 flow conv): LDS-tiled MFMA GEMM
+// with M = (tap, cout) (conv3d_flow.hip)
+bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride);
+size_t da_conv3_flow_wgrad_ws_bytes(int Cin, int Cout);
+int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
+                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1572,6 +1572,13 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         { const int rc2 = da_reduce_partials(sp.partial, nb, O, dw_tio, st); if (rc2) return rc2; }
         return 0;
     }
+    if (s2d_cin == 0 && !pro && da_conv3_flow_wgrad_supported(C1, C2, Cout, stride) && ws_bytes >= da_conv3_flow_wgrad_ws_bytes(C1 + C2, Cout)) {
+        static int off = -1; if (off < 0) { const char* e = getenv("DA_NO_FLOW_WGRAD"); off = (e && atoi(e)) ? 1 : 0; }
+        if (!off) {
+            const int rc = da_conv3_flow_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes, st);
+            if (rc != DA_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (stride == 1 && s2d_cin == 0 && Cout <= 4 && C1 + C2 <= 32 && (unsigned long long)D * H * W * (C1 > C2 ? C1 : C2) * 4ull < 0xFFFFFFF0ull) {
         // Very few OUTPUT channels (the 24 -> 3 flow conv, voxel_morph.py:57): swap the operands.  dW[tap][ci][co] =
         // sum_u dy[u - tap][co] x[u][ci] is the small-Cin weight gradient of a conv with "input" dy (Cout channels), "output

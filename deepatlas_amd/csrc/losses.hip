@@ -440,6 +440,14 @@ static BendK bending_coeffs(int N, int D, int H, int W, const float* spacing3, i
 
 #define BU(dd, hh, ww) u[((((long long)(dd)) * H + (hh)) * W + (ww)) * 3 + c]
 
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const float* __restrict__ u, long long vox) {          // one voxel's three displacement components (12 contiguous bytes)
+    const float* p = u + vox * 3;
+    return F3{p[0], p[1], p[2]};
+}
+
+// One thread per interior voxel, all three channels: the 19 points of the six difference stencils are 12-byte voxel reads that
+// neighbouring threads share cache lines on (the per-element form read every point as a stride-3 scalar).
 template <bool L1>
 __global__ void bending_partial_kernel(const float* __restrict__ disp, int D, int H, int W, BendK K,
                                        double* __restrict__ partial) {
@@ -447,22 +455,31 @@ __global__ void bending_partial_kernel(const float* __restrict__ disp, int D, in
     const int n = blockIdx.y;
     const float* u = disp + (long long)n * D * H * W * 3;
     const int Di = D - 2, Hi = H - 2, Wi = W - 2;
-    const long long total = (long long)Di * Hi * Wi * 3;
+    const long long total = (long long)Di * Hi * Wi;
+    const long long sH = W, sD = (long long)H * W;
     float acc = 0.f; double dacc = 0.0; int cnt = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % 3); long long r = i / 3;
+        long long r = i;
         const int w = (int)(r % Wi) + 1; r /= Wi;
         const int h = (int)(r % Hi) + 1; const int d = (int)(r / Hi) + 1;
-        const float u0 = BU(d, h, w);
-        const float t0 = BU(d + 1, h, w) + BU(d - 1, h, w) - 2.f * u0;
-        const float t1 = BU(d, h + 1, w) + BU(d, h - 1, w) - 2.f * u0;
-        const float t2 = BU(d, h, w + 1) + BU(d, h, w - 1) - 2.f * u0;
-        const float t3 = BU(d + 1, h + 1, w) + BU(d - 1, h - 1, w) - BU(d + 1, h - 1, w) - BU(d - 1, h + 1, w);
-        const float t4 = BU(d, h + 1, w + 1) + BU(d, h - 1, w - 1) - BU(d, h + 1, w - 1) - BU(d, h - 1, w + 1);
-        const float t5 = BU(d + 1, h, w + 1) + BU(d - 1, h, w - 1) - BU(d + 1, h, w - 1) - BU(d - 1, h, w + 1);
-        if (L1) acc += K.k[c][0] * fabsf(t0) + K.k[c][1] * fabsf(t1) + K.k[c][2] * fabsf(t2) + K.k[c][3] * fabsf(t3) + K.k[c][4] * fabsf(t4) + K.k[c][5] * fabsf(t5);
-        else acc += K.k[c][0] * t0 * t0 + K.k[c][1] * t1 * t1 + K.k[c][2] * t2 * t2 + K.k[c][3] * t3 * t3 + K.k[c][4] * t4 * t4 + K.k[c][5] * t5 * t5;
-        if (++cnt == 32) { dacc += (double)acc; acc = 0.f; cnt = 0; }
+        const long long p = ((long long)d * H + h) * W + w;
+        const F3 c0 = ld3(u, p);
+        const F3 dp = ld3(u, p + sD), dm = ld3(u, p - sD), hp = ld3(u, p + sH), hm = ld3(u, p - sH), wp = ld3(u, p + 1), wm = ld3(u, p - 1);
+        const F3 dhpp = ld3(u, p + sD + sH), dhmm = ld3(u, p - sD - sH), dhpm = ld3(u, p + sD - sH), dhmp = ld3(u, p - sD + sH);
+        const F3 hwpp = ld3(u, p + sH + 1), hwmm = ld3(u, p - sH - 1), hwpm = ld3(u, p + sH - 1), hwmp = ld3(u, p - sH + 1);
+        const F3 dwpp = ld3(u, p + sD + 1), dwmm = ld3(u, p - sD - 1), dwpm = ld3(u, p + sD - 1), dwmp = ld3(u, p - sD + 1);
+#define BEND_CH(f, c)                                                                                   \
+        {                                                                                               \
+            const float t0 = dp.f + dm.f - 2.f * c0.f, t1 = hp.f + hm.f - 2.f * c0.f, t2 = wp.f + wm.f - 2.f * c0.f;   \
+            const float t3 = dhpp.f + dhmm.f - dhpm.f - dhmp.f;                                         \
+            const float t4 = hwpp.f + hwmm.f - hwpm.f - hwmp.f;                                         \
+            const float t5 = dwpp.f + dwmm.f - dwpm.f - dwmp.f;                                         \
+            if (L1) acc += K.k[c][0] * fabsf(t0) + K.k[c][1] * fabsf(t1) + K.k[c][2] * fabsf(t2) + K.k[c][3] * fabsf(t3) + K.k[c][4] * fabsf(t4) + K.k[c][5] * fabsf(t5); \
+            else acc += K.k[c][0] * t0 * t0 + K.k[c][1] * t1 * t1 + K.k[c][2] * t2 * t2 + K.k[c][3] * t3 * t3 + K.k[c][4] * t4 * t4 + K.k[c][5] * t5 * t5; \
+        }
+        BEND_CH(x, 0) BEND_CH(y, 1) BEND_CH(z, 2)
+#undef BEND_CH
+        if (++cnt == 16) { dacc += (double)acc; acc = 0.f; cnt = 0; }
     }
     dacc += (double)acc;
     const double s = da_block_sum(dacc, red);
@@ -477,57 +494,92 @@ __global__ void scalar_finalize_kernel(const double* __restrict__ partial, int c
     if (threadIdx.x == 0) loss[0] = (float)s;
 }
 
-// gather-form backward: d loss / d u[p] = 2 * sum_terms K * sum_{centres q containing p} term(q) * coef  (L1: sign(term(q)) and no 2)
+// gather-form gradient of one element: d loss / d u[p] = 2 * sum_terms K * sum_{centres q containing p} term(q) * coef  (L1: sign(term(q)), no 2)
+template <bool L1>
+__device__ __forceinline__ float bend_grad_elem(const float* __restrict__ u, int d, int h, int w, int c, int D, int H, int W, const BendK& K) {
+    auto interior = [&](int dd, int hh, int ww) { return dd >= 1 && dd < D - 1 && hh >= 1 && hh < H - 1 && ww >= 1 && ww < W - 1; };
+    auto f = [](float t) { return L1 ? (t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f)) : t; };      // d|t|/dt = sign(t) (0 at 0, torch.abs)
+    float g = 0.f;
+    {   // second differences: centres p-e (+1), p+e (+1), p (-2) along each axis
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (interior(d, h, w)) {
+            const float u0 = BU(d, h, w);
+            s0 -= 2.f * f(BU(d + 1, h, w) + BU(d - 1, h, w) - 2.f * u0);
+            s1 -= 2.f * f(BU(d, h + 1, w) + BU(d, h - 1, w) - 2.f * u0);
+            s2 -= 2.f * f(BU(d, h, w + 1) + BU(d, h, w - 1) - 2.f * u0);
+        }
+#pragma unroll
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+            if (interior(d + sgn, h, w)) s0 += f(BU(d + 2 * sgn, h, w) + BU(d, h, w) - 2.f * BU(d + sgn, h, w));
+            if (interior(d, h + sgn, w)) s1 += f(BU(d, h + 2 * sgn, w) + BU(d, h, w) - 2.f * BU(d, h + sgn, w));
+            if (interior(d, h, w + sgn)) s2 += f(BU(d, h, w + 2 * sgn) + BU(d, h, w) - 2.f * BU(d, h, w + sgn));
+        }
+        g += K.k[c][0] * s0 + K.k[c][1] * s1 + K.k[c][2] * s2;
+    }
+    {   // mixed differences: centre q = p - (sa*ea + sb*eb) has coefficient sa*sb for u[p]
+        float s3 = 0.f, s4 = 0.f, s5 = 0.f;
+#pragma unroll
+        for (int sa = -1; sa <= 1; sa += 2)
+#pragma unroll
+            for (int sb = -1; sb <= 1; sb += 2) {
+                const float cf = (float)(sa * sb);
+                { const int qd = d - sa, qh = h - sb;   // (D,H)
+                  if (interior(qd, qh, w)) s3 += cf * f(BU(qd + 1, qh + 1, w) + BU(qd - 1, qh - 1, w) - BU(qd + 1, qh - 1, w) - BU(qd - 1, qh + 1, w)); }
+                { const int qh = h - sa, qw = w - sb;   // (H,W)
+                  if (interior(d, qh, qw)) s4 += cf * f(BU(d, qh + 1, qw + 1) + BU(d, qh - 1, qw - 1) - BU(d, qh + 1, qw - 1) - BU(d, qh - 1, qw + 1)); }
+                { const int qd = d - sa, qw = w - sb;   // (D,W)
+                  if (interior(qd, h, qw)) s5 += cf * f(BU(qd + 1, h, qw + 1) + BU(qd - 1, h, qw - 1) - BU(qd + 1, h, qw - 1) - BU(qd - 1, h, qw + 1)); }
+            }
+        g += K.k[c][3] * s3 + K.k[c][4] * s4 + K.k[c][5] * s5;
+    }
+    return g;
+}
+
+// One thread per voxel, three channels.  'L2', voxel at least two away from every face (all 25 stencil centres that contain it are
+// interior): the composition S^T S of each difference stencil with its own adjoint is a FIXED stencil --
+//   second difference along e:  u(p+2e) - 4 u(p+e) + 6 u(p) - 4 u(p-e) + u(p-2e)
+//   mixed difference in (a, b): 4 u(p) - 2 [u(p+-2a) + u(p+-2b)] + [u(p+2a+2b) + u(p+2a-2b) + u(p-2a+2b) + u(p-2a-2b)]
+// -- 25 voxel reads instead of ~110 for the term-by-term gather.  The shell within two voxels of a face (and 'L1', whose sign() does
+// not commute) takes the term-by-term form.
 template <bool L1>
 __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ dloss,
                                    float* __restrict__ d_disp, int D, int H, int W, BendK K) {
     const int n = blockIdx.y;
     const float* u = disp + (long long)n * D * H * W * 3;
     float* du = d_disp + (long long)n * D * H * W * 3;
-    const long long total = (long long)D * H * W * 3;
+    const long long total = (long long)D * H * W;
     const float gl = (L1 ? 1.f : 2.f) * dloss[0];
-    auto interior = [&](int d, int h, int w) { return d >= 1 && d < D - 1 && h >= 1 && h < H - 1 && w >= 1 && w < W - 1; };
-    auto f = [](float t) { return L1 ? (t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f)) : t; };      // d|t|/dt = sign(t) (0 at 0, torch.abs)
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % 3); long long r = i / 3;
+    const long long sH = W, sD = (long long)H * W;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        long long r = p;
         const int w = (int)(r % W); r /= W;
         const int h = (int)(r % H); const int d = (int)(r / H);
-        float g = 0.f;
-        // second differences: centres p-e (+1), p+e (+1), p (-2) along each axis
-        {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            if (interior(d, h, w)) {
-                const float u0 = BU(d, h, w);
-                s0 -= 2.f * f(BU(d + 1, h, w) + BU(d - 1, h, w) - 2.f * u0);
-                s1 -= 2.f * f(BU(d, h + 1, w) + BU(d, h - 1, w) - 2.f * u0);
-                s2 -= 2.f * f(BU(d, h, w + 1) + BU(d, h, w - 1) - 2.f * u0);
-            }
-#pragma unroll
-            for (int sgn = -1; sgn <= 1; sgn += 2) {
-                if (interior(d + sgn, h, w)) s0 += f(BU(d + 2 * sgn, h, w) + BU(d, h, w) - 2.f * BU(d + sgn, h, w));
-                if (interior(d, h + sgn, w)) s1 += f(BU(d, h + 2 * sgn, w) + BU(d, h, w) - 2.f * BU(d, h + sgn, w));
-                if (interior(d, h, w + sgn)) s2 += f(BU(d, h, w + 2 * sgn) + BU(d, h, w) - 2.f * BU(d, h, w + sgn));
-            }
-            g += K.k[c][0] * s0 + K.k[c][1] * s1 + K.k[c][2] * s2;
+        float g0, g1, g2;
+        const bool deep = !L1 && d >= 2 && d < D - 2 && h >= 2 && h < H - 2 && w >= 2 && w < W - 2;
+        if (deep) {
+            const F3 c0 = ld3(u, p);
+            const F3 d1p = ld3(u, p + sD), d1m = ld3(u, p - sD), d2p = ld3(u, p + 2 * sD), d2m = ld3(u, p - 2 * sD);
+            const F3 h1p = ld3(u, p + sH), h1m = ld3(u, p - sH), h2p = ld3(u, p + 2 * sH), h2m = ld3(u, p - 2 * sH);
+            const F3 w1p = ld3(u, p + 1), w1m = ld3(u, p - 1), w2p = ld3(u, p + 2), w2m = ld3(u, p - 2);
+            const F3 dhpp = ld3(u, p + 2 * sD + 2 * sH), dhpm = ld3(u, p + 2 * sD - 2 * sH), dhmp = ld3(u, p - 2 * sD + 2 * sH), dhmm = ld3(u, p - 2 * sD - 2 * sH);
+            const F3 hwpp = ld3(u, p + 2 * sH + 2), hwpm = ld3(u, p + 2 * sH - 2), hwmp = ld3(u, p - 2 * sH + 2), hwmm = ld3(u, p - 2 * sH - 2);
+            const F3 dwpp = ld3(u, p + 2 * sD + 2), dwpm = ld3(u, p + 2 * sD - 2), dwmp = ld3(u, p - 2 * sD + 2), dwmm = ld3(u, p - 2 * sD - 2);
+#define BEND_G(f, c)                                                                                                  \
+            (K.k[c][0] * (d2p.f + d2m.f - 4.f * (d1p.f + d1m.f) + 6.f * c0.f) +                                           \
+             K.k[c][1] * (h2p.f + h2m.f - 4.f * (h1p.f + h1m.f) + 6.f * c0.f) +                                           \
+             K.k[c][2] * (w2p.f + w2m.f - 4.f * (w1p.f + w1m.f) + 6.f * c0.f) +                                           \
+             K.k[c][3] * (4.f * c0.f - 2.f * (d2p.f + d2m.f + h2p.f + h2m.f) + (dhpp.f + dhpm.f + dhmp.f + dhmm.f)) +     \
+             K.k[c][4] * (4.f * c0.f - 2.f * (h2p.f + h2m.f + w2p.f + w2m.f) + (hwpp.f + hwpm.f + hwmp.f + hwmm.f)) +     \
+             K.k[c][5] * (4.f * c0.f - 2.f * (d2p.f + d2m.f + w2p.f + w2m.f) + (dwpp.f + dwpm.f + dwmp.f + dwmm.f)))
+            g0 = BEND_G(x, 0); g1 = BEND_G(y, 1); g2 = BEND_G(z, 2);
+#undef BEND_G
+        } else {
+            g0 = bend_grad_elem<L1>(u, d, h, w, 0, D, H, W, K);
+            g1 = bend_grad_elem<L1>(u, d, h, w, 1, D, H, W, K);
+            g2 = bend_grad_elem<L1>(u, d, h, w, 2, D, H, W, K);
         }
-        // mixed differences: centre q = p - (sa*ea + sb*eb) has coefficient sa*sb for u[p]
-        {
-            float s3 = 0.f, s4 = 0.f, s5 = 0.f;
-#pragma unroll
-            for (int sa = -1; sa <= 1; sa += 2)
-#pragma unroll
-                for (int sb = -1; sb <= 1; sb += 2) {
-                    const float cf = (float)(sa * sb);
-                    { const int qd = d - sa, qh = h - sb;   // (D,H)
-                      if (interior(qd, qh, w)) s3 += cf * f(BU(qd + 1, qh + 1, w) + BU(qd - 1, qh - 1, w) - BU(qd + 1, qh - 1, w) - BU(qd - 1, qh + 1, w)); }
-                    { const int qh = h - sa, qw = w - sb;   // (H,W)
-                      if (interior(d, qh, qw)) s4 += cf * f(BU(d, qh + 1, qw + 1) + BU(d, qh - 1, qw - 1) - BU(d, qh + 1, qw - 1) - BU(d, qh - 1, qw + 1)); }
-                    { const int qd = d - sa, qw = w - sb;   // (D,W)
-                      if (interior(qd, h, qw)) s5 += cf * f(BU(qd + 1, h, qw + 1) + BU(qd - 1, h, qw - 1) - BU(qd + 1, h, qw - 1) - BU(qd - 1, h, qw + 1)); }
-                }
-            g += K.k[c][3] * s3 + K.k[c][4] * s4 + K.k[c][5] * s5;
-        }
-        du[i] = gl * g;
+        float* o = du + p * 3;
+        o[0] = gl * g0; o[1] = gl * g1; o[2] = gl * g2;
     }
 }
 #undef BU
@@ -743,8 +795,8 @@ extern "C" int da_bending_fwd(const float* disp, int N, int D, int H, int W, con
     if (ws_bytes < da_bending_ws_bytes(N, D, H, W)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
     const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize, norm);
-    const long long total = (long long)(D - 2) * (H - 2) * (W - 2) * 3;
-    int nblocks = (int)da_cdiv(total, 256 * 2); if (nblocks > kBendBlocks) nblocks = kBendBlocks; if (nblocks < 1) nblocks = 1;
+    const long long total = (long long)(D - 2) * (H - 2) * (W - 2);
+    int nblocks = (int)da_cdiv(total, 256); if (nblocks > kBendBlocks) nblocks = kBendBlocks; if (nblocks < 1) nblocks = 1;
     if (norm == 2) hipLaunchKernelGGL((bending_partial_kernel<false>), dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
     else hipLaunchKernelGGL((bending_partial_kernel<true>), dim3(nblocks, N), dim3(256), 0, st, disp, D, H, W, K, (double*)ws);
     DA_LAUNCH_CHECK();
@@ -757,7 +809,7 @@ extern "C" int da_bending_bwd(const float* disp, const float* dloss, float* d_di
                               const float* spacing3, int normalize, int norm, void* stream) {
     if (!disp || !dloss || !d_disp || N <= 0 || D < 3 || H < 3 || W < 3 || (norm != 1 && norm != 2)) return DA_ERR_BADARG;
     const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize, norm);
-    const long long total = (long long)D * H * W * 3;
+    const long long total = (long long)D * H * W;
     if (norm == 2) hipLaunchKernelGGL((bending_bwd_kernel<false>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
     else hipLaunchKernelGGL((bending_bwd_kernel<true>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
     DA_LAUNCH_CHECK();

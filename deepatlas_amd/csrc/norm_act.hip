@@ -252,6 +252,51 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
         dx[i] = dy[i] * (y[i] > 0.f ? 1.f : slope);
 }
 
+// Backward of a conv block WITHOUT BatchNorm (modules.convBlock, the registration net): dx = (g1 [+ g2]) * act'(y) and, in the same
+// pass, the per-channel column sums of dx = the convolution's bias gradient.  g2 is the second incoming gradient when the block's
+// output has two consumers (skip connection): the sum autograd would form in its own pass happens here.  Row-blocked like
+// col_partial_kernel: a thread keeps one channel quad, per-thread fp32 sums -> per-block doubles -> colsum_finalize_kernel.
+template <int VEC>
+__global__ void act_bwd_add_dbias_kernel(const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ y,
+                                         float slope, float* __restrict__ dx, long long M, int C, long long rows_per_block,
+                                         double* __restrict__ partial) {
+    extern __shared__ double sh[];   // [rpi][C]
+    const int cq = C / VEC;
+    const int rpi = blockDim.x / cq;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    float a0[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a0[j] = 0.f;
+    for (long long row = r0 + r; row < r1; row += rpi) {
+        float gv[VEC], yv[VEC];
+        if (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(g1 + row * C + q * 4);
+            if (g2) { const float4 u = *reinterpret_cast<const float4*>(g2 + row * C + q * 4); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+            if (y) { const float4 v = *reinterpret_cast<const float4*>(y + row * C + q * 4); yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w; }
+        } else {
+            gv[0] = g1[row * C + q] + (g2 ? g2[row * C + q] : 0.f);
+            if (y) yv[0] = y[row * C + q];
+        }
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { o[j] = y ? gv[j] * (yv[j] > 0.f ? 1.f : slope) : gv[j]; a0[j] += o[j]; }
+        if (VEC == 4) *reinterpret_cast<float4*>(dx + row * C + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        else dx[row * C + q] = o[0];
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sh[r * C + q * VEC + j] = (double)a0[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double t0 = 0.0;
+        for (int rr = 0; rr < rpi; ++rr) t0 += sh[rr * C + c];
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = t0;
+    }
+}
+
 __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* out) {
     const int c = blockIdx.x;
     double s = 0.0;
@@ -389,6 +434,26 @@ extern "C" int da_act_bwd(const float* dy, const float* y, float act_slope, floa
     if (!dy || !y || !dx || numel <= 0) return DA_ERR_BADARG;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(da_grid(numel / 4 + 1, 256)), dim3(256), 0, da_stream(stream), dy, y, act_slope < 0.f ? 1.f : act_slope, dx, numel);
     DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_act_bwd_add_dbias(const float* g1, const float* g2, const float* y, float act_slope, float* dx, float* dbias,
+                                    long long M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (!g1 || !dx || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (dbias && ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    double* partial = dbias ? (double*)ws : nullptr;
+    const float* yy = act_slope < 0.f ? nullptr : y;          // no activation: dx = g1 + g2
+    if (act_slope >= 0.f && !y) return DA_ERR_BADARG;
+    const size_t shm = (size_t)p.rpi * C * sizeof(double);
+    hipStream_t st = da_stream(stream);
+    if (p.vec == 4) hipLaunchKernelGGL((act_bwd_add_dbias_kernel<4>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
+    else hipLaunchKernelGGL((act_bwd_add_dbias_kernel<1>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
+    DA_LAUNCH_CHECK();
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, C, dbias);
+        DA_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -462,9 +462,11 @@ __global__ void label_warp_dice_bwd_kernel(const void* __restrict__ lab_m, int b
     }
 }
 
-// A[n][u] += w, B[n][u][St[v]] += w over the 8 taps of every voxel v  (A, B zero-filled by the launcher)
+// B[n][u][St[v]] += w over the 8 taps of every voxel v  (B zero-filled by the launcher).  A = W^T 1 needs no scatter of its own: every
+// weight lands in exactly one class channel, so A[u] = sum_c B[u][c] (formed by the consumer from the row it reads anyway); voxels whose
+// target label is outside [0, C) put their weights into the separate array A_extra (NULL when the caller knows there are none).
 __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int bt, const float* __restrict__ disp,
-                                           float* __restrict__ A, float* __restrict__ B, int N, int D, int H, int W, int C) {
+                                           float* __restrict__ A_extra, float* __restrict__ B, int N, int D, int H, int W, int C) {
     const long long V = (long long)D * H * W, nvox = V * N;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
         long long r = v;
@@ -486,8 +488,8 @@ __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int b
             if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
                 const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
                 const long long uu = sbase + ((long long)z * H + y) * W + x;
-                atomicAdd(A + uu, wgt);
                 if (lok) atomicAdd(B + uu * C + lab, wgt);
+                else if (A_extra) atomicAdd(A_extra + uu, wgt);
             }
         }
     }
@@ -509,7 +511,9 @@ __global__ void seg_anat_dlogits_kernel(const float* __restrict__ prob, const vo
         const int n = (int)(row / V);
         const float4 pv = *reinterpret_cast<const float4*>(prob + row * C + q * 4);
         const float4 bv = *reinterpret_cast<const float4*>(B + row * C + q * 4);
-        const float a = A[row];
+        float a = bv.x + bv.y + bv.z + bv.w;                            // A[u] = sum_c B[u][c] (+ the out-of-range-label weights)
+        for (int k = 1; k < lpv; k <<= 1) a += __shfl_xor(a, k);
+        if (A) a += A[row];
         const float p[4] = {pv.x, pv.y, pv.z, pv.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
         const int lab = (coef_s && lab_m) ? warp_label_at(lab_m, bm, row) - q * 4 : -1;
         float g[4];
@@ -659,13 +663,12 @@ extern "C" int da_label_warp_dice_bwd(const void* lab_m, int lab_m_bytes, const 
 
 extern "C" int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const float* disp, float* A, float* B,
                                       int N, int D, int H, int W, int C, void* stream) {
-    if (!lab_t || !disp || !A || !B || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
+    if (!lab_t || !disp || !B || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0 || (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
     hipStream_t st = da_stream(stream);
     const long long nvox = (long long)N * D * H * W;
-    hipError_t e = hipMemsetAsync(A, 0, (size_t)nvox * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(B, 0, (size_t)nvox * C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(B, 0, (size_t)nvox * C * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    if (A) { e = hipMemsetAsync(A, 0, (size_t)nvox * sizeof(float), st); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(warp_adjoint_labels_kernel, dim3(da_grid(nvox, 256)), dim3(256), 0, st, lab_t, lab_t_bytes, disp, A, B, N, D, H, W, C);
     DA_LAUNCH_CHECK();
     return 0;
@@ -674,7 +677,7 @@ extern "C" int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const 
 extern "C" int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, float* B_dlogits,
                                    const float* coef_sup, const float* coef_anat, const float* dloss_sup, const float* dloss_anat,
                                    int N, long long V, int C, void* stream) {
-    if (!prob || !A || !B_dlogits || !coef_anat || !dloss_anat || N <= 0 || V <= 0 || C <= 0) return DA_ERR_BADARG;
+    if (!prob || !B_dlogits || !coef_anat || !dloss_anat || N <= 0 || V <= 0 || C <= 0) return DA_ERR_BADARG;
     if (coef_sup && (!lab_m || !dloss_sup || (lab_m_bytes != 1 && lab_m_bytes != 8))) return DA_ERR_BADARG;
     int lpv; if (!vec_ok(C, &lpv)) return DA_ERR_UNSUPPORTED;
     const long long total = (long long)N * V * lpv;

@@ -228,8 +228,15 @@ class convBlock(nn.Module):
             raise NotImplementedError('HIP conv path covers kernel 3, padding 1, stride 1|2')
         self.stride = stride
 
-    def forward(self, x, skip=None):
+    def forward(self, x, skip=None, fork=False):
+        """fork=True (no BatchNorm, no residual): returns the block's output twice -- for an output with two consumers (the
+        registration net's skip connections) the two gradients are then summed inside the activation-backward pass."""
         slope = _slope_of(self.nonlinear)
+        if fork and self.bn is None and not self.residual:
+            return ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, slope, False, True)
+        if fork:
+            y = self.forward(x, skip)
+            return y, y
         if self.bn is not None:
             y = ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, -1.0)
             bn = self.bn

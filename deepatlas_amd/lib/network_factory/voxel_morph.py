@@ -42,18 +42,20 @@ class VoxelMorphCVPR2018(nn.Module):
     def forward(self, source, target):
         up = ops.UpsampleNearestFn.apply
         # cat(source, target) is a two-pointer conv input (voxel_morph.py:65)
-        e1 = self.encoders[0](source, target)
-        e2 = self.encoders[1](e1)
-        e3 = self.encoders[2](e2)
-        e4 = self.encoders[3](e3)
+        # encoder outputs feed the next encoder AND a decoder (skip): fork=True hands out two aliases so that the two gradients are
+        # summed inside the block's activation-backward pass instead of by a separate autograd accumulation pass
+        e1, e1s = self.encoders[0](source, target, fork=True)
+        e2, e2s = self.encoders[1](e1, fork=True)
+        e3, e3s = self.encoders[2](e2, fork=True)
+        e4, e4s = self.encoders[3](e3, fork=True)
         e5 = self.encoders[4](e4)
         d1 = self.decoders[0](up(e5, e4.shape[2:]))
         # F.interpolate(cat(a, b)) == cat(F.interpolate(a), F.interpolate(b)) for nearest (voxel_morph.py:74,76)
-        d2 = self.decoders[1](up(d1, e3.shape[2:]), up(e4, e3.shape[2:]))
-        d3 = self.decoders[2](up(d2, e2.shape[2:]), up(e3, e2.shape[2:]))
-        d4 = self.decoders[3](d3, e2)
+        d2 = self.decoders[1](up(d1, e3.shape[2:]), up(e4s, e3.shape[2:]))
+        d3 = self.decoders[2](up(d2, e2.shape[2:]), up(e3s, e2.shape[2:]))
+        d4 = self.decoders[3](d3, e2s)
         d5 = self.decoders[4](up(d4, e1.shape[2:]))
-        disp_field = self.flow(d5, e1)
+        disp_field = self.flow(d5, e1s)
         warped_source, deform_field = ops.WarpFn.apply(source, disp_field)
         return disp_field, warped_source, deform_field
 

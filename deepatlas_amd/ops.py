@@ -256,8 +256,11 @@ class Conv3dK3Fn(Function):
     def forward(ctx, x1, x2, weight, bias, stride, act_slope, *extra):
         # extra[0] (optional): `weight` is a ConvTranspose3d(k=3, s=1, p=1) weight [Cin][Cout][3,3,3] (unets.py:88-96): the same
         # operation as this convolution with flipped taps, so only the weight re-layout kernels differ
+        # extra[1] (optional): fork -- the output is returned TWICE (two aliases) for a tensor with two consumers (skip connection):
+        # the two gradients then arrive separately and are summed inside the activation-backward pass instead of by autograd
         transposed = bool(extra[0]) if extra else False
-        ctx.n_extra, ctx.transposed = len(extra), transposed
+        fork = bool(extra[1]) if len(extra) > 1 else False
+        ctx.n_extra, ctx.transposed, ctx.fork = len(extra), transposed, fork
         a1 = ndhwc(x1)
         a2 = ndhwc(x2) if x2 is not None else None
         N, D, H, W, C1 = a1.shape
@@ -284,17 +287,30 @@ class Conv3dK3Fn(Function):
         ctx.has_bias = bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(a1, a2, w_tio, out if act_slope >= 0 else None)
+        if fork:
+            return ncdhw(out), ncdhw(out.view(out.shape))
         return ncdhw(out)
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *gmore):
         a1, a2, w_tio, out = ctx.saved_tensors
         N, D, H, W, C1, C2, Cout, stride, slope, wsb = ctx.dims
         st = stream()
+        g_b = gmore[0] if (ctx.fork and gmore) else None
+        if gout is None:
+            gout, g_b = g_b, None
         g = ndhwc(gout)
-        if out is not None:                      # fused activation: dy = dout * act'(y)
+        gb2 = ndhwc(g_b) if g_b is not None else None
+        want_w = ctx.needs_input_grad[2]
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
+        db = None
+        if out is not None or gb2 is not None:
+            # dy = (g [+ g']) * act'(y) and the bias gradient (column sums of dy) in one pass
             g2 = torch.empty_like(g)
-            call('da_act_bwd', ptr(g), ptr(out), slope, ptr(g2), g.numel(), st)
+            M = g.numel() // Cout
+            db = _empty((Cout,), a1) if want_b else None
+            bwp, bwn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(M, Cout)), a1)
+            call('da_act_bwd_add_dbias', ptr(g), ptr(gb2), ptr(out), slope if out is not None else -1.0, ptr(g2), ptr(db), M, Cout, bwp, bwn, st)
             g = g2
         wp, wn = _ws(wsb, a1)
         dx1 = dx2 = None
@@ -303,17 +319,22 @@ class Conv3dK3Fn(Function):
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3), N * D * H * W)
             call('da_conv3d_k3_dgrad', ptr(g), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, stride, wp, wn, st)
-        dw = db = None
-        gw, gb = _async_target(ctx.wparam), (_async_target(ctx.bparam) if ctx.has_bias else None)
-        if ctx.needs_input_grad[2] and gw is not None and (not ctx.has_bias or gb is not None):
+        dw = None
+        need_db_in_wgrad = want_b and db is None
+        gw = _async_target(ctx.wparam) if want_w else None
+        gbt = _async_target(ctx.bparam) if want_b else None
+        if want_w and gw is not None and (not want_b or gbt is not None):
             global _last_side_flops
             _last_side_flops = 54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3)
+            if db is not None:
+                gbt.add_(db)                         # the fused pass above already produced the bias gradient (main stream)
+                db = None
             side = side_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 sst = stream()
                 dw_tio = torch.empty_like(w_tio)
-                dbs = _empty((Cout,), a1) if ctx.has_bias else None
+                dbs = _empty((Cout,), a1) if need_db_in_wgrad else None
                 swp, swn = _ws(wsb, a1)
                 call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(dbs), N, D, H, W, Cout, stride, swp, swn, sst)
                 dws = torch.empty_like(gw)
@@ -323,18 +344,21 @@ class Conv3dK3Fn(Function):
                     call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
                 gw.add_(dws)
                 if dbs is not None:
-                    gb.add_(dbs)
+                    gbt.add_(dbs)
             _side_keep.extend(t for t in (a1, a2, g) if t is not None)
-        elif ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+        elif want_w or need_db_in_wgrad:
             dw_tio = torch.empty_like(w_tio)
-            db = _empty((Cout,), a1) if ctx.has_bias else None
-            call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(db), N, D, H, W, Cout, stride, wp, wn, st)
-            if ctx.transposed:
-                dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
-                call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
-            else:
-                dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
-                call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+            dbw = _empty((Cout,), a1) if need_db_in_wgrad else None
+            call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(dbw), N, D, H, W, Cout, stride, wp, wn, st)
+            if dbw is not None:
+                db = dbw
+            if want_w:
+                if ctx.transposed:
+                    dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
+                    call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
+                else:
+                    dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
+                    call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None) + (None,) * ctx.n_extra
 
 
@@ -1090,7 +1114,9 @@ class SegPhaseLossFn(Function):
         ga = g_a.detach().reshape(1).to(torch.float32).contiguous() if g_a is not None else zero()
         B = ctx.scratch if ctx.scratch is not None else torch.empty_like(prob)
         ctx.scratch = None
-        A = _empty((N, D * H * W), prob)
+        # labels outside [0, C) (the reference's one-hot scatter would raise on them) put their weights into a separate array: uint8 labels
+        # with C = 256 cannot have any, everything else gets the array
+        A = None if (bt == 1 and C >= 256) else _empty((N, D * H * W), prob)
         call('da_warp_adjoint_labels', ptr(lt), bt, ptr(u), ptr(A), ptr(B), N, D, H, W, C, st)
         call('da_seg_anat_dlogits', ptr(prob), ptr(lm), bm, ptr(A), ptr(B), ptr(coef_s), ptr(coef_a), ptr(gs) if coef_s is not None else None,
              ptr(ga), N, D * H * W, C, st)

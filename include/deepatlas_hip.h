@@ -181,6 +181,11 @@ int da_bn_act_bwd_dbias(const float* dy, const float* x, const float* mean, cons
 /* Backward of a bare activation from its OUTPUT y (ReLU / LeakyReLU): dx = dy * (y > 0 ? 1 : slope). */
 int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream);
 /* Per-channel column sum of x[M][C] -> out[C] (bias gradients). */
+/* backward of a conv block without BatchNorm (modules.py:56-58 conv -> act): dx = (g1 [+ g2]) * act'(y) and dbias = column sums of dx
+ * in ONE pass.  g2 (may be NULL): second incoming gradient of a block whose output has two consumers (skip connection); y: the
+ * block's ACTIVATED output (unused when act_slope < 0); dbias may be NULL; ws as da_bn_ws_bytes(M, C). */
+int da_act_bwd_add_dbias(const float* g1, const float* g2, const float* y, float act_slope, float* dx, float* dbias,
+                         long long M, int C, void* ws, size_t ws_bytes, void* stream);
 int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- MaxPool3d(2) (row a2; unets.py:230,267) ------------------------------------------------- */
@@ -225,8 +230,9 @@ int da_identity_grid(float* out, int D, int H, int W, int normalize, void* strea
  *  registration phase: loss = Dice(warp(onehot(lab_m), id + disp), onehot(lab_t)) straight from the two label maps (no warped
  *    one-hot, no gradient tensor); bwd writes d loss / d disp.
  *  segmentation phase: the adjoint warp of g is coef[1][c] A[u] + coef[0][c] B[u][c] with A = W^T 1 ([N][V]) and
- *    B = W^T onehot(lab_t) ([N][V][C]) -- da_warp_adjoint_labels zero-fills and scatters both (16 float atomics per voxel instead of
- *    8 C) -- and da_seg_anat_dlogits turns B IN PLACE into d(loss_sup + loss_anat) / d logits through the softmax Jacobian
+ *    B = W^T onehot(lab_t) ([N][V][C]) -- da_warp_adjoint_labels zero-fills and scatters B (8 float atomics per voxel instead of 8 C);
+ *    A[u] = sum_c B[u][c] is formed on the fly, the optional array A only collects the weights of voxels whose target label is outside
+ *    [0, C) (pass NULL when the labels are known to be valid) -- and da_seg_anat_dlogits turns B IN PLACE into d(loss_sup + loss_anat) / d logits through the softmax Jacobian
  *    (prob = softmax(logits); coef_sup / lab_m / dloss_sup NULL when there is no supervised Dice term). */
 size_t da_label_warp_dice_ws_bytes(int N, int C);
 int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,

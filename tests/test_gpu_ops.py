@@ -969,3 +969,27 @@ def test_synthetic_volume_generator_bit_exact_vs_oracle(structured):
     if not structured:
         assert abs(float(big.mean()) - 0.5) < 1e-3
         assert np.array_equal(big[1, 0, :2, :3].cpu().numpy(), dp.synth_volume(2, (160, 192, 160), 32, 0, 0.1, 7)[0][1, :2, :3])
+
+
+@pytest.mark.parametrize('slope,Cout', [(0.0, 16), (0.01, 32), (-1.0, 3)])
+def test_conv3d_forked_output_sums_its_two_gradients_in_the_activation_backward(slope, Cout):
+    """Conv3dK3Fn(fork=True) hands out two aliases of its output (the registration net's skip connections, voxel_morph.py:66-82); the two
+    incoming gradients are summed inside da_act_bwd_add_dbias together with act' and the bias gradient.  Against torch-CPU where the
+    output is simply used twice."""
+    from deepatlas_amd import ops
+    C1, C2, N, D, H, W = 8, 16, 1, 6, 9, 18
+    x1, x2 = rnd((N, C1, D, H, W), 1), rnd((N, C2, D, H, W), 2)
+    w, b = rnd((Cout, C1 + C2, 3, 3, 3), 3, 0.2), rnd((Cout,), 4, 0.1)
+    xr1, xr2, wr, br = (t.clone().requires_grad_(True) for t in (x1, x2, w, b))
+    yr = F.conv3d(torch.cat((xr1, xr2), 1), wr, br, padding=1)
+    if slope >= 0:
+        yr = F.leaky_relu(yr, slope) if slope > 0 else F.relu(yr)
+    ga, gb = rnd(tuple(yr.shape), 5), rnd(tuple(yr.shape), 6)
+    ((yr * ga).sum() + (yr * gb).sum()).backward()
+    xg1, xg2 = cl(x1).requires_grad_(True), cl(x2).requires_grad_(True)
+    wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    ya, yb = ops.Conv3dK3Fn.apply(xg1, xg2, wg, bg, 1, slope, False, True)
+    assert ya.data_ptr() == yb.data_ptr()
+    ((ya * cl(ga)).sum() + (yb * cl(gb)).sum()).backward()
+    check(ya, yr, what='fwd'); check(xg1.grad, xr1.grad, what='dgrad1'); check(xg2.grad, xr2.grad, what='dgrad2')
+    check(wg.grad, wr.grad, what='wgrad'); check(bg.grad, br.grad, what='bgrad')
