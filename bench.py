@@ -138,6 +138,7 @@ def make_workloads(args, dev, rank, which):
     model = get_network(args.net)(in_channel=1, n_classes=n_classes, bias=True, BN=True)
     model.weights_init()
     model.to(dev).train()
+    model.lazy_head = not args.no_fused_head       # head + softmax + Dice as one kernel pair (ops.HeadDiceFn), as SegmentationExperiment trains
     crit = get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     parallel.broadcast_parameters(opt)
@@ -290,6 +291,7 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="matrix arithmetic of the 3x3x3 convolutions: 'fp32' = the reference's arithmetic (the headline metric); 'bf16' = "
                          "bf16 operands, fp32 accumulate (BASELINE configs[4]'s mixed precision; not the headline)")
+    ap.add_argument('--no-fused-head', action='store_true', help='run the 1x1x1 head, softmax and Dice as separate kernels (logits materialised)')
     ap.add_argument('--sync-wgrad', action='store_true', help='weight gradients on the main stream (default: side stream, overlapped with the HBM-bound backward kernels)')
     ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
                     help="segmentation network of the 'seg' workload; 'UNet' = the fixed 19 M-parameter net (SURVEY.md row f3), not the headline config")

@@ -84,6 +84,9 @@ SIGNATURES = {
     'da_softmax_fwd': (I, [P, P, LL, I, P]),
     'da_softmax_bwd': (I, [P, P, P, LL, I, P]),
     'da_one_hot': (I, [P, I, P, LL, I, P]),
+    'da_head_dice_ws_bytes': (SZ, [I, LL, I, I]),
+    'da_head_dice_fwd': (I, [P, P, P, F, P, P, P, I, I, LL, I, I, I, I, F, P, P, P, SZ, P]),
+    'da_head_dice_bwd': (I, [P, P, P, F, P, P, P, I, P, P, P, P, P, I, LL, I, I, P, SZ, P]),
     'da_ncc_ws_bytes': (SZ, [I, LL]),
     'da_ncc_fwd': (I, [P, P, I, LL, P, P, P, SZ, P]),
     'da_ncc_bwd': (I, [P, P, P, P, P, P, I, LL, P]),

@@ -1,0 +1,422 @@
+// Fused segmentation head + softmax + Dice:  loss = Dice(softmax(x W + b), labels)  without ever writing the logits.
+//
+// Reference: the 1x1x1 output convolution (unets.py:249-250) followed by DiceLossMultiClass.forward with softmax=True and an index
+// target (lib/loss.py:410-476).  At 160x192x160 with 32 classes the logits are the largest tensor of the step (629 MB per volume) and
+// the op-by-op path moves them six times (head forward write, Dice forward read, Dice backward read + gradient write, head data
+// gradient read, head weight gradient read).  The head is a 16 -> 32 channel GEMM -- cheaper to recompute than to store:
+//   forward : read x (64 B / voxel), logits on the matrix cores, softmax + the three Dice sums per class in registers; nothing written
+//   backward: read x again, recompute logits / softmax, form d loss / d logits from Dice's rank-structured gradient
+//             g[v][c] = coef0[c] [label == c] + coef1[c], and feed it straight into the data-gradient GEMM (dx written once), the
+//             weight-gradient GEMM and the bias gradient (per-workgroup partials, reduced in a fixed order).
+// HBM-bound: algorithmic bytes forward (4 Cin + 1) per voxel, backward (8 Cin + 1) per voxel.
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32), operand layouts as in pointwise_mfma.hip (A rows from global in fragment order).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kHdBlocks = 1024;           // workgroups per sample (forward partial sums) / in total (backward partials)
+constexpr int MT = 4;                     // M-tiles (16 voxels) per wave and chunk: a workgroup covers 256 voxels per iteration
+
+struct HdP {
+    const float* x; const float* ps; const float* pt; float pslope;      // input [N][V][K] (+ optional deferred BatchNorm + activation)
+    const float* wp_fwd; const float* wp_bwd; const float* bias;
+    const void* labels; int label_bytes;
+    long long V; int N, K, C;
+    double* partial;                         // fwd: [N][gridDim.x][3][C]
+    const float* coef; const float* dloss;   // bwd
+    float* dx; float* wpartial;              // bwd: dx [N][V][K]; per-workgroup [K*C + C] partial (dW, dbias)
+};
+
+__device__ __forceinline__ float hd_act01(float z, float s) { return fmaxf(z, z * s); }
+__device__ __forceinline__ long long hd_label(const void* labels, int label_bytes, long long i) {
+    return label_bytes == 1 ? (long long)((const unsigned char*)labels)[i] : ((const long long*)labels)[i];
+}
+
+// packed B: wp[n][c][lane][m] = B[k = 16c + 4(lane>>4) + m][j = 16n + (lane&15)];  transposed == 0: B[k][j] = w[k*Nt + j], else w[j*Kt + k]
+__global__ void hd_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int N, int transposed) {
+    const int KC = K / 16, NT = N / 16;
+    const int total = NT * KC * 256;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int m = idx & 3, lane = (idx >> 2) & 63;
+        int rest = idx >> 8;
+        const int c = rest % KC; const int n = rest / KC;
+        const int k = 16 * c + 4 * (lane >> 4) + m, j = 16 * n + (lane & 15);
+        wp[idx] = transposed ? w[(size_t)j * K + k] : w[(size_t)k * N + j];
+    }
+}
+
+// One chunk = 64 voxels per wave = MT tiles of 16.  The GEMM is run TRANSPOSED, logits^T = W^T x^T: M = classes, N = voxels, so that in
+// the MFMA result layout a lane holds classes 16n + 4g + reg (8 of them for 32 classes) of ONE voxel (tile t, voxel i = lane & 15).
+// The softmax of a voxel is then a reduction over this lane's registers and the three other lane groups (two DPP-free xor steps),
+// the voxel's label is one load per tile, and in the backward pass the gradient with respect to the logits is already in the B-operand
+// layout of the data-gradient GEMM (no transpose through LDS), whose result comes out as 4 consecutive input channels per lane
+// (16-byte stores).  Returns probabilities in acc (0 for voxels past the end).
+template <int KC, int NT>
+__device__ __forceinline__ void hd_probs(const HdP& p, const float* __restrict__ xs, long long vbase, int i, int g,
+                                         const float4 (&wf)[NT][KC], const float (&bv)[NT][4], float4 (&a)[MT][KC], f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const long long vox = vbase + t * 16 + i;
+        const bool ok = vox < p.V;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            a[t][c] = ok ? *reinterpret_cast<const float4*>(xs + vox * p.K + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.ps) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.ps + 16 * c + 4 * g), sf = *reinterpret_cast<const float4*>(p.pt + 16 * c + 4 * g);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                a[t][c].x = hd_act01(a[t][c].x * sc.x + sf.x, p.pslope); a[t][c].y = hd_act01(a[t][c].y * sc.y + sf.y, p.pslope);
+                a[t][c].z = hd_act01(a[t][c].z * sc.z + sf.z, p.pslope); a[t][c].w = hd_act01(a[t][c].w * sc.w + sf.w, p.pslope);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
+    // A = W^T fragment (lane: class 16n + i, input channel 16c + 4g + m), B = x^T fragment (lane: voxel i, input channel 16c + 4g + m)
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].x, a[t][c].x, acc[t][n], 0, 0, 0);
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].y, a[t][c].y, acc[t][n], 0, 0, 0);
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].z, a[t][c].z, acc[t][n], 0, 0, 0);
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].w, a[t][c].w, acc[t][n], 0, 0, 0);
+            }
+    // softmax over the classes of voxel (t, i): NT * 4 values in this lane x the four lane groups (F.softmax(source, dim=1), loss.py:426-427)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const bool valid = vbase + t * 16 + i < p.V;
+        float m = acc[t][0][0];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) m = fmaxf(m, acc[t][n][reg]);
+        m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { acc[t][n][reg] = __expf(acc[t][n][reg] - m); s += acc[t][n][reg]; }      // v_exp_f32: arguments <= 0, relative error ~1e-6
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float inv = valid ? 1.f / s : 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[t][n][reg] *= inv;
+    }
+}
+
+// weights as the A operand: wf[n][c] (lane (i, g)) = W[input channel 16c + 4g + m][class 16n + i], m = .x .. .w  = packed B of the plain form
+// bias of this lane's classes 16n + 4g + reg
+template <int NT>
+__device__ __forceinline__ void hd_bias(const HdP& p, int g, float (&bv)[NT][4]) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) bv[n][reg] = p.bias ? p.bias[16 * n + 4 * g + reg] : 0.f;
+}
+
+template <int KC, int NT>
+__global__ void __launch_bounds__(256) head_dice_fwd_kernel(HdP p) {
+    __shared__ double sred[4][3][NT * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int n_s = blockIdx.y;
+    const float* xs = p.x + (long long)n_s * p.V * p.K;
+    const long long lbase = (long long)n_s * p.V;
+    float4 wf[NT][KC]; float bv[NT][4];
+    hd_bias<NT>(p, g, bv);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) wf[n][c] = reinterpret_cast<const float4*>(p.wp_fwd)[(n * KC + c) * 64 + lane];
+    float sI[NT][4], sS[NT][4], sT[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) sI[n][reg] = sS[n][reg] = sT[n][reg] = 0.f;
+    const long long nchunks = (p.V + 255) / 256;
+    for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
+        const long long vbase = cb * 256 + wave * 64;
+        float4 a[MT][KC]; f32x4 acc[MT][NT];
+        hd_probs<KC, NT>(p, xs, vbase, i, g, wf, bv, a, acc);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const long long vox = vbase + t * 16 + i;
+            const int rel = (vox < p.V ? (int)hd_label(p.labels, p.label_bytes, lbase + vox) : -1) - 4 * g;     // hit: rel == 16n + reg
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float pr = acc[t][n][reg];
+                    const bool hit = rel == 16 * n + reg;
+                    sS[n][reg] += pr; sI[n][reg] += hit ? pr : 0.f; sT[n][reg] += hit ? 1.f : 0.f;
+                }
+        }
+    }
+    // per-lane fp32 sums cover at most a few hundred voxels; everything past them is double: the 16 voxel lanes, then the four waves
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            double a0 = (double)sI[n][reg], a1 = (double)sS[n][reg], a2 = (double)sT[n][reg];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+            if (i == 0) { const int c = 16 * n + 4 * g + reg; sred[wave][0][c] = a0; sred[wave][1][c] = a1; sred[wave][2][c] = a2; }
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * p.C; idx += blockDim.x) {
+        const int k = idx / p.C, c = idx % p.C;
+        p.partial[(((size_t)n_s * gridDim.x + blockIdx.x) * 3 + k) * p.C + c] = (sred[0][k][c] + sred[1][k][c]) + (sred[2][k][c] + sred[3][k][c]);
+    }
+}
+
+template <int KC, int NT>
+__global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
+    constexpr int K = KC * 16, C = NT * 16, LDX = K + 4, LDD = C + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    float* xl = lds + wave * (64 * LDX + 64 * LDD);          // this wave's activated-input tile [64 voxels][LDX]
+    float* dl = xl + 64 * LDX;                               // this wave's d loss / d logits tile [64 voxels][LDD]
+    float4 wf[NT][KC]; float bv[NT][4];
+    hd_bias<NT>(p, g, bv);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) wf[n][c] = reinterpret_cast<const float4*>(p.wp_fwd)[(n * KC + c) * 64 + lane];
+    // data gradient, A operand: wd[c][n][reg] (lane (i, g)) = W[input channel 16c + i][class 16n + 4g + reg]
+    float wd[KC][NT][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) wd[c][n][reg] = p.wp_bwd[(size_t)(16 * c + i) * C + 16 * n + 4 * g + reg];
+    const float gl = p.dloss[0];
+    f32x4 wacc[KC][NT];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wacc[c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float db[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) db[n][reg] = 0.f;
+    const long long chunks_per_sample = (p.V + 255) / 256, nchunks = chunks_per_sample * p.N;
+    for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
+        const int n_s = (int)(cb / chunks_per_sample);
+        const long long vbase = (cb - (long long)n_s * chunks_per_sample) * 256 + wave * 64;
+        const float* xs = p.x + (long long)n_s * p.V * p.K;
+        float* dxs = p.dx + (long long)n_s * p.V * p.K;
+        const long long lbase = (long long)n_s * p.V;
+        const float* c0 = p.coef + (size_t)n_s * p.C;                  // coef[0][n][c]
+        const float* c1 = p.coef + (size_t)(p.N + n_s) * p.C;          // coef[1][n][c]
+        float4 a[MT][KC]; f32x4 acc[MT][NT];
+        hd_probs<KC, NT>(p, xs, vbase, i, g, wf, bv, a, acc);
+        // activated input tile -> LDS [voxel][cin] (A operand of the weight-gradient GEMM, read transposed)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) *reinterpret_cast<float4*>(xl + (t * 16 + i) * LDX + 16 * c + 4 * g) = a[t][c];
+        float k0[NT][4], k1[NT][4];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { k0[n][reg] = c0[16 * n + 4 * g + reg]; k1[n][reg] = c1[16 * n + 4 * g + reg]; }
+        // d loss / d logits = gl * p * (g - sum_c g p),  g = coef0 [label == c] + coef1   (Dice backward through the softmax Jacobian)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const long long vox = vbase + t * 16 + i;
+            const int rel = (vox < p.V ? (int)hd_label(p.labels, p.label_bytes, lbase + vox) : -1) - 4 * g;
+            float gg[NT][4], dot = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { gg[n][reg] = k0[n][reg] * (rel == 16 * n + reg ? 1.f : 0.f) + k1[n][reg]; dot += gg[n][reg] * acc[t][n][reg]; }
+            dot += __shfl_xor(dot, 16); dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float d = gl * acc[t][n][reg] * (gg[n][reg] - dot);       // voxels past the end: p = 0 -> 0
+                    db[n][reg] += d;
+                    acc[t][n][reg] = d;
+                }
+                *reinterpret_cast<float4*>(dl + (t * 16 + i) * LDD + 16 * n + 4 * g) = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
+            }
+        }
+        // data gradient: dx^T[k][voxel] = sum_c W[k][c] dl[c][voxel]; the dl registers are the B operand as they stand
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            f32x4 dacc[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) dacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) dacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[c][n][reg], acc[t][n][reg], dacc[c], 0, 0, 0);
+            const long long vox = vbase + t * 16 + i;
+            if (vox < p.V) {
+#pragma unroll
+                for (int c = 0; c < KC; ++c)          // lane (voxel i, group g) holds input channels 16c + 4g .. + 3
+                    *reinterpret_cast<float4*>(dxs + vox * p.K + 16 * c + 4 * g) = make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]);
+            }
+        }
+        __syncthreads();
+        // weight gradient: dW[k][c] += sum_voxels xa[voxel][k] dl[voxel][c]   (K dimension = the 64 voxels of this wave's chunk)
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            float av[KC], bw[NT];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) av[c] = xl[(4 * s + g) * LDX + 16 * c + i];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw[n] = dl[(4 * s + g) * LDD + 16 * n + i];
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) wacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bw[n], wacc[c][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // per-workgroup partials: dW [K][C] then dbias [C]; the four waves are folded through LDS in a fixed order
+    __syncthreads();
+    float* red = lds;                                         // [K*C + C]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * c + 4 * g + reg) * C + 16 * n + i;         // row (input channel) = 4g + reg, col (class) = i
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + wacc[c][n][reg];
+                    }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float d = db[n][reg];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) d += __shfl_xor(d, o);
+                    const int cidx = K * C + 16 * n + 4 * g + reg;
+                    if (i == 0) red[cidx] = (w == 0 ? 0.f : red[cidx]) + d;
+                }
+        }
+        __syncthreads();
+    }
+    float* part = p.wpartial + (size_t)blockIdx.x * (K * C + C);
+    for (int idx = threadIdx.x; idx < K * C + C; idx += blockDim.x) part[idx] = red[idx];
+}
+
+static bool hd_shape_ok(int K, int C) { return (K == 16 || K == 64) && (C == 16 || C == 32); }
+
+}  // namespace
+
+extern "C" size_t da_head_dice_ws_bytes(int N, long long V, int Cin, int C) {
+    (void)V;
+    const size_t pack = da_align((size_t)2 * Cin * C * sizeof(float));
+    const size_t fwd = da_align((size_t)N * kHdBlocks * 3 * C * sizeof(double)) + da_align((size_t)3 * N * C * sizeof(float));
+    const size_t bwd = da_align((size_t)kHdBlocks * (Cin * C + C) * sizeof(float)) + da_align((size_t)(Cin * C + C) * sizeof(float));
+    return pack + (fwd > bwd ? fwd : bwd);
+}
+
+template <int KC, int NT>
+static int hd_launch_fwd(const HdP& p, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL((head_dice_fwd_kernel<KC, NT>), dim3(nblocks, p.N), dim3(256), 0, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+template <int KC, int NT>
+static int hd_launch_bwd(const HdP& p, int nblocks, hipStream_t st) {
+    const size_t shm = (size_t)4 * (64 * (KC * 16 + 4) + 64 * (NT * 16 + 4)) * sizeof(float);
+    auto kern = head_dice_bwd_kernel<KC, NT>;
+    static bool attr_set = false;
+    if (!attr_set && shm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_head_dice_fwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                const float* w_io, const float* bias, const void* labels, int label_bytes,
+                                int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
+                                float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w_io || !labels || !loss || !coef || N <= 0 || N > 64 || V <= 0 || (label_bytes != 1 && label_bytes != 8) ||
+        ((pro_scale == nullptr) != (pro_shift == nullptr))) return DA_ERR_BADARG;
+    if (!hd_shape_ok(Cin, C) || (pro_scale && pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_head_dice_ws_bytes(N, V, Cin, C)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    float* wp = (float*)ws;
+    hipLaunchKernelGGL(hd_pack_kernel, dim3(da_grid(Cin * C, 256, 64)), dim3(256), 0, st, w_io, wp, Cin, C, 0);
+    DA_LAUNCH_CHECK();
+    char* rest = (char*)ws + da_align((size_t)2 * Cin * C * sizeof(float));
+    double* partial = (double*)rest;
+    float* isc = (float*)(rest + da_align((size_t)N * kHdBlocks * 3 * C * sizeof(double)));
+    int nblocks = (int)da_cdiv(V, 256 * 2); if (nblocks > kHdBlocks) nblocks = kHdBlocks; if (nblocks < 1) nblocks = 1;
+    HdP p;
+    p.x = x; p.ps = pro_scale; p.pt = pro_shift; p.pslope = pro_scale ? (pro_slope < 0.f ? 1.f : pro_slope) : 1.f;
+    p.wp_fwd = wp; p.wp_bwd = nullptr; p.bias = bias; p.labels = labels; p.label_bytes = label_bytes;
+    p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = partial; p.coef = nullptr; p.dloss = nullptr; p.dx = nullptr; p.wpartial = nullptr;
+    int rc;
+    if (Cin == 16 && C == 32) rc = hd_launch_fwd<1, 2>(p, nblocks, st);
+    else if (Cin == 16 && C == 16) rc = hd_launch_fwd<1, 1>(p, nblocks, st);
+    else if (Cin == 64 && C == 32) rc = hd_launch_fwd<4, 2>(p, nblocks, st);
+    else rc = hd_launch_fwd<4, 1>(p, nblocks, st);
+    if (rc) return rc;
+    return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
+}
+
+extern "C" int da_head_dice_bwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                const float* w_io, const float* bias, const void* labels, int label_bytes,
+                                const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
+                                int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w_io || !labels || !coef || !dloss || !dx || !dw_io || N <= 0 || V <= 0 || (label_bytes != 1 && label_bytes != 8) ||
+        ((pro_scale == nullptr) != (pro_shift == nullptr))) return DA_ERR_BADARG;
+    if (!hd_shape_ok(Cin, C) || (pro_scale && pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_head_dice_ws_bytes(N, V, Cin, C)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    float* wpf = (float*)ws;
+    const float* wpb = w_io;                 // the data-gradient A fragments are read straight from w_io [Cin][C]
+    hipLaunchKernelGGL(hd_pack_kernel, dim3(da_grid(Cin * C, 256, 64)), dim3(256), 0, st, w_io, wpf, Cin, C, 0);
+    DA_LAUNCH_CHECK();
+    char* rest = (char*)ws + da_align((size_t)2 * Cin * C * sizeof(float));
+    float* wpartial = (float*)rest;
+    const int O = Cin * C + C;
+    float* folded = (float*)(rest + da_align((size_t)kHdBlocks * O * sizeof(float)));
+    const long long nchunks = da_cdiv(V, 256) * N;
+    int nblocks = (int)(nchunks < kHdBlocks ? nchunks : kHdBlocks); if (nblocks < 1) nblocks = 1;
+    HdP p;
+    p.x = x; p.ps = pro_scale; p.pt = pro_shift; p.pslope = pro_scale ? (pro_slope < 0.f ? 1.f : pro_slope) : 1.f;
+    p.wp_fwd = wpf; p.wp_bwd = wpb; p.bias = bias; p.labels = labels; p.label_bytes = label_bytes;
+    p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = nullptr; p.coef = coef; p.dloss = dloss; p.dx = dx; p.wpartial = wpartial;
+    int rc;
+    if (Cin == 16 && C == 32) rc = hd_launch_bwd<1, 2>(p, nblocks, st);
+    else if (Cin == 16 && C == 16) rc = hd_launch_bwd<1, 1>(p, nblocks, st);
+    else if (Cin == 64 && C == 32) rc = hd_launch_bwd<4, 2>(p, nblocks, st);
+    else rc = hd_launch_bwd<4, 1>(p, nblocks, st);
+    if (rc) return rc;
+    rc = da_reduce_partials(wpartial, nblocks, O, folded, st);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dw_io, folded, (size_t)Cin * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    if (dbias) { e = hipMemcpyAsync(dbias, folded + (size_t)Cin * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
+    return 0;
+}

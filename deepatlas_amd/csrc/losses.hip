@@ -535,51 +535,43 @@ __device__ __forceinline__ float bend_grad_elem(const float* __restrict__ u, int
     return g;
 }
 
-// One thread per voxel, three channels.  'L2', voxel at least two away from every face (all 25 stencil centres that contain it are
-// interior): the composition S^T S of each difference stencil with its own adjoint is a FIXED stencil --
+// One thread per element (c fastest: a wave instruction reads 256 contiguous bytes).  'L2', voxel at least two away from every face
+// (all 25 stencil centres that contain it are interior): the composition S^T S of each difference stencil with its own adjoint is a
+// FIXED stencil --
 //   second difference along e:  u(p+2e) - 4 u(p+e) + 6 u(p) - 4 u(p-e) + u(p-2e)
 //   mixed difference in (a, b): 4 u(p) - 2 [u(p+-2a) + u(p+-2b)] + [u(p+2a+2b) + u(p+2a-2b) + u(p-2a+2b) + u(p-2a-2b)]
-// -- 25 voxel reads instead of ~110 for the term-by-term gather.  The shell within two voxels of a face (and 'L1', whose sign() does
-// not commute) takes the term-by-term form.
+// -- 25 reads instead of ~110 for the term-by-term gather.  The shell within two voxels of a face (and 'L1', whose sign() does not
+// commute with the composition) takes the term-by-term form.
 template <bool L1>
 __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ dloss,
                                    float* __restrict__ d_disp, int D, int H, int W, BendK K) {
     const int n = blockIdx.y;
     const float* u = disp + (long long)n * D * H * W * 3;
     float* du = d_disp + (long long)n * D * H * W * 3;
-    const long long total = (long long)D * H * W;
+    const long long total = (long long)D * H * W * 3;
     const float gl = (L1 ? 1.f : 2.f) * dloss[0];
-    const long long sH = W, sD = (long long)H * W;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
-        long long r = p;
+    const long long sW = 3, sH = (long long)W * 3, sD = (long long)H * W * 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3); long long r = i / 3;
         const int w = (int)(r % W); r /= W;
         const int h = (int)(r % H); const int d = (int)(r / H);
-        float g0, g1, g2;
+        float g;
         const bool deep = !L1 && d >= 2 && d < D - 2 && h >= 2 && h < H - 2 && w >= 2 && w < W - 2;
         if (deep) {
-            const F3 c0 = ld3(u, p);
-            const F3 d1p = ld3(u, p + sD), d1m = ld3(u, p - sD), d2p = ld3(u, p + 2 * sD), d2m = ld3(u, p - 2 * sD);
-            const F3 h1p = ld3(u, p + sH), h1m = ld3(u, p - sH), h2p = ld3(u, p + 2 * sH), h2m = ld3(u, p - 2 * sH);
-            const F3 w1p = ld3(u, p + 1), w1m = ld3(u, p - 1), w2p = ld3(u, p + 2), w2m = ld3(u, p - 2);
-            const F3 dhpp = ld3(u, p + 2 * sD + 2 * sH), dhpm = ld3(u, p + 2 * sD - 2 * sH), dhmp = ld3(u, p - 2 * sD + 2 * sH), dhmm = ld3(u, p - 2 * sD - 2 * sH);
-            const F3 hwpp = ld3(u, p + 2 * sH + 2), hwpm = ld3(u, p + 2 * sH - 2), hwmp = ld3(u, p - 2 * sH + 2), hwmm = ld3(u, p - 2 * sH - 2);
-            const F3 dwpp = ld3(u, p + 2 * sD + 2), dwpm = ld3(u, p + 2 * sD - 2), dwmp = ld3(u, p - 2 * sD + 2), dwmm = ld3(u, p - 2 * sD - 2);
-#define BEND_G(f, c)                                                                                                  \
-            (K.k[c][0] * (d2p.f + d2m.f - 4.f * (d1p.f + d1m.f) + 6.f * c0.f) +                                           \
-             K.k[c][1] * (h2p.f + h2m.f - 4.f * (h1p.f + h1m.f) + 6.f * c0.f) +                                           \
-             K.k[c][2] * (w2p.f + w2m.f - 4.f * (w1p.f + w1m.f) + 6.f * c0.f) +                                           \
-             K.k[c][3] * (4.f * c0.f - 2.f * (d2p.f + d2m.f + h2p.f + h2m.f) + (dhpp.f + dhpm.f + dhmp.f + dhmm.f)) +     \
-             K.k[c][4] * (4.f * c0.f - 2.f * (h2p.f + h2m.f + w2p.f + w2m.f) + (hwpp.f + hwpm.f + hwmp.f + hwmm.f)) +     \
-             K.k[c][5] * (4.f * c0.f - 2.f * (d2p.f + d2m.f + w2p.f + w2m.f) + (dwpp.f + dwpm.f + dwmp.f + dwmm.f)))
-            g0 = BEND_G(x, 0); g1 = BEND_G(y, 1); g2 = BEND_G(z, 2);
-#undef BEND_G
+            const float* q = u + i;
+            const float c0 = q[0];
+            const float d2 = q[2 * sD] + q[-2 * sD], d1 = q[sD] + q[-sD];
+            const float h2 = q[2 * sH] + q[-2 * sH], h1 = q[sH] + q[-sH];
+            const float w2 = q[2 * sW] + q[-2 * sW], w1 = q[sW] + q[-sW];
+            const float dh = q[2 * sD + 2 * sH] + q[2 * sD - 2 * sH] + q[-2 * sD + 2 * sH] + q[-2 * sD - 2 * sH];
+            const float hw = q[2 * sH + 2 * sW] + q[2 * sH - 2 * sW] + q[-2 * sH + 2 * sW] + q[-2 * sH - 2 * sW];
+            const float dw = q[2 * sD + 2 * sW] + q[2 * sD - 2 * sW] + q[-2 * sD + 2 * sW] + q[-2 * sD - 2 * sW];
+            g = K.k[c][0] * (d2 - 4.f * d1 + 6.f * c0) + K.k[c][1] * (h2 - 4.f * h1 + 6.f * c0) + K.k[c][2] * (w2 - 4.f * w1 + 6.f * c0) +
+                K.k[c][3] * (4.f * c0 - 2.f * (d2 + h2) + dh) + K.k[c][4] * (4.f * c0 - 2.f * (h2 + w2) + hw) + K.k[c][5] * (4.f * c0 - 2.f * (d2 + w2) + dw);
         } else {
-            g0 = bend_grad_elem<L1>(u, d, h, w, 0, D, H, W, K);
-            g1 = bend_grad_elem<L1>(u, d, h, w, 1, D, H, W, K);
-            g2 = bend_grad_elem<L1>(u, d, h, w, 2, D, H, W, K);
+            g = bend_grad_elem<L1>(u, d, h, w, c, D, H, W, K);
         }
-        float* o = du + p * 3;
-        o[0] = gl * g0; o[1] = gl * g1; o[2] = gl * g2;
+        du[i] = gl * g;
     }
 }
 #undef BU
@@ -809,7 +801,7 @@ extern "C" int da_bending_bwd(const float* disp, const float* dloss, float* d_di
                               const float* spacing3, int normalize, int norm, void* stream) {
     if (!disp || !dloss || !d_disp || N <= 0 || D < 3 || H < 3 || W < 3 || (norm != 1 && norm != 2)) return DA_ERR_BADARG;
     const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize, norm);
-    const long long total = (long long)D * H * W;
+    const long long total = (long long)D * H * W * 3;
     if (norm == 2) hipLaunchKernelGGL((bending_bwd_kernel<false>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
     else hipLaunchKernelGGL((bending_bwd_kernel<true>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
     DA_LAUNCH_CHECK();

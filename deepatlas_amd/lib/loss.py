@@ -26,6 +26,17 @@ class DiceLossMultiClass(nn.Module):
         or B x C x D x M x N class probabilities (lib/loss.py:410-416)."""
         assert source.shape[0] == target.shape[0]
         assert source.shape[-3:] == target.squeeze().shape[-3:]
+        if isinstance(source, ops.LazyLogits):
+            # the network's output convolution has not been run (model.lazy_head): head + softmax + Dice in one kernel pair when this
+            # is the softmax-Dice of logits against an index mask (models/segmentation.py:141-157), real logits otherwise
+            if (self.softmax and len(target.shape) == len(source.shape) - 1 and self.n_class == source.shape[1]
+                    and self.weight_type in ('Simple', 'Volume', 'Uniform')):
+                x = source.x
+                if isinstance(x, ops.LazyAct):
+                    return ops.HeadDiceFn.apply(x.raw, source.weight, source.bias, target, self.weight_type, self.no_bg, self.eps,
+                                                (x.scale, x.shift, x.slope))
+                return ops.HeadDiceFn.apply(x, source.weight, source.bias, target, self.weight_type, self.no_bg, self.eps)
+            source = source.materialize()
         if self.n_class is None:
             self.n_class = max(torch.unique(target).max(), torch.unique(source).max()).long().item() + 1
         shape = list(source.shape)

@@ -185,7 +185,12 @@ class HeadConv(nn.Conv3d):
 
     supports_lazy = True      # accepts an ops.LazyAct input (deferred BatchNorm + activation of the last decoder block)
 
+    lazy = False              # set through the network's `lazy_head` attribute: return an ops.LazyLogits instead of running the conv
+
     def forward(self, x):
+        if (self.lazy and self.training and ops.FUSE_HEAD_DICE and torch.is_grad_enabled()
+                and ops.head_dice_supported(self.weight.shape[1], self.weight.shape[0])):
+            return ops.LazyLogits(x, self.weight, self.bias)
         if isinstance(x, ops.LazyAct):
             return ops.Conv1x1Fn.apply(x.raw, self.weight, self.bias, (x.scale, x.shift, x.slope))
         return ops.Conv1x1Fn.apply(x, self.weight, self.bias)

@@ -68,6 +68,18 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
         def weights_init(self):
             self.apply(init_conv_weights)
 
+        @property
+        def lazy_head(self):
+            """True: in training mode forward() returns an ops.LazyLogits (the output convolution is evaluated inside the fused
+            head + softmax + Dice kernels by DiceLossMultiClass, or on .materialize()); default False: a logits tensor, always."""
+            return any(m.lazy for m in self.modules() if isinstance(m, HeadConv))
+
+        @lazy_head.setter
+        def lazy_head(self, flag):
+            for m in self.modules():
+                if isinstance(m, HeadConv):
+                    m.lazy = bool(flag)
+
         def forward(self, x):
             """unets.py:259-278.  The skip concat (up-sampled first, skip second) is a two-pointer conv input."""
             # Deferred BatchNorm + activation (ops.LazyAct): inside conv -> conv chains the activated tensor is never written; the next
@@ -108,7 +120,7 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
                 for k in range(1, len(blocks)):
                     nxt = blocks[k + 1] if k + 1 < len(blocks) else None
                     y = blocks[k](y, lazy_out=True) if lazy_ok(blocks[k], nxt) else blocks[k](y)
-                x = (y + x) if self.res else y            # res=True: `dec(cat(x, skip)) + x` (unets.py:275)
+                x = (ops.materialize_logits(y) + x) if self.res else y            # res=True: `dec(cat(x, skip)) + x` (unets.py:275)
             return x
 
     return UNetTemplate
@@ -146,6 +158,15 @@ class UNet(nn.Module):
         self.dc2 = self.decoder(64 + 128, 64, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
         self.dc1 = self.decoder(64, 64, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
         self.dc0 = HeadConv(64, n_classes, kernel_size=1, stride=1, padding=0, bias=bias)
+
+    @property
+    def lazy_head(self):
+        """see UNetTemplate.lazy_head"""
+        return self.dc0.lazy
+
+    @lazy_head.setter
+    def lazy_head(self, flag):
+        self.dc0.lazy = bool(flag)
 
     def weights_init(self):
         """unets.py:102-110: xavier-normal on every module whose class name contains 'Conv' (the nn.Conv3d / ConvTranspose3d

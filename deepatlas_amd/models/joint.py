@@ -60,7 +60,7 @@ class DeepAtlasJointStep:
         if seg_m is None:
             with torch.no_grad():
                 self.seg.eval()
-                prob_m = ops.SoftmaxFn.apply(self.seg(im_m))
+                prob_m = ops.SoftmaxFn.apply(ops.materialize_logits(self.seg(im_m)))
         disp, warped, deform = self.reg(im_m, im_t)
         fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
         l_sim = self.ncc(warped, im_t)
@@ -82,7 +82,7 @@ class DeepAtlasJointStep:
         # ---- segmentation phase (deformation fixed)
         self.seg.train()
         self.seg_opt.zero_grad()
-        logits = self.seg(im_m)
+        logits = ops.materialize_logits(self.seg(im_m))
         if fused and not ops.DETERMINISTIC:
             # both Dice terms as one node: structured adjoint warp + one pass to the logit gradient (ops.SegPhaseLossFn); its scatter
             # uses float atomics, so deterministic runs take the composed path below (fixed-point accumulation in WarpFn)

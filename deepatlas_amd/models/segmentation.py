@@ -88,6 +88,11 @@ class SegmentationExperiment(BaseExperiment):
         model_type = get_network(self.config['model'])
         self.model = model_type(**self.config['model_settings'])
         self.model.to(self.device)
+        # softmax-Dice training (train_seg.py:55): the output convolution is evaluated inside the fused head + softmax + Dice kernels
+        # (ops.HeadDiceFn) and the logits tensor is only built on demand (train_step's `output`.materialize(), eval mode)
+        if (self.config.get('fuse_head_dice', True) and self.config.get('loss') == 'dice'
+                and self.config.get('loss_settings', {}).get('softmax') and hasattr(type(self.model), 'lazy_head')):
+            self.model.lazy_head = True
 
     def setup_loss(self):
         self.criterion = get_loss_function(self.config['loss'])(**self.config['loss_settings']).to(self.device)

@@ -1027,6 +1027,95 @@ class WarpLabelsFn(Function):
         return None, ncdhw(d_disp), None
 
 
+# ------------------------------------------------------------------------------------------------
+# fused segmentation head + softmax + Dice
+# ------------------------------------------------------------------------------------------------
+# models/segmentation.py:141-157 calls `output = self.model(images); loss = self.criterion(output, truths)`.  With `model.lazy_head`
+# set (SegmentationExperiment and bench.py do, for the softmax-Dice criterion) the network's 1x1x1 output convolution is not run on
+# its own: forward() returns a LazyLogits, and DiceLossMultiClass evaluates head + softmax + Dice in one kernel pair (da_head_dice_*)
+# that never writes the 629 MB-per-volume logits.  Anything else that touches the object gets real logits via .materialize().
+FUSE_HEAD_DICE = os.environ.get('DA_FUSE_HEAD_DICE', '1') != '0'
+
+
+def head_dice_supported(cin, n_classes):
+    return cin in (16, 64) and n_classes in (16, 32)
+
+
+class LazyLogits(object):
+    """The segmentation head's output before anyone has asked for it: (input tensor or LazyAct, weight, bias)."""
+    __slots__ = ('x', 'weight', 'bias', '_logits')
+
+    def __init__(self, x, weight, bias):
+        self.x, self.weight, self.bias, self._logits = x, weight, bias, None
+
+    @property
+    def shape(self):
+        xs = self.x.shape
+        return torch.Size((xs[0], self.weight.shape[0]) + tuple(xs[2:]))
+
+    def materialize(self):
+        if self._logits is None:
+            if isinstance(self.x, LazyAct):
+                self._logits = Conv1x1Fn.apply(self.x.raw, self.weight, self.bias, (self.x.scale, self.x.shift, self.x.slope))
+            else:
+                self._logits = Conv1x1Fn.apply(self.x, self.weight, self.bias)
+        return self._logits
+
+    def detach(self):
+        return self.materialize().detach()
+
+
+def materialize_logits(x):
+    return x.materialize() if isinstance(x, LazyLogits) else x
+
+
+class HeadDiceFn(Function):
+    """Dice(softmax(conv1x1(x)), labels) as one node (da_head_dice_fwd / _bwd): the logits are never written; the backward pass
+    recomputes them from x and produces dx, dW, db directly."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels, weight_type, no_bg, eps, *extra):
+        pro = extra[0] if extra else None            # (scale, shift, slope) still to be applied to x (LazyAct input)
+        ctx.n_extra = len(extra)
+        a = ndhwc(x)
+        N, D, H, W, Cin = a.shape
+        C = weight.shape[0]
+        V = D * H * W
+        st = stream()
+        lab, lb = _labels(labels.reshape(N, -1))
+        if lab.shape[1] != V:
+            raise ValueError('label map and input must cover the same volume')
+        w_io = _empty((Cin, C), a)
+        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_io), C, Cin, 1, st)
+        b = bias.detach().contiguous() if bias is not None else None
+        loss = _empty((1,), a)
+        coef = _empty((2, N, C), a)
+        wsb = nat.lib().da_head_dice_ws_bytes(N, V, Cin, C)
+        wp, wn = _ws(wsb, a)
+        ps, pt, sl = _pro_args(pro)
+        call('da_head_dice_fwd', ptr(a), ps, pt, sl, ptr(w_io), ptr(b), ptr(lab), lb, N, V, Cin, C, _WEIGHT_TYPES[weight_type], 1 if no_bg else 0,
+             float(eps), ptr(loss), ptr(coef), wp, wn, st)
+        ctx.cfg = (N, V, Cin, C, lb, wsb, pro[2] if pro is not None else -1.0, bias is not None)
+        ctx.save_for_backward(a, w_io, b, lab, coef, pro[0] if pro is not None else None, pro[1] if pro is not None else None)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        a, w_io, b, lab, coef, ps, pt = ctx.saved_tensors
+        N, V, Cin, C, lb, wsb, sl, has_bias = ctx.cfg
+        st = stream()
+        gl = gloss.detach().reshape(1).to(torch.float32).contiguous()
+        dx = torch.empty_like(a)
+        dw_io = torch.empty_like(w_io)
+        db = _empty((C,), a) if has_bias else None
+        wp, wn = _ws(wsb, a)
+        call('da_head_dice_bwd', ptr(a), ptr(ps), ptr(pt), float(sl), ptr(w_io), ptr(b), ptr(lab), lb, ptr(coef), ptr(gl),
+             ptr(dx), ptr(dw_io), ptr(db), N, V, Cin, C, wp, wn, st)
+        dw = _empty((C, Cin, 1, 1, 1), a)
+        call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), C, Cin, 1, st)
+        return (ncdhw(dx), dw, db, None, None, None, None) + (None,) * ctx.n_extra
+
+
 def fused_anatomy_supported(n_classes):
     """The fused anatomy-loss kernels take class counts whose 4-channel lane groups are a power of two (4, 8, 16, 32, 64)."""
     q = n_classes // 4

@@ -269,6 +269,22 @@ int da_softmax_bwd(const float* dy, const float* y, float* dx, long long M, int 
 /* lib/transforms.py:675-689 mask_to_one_hot: labels[N][V] -> out[N][V][C] float */
 int da_one_hot(const void* labels, int label_bytes, float* out, long long M, int C, void* stream);
 
+/* ---- fused segmentation head + softmax + Dice (rows a5 + a11: unets.py:249-250 followed by lib/loss.py:410-476 with softmax=True and
+ *      an index target).  loss = Dice(softmax(x W + b), labels) WITHOUT writing the logits: the 16 -> 32 head is recomputed in the
+ *      backward pass, which turns Dice's gradient straight into dx, dW and db.  x [N][V][Cin] channels-last; w_io [Cin][C];
+ *      pro_scale / pro_shift (may be NULL) + pro_slope: BatchNorm + activation of the producer still to be applied to x (as in
+ *      da_conv1x1_fwd_pro); coef [2][N][C] as da_dice_fwd.  Shapes: Cin in {16, 64}, C in {16, 32}; others -> DA_ERR_UNSUPPORTED
+ *      (callers then run da_conv1x1_* + da_dice_*).  dx is the gradient with respect to the ACTIVATED input. */
+size_t da_head_dice_ws_bytes(int N, long long V, int Cin, int C);
+int da_head_dice_fwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                     const float* w_io, const float* bias, const void* labels, int label_bytes,
+                     int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
+                     float* loss, float* coef, void* ws, size_t ws_bytes, void* stream);
+int da_head_dice_bwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                     const float* w_io, const float* bias, const void* labels, int label_bytes,
+                     const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
+                     int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- NCC loss (row a12; lib/loss.py:493-501) -------------------------------------------------- */
 size_t da_ncc_ws_bytes(int N, long long V);
 int da_ncc_fwd(const float* x, const float* y, int N, long long V, float* loss, double* stats /*[N][8]*/,

@@ -993,3 +993,60 @@ def test_conv3d_forked_output_sums_its_two_gradients_in_the_activation_backward(
     ((ya * cl(ga)).sum() + (yb * cl(gb)).sum()).backward()
     check(ya, yr, what='fwd'); check(xg1.grad, xr1.grad, what='dgrad1'); check(xg2.grad, xr2.grad, what='dgrad2')
     check(wg.grad, wr.grad, what='wgrad'); check(bg.grad, br.grad, what='bgrad')
+
+
+@pytest.mark.parametrize('Cin,C,N,dims,pro,wt,no_bg', [(16, 32, 2, (5, 7, 9), False, 'Uniform', False), (16, 32, 1, (8, 8, 16), True, 'Simple', True),
+                                                        (16, 16, 1, (3, 5, 7), True, 'Volume', False), (64, 32, 1, (4, 6, 5), False, 'Uniform', False),
+                                                        (64, 16, 2, (2, 3, 5), True, 'Uniform', True)])
+def test_fused_head_softmax_dice_vs_torch_cpu(Cin, C, N, dims, pro, wt, no_bg):
+    """da_head_dice_fwd / _bwd (the 1x1x1 head, softmax and Dice without the logits tensor) against torch-CPU's conv3d + the oracle's
+    DiceLossMultiClass restatement: loss, dx, dW, db; ragged voxel counts (not a multiple of the 256-voxel workgroup chunk), batch 2,
+    int64 and uint8 labels, every weighting, with and without a deferred BatchNorm + LeakyReLU on the input."""
+    from oracle import losses
+    from deepatlas_amd import ops
+    D, H, W = dims
+    x, w, b = rnd((N, Cin, D, H, W), 1, 2.0), rnd((C, Cin, 1, 1, 1), 2, 0.5), rnd((C,), 3, 0.2)
+    y = torch.randint(0, C, (N, D, H, W), generator=torch.Generator().manual_seed(4))
+    sc, sh = torch.rand(Cin, generator=torch.Generator().manual_seed(5)) + 0.5, torch.rand(Cin, generator=torch.Generator().manual_seed(6)) - 0.5
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = F.leaky_relu(xr * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1), 0.01) if pro else xr
+    xin.retain_grad()
+    lr_ = losses.dice_loss(F.conv3d(xin, wr, br), y, C, weight_type=wt, no_bg=no_bg, softmax=True, eps=1e-6)
+    lr_.backward()
+    for labels in (y.to(dev()), y.to(torch.uint8).to(dev())):
+        xg, wg, bg = cl(x).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+        if pro:
+            lg = ops.HeadDiceFn.apply(xg, wg, bg, labels, wt, no_bg, 1e-6, (sc.to(dev()), sh.to(dev()), 0.01))
+        else:
+            lg = ops.HeadDiceFn.apply(xg, wg, bg, labels, wt, no_bg, 1e-6)
+        lg.backward()
+        assert abs(lg.item() - lr_.item()) < 1e-5, (lg.item(), lr_.item())
+        check(xg.grad, xin.grad, what='dx (wrt the activated input)')
+        check(wg.grad, wr.grad, what='dW'); check(bg.grad, br.grad, what='db')
+
+
+def test_fused_head_softmax_dice_full_size_matches_composition():
+    """At 2 x 160 x 192 x 160, 16 -> 32: the fused kernels against the op-by-op composition they replace (Conv1x1Fn + DiceFn), loss and
+    strided samples of dx / dW / db -- exercises the > 4 GiB-per-tensor addressing (the logits they never build would be 1.26 GB)."""
+    from deepatlas_amd import ops
+    from deepatlas_amd.lib.datasets import synthetic_batch_on_device
+    d = dev()
+    shape, C, Cin, N = (160, 192, 160), 32, 16, 2
+    _, lab = synthetic_batch_on_device(N, shape, C, seed=9, device=d, structured=True)
+    g = torch.Generator(device=d).manual_seed(10)
+    x = torch.empty((N,) + shape + (Cin,), device=d).uniform_(-2, 2, generator=g).permute(0, 4, 1, 2, 3)
+    w = (torch.rand((C, Cin, 1, 1, 1), generator=torch.Generator().manual_seed(11)) - 0.5).to(d)
+    b = (torch.rand((C,), generator=torch.Generator().manual_seed(12)) - 0.5).to(d)
+    res = []
+    for fused in (False, True):
+        xg, wg, bg = x.detach().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        if fused:
+            loss = ops.HeadDiceFn.apply(xg, wg, bg, lab, 'Uniform', False, 1e-6)
+        else:
+            loss = ops.DiceFn.apply(ops.Conv1x1Fn.apply(xg, wg, bg), lab, None, 'Uniform', False, True, 1e-6)
+        loss.backward()
+        res.append((loss.item(), xg.grad.reshape(-1)[::1009].cpu().numpy(), wg.grad.cpu().numpy(), bg.grad.cpu().numpy()))
+        del xg, loss
+    assert abs(res[0][0] - res[1][0]) < 1e-6
+    for k, what in ((1, 'dx'), (2, 'dW'), (3, 'db')):
+        assert rel_l2(res[1][k], res[0][k]) < 1e-4, (what, rel_l2(res[1][k], res[0][k]))
