@@ -145,14 +145,29 @@ def make_workloads(args, dev, rank, which):
     from deepatlas_amd.lib.datasets import synthetic_batch_on_device
     x, y = synthetic_batch_on_device(args.batch, shape, n_classes, seed=230 + rank, device=dev)
 
-    def seg_step():
+    def seg_grads():
         opt.zero_grad()
         out = model(x)
         loss = crit(out, y)
         loss.backward()
+        return dict(loss=loss.detach())
+
+    def seg_step():
+        loss = seg_grads()['loss']
         parallel.allreduce_gradients(opt)
         opt.step()
         return loss
+
+    def graphed(segments, between, optimizers, key):
+        """--graph: the step captured once as HIP graph(s) and replayed (deepatlas_amd/graphs.py); collectives stay outside the graphs"""
+        from deepatlas_amd.graphs import GraphedStep
+        g = GraphedStep(segments, optimizers, between=between, warmup=2)
+        for _ in range(4):          # 2 eager steps, capture + first replay, one more replay: all before any timed region
+            g()
+        return lambda: g()[key]
+
+    if args.graph:
+        seg_step = graphed([seg_grads, lambda: opt.step()], [lambda: parallel.allreduce_gradients(opt)], [opt], 'loss')
 
     prec = 'fp32' if args.precision == 'fp32' else 'bf16 matrix mode'
     out = {}
@@ -177,13 +192,15 @@ def make_workloads(args, dev, rank, which):
         im_m, im_t, sm, st_ = x[:1], x2, y[:1], y2
         if 'reg' in which:
             rstep = RegistrationStep(reg, ropt)
+            reg_fn = (lambda: rstep(im_m, im_t)[0]) if not args.graph else graphed(*rstep.segments(im_m, im_t), 'loss')
             out['reg'] = Workload('reg-only VoxelMorph + trilinear warp + NCC + bending + Adam, 1 pair/GPU, %dx%dx%d %s (BASELINE configs[2])'
-                                  % (shape + (prec,)), lambda: rstep(im_m, im_t)[0], 1, 'pairs/s', REG_TRAIN_FLOP_PER_VOXEL * V, lambda r: r)
+                                  % (shape + (prec,)), reg_fn, 1, 'pairs/s', REG_TRAIN_FLOP_PER_VOXEL * V, lambda r: r)
         if 'joint' in which:
             jstep = DeepAtlasJointStep(model, opt, reg, ropt, n_classes)
+            joint_fn = (lambda: jstep(im_m, im_t, sm, st_)['loss_seg']) if not args.graph else graphed(*jstep.segments(im_m, im_t, sm, st_), 'loss_seg')
             out['joint'] = Workload('joint DeepAtlas alternating step (reg phase + seg phase, 32-ch seg warp), 1 pair/GPU, %dx%dx%d %s '
                                     '(BASELINE configs[3] per-GPU shape)' % (shape + (prec,)),
-                                    lambda: jstep(im_m, im_t, sm, st_)['loss_seg'], 1, 'pairs/s',
+                                    joint_fn, 1, 'pairs/s',
                                     (SEG_TRAIN_FLOP_PER_VOXEL + REG_TRAIN_FLOP_PER_VOXEL) * V if args.net == 'UNet_light' else None, lambda r: r)
     return out, n_classes
 
@@ -291,6 +308,8 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="matrix arithmetic of the 3x3x3 convolutions: 'fp32' = the reference's arithmetic (the headline metric); 'bf16' = "
                          "bf16 operands, fp32 accumulate (BASELINE configs[4]'s mixed precision; not the headline)")
+    ap.add_argument('--graph', action='store_true', help='capture each step once as HIP graph(s) and replay it (one host call per step; per-call '
+                    'HIP-event timing is then taken in the eager post-run pass only)')
     ap.add_argument('--no-fused-head', action='store_true', help='run the 1x1x1 head, softmax and Dice as separate kernels (logits materialised)')
     ap.add_argument('--sync-wgrad', action='store_true', help='weight gradients on the main stream (default: side stream, overlapped with the HBM-bound backward kernels)')
     ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
@@ -334,7 +353,7 @@ def main():
     # gradients on a second stream (ops.ASYNC_WGRAD): timing events recorded there serialise it against the main stream and
     # overlapping kernels time each other's slowdown, so backward kernels are timed in a separate short pass after the timed region.
     head = wls[args.workload]
-    dt, per_rank, final_loss, prof, launches = time_workload(head, args, world, dev, None if args.no_profile else CONV_FWD_CALLS)
+    dt, per_rank, final_loss, prof, launches = time_workload(head, args, world, dev, None if (args.no_profile or args.graph) else CONV_FWD_CALLS)
     head_res = result_of(head, dt, per_rank, world, args, launches)
 
     bwd_rows = []
@@ -406,7 +425,7 @@ def main():
                     dtype='f32' if args.precision == 'fp32' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
                     config=dict(workload=head.name, global_batch=world * head.units, volume=list(shape), n_classes=n_classes,
                                 parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision,
-                                c_abi_launches_per_step=head_res['c_abi_launches_per_step'], rccl=rccl,
+                                c_abi_launches_per_step=head_res['c_abi_launches_per_step'], hip_graph=bool(args.graph), rccl=rccl,
                                 ms_per_step_per_rank=head_res.get('ms_per_step_per_rank')),
                     roofline=roofline, extra=extra or None)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'seg':

@@ -116,6 +116,8 @@ SIGNATURES = {
     'da_gradloss_fwd': (I, [P, I, I, I, I, P, I, I, P, P, SZ, P]),
     'da_gradloss_bwd': (I, [P, P, P, I, I, I, I, P, I, I, P]),
     'da_adam_step': (I, [P, P, P, P, LL, F, F, F, F, I, F, P]),
+    'da_adam_host_state': (I, [F, F, F, F, I, F, P]),
+    'da_adam_step_dev': (I, [P, P, P, P, LL, P, P]),
 }
 
 _lib = None
@@ -216,15 +218,25 @@ def require_cuda(*tensors):
 
 
 class _Workspace:
-    """One growing scratch buffer per device and stream; kernels on one stream are ordered, so it is shared by all ops on it."""
+    """One growing scratch buffer per device and stream; kernels on one stream are ordered, so it is shared by all ops on it.
+    While a HIP graph is being captured (graphs.GraphedStep sets `capture_tag`) the buffers are separate ones, allocated INSIDE the
+    capture: they live in that graph's private memory pool and are kept for as long as the process runs, so a replay never finds its
+    scratch reallocated or released by someone else's larger request (or by the empty_cache() of a later capture)."""
 
     def __init__(self):
         self.buf = {}
+        self.capture_tag = None
 
     def get(self, nbytes, device):
         nbytes = int(nbytes) + 256
         # one buffer per (device, stream): kernels on one stream are ordered, kernels on different streams are not
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        if self.capture_tag is not None and torch.cuda.is_current_stream_capturing():
+            key = key + (self.capture_tag, len([k for k in self.buf if k[:3] == key and len(k) == 5 and k[3] == self.capture_tag]))
+            # (a larger request during the same capture gets ANOTHER buffer; the earlier one stays referenced by the nodes already captured)
+            for k, b in self.buf.items():
+                if len(k) == 5 and k[:4] == key[:4] and b.numel() >= nbytes:
+                    return c_void_p(b.data_ptr()), c_size_t(b.numel())
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

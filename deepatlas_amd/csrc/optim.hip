@@ -5,16 +5,33 @@
 
 namespace {
 
+// one element of the update; contraction off so that the two kernels below (scalars as launch arguments / scalars from device memory)
+// round identically whatever the compiler would otherwise fuse
+__device__ __forceinline__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                            long long i, float lr_over_bc1, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+#pragma clang fp contract(off)
+    const float gi = g[i] * gscale;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;       // sqrt(v)/sqrt(bc2) + eps
+    p[i] = p[i] - lr_over_bc1 * (mi / denom);
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long long n, float lr_over_bc1, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;       // sqrt(v)/sqrt(bc2) + eps
-        p[i] = p[i] - lr_over_bc1 * (mi / denom);
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        adam_update(p, g, m, v, i, lr_over_bc1, beta1, beta2, eps, inv_sqrt_bc2, gscale);
+}
+
+// The same update with every per-step scalar read from DEVICE memory, so that the launch can sit in a captured HIP graph and be
+// replayed: state6 = {lr / bc1, beta1, beta2, eps, 1 / sqrt(bc2), grad_scale}, computed on the HOST for the step about to run with exactly
+// the expressions of da_adam_step (bit-identical updates) and copied over before each replay.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long long n, const float* __restrict__ state) {
+    const float lr_over_bc1 = state[0], beta1 = state[1], beta2 = state[2], eps = state[3], inv_sqrt_bc2 = state[4], gscale = state[5];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        adam_update(p, g, m, v, i, lr_over_bc1, beta1, beta2, eps, inv_sqrt_bc2, gscale);
 }
 
 // generic 3-axis permutation of a [A][B][K] tensor into [K][P][Q]; mode selects which of (A,B) is Cin
@@ -99,6 +116,22 @@ extern "C" int da_adam_step(float* p, const float* g, float* m, float* v, long l
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(da_grid(n, 256)), dim3(256), 0, da_stream(stream), p, g, m, v, n,
                        (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_adam_host_state(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* state6_host) {
+    if (!state6_host || step < 1) return DA_ERR_BADARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    state6_host[0] = (float)((double)lr / bc1); state6_host[1] = beta1; state6_host[2] = beta2; state6_host[3] = eps;
+    state6_host[4] = (float)(1.0 / sqrt(bc2)); state6_host[5] = grad_scale;
+    return 0;
+}
+
+extern "C" int da_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float* state6, void* stream) {
+    if (!p || !g || !m || !v || !state6 || n <= 0) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(da_grid(n, 256)), dim3(256), 0, da_stream(stream), p, g, m, v, n, (const float*)state6);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -24,7 +24,8 @@ class RegistrationStep:
         self.model, self.opt, self.lam_reg = reg_model, optimizer, lam_reg
         self.ncc, self.bend = NormalizedCrossCorrelationLoss(), BendingEnergyLoss()
 
-    def __call__(self, source, target):
+    def gradients(self, source, target):
+        """zero_grad -> forward -> losses -> backward (device work only: capturable in a HIP graph, graphs.GraphedStep)."""
         self.model.train()
         self.opt.zero_grad()
         disp, warped, deform = self.model(source, target)
@@ -32,9 +33,18 @@ class RegistrationStep:
         l_reg = self.bend(disp)
         loss = l_sim + self.lam_reg * l_reg
         loss.backward()
+        return dict(loss=loss.detach(), disp=disp.detach(), warped=warped.detach(), deform=deform.detach(), sim=l_sim.detach(), bend=l_reg.detach())
+
+    def segments(self, source, target):
+        """(segments, between, optimizers) for graphs.GraphedStep: the gradient all-reduce sits between the two segments."""
+        return ([lambda: self.gradients(source, target), lambda: self.opt.step()],
+                [lambda: parallel.allreduce_gradients(self.opt)], [self.opt])
+
+    def __call__(self, source, target):
+        r = self.gradients(source, target)
         parallel.allreduce_gradients(self.opt)
         self.opt.step()
-        return loss.detach(), (disp.detach(), warped.detach(), deform.detach()), (l_sim.detach(), l_reg.detach())
+        return r['loss'], (r['disp'], r['warped'], r['deform']), (r['sim'], r['bend'])
 
 
 class DeepAtlasJointStep:
@@ -51,10 +61,38 @@ class DeepAtlasJointStep:
         self.dice_prob = DiceLossMultiClass(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)
 
     def __call__(self, im_m, im_t, seg_m, seg_t):
+        r = self.reg_gradients(im_m, im_t, seg_m, seg_t)
+        parallel.allreduce_gradients(self.reg_opt)
+        self.reg_opt.step()
+        s = self.seg_gradients(im_m, seg_m, seg_t, r['disp'])
+        parallel.allreduce_gradients(self.seg_opt)
+        self.seg_opt.step()
+        r.pop('disp')
+        r.update(s)
+        return r
+
+    def segments(self, im_m, im_t, seg_m, seg_t):
+        """(segments, between, optimizers) for graphs.GraphedStep: reg gradients | reg update + seg gradients | seg update, with the
+        two flat-bucket all-reduces in the gaps."""
+        st = {}
+
+        def first():
+            st.update(self.reg_gradients(im_m, im_t, seg_m, seg_t))
+            return {k: v for k, v in st.items() if k != 'disp'}
+
+        def second():
+            self.reg_opt.step()
+            return self.seg_gradients(im_m, seg_m, seg_t, st['disp'])
+
+        return ([first, second, lambda: self.seg_opt.step()],
+                [lambda: parallel.allreduce_gradients(self.reg_opt), lambda: parallel.allreduce_gradients(self.seg_opt)],
+                [self.reg_opt, self.seg_opt])
+
+    def reg_gradients(self, im_m, im_t, seg_m, seg_t):
+        """registration phase up to its gradients (segmentation net frozen)."""
         lam = self.lam
         # Dice against one-hot(seg_t): the fused kernel takes the index mask directly (t in {0,1} either way), so the target
         # one-hot is never materialised
-        # ---- registration phase (segmentation net not involved: the moving segmentation is given)
         self.reg.train()
         self.reg_opt.zero_grad()
         if seg_m is None:
@@ -76,10 +114,12 @@ class DeepAtlasJointStep:
             l_anat = self.dice_prob(warped_seg, seg_t)
         loss_r = lam['sim'] * l_sim + lam['reg'] * l_reg + lam['anat'] * l_anat
         loss_r.backward()
-        parallel.allreduce_gradients(self.reg_opt)
-        self.reg_opt.step()
-        disp = disp.detach()
-        # ---- segmentation phase (deformation fixed)
+        return dict(loss_reg=loss_r.detach(), sim=l_sim.detach(), bend=l_reg.detach(), anat_reg=l_anat.detach(), disp=disp.detach())
+
+    def seg_gradients(self, im_m, seg_m, seg_t, disp):
+        """segmentation phase up to its gradients (deformation fixed)."""
+        lam = self.lam
+        fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
         self.seg.train()
         self.seg_opt.zero_grad()
         logits = ops.materialize_logits(self.seg(im_m))
@@ -94,7 +134,4 @@ class DeepAtlasJointStep:
             l_anat2 = self.dice_prob(warped_prob, seg_t)
         loss_s = lam['sp'] * l_sp + lam['anat'] * l_anat2
         loss_s.backward()
-        parallel.allreduce_gradients(self.seg_opt)
-        self.seg_opt.step()
-        return dict(loss_reg=loss_r.detach(), loss_seg=loss_s.detach(), sim=l_sim.detach(), bend=l_reg.detach(),
-                    anat_reg=l_anat.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach())
+        return dict(loss_seg=loss_s.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach())

@@ -94,17 +94,25 @@ def enable_async_wgrad(flag=True):
 
 
 def side_stream():
-    global _side_stream
+    """The second HIP stream; every caller is about to queue work on it."""
+    global _side_stream, _side_dirty
     if _side_stream is None:
         _side_stream = torch.cuda.Stream()
+    _side_dirty = True
     return _side_stream
 
 
+_side_dirty = False      # work has been queued on the side stream since the last join
+
+
 def join_side_stream():
-    """Make the current stream wait for every weight gradient issued on the side stream."""
-    if _side_stream is not None:
+    """Make the current stream wait for every weight gradient issued on the side stream.  Nothing outstanding -> no stream
+    dependency at all (inside a HIP-graph capture a wait on work from before the capture would be illegal)."""
+    global _side_dirty
+    if _side_stream is not None and (_side_dirty or _side_keep):
         torch.cuda.current_stream().wait_stream(_side_stream)
-        _side_keep.clear()
+    _side_keep.clear()
+    _side_dirty = False
 
 
 _last_side_flops = 0.0          # FLOPs of the weight gradient most recently queued on the side stream
@@ -120,7 +128,7 @@ def _serialize_matrix_kernels(flops, voxels):
     38.7 to 40.9 ms -- so the schedule is pinned instead of left to chance: 39.05 ms in either case.  The rule is deliberately
     narrow: on coarse, few-tile layers (all of the full UNet below full resolution) overlapping MFMA kernels fill each other's
     tails and waiting costs 10 % (268 vs 300 ms per step), and equally long kernels are left to overlap too."""
-    if (ASYNC_WGRAD and _side_stream is not None and flops >= _SERIALIZE_MIN_FLOPS and voxels >= _SERIALIZE_MIN_VOXELS
+    if (ASYNC_WGRAD and _side_stream is not None and _side_dirty and flops >= _SERIALIZE_MIN_FLOPS and voxels >= _SERIALIZE_MIN_VOXELS
             and _last_side_flops <= _SERIALIZE_MAX_RATIO * flops):
         torch.cuda.current_stream().wait_stream(_side_stream)
 

@@ -35,6 +35,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         ops.register_flat_bucket(self.flat_g)
+        # device copy of this step's scalars for the graph-capturable update (da_adam_step_dev): refreshed before every replay
+        self._dev_state = torch.zeros(6, dtype=torch.float32, device=dev)
+        self.device_step = False          # True inside a captured step: step() launches da_adam_step_dev
         self._steps = 0
         self._slices = []
         off = 0
@@ -48,6 +51,23 @@ class FlatAdam(torch.optim.Optimizer):
                              'exp_avg_sq': self.flat_v[off:off + k].view(p.shape)}
             self._slices.append((p, off, k))
             off += k
+
+    def sync_device_state(self, grad_scale=1.0):
+        """Host -> device copy of the scalars of the step about to run ({lr / bc1, betas, eps, 1 / sqrt(bc2), grad_scale}, from
+        da_adam_host_state) ahead of a graph replay.  One 24-byte copy; lr schedulers keep working because lr is re-read every step."""
+        import ctypes
+        g = self.param_groups[0]
+        host = (ctypes.c_float * 6)()
+        nat.call('da_adam_host_state', float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self._steps + 1,
+                 float(grad_scale), ctypes.cast(host, ctypes.c_void_p))
+        self._dev_state.copy_(torch.tensor(list(host), dtype=torch.float32))
+
+    def note_replayed_step(self):
+        """Book-keeping of a step that ran inside a replayed graph (the host-side part of step())."""
+        self._steps += 1
+        for p, _, _ in self._slices:
+            if p.requires_grad:
+                self.state[p]['step'] += 1
 
     def _set_step_count(self, n):
         self._steps = int(n)
@@ -97,6 +117,14 @@ class FlatAdam(torch.optim.Optimizer):
                 raise RuntimeError('FlatAdam: a parameter no longer lives in the flat bucket (model.to()/.half() after constructing the '
                                    'optimiser?); build the optimiser after moving the model')
         mask = self._frozen_mask()
+        if self.device_step:
+            # being captured into a HIP graph (graphs.GraphedStep): step count and hyper-parameters come from device memory; the
+            # host-side book-keeping happens per REPLAY in note_replayed_step()
+            if mask is not None:
+                raise NotImplementedError('FlatAdam: frozen parameters are not supported inside a captured step')
+            call('da_adam_step_dev', ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), self.flat_p.numel(),
+                 ptr(self._dev_state), stream())
+            return loss
         if mask is not None:                        # frozen slices: keep p, m, v exactly as they are
             keep = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone())
         self._steps += 1

@@ -379,6 +379,12 @@ int da_label_overlap_counts(const void* pred, int pred_bytes, const void* truth,
 int da_adam_step(float* p, const float* g, float* m, float* v, long long n,
                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* the same update with its per-step scalars in DEVICE memory -- state6 = {lr / bc1, beta1, beta2, eps, 1 / sqrt(bc2), grad_scale} -- so
+ * that the launch can be captured in a HIP graph and replayed (deepatlas_amd/graphs.py); da_adam_host_state fills a HOST array with
+ * those six values for step `step`, using da_adam_step's own expressions (the two paths update bit-identically). */
+int da_adam_host_state(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* state6_host);
+int da_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float* state6, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

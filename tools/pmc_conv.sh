@@ -16,4 +16,12 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCL
 f=$(ls $O/$c/*/*counter_collection.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" $O/conv3d_48to16_$c.csv; fi
 rm -rf $O/$c
+# fourth pass: FETCH_SIZE calibration on known byte counts in the conv kernels' own request shapes (tools/ubench/fetch_calib.hip)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/ubench/fetch_calib.hip -o /tmp/fetch_calib > $O/calib_build.log 2>&1
+c=CALIB
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$c -- /tmp/fetch_calib > $O/$c.log 2>&1 < /dev/null
+f=$(ls $O/$c/*/*counter_collection.csv 2>/dev/null | head -1)
+if [ -n "$f" ]; then cp "$f" $O/fetch_calib_FETCH_SIZE.csv; fi
+rm -rf $O/$c
+git rev-parse --short HEAD > $O/commit.txt 2>/dev/null || true
 ls -la $O

@@ -4,10 +4,11 @@ MI355X_MICROARCH.md prescribes) into profiles/rNN_pmc_traffic.json: HBM-side byt
 dominant layer, keyed by the C-ABI call signature bench.py reports as `roofline.kernel`.
 
 Units / corrections: rocprofv3 reports both counters in KiB.  WRITE_SIZE of the forward kernel equals the algorithmic output
-(N*V*Cout*4 B = 614400 KiB) exactly, so no write correction.  The gfx950 "FETCH_SIZE reports half" artefact applies to
-128-byte requests; these kernels stage 64-byte runs (one voxel's 16-channel chunk per 4 lanes), and doubling would exceed the
-bytes the kernel requests from L2 in total, so FETCH_SIZE is taken as is.
-Usage: python tools/pmc_summary.py gpurun_out/pmc profiles r01"""
+(N*V*Cout*4 B = 614400 KiB) exactly, so no write correction.  FETCH_SIZE is CALIBRATED (MI355X_MICROARCH.md: gfx950 reports half the
+bytes of a wide coalesced streaming read; other widths uncalibrated): tools/ubench/fetch_calib.hip streams 1 GiB once in the two request
+shapes of the halo staging (contiguous 16 B / lane; 64-byte runs at a 128-byte stride) under the same counter, and the measured
+requested-bytes / FETCH_SIZE factors are applied to the conv kernels' raw FETCH_SIZE in proportion to the bytes each shape stages.
+Usage: python tools/pmc_summary.py gpurun_out/pmc profiles r02"""
 import collections
 import csv
 import json
@@ -31,24 +32,57 @@ def main():
         for k, v in agg.items():
             v = v[1:] if len(v) > 1 else v          # first launch includes cold allocation effects
             per.setdefault(k, {})[c] = sum(v) / len(v)
-    sig = {'conv3_mfma_fwd_kernel<16, 1, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-           'conv3_mfma_fwd_kernel<16, 1, false, true>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-           'conv3_mfma_fwd_kernel<16, 3, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-           'conv3_mfma_wgrad_kernel<16, 1, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+    # kernel template instantiations at HEAD: fwd <CK, NREP, MASKED, STATS, BF, PRO, DYN>, wgrad <CK, NREP, YS, MASKED, BF, PRO>
+    sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+           'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+           'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+           'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     vox = 2 * 160 * 192 * 160
     alg = {'fwd': vox * (48 + 16) * 4, 'dgrad': vox * (16 + 48) * 4, 'wgrad': vox * (48 + 16) * 4 + 27 * 48 * 16 * 4}
     res = {'unit': 'bytes per launch', 'counters': 'FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, KiB -> bytes)',
            'layer': '3x3x3 conv 48(=32+16 concat) -> 16, batch 2, 160x192x160 fp32', 'calls': {}}
+    commit = '?'
+    try:
+        commit = open(os.path.join(src, 'commit.txt')).read().strip() or '?'
+    except OSError:
+        pass
+    res['commit'] = commit
+    # calibration (tools/ubench/fetch_calib.hip): requested bytes / FETCH_SIZE for the two request shapes of the halo staging
+    calib = {}
+    fc = os.path.join(src, 'fetch_calib_FETCH_SIZE.csv')
+    if os.path.isfile(fc):
+        shutil.copyfile(fc, os.path.join(dst, '%s_fetch_calib_pmc_fetch_size.csv' % tag))
+        want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 29)}
+        got = collections.defaultdict(list)
+        for r in csv.DictReader(open(fc)):
+            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            if k in want:
+                got[k].append(float(r['Counter_Value']) * 1024.0)
+        for k, v in got.items():
+            v = v[1:] if len(v) > 1 else v
+            m = sum(v) / len(v)
+            calib[k] = {'requested_bytes': want[k], 'fetch_size_bytes': m, 'requested_over_fetch_size': want[k] / m if m else None}
+    res['fetch_size_calibration'] = calib
     for k, name in sig.items():
-        kk = k[:-1] + ', false, false>'
-        if kk in per:
-            per[k] = per[kk]
         if k not in per:
             continue
         f, w = per[k].get('FETCH_SIZE', 0.0), per[k].get('WRITE_SIZE', 0.0)
         a = alg[name.split('_')[3].split('[')[0]]            # 'fwd' also for da_conv3d_k3_fwd_bnstats
-        res['calls'][name] = {'kernel': k, 'fetch_bytes': f, 'write_bytes': w, 'traffic_bytes': f + w,
-                              'algorithmic_bytes': a, 'traffic_over_algorithmic': (f + w) / a}
+        # corrected fetch: the forward / weight-gradient kernels stage in1 (32-channel tensor: 64-B runs at a 128-B stride, "half" shape)
+        # and in2 (16-channel tensor: contiguous, "contig" shape); the data gradient stages dy (16 channels: contiguous)
+        fc_contig = (calib.get('stream_b128_contig') or {}).get('requested_over_fetch_size') or 1.0
+        fc_half = (calib.get('stream_b128_half') or {}).get('requested_over_fetch_size') or 1.0
+        # bytes staged per shape (in units of one 16-channel tensor): forward: in1 = 2 half-shape, in2 = 1 contiguous; weight gradient: the
+        # same + dy = 1 contiguous; data gradient: dy = 1 contiguous.  raw = sum_s actual_s / factor_s with equal over-fetch ratios, so
+        # actual = raw * sum_s B_s / sum_s (B_s / factor_s)
+        b_half, b_contig = (0.0, 1.0) if 'dgrad' in name else ((2.0, 2.0) if 'wgrad' in name else (2.0, 1.0))
+        share_half = b_half / (b_half + b_contig)
+        fcorr = f * (b_half + b_contig) / (b_half / fc_half + b_contig / fc_contig)
+        res['calls'][name] = {'kernel': k, 'fetch_bytes_raw': f, 'fetch_bytes': fcorr, 'write_bytes': w, 'traffic_bytes': fcorr + w,
+                              'algorithmic_bytes': a, 'traffic_over_algorithmic': (fcorr + w) / a,
+                              'fetch_correction': 'raw FETCH_SIZE x %.4f: staged bytes are %.0f %% 64-B runs at a 128-B stride (calibration factor %.3f) and %.0f %% '
+                                                  'contiguous 16 B/lane (factor %.3f); raw = sum of actual / factor' % (fcorr / f if f else 0.0, 100 * share_half, fc_half,
+                                                                                                                   100 * (1 - share_half), fc_contig)}
     # third pass (SQ block): matrix-pipe occupancy.  SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x (wave-level v_mfma_f32_16x16x4_f32 count),
     # summed over the 1024 SIMDs; divided by SIMDs and kernel duration it is the rate at which a SIMD's matrix pipe is busy, to be
     # read against the shader clock (2.4 GHz peak; ~1.95-2.0 GHz sustained under this load, DA_CLK probe in DESIGN.md 4.1).
@@ -62,8 +96,7 @@ def main():
             if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
                 sq[k]['duration_ns'].append(float(int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
         for k, name in sig.items():
-            kk = k[:-1] + ', false, false>'                  # template arguments added since the map above was written (bf16, prologue)
-            v = sq.get(kk) or sq.get(k)
+            v = sq.get(k)
             if not v or name not in res['calls']:
                 continue
             m = {c: (sum(x[1:]) / len(x[1:]) if len(x) > 1 else x[0]) for c, x in v.items()}
