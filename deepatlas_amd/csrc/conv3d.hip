@@ -321,6 +321,17 @@ static bool force_direct() {
 }
 extern "C" int da_set_conv_direct(int on) { const int prev = force_direct() ? 1 : 0; g_force_direct = on ? 1 : 0; return prev; }
 
+// Coarse stride-2 layers (the registration encoder below 40^3) are latency-bound on the space-to-depth route (a chain of four launches,
+// 16 channel chunks per tile walked one after the other: 0.15 - 0.28 ms for 0.05 - 0.4 GFLOP).  Measured alternative: the direct
+// kernels are 2 - 8x SLOWER there (forward 0.33 vs 0.15 ms, data gradient 0.52 vs 0.05, weight gradient 0.58 vs 0.07 at 40^3 -> 20^3),
+// so the switch stays off: DA_S2_DIRECT_MAX_OUT_VOX = largest output-voxel count that takes the direct kernels (default 0 = never).
+static bool s2_prefers_direct(int N, int D, int H, int W) {
+    static long long thr = -1;
+    if (thr < 0) { const char* e = getenv("DA_S2_DIRECT_MAX_OUT_VOX"); thr = e ? atoll(e) : 0; }
+    const long long out = (long long)N * ((D - 1) / 2 + 1) * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    return out <= thr;
+}
+
 extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int C2,
                                 const float* w_tio, const float* bias, float* out,
                                 int N, int D, int H, int W, int Cout, int stride, float act_slope,
@@ -328,7 +339,7 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
     if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
         return DA_ERR_BADARG;
     hipStream_t st = da_stream(stream);
-    if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout)) {
+    if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout) && !s2_prefers_direct(N, D, H, W)) {
         if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
         return da_conv3_s2_fwd(in1, C1, w_tio, bias, out, N, D, H, W, Cout, act_slope, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
     }
@@ -431,7 +442,7 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
         DA_LAUNCH_CHECK();
         return da_conv3_direct_fwd(dy, Cout, nullptr, 0, wf, nullptr, dx1, C1, dx2, C2, N, D, H, W, Cin, 1, -1.f, st);
     }
-    if (!force_direct() && da_conv3_s2_supported(C1, C2, Cout))
+    if (!force_direct() && da_conv3_s2_supported(C1, C2, Cout) && !s2_prefers_direct(N, D, H, W))
         return da_conv3_s2_dgrad(dy, w_tio, dx1, C1, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
     const int Do = (D - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long nvox = (long long)N * D * H * W;
@@ -452,9 +463,9 @@ extern "C" int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, in
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const int O = 27 * Cin * Cout;
     int rc = 0;
-    if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout)) {
+    if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout) && !s2_prefers_direct(N, D, H, W)) {
         rc = da_conv3_s2_wgrad(in1, C1, dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
-    } else if (!force_direct() && da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) {
+    } else if (!force_direct() && stride == 1 && da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) {
         rc = da_conv3_mfma_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, st);
     } else {
         rc = DA_ERR_UNSUPPORTED;

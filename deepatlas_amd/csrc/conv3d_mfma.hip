@@ -462,27 +462,42 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const Frag* wch = reinterpret_cast<const Frag*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
             if (has_next && !(p.ablate & 1)) issue_stage(item + 1, pre);
             unsigned msk = p.masks[p.maskmode == 1 ? ch : (int)blockIdx.y];
-            while (msk) {
-                const int sidx = __builtin_ctz(msk); msk &= msk - 1;
+            // software-pipelined over the live taps: the fragments of the NEXT tap (weights from global / L2, eight A rows from LDS) are
+            // requested before the current tap's 32 * NREP MFMAs issue, so neither latency sits between two taps (the plain loop paid
+            // both per tap: a chunk has only 1 .. 8 taps, there is nothing else to hide them behind).
+            auto load_tap = [&](int sidx, Frag (&bb)[NREP], Frag (&aa)[TY]) {
                 const AElem* ap = abase + (((sidx / 9) * HY + (sidx / 3) % 3) * HX + sidx % 3) * CK;
-                Frag bb[NREP], aa[TY];
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) bb[nn] = wch[((size_t)sidx * p.NT + nn) * 64];
 #pragma unroll
                 for (int r = 0; r < TY; ++r) aa[r] = *reinterpret_cast<const Frag*>(ap + r * (HX * CK));
-                if constexpr (BF) {
+            };
+            if (msk) {
+                Frag bb[NREP], aa[TY];
+                { const int s0 = __builtin_ctz(msk); msk &= msk - 1; load_tap(s0, bb, aa); }
+                while (true) {
+                    const bool more = msk != 0;
+                    Frag bn[NREP], an[TY];
+                    if (more) { const int s1 = __builtin_ctz(msk); msk &= msk - 1; load_tap(s1, bn, an); }
+                    if constexpr (BF) {
 #pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn)
+                        for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                        for (int r = 0; r < TY; ++r) acc[r][nn] = mma_bf(acc[r][nn], aa[r], bb[nn]);
-                } else {
+                            for (int r = 0; r < TY; ++r) acc[r][nn] = mma_bf(acc[r][nn], aa[r], bb[nn]);
+                    } else {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn)
+                            for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                        for (int r = 0; r < TY; ++r)
-                            acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r][m], bb[nn][m], acc[r][nn], 0, 0, 0);
+                                for (int r = 0; r < TY; ++r)
+                                    acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r][m], bb[nn][m], acc[r][nn], 0, 0, 0);
+                    }
+                    if (!more) break;
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn) bb[nn] = bn[nn];
+#pragma unroll
+                    for (int r = 0; r < TY; ++r) aa[r] = an[r];
                 }
             }
         } else {
@@ -901,12 +916,25 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
     }
 
+    // MASKED (stride 2 through space-to-depth: a chunk is one input parity and only (1|2)^3 of the 27 taps are non-zero): the live taps
+    // are dealt round-robin to the waves -- slot k of wave w takes the (4k + w)-th live tap -- instead of the fixed tap = w + 4k, which
+    // leaves the 8-tap parity with 3 / 3 / 1 / 1 taps per wave (and the 4-tap ones with 2 / 1 / 1 / 0).
+    int slot_tap[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        if (MASKED && CK == 16) {
+            unsigned m = p.masks[ch] & 0x7FFFFFFu;
+            int want = 4 * k + wave, t = 27;
+            while (m) { const int b = __builtin_ctz(m); m &= m - 1; if (want-- == 0) { t = b; break; } }
+            slot_tap[k] = t;
+        } else slot_tap[k] = wave + 4 * k;
+    }
     // per-lane A offsets (floats) for this wave's tap slots
     int offA[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         int tap;
-        if (CK == 16) tap = wave + 4 * k; else tap = 2 * (wave + 4 * k) + (i >> 3);
+        if (CK == 16) tap = slot_tap[k]; else tap = 2 * (wave + 4 * k) + (i >> 3);
         if (BF && CK == 8) tap = 2 * (wave + 4 * k) + ((i & 3) >> 1);      // transpose-read source lane: channel quad i & 3 of the 16 (tap, ci) rows
         if (tap > 26) tap = 26;                               // garbage slot, never written out
         if (BF) offA[k] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK + ((CK == 16) ? (i & 3) * 4 : (i & 1) * 4);
@@ -920,9 +948,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     // sparse tap sets (stride-2 via space-to-depth): this wave's tap slot k is live iff its tap is in the chunk's mask
     bool live[TPW];
     {
-        const unsigned msk = MASKED ? p.masks[ch] : 0x7FFFFFFu;
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) live[k] = !MASKED || (((msk >> (wave + 4 * k)) & 1u) != 0 && wave + 4 * k < 27);
+        for (int k = 0; k < TPW; ++k) live[k] = !MASKED || slot_tap[k] < 27;
     }
 
     const TileWalk tw = tile_walk(p.ntiles);
@@ -1065,7 +1092,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 4 * g + reg;
                 int tap, ci;
-                if (CK == 16) { tap = wave + 4 * k; ci = row; } else { tap = 2 * (wave + 4 * k) + (row >> 3); ci = row & 7; }
+                if (CK == 16) { tap = slot_tap[k]; ci = row; } else { tap = 2 * (wave + 4 * k) + (row >> 3); ci = row & 7; }
                 if (tap < 27 && co < p.Cout && (CK == 16 || wave + 4 * k < 14))
                     part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[k][nn][reg];
             }
