@@ -348,6 +348,12 @@ def main():
     shape = tuple(args.shape)
     extra_legs = [] if (args.no_extra or args.workload != 'seg' or args.net != 'UNet_light') else ['reg', 'joint']
     wls, n_classes = make_workloads(args, dev, rank, [args.workload] + extra_legs)
+    # Python's cyclic collector walks every live container each time it runs a full collection; with three models, their optimisers and
+    # the autograd graphs of a step alive that costs the (host-bound) small-volume and bf16 legs milliseconds per step.  Standard
+    # training-loop hygiene: move everything built so far out of the collector's reach.
+    import gc
+    gc.collect()
+    gc.freeze()
 
     # ---- headline: the timed region carries HIP-event timing of the FORWARD conv calls only.  The backward pass runs its weight
     # gradients on a second stream (ops.ASYNC_WGRAD): timing events recorded there serialise it against the main stream and

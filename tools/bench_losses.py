@@ -39,14 +39,36 @@ def main():
         'da_warp_fwd[1]': 5 * 4 * V, 'da_warp_bwd[1]': 8 * 4 * V,
         'da_warp_fwd[32]': 67 * 4 * V, 'da_warp_bwd[32]': (70 + 32) * 4 * V,
         'da_argmax_dice_counts': (32 * 4 + 1) * V, 'da_label_overlap_counts': 2 * V,
+        # round 2: fused kernels (bytes = what has to cross HBM once)
+        'da_head_dice_fwd': (16 * 4 + 1) * V, 'da_head_dice_bwd': (2 * 16 * 4 + 1) * V,                 # read x (+ write dx), labels
+        'da_label_warp_dice_fwd': (12 + 2) * V, 'da_label_warp_dice_bwd': (12 + 2 + 12) * V,            # disp + two label maps (+ d_disp)
+        'da_warp_adjoint_labels': (32 * 4 + 12 + 1) * V,                                                # B written once, disp + labels read
+        'da_seg_anat_dlogits': (3 * 32 * 4 + 1) * V,                                                    # prob, B read; d logits written
+        'da_xent_fwd': (32 * 4 + 1) * V, 'da_xent_bwd': (2 * 32 * 4 + 1) * V,
+        'da_act_bwd_add_dbias': 4 * 16 * 4 * V,                                                         # g1, g2, y read; dx written (16 channels)
     }
     prof = nat.CallProfiler()
     crit_d = L.DiceLossMultiClass(n_class=32, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
     crit_n, crit_b, crit_g, crit_l = L.NormalizedCrossCorrelationLoss(), L.BendingEnergyLoss(), L.gradientLoss(), L.VoxelMorphLNCC().to(dev)
     src32 = cl(torch.rand((1, 32, D, H, W), generator=g))
 
+    x16 = cl(torch.rand((1, 16, D, H, W), generator=g))
+    w_head, b_head = (torch.rand((32, 16, 1, 1, 1), generator=g) - 0.5).to(dev), (torch.rand((32,), generator=g) - 0.5).to(dev)
+    lab8 = labels.to(torch.uint8)
+    lab8b = labels2.to(torch.uint8)
+    ce = L.get_loss_function('cross_entropy')()
+    g16a, g16b = cl(torch.rand((1, 16, D, H, W), generator=g)), cl(torch.rand((1, 16, D, H, W), generator=g))
+
     def once():
         x = logits.clone().requires_grad_(True); crit_d(x, labels.long()).backward()
+        xh = x16.clone().requires_grad_(True); wh = w_head.clone().requires_grad_(True)
+        ops.HeadDiceFn.apply(xh, wh, b_head, lab8, 'Uniform', False, 1e-6).backward()
+        u = disp.clone().requires_grad_(True); ops.LabelWarpDiceFn.apply(lab8, lab8b, u, 32, 'Uniform', False, 1e-6).backward()
+        x = logits.clone().requires_grad_(True)
+        ls, la = ops.SegPhaseLossFn.apply(x, lab8, disp, lab8b, 'Uniform', False, 1e-6); (ls + la).backward()
+        x = logits.clone().requires_grad_(True); ce(x, lab8).backward()
+        ya, yb = ops.Conv3dK3Fn.apply(x16[:, :8], None, torch.zeros((16, 8, 3, 3, 3), device=dev, requires_grad=True), None, 1, 0.0, False, True)
+        (ya * g16a + yb * g16b).sum().backward()
         i1 = img1.clone().requires_grad_(True); crit_n(i1, img2).backward()
         u = disp.clone().requires_grad_(True); crit_b(u).backward()
         u = disp.clone().requires_grad_(True); crit_g(u).backward()

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): round-2 evidence -> gpurun_out/r02/ (copy what is to be judged into profiles/).
+#   bench lines (default run = seg headline + reg + joint extras; graph mode; 192x224x192; bf16 matrix mode), rocprofv3 kernel
+#   summaries + two-stream timeline of the three workloads, per-C-ABI-call tables, HBM-bound call table, isolated conv layers.
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r02; rm -rf $O; mkdir -p $O
+git rev-parse --short HEAD > $O/commit.txt 2>/dev/null || true
+timeout 900 python bench.py > $O/bench_default.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_default.log | tail -1 > $O/bench_default.json
+timeout 600 python bench.py --no-cpu-baseline --graph > $O/bench_graph.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_graph.log | tail -1 > $O/bench_graph.json
+timeout 600 python bench.py --no-cpu-baseline --shape 192 224 192 > $O/bench_192x224x192.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_192x224x192.log | tail -1 > $O/bench_192x224x192.json
+timeout 600 python bench.py --no-cpu-baseline --precision bf16 > $O/bench_bf16.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
+timeout 600 python bench.py --no-cpu-baseline --precision bf16 --shape 192 224 192 > $O/bench_bf16_192x224x192.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_bf16_192x224x192.log | tail -1 > $O/bench_bf16_192x224x192.json
+timeout 600 python bench.py --no-cpu-baseline --shape 32 32 32 --steps 20 --warmup 5 --no-profile > $O/bench_host_floor_32.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_host_floor_32.log | tail -1 > $O/bench_host_floor_32.json
+timeout 600 python bench.py --no-cpu-baseline --shape 32 32 32 --steps 20 --warmup 5 --graph > $O/bench_host_floor_32_graph.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_host_floor_32_graph.log | tail -1 > $O/bench_host_floor_32_graph.json
+for w in seg reg joint; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$w -- python bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/prof_$w.log 2>&1 < /dev/null
+  f=$(ls $O/prof_$w/*/*.db 2>/dev/null | head -1)
+  if [ -n "$f" ]; then
+    python tools/rocpd_summary.py "$f" --top 60 > $O/${w}_kernel_stats.txt 2>&1 < /dev/null
+    python tools/rocpd_timeline.py "$f" > $O/${w}_timeline.txt 2>&1 < /dev/null
+  fi
+  rm -rf $O/prof_$w
+  timeout 600 python tools/step_calls.py $w 2>&1 | grep -v amdgpu.ids > $O/${w}_calls.txt
+done
+timeout 600 python tools/bench_losses.py 2>&1 | grep -v amdgpu.ids | grep -v '^\[' > $O/hbm_bound_calls.txt
+timeout 600 python tools/bench_conv.py --layer 32,16,16,2,160,192,160 2>&1 | grep -v amdgpu.ids > $O/conv_layers_isolated.txt
+timeout 600 python tools/bench_conv.py --layer 16,0,16,2,160,192,160 2>&1 | grep -v amdgpu.ids >> $O/conv_layers_isolated.txt
+timeout 600 python tools/bench_conv.py --layer 64,32,32,2,80,96,80 2>&1 | grep -v amdgpu.ids >> $O/conv_layers_isolated.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_conv -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --iters 5 > $O/prof_conv.log 2>&1 < /dev/null
+f=$(ls $O/prof_conv/*/*.db 2>/dev/null | head -1)
+if [ -n "$f" ]; then python tools/rocpd_summary.py "$f" > $O/conv3d_48to16_kernel_stats.txt 2>&1 < /dev/null; fi
+rm -rf $O/prof_conv
+ls -la $O
