@@ -73,8 +73,9 @@ def main():
         u = disp.clone().requires_grad_(True); crit_b(u).backward()
         u = disp.clone().requires_grad_(True); crit_g(u).backward()
         i1 = img1.clone().requires_grad_(True); i2 = img2.clone().requires_grad_(True); crit_l(i1, i2).backward()
-        for s in (img1, src32):
-            sr = s.clone().requires_grad_(True); u = disp.clone().requires_grad_(True)
+        # the image warp's source never needs a gradient (registration step: d_disp only); the 32-channel probability warp does
+        for s, need in ((img1, False), (src32, True)):
+            sr = s.clone().requires_grad_(need); u = disp.clone().requires_grad_(True)
             out, _ = ops.WarpFn.apply(sr, u); out.sum().backward()
         em.eval_dice_counts(logits, labels)
         ops.label_overlap_counts(labels, labels2, 32)

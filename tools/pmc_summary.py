@@ -46,6 +46,12 @@ def main():
         commit = open(os.path.join(src, 'commit.txt')).read().strip() or '?'
     except OSError:
         pass
+    if commit == '?':          # the GPU box gets a snapshot without .git: the summary is folded where the history is
+        try:
+            import subprocess
+            commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=os.path.dirname(os.path.abspath(__file__)), text=True).strip() + ' (summary folded at this commit; the CSVs were collected on the working-tree snapshot gpurun pushed at or shortly before it)'
+        except Exception:
+            pass
     res['commit'] = commit
     # calibration (tools/ubench/fetch_calib.hip): requested bytes / FETCH_SIZE for the two request shapes of the halo staging
     calib = {}
