@@ -19,12 +19,13 @@ namespace {
 
 constexpr int TZ = 4, TY = 8, TX = 16, TVOX = TZ * TY * TX;
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;
-constexpr int MT = 6;                     // M-tiles: 27 * Cout <= 96
+constexpr int MT_MAX = 6;                 // M-tiles: 27 * Cout <= 96
 constexpr int kFlowBlocks = 512;          // 2 workgroups per CU
 
 struct FlowWgP {
     const float* in1; const float* in2; int C1, C2;        // x = concat(in1, in2); C1, C2 in {0, 4, 8, 12, 16}
-    const float* dy; float* partial;
+    const float* dy; const float* dyb; int Cd1;            // dy channels [0, Cd1) from dy (stride Cd1), [Cd1, Cout) from dyb (stride Cout - Cd1)
+    float* partial;
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles;
 };
 
@@ -32,12 +33,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const float* base, u
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
-template <int S1>      // LDS row stride (floats) of the in1 tile: 8 or 16
+// MT: M-tiles of 16 (tap, cout) rows; TWO: a second N-tile for in1; S1: LDS row stride (floats) of the in1 tile, 8 or 16
+template <int MT, bool TWO, int S1>
 __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
+    constexpr int NTT = TWO ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xa = lds;                               // in2 tile  [TVOX][16]
-    float* xb = xa + TVOX * 16;                    // in1 tile  [TVOX][S1]
-    float* dyl = xb + TVOX * S1;                   // dy halo tile [HVOX][Cout]
+    float* xb = xa + TVOX * 16;                    // in1 tile  [TVOX][S1]   (TWO only)
+    float* dyl = xb + (TWO ? TVOX * S1 : 0);       // dy halo tile [HVOX][Cout]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -54,9 +57,11 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
         const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
         offA[mt] = (((2 - tz) * HY + (2 - ty)) * HX + (2 - tx)) * Cout + co;
     }
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NTT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // static share of the tile list (contiguous range per workgroup: neighbouring tiles share dy halo rows in L2)
     const int per = (p.ntiles + gridDim.x - 1) / gridDim.x;
@@ -75,7 +80,9 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
         const unsigned long long vol = (unsigned long long)p.D * p.H * p.W;
         const __amdgpu_buffer_rsrc_t r2 = flow_rsrc(p.C2 > 0 ? p.in2 + (size_t)n * vol * p.C2 : p.dy, p.C2 > 0 ? (unsigned)(vol * p.C2 * 4ull) : 0u);
         const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p.C1 > 0 ? p.in1 + (size_t)n * vol * p.C1 : p.dy, p.C1 > 0 ? (unsigned)(vol * p.C1 * 4ull) : 0u);
-        const __amdgpu_buffer_rsrc_t ry = flow_rsrc(p.dy + (size_t)n * vol * Cout, (unsigned)(vol * Cout * 4ull));
+        const int Cd2 = Cout - p.Cd1;
+        const __amdgpu_buffer_rsrc_t ry = flow_rsrc(p.dy + (size_t)n * vol * p.Cd1, (unsigned)(vol * p.Cd1 * 4ull));
+        const __amdgpu_buffer_rsrc_t ry2 = flow_rsrc(Cd2 > 0 ? p.dyb + (size_t)n * vol * Cd2 : p.dy, Cd2 > 0 ? (unsigned)(vol * Cd2 * 4ull) : 0u);
 #pragma unroll
         for (int it = 0; it < NX2; ++it) {
             const int idx = threadIdx.x + it * 256;
@@ -85,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
                 const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
                 pa[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * 4) : 0xFFFFFFFFu, 0, 0));
             }
-            {   // in1: Q1 quads per voxel
+            if (TWO) {   // in1: Q1 quads per voxel
                 const int c4 = Q1 > 0 ? idx % Q1 : 0, v = Q1 > 0 ? idx / Q1 : TVOX;
                 const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
                 const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
@@ -99,7 +106,9 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
             const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
             const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bool ok = hv < HVOX && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            pd[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? (unsigned)((((z * p.H + y) * p.W + x) * Cout + co) * 4) : 0xFFFFFFFFu, 0, 0));
+            const unsigned vo = (unsigned)((z * p.H + y) * p.W + x);
+            pd[it] = co < p.Cd1 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? (vo * p.Cd1 + co) * 4u : 0xFFFFFFFFu, 0, 0))
+                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry2, ok ? (vo * Cd2 + (co - p.Cd1)) * 4u : 0xFFFFFFFFu, 0, 0));
         }
     };
     auto write_lds = [&]() {
@@ -107,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
         for (int it = 0; it < NX2; ++it) {
             const int idx = threadIdx.x + it * 256;
             if (Q2 > 0 && idx < TVOX * Q2) *reinterpret_cast<float4*>(xa + (idx / Q2) * 16 + (idx % Q2) * 4) = pa[it];
-            if (Q1 > 0 && idx < TVOX * Q1) *reinterpret_cast<float4*>(xb + (idx / Q1) * S1 + (idx % Q1) * 4) = pb[it];
+            if (TWO && Q1 > 0 && idx < TVOX * Q1) *reinterpret_cast<float4*>(xb + (idx / Q1) * S1 + (idx % Q1) * 4) = pb[it];
         }
 #pragma unroll
         for (int it = 0; it < NDY; ++it) {
@@ -117,7 +126,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
     };
     // channels a tensor does not have stay zero for the whole launch (written once, never overwritten)
     for (int idx = threadIdx.x; idx < TVOX * 16; idx += 256) xa[idx] = 0.f;
-    for (int idx = threadIdx.x; idx < TVOX * S1; idx += 256) xb[idx] = 0.f;
+    if (TWO) for (int idx = threadIdx.x; idx < TVOX * S1; idx += 256) xb[idx] = 0.f;
     __syncthreads();
     if (t_begin < t_end) { issue(t_begin); write_lds(); }
     __syncthreads();
@@ -136,11 +145,11 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
                 float a[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[mt] = arow[xs * 4 * Cout + offA[mt]];
-                const float b0 = b2row[xs * 4 * 16], b1 = b1row[xs * 4 * S1];
+                const float b0 = b2row[xs * 4 * 16], b1 = TWO ? b1row[xs * 4 * S1] : 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][1], 0, 0, 0);
+                    if (TWO) acc[mt][NTT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][NTT - 1], 0, 0, 0);
                 }
             }
         }
@@ -158,8 +167,8 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    float4* slot = red + (mt * 2 + nt) * 64 + lane;
+                for (int nt = 0; nt < NTT; ++nt) {
+                    float4* slot = red + (mt * NTT + nt) * 64 + lane;
                     float4 cur = (w == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
                     cur.x += acc[mt][nt][0]; cur.y += acc[mt][nt][1]; cur.z += acc[mt][nt][2]; cur.w += acc[mt][nt][3];
                     *slot = cur;
@@ -169,9 +178,9 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
     }
     const int O = 27 * Cin * Cout;
     float* part = p.partial + (size_t)blockIdx.x * O;
-    for (int idx = threadIdx.x; idx < MT * 2 * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < MT * NTT * 64; idx += 256) {
         const int ln = idx & 63, q = idx >> 6;
-        const int nt = q & 1, mt = q >> 1;
+        const int nt = q % NTT, mt = q / NTT;
         const float4 v = red[idx];
         const float vals[4] = {v.x, v.y, v.z, v.w};
         const int col = ln & 15;                                 // C / D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -193,6 +202,26 @@ bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride) {
 
 size_t da_conv3_flow_wgrad_ws_bytes(int Cin, int Cout) { return da_align((size_t)kFlowBlocks * 27 * Cin * Cout * sizeof(float)); }
 
+template <int MTT, bool TWO, int S1>
+static int flow_launch(const FlowWgP& p, int nb, hipStream_t st) {
+    const size_t red_bytes = (size_t)MTT * (TWO ? 2 : 1) * 64 * sizeof(float4);
+    size_t shm = ((size_t)TVOX * 16 + (TWO ? (size_t)TVOX * S1 : 0) + (size_t)HVOX * p.Cout) * sizeof(float);
+    if (shm < red_bytes) shm = red_bytes;
+    auto kern = flow_wgrad_kernel<MTT, TWO, S1>;
+    static bool attr_set = false;
+    if (!attr_set) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return (int)e; attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+static void flow_geom(FlowWgP& p, int N, int D, int H, int W, int* nb) {
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.ntz = (D + TZ - 1) / TZ; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
+    p.ntiles = N * p.ntz * p.nty * p.ntx;
+    *nb = p.ntiles < kFlowBlocks ? p.ntiles : kFlowBlocks;
+}
+
 int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!da_conv3_flow_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
@@ -203,25 +232,52 @@ int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     // N-tile 0 takes the tensor called in2; a single-tensor input is passed as in2 so that it lands in the full-width tile
     if (C2 == 0) { p.in1 = nullptr; p.C1 = 0; p.in2 = in1; p.C2 = C1; }
     else { p.in1 = in1; p.C1 = C1; p.in2 = in2; p.C2 = C2; }
-    p.dy = dy; p.partial = (float*)ws;
-    p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout;
-    p.ntz = (D + TZ - 1) / TZ; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
-    p.ntiles = N * p.ntz * p.nty * p.ntx;
-    int nb = p.ntiles < kFlowBlocks ? p.ntiles : kFlowBlocks;
-    const int S1 = p.C1 <= 8 ? 8 : 16;
-    const size_t red_bytes = (size_t)MT * 2 * 64 * sizeof(float4);
-    size_t shm = ((size_t)TVOX * 16 + (size_t)TVOX * S1 + (size_t)HVOX * Cout) * sizeof(float);
-    if (shm < red_bytes) shm = red_bytes;
-    if (S1 == 8) {
-        static bool set8 = false;
-        if (!set8) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return (int)e; set8 = true; }
-        hipLaunchKernelGGL(flow_wgrad_kernel<8>, dim3(nb), dim3(256), shm, st, p);
-    } else {
-        static bool set16 = false;
-        if (!set16) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return (int)e; set16 = true; }
-        hipLaunchKernelGGL(flow_wgrad_kernel<16>, dim3(nb), dim3(256), shm, st, p);
-    }
-    DA_LAUNCH_CHECK();
+    p.dy = dy; p.dyb = nullptr; p.Cd1 = Cout; p.partial = (float*)ws; p.Cout = Cout;
+    int nb;
+    flow_geom(p, N, D, H, W, &nb);
+    int rc;
+    if (p.C1 == 0) rc = flow_launch<MT_MAX, false, 8>(p, nb, st);
+    else if (p.C1 <= 8) rc = flow_launch<MT_MAX, true, 8>(p, nb, st);
+    else rc = flow_launch<MT_MAX, true, 16>(p, nb, st);
+    if (rc) return rc;
     // the kernel's ci order is the conv's own (in1's channels first); with the single-tensor swap above C1 == 0 keeps it that way
     return da_reduce_partials(p.partial, nb, O, dw_tio, st);
+}
+
+// ---- very few INPUT channels (the first layers: seg 1 -> 8, reg 1 + 1 -> 16): the same kernel with the operands' roles exchanged.
+// dW[tap][ci][co] = sum_u x[u + tap - 1][ci] dy[u][co] = sum_p dy[p][co] x[p - (tap' - 1)][ci] with tap' the mirrored tap: "X" = dy (Cout channels,
+// the N-tile), "DY" = x (Cin <= 3 channels, possibly two one-channel tensors, read through the halo windows).  The result comes out
+// as [tap'][co][ci] and is permuted into dw_tio [tap][ci][co] by a tiny kernel.
+__global__ void fewcin_place_kernel(const float* __restrict__ tmp, float* __restrict__ dw, int Cin, int Cout) {
+    const int O = 27 * Cin * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < O; i += gridDim.x * blockDim.x) {
+        const int ci = i % Cin; const int r = i / Cin; const int co = r % Cout; const int t = r / Cout;
+        dw[((size_t)(26 - t) * Cin + ci) * Cout + co] = tmp[i];
+    }
+}
+
+bool da_conv3_fewcin_wgrad_supported(int C1, int C2, int Cout, int stride) {
+    return stride == 1 && C1 >= 1 && C2 >= 0 && C1 + C2 <= 2 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16;
+}
+
+int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
+                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!da_conv3_fewcin_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
+    const int Cin = C1 + C2, O = 27 * Cin * Cout;
+    if (ws_bytes < da_align((size_t)kFlowBlocks * O * sizeof(float)) + da_align((size_t)O * sizeof(float))) return DA_ERR_WS_SMALL;
+    if ((unsigned long long)D * H * W * 16ull * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+    FlowWgP p;
+    p.in1 = nullptr; p.C1 = 0; p.in2 = dy; p.C2 = Cout;                   // "X" = dy
+    p.dy = in1; p.dyb = in2; p.Cd1 = C1; p.Cout = Cin;                    // "DY" = x (one or two tensors)
+    p.partial = (float*)ws;
+    int nb;
+    flow_geom(p, N, D, H, W, &nb);
+    const int rc = Cin == 1 ? flow_launch<2, false, 8>(p, nb, st) : flow_launch<4, false, 8>(p, nb, st);
+    if (rc) return rc;
+    float* tmp = (float*)((char*)ws + da_align((size_t)kFlowBlocks * O * sizeof(float)));
+    const int rc2 = da_reduce_partials(p.partial, nb, O, tmp, st);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(fewcin_place_kernel, dim3(da_grid(O, 256, 64)), dim3(256), 0, st, tmp, dw_tio, Cin, Cout);
+    DA_LAUNCH_CHECK();
+    return 0;
 }

@@ -53,3 +53,7 @@ bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride);
 size_t da_conv3_flow_wgrad_ws_bytes(int Cin, int Cout);
 int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+// ... and with the operands' roles exchanged for <= 2 input channels (first layers: seg 1 -> 8, reg 1 + 1 -> 16)
+bool da_conv3_fewcin_wgrad_supported(int C1, int C2, int Cout, int stride);
+int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
+                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);

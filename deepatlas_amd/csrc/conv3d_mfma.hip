@@ -1582,6 +1582,13 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro) {
     if (pro && (stride != 1 || s2d_cin > 0 || C1 + C2 > kProMaxC || pick_ck(C1, C2) == 0 || Cout % 4 != 0 || Cout <= 4)) return DA_ERR_UNSUPPORTED;
+    if (!pro && s2d_cin == 0 && da_conv3_fewcin_wgrad_supported(C1, C2, Cout, stride)) {
+        static int off = -1; if (off < 0) { const char* e = getenv("DA_NO_FLOW_WGRAD"); off = (e && atoi(e)) ? 1 : 0; }
+        if (!off) {
+            const int rc = da_conv3_fewcin_wgrad(in1, C1, in2, C2, dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes, st);
+            if (rc != DA_ERR_UNSUPPORTED && rc != DA_ERR_WS_SMALL) return rc;
+        }
+    }
     if (smallcin_ok(C1, C2, Cout, stride)) {
         const int Cin = C1 + C2, O = 27 * Cin * Cout;
         if (ws_bytes < (size_t)kScBlocks * O * sizeof(float)) return DA_ERR_WS_SMALL;
