@@ -38,6 +38,7 @@ SIGNATURES = {
     'da_conv3d_k3_wgrad_pro': (I, [P, I, P, P, F, P, I, P, P, F, P, P, I, I, I, I, I, P, SZ, P]),
     'da_set_conv_direct': (I, [I]),
     'da_set_matrix_bf16': (I, [I]),
+    'da_set_matrix_mode': (I, [I]),
     'da_pointwise_ws_bytes': (SZ, [I, I, I]),
     'da_conv1x1_fwd': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
     'da_conv1x1_fwd_pro': (I, [P, P, P, F, P, P, P, LL, I, I, P, SZ, P]),

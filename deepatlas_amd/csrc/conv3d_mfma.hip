@@ -63,6 +63,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t da_rsrc(const float* base, uns
 __device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
 }
+// Split mode (SP): x = h + m + l EXACTLY, each term a bf16 -- h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even of
+// the running remainder (3 x 8 significand bits cover fp32's 24; the subtractions are exact in fp32).  Four values at a time, packed
+// like da_bf16x2 (element 0 in the low half).
+__device__ __forceinline__ void da_split3(const float4 v, uint2& h, uint2& m, uint2& l) {
+    h = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
+    const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xFFFF0000u);
+    const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xFFFF0000u);
+    m = make_uint2(da_bf16x2(rx, ry), da_bf16x2(rz, rw));
+    const float sx = rx - __uint_as_float(m.x << 16), sy = ry - __uint_as_float(m.x & 0xFFFF0000u);
+    const float sz = rz - __uint_as_float(m.y << 16), sw = rw - __uint_as_float(m.y & 0xFFFF0000u);
+    l = make_uint2(da_bf16x2(sx, sy), da_bf16x2(sz, sw));
+}
 __device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
@@ -102,7 +114,7 @@ __device__ __forceinline__ float da_act01(float z, float s) { return fmaxf(z, z 
 // Input prologue (PRO variants): the staged tensor is a RAW convolution output whose BatchNorm + LeakyReLU has not been applied
 // yet; it is applied here, on the way into LDS, with exactly the expression of bn_act_fwd_kernel (norm_act.hip) so the result is
 // bit-identical to materialising the activated tensor first.  Padding (out-of-volume voxels, mask bit clear) stays zero.
-template <int CK, int HZ, int IT0, int IT1, bool BF>
+template <int CK, int HZ, int IT0, int IT1, bool BF, bool SP = false>
 __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const float4* pre, unsigned vmask, float4 sc, float4 sf, float slope) {
     constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
 #pragma unroll
@@ -114,21 +126,28 @@ __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const f
             float4 v;
             v.x = ok ? da_act01(t.x * sc.x + sf.x, slope) : 0.f; v.y = ok ? da_act01(t.y * sc.y + sf.y, slope) : 0.f;
             v.z = ok ? da_act01(t.z * sc.z + sf.z, slope) : 0.f; v.w = ok ? da_act01(t.w * sc.w + sf.w, slope) : 0.f;
-            if constexpr (BF) reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
+            if constexpr (SP) {
+                uint2 h, m, l; da_split3(v, h, m, l);
+                reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = m; reinterpret_cast<uint2*>(lds)[idx + 2 * TOTAL] = l;
+            } else if constexpr (BF) reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
             else reinterpret_cast<float4*>(lds)[idx] = v;
         }
     }
 }
 
 // BF: the LDS image holds bf16 (same [voxel][CK] order, 8 bytes per channel quad): converted once here instead of at every tap
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false>
+// SP: three bf16 planes (h, m, l of da_split3), each in the BF layout, TOTAL quads apart
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false, bool SP = false>
 __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
     constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
         const int idx = threadIdx.x + it * 256;
         if (idx < TOTAL) {
-            if constexpr (BF) {
+            if constexpr (SP) {
+                uint2 h, m, l; da_split3(pre[it - IT0], h, m, l);
+                reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = m; reinterpret_cast<uint2*>(lds)[idx + 2 * TOTAL] = l;
+            } else if constexpr (BF) {
                 const float4 v = pre[it - IT0];
                 reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
             } else reinterpret_cast<float4*>(lds)[idx] = pre[it - IT0];
@@ -171,6 +190,44 @@ template <int CK, int HZ> struct StageCursor {
         hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
         hz += SZ + cy;
         return v;
+    }
+};
+// Per-thread constants of the halo staging (replaces the cursor inside the persistent loop): iteration `it` of this thread covers
+// halo voxel (hz, hy, hx) = pk[it] >> 16, (pk[it] >> 8) & 255, pk[it] & 255 and channel quad threadIdx.x % Q.  The byte offsets of one
+// item's NIT loads are computed in one go at the top of the item: 7 VALU operations per load for a tile whose whole halo lies
+// inside the volume (the common case, a wave-uniform branch around pure arithmetic), bounds checks only on boundary tiles.
+template <int CK, int HZ> struct StageMap {
+    static constexpr int NIT = StageGeom<CK, HZ>::NIT, Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
+    unsigned pk[NIT];
+    int c4x4;
+    __device__ __forceinline__ void init() {
+        c4x4 = ((int)threadIdx.x % Q) * 4;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int hv = ((int)threadIdx.x + it * 256) / Q;
+            const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
+            pk[it] = (hv < TOTAL / Q) ? ((unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx) : 0xFFFF0000u;     // past the tile: hz = 65535 is never inside
+        }
+    }
+    // tile-level part (wave-uniform): is the whole halo inside the volume, voxel index of the halo's corner
+    struct Tile { bool interior, valid; int z0, y0, x0, basev, H, W, D, Cs4, cofs4; };
+    __device__ __forceinline__ Tile tile(int z0, int y0, int x0, int D, int H, int W, int Cs, int choff, bool valid) const {
+        Tile t;
+        t.valid = valid; t.z0 = z0; t.y0 = y0; t.x0 = x0; t.D = D; t.H = H; t.W = W;
+        t.interior = valid && z0 >= 1 && z0 + HZ - 2 < D && y0 >= 1 && y0 + HY - 2 < H && x0 >= 1 && x0 + HX - 2 < W;
+        t.basev = ((z0 - 1) * H + (y0 - 1)) * W + (x0 - 1);
+        t.Cs4 = Cs * 4; t.cofs4 = (choff + c4x4) * 4;
+        return t;
+    }
+    __device__ __forceinline__ unsigned offset(const Tile& t, int it) const {
+        const int hz = (int)(pk[it] >> 16), hy = (int)((pk[it] >> 8) & 255u), hx = (int)(pk[it] & 255u);
+        if (t.interior) {
+            const unsigned o = (unsigned)((t.basev + (hz * t.H + hy) * t.W + hx) * t.Cs4 + t.cofs4);
+            return ((it + 1) * 256 <= TOTAL || hz != 0xFFFF) ? o : 0xFFFFFFFFu;
+        }
+        const int z = t.z0 - 1 + hz, y = t.y0 - 1 + hy, x = t.x0 - 1 + hx;
+        const bool inb = t.valid && (unsigned)z < (unsigned)t.D && (unsigned)y < (unsigned)t.H && (unsigned)x < (unsigned)t.W;
+        return inb ? (unsigned)(((z * t.H + y) * t.W + x) * t.Cs4 + t.cofs4) : 0xFFFFFFFFu;
     }
 };
 __device__ __forceinline__ void da_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
@@ -228,6 +285,8 @@ struct FwdP {
     unsigned long long* clk;
     const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: per-channel scale / shift / act slope still to be applied to in1 / in2
     int* dyn_ctr;    // DYN: tile counters [gridDim.y][8 XCDs], zeroed by the pack kernel of the same call
+    const int4* tiles;   // (n, z0, y0, x0) of every tile in brick order, written by the pack kernel of the same call: the persistent loop
+                         // reads one entry per item through the scalar cache instead of decomposing the position (~10 integer divisions)
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
@@ -238,9 +297,17 @@ struct FwdP {
 // next position from that XCD's counter (one atomic per tile by thread 0, two tiles ahead, handed to the other waves through a
 // 4-entry LDS ring), so a kernel whose workgroups start at different times -- behind another persistent kernel on the other stream
 // -- still finishes together.  Not for the STATS variant: its per-workgroup partial sums would then depend on the draw order.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue
+// SP: split mode (da_set_matrix_mode(2)) -- fp32 products on the bf16 matrix pipe.  Both operands are split exactly into three bf16 terms
+// (da_split3: activations while they are staged, weights in the pack kernel) and a K-step of an (M-tile, N-tile) pair is six
+// v_mfma_f32_16x16x32_bf16: a.l b.h + a.h b.l + a.m b.m + a.h b.m + a.m b.h + a.h b.h, smallest terms first, fp32 accumulate.  The three
+// dropped products are <= 2^-25 |a b| together, i.e. below the rounding of ONE fp32 multiply-add (tools/ubench/split_bf16.hip: the error
+// against double is smaller than that of the v_mfma_f32_16x16x4_f32 chain), at 6/16 of the matrix-pipe time.  LDS holds the three planes
+// (CK = 8: 3 x 17 KB, two workgroups per CU as before); fragments of the next two rows are read while the current two rows' 12 MFMAs issue.
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(!DYN || (!STATS && !MASKED && !PRO), "dynamic tile walk: plain forward / data-gradient variants only");
+    static_assert(!SP || (BF && !MASKED && !DYN && CK == 8), "split mode: dense bf16 K = 32 kernels on 8-channel chunks");
+    constexpr int NP = SP ? 3 : 1;                                  // operand planes
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // K32: the dense bf16 kernels use v_mfma_f32_16x16x32_bf16 (K = 32 = two taps x 16 cin, or four taps x 8 cin; 16 cycles per
     // SIMD for twice the K of the 16x16x16 form, which gfx950 issues at ~32 cycles); the sparse-tap variant keeps one tap per step.
@@ -271,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // DYN: this workgroup's XCD range [xlo, xhi) of the brick order, its counter, and the ring of drawn positions.  (Out-of-range
     // buffer ATOMICS fault on gfx950 -- tools/ubench/buffer_atomic_oob.hip -- so the draw sits in an exec-mask branch of thread 0.)
     int xlo = 0, xhi = 0;
-    int* sp = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB);
+    int* sp = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB * NP);
     int* ctr = nullptr;
     if constexpr (DYN) {
         const int G = gridDim.x, X = (G % 8 == 0) ? 8 : 1, xcd = blockIdx.x % X;
@@ -286,11 +353,17 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         else return tw.lo + k * tw.J;
     };
 
-    auto item_coords = [&](int item, int& n, int& z0, int& y0, int& x0, int& ch) {
-        ch = item % nchunks;
-        int tx, ty, tz;
-        brick_tile<2, 4, 8>(tile_pos(item / nchunks), p.ntx, p.nty, p.ntz, n, tx, ty, tz);   // brick = 32^3 voxels
-        x0 = tx * TX; y0 = ty * TY; z0 = tz * TZ;
+    // work item = (k-th tile of this workgroup's walk, channel chunk): the current and the next item's coordinates are kept in SGPRs
+    int cK = 0, cCh = 0, cN, cZ, cY, cX, nK, nCh, nN, nZ, nY, nX;
+    auto tile_at = [&](int k, int& n, int& z0, int& y0, int& x0) {
+        int pos = tile_pos(k); pos = pos < p.ntiles ? pos : p.ntiles - 1;               // (past the walk: any valid entry; never used)
+        const int4 t = p.tiles[__builtin_amdgcn_readfirstlane(pos)];
+        n = t.x; z0 = t.y; y0 = t.z; x0 = t.w;
+    };
+    auto advance = [&]() { nCh = cCh + 1; nK = cK; if (nCh == nchunks) { nCh = 0; nK = cK + 1; } tile_at(nK, nN, nZ, nY, nX); };
+    tile_at(0, cN, cZ, cY, cX); advance();
+    auto item_coords = [&](int which, int& n, int& z0, int& y0, int& x0, int& ch) {      // which: 0 = current item, 1 = next item
+        if (which) { n = nN; z0 = nZ; y0 = nY; x0 = nX; ch = nCh; } else { n = cN; z0 = cZ; y0 = cY; x0 = cX; ch = cCh; }
     };
     auto issue_stage = [&](int item, float4* pre) {          // iterations [0, PRE)
         int n, z0, y0, x0, ch;
@@ -307,9 +380,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const float* src = (cbase < p.C1) ? p.in1 : p.in2;
             const int Cs = (cbase < p.C1) ? p.C1 : p.C2, choff = (cbase < p.C1) ? cbase : cbase - p.C1;
             constexpr int R = NIT - PRE, B1 = PRE + (R + 2) / 3, B2 = PRE + 2 * ((R + 2) / 3) < NIT ? PRE + 2 * ((R + 2) / 3) : NIT;
-            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF>(lds, tmp); }
-            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF>(lds, tmp); }
-            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF>(lds, tmp); }
+            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
+            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
+            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
         }
     };
 
@@ -328,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // DOUBLE accumulators held by the first NREP*16 threads (wave shuffles over q/g, then the 4 waves through a 2 KiB LDS
     // strip behind the tile; everything past the per-lane sums is double), so E[x^2] - mean^2 keeps the accuracy of the stand-alone statistics pass.
     double dsum1 = 0.0, dsum2 = 0.0;
-    double* sred = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB);      // [wave][2][NREP*16] doubles
+    double* sred = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB * NP);      // [wave][2][NREP*16] doubles
     int tiles_done = 0;
     auto stats_flush = [&]() {
         if constexpr (STATS) {
@@ -381,10 +454,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W, &vm);
         else stage_load<CK, HZ, 0, PRE>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W, &vm);
         load_pro(0);
-        stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
+        stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
     } else {
     issue_stage(0, pre);
-    stage_write<CK, HZ, 0, PRE, BF>(lds, pre);
+    stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);
     stage_rest(0);
     }
     __syncthreads();
@@ -393,6 +466,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     const AElem* abase = K32 ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + ((CK == 16) ? (g & 1) * 8 : 0)
                        : (CK == 16) ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + g * 4
                                     : reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
+    StageMap<CK, HZ> smap; if constexpr (SP) smap.init();
     const bool hi = (g >> 1) != 0;
     auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
     auto a_off8 = [&](int s) -> int {                                                              // CK8: two taps per step
@@ -403,6 +477,11 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         int tap = (CK == 16) ? 2 * s + (g >> 1) : 4 * s + g; if (tap > 26) tap = 26;             // (taps past 26 carry zero weights)
         return (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK;
     };
+    int aoff32[SP ? NSTEPS : 1];                         // SP: per-lane tap offsets of the K-steps, computed once instead of once per item
+    if constexpr (SP) {
+#pragma unroll
+        for (int t = 0; t < NSTEPS; ++t) aoff32[t] = a_off32(t);
+    }
 
     // ---- vector-memory scheduling.  vmcnt retires IN ORDER on gfx9 and counts stores as well as loads, and the CU's vector
     // memory pipe is a FIFO shared by both resident workgroups.  A B fragment requested behind a 69 KB staging burst (or behind
@@ -413,9 +492,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // before this item's epilogue stores); (2) the next item's staging loads are spread over the K-steps, at most one per step;
     // (3) nothing that touches vector memory sits inside a branch: invalid work (no next item, not the last chunk, ragged
     // lanes) is expressed as out-of-range buffer offsets, so hipcc's s_waitcnt vmcnt(N) stay exact instead of collapsing to 0.
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * (K32 ? 1024 : 256 * EB)), 0x00020000);
-    auto wb = [&](int chunk, int step, int nn) -> Frag {
-        if constexpr (K32) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * (K32 ? 1024 * NP : 256 * EB)), 0x00020000);
+    auto wb = [&](int chunk, int step, int nn, int pl = 0) -> Frag {
+        if constexpr (SP) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 3 + pl) * 1024), 0));
+        else if constexpr (K32) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
         else if constexpr (BF) return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rsw, (unsigned)lane * 8u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 512), 0));
         else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
     };
@@ -425,18 +505,20 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         else if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
         else return c;
     };
-    constexpr int LB = (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2)
+    constexpr int LB = SP ? 1 : (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2; a split-mode K-step is 6 x 8 MFMAs long)
     constexpr int RB = LB + 1;                          // ring slots
-    constexpr int TAIL = 5;                             // K-steps at the end of an item without staging loads (they must land before stage_write)
-    constexpr int PRO_DELAY = 3;                        // K-steps between a staging load and its prologue arithmetic (< TAIL)
+    constexpr int TAIL = SP ? 2 : 5;                    // K-steps at the end of an item without staging loads (they must land before stage_write)
+    constexpr int PRO_DELAY = SP ? 1 : 3;               // K-steps between a staging load and its prologue arithmetic (< TAIL)
     constexpr bool PRO_IN = PRO && NREP == 1;           // prologue arithmetic inside the K loop (one N-tile: registers to spare); else between the barriers
     static_assert(!PRO || NSTEPS - TAIL + PRO_DELAY <= NSTEPS, "prologue arithmetic must fall inside the K loop");
-    Frag bq[RB][NREP], nb[LB][NREP];
+    Frag bq[RB][NREP][NP], nb[LB][NREP][NP];
     if constexpr (!MASKED) {
 #pragma unroll
         for (int t = 0; t < LB; ++t)
 #pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) nb[t][nn] = wb(0, t, nn);     // item 0 is chunk 0
+            for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) nb[t][nn][pl] = wb(0, t, nn, pl);     // item 0 is chunk 0
     }
     // bias of this lane's 4 couts after the epilogue transpose (constant for the whole launch)
     const int q = lane & 3, a4 = (lane & 15) >> 2;
@@ -449,18 +531,18 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll 1
     for (int item = 0; item < nitems; ++item) {
         int n, z0, y0, x0, ch;
-        item_coords(item, n, z0, y0, x0, ch);
-        const bool has_next = DYN ? ((ch + 1 < nchunks) || tile_pos(item / nchunks + 1) < xhi) : (item + 1 < nitems);
+        item_coords(0, n, z0, y0, x0, ch);
+        const bool has_next = DYN ? ((ch + 1 < nchunks) || tile_pos(cK + 1) < xhi) : (item + 1 < nitems);
         const bool last = (ch == nchunks - 1);
         if constexpr (DYN) {       // on a tile's first chunk: draw the position of the tile after next; published below, before the barriers
-            if (threadIdx.x == 0 && ch == 0) sp[(item / nchunks + 2) & 3] = xlo + atomicAdd(ctr, 1);
+            if (threadIdx.x == 0 && ch == 0) sp[(cK + 2) & 3] = xlo + atomicAdd(ctr, 1);
         }
 
         if constexpr (MASKED) {
             // sparse tap set (a stride-2 conv expressed as a stride-1 conv over the space-to-depth input: a channel chunk
             // belongs to one input parity and only (1|2)^3 of the 27 taps are non-zero).  Staging-bound, so a plain loop.
             const Frag* wch = reinterpret_cast<const Frag*>(p.wp) + ((size_t)ch * NSTEPS * p.NT + nt0) * 64 + lane;
-            if (has_next && !(p.ablate & 1)) issue_stage(item + 1, pre);
+            if (has_next && !(p.ablate & 1)) issue_stage(1, pre);
             unsigned msk = p.masks[p.maskmode == 1 ? ch : (int)blockIdx.y];
             // software-pipelined over the live taps: the fragments of the NEXT tap (weights from global / L2, eight A rows from LDS) are
             // requested before the current tap's 32 * NREP MFMAs issue, so neither latency sits between two taps (the plain loop paid
@@ -507,25 +589,41 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         // MFMA order: component m outermost, M-tile r innermost -> 4*NREP independent accumulators between two uses of the
         // same one (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
         constexpr int HALF = TY / 2;
-        auto step_ptr = [&](int s) -> const AElem* { return K32 ? abase + a_off32(s) : (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
+        auto step_ptr = [&](int s) -> const AElem* { return SP ? abase + aoff32[s] : K32 ? abase + a_off32(s) : (CK == 16) ? abase + a_off(s) : abase + a_off8(s); };
         const int ch_next = (ch + 1 == nchunks) ? 0 : ch + 1;
 #pragma unroll
         for (int t = 0; t < LB; ++t)
 #pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) bq[t % RB][nn] = nb[t][nn];
-        StageCursor<CK, HZ> cur;
+            for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) bq[t % RB][nn][pl] = nb[t][nn][pl];
+        StageCursor<CK, HZ> cur;                              // next item's staging loads: cursor (fp32 / bf16 kernels) ...
+        typename StageMap<CK, HZ>::Tile stile;                // ... or per-thread halo map (SP: registers to spare, ~60 % fewer instructions)
+        __amdgpu_buffer_rsrc_t rsn;
         if constexpr (PRO) vm = 0;
-        if constexpr (PRO_IN) load_pro(has_next ? item + 1 : item);               // constants of the tile staged during this item
+        if constexpr (PRO_IN) load_pro(has_next ? 1 : 0);               // constants of the tile staged during this item
         {
             int n2, z2, y2, x2, ch2;
-            item_coords(item + 1, n2, z2, y2, x2, ch2);
+            item_coords(1, n2, z2, y2, x2, ch2);
             const int cbase = ch2 * CK;
             const bool first = cbase < p.C1;
-            cur.init(first ? p.in1 : p.in2, first ? p.C1 : p.C2, first ? cbase : cbase - p.C1, n2, z2, y2, x2, p.D, p.H, p.W,
-                     has_next && !(p.ablate & 1));
+            const int Csn = first ? p.C1 : p.C2;
+            if constexpr (SP) {
+                const long long sample = (long long)p.D * p.H * p.W * Csn;
+                rsn = da_rsrc((first ? p.in1 : p.in2) + (long long)n2 * sample, (unsigned)(sample * sizeof(float)));
+                stile = smap.tile(z2, y2, x2, p.D, p.H, p.W, Csn, first ? cbase : cbase - p.C1, has_next && !(p.ablate & 1));
+            } else cur.init(first ? p.in1 : p.in2, Csn, first ? cbase : cbase - p.C1, n2, z2, y2, x2, p.D, p.H, p.W, has_next && !(p.ablate & 1));
         }
         Frag A0[HALF], A1[HALF];
-        {
+        constexpr int PLANE_E = StageGeom<CK, HZ>::TOTAL * 4;             // elements per operand plane (SP)
+        Frag AC[NP][2];                                                     // SP: fragments of the current row pair
+        if constexpr (SP) {
+            const AElem* ap = step_ptr(0);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) AC[pl][rr] = *reinterpret_cast<const Frag*>(ap + pl * PLANE_E + rr * (HX * CK));
+        } else {
             const AElem* ap = step_ptr(0);
 #pragma unroll
             for (int r = 0; r < HALF; ++r) A0[r] = *reinterpret_cast<const Frag*>(ap + r * (HX * CK));
@@ -534,14 +632,22 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         for (int s = 0; s < NSTEPS; ++s) {
             // weights of K-step s + LB (of this chunk, or of the next item's chunk)
 #pragma unroll
-            for (int nn = 0; nn < NREP; ++nn) {
-                if (s + LB < NSTEPS) bq[(s + LB) % RB][nn] = wb(ch, s + LB, nn);
-                else nb[s + LB - NSTEPS][nn] = wb(ch_next, s + LB - NSTEPS, nn);
-            }
+            for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    if (s + LB < NSTEPS) bq[(s + LB) % RB][nn][pl] = wb(ch, s + LB, nn, pl);
+                    else nb[s + LB - NSTEPS][nn][pl] = wb(ch_next, s + LB - NSTEPS, nn, pl);
+                }
             // next item's staging loads scheduled on this step
 #pragma unroll
             for (int j = 0; j < PRE; ++j)
-                if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) { pre[j] = cur.next(); if constexpr (PRO) vm |= (cur.last_inb ? 1u : 0u) << j; }
+                if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) {
+                    if constexpr (SP) {
+                        const unsigned so = smap.offset(stile, j);
+                        pre[j] = da_buf_load4(rsn, so);
+                        if constexpr (PRO) vm |= (so != 0xFFFFFFFFu ? 1u : 0u) << j;
+                    } else { pre[j] = cur.next(); if constexpr (PRO) vm |= (cur.last_inb ? 1u : 0u) << j; }
+                }
             if constexpr (PRO_IN) {   // the deferred BatchNorm + activation of a staged quad, PRO_DELAY K-steps after its load was issued:
                                       // by then it has landed, and the VALU work hides under the other wave's MFMAs instead of sitting between the barriers
 #pragma unroll
@@ -554,13 +660,41 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                     }
             }
             const AElem* ap = step_ptr(s);
+            if constexpr (SP) {
+                // row pairs: the three planes' fragments of the NEXT pair (or of the next K-step's first pair) are read while the 12 * NREP
+                // MFMAs of the current pair issue.  Products smallest first: (a, b) plane pairs (h, l) (l, h) (m, m) (h, m) (m, h) (h, h).
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                const AElem* anx = (s + 1 < NSTEPS) ? step_ptr(s + 1) : ap;
+#pragma unroll
+                for (int qd = 0; qd < TY / 2; ++qd) {
+                    Frag AN[NP][2];
+                    const AElem* src = (qd + 1 < TY / 2) ? ap + (2 * qd + 2) * (HX * CK) : anx;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) AN[pl][rr] = *reinterpret_cast<const Frag*>(src + pl * PLANE_E + rr * (HX * CK));
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                            for (int rr = 0; rr < 2; ++rr)
+                                acc[2 * qd + rr][nn] = mma_bf(acc[2 * qd + rr][nn], AC[PA[pr] % NP][rr], bq[s % RB][nn][PB[pr] % NP]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) AC[pl][rr] = AN[pl][rr];
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < HALF; ++r) A1[r] = *reinterpret_cast<const Frag*>(ap + (HALF + r) * (HX * CK));
             if constexpr (BF) {
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                    for (int r = 0; r < HALF; ++r) acc[r][nn] = mma_bf(acc[r][nn], A0[r], bq[s % RB][nn]);
+                    for (int r = 0; r < HALF; ++r) acc[r][nn] = mma_bf(acc[r][nn], A0[r], bq[s % RB][nn][0]);
             } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -568,7 +702,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                 for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                     for (int r = 0; r < HALF; ++r)
-                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bq[s % RB][nn][m], acc[r][nn], 0, 0, 0);
+                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bq[s % RB][nn][0][m], acc[r][nn], 0, 0, 0);
                 if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
             }
             }
@@ -581,7 +715,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                    for (int r = 0; r < HALF; ++r) acc[HALF + r][nn] = mma_bf(acc[HALF + r][nn], A1[r], bq[s % RB][nn]);
+                    for (int r = 0; r < HALF; ++r) acc[HALF + r][nn] = mma_bf(acc[HALF + r][nn], A1[r], bq[s % RB][nn][0]);
             } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -589,7 +723,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                 for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                     for (int r = 0; r < HALF; ++r)
-                        acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bq[s % RB][nn][m], acc[HALF + r][nn], 0, 0, 0);
+                        acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bq[s % RB][nn][0][m], acc[HALF + r][nn], 0, 0, 0);
                 if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
             }
             }
@@ -664,15 +798,17 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             }
         }
         if (STATS && last && ((++tiles_done) & 1) == 0) stats_flush();
-        if constexpr (PRO && !PRO_IN) load_pro(has_next ? item + 1 : item);      // outside the branch: no vector memory in branches
+        if constexpr (PRO && !PRO_IN) load_pro(has_next ? 1 : 0);      // outside the branch: no vector memory in branches
         if constexpr (DYN) { if (!has_next) break; }
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
-            if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
-            else stage_write<CK, HZ, 0, PRE, BF>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
-            if constexpr (!PRO) stage_rest(item + 1);
+            if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
+            else stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
+            if constexpr (!PRO) stage_rest(1);
             __syncthreads();
         }
+        cK = nK; cCh = nCh; cN = nN; cZ = nZ; cY = nY; cX = nX;
+        advance();
     }
     if (p.clk && blockIdx.x == 17 && blockIdx.y == 0 && threadIdx.x == 0) { p.clk[0] = __builtin_readcyclecounter() - clk0; p.clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
     if constexpr (STATS) {
@@ -843,8 +979,15 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
 
 // packed B operand: wp[chunk][step][ntile][lane][m]
 __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
-                                        int CK, int NSTEPS, int NTpad, int flipped, long long total, int bf, int* zero_ctr, int nctr) {
+                                        int CK, int NSTEPS, int NTpad, int flipped, long long total, int bf, int* zero_ctr, int nctr,
+                                        int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
     if (zero_ctr && blockIdx.x == 0 && (int)threadIdx.x < nctr) zero_ctr[threadIdx.x] = 0;      // DYN tile counters of the launch that follows
+    // tile table of the launch that follows: brick-order position -> (sample, z0, y0, x0)
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < ntiles; pos += gridDim.x * blockDim.x) {
+        int n, tx, ty, tz;
+        brick_tile<2, 4, 8>(pos, ntx, nty, ntz, n, tx, ty, tz);                                 // brick = 32^3 voxels
+        tiles[pos] = make_int4(n, tz * 4, ty * TY, tx * TX);
+    }
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx & 3); const int lane = (int)((idx >> 2) & 63);
         long long rest = idx >> 8;
@@ -854,7 +997,7 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
         int tap, c4;
         if (CK == 16) { tap = s; c4 = g; } else { const int qd = s * 4 + g; tap = qd >> 1; c4 = qd & 1; }
         const int cin = ch * CK + c4 * 4 + m, cout = nt * 16 + j;
-        if (bf == 2) {      // v_mfma_f32_16x16x32_bf16: 8 bf16 per lane, lane group g = tap 2s + (g>>1), cin half g&1 (CK 16) | tap 4s + g (CK 8)
+        if (bf >= 2) {      // v_mfma_f32_16x16x32_bf16: 8 bf16 per lane, lane group g = tap 2s + (g>>1), cin half g&1 (CK 16) | tap 4s + g (CK 8)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int e = 2 * m + h;
@@ -863,7 +1006,12 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
                 float v2 = 0.f;
                 if (tp < 27 && cout < Cout && ci < Cin)
                     v2 = flipped ? w[((size_t)(26 - tp) * Cout + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * Cout + cout];
-                reinterpret_cast<unsigned short*>(wp)[idx * 2 + h] = __builtin_bit_cast(unsigned short, (__bf16)v2);
+                if (bf == 3) {      // split mode: three planes (h, m, l) of 1 KiB per (chunk, step, N-tile), the same exact split as da_split3
+                    unsigned short* o = reinterpret_cast<unsigned short*>(wp) + (idx >> 8) * 1536 + lane * 8 + e;
+                    const __bf16 bh = (__bf16)v2; const float r1 = v2 - (float)bh;
+                    const __bf16 bm = (__bf16)r1; const float r2 = r1 - (float)bm;
+                    o[0] = __builtin_bit_cast(unsigned short, bh); o[512] = __builtin_bit_cast(unsigned short, bm); o[1024] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+                } else reinterpret_cast<unsigned short*>(wp)[idx * 2 + h] = __builtin_bit_cast(unsigned short, (__bf16)v2);
             }
             continue;
         }
@@ -1267,9 +1415,12 @@ static int pick_nrep(int NT) { return NT <= 3 ? NT : (NT % 2 == 0 ? 2 : (NT % 3 
 static const int kDynCtrInts = 256;          // tile counters [<= 32 cout groups][8 XCDs] behind the packed weights
 static size_t packed_bytes(int Cin, int Cout, int CK) {
     const int NT = (Cout + 15) / 16, NREP = pick_nrep(NT);
-    const int NTpad = (NT + NREP - 1) / NREP * NREP;
+    const int NTpad = ((NT + NREP - 1) / NREP * NREP + 1) & ~1;      // (even: the bf16 / split modes use <= 2 N-tiles per workgroup)
     const int NSTEPS = (27 * CK + 15) / 16;
-    return da_align((size_t)(Cin / CK) * NSTEPS * NTpad * 256 * sizeof(float)) + da_align(kDynCtrInts * sizeof(int));
+    size_t b = (size_t)(Cin / CK) * NSTEPS * NTpad * 256 * sizeof(float);
+    const size_t sp = (size_t)(Cin / 8) * 7 * NTpad * 3072;           // split mode: 8-channel chunks, 7 K-steps of 32, three 1 KiB planes
+    if (Cin % 8 == 0 && sp > b) b = sp;
+    return da_align(b) + da_align(kDynCtrInts * sizeof(int));
 }
 
 struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; };
@@ -1295,7 +1446,11 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout) {
 
 }  // namespace
 
+static size_t tile_table_bytes(int N, int D, int H, int W) {
+    return da_align((size_t)N * ((D + 3) / 4) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * sizeof(int4));
+}
 static const int kScBlocksFwd = 1024;
+// layout of a forward / data-gradient call: [packed weights | tile counters][tile table]; of a weight-gradient call: [partials]
 size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int stride) {
     if (stride != 1) return 0;
     size_t pk = 0;
@@ -1305,7 +1460,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
     if (Cin % 8 == 0) part = wgrad_plan(N, D, H, W, Cin, 0, Cout).partial_bytes;
     if (Cin <= 4 && Cout <= 32) part = da_align((size_t)kScBlocksFwd * 27 * Cin * Cout * sizeof(float));
     if (Cout <= 4 && Cin <= 32) { const size_t sw = da_align((size_t)(kScBlocksFwd + 1) * 27 * Cin * Cout * sizeof(float)); if (sw > part) part = sw; }   // swapped-operand weight gradient
-    return pk + part;
+    return pk + tile_table_bytes(N, D, H, W) + part;
 }
 
 bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, int Cs2) {
@@ -1320,10 +1475,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
-    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN>;
+    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 3 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1370,10 +1525,12 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
                       void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro) {
     (void)stride;
     const int Cin = C1 + C2;
-    const int CK = pick_ck(C1, C2);
+    int CK = pick_ck(C1, C2);
     if (!CK) return DA_ERR_UNSUPPORTED;
     if (pro && (s2d_cin > 0 || w_is_flipped_tr || Cin > kProMaxC)) return DA_ERR_UNSUPPORTED;
-    const bool bf = da_matrix_bf16();
+    const bool split = da_matrix_mode() == 2 && s2d_cin == 0;      // (the sparse-tap stride-2 route keeps the native fp32 kernels)
+    const bool bf = da_matrix_mode() == 1;
+    if (split) CK = 8;
     {   // every tensor is addressed per sample through a buffer descriptor with 32-bit byte offsets
         const unsigned long long vox4 = (unsigned long long)D * H * W * 4ull;
         const int cmax = (C1 > C2 ? C1 : C2) > (Cs1 > Cs2 ? Cs1 : Cs2) ? (C1 > C2 ? C1 : C2) : (Cs1 > Cs2 ? Cs1 : Cs2);
@@ -1381,7 +1538,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     const int NT = (Cout + 15) / 16;
     int NREP = pick_nrep(NT);
-    if ((bf || pro) && NREP > 2) NREP = 2;        // bf16 mode is not matrix-bound, three N-tiles would spill; the prologue variant parks the whole next tile in registers
+    if ((bf || split || pro) && NREP > 2) NREP = 2;        // bf16 mode is not matrix-bound, three N-tiles would spill; the prologue variant parks the whole next tile in registers
     {   // Coarse levels have few tiles (30 per volume at 20x24x20, 180 at 40x48x40): the persistent grid then runs one or two
         // uneven rounds.  Makespan model: a workgroup walks ceil(tiles / nblk) tiles, each costing ~NREP (one N-tile per
         // workgroup is ~8 % less efficient per FLOP but quadruples / doubles the number of work items); take the cheaper.
@@ -1397,19 +1554,23 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         }
     }
     const int gy = (NT + NREP - 1) / NREP, NTpad = gy * NREP;
-    const int pkmode = bf ? (s2d_cin > 0 ? 1 : 2) : 0;       // 0 fp32 | 1 bf16, one tap per K-step (sparse taps) | 2 bf16, K = 32 per step
-    const int NSTEPS = pkmode == 2 ? (CK == 16 ? 14 : 7) : (27 * CK + 15) / 16;
+    const int pkmode = split ? 3 : bf ? (s2d_cin > 0 ? 1 : 2) : 0;       // 0 fp32 | 1 bf16, one tap per K-step (sparse taps) | 2 bf16, K = 32 per step | 3 split: three bf16 planes, K = 32
+    const int NSTEPS = pkmode >= 2 ? (CK == 16 ? 14 : 7) : (27 * CK + 15) / 16;
     const size_t pk = packed_bytes(Cin, Cout, CK);
-    if (ws_bytes < pk) return DA_ERR_WS_SMALL;
+    if (ws_bytes < pk + tile_table_bytes(N, D, H, W)) return DA_ERR_WS_SMALL;
     float* wp = (float*)ws;
+    int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + pk);
     const long long total = (long long)(Cin / CK) * NSTEPS * NTpad * 256;
     int* dyn_ctr = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pk - da_align(kDynCtrInts * sizeof(int)));
     static int dyn_env = -1; if (dyn_env < 0) { const char* e = getenv("DA_DYN_TILES"); dyn_env = (e && atoi(e)) ? 1 : 0; }
-    const bool dyn = dyn_env && !bf && !pro && s2d_cin == 0 && !stats_partial && gy * 8 <= kDynCtrInts;
-    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode,
-                       dyn ? dyn_ctr : nullptr, gy * 8);
-    DA_LAUNCH_CHECK();
+    const bool dyn = dyn_env && !bf && !split && !pro && s2d_cin == 0 && !stats_partial && gy * 8 <= kDynCtrInts;
     FwdP p;
+    p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
+    p.ntiles = N * p.ntz * p.nty * p.ntx;
+    hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total > p.ntiles ? total : p.ntiles, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode,
+                       dyn ? dyn_ctr : nullptr, gy * 8, tiles, p.ntiles, p.ntx, p.nty, p.ntz);
+    DA_LAUNCH_CHECK();
+    p.tiles = tiles;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.wp = wp; p.bias = bias;
     p.out1 = out1; p.out2 = out2; p.Cs1 = Cs1; p.Cs2 = Cs2;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.NT = NTpad;
@@ -1438,6 +1599,14 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         if (pro_slopes(pro, C2, &p.pslope1, &p.pslope2)) return DA_ERR_UNSUPPORTED;
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
+    }
+    if (split) {
+        if (stats_partial && stats_nparts) *stats_nparts = p.nblocks;
+#define DA_SP_CASE(nr) if (NREP == nr) return stats_partial ? (pro ? launch_fwd_mfma<8, nr, false, true, true, true, false, true>(p, gy, st) : launch_fwd_mfma<8, nr, false, true, true, false, false, true>(p, gy, st)) \
+                                                              : (pro ? launch_fwd_mfma<8, nr, false, false, true, true, false, true>(p, gy, st) : launch_fwd_mfma<8, nr, false, false, true, false, false, true>(p, gy, st))
+        DA_SP_CASE(1); DA_SP_CASE(2);
+#undef DA_SP_CASE
+        return DA_ERR_UNSUPPORTED;
     }
     if (stats_partial && p.maskmode == 0 && (CK == 16 || CK == 8) && NREP <= 2) {
         if (stats_nparts) *stats_nparts = p.nblocks;
@@ -1469,13 +1638,22 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     return DA_ERR_UNSUPPORTED;
 }
 
-// bf16 matrix mode: process-wide switch (like da_set_conv_direct); returns the previous setting
-static int g_matrix_bf16 = -1;          // -1: not decided yet (env DA_MATRIX_BF16=1 turns it on for tools)
-bool da_matrix_bf16() {
-    if (g_matrix_bf16 < 0) { const char* e = getenv("DA_MATRIX_BF16"); g_matrix_bf16 = (e && atoi(e) != 0) ? 1 : 0; }
-    return g_matrix_bf16 != 0;
+// matrix mode of the 3x3x3 convolutions: process-wide switch (like da_set_conv_direct); the setters return the previous setting.
+//   0  fp32 operands on v_mfma_f32_16x16x4_f32 (an fmaf chain)
+//   1  operands ROUNDED to bf16 (BASELINE configs[4]'s precision; not fp32-accurate)
+//   2  fp32 operands split exactly into three bf16 terms, six partial products per multiply on the bf16 pipe, fp32 accumulate
+static int g_matrix_mode = -1;          // -1: not decided yet (env DA_MATRIX_MODE=0|1|2, or the older DA_MATRIX_BF16=1, for tools)
+int da_matrix_mode() {
+    if (g_matrix_mode < 0) {
+        const char* m = getenv("DA_MATRIX_MODE"); const char* e = getenv("DA_MATRIX_BF16");
+        g_matrix_mode = m ? atoi(m) : ((e && atoi(e) != 0) ? 1 : 0);
+        if (g_matrix_mode < 0 || g_matrix_mode > 2) g_matrix_mode = 0;
+    }
+    return g_matrix_mode;
 }
-extern "C" int da_set_matrix_bf16(int on) { const int prev = da_matrix_bf16() ? 1 : 0; g_matrix_bf16 = on ? 1 : 0; return prev; }
+bool da_matrix_bf16() { return da_matrix_mode() == 1; }
+extern "C" int da_set_matrix_bf16(int on) { const int prev = da_matrix_mode() == 1 ? 1 : 0; g_matrix_mode = on ? 1 : 0; return prev; }
+extern "C" int da_set_matrix_mode(int mode) { const int prev = da_matrix_mode(); if (mode < 0 || mode > 2) return -1; g_matrix_mode = mode; return prev; }
 
 static bool smallcin_ok(int C1, int C2, int Cout, int stride) { return stride == 1 && C1 + C2 <= 4 && Cout <= 32; }   // + 32-bit offsets, checked at launch
 static const int kScBlocks = 1024;

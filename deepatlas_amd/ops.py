@@ -65,15 +65,21 @@ _side_keep = []          # tensors the side stream still reads: referenced until
                          # event-polled frees made the caching allocator fall back to hipMalloc on random steps (40 -> 64 ms)
 
 
+MATRIX_MODES = ('fp32', 'bf16', 'fp32_split')
+
+
 def set_matrix_precision(mode):
-    """'fp32' (default: exact fp32 MFMA, the reference's arithmetic) or 'bf16': the 3x3x3 convolutions round their operands to bf16
-    while staging them and accumulate in fp32 on the bf16 matrix pipe (BASELINE config 5); everything else stays fp32.
-    Process-wide; returns the previous mode."""
-    if mode not in ('fp32', 'bf16'):
-        raise ValueError("matrix precision must be 'fp32' or 'bf16', got %r" % (mode,))
+    """Arithmetic of the 3x3x3 convolutions on the matrix cores (process-wide; returns the previous mode):
+    'fp32'        fp32 operands on the fp32 matrix instructions (one fmaf per product, like the reference's CPU convolution);
+    'fp32_split'  fp32 operands split exactly into three bf16 terms, six partial products per multiply on the bf16 matrix pipe with fp32
+                  accumulation: fp32-accurate (error against double not larger than 'fp32', tests/test_gpu_split.py) at 6/16 of the
+                  matrix time;
+    'bf16'        operands ROUNDED to bf16 (BASELINE config 5); everything else stays fp32."""
+    if mode not in MATRIX_MODES:
+        raise ValueError("matrix precision must be one of %r, got %r" % (MATRIX_MODES, mode))
     from ._native import lib
-    prev = lib().da_set_matrix_bf16(1 if mode == 'bf16' else 0)
-    return 'bf16' if prev else 'fp32'
+    prev = lib().da_set_matrix_mode(MATRIX_MODES.index(mode))
+    return MATRIX_MODES[prev]
 
 
 # Every kernel of the package reduces in a fixed order (per-block partials + a second launch) except ONE: the scatter of the trilinear

@@ -106,6 +106,15 @@ int da_set_conv_direct(int on);
  * v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm, losses and the optimiser stay fp32.
  * Off by default (exact fp32 v_mfma_f32_16x16x4_f32); returns the previous setting. */
 int da_set_matrix_bf16(int on);
+/* Matrix mode of the 3x3x3 convolutions (forward, data gradient, weight gradient); returns the previous mode, -1 for an unknown one.
+ *   0  fp32 operands on v_mfma_f32_16x16x4_f32 -- one fmaf per product, the arithmetic of the reference's nn.Conv3d on the CPU
+ *      (lib/network_factory/modules.py:48);
+ *   1  = da_set_matrix_bf16(1): operands ROUNDED to bf16 (not fp32-accurate);
+ *   2  "split": every fp32 operand is decomposed EXACTLY into three bf16 terms (x = h + m + l) and a product is formed from six of the
+ *      nine partial products (h h, h m, m h, m m, h l, l h) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The dropped terms are
+ *      below 2^-25 |x y|, i.e. below the rounding of one fp32 multiply-add: results are fp32-accurate (measured against double: not worse
+ *      than mode 0, tests/test_gpu_split.py), at 6/16 of the matrix-pipe time.  Tensors in HBM stay fp32. */
+int da_set_matrix_mode(int mode);
 
 /* ---- 1x1x1 convolution (segmentation head, row a5; unets.py:249-250) ------------------------- */
 /* scratch for the packed weights of the 1x1 / transposed-conv forward and data-gradient launchers */
