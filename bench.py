@@ -29,6 +29,17 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 matrix peak
+# 'fp32_split' (the headline's matrix mode): every fp32 product is six bf16 x bf16 partial products on the bf16 pipe, so the ceiling of
+# the ALGORITHMIC (2 * 27 * Cin * Cout per voxel) rate is the bf16 peak / 6
+SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+PRECISION_NOTE = {
+    'fp32': 'fp32 operands on v_mfma_f32_16x16x4_f32 (one fmaf per product)',
+    'fp32_split': 'fp32 tensors; in the 3x3x3 convolutions every operand is split EXACTLY into three bf16 terms and a product is the sum of six '
+                  'bf16 x bf16 partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate -- error against double not larger than the '
+                  'fmaf chain (tests/test_gpu_split.py); everything else is plain fp32',
+    'bf16': 'operands of the 3x3x3 convolutions ROUNDED to bf16, fp32 accumulate (BASELINE configs[4]); fp32 elsewhere',
+}
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
 
 # algorithmic conv FLOPs per voxel of one TRAINING pass (forward + data gradient + weight gradient = 3 x forward)
@@ -169,12 +180,12 @@ def make_workloads(args, dev, rank, which):
     if args.graph:
         seg_step = graphed([seg_grads, lambda: opt.step()], [lambda: parallel.allreduce_gradients(opt)], [opt], 'loss')
 
-    prec = 'fp32' if args.precision == 'fp32' else 'bf16 matrix mode'
+    prec = {'fp32': 'fp32', 'fp32_split': 'fp32', 'bf16': 'bf16 matrix mode'}[args.precision]
     out = {}
     if 'seg' in which:
         if args.net == 'UNet_light':
             nm = 'seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (BASELINE configs[1]%s)' % (
-                args.batch, shape[0], shape[1], shape[2], prec, '' if args.precision == 'fp32' else " shape with configs[4]'s precision")
+                args.batch, shape[0], shape[1], shape[2], prec, '' if args.precision != 'bf16' else " shape with configs[4]'s precision")
             fl = SEG_TRAIN_FLOP_PER_VOXEL * V * args.batch
         else:
             nm = 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (SURVEY row f3, not a BASELINE config)' % (
@@ -244,15 +255,17 @@ def result_of(wl, dt, per_rank, world, args, launches):
              c_abi_launches_per_step=round(launches, 1))
     if wl.flops_per_step:
         r['step_tflops'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12, 2)
-        if args.precision == 'fp32':
+        if args.precision != 'bf16':
             r['step_frac_of_fp32_mfma_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if args.precision == 'fp32_split':
+            r['step_frac_of_split_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / SPLIT_MFMA_PEAK_TFLOPS, 4)
     if world > 1:
         r['ms_per_step_per_rank'] = [round(t / args.steps * 1e3, 3) for t in per_rank]
     return r
 
 
-def call_table(summ):
-    """{(name, ints): (n, ms)} -> list of per-call records sorted by total time."""
+def call_table(summ, peak=FP32_MFMA_PEAK_TFLOPS):
+    """{(name, ints): (n, ms)} -> list of per-call records sorted by total time; frac = algorithmic TFLOP/s / `peak`."""
     rows = []
     for k, (n, ms) in summ.items():
         fl = conv_flops(k)
@@ -260,12 +273,12 @@ def call_table(summ):
             continue
         tf = fl * n / (ms * 1e-3) / 1e12
         rows.append(dict(call='%s%s' % (k[0], list(conv_dims(k))), launches=n, avg_ms=round(ms / n, 4), total_ms=round(ms, 3),
-                         tflops=round(tf, 2), frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), _key=k, _fl=fl))
+                         tflops=round(tf, 2), frac=round(tf / peak, 4), _key=k, _fl=fl))
     rows.sort(key=lambda r: -r['total_ms'])
     return rows
 
 
-def pmc_traffic_for(kname):
+def pmc_traffic_for(kname, precision):
     """HBM bytes per launch of a call from the newest committed PMC passes at this round (tools/pmc_conv.sh -> tools/pmc_summary.py):
     FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape.  A separate rocprofv3 run, not
     a measurement of this process -- `traffic_source` says so."""
@@ -275,6 +288,8 @@ def pmc_traffic_for(kname):
     try:
         doc = json.load(open(files[-1]))
         calls = doc['calls']
+        if doc.get('matrix_precision', 'fp32') != precision:
+            return None
     except (OSError, ValueError, KeyError):
         return None
     cands = [kname]
@@ -305,9 +320,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
     ap.add_argument('--no-extra', action='store_true', help="skip the reg / joint legs and the post-run backward-kernel timing pass")
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                    help="matrix arithmetic of the 3x3x3 convolutions: 'fp32' = the reference's arithmetic (the headline metric); 'bf16' = "
-                         "bf16 operands, fp32 accumulate (BASELINE configs[4]'s mixed precision; not the headline)")
+    ap.add_argument('--precision', default='fp32_split', choices=['fp32_split', 'fp32', 'bf16'],
+                    help="matrix arithmetic of the 3x3x3 convolutions.  'fp32_split' (headline): fp32 operands split exactly into three bf16 "
+                         "terms, six partial products per multiply on the bf16 pipe, fp32 accumulate -- fp32-accurate; 'fp32': the fp32 matrix "
+                         "instructions (one fmaf per product; also timed by the default run, under extra.native_fp32_mfma); 'bf16': operands "
+                         "ROUNDED to bf16 (BASELINE configs[4]'s mixed precision; not fp32-accurate, never the headline)")
     ap.add_argument('--graph', action='store_true', help='capture each step once as HIP graph(s) and replay it (one host call per step; per-call '
                     'HIP-event timing is then taken in the eager post-run pass only)')
     ap.add_argument('--no-fused-head', action='store_true', help='run the 1x1x1 head, softmax and Dice as separate kernels (logits materialised)')
@@ -363,7 +380,8 @@ def main():
     head_res = result_of(head, dt, per_rank, world, args, launches)
 
     bwd_rows = []
-    if prof is not None and not args.no_extra and args.precision == 'fp32':
+    peak = SPLIT_MFMA_PEAK_TFLOPS if args.precision == 'fp32_split' else FP32_MFMA_PEAK_TFLOPS
+    if prof is not None and not args.no_extra and args.precision != 'bf16':
         # post-run pass: 3 steps with every conv call timed and the weight gradients on the MAIN stream (nothing overlaps: clean
         # per-kernel durations of the data / weight gradients).  Not part of `value`.
         ops.enable_async_wgrad(False)
@@ -376,23 +394,36 @@ def main():
         torch.cuda.synchronize()
         nat.profiler = None
         ops.enable_async_wgrad(not args.sync_wgrad)
-        bwd_rows = call_table(p2.summary())
+        bwd_rows = call_table(p2.summary(), peak)
 
     extra = {}
     for leg in extra_legs:
         edt, eper, eloss, _, elaunch = time_workload(wls[leg], args, world, dev, None)
         extra[leg] = dict(result_of(wls[leg], edt, eper, world, args, elaunch), final_loss=round(eloss, 6))
+    if args.precision == 'fp32_split' and not args.no_extra and not args.graph:
+        # the same headline workload on the fp32 matrix instructions (mode 'fp32'), same --steps / --warmup: the A/B of the split mode
+        ops.set_matrix_precision('fp32')
+        a2 = argparse.Namespace(**dict(vars(args), precision='fp32'))
+        edt, eper, eloss, _, elaunch = time_workload(head, a2, world, dev, None)
+        extra['native_fp32_mfma'] = dict(result_of(head, edt, eper, world, a2, elaunch), final_loss=round(eloss, 6),
+                                         matrix_arithmetic=PRECISION_NOTE['fp32'])
+        ops.set_matrix_precision(args.precision)
 
     if rank == 0:
         roofline = None
         if prof is not None:
-            rows = call_table(prof.summary())
+            rows = call_table(prof.summary(), peak)
             tot_fl = sum(r['_fl'] * r['launches'] for r in rows)
             tot_ms = sum(r['total_ms'] for r in rows)
             top = rows[0]                                                       # forward call with the most time in the timed region
             if args.precision == 'bf16':     # bf16 matrix mode: the convolutions are no longer matrix-bound -> price the call against HBM
                 gbs = conv_bytes(top['_key']) * top['launches'] / (top['total_ms'] * 1e-3) / 1e9
                 rl_head = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
+            elif args.precision == 'fp32_split':
+                rl_head = dict(bound='mfma', achieved=top['tflops'], peak=round(SPLIT_MFMA_PEAK_TFLOPS, 1), unit='TFLOP/s', frac=top['frac'], traffic=None,
+                               peak_note='algorithmic fp32 FLOPs (2*27*Cin*Cout per voxel) against the dense bf16 matrix peak / 6: the split mode '
+                                         'issues six bf16 MFMA products per fp32 multiply',
+                               frac_of_fp32_mfma_peak=round(top['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4))
             else:
                 rl_head = dict(bound='mfma', achieved=top['tflops'], peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=top['frac'], traffic=None)
             roofline = dict(rl_head, kernel=top['call'], avg_ms=top['avg_ms'], launches=top['launches'], flops_per_launch=top['_fl'],
@@ -400,12 +431,14 @@ def main():
                             traffic_source=None, profiled_calls=CONV_FWD_CALLS,
                             all_profiled=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
                                               frac_of_step=round(tot_ms / args.steps / head_res['ms_per_step'], 3)))
-            if args.precision == 'fp32':
-                pm = pmc_traffic_for(top['call'])
+            if args.precision != 'bf16':
+                pm = pmc_traffic_for(top['call'], args.precision)
                 if pm:
                     roofline.update(pm)
-            if head.flops_per_step and args.precision == 'fp32':
-                roofline['step_frac'] = head_res['step_frac_of_fp32_mfma_peak']       # algorithmic conv FLOPs per step / ms_per_step / peak
+            if head.flops_per_step and args.precision != 'bf16':
+                # algorithmic conv FLOPs per step / ms_per_step / the peak of the mode
+                roofline['step_frac'] = head_res['step_frac_of_split_peak' if args.precision == 'fp32_split' else 'step_frac_of_fp32_mfma_peak']
+                roofline['step_frac_of_fp32_mfma_peak'] = head_res['step_frac_of_fp32_mfma_peak']
                 roofline['step_tflops'] = head_res['step_tflops']
             if bwd_rows:
                 # the same layer's three kernels (forward / data gradient / weight gradient) without overlap, and the slowest training
@@ -423,14 +456,15 @@ def main():
                     all_conv_calls=dict(tflops=round(sum(r['_fl'] * r['launches'] for r in bwd_rows) / (sum(r['total_ms'] for r in bwd_rows) * 1e-3) / 1e12, 2),
                                         ms_per_step=round(sum(r['total_ms'] for r in bwd_rows) / 3, 3)))
         metric = 'training volumes/sec at 160x192x160 fp32; Dice vs CPU ref'          # BASELINE.json's metric (the default invocation)
-        if shape != (160, 192, 160) or args.precision != 'fp32':
-            metric = 'training volumes/sec at %dx%dx%d %s' % (shape[0], shape[1], shape[2], 'fp32' if args.precision == 'fp32' else 'bf16 matrix mode')
+        if shape != (160, 192, 160) or args.precision == 'bf16':
+            metric = 'training volumes/sec at %dx%dx%d %s' % (shape[0], shape[1], shape[2], 'fp32' if args.precision != 'bf16' else 'bf16 matrix mode')
         line = dict(metric=metric, value=head_res['value'], unit='volumes/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head_res['ms_per_step'],
                     higher_is_better=True, scaling='weak', vs_baseline=None,
-                    dtype='f32' if args.precision == 'fp32' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
+                    dtype='f32' if args.precision != 'bf16' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
                     config=dict(workload=head.name, global_batch=world * head.units, volume=list(shape), n_classes=n_classes,
                                 parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision,
+                                matrix_arithmetic=PRECISION_NOTE[args.precision],
                                 c_abi_launches_per_step=head_res['c_abi_launches_per_step'], hip_graph=bool(args.graph), rccl=rccl,
                                 ms_per_step_per_rank=head_res.get('ms_per_step_per_rank')),
                     roofline=roofline, extra=extra or None)

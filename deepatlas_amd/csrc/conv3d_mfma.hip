@@ -1038,16 +1038,21 @@ struct WgP {
 // Its fragments need 4 consecutive VOXELS of one channel per lane while the tiles are channel-contiguous, which is exactly
 // what ds_read_b64_tr_b16 delivers: in each 16-lane group lane s supplies the address of (voxel 4g + s/4, channel quad s%4)
 // and receives (voxels 4g .. 4g+3, channel s) -- checked in tools/ubench/ds_read_tr16.hip.
-template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets; PRO: input prologue (BN + act applied to x while staging)
+// SP (split mode, see conv3_mfma_fwd_kernel): x and dY are split exactly into three bf16 planes while they are staged; K = 32 = two
+// rows of 16 voxels per v_mfma_f32_16x16x32_bf16 (lane group g: row 2 rp + (g >> 1), voxels 8 (g & 1) .. + 7 = two transpose reads), six
+// products per (tap slot, N-tile, row pair); the fragments of the next two tap slots are read while the current two slots' MFMAs issue.
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets; PRO: input prologue (BN + act applied to x while staging)
 __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(!(BF && YS), "bf16 mode stages dY in channel quads");
+    static_assert(!SP || (BF && !MASKED && CK == 8), "split mode: dense bf16 kernels on 8-channel chunks");
+    constexpr int NP = SP ? 3 : 1;
     constexpr int TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
     constexpr int CG = NREP * 16;
     constexpr int TPW = (CK == 16) ? 7 : 4;                     // tap slots per wave (CK = 8: tap PAIRS, 14 in total)
     constexpr bool SWZ = !BF && (CG % 32) == 0;
     float* ldsA = lds;
-    float* ldsY = BF ? lds + HZ * HY * HX * CK / 2 : lds + HZ * HY * HX * CK;
+    float* ldsY = BF ? lds + HZ * HY * HX * CK / 2 * NP : lds + HZ * HY * HX * CK;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
@@ -1139,8 +1144,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         }
     };
     auto write_lds = [&]() {
-        if constexpr (PRO) stage_write_pro<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA, vmA, psc, psf, pslope);
-        else stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA);
+        if constexpr (PRO) stage_write_pro<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF, SP>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF, SP>(ldsA, preA);
         // dY tile [TVOX][CG] (channel halves XOR-swizzled by voxel parity when CG % 32 == 0)
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
@@ -1149,7 +1154,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             int c = c4 * 4;
             if (SWZ) c ^= (v & 1) << 4;
             if (idx < TVOX * QY) {
-                if constexpr (BF) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));   // linear [v][CG] in bf16
+                if constexpr (SP) {
+                    uint2 h, m, l; da_split3(preY[it], h, m, l);
+                    reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
+                } else if constexpr (BF) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));   // linear [v][CG] in bf16
                 else *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
             }
         }
@@ -1164,7 +1172,72 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         // steps use compile-time offsets (ds_read immediates), so the VALU work per 28*NREP MFMAs is a handful of adds.
         // Fragments of step j+1 are read while the MFMAs of step j issue (hipcc otherwise serialises read->wait->mfma).
         const int swz = SWZ ? ((g & 1) << 4) : 0;             // voxel parity == g & 1 (row base and 4*j are even)
-        if constexpr (BF) {
+        if constexpr (SP) {
+            typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+            const short* ldsAh = reinterpret_cast<const short*>(ldsA);
+            const short* ldsYh = reinterpret_cast<const short*>(ldsY);
+            constexpr int PLA = HZ * HY * HX * CK, PLY = TVOX * CG;            // elements per plane
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // (x, dY) plane pairs, smallest products first
+            constexpr int NU = (TVOX / 32) * 2;                                    // units: (row pair, tap-slot pair)
+            // lane (i, g): source address of the transpose reads = voxel 8 (g & 1) + (i >> 2) [+ 4] of row 2 rp + (g >> 1), channel quad i & 3
+            auto tr8 = [&](const short* q, int step) -> bf16x8 {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)q);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(q + step));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+            auto rowA = [&](int rp) -> const short* {
+                const int row = 2 * rp + (g >> 1);
+                return ldsAh + (((row >> 3) * HY + (row & 7)) * HX + 8 * (g & 1) + (i >> 2)) * CK;
+            };
+            auto rowY = [&](int rp) -> const short* {
+                const int row = 2 * rp + (g >> 1);
+                return ldsYh + (row * 16 + 8 * (g & 1) + (i >> 2)) * CG + (i & 3) * 4;
+            };
+            auto loadA = [&](int u, bf16x8 (&a)[2][NP]) {
+                const short* ar = rowA(u >> 1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) a[kk][pl] = tr8(ar + offA[2 * (u & 1) + kk] + pl * PLA, 4 * CK);
+            };
+            auto loadB = [&](int rp, bf16x8 (&b)[NREP][NP]) {
+                const short* yr = rowY(rp);
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) b[nn][pl] = tr8(yr + nn * 16 + pl * PLY, 4 * CG);
+            };
+            const bool slot3 = wave + 12 < 14;                                     // waves 2, 3 own three tap pairs, not four
+            bf16x8 aC[2][NP], bC[NREP][NP];
+            loadB(0, bC); loadA(0, aC);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 aN[2][NP], bN[NREP][NP];
+                if (u + 1 < NU) { loadA(u + 1, aN); if ((u & 1) == 1) loadB((u + 1) >> 1, bN); }
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int nn = 0; nn < NREP; ++nn) {
+                        acc[2 * (u & 1)][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aC[0][PA[pr] % NP], bC[nn][PB[pr] % NP], acc[2 * (u & 1)][nn], 0, 0, 0);
+                        if ((u & 1) == 0 || slot3)
+                            acc[2 * (u & 1) + 1][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aC[1][PA[pr] % NP], bC[nn][PB[pr] % NP], acc[2 * (u & 1) + 1][nn], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < NU) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) aC[kk][pl] = aN[kk][pl];
+                    if ((u & 1) == 1) {
+#pragma unroll
+                        for (int nn = 0; nn < NREP; ++nn)
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl) bC[nn][pl] = bN[nn][pl];
+                    }
+                }
+            }
+        } else if constexpr (BF) {
             typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
             const short* ldsAh = reinterpret_cast<const short*>(ldsA);
             const short* ldsYh = reinterpret_cast<const short*>(ldsY);
@@ -1424,11 +1497,12 @@ static size_t packed_bytes(int Cin, int Cout, int CK) {
 }
 
 struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; };
-static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout) {
+static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, bool split = false) {
     WgPlan q;
     q.CK = pick_ck(C1, C2);
     const int NT = (Cout + 15) / 16;
     q.NREP = NT >= 2 ? 2 : 1;
+    if (split && q.CK) { q.CK = 8; q.NREP = 1; }             // split mode: three bf16 planes of x and dY in LDS -> 8-channel chunks, one cout tile
     q.ngroups = (NT + q.NREP - 1) / q.NREP;
     q.nchunks = q.CK ? (C1 + C2) / q.CK : 1;
     q.ntz = (D + 1) / 2; q.nty = (H + TY - 1) / TY; q.ntx = (W + TX - 1) / TX;
@@ -1742,10 +1816,10 @@ __global__ void swapped_wgrad_place_kernel(const float* __restrict__ tmp, float*
     }
 }
 
-template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false>
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
-    const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4);
-    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF, PRO>;
+    const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4) * (SP ? 3 : 1);
+    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF, PRO, SP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1814,7 +1888,8 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         DA_LAUNCH_CHECK();
         return 0;
     }
-    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout);
+    const bool split = da_matrix_mode() == 2 && s2d_cin == 0 && Cout % 4 == 0 && pick_ck(C1, C2) != 0;
+    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
@@ -1837,14 +1912,17 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
+        if (split) rcp = launch_wgrad_mfma<8, 1, false, false, true, true, true>(p, q, st);
+        else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
-        DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2);
+        { DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2); }
 #undef DA_WP_CASE
         if (rcp) return rcp;
         return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (p.maskmode != 0) {
+    if (split) rc = launch_wgrad_mfma<8, 1, false, false, true, false, true>(p, q, st);
+    else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
         if (bf) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true>(p, q, st);
         else rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true>(p, q, st);
