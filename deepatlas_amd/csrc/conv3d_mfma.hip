@@ -60,8 +60,11 @@ template <int CK, int HZ> struct StageGeom {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t da_rsrc(const float* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+__device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // round-to-nearest-even, ONE v_cvt_pk_bf16_f32 for the pair
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 // Split mode (SP): x = h + m + l EXACTLY, each term a bf16 -- h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even of
 // the running remainder (3 x 8 significand bits cover fp32's 24; the subtractions are exact in fp32).  Four values at a time, packed
@@ -1032,7 +1035,16 @@ struct WgP {
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, tiles_per_slab, O;
     unsigned masks[16]; int maskmode;   // per channel chunk tap masks (0 = all taps)
     const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: see FwdP
+    const int4* tiles;                  // split kernel: (n, z0, y0, x0) per brick-order position (wgrad_tiles_kernel)
 };
+
+__global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < ntiles; pos += gridDim.x * blockDim.x) {
+        int n, tx, ty, tz;
+        brick_tile<2, 4, 16>(pos, ntx, nty, ntz, n, tx, ty, tz);                                // brick = 32^3 voxels
+        tiles[pos] = make_int4(n, tz * 2, ty * TY, tx * TX);
+    }
+}
 
 // BF (bf16 matrix mode): both LDS tiles hold bf16 and one v_mfma_f32_16x16x16_bf16 consumes a whole row of 16 voxels (K = 16).
 // Its fragments need 4 consecutive VOXELS of one channel per lane while the tiles are channel-contiguous, which is exactly
@@ -1321,6 +1333,208 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient in split mode, second form (the default): every wave owns two output rows of the 2 x 8 x 16 tile and ALL 27 taps.
+//   * K = 32 per v_mfma_f32_16x16x32_bf16 = 16 voxels along x times the tile's two z planes (lane group g: plane g >> 1, voxels
+//     8 (g & 1) .. + 7), so a shift along y moves whole fragments: the x fragment of halo row h serves (row, dy) = (h, 0), (h - 1, 1),
+//     (h - 2, 2) -- four fragments per tap class instead of six;
+//   * M = 16 rows = two taps x 8 cin that share dy: the nine (dz, dx) combinations form four pairs and one single (class 4, upper half
+//     idle: 27 taps in 30 slots);
+//   * the dY fragments of the wave's two rows are read once per tile and stay in registers for all 15 (class, dy) accumulators.
+// LDS reads per MFMA fall from ~1.3 to ~0.7 ds_read_b64_tr_b16, all four waves carry the same load, and the accumulators (per-wave
+// partial sums over the wave's rows) are reduced across the waves through LDS once, at the end of the persistent loop.
+// ---------------------------------------------------------------------------------------------------
+template <bool PRO>
+__global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CK = 8, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
+    constexpr int PLA = HZ * HY * HX * CK, PLY = TVOX * CG;                 // elements per plane
+    float* ldsA = lds;
+    float* ldsY = lds + PLA / 2 * 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+    const short* ldsAh = reinterpret_cast<const short*>(ldsA);
+    const short* ldsYh = reinterpret_cast<const short*>(ldsY);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4, q = i & 3, vq = i >> 2;
+    const int ch = blockIdx.y, cg = blockIdx.z;
+    const int cbase = ch * CK;
+    const float* src; int Cs, choff;
+    if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
+    unsigned vmA = 0;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
+    if constexpr (PRO) {
+        const int cofs = choff + ((int)threadIdx.x % StageGeom<CK, HZ>::Q) * 4;
+        psc = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.ps1 : p.ps2) + cofs);
+        psf = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.pt1 : p.pt2) + cofs);
+        pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
+    }
+    // transpose-read source of this lane: voxel 8 (g & 1) + vq [+ 4] of plane g >> 1, channel quad q = (tap half q >> 1, cin quad q & 1)
+    const int laneA = ((((g >> 1) * HY) + 2 * wave) * HX + 8 * (g & 1) + vq) * CK + (q & 1) * 4;
+    int offC[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int combo = (c < 4) ? 2 * c + (q >> 1) : 8;                   // (class 4, upper tap half: re-reads tap 8; its rows are never written)
+        offC[c] = ((combo / 3) * HY * HX + combo % 3) * CK;
+    }
+    const int laneY = ((((g >> 1) * TY) + 2 * wave) * TX + 8 * (g & 1) + vq) * CG + q * 4;
+    auto tr8 = [&](const short* a, int step) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    struct F3 { bf16x8 p[3]; };
+    auto loadF = [&](int c, int h) -> F3 {                                  // x fragment of class c, halo row 2 wave + h
+        F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * CK);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
+        return f;
+    };
+    auto loadY = [&](int r) -> F3 {                                         // dY fragment of output row 2 wave + r
+        F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(a + pl * PLY, 4 * CG);
+        return f;
+    };
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const TileWalk tw = tile_walk(p.ntiles);
+    constexpr int NITA = StageGeom<CK, HZ>::NIT, QY = CG / 4, NITY = (TVOX * QY + 255) / 256;
+    float4 preA[NITA], preY[NITY];
+    // Per-thread constants of the two staging patterns (the tile coordinates come from the table the launcher's tile kernel wrote):
+    // x halo: StageMap; dY: iteration `it` covers voxel v = it * 64 + threadIdx.x / 4, cout quad threadIdx.x % 4.
+    StageMap<CK, HZ> smap; smap.init();
+    const int yq4 = (cg * CG + ((int)threadIdx.x % QY) * 4);
+    const int yv0 = (int)threadIdx.x / QY;
+    auto issue_loads = [&](int tile) {
+        int pos = tw.lo + tile * tw.J; pos = pos < p.ntiles ? pos : p.ntiles - 1;
+        const int4 t = p.tiles[__builtin_amdgcn_readfirstlane(pos)];
+        const int n = t.x, z0 = t.y, y0 = t.z, x0 = t.w;
+        {
+            const long long sample = (long long)p.D * p.H * p.W * Cs;
+            const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+            const typename StageMap<CK, HZ>::Tile st = smap.tile(z0, y0, x0, p.D, p.H, p.W, Cs, choff, true);
+            if constexpr (PRO) vmA = 0;
+#pragma unroll
+            for (int it = 0; it < NITA; ++it) {
+                const unsigned so = smap.offset(st, it);
+                preA[it] = da_buf_load4(rs, so);
+                if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
+            }
+        }
+        const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (long long)n * sampleY, (unsigned)(sampleY * sizeof(float)));
+        const bool inside = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;      // wave-uniform: the whole dY tile exists
+        const int basev = (z0 * p.H + y0) * p.W + x0;
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int v = yv0 + it * (256 / QY);
+            const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+            unsigned off;
+            if (inside) off = (unsigned)(((basev + (vz * p.H + vy) * p.W + vx) * p.Cout + yq4) * 4);
+            else {
+                const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+                const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
+                off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * 4) : 0xFFFFFFFFu;
+            }
+            preY[it] = da_buf_load4(ry, off);
+        }
+    };
+    auto write_lds = [&]() {
+        if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, true>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, NITA, true, true>(ldsA, preA);
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < TVOX * QY) {
+                uint2 h, m, l; da_split3(preY[it], h, m, l);
+                reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
+            }
+        }
+    };
+    if (tw.cnt > 0) { issue_loads(0); write_lds(); }
+    __syncthreads();
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // (x, dY) plane pairs, smallest products first
+#pragma unroll 1
+    for (int tile = 0; tile < tw.cnt; ++tile) {
+        const bool has_next = tile + 1 < tw.cnt;
+        if (has_next) issue_loads(tile + 1);                    // next tile's global loads fly during this tile's MFMAs
+        F3 Y0 = loadY(0), Y1 = loadY(1);
+        F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            Fd = loadF(c, 3);
+            if (c < 4) Na = loadF(c + 1, 0);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {                    // output row 2 wave: halo rows 0, 1, 2 <-> dy 0, 1, 2
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa.p[PA[pr]], Y0.p[PB[pr]], acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y0.p[PB[pr]], acc[c][1], 0, 0, 0);
+                acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y0.p[PB[pr]], acc[c][2], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 4) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {                    // output row 2 wave + 1: halo rows 1, 2, 3
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y1.p[PB[pr]], acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y1.p[PB[pr]], acc[c][1], 0, 0, 0);
+                acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd.p[PA[pr]], Y1.p[PB[pr]], acc[c][2], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 4) { Fa = Na; Fb = Nb; Fc = Nc; }
+        }
+        if (has_next) {
+            __syncthreads();
+            write_lds();
+            __syncthreads();
+        }
+    }
+    // reduce the four waves' partial sums through LDS (two rounds of <= 30 KB), then wave 0 writes this slab's partial dW
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds);
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) red[((slot * 15) + c * 3 + d) * 64 + lane] = make_float4(acc[c][d][0], acc[c][d][1], acc[c][d][2], acc[c][d][3]);
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float4 v = red[((slot * 15) + c * 3 + d) * 64 + lane];
+                acc[c][d][0] += v.x; acc[c][d][1] += v.y; acc[c][d][2] += v.z; acc[c][d][3] += v.w;
+            }
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) add(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave == 0) {
+        add(0);
+        float* part = p.partial + (size_t)blockIdx.x * p.O;
+        const int Cin = p.C1 + p.C2;
+        const int co = cg * CG + i;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 4 * g + reg;
+                    const int combo = 2 * c + (row >> 3);
+                    const int tap = (combo / 3) * 9 + d * 3 + combo % 3, ci = row & 7;
+                    if (combo < 9 && co < p.Cout) part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[c][d][reg];
+                }
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
         double s = 0.0;
@@ -1523,6 +1737,9 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
 static size_t tile_table_bytes(int N, int D, int H, int W) {
     return da_align((size_t)N * ((D + 3) / 4) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * sizeof(int4));
 }
+static size_t wg_tile_table_bytes(int N, int D, int H, int W) {
+    return da_align((size_t)N * ((D + 1) / 2) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX) * sizeof(int4));
+}
 static const int kScBlocksFwd = 1024;
 // layout of a forward / data-gradient call: [packed weights | tile counters][tile table]; of a weight-gradient call: [partials]
 size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int stride) {
@@ -1534,7 +1751,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
     if (Cin % 8 == 0) part = wgrad_plan(N, D, H, W, Cin, 0, Cout).partial_bytes;
     if (Cin <= 4 && Cout <= 32) part = da_align((size_t)kScBlocksFwd * 27 * Cin * Cout * sizeof(float));
     if (Cout <= 4 && Cin <= 32) { const size_t sw = da_align((size_t)(kScBlocksFwd + 1) * 27 * Cin * Cout * sizeof(float)); if (sw > part) part = sw; }   // swapped-operand weight gradient
-    return pk + tile_table_bytes(N, D, H, W) + part;
+    return pk + tile_table_bytes(N, D, H, W) + part + wg_tile_table_bytes(N, D, H, W);
 }
 
 bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, int Cs2) {
@@ -1831,6 +2048,22 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     return 0;
 }
 
+template <bool PRO>
+static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
+    const size_t shm = (size_t)(4 * HY * HX * 8 + 2 * TY * TX * 16) * 2 * 3;
+    auto kern = conv3_split_wgrad_kernel<PRO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(q.nslabs, q.nchunks, q.ngroups), dim3(256), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static bool split_wgrad_v1() { static int v = -1; if (v < 0) { const char* e = getenv("DA_SPLIT_WGRAD_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
+
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro) {
     if (pro && (stride != 1 || s2d_cin > 0 || C1 + C2 > kProMaxC || pick_ck(C1, C2) == 0 || Cout % 4 != 0 || Cout <= 4)) return DA_ERR_UNSUPPORTED;
@@ -1893,8 +2126,15 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
-    if (ws_bytes < q.partial_bytes) return DA_ERR_WS_SMALL;
+    if (ws_bytes < q.partial_bytes + (split ? wg_tile_table_bytes(N, D, H, W) : 0)) return DA_ERR_WS_SMALL;
     WgP p;
+    p.tiles = nullptr;
+    if (split && !split_wgrad_v1()) {
+        int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
+        hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
+        DA_LAUNCH_CHECK();
+        p.tiles = tiles;
+    }
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.dy = dy; p.partial = (float*)ws;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout;
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles; p.tiles_per_slab = q.tps;
@@ -1912,7 +2152,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
-        if (split) rcp = launch_wgrad_mfma<8, 1, false, false, true, true, true>(p, q, st);
+        if (split) rcp = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, true, true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
         { DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2); }
@@ -1921,7 +2161,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (split) rc = launch_wgrad_mfma<8, 1, false, false, true, false, true>(p, q, st);
+    if (split) rc = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, false, true>(p, q, st) : launch_split_wgrad<false>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
         if (bf) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true>(p, q, st);
