@@ -1875,6 +1875,8 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     { static int abl = -1; if (abl < 0) { const char* e = getenv("DA_ABLATE"); abl = e ? atoi(e) : 0; } p.ablate = abl; }
     {   // one resident round: 2 workgroups per CU x 256 CUs, split over the cout groups
+        // (a third workgroup per CU for the split kernels -- 168 VGPRs, 3 x 52 KB of LDS -- was measured and dropped: in split mode the
+        // matrix pipe is already busy ~100 % of the shader cycles and the clock is set by the power limit)
         static int nres = -1; if (nres < 0) { const char* e = getenv("DA_FWD_BLOCKS"); nres = e ? atoi(e) : 512; }
         int nblk = nres / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
         if (nblk >= 8) nblk &= ~7;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)

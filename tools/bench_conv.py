@@ -24,6 +24,9 @@ def main():
     x2 = (torch.rand((N, D, H, W, C2), generator=g) * 2 - 1).to(dev) if C2 else None
     w = (torch.rand((27, C1 + C2, Cout), generator=g) * 0.2 - 0.1).to(dev)
     dy = (torch.rand((N, D, H, W, Cout), generator=g) * 2 - 1).to(dev)
+    if os.environ.get('DA_ZERO') == '1':          # power experiment: same instruction stream on all-zero operands (no toggling in the multipliers)
+        x1.zero_(); w.zero_(); dy.zero_()
+        if C2: x2.zero_()
     out = torch.empty_like(dy)
     dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
     dw = torch.empty_like(w)

@@ -1,9 +1,12 @@
 #!/bin/bash
 # GPU box (via gpurun): HBM traffic of the dominant conv layer (48->16 = concat 32+16, batch 2, 160x192x160), one counter per pass
 # as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Output: gpurun_out/pmc/*.csv
+# usage: tools/pmc_conv.sh [matrix mode: 2 = fp32_split (default, the headline), 0 = fp32 MFMA]
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
+export DA_MATRIX_MODE=${1:-2}
 O=gpurun_out/pmc; rm -rf $O; mkdir -p $O
+echo $DA_MATRIX_MODE > $O/matrix_mode.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --iters 3 > $O/$c.log 2>&1 < /dev/null
   f=$(ls $O/$c/*/*counter_collection.csv 2>/dev/null | head -1)

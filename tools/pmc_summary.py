@@ -29,18 +29,33 @@ def main():
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
             agg[k].append(float(r['Counter_Value']) * 1024.0)
+            agg[k + '@' + r['Grid_Size']].append(float(r['Counter_Value']) * 1024.0)          # same kernel, different launch shape (split mode: forward vs data gradient)
         for k, v in agg.items():
             v = v[1:] if len(v) > 1 else v          # first launch includes cold allocation effects
             per.setdefault(k, {})[c] = sum(v) / len(v)
-    # kernel template instantiations at HEAD: fwd <CK, NREP, MASKED, STATS, BF, PRO, DYN>, wgrad <CK, NREP, YS, MASKED, BF, PRO>
-    sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-           'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-           'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-           'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+    # kernel template instantiations at HEAD: fwd <CK, NREP, MASKED, STATS, BF, PRO, DYN, SP>, wgrad <CK, NREP, YS, MASKED, BF, PRO, SP>,
+    # split weight gradient conv3_split_wgrad_kernel<PRO>
+    mode = 0
+    try:
+        mode = int(open(os.path.join(src, 'matrix_mode.txt')).read().strip())
+    except (OSError, ValueError):
+        pass
+    if mode == 2:
+        # (the data gradient 16 -> 48 runs the forward kernel with one N-tile per workgroup and three cout groups: 168 x 3 workgroups)
+        sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_split_wgrad_kernel<false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+    else:
+        sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     vox = 2 * 160 * 192 * 160
     alg = {'fwd': vox * (48 + 16) * 4, 'dgrad': vox * (16 + 48) * 4, 'wgrad': vox * (48 + 16) * 4 + 27 * 48 * 16 * 4}
     res = {'unit': 'bytes per launch', 'counters': 'FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, KiB -> bytes)',
-           'layer': '3x3x3 conv 48(=32+16 concat) -> 16, batch 2, 160x192x160 fp32', 'calls': {}}
+           'layer': '3x3x3 conv 48(=32+16 concat) -> 16, batch 2, 160x192x160 fp32', 'calls': {},
+           'matrix_precision': {0: 'fp32', 1: 'bf16', 2: 'fp32_split'}.get(mode, 'fp32')}
     commit = '?'
     try:
         commit = open(os.path.join(src, 'commit.txt')).read().strip() or '?'
@@ -58,7 +73,9 @@ def main():
     fc = os.path.join(src, 'fetch_calib_FETCH_SIZE.csv')
     if os.path.isfile(fc):
         shutil.copyfile(fc, os.path.join(dst, '%s_fetch_calib_pmc_fetch_size.csv' % tag))
-        want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 29)}
+        # bytes of the 64-B sectors each kernel touches (= what has to cross the L2 - fabric interface): the 32-B-run shapes touch twice /
+        # as many sector bytes as they request
+        want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 29), 'stream_b128_run32<64>': float(1 << 30), 'stream_b128_run32<128>': float(1 << 29)}
         got = collections.defaultdict(list)
         for r in csv.DictReader(open(fc)):
             k = r['Kernel_Name'].split('(')[0].replace('void ', '')
@@ -67,7 +84,7 @@ def main():
         for k, v in got.items():
             v = v[1:] if len(v) > 1 else v
             m = sum(v) / len(v)
-            calib[k] = {'requested_bytes': want[k], 'fetch_size_bytes': m, 'requested_over_fetch_size': want[k] / m if m else None}
+            calib[k] = {'sector_bytes_touched': want[k], 'fetch_size_bytes': m, 'requested_over_fetch_size': want[k] / m if m else None}
     res['fetch_size_calibration'] = calib
     for k, name in sig.items():
         if k not in per:
@@ -82,13 +99,22 @@ def main():
         # same + dy = 1 contiguous; data gradient: dy = 1 contiguous.  raw = sum_s actual_s / factor_s with equal over-fetch ratios, so
         # actual = raw * sum_s B_s / sum_s (B_s / factor_s)
         b_half, b_contig = (0.0, 1.0) if 'dgrad' in name else ((2.0, 2.0) if 'wgrad' in name else (2.0, 1.0))
+        if mode == 2:
+            # split mode stages 8-channel chunks: in1 (32 channels) as 32-B runs at a 128-B stride, in2 / dy-as-input (16 channels) as 32-B runs at a
+            # 64-B stride; the weight gradient's dY tile is staged in whole 64-B voxel rows (contiguous).  "half" below = the 128-B-stride
+            # shape, "contig" = the 64-B-stride shape (+ the contiguous dY of the weight gradient, whose factor is folded in by weight)
+            fcc = fc_contig
+            fc_half = (calib.get('stream_b128_run32<128>') or {}).get('requested_over_fetch_size') or 1.0
+            f64 = (calib.get('stream_b128_run32<64>') or {}).get('requested_over_fetch_size') or 2.0
+            fc_contig = f64 if 'wgrad' not in name else 2.0 / (1.0 / f64 + 1.0 / fcc)
         share_half = b_half / (b_half + b_contig)
         fcorr = f * (b_half + b_contig) / (b_half / fc_half + b_contig / fc_contig)
         res['calls'][name] = {'kernel': k, 'fetch_bytes_raw': f, 'fetch_bytes': fcorr, 'write_bytes': w, 'traffic_bytes': fcorr + w,
                               'algorithmic_bytes': a, 'traffic_over_algorithmic': (fcorr + w) / a,
-                              'fetch_correction': 'raw FETCH_SIZE x %.4f: staged bytes are %.0f %% 64-B runs at a 128-B stride (calibration factor %.3f) and %.0f %% '
-                                                  'contiguous 16 B/lane (factor %.3f); raw = sum of actual / factor' % (fcorr / f if f else 0.0, 100 * share_half, fc_half,
-                                                                                                                   100 * (1 - share_half), fc_contig)}
+                              'fetch_correction': 'raw FETCH_SIZE x %.4f: %.0f %% of the staged bytes come from the 32-channel tensor (one 64-B sector per request, calibration '
+                                                  'factor %.3f) and %.0f %% from 16-channel tensors (adjacent sectors merge into 128-B requests tallied as 64 B, factor %.3f); '
+                                                  'raw = sum of actual / factor.  FETCH_SIZE counts L2 misses, Infinity-Cache hits included'
+                                                  % (fcorr / f if f else 0.0, 100 * share_half, fc_half, 100 * (1 - share_half), fc_contig)}
     # third pass (SQ block): matrix-pipe occupancy.  SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x (wave-level v_mfma_f32_16x16x4_f32 count),
     # summed over the 1024 SIMDs; divided by SIMDs and kernel duration it is the rate at which a SIMD's matrix pipe is busy, to be
     # read against the shader clock (2.4 GHz peak; ~1.95-2.0 GHz sustained under this load, DA_CLK probe in DESIGN.md 4.1).
@@ -97,10 +123,11 @@ def main():
         shutil.copyfile(fsq, os.path.join(dst, '%s_%s_pmc_sq_counters.csv' % (tag, layer)))
         sq = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(fsq)):
-            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            sq[k][r['Counter_Name']].append(float(r['Counter_Value']))
-            if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
-                sq[k]['duration_ns'].append(float(int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+            k0 = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            for k in (k0, k0 + '@' + r['Grid_Size']):
+                sq[k][r['Counter_Name']].append(float(r['Counter_Value']))
+                if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
+                    sq[k]['duration_ns'].append(float(int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
         for k, name in sig.items():
             v = sq.get(k)
             if not v or name not in res['calls']:

@@ -12,6 +12,8 @@ timeout 600 python bench.py --no-cpu-baseline --graph > $O/bench_graph.log 2>&1 
 grep '"metric"' $O/bench_graph.log | tail -1 > $O/bench_graph.json
 timeout 600 python bench.py --no-cpu-baseline --shape 192 224 192 > $O/bench_192x224x192.log 2>&1 < /dev/null
 grep '"metric"' $O/bench_192x224x192.log | tail -1 > $O/bench_192x224x192.json
+timeout 600 python bench.py --no-cpu-baseline --precision fp32 > $O/bench_fp32_mfma.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_fp32_mfma.log | tail -1 > $O/bench_fp32_mfma.json
 timeout 600 python bench.py --no-cpu-baseline --precision bf16 > $O/bench_bf16.log 2>&1 < /dev/null
 grep '"metric"' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
 timeout 600 python bench.py --no-cpu-baseline --precision bf16 --shape 192 224 192 > $O/bench_bf16_192x224x192.log 2>&1 < /dev/null
@@ -31,10 +33,20 @@ for w in seg reg joint; do
   timeout 600 python tools/step_calls.py $w 2>&1 | grep -v amdgpu.ids > $O/${w}_calls.txt
 done
 timeout 600 python tools/bench_losses.py 2>&1 | grep -v amdgpu.ids | grep -v '^\[' > $O/hbm_bound_calls.txt
-timeout 600 python tools/bench_conv.py --layer 32,16,16,2,160,192,160 2>&1 | grep -v amdgpu.ids > $O/conv_layers_isolated.txt
-timeout 600 python tools/bench_conv.py --layer 16,0,16,2,160,192,160 2>&1 | grep -v amdgpu.ids >> $O/conv_layers_isolated.txt
-timeout 600 python tools/bench_conv.py --layer 64,32,32,2,80,96,80 2>&1 | grep -v amdgpu.ids >> $O/conv_layers_isolated.txt
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_conv -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --iters 5 > $O/prof_conv.log 2>&1 < /dev/null
+rm -f $O/conv_layers_isolated.txt
+for m in 2 0; do
+  echo "# DA_MATRIX_MODE=$m ($([ $m = 2 ] && echo fp32_split || echo 'fp32 MFMA'))" >> $O/conv_layers_isolated.txt
+  for L in 32,16,16,2,160,192,160 16,0,16,2,160,192,160 8,0,16,2,160,192,160 64,32,32,2,80,96,80 64,64,64,2,40,48,40; do
+    DA_MATRIX_MODE=$m timeout 600 python tools/bench_conv.py --layer $L 2>&1 | grep -v amdgpu.ids >> $O/conv_layers_isolated.txt
+  done
+done
+echo "# power: the same split-mode kernels on all-zero operands (DA_ZERO=1), and the sustained shader clock of the forward kernel (DA_CLK=1)" >> $O/conv_layers_isolated.txt
+DA_MATRIX_MODE=2 DA_ZERO=1 timeout 600 python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --what fwd,dgrad,wgrad 2>&1 | grep -v amdgpu.ids >> $O/conv_layers_isolated.txt
+for z in 0 1; do echo "# DA_ZERO=$z" >> $O/conv_layers_isolated.txt; DA_MATRIX_MODE=2 DA_ZERO=$z DA_CLK=1 timeout 600 python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --what fwd --iters 3 2>&1 | grep clk | tail -2 >> $O/conv_layers_isolated.txt; done
+echo "# DA_MATRIX_MODE=0" >> $O/conv_layers_isolated.txt; DA_MATRIX_MODE=0 DA_CLK=1 timeout 600 python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --what fwd --iters 3 2>&1 | grep clk | tail -2 >> $O/conv_layers_isolated.txt
+timeout 300 tools/ubench/split_bf16 > $O/ubench_split_bf16.txt 2>&1
+timeout 300 tools/ubench/mfma_power > $O/ubench_mfma_power.txt 2>&1
+DA_MATRIX_MODE=2 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_conv -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --iters 5 > $O/prof_conv.log 2>&1 < /dev/null
 f=$(ls $O/prof_conv/*/*.db 2>/dev/null | head -1)
 if [ -n "$f" ]; then python tools/rocpd_summary.py "$f" > $O/conv3d_48to16_kernel_stats.txt 2>&1 < /dev/null; fi
 rm -rf $O/prof_conv

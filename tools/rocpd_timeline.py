@@ -17,7 +17,7 @@ def short(name):
 
 
 def is_matrix(name):
-    return name.startswith('conv3_mfma_')
+    return name.startswith('conv3_mfma_') or name.startswith('conv3_split_wgrad')
 
 
 def main():

@@ -19,7 +19,7 @@ class A:
 
 
 a = A()
-a.graph, a.shape, a.batch, a.net, a.precision, a.no_fused_head = False, shape, 2, 'UNet_light', os.environ.get('PRECISION', 'fp32'), os.environ.get('NO_FUSED_HEAD') == '1'
+a.graph, a.shape, a.batch, a.net, a.precision, a.no_fused_head = False, shape, 2, 'UNet_light', os.environ.get('PRECISION', 'fp32_split'), os.environ.get('NO_FUSED_HEAD') == '1'
 ops.enable_async_wgrad(False)
 ops.set_matrix_precision(a.precision)
 dev = torch.device('cuda', 0)
