@@ -237,6 +237,18 @@ __device__ __forceinline__ void da_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, byte_off, 0, 0);
 }
 template <bool B> struct BoolC { static constexpr bool value = B; };
+// Wave priority rotation (experiment, DA_PRIO_ROT=1; off by default).  The persistent kernels keep 2 - 3 workgroups per CU alive for the
+// whole launch, and the CU arbitrates instruction issue between their waves by priority, then by AGE: with equal priorities the
+// first-dispatched workgroup of a CU runs ~20 % faster than the last one for the whole kernel (DA_CLK=1 DA_CLK_DUMP=1: lifetimes 1.39 /
+// 1.67 / 1.91 ms on every CU for equal work, split-mode 48 -> 16 forward).  Rotating s_setprio over the co-resident workgroups once per work
+// item (rank = dispatch round, 256 workgroups per round) halves the spread of the finish times (508 -> 253 us) and changes the kernel time
+// by nothing (2.27 -> 2.28 ms): the kernel is power-bound, the early finishers' CUs were not wasted -- the survivors ran at a higher clock.
+__device__ __forceinline__ void da_setprio(int p) {
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
 // lane ^ 1 / lane ^ 2 exchanges inside a lane quad as DPP quad_perm moves (VALU, no trip through the LDS crossbar like __shfl_xor)
 __device__ __forceinline__ float da_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float da_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
@@ -290,6 +302,7 @@ struct FwdP {
     int* dyn_ctr;    // DYN: tile counters [gridDim.y][8 XCDs], zeroed by the pack kernel of the same call
     const int4* tiles;   // (n, z0, y0, x0) of every tile in brick order, written by the pack kernel of the same call: the persistent loop
                          // reads one entry per item through the scalar cache instead of decomposing the position (~10 integer divisions)
+    int prio_ranks;  // co-resident workgroups per CU taking turns at the top wave priority (0: off)
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
@@ -531,8 +544,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int co = (nt0 + nn) * 16 + 4 * a4 + j; bvv[nn][j] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
 
+    const int prio_rank = (int)((blockIdx.x + gridDim.x * blockIdx.y) / 256u);
 #pragma unroll 1
     for (int item = 0; item < nitems; ++item) {
+        if (p.prio_ranks > 1) da_setprio((prio_rank + item) % p.prio_ranks);
         int n, z0, y0, x0, ch;
         item_coords(0, n, z0, y0, x0, ch);
         const bool has_next = DYN ? ((ch + 1 < nchunks) || tile_pos(cK + 1) < xhi) : (item + 1 < nitems);
@@ -813,7 +828,18 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         cK = nK; cCh = nCh; cN = nN; cZ = nZ; cY = nY; cX = nX;
         advance();
     }
-    if (p.clk && blockIdx.x == 17 && blockIdx.y == 0 && threadIdx.x == 0) { p.clk[0] = __builtin_readcyclecounter() - clk0; p.clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+    if (p.clk && threadIdx.x == 0) {      // DA_CLK: block 17's cycles / wall time, and the span of block lifetimes over the whole grid
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 17 && blockIdx.y == 0) { p.clk[0] = __builtin_readcyclecounter() - clk0; p.clk[1] = rt1 - rt0; }
+        atomicMin(p.clk + 2, rt0); atomicMax(p.clk + 3, rt0); atomicMin(p.clk + 4, rt1); atomicMax(p.clk + 5, rt1);
+        if (blockIdx.y == 0 && blockIdx.x < 1024) {      // per-workgroup record: XCC, hardware id, lifetime
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            p.clk[8 + 2 * blockIdx.x] = ((unsigned long long)xcc << 32) | hwid;
+            p.clk[9 + 2 * blockIdx.x] = rt1 - rt0;
+        }
+    }
     if constexpr (STATS) {
         stats_flush();
         if ((int)threadIdx.x < NREP * 16) {
@@ -1036,6 +1062,7 @@ struct WgP {
     unsigned masks[16]; int maskmode;   // per channel chunk tap masks (0 = all taps)
     const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: see FwdP
     const int4* tiles;                  // split kernel: (n, z0, y0, x0) per brick-order position (wgrad_tiles_kernel)
+    int prio_ranks;                     // see da_setprio
 };
 
 __global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
@@ -1176,8 +1203,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     };
     if (tile_begin < tile_end) { issue_loads(tile_begin); write_lds(); }
     __syncthreads();
+    const int prio_rank = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) / 256u);
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
+        if (p.prio_ranks > 1) da_setprio((prio_rank + tile) % p.prio_ranks);
         const bool has_next = tile + 1 < tile_end;
         if (has_next) issue_loads(tile + 1);                 // next tile's global loads fly during this tile's MFMAs
         // K loop: 16 rows (vz, vy) x 4 K-steps (4 voxels along x each).  Per row one base address per operand; the four
@@ -1459,8 +1488,10 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     if (tw.cnt > 0) { issue_loads(0); write_lds(); }
     __syncthreads();
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // (x, dY) plane pairs, smallest products first
+    const int prio_rank = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) / 256u);
 #pragma unroll 1
     for (int tile = 0; tile < tw.cnt; ++tile) {
+        if (p.prio_ranks > 1) da_setprio((prio_rank + tile) % p.prio_ranks);
         const bool has_next = tile + 1 < tw.cnt;
         if (has_next) issue_loads(tile + 1);                    // next tile's global loads fly during this tile's MFMAs
         F3 Y0 = loadY(0), Y1 = loadY(1);
@@ -1776,11 +1807,23 @@ static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    { static int occ = -1; if (occ < 0) { occ = getenv("DA_OCC") ? 1 : 0; if (occ) { int nb = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, shm); fprintf(stderr, "[occ] <%d,%d,M%d,S%d,BF%d,PRO%d,DYN%d,SP%d> lds %zu B -> %d workgroups per CU\n", CK, NREP, (int)MASKED, (int)STATS, (int)BF, (int)PRO, (int)DYN, (int)SP, shm, nb); } } }
     static unsigned long long* dclk = nullptr; static int want = -1;
-    if (want < 0) { want = getenv("DA_CLK") ? 1 : 0; if (want) (void)hipMalloc(&dclk, 16); }
+    if (want < 0) { want = getenv("DA_CLK") ? 1 : 0; if (want) (void)hipMalloc(&dclk, 64 + 1024 * 16); }
     FwdP q = p; q.clk = want ? dclk : nullptr;
+    if (want) { const unsigned long long init[6] = {0, 0, ~0ull, 0, ~0ull, 0}; (void)hipMemcpyAsync(dclk, init, 48, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
     hipLaunchKernelGGL(kern, dim3(p.nblocks, gy), dim3(256), shm, st, q);
-    if (want) { unsigned long long h[2]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, dclk, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[clk] cycles %llu realtime %llu -> %.0f MHz\n", h[0], h[1], (double)h[0] / (double)h[1] * 100.0); }
+    if (want) {
+        unsigned long long h[6]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, dclk, 48, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[clk] cycles %llu realtime %llu -> %.0f MHz; grid %d x %d: starts span %.1f us, ends span %.1f us, first start -> last end %.1f us\n", h[0], h[1],
+                (double)h[0] / (double)h[1] * 100.0, p.nblocks, gy, (h[3] - h[2]) * 0.01, (h[5] - h[4]) * 0.01, (h[5] - h[2]) * 0.01);
+        if (getenv("DA_CLK_DUMP")) {
+            static unsigned long long rec[2048];
+            const int nb = p.nblocks < 1024 ? p.nblocks : 1024;
+            (void)hipMemcpy(rec, dclk + 8, (size_t)nb * 16, hipMemcpyDeviceToHost);
+            for (int b = 0; b < nb; ++b) fprintf(stderr, "[blk] %d xcc %llu hwid %08llx life_us %.1f\n", b, (rec[2 * b] >> 32) & 15, rec[2 * b] & 0xffffffffull, rec[2 * b + 1] * 0.01);
+        }
+    }
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -1882,6 +1925,8 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         if (nblk >= 8) nblk &= ~7;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
         p.nblocks = nblk;
     }
+    { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
+      const int resident = (p.nblocks * gy + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident); }
     p.stats_partial = stats_partial;
     if (stats_nparts) *stats_nparts = 0;
     p.ps1 = p.pt1 = p.ps2 = p.pt2 = nullptr; p.pslope1 = p.pslope2 = -1.f;
@@ -2131,6 +2176,8 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (ws_bytes < q.partial_bytes + (split ? wg_tile_table_bytes(N, D, H, W) : 0)) return DA_ERR_WS_SMALL;
     WgP p;
     p.tiles = nullptr;
+    { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
+      const int resident = (q.nslabs * q.nchunks * q.ngroups + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident); }
     if (split && !split_wgrad_v1()) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
         hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
