@@ -102,11 +102,16 @@ def test_matrix_precision_switch_round_trip():
     from deepatlas_amd import ops
     prev = ops.set_matrix_precision('bf16')
     try:
-        assert prev in ('fp32', 'bf16')
+        assert prev in ops.MATRIX_MODES
         assert ops.set_matrix_precision('fp32') == 'bf16'
+        assert ops.set_matrix_precision('fp32_split') == 'fp32'            # the exact three-way split (da_set_matrix_mode(2))
+        assert ops.set_matrix_precision('fp32') == 'fp32_split'
         assert ops.set_matrix_precision('fp32') == 'fp32'
         with pytest.raises(ValueError):
             ops.set_matrix_precision('fp16')
+        from deepatlas_amd._native import lib
+        assert lib().da_set_matrix_mode(7) == -1 and ops.set_matrix_precision('fp32') == 'fp32'      # unknown mode refused, nothing changed
+        assert lib().da_set_matrix_bf16(1) == 0 and lib().da_set_matrix_mode(0) == 1                  # the older entry is mode 1
     finally:
         ops.set_matrix_precision(prev)
 
@@ -135,3 +140,42 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     assert L.da_conv1x1_fwd_pro(fake, None, None, 0.01, fake, None, fake, 100, 16, 32, fake, 1 << 20, None) == BAD                # prologue entry without a prologue
     assert L.da_bn_act_fwd(None, fake, fake, 0.01, fake, 10, 16, None) == BAD
     assert L.da_maxpool2_fwd(fake, fake, 0, 8, 8, 8, 16, None) == BAD
+
+
+def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_accurate():
+    """The arithmetic behind the split matrix mode, restated in numpy: x = h + m + l EXACTLY with h = bf16(x), m = bf16(x - h),
+    l = bf16(x - h - m) (round-to-nearest-even), for normal, huge and wide-dynamic-range fp32 values (|x| >= 2^-100; absolute error <= 2^-133 below); and the six partial products
+    h h' + h m' + m h' + m m' + h l' + l h' reproduce x y to better than one fp32 rounding (the dropped terms are <= 2^-23 |x y|)."""
+    import numpy as np
+
+    def bf16(a):                                  # fp32 -> bf16 (round to nearest even) -> fp32
+        u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return r.astype(np.uint32).view(np.float32)
+
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.standard_normal(200000), rng.standard_normal(50000) * np.exp(8 * rng.standard_normal(50000)),
+                        [1.0, -1.0, 3.0e38, -3.0e38, 1.2e-38, 2.0 ** -100, 1.0 + 2.0 ** -23, 255.99998]]).astype(np.float32)
+    h = bf16(x)
+    r1 = (x - h).astype(np.float32)               # exact: |r1| <= ulp_bf16(x) / 2 has at most 16 significant bits
+    assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - h.astype(np.float64))
+    m = bf16(r1)
+    r2 = (r1 - m).astype(np.float32)
+    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - m.astype(np.float64))
+    l = bf16(r2)
+    big = np.abs(x) >= 2.0 ** -100                # below ~2^-109 the last term enters bf16's denormal range (absolute error <= 2^-133 there)
+    assert np.array_equal(l[big], r2[big]), 'the second remainder has at most 8 significant bits'
+    assert np.array_equal((h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64))[big], x.astype(np.float64)[big])
+    assert np.all(np.abs(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64) - x.astype(np.float64)) <= 2.0 ** -133)
+    assert np.all(np.abs(m) <= np.abs(x) * 2.0 ** -8) and np.all(np.abs(l)[big] <= np.abs(x)[big] * 2.0 ** -16)
+    # six of the nine partial products against the exact product (float64 holds both exactly)
+    y = rng.permutation(x)
+    hy = bf16(y); my = bf16((y - hy).astype(np.float32)); ly = ((y - hy).astype(np.float32) - my).astype(np.float32)
+    H, M, L, Hy, My, Ly = [a.astype(np.float64) for a in (h, m, l, hy, my, ly)]
+    six = H * Hy + H * My + M * Hy + M * My + H * Ly + L * Hy
+    exact = x.astype(np.float64) * y.astype(np.float64)
+    ok = np.isfinite(exact) & (np.abs(x) >= 2.0 ** -60) & (np.abs(y) >= 2.0 ** -60) & (np.abs(exact) < 1e300)
+    rel = np.abs(six - exact)[ok] / np.abs(exact)[ok]
+    assert rel.max() <= 2.0 ** -23 and np.sqrt(np.mean(rel ** 2)) < 2.0 ** -26, (rel.max(), np.sqrt(np.mean(rel ** 2)))
+    fp32_rounding = np.abs((x * y).astype(np.float64) - exact)[ok] / np.abs(exact)[ok]      # one fp32 multiply for comparison
+    assert np.sqrt(np.mean(rel ** 2)) < np.sqrt(np.mean(fp32_rounding[np.isfinite(fp32_rounding)] ** 2))
