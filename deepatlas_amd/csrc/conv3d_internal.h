@@ -15,17 +15,21 @@ int da_matrix_mode();                  // 0 fp32 MFMA | 1 bf16-rounded operands 
 // (slope as in da_conv3d_k3_fwd: < 0 identity, 0 ReLU, > 0 LeakyReLU) are applied while the tile is staged.  A null scale
 // pointer = that input is already activated.
 struct DaPro { const float* s1; const float* t1; float slope1; const float* s2; const float* t2; float slope2; };
+// Stride-2 layers (conv3d_s2.hip) run as tap-masked stride-1 convolutions over the space-to-depth view of their input (s2d_cin > 0).
+// fuse_in: `in1` is the ORIGINAL tensor (s2d_cin channels, D0 x H0 x W0) and the staging loads apply the view; fuse_out (data gradient):
+// `out1` is the original-resolution gradient and the epilogue stores apply the inverse view -- no space_to_depth / depth_to_space copies.
+struct DaS2dFuse { int D0, H0, W0, fuse_in, fuse_out; };
 bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1 = -1, int Cs2 = 0);   // Cs1/Cs2: output split (dgrad of a concat conv)
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
                       void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0, double* stats_partial = nullptr, int* stats_nparts = nullptr,
-                      const DaPro* pro = nullptr);
+                      const DaPro* pro = nullptr, const DaS2dFuse* s2f = nullptr);
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0,
-                        const DaPro* pro = nullptr);
+                        const DaPro* pro = nullptr, const DaS2dFuse* s2f = nullptr);
 
 int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         float* out1, int Cs1, float* out2, int Cs2,

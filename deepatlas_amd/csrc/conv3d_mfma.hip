@@ -110,6 +110,41 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
     }
 }
 
+// The same staging for a tensor that is only VIRTUALLY space-to-depth (stride-2 layers, conv3d_s2.hip): (z, y, x) and `choff` address
+// S[q][r * cin + c] = X[2 q + r][c] (r = (rz, ry, rx) parity), and the loads go straight to X (cin channels, D0 x H0 x W0) -- the
+// space_to_depth2 copy pass and its 8 * cin-channel tensor disappear.  A chunk lies inside one parity (cin % CK == 0).
+struct S2dSrc { int cin, D0, H0, W0; };
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
+__device__ __forceinline__ void stage_load_s2d(float4* pre, const float* __restrict__ src, S2dSrc s2, int choff,
+                                               int n, int z0, int y0, int x0, int D, int H, int W) {
+    constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
+    constexpr int STEP = 256 / Q;
+    constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
+    const long long sample = (long long)s2.D0 * s2.H0 * s2.W0 * s2.cin;
+    const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+    int idx = threadIdx.x + IT0 * 256;
+    asm volatile("" : "+v"(idx));
+    const int c4 = idx % Q; int hv = idx / Q;
+    int hx = hv % HX; int t = hv / HX;
+    int hy = t % HY; int hz = t / HY;
+    const int r = choff / s2.cin;                                  // wave-uniform: the chunk's parity
+    const int cofs = choff - r * s2.cin + c4 * 4;
+    const int rz = (r >> 2) & 1, ry = (r >> 1) & 1, rx = r & 1;
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const int zs = 2 * z + rz, ys = 2 * y + ry, xs = 2 * x + rx;
+        const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q)
+                         && zs < s2.D0 && ys < s2.H0 && xs < s2.W0;
+        const unsigned off = (unsigned)((((zs * s2.H0 + ys) * s2.W0 + xs) * s2.cin + cofs) * 4);
+        pre[it - IT0] = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        hv += STEP;
+        hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
+        hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
+        hz += SZ + cy;
+    }
+}
+
 // LeakyReLU / ReLU / identity as max(z, z * s) with s = slope in [0, 1) or s = 1 for "no activation": two VALU operations, no
 // compares, and bit-identical to da_act() for every finite or non-finite z (z > 0: z; z < 0: z * s >= z; -0 and NaN propagate alike).
 __device__ __forceinline__ float da_act01(float z, float s) { return fmaxf(z, z * s); }
@@ -303,6 +338,8 @@ struct FwdP {
     const int4* tiles;   // (n, z0, y0, x0) of every tile in brick order, written by the pack kernel of the same call: the persistent loop
                          // reads one entry per item through the scalar cache instead of decomposing the position (~10 integer divisions)
     int prio_ranks;  // co-resident workgroups per CU taking turns at the top wave priority (0: off)
+    S2dSrc s2in;     // MASKED forward: in1 is the ORIGINAL tensor of a stride-2 layer, read as its space-to-depth view (cin > 0)
+    S2dSrc s2out;    // MASKED data gradient: the 8 * cin output channels are scattered to the original-resolution gradient (cin > 0)
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
 
@@ -319,8 +356,9 @@ struct FwdP {
 // dropped products are <= 2^-25 |a b| together, i.e. below the rounding of ONE fp32 multiply-add (tools/ubench/split_bf16.hip: the error
 // against double is smaller than that of the v_mfma_f32_16x16x4_f32 chain), at 6/16 of the matrix-pipe time.  LDS holds the three planes
 // (CK = 8: 3 x 17 KB, two workgroups per CU as before); fragments of the next two rows are read while the current two rows' 12 MFMAs issue.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
+    static_assert(S2F == 0 || MASKED, "fused space-to-depth addressing belongs to the tap-masked (stride-2) variants");
     static_assert(!DYN || (!STATS && !MASKED && !PRO), "dynamic tile walk: plain forward / data-gradient variants only");
     static_assert(!SP || (BF && !MASKED && !DYN && CK == 8), "split mode: dense bf16 K = 32 kernels on 8-channel chunks");
     constexpr int NP = SP ? 3 : 1;                                  // operand planes
@@ -385,7 +423,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         int n, z0, y0, x0, ch;
         item_coords(item, n, z0, y0, x0, ch);
         const int cbase = ch * CK;
-        if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        if constexpr (S2F == 1) stage_load_s2d<CK, HZ, 0, PRE>(pre, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        else if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
         else stage_load<CK, HZ, 0, PRE>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W);
     };
     auto stage_rest = [&](int item) {                         // iterations [PRE, NIT): global -> LDS, in <= 3 batches
@@ -396,9 +435,17 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const float* src = (cbase < p.C1) ? p.in1 : p.in2;
             const int Cs = (cbase < p.C1) ? p.C1 : p.C2, choff = (cbase < p.C1) ? cbase : cbase - p.C1;
             constexpr int R = NIT - PRE, B1 = PRE + (R + 2) / 3, B2 = PRE + 2 * ((R + 2) / 3) < NIT ? PRE + 2 * ((R + 2) / 3) : NIT;
+            if constexpr (S2F == 1) {
+                {
+                    { float4 tmp[B1 - PRE]; stage_load_s2d<CK, HZ, PRE, B1>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
+                    if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load_s2d<CK, HZ, B1, B2>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
+                    if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load_s2d<CK, HZ, B2, NIT>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
+                }
+            } else {
             { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
             if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
             if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
+            }
         }
     };
 
@@ -794,13 +841,31 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                 float* dbase = first ? p.out1 : p.out2;
                 const int Cd = first ? p.Cs1 : p.Cs2;
                 const int cd = cb - (first ? 0 : p.Cs1) + 4 * a4;
-                const long long sample = (long long)p.D * p.H * p.W * Cd;
-                const __amdgpu_buffer_rsrc_t ro = da_rsrc(dbase + (long long)n * sample, (unsigned)(sample * sizeof(float)));
                 const bool cok = do_ep && (cb + 4 * a4 + 3 < p.Cout) && z < p.D && x < p.W;
+                constexpr bool scattered = (S2F == 2);
+                if constexpr (S2F == 2) {
+                    {      // depth-to-space folded into the stores: N-tile cb = (parity, 16 channels) of the original-resolution tensor
+                        const int rr = cb / p.s2out.cin, c0 = cb - rr * p.s2out.cin + 4 * a4;
+                        const int zs = 2 * z + ((rr >> 2) & 1), xs = 2 * x + (rr & 1), ry = (rr >> 1) & 1;
+                        const long long sample0 = (long long)p.s2out.D0 * p.s2out.H0 * p.s2out.W0 * p.s2out.cin;
+                        const __amdgpu_buffer_rsrc_t r0 = da_rsrc(p.out1 + (long long)n * sample0, (unsigned)(sample0 * sizeof(float)));
+                        const bool ok0 = cok && zs < p.s2out.D0 && xs < p.s2out.W0;
 #pragma unroll
-                for (int r = 0; r < TY; ++r) {
-                    const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * Cd + cd) * 4);
-                    da_buf_store4(ro, (cok && y0 + r < p.H) ? off : 0xFFFFFFFFu, acc[r][nn]);
+                        for (int r = 0; r < TY; ++r) {
+                            const int ys = 2 * (y0 + r) + ry;
+                            const unsigned off = (unsigned)((((zs * p.s2out.H0 + ys) * p.s2out.W0 + xs) * p.s2out.cin + c0) * 4);
+                            da_buf_store4(r0, (ok0 && y0 + r < p.H && ys < p.s2out.H0) ? off : 0xFFFFFFFFu, acc[r][nn]);
+                        }
+                    }
+                }
+                if constexpr (!scattered) {
+                    const long long sample = (long long)p.D * p.H * p.W * Cd;
+                    const __amdgpu_buffer_rsrc_t ro = da_rsrc(dbase + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+#pragma unroll
+                    for (int r = 0; r < TY; ++r) {
+                        const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * Cd + cd) * 4);
+                        da_buf_store4(ro, (cok && y0 + r < p.H) ? off : 0xFFFFFFFFu, acc[r][nn]);
+                    }
                 }
             }
             if (do_ep) {
@@ -1063,6 +1128,7 @@ struct WgP {
     const float* ps1; const float* pt1; const float* ps2; const float* pt2; float pslope1, pslope2;   // PRO: see FwdP
     const int4* tiles;                  // split kernel: (n, z0, y0, x0) per brick-order position (wgrad_tiles_kernel)
     int prio_ranks;                     // see da_setprio
+    S2dSrc s2in;                        // MASKED: in1 is the original tensor of a stride-2 layer, read as its space-to-depth view (cin > 0)
 };
 
 __global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
@@ -1159,6 +1225,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         int n, z0, y0, x0;
         tile_coords(tile, n, z0, y0, x0);
         if constexpr (PRO) { vmA = 0; stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W, &vmA); }
+        else if (MASKED && p.s2in.cin > 0) stage_load_s2d<CK, HZ>(preA, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
         else stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
         const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (long long)n * sampleY, (unsigned)(sampleY * sizeof(float)));
@@ -1797,10 +1864,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 3 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP>;
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1856,7 +1923,7 @@ static int pro_slopes(const DaPro* pro, int C2, float* s1, float* s2) {
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f) {
     (void)stride;
     const int Cin = C1 + C2;
     int CK = pick_ck(C1, C2);
@@ -1927,6 +1994,11 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
       const int resident = (p.nblocks * gy + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident); }
+    p.s2in = S2dSrc{0, 0, 0, 0}; p.s2out = S2dSrc{0, 0, 0, 0};
+    if (s2f && s2d_cin > 0) {
+        if (s2f->fuse_in && !w_is_flipped_tr) p.s2in = S2dSrc{s2d_cin, s2f->D0, s2f->H0, s2f->W0};
+        if (s2f->fuse_out && w_is_flipped_tr) p.s2out = S2dSrc{s2d_cin, s2f->D0, s2f->H0, s2f->W0};
+    }
     p.stats_partial = stats_partial;
     if (stats_nparts) *stats_nparts = 0;
     p.ps1 = p.pt1 = p.ps2 = p.pt2 = nullptr; p.pslope1 = p.pslope2 = -1.f;
@@ -1960,8 +2032,10 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         return DA_ERR_UNSUPPORTED;
     }
     if (p.maskmode != 0) {
-        if (NREP == 1) return bf ? launch_fwd_mfma<16, 1, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 1, true>(p, gy, st);
-        if (NREP == 2) return bf ? launch_fwd_mfma<16, 2, true, false, true>(p, gy, st) : launch_fwd_mfma<16, 2, true>(p, gy, st);
+        const int s2f = p.s2in.cin > 0 ? 1 : (p.s2out.cin > 0 ? 2 : 0);
+#define DA_M_CASE(nr, f) if (NREP == nr && s2f == f) return bf ? launch_fwd_mfma<16, nr, true, false, true, false, false, false, f>(p, gy, st) : launch_fwd_mfma<16, nr, true, false, false, false, false, false, f>(p, gy, st)
+        DA_M_CASE(1, 0); DA_M_CASE(1, 1); DA_M_CASE(1, 2); DA_M_CASE(2, 0); DA_M_CASE(2, 1); DA_M_CASE(2, 2);
+#undef DA_M_CASE
         return DA_ERR_UNSUPPORTED;
     }
     if (dyn) {       // experiment (DA_DYN_TILES=1): work-stealing tile walk for the plain fp32 forward / data-gradient kernels
@@ -2112,7 +2186,7 @@ static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
 static bool split_wgrad_v1() { static int v = -1; if (v < 0) { const char* e = getenv("DA_SPLIT_WGRAD_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
 
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro) {
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f) {
     if (pro && (stride != 1 || s2d_cin > 0 || C1 + C2 > kProMaxC || pick_ck(C1, C2) == 0 || Cout % 4 != 0 || Cout <= 4)) return DA_ERR_UNSUPPORTED;
     if (!pro && s2d_cin == 0 && da_conv3_fewcin_wgrad_supported(C1, C2, Cout, stride)) {
         static int off = -1; if (off < 0) { const char* e = getenv("DA_NO_FLOW_WGRAD"); off = (e && atoi(e)) ? 1 : 0; }
@@ -2176,6 +2250,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (ws_bytes < q.partial_bytes + (split ? wg_tile_table_bytes(N, D, H, W) : 0)) return DA_ERR_WS_SMALL;
     WgP p;
     p.tiles = nullptr;
+    p.s2in = (s2f && s2d_cin > 0 && s2f->fuse_in) ? S2dSrc{s2d_cin, s2f->D0, s2f->H0, s2f->W0} : S2dSrc{0, 0, 0, 0};
     { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
       const int resident = (q.nslabs * q.nchunks * q.ngroups + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident); }
     if (split && !split_wgrad_v1()) {

@@ -82,6 +82,9 @@ static S2Plan s2_plan(int N, int D, int H, int W, int Cin, int Cout) {
     return p;
 }
 
+// DA_S2D_COPY=1: the earlier route through materialised space-to-depth tensors (A/B of the fused addressing)
+bool s2_fused() { static int v = -1; if (v < 0) { const char* e = getenv("DA_S2D_COPY"); v = (e && atoi(e)) ? 0 : 1; } return v == 1; }
+
 }  // namespace
 
 bool da_conv3_s2_supported(int C1, int C2, int Cout) { return C2 == 0 && C1 % 16 == 0 && C1 <= 32 && Cout >= 8 && Cout % 4 == 0; }
@@ -97,13 +100,17 @@ int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* b
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     float* S = (float*)ws; float* We = (float*)((char*)ws + p.s_bytes); char* inner = (char*)ws + p.s_bytes + 2 * p.we_bytes;
-    const long long tot = (long long)N * p.Dq * p.Hq * p.Wq * 8 * (Cin / 4);
-    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, in, S, N, D, H, W, Cin, p.Dq, p.Hq, p.Wq);
-    DA_LAUNCH_CHECK();
+    const bool fused = s2_fused();
+    if (!fused) {
+        const long long tot = (long long)N * p.Dq * p.Hq * p.Wq * 8 * (Cin / 4);
+        hipLaunchKernelGGL(space_to_depth2_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, in, S, N, D, H, W, Cin, p.Dq, p.Hq, p.Wq);
+        DA_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(expand_weights_s2d_kernel, dim3(da_grid(27 * 8 * Cin * Cout, 256, 512)), dim3(256), 0, st, w_tio, We, Cin, Cout);
     DA_LAUNCH_CHECK();
-    return da_conv3_mfma_fwd(S, 8 * Cin, nullptr, 0, We, 0, bias, out, Cout, nullptr, 0, N, p.Dq, p.Hq, p.Wq, Cout, 1, slope,
-                             inner, p.inner_bytes, st, Cin);
+    const DaS2dFuse f = {D, H, W, 1, 0};
+    return da_conv3_mfma_fwd(fused ? in : S, 8 * Cin, nullptr, 0, We, 0, bias, out, Cout, nullptr, 0, N, p.Dq, p.Hq, p.Wq, Cout, 1, slope,
+                             inner, p.inner_bytes, st, Cin, nullptr, nullptr, nullptr, fused ? &f : nullptr);
 }
 
 int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, int N, int D, int H, int W, int Cout,
@@ -114,9 +121,11 @@ int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, i
     hipLaunchKernelGGL(expand_weights_s2d_kernel, dim3(da_grid(27 * 8 * Cin * Cout, 256, 512)), dim3(256), 0, st, w_tio, We, Cin, Cout);
     DA_LAUNCH_CHECK();
     // dS = conv(dY, flip/transpose(W')) : logical Cin = Cout, logical Cout = 8*Cin
-    int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, We, 1, nullptr, dS, 8 * Cin, nullptr, 0, N, p.Dq, p.Hq, p.Wq, 8 * Cin, 1, -1.f,
-                               inner, p.inner_bytes, st, Cin);
-    if (rc) return rc;
+    const bool fused = s2_fused();
+    const DaS2dFuse f = {D, H, W, 0, 1};
+    int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, We, 1, nullptr, fused ? dx : dS, 8 * Cin, nullptr, 0, N, p.Dq, p.Hq, p.Wq, 8 * Cin, 1, -1.f,
+                               inner, p.inner_bytes, st, Cin, nullptr, nullptr, nullptr, fused ? &f : nullptr);
+    if (rc || fused) return rc;
     const long long tot = (long long)N * D * H * W * (Cin / 4);
     hipLaunchKernelGGL(depth_to_space2_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, dS, dx, N, D, H, W, Cin, p.Dq, p.Hq, p.Wq);
     DA_LAUNCH_CHECK();
@@ -128,10 +137,14 @@ int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, 
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     float* S = (float*)ws; float* dWe = (float*)((char*)ws + p.s_bytes + p.we_bytes); char* inner = (char*)ws + p.s_bytes + 2 * p.we_bytes;
-    const long long tot = (long long)N * p.Dq * p.Hq * p.Wq * 8 * (Cin / 4);
-    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, in, S, N, D, H, W, Cin, p.Dq, p.Hq, p.Wq);
-    DA_LAUNCH_CHECK();
-    int rc = da_conv3_mfma_wgrad(S, 8 * Cin, nullptr, 0, dy, dWe, N, p.Dq, p.Hq, p.Wq, Cout, 1, inner, p.inner_bytes, st, Cin);
+    const bool fused = s2_fused();
+    if (!fused) {
+        const long long tot = (long long)N * p.Dq * p.Hq * p.Wq * 8 * (Cin / 4);
+        hipLaunchKernelGGL(space_to_depth2_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, in, S, N, D, H, W, Cin, p.Dq, p.Hq, p.Wq);
+        DA_LAUNCH_CHECK();
+    }
+    const DaS2dFuse f = {D, H, W, 1, 0};
+    int rc = da_conv3_mfma_wgrad(fused ? in : S, 8 * Cin, nullptr, 0, dy, dWe, N, p.Dq, p.Hq, p.Wq, Cout, 1, inner, p.inner_bytes, st, Cin, nullptr, fused ? &f : nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(extract_wgrad_s2d_kernel, dim3(da_grid(27 * Cin * Cout, 256, 512)), dim3(256), 0, st, dWe, dw_tio, Cin, Cout);
     DA_LAUNCH_CHECK();
