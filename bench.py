@@ -423,7 +423,10 @@ def main():
                 rl_head = dict(bound='mfma', achieved=top['tflops'], peak=round(SPLIT_MFMA_PEAK_TFLOPS, 1), unit='TFLOP/s', frac=top['frac'], traffic=None,
                                peak_note='algorithmic fp32 FLOPs (2*27*Cin*Cout per voxel) against the dense bf16 matrix peak / 6: the split mode '
                                          'issues six bf16 MFMA products per fp32 multiply',
-                               frac_of_fp32_mfma_peak=round(top['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4))
+                               frac_of_fp32_mfma_peak=round(top['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4),
+                               bound_note='power: the same binary on all-zero operands runs 1.33x faster at a 2.16 instead of 1.55 - 1.6 GHz shader '
+                                          'clock (DESIGN.md 4.8, profiles/r02_conv3d_layers_isolated.txt); the six-MFMA K loop with its LDS reads alone '
+                                          'sustains 308 TFLOP/s on random operands (profiles/r02_ubench_mfma_power.txt)')
             else:
                 rl_head = dict(bound='mfma', achieved=top['tflops'], peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=top['frac'], traffic=None)
             roofline = dict(rl_head, kernel=top['call'], avg_ms=top['avg_ms'], launches=top['launches'], flops_per_launch=top['_fl'],
