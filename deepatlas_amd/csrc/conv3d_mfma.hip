@@ -272,6 +272,7 @@ __device__ __forceinline__ void da_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, byte_off, 0, 0);
 }
 template <bool B> struct BoolC { static constexpr bool value = B; };
+template <int V> struct IntC { static constexpr int value = V; };
 // Wave priority rotation (experiment, DA_PRIO_ROT=1; off by default).  The persistent kernels keep 2 - 3 workgroups per CU alive for the
 // whole launch, and the CU arbitrates instruction issue between their waves by priority, then by AGE: with equal priorities the
 // first-dispatched workgroup of a CU runs ~20 % faster than the last one for the whole kernel (DA_CLK=1 DA_CLK_DUMP=1: lifetimes 1.39 /
@@ -356,9 +357,14 @@ struct FwdP {
 // dropped products are <= 2^-25 |a b| together, i.e. below the rounding of ONE fp32 multiply-add (tools/ubench/split_bf16.hip: the error
 // against double is smaller than that of the v_mfma_f32_16x16x4_f32 chain), at 6/16 of the matrix-pipe time.  LDS holds the three planes
 // (CK = 8: 3 x 17 KB, two workgroups per CU as before); fragments of the next two rows are read while the current two rows' 12 MFMAs issue.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(S2F == 0 || MASKED, "fused space-to-depth addressing belongs to the tap-masked (stride-2) variants");
+    // PAIR (split mode, one N-tile): two consecutive 8-channel chunks share every 64-byte sector of their input.  Staged one work item apart
+    // the second one misses L2 (the launch turns its L2 over in about one item time): FETCH_SIZE 1.8x the algorithmic bytes.  With PAIR the
+    // loads of BOTH chunks are issued together during the odd item of a pair; the second chunk's data waits in registers (pre2) through the
+    // even item.  The item loop is unrolled by two (lambda instantiated per phase) so that the even phase contains no load instructions.
+    static_assert(!PAIR || (SP && NREP == 1 && !PRO), "paired staging: split mode, one N-tile, no input prologue");
     static_assert(!DYN || (!STATS && !MASKED && !PRO), "dynamic tile walk: plain forward / data-gradient variants only");
     static_assert(!SP || (BF && !MASKED && !DYN && CK == 8), "split mode: dense bf16 K = 32 kernels on 8-channel chunks");
     constexpr int NP = SP ? 3 : 1;                                  // operand planes
@@ -494,6 +500,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         }
     };
     float4 pre[PRE > 0 ? PRE : 1];
+    float4 pre2[PAIR ? PRE : 1];          // PAIR: the second chunk of the pair staged during the previous odd item
     // PRO: scale / shift / slope of the channel quad this thread stages (256 % Q == 0: the quad is fixed per thread and chunk).
     // Unconditional loads from always-valid arrays (the host substitutes identity arrays for an input without a prologue).
     unsigned vm = 0;
@@ -522,6 +529,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     issue_stage(0, pre);
     stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);
     stage_rest(0);
+    if constexpr (PAIR) stage_load<CK, HZ, 0, PRE>(pre2, p.in1, p.C1, CK, cN, cZ, cY, cX, p.D, p.H, p.W);      // item 1 = chunk 1 of the first tile
     }
     __syncthreads();
 
@@ -592,12 +600,14 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         for (int j = 0; j < 4; ++j) { const int co = (nt0 + nn) * 16 + 4 * a4 + j; bvv[nn][j] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
 
     const int prio_rank = (int)((blockIdx.x + gridDim.x * blockIdx.y) / 256u);
-#pragma unroll 1
-    for (int item = 0; item < nitems; ++item) {
+    // one work item; PH: 0 = unpaired, 1 = even item of a pair (no staging loads: the next item's tile is in pre2), 2 = odd item (loads both
+    // chunks of the next pair).  Returns false when the walk is over (DYN).
+    auto item_body = [&](int item, auto PHC) -> bool {
+        constexpr int PH = decltype(PHC)::value;
         if (p.prio_ranks > 1) da_setprio((prio_rank + item) % p.prio_ranks);
         int n, z0, y0, x0, ch;
         item_coords(0, n, z0, y0, x0, ch);
-        const bool has_next = DYN ? ((ch + 1 < nchunks) || tile_pos(cK + 1) < xhi) : (item + 1 < nitems);
+        const bool has_next = PH == 1 ? true : DYN ? ((ch + 1 < nchunks) || tile_pos(cK + 1) < xhi) : (item + 1 < nitems);
         const bool last = (ch == nchunks - 1);
         if constexpr (DYN) {       // on a tile's first chunk: draw the position of the tile after next; published below, before the barriers
             if (threadIdx.x == 0 && ch == 0) sp[(cK + 2) & 3] = xlo + atomicAdd(ctr, 1);
@@ -673,7 +683,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const int cbase = ch2 * CK;
             const bool first = cbase < p.C1;
             const int Csn = first ? p.C1 : p.C2;
-            if constexpr (SP) {
+            if constexpr (SP && PH == 1) { (void)Csn; }
+            else if constexpr (SP) {
                 const long long sample = (long long)p.D * p.H * p.W * Csn;
                 rsn = da_rsrc((first ? p.in1 : p.in2) + (long long)n2 * sample, (unsigned)(sample * sizeof(float)));
                 stile = smap.tile(z2, y2, x2, p.D, p.H, p.W, Csn, first ? cbase : cbase - p.C1, has_next && !(p.ablate & 1));
@@ -707,9 +718,11 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
             for (int j = 0; j < PRE; ++j)
                 if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) {
-                    if constexpr (SP) {
+                    if constexpr (SP && PH == 1) { }
+                    else if constexpr (SP) {
                         const unsigned so = smap.offset(stile, j);
                         pre[j] = da_buf_load4(rsn, so);
+                        if constexpr (PH == 2) pre2[j] = da_buf_load4(rsn, so == 0xFFFFFFFFu ? so : so + CK * 4u);      // the same voxel's next 8 channels
                         if constexpr (PRO) vm |= (so != 0xFFFFFFFFu ? 1u : 0u) << j;
                     } else { pre[j] = cur.next(); if constexpr (PRO) vm |= (cur.last_inb ? 1u : 0u) << j; }
                 }
@@ -882,16 +895,29 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         }
         if (STATS && last && ((++tiles_done) & 1) == 0) stats_flush();
         if constexpr (PRO && !PRO_IN) load_pro(has_next ? 1 : 0);      // outside the branch: no vector memory in branches
-        if constexpr (DYN) { if (!has_next) break; }
+        if constexpr (DYN) { if (!has_next) return false; }
         if (has_next && !(p.ablate & 4)) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
             if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
+            else if constexpr (PH == 1) stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre2);
             else stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
             if constexpr (!PRO) stage_rest(1);
             __syncthreads();
         }
         cK = nK; cCh = nCh; cN = nN; cZ = nZ; cY = nY; cX = nX;
         advance();
+        return true;
+    };
+    if constexpr (PAIR) {
+#pragma unroll 1
+        for (int item = 0; item < nitems; item += 2) {
+            if (!item_body(item, IntC<1>{})) break;
+            if (!item_body(item + 1, IntC<2>{})) break;
+        }
+    } else {
+#pragma unroll 1
+        for (int item = 0; item < nitems; ++item)
+            if (!item_body(item, IntC<0>{})) break;
     }
     if (p.clk && threadIdx.x == 0) {      // DA_CLK: block 17's cycles / wall time, and the span of block lifetimes over the whole grid
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -1864,10 +1890,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 3 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F>;
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -2012,6 +2038,11 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     }
     if (split) {
         if (stats_partial && stats_nparts) *stats_nparts = p.nblocks;
+        // paired staging (one sector fetch per two chunks): one N-tile, an even number of 8-channel chunks that pair up inside in1 / in2
+        static int nopair = -1; if (nopair < 0) { const char* e = getenv("DA_NO_PAIR"); nopair = (e && atoi(e)) ? 1 : 0; }
+        if (!nopair && NREP == 1 && !pro && C1 % 16 == 0 && C2 % 16 == 0)
+            return stats_partial ? launch_fwd_mfma<8, 1, false, true, true, false, false, true, 0, true>(p, gy, st)
+                                 : launch_fwd_mfma<8, 1, false, false, true, false, false, true, 0, true>(p, gy, st);
 #define DA_SP_CASE(nr) if (NREP == nr) return stats_partial ? (pro ? launch_fwd_mfma<8, nr, false, true, true, true, false, true>(p, gy, st) : launch_fwd_mfma<8, nr, false, true, true, false, false, true>(p, gy, st)) \
                                                               : (pro ? launch_fwd_mfma<8, nr, false, false, true, true, false, true>(p, gy, st) : launch_fwd_mfma<8, nr, false, false, true, false, false, true>(p, gy, st))
         DA_SP_CASE(1); DA_SP_CASE(2);

@@ -33,7 +33,7 @@ def main():
         for k, v in agg.items():
             v = v[1:] if len(v) > 1 else v          # first launch includes cold allocation effects
             per.setdefault(k, {})[c] = sum(v) / len(v)
-    # kernel template instantiations at HEAD: fwd <CK, NREP, MASKED, STATS, BF, PRO, DYN, SP>, wgrad <CK, NREP, YS, MASKED, BF, PRO, SP>,
+    # kernel template instantiations at HEAD: fwd <CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR>, wgrad <CK, NREP, YS, MASKED, BF, PRO, SP>,
     # split weight gradient conv3_split_wgrad_kernel<PRO>
     mode = 0
     try:
@@ -42,14 +42,14 @@ def main():
         pass
     if mode == 2:
         # (the data gradient 16 -> 48 runs the forward kernel with one N-tile per workgroup and three cout groups: 168 x 3 workgroups)
-        sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+        sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true, 0, true>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_split_wgrad_kernel<false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     else:
-        sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+        sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false, 0, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false, 0, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false, 0, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     vox = 2 * 160 * 192 * 160
     alg = {'fwd': vox * (48 + 16) * 4, 'dgrad': vox * (16 + 48) * 4, 'wgrad': vox * (48 + 16) * 4 + 27 * 48 * 16 * 4}
