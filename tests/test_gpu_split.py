@@ -142,3 +142,34 @@ def test_parity_suite_holds_in_split_mode(name, fn, golden):
         fn(golden)
     finally:
         ops.set_matrix_precision(prev)
+
+
+def test_segmentation_experiment_takes_fp32_split_from_its_config(tmp_path):
+    """`matrix_precision: fp32_split` in the experiment config (the reference's config has no such key: models/segmentation.py:33-61 runs unchanged)
+    switches the process to split mode; an epoch of two 32^3 volumes tracks oracle.steps.seg_step loss by loss."""
+    import argparse
+    import train_seg
+    from oracle import nets, steps
+    from deepatlas_amd import ops
+    from deepatlas_amd.models.segmentation import SegmentationExperiment
+    ns = argparse.Namespace(device='0', debug=False, preload=False, num_samples=1, num_epochs=1, lr=1e-3, test_only=False,
+                            data_root='./data', log_root=str(tmp_path), shape=[32, 32, 32])
+    cfg = train_seg.build_config(ns)
+    cfg['matrix_precision'] = 'fp32_split'
+    prev = ops.set_matrix_precision('fp32')
+    try:
+        exp = SegmentationExperiment(cfg)
+        exp.setup_train()
+        assert ops.set_matrix_precision('fp32_split') == 'fp32_split'          # setup_optimizer switched the mode
+        exp.initialize_model(exp.model, exp.optimizer, '')
+        sd = {k: v.detach().cpu().clone() for k, v in exp.model.state_dict().items()}
+        o_opt = steps.Adam(steps.trainable(sd), lr=exp.optimizer.param_groups[0]['lr'])
+        n = 0
+        for images, truths, name in exp.training_data_loader:
+            loss, out = exp.train_step(images, truths)
+            o_loss, _, _ = steps.seg_step(sd, o_opt, images, truths, nets.UNET_LIGHT, 32)
+            assert abs(loss.item() - o_loss.item()) < 1e-4, (n, loss.item(), o_loss.item())
+            n += 1
+        assert n == 2
+    finally:
+        ops.set_matrix_precision(prev)
