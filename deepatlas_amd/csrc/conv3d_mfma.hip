@@ -897,12 +897,14 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         if constexpr (PRO && !PRO_IN) load_pro(has_next ? 1 : 0);      // outside the branch: no vector memory in branches
         if constexpr (DYN) { if (!has_next) return false; }
         if (has_next && !(p.ablate & 4)) {
+            if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(0);       // DA_PHASE_PRIO: the staging phase yields to the co-resident workgroup's K loop
             __syncthreads();                       // every wave is done reading this item's LDS tile
             if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
             else if constexpr (PH == 1) stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre2);
             else stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
             if constexpr (!PRO) stage_rest(1);
             __syncthreads();
+            if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(2);
         }
         cK = nK; cCh = nCh; cN = nN; cZ = nZ; cY = nY; cX = nX;
         advance();
@@ -1611,9 +1613,11 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             if (c < 4) { Fa = Na; Fb = Nb; Fc = Nc; }
         }
         if (has_next) {
+            if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             write_lds();
             __syncthreads();
+            if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(2);
         }
     }
     // reduce the four waves' partial sums through LDS (two rounds of <= 30 KB), then wave 0 writes this slab's partial dW
@@ -2019,7 +2023,8 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
         p.nblocks = nblk;
     }
     { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
-      const int resident = (p.nblocks * gy + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident); }
+      const int resident = (p.nblocks * gy + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident);
+      static int phase = -1; if (phase < 0) { const char* e = getenv("DA_PHASE_PRIO"); phase = (e && atoi(e)) ? 1 : 0; } if (phase) p.prio_ranks = -1; }
     p.s2in = S2dSrc{0, 0, 0, 0}; p.s2out = S2dSrc{0, 0, 0, 0};
     if (s2f && s2d_cin > 0) {
         if (s2f->fuse_in && !w_is_flipped_tr) p.s2in = S2dSrc{s2d_cin, s2f->D0, s2f->H0, s2f->W0};
@@ -2283,7 +2288,8 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     p.tiles = nullptr;
     p.s2in = (s2f && s2d_cin > 0 && s2f->fuse_in) ? S2dSrc{s2d_cin, s2f->D0, s2f->H0, s2f->W0} : S2dSrc{0, 0, 0, 0};
     { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
-      const int resident = (q.nslabs * q.nchunks * q.ngroups + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident); }
+      const int resident = (q.nslabs * q.nchunks * q.ngroups + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident);
+      static int phase = -1; if (phase < 0) { const char* e = getenv("DA_PHASE_PRIO"); phase = (e && atoi(e)) ? 1 : 0; } if (phase) p.prio_ranks = -1; }
     if (split && !split_wgrad_v1()) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
         hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
