@@ -1102,7 +1102,8 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
 // packed B operand: wp[chunk][step][ntile][lane][m]
 __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
                                         int CK, int NSTEPS, int NTpad, int flipped, long long total, int bf, int* zero_ctr, int nctr,
-                                        int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
+                                        int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz, int cout0, int CoutW) {
+    // (cout0, CoutW: this launch covers output channels [cout0, cout0 + Cout) of a weight tensor with CoutW output channels)
     if (zero_ctr && blockIdx.x == 0 && (int)threadIdx.x < nctr) zero_ctr[threadIdx.x] = 0;      // DYN tile counters of the launch that follows
     // tile table of the launch that follows: brick-order position -> (sample, z0, y0, x0)
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < ntiles; pos += gridDim.x * blockDim.x) {
@@ -1127,7 +1128,7 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
                 const int ci = ch * CK + ((CK == 16) ? (g & 1) * 8 : 0) + e;
                 float v2 = 0.f;
                 if (tp < 27 && cout < Cout && ci < Cin)
-                    v2 = flipped ? w[((size_t)(26 - tp) * Cout + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * Cout + cout];
+                    v2 = flipped ? w[((size_t)(26 - tp) * CoutW + cout0 + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * CoutW + cout0 + cout];
                 if (bf == 3) {      // split mode: three planes (h, m, l) of 1 KiB per (chunk, step, N-tile), the same exact split as da_split3
                     unsigned short* o = reinterpret_cast<unsigned short*>(wp) + (idx >> 8) * 1536 + lane * 8 + e;
                     const __bf16 bh = (__bf16)v2; const float r1 = v2 - (float)bh;
@@ -1139,7 +1140,7 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
         }
         float v = 0.f;
         if (tap < 27 && cout < Cout && cin < Cin)
-            v = flipped ? w[((size_t)(26 - tap) * Cout + cout) * Cin + cin] : w[((size_t)tap * Cin + cin) * Cout + cout];
+            v = flipped ? w[((size_t)(26 - tap) * CoutW + cout0 + cout) * Cin + cin] : w[((size_t)tap * Cin + cin) * CoutW + cout0 + cout];
         if (bf) reinterpret_cast<unsigned short*>(wp)[idx] = __builtin_bit_cast(unsigned short, (__bf16)v);      // same [..][lane][m] order, 2 bytes each
         else wp[idx] = v;
     }
@@ -1950,10 +1951,37 @@ static int pro_slopes(const DaPro* pro, int C2, float* s1, float* s2) {
     return 0;
 }
 
+static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
+                               const float* bias, float* out1, int Cs1, float* out2, int Cs2,
+                               int N, int D, int H, int W, int Cout, int stride, float slope,
+                               void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f,
+                               int cout0, int CoutW);
+
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
                       void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f) {
+    // Split mode, data gradient of a concat layer whose outputs are 32 + 16 channels (the 48 -> 16 decoder convolution: three N-tiles).  One
+    // launch with one N-tile per workgroup stages dY three times; two launches -- two N-tiles sharing every dY fragment for the first output
+    // tensor, one N-tile (paired staging) for the second -- stage it twice and write each output tensor from its own launch.
+    static int no2 = -1; if (no2 < 0) { const char* e = getenv("DA_NO_DGRAD_SPLIT_LAUNCH"); no2 = (e && atoi(e)) ? 1 : 0; }
+    if (!no2 && da_matrix_mode() == 2 && w_is_flipped_tr && s2d_cin == 0 && !stats_partial && !pro && Cs2 > 0 && Cs1 == 32 && Cs2 == 16 && Cout == 48 &&
+        pick_ck(C1, C2) != 0) {
+        int rc = conv3_mfma_fwd_impl(in1, C1, in2, C2, w_tio, 1, bias, out1, 32, nullptr, 0, N, D, H, W, 32, stride, slope, ws, ws_bytes, st, 0, nullptr, nullptr,
+                                     nullptr, nullptr, 0, Cout);
+        if (rc) return rc;
+        return conv3_mfma_fwd_impl(in1, C1, in2, C2, w_tio, 1, bias ? bias + 32 : nullptr, out2, 16, nullptr, 0, N, D, H, W, 16, stride, slope, ws, ws_bytes, st, 0,
+                                   nullptr, nullptr, nullptr, nullptr, 32, Cout);
+    }
+    return conv3_mfma_fwd_impl(in1, C1, in2, C2, w_tio, w_is_flipped_tr, bias, out1, Cs1, out2, Cs2, N, D, H, W, Cout, stride, slope, ws, ws_bytes, st, s2d_cin,
+                               stats_partial, stats_nparts, pro, s2f, 0, Cout);
+}
+
+static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
+                               const float* bias, float* out1, int Cs1, float* out2, int Cs2,
+                               int N, int D, int H, int W, int Cout, int stride, float slope,
+                               void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f,
+                               int cout0, int CoutW) {
     (void)stride;
     const int Cin = C1 + C2;
     int CK = pick_ck(C1, C2);
@@ -1999,7 +2027,7 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx;
     hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total > p.ntiles ? total : p.ntiles, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode,
-                       dyn ? dyn_ctr : nullptr, gy * 8, tiles, p.ntiles, p.ntx, p.nty, p.ntz);
+                       dyn ? dyn_ctr : nullptr, gy * 8, tiles, p.ntiles, p.ntx, p.nty, p.ntz, cout0, CoutW);
     DA_LAUNCH_CHECK();
     p.tiles = tiles;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.wp = wp; p.bias = bias;
