@@ -8,14 +8,19 @@ export DA_MATRIX_MODE=${1:-2}
 O=gpurun_out/pmc; rm -rf $O; mkdir -p $O
 echo $DA_MATRIX_MODE > $O/matrix_mode.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --iters 3 > $O/$c.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --what fwd,fwdstats,wgrad --iters 3 > $O/$c.log 2>&1 < /dev/null
   f=$(ls $O/$c/*/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then cp "$f" $O/conv3d_48to16_$c.csv; fi
+  rm -rf $O/$c
+  # the data gradient in its own process: in split mode it is two launches, one of them the forward's kernel at the forward's grid
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --what dgrad --iters 3 > $O/${c}_dgrad.log 2>&1 < /dev/null
+  f=$(ls $O/$c/*/*counter_collection.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then cp "$f" $O/conv3d_48to16_dgrad_$c.csv; fi
   rm -rf $O/$c
 done
 # third pass: matrix-pipe utilisation of the same kernels (SQ block: 8 slots, GRBM: 2 -- no TCC counters in this pass)
 c=SQ
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$c -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --iters 3 > $O/$c.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$c -- python tools/bench_conv.py --layer 32,16,16,2,160,192,160 --what fwd,fwdstats,wgrad --iters 3 > $O/$c.log 2>&1 < /dev/null
 f=$(ls $O/$c/*/*counter_collection.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" $O/conv3d_48to16_$c.csv; fi
 rm -rf $O/$c

@@ -51,6 +51,21 @@ def main():
                'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false, 0, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false, 0, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+    # data gradient: collected in its own process (tools/pmc_conv.sh); per call = the sum over its conv kernels (split mode: two launches)
+    dg_calls = 6.0                                   # bench_conv.py --iters 3: 3 warm-up + 3 timed calls
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        f = os.path.join(src, '%s_dgrad_%s.csv' % (layer, c))
+        if not os.path.isfile(f):
+            continue
+        shutil.copyfile(f, os.path.join(dst, '%s_%s_dgrad_pmc_%s.csv' % (tag, layer, c.lower())))
+        tot, names = 0.0, set()
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            if k.startswith('conv3_mfma_fwd_kernel'):
+                tot += float(r['Counter_Value']) * 1024.0
+                names.add(k)
+        per.setdefault('__dgrad__', {})[c] = tot / dg_calls
+        per['__dgrad__']['names'] = ' + '.join(sorted(names))
     vox = 2 * 160 * 192 * 160
     alg = {'fwd': vox * (48 + 16) * 4, 'dgrad': vox * (16 + 48) * 4, 'wgrad': vox * (48 + 16) * 4 + 27 * 48 * 16 * 4}
     res = {'unit': 'bytes per launch', 'counters': 'FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, KiB -> bytes)',
@@ -86,6 +101,9 @@ def main():
             m = sum(v) / len(v)
             calib[k] = {'sector_bytes_touched': want[k], 'fetch_size_bytes': m, 'requested_over_fetch_size': want[k] / m if m else None}
     res['fetch_size_calibration'] = calib
+    if '__dgrad__' in per:
+        sig = {k: v for k, v in sig.items() if 'dgrad' not in v}
+        sig['__dgrad__'] = 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]'
     for k, name in sig.items():
         if k not in per:
             continue
@@ -109,7 +127,7 @@ def main():
             fc_contig = f64 if 'wgrad' not in name else 2.0 / (1.0 / f64 + 1.0 / fcc)
         share_half = b_half / (b_half + b_contig)
         fcorr = f * (b_half + b_contig) / (b_half / fc_half + b_contig / fc_contig)
-        res['calls'][name] = {'kernel': k, 'fetch_bytes_raw': f, 'fetch_bytes': fcorr, 'write_bytes': w, 'traffic_bytes': fcorr + w,
+        res['calls'][name] = {'kernel': per[k].get('names', k), 'fetch_bytes_raw': f, 'fetch_bytes': fcorr, 'write_bytes': w, 'traffic_bytes': fcorr + w,
                               'algorithmic_bytes': a, 'traffic_over_algorithmic': (fcorr + w) / a,
                               'fetch_correction': 'raw FETCH_SIZE x %.4f: %.0f %% of the staged bytes come from the 32-channel tensor (one 64-B sector per request, calibration '
                                                   'factor %.3f) and %.0f %% from 16-channel tensors (adjacent sectors merge into 128-B requests tallied as 64 B, factor %.3f); '
