@@ -173,3 +173,30 @@ def test_segmentation_experiment_takes_fp32_split_from_its_config(tmp_path):
         assert n == 2
     finally:
         ops.set_matrix_precision(prev)
+
+
+# ---- randomised shapes in split mode (hypothesis, derandomised): ragged volumes smaller and larger than a tile, one and two samples, every
+# channel class the split kernels take -- single 8-channel chunk, chunk pairs (paired staging), concat inputs, one / two / three N-tiles
+# (the 32 + 16 data gradient goes through its two-launch form) -- against torch-CPU in fp32 at the package's 1e-4 (rel-l2 and element-wise).
+from hypothesis import given, settings, strategies as st, HealthCheck  # noqa: E402
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(c1=st.sampled_from([8, 16, 32, 48, 64]), c2=st.sampled_from([0, 0, 8, 16, 32]), cout=st.sampled_from([8, 16, 32, 48, 64]),
+       d=st.integers(1, 11), h=st.integers(1, 19), w=st.integers(1, 35), n=st.integers(1, 2))
+def test_split_mode_random_shapes(c1, c2, cout, d, h, w, n):
+    from deepatlas_amd import ops
+    from test_gpu_ops import check
+    x1 = rnd((n, c1, d, h, w), 1)
+    x2 = rnd((n, c2, d, h, w), 2) if c2 else None
+    wt, b = rnd((cout, c1 + c2, 3, 3, 3), 3, 0.2), rnd((cout,), 4, 0.1)
+    xr1 = x1.clone().requires_grad_(True)
+    xr2 = x2.clone().requires_grad_(True) if c2 else None
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(torch.cat((xr1, xr2), 1) if c2 else xr1, wr, br, padding=1)
+    go = rnd(tuple(yr.shape), 5)
+    yr.backward(go)
+    out = _run('fp32_split', x1, x2, wt, b, go)
+    ref = [yr.detach(), xr1.grad] + ([xr2.grad] if c2 else []) + [wr.grad, br.grad]
+    for nm, a, r in zip(['fwd', 'dgrad1'] + (['dgrad2'] if c2 else []) + ['wgrad', 'bgrad'], out, ref):
+        check(a, r, what=nm)
