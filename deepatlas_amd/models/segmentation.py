@@ -104,7 +104,7 @@ class SegmentationExperiment(BaseExperiment):
         ops.enable_async_wgrad(bool(self.config.get('async_wgrad', True)))
         # matrix mode of the 3x3x3 convolutions: 'fp32' (default: fp32 matrix instructions), 'fp32_split' (fp32-accurate products from an exact
         # three-way bf16 split, ~1.4x faster; what bench.py measures) or 'bf16' (operands rounded, BASELINE config 5)
-        ops.set_matrix_precision(self.config.get('matrix_precision', 'fp32'))
+        ops.set_matrix_precision(self.config.get('matrix_precision') or 'fp32')
         if self.config['lr_mode'] == 'plateau':
             self.scheduler = lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='max',
                                                             patience=100 // self.config['valid_epoch_period'],

@@ -41,8 +41,8 @@ def build_config(args):
     config['valid_data_dir'] = config['data_dir']
     config['log_dir'] = './{}/{}'.format(args.log_root, config['data'])
     config['device'] = 'cuda:{}'.format(args.device) if args.device.isdigit() else args.device
-    if getattr(args, 'matrix_precision', None):           # not a key of the reference's config: absent = 'fp32' (the fp32 matrix instructions)
-        config['matrix_precision'] = args.matrix_precision
+    if not config.get('matrix_precision'):                # (--matrix-precision; not a key of the reference's config: absent = 'fp32', the fp32 matrix instructions)
+        config.pop('matrix_precision', None)
     return config
 
 
