@@ -221,7 +221,7 @@ def require_cuda(*tensors):
 class _Workspace:
     """One growing scratch buffer per device and stream; kernels on one stream are ordered, so it is shared by all ops on it.
     While a HIP graph is being captured (graphs.GraphedStep sets `capture_tag`) the buffers are separate ones, allocated INSIDE the
-    capture: they live in that graph's private memory pool and are kept for as long as the process runs, so a replay never finds its
+    capture: they live in that graph's private memory pool and are kept until the owning GraphedStep is closed, so a replay never finds its
     scratch reallocated or released by someone else's larger request (or by the empty_cache() of a later capture)."""
 
     def __init__(self):
@@ -243,6 +243,12 @@ class _Workspace:
             b = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
             self.buf[key] = b
         return c_void_p(b.data_ptr()), c_size_t(b.numel())
+
+
+    def release(self, tag):
+        """Forget the buffers allocated under capture tag `tag` (graphs.GraphedStep.close())."""
+        for k in [k for k in self.buf if len(k) == 5 and k[3] == tag]:
+            del self.buf[k]
 
 
 workspace = _Workspace()

@@ -13,7 +13,7 @@ class BaseExperiment():
         self.config = config
 
     def setup_log(self):
-        pass
+        """Logging (tensorboard in the reference) is out of scope for the hot path: nothing to set up."""
 
     def setup_random_seed(self):
         """models/base.py:33-39."""
@@ -55,13 +55,12 @@ class BaseExperiment():
 
     @staticmethod
     def save_checkpoint(state, is_best, path, prefix=None, name='checkpoint.pth.tar', max_keep=1):
-        """models/base.py:70-78."""
-        if not os.path.exists(path):
-            os.makedirs(path)
-        name = '_'.join([prefix, name]) if prefix else name
-        best_name = '_'.join([prefix, 'model_best.pth.tar']) if prefix else 'model_best.pth.tar'
-        torch.save(state, os.path.join(path, name))
-        if is_best:
-            torch.save(state, os.path.join(path, best_name))
+        """Same files as models/base.py:70-78 writes: <path>/[<prefix>_]<name>, and a second copy [<prefix>_]model_best.pth.tar when
+        `is_best` (`max_keep` is accepted and unused there too)."""
+        os.makedirs(path, exist_ok=True)
+        stem = (prefix + '_') if prefix else ''
+        targets = [stem + name] + ([stem + 'model_best.pth.tar'] if is_best else [])
+        for fname in targets:
+            torch.save(state, os.path.join(path, fname))
 
     initialize_model = staticmethod(utils.initialize_model)   # models/base.py:80-120

@@ -102,9 +102,10 @@ class SegmentationExperiment(BaseExperiment):
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.config['learning_rate'])
         # conv weight gradients on a second stream, accumulated into the optimiser's flat bucket (joined in zero_grad / step)
         ops.enable_async_wgrad(bool(self.config.get('async_wgrad', True)))
-        # matrix mode of the 3x3x3 convolutions: 'fp32' (default: fp32 matrix instructions), 'fp32_split' (fp32-accurate products from an exact
-        # three-way bf16 split, ~1.4x faster; what bench.py measures) or 'bf16' (operands rounded, BASELINE config 5)
-        ops.set_matrix_precision(self.config.get('matrix_precision') or 'fp32')
+        # matrix mode of the 3x3x3 convolutions: 'fp32_split' (default, and what bench.py measures: fp32-accurate products from an exact
+        # three-way bf16 split on the bf16 matrix pipe), 'fp32' (the fp32 matrix instructions, the A/B) or 'bf16' (operands rounded,
+        # BASELINE config 5)
+        ops.set_matrix_precision(self.config.get('matrix_precision') or ops.DEFAULT_MATRIX_PRECISION)
         if self.config['lr_mode'] == 'plateau':
             self.scheduler = lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='max',
                                                             patience=100 // self.config['valid_epoch_period'],

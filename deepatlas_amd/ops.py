@@ -66,6 +66,9 @@ _side_keep = []          # tensors the side stream still reads: referenced until
 
 
 MATRIX_MODES = ('fp32', 'bf16', 'fp32_split')
+# What the training entry points (SegmentationExperiment / train_seg.py, JointExperiment, bench.py) switch to unless told otherwise.  The C
+# library itself starts in 'fp32' (mode 0): the kernel-variant bit-identity tests are written against the fp32 matrix instructions.
+DEFAULT_MATRIX_PRECISION = 'fp32_split'
 
 
 def set_matrix_precision(mode):

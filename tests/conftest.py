@@ -22,6 +22,7 @@ def _reset_process_wide_switches():
     if mod is not None:
         mod.enable_async_wgrad(False)
         mod.set_deterministic(False)
+        mod.set_matrix_precision('fp32')          # experiments switch to 'fp32_split'; the library default is the fp32 matrix instructions
 
 
 @pytest.fixture(scope='session')

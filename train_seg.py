@@ -41,7 +41,7 @@ def build_config(args):
     config['valid_data_dir'] = config['data_dir']
     config['log_dir'] = './{}/{}'.format(args.log_root, config['data'])
     config['device'] = 'cuda:{}'.format(args.device) if args.device.isdigit() else args.device
-    if not config.get('matrix_precision'):                # (--matrix-precision; not a key of the reference's config: absent = 'fp32', the fp32 matrix instructions)
+    if not config.get('matrix_precision'):                # (--matrix-precision; not a key of the reference's config: absent = the package default, 'fp32_split')
         config.pop('matrix_precision', None)
     return config
 
@@ -59,8 +59,9 @@ def main(argv=None):
     parser.add_argument('--log-root', '-log', default='./logs', type=str, help='root of the log folders')
     parser.add_argument('--shape', nargs=3, type=int, default=[64, 64, 64], help='synthetic volume size D H W (multiples of 8)')
     parser.add_argument('--matrix-precision', default=None, choices=['fp32', 'fp32_split', 'bf16'],
-                        help="arithmetic of the 3x3x3 convolutions: 'fp32' (default) fp32 matrix instructions; 'fp32_split' fp32-accurate products from an "
-                             "exact three-way bf16 split, ~1.4x faster convolutions (what bench.py measures); 'bf16' operands rounded to bf16")
+                        help="arithmetic of the 3x3x3 convolutions: 'fp32_split' (default; what bench.py measures) fp32-accurate products from an exact "
+                             "three-way bf16 split on the bf16 matrix pipe; 'fp32' the fp32 matrix instructions (A/B, ~1.35x slower); 'bf16' operands "
+                             "rounded to bf16 (not fp32-accurate)")
     args = parser.parse_args(argv)
     exp = SegmentationExperiment(build_config(args))
     if not args.test_only:
