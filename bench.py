@@ -81,29 +81,124 @@ def conv_bytes(key):
     return 4.0 * N * ((C1 + C2) * D * H * W + Cout * Do * Ho * Wo)
 
 
-def cpu_baseline(shape, batch, n_classes, budget_s=20.0):
-    """The oracle (plain-torch CPU restatement of the reference step) timed on this box's host cores."""
+def cpu_baseline(shape, batch, n_classes, budget_s=20.0, keep_reference=False):
+    """The oracle (plain-torch CPU restatement of the reference step, models/segmentation.py:141-157) timed on this box's host cores.
+    Inputs are the STRUCTURED synthetic volumes (blocky labels, image = label / 31 + noise: SURVEY.md 8d "Dice-parity inputs"), weights
+    the closed-form fill: the warm-up step doubles as the reference of `parity_fullsize` (keep_reference=True returns what the GPU side
+    is compared with: initial weights, inputs, first-step loss and train-mode logits)."""
     from oracle import nets, steps
+    from deepatlas_amd.lib.datasets import SyntheticSegDataset
     torch.manual_seed(230)
     spec = nets.UNET_LIGHT
     sd = nets.closed_form_fill(nets.unet_param_shapes(1, n_classes, spec['encoders'], spec['decoders']), seed=1)
-    g = torch.Generator().manual_seed(230)
-    x = torch.rand((batch, 1) + shape, generator=g)
-    y = torch.randint(0, n_classes, (batch,) + shape, generator=g, dtype=torch.uint8)
+    ds = SyntheticSegDataset(batch, shape, n_classes, seed=230)
+    x = torch.stack([ds[i][0] for i in range(batch)])
+    y = torch.stack([ds[i][1] for i in range(batch)])
+    ref = dict(sd0={k: v.clone() for k, v in sd.items()}, x=x, y=y) if keep_reference else None
     opt = steps.Adam(steps.trainable(sd), lr=1e-3)
     t0 = time.time()
-    steps.seg_step(sd, opt, x, y, spec, n_classes)                # warm-up (allocator, thread pool)
+    loss0, logits0, _ = steps.seg_step(sd, opt, x, y, spec, n_classes)                # warm-up (allocator, thread pool) = the parity step
     warm = time.time() - t0
+    if keep_reference:
+        ref.update(loss=float(loss0.item()), logits=logits0)
+    del logits0
     n, t0 = 0, time.time()
     while True:
         steps.seg_step(sd, opt, x, y, spec, n_classes)
         n += 1
-        if time.time() - t0 > budget_s or n >= 3:
+        if time.time() - t0 > budget_s or n >= 2:
             break
     dt = (time.time() - t0) / n
-    return dict(value=batch / dt, unit='volumes/s', cores=torch.get_num_threads(), kind='port',
+    base = dict(value=batch / dt, unit='volumes/s', cores=torch.get_num_threads(), kind='port',
                 sample='%d timed step(s) of the same workload (batch %d, %dx%dx%d) after 1 warm-up step of %.1f s; %.2f s/step'
                        % (n, batch, shape[0], shape[1], shape[2], warm, dt))
+    return (base, ref) if keep_reference else base
+
+
+def parity_fullsize(ref, n_classes, dev, modes, train_steps=150):
+    """Whole-network parity at the metric's own size, outside every timed region.  modes[0] is the shipped matrix mode.
+    (1) First step, per mode: the shipped training step (fused head + softmax + Dice, side-stream weight gradients) from the oracle's
+        initial weights on the oracle's batch -- loss and train-mode logits against oracle.steps.seg_step.
+    (2) "Dice vs CPU ref" (BASELINE's metric; models/segmentation.py:179-201): the modes[0] model trains `train_steps` more steps on the
+        device (structured volumes: learnable, so the Dice is not the ~0 of an untrained net), its checkpoint is handed to the oracle
+        (strict state_dict), and eval-mode logits, first-max argmax and per-class Dice from integer counts are compared on that SAME
+        checkpoint -- per mode on the device, ONE eval-mode CPU forward.  (Two independently trained states differ by Adam's sign-like
+        steps on rounding-level gradients, SURVEY.md 7: not a kernel property.)"""
+    from oracle import nets, losses
+    from deepatlas_amd import ops
+    from deepatlas_amd.lib import evalMetrics as M
+    from deepatlas_amd.lib.loss import get_loss_function
+    from deepatlas_amd.lib.network_factory import get_network
+    from deepatlas_amd.optim import FlatAdam
+    import numpy as np
+    prev = ops.set_matrix_precision(modes[0])
+    out = []
+    try:
+        x, y = ref['x'].to(dev), ref['y'].to(dev)
+        crit = get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+
+        def fresh(sd):
+            m = get_network('UNet_light')(in_channel=1, n_classes=n_classes, bias=True, BN=True)
+            m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+            return m.to(dev)
+        o = ref['logits'].to(dev)
+        trained = None
+        for mode in modes:
+            ops.set_matrix_precision(mode)
+            twin = fresh(ref['sd0']).train()                       # train-mode logits (its BatchNorm buffers move; it is thrown away)
+            with torch.no_grad():
+                logits = ops.materialize_logits(twin(x))
+            num, den = float((logits - o).double().norm()), float(o.double().norm())
+            mx = float((logits - o).abs().max() / o.abs().max())
+            del twin, logits
+            model = fresh(ref['sd0']).train()
+            model.lazy_head = True
+            opt = FlatAdam(model.parameters(), lr=1e-3)
+            opt.zero_grad()
+            loss = crit(model(x), y)
+            loss.backward()
+            opt.step()
+            loss = float(loss.item())
+            out.append(dict(matrix_precision=mode, loss=loss, oracle_loss=ref['loss'], loss_abs_diff=abs(loss - ref['loss']),
+                            logits_rel_l2=num / den, logits_max_abs_over_max=mx))
+            if trained is None:
+                for _ in range(train_steps):
+                    opt.zero_grad()
+                    last = crit(model(x), y)
+                    last.backward()
+                    opt.step()
+                torch.cuda.synchronize()
+                trained = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+                out[0].update(train_steps=1 + train_steps, trained_loss=float(last.item()))
+            del model, opt
+        del o
+        # the oracle's eval path on the trained checkpoint (one eval-mode CPU forward)
+        with torch.no_grad():
+            oe = nets.unet_forward({k: v.clone() for k, v in trained.items()}, ref['x'], nets.UNET_LIGHT, training=False)
+        o_dice = np.stack([losses.eval_dice_per_class(oe[i:i + 1], ref['y'][i:i + 1], n_classes)[0] for i in range(oe.shape[0])])
+        o_am = torch.max(oe, 1)[1]
+        top2 = torch.topk(oe, 2, dim=1)[0]
+        near = (top2[:, 0] - top2[:, 1]) < 1e-4 * top2[:, 0].abs().clamp_min(1.0)
+        both = ~np.isnan(o_dice)
+        oe_dev, oe_norm = oe.to(dev), float(oe.double().norm())
+        for mode, rec in zip(modes, out):
+            ops.set_matrix_precision(mode)
+            ev_model = fresh(trained).eval()
+            with torch.no_grad():
+                pred = ev_model(x)
+            dice = M.metricEval('dice', pred, y)                                    # [N][C-1], exact integer counts on the device
+            flips = torch.max(pred, 1)[1].cpu() != o_am
+            rec.update(eval_logits_rel_l2=float((pred - oe_dev).double().norm()) / oe_norm,
+                       eval_dice_mean=float(np.nanmean(dice)), oracle_eval_dice_mean=float(np.nanmean(o_dice)),
+                       eval_dice_abs_diff=float(np.abs(dice[both] - o_dice[both]).max()) if both.any() else 0.0,
+                       eval_dice_mean_abs_diff=abs(float(np.nanmean(dice)) - float(np.nanmean(o_dice))),
+                       nan_pattern_equal=bool(np.array_equal(np.isnan(dice), np.isnan(o_dice))),
+                       voxels=int(o_am.numel()), argmax_flips=int(flips.sum()), near_tie_flips=int((flips & near).sum()),
+                       flips_away_from_ties=int((flips & ~near).sum()))
+            del ev_model, pred
+        return out
+    finally:
+        ops.set_matrix_precision(prev)
 
 
 def free_port():
@@ -471,8 +566,17 @@ def main():
                                 c_abi_launches_per_step=head_res['c_abi_launches_per_step'], hip_graph=bool(args.graph), rccl=rccl,
                                 ms_per_step_per_rank=head_res.get('ms_per_step_per_rank')),
                     roofline=roofline, extra=extra or None)
-        if world == 1 and not args.no_cpu_baseline and args.workload == 'seg':
-            line['cpu_baseline'] = cpu_baseline(shape, args.batch, n_classes)
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'seg' and args.net == 'UNet_light':
+            # CPU leg: the oracle's step timed on the host cores; its first step is also the reference of the full-size parity block
+            # (the GPU side runs it once per matrix mode, outside every timed region)
+            line['cpu_baseline'], ref = cpu_baseline(shape, args.batch, n_classes, keep_reference=True)
+            modes = [args.precision] + (['fp32'] if args.precision == 'fp32_split' else [])
+            par = parity_fullsize(ref, n_classes, dev, modes)
+            line['parity_fullsize'] = dict(par[0], note='shipped step vs oracle.steps.seg_step on the same closed-form weights and structured batch '
+                                                       '(batch %d, %dx%dx%d): first-step loss / train-mode logits; eval logits / argmax / Dice of '
+                                                       'the device-trained checkpoint vs the oracle\'s eval path on that checkpoint'
+                                                       % ((args.batch,) + shape),
+                                           other_modes=par[1:] or None)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

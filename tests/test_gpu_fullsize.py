@@ -233,3 +233,21 @@ def test_full_size_fused_bn_block_crops_vs_torch_cpu():
         yr = F.conv3d(xin, w, b, padding=0).double()
         ref = F.leaky_relu(yr * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), 0.01).float()
         assert_close(out[n:n + 1, :, d0:d0 + bd, h0:h0 + bh, w0:w0 + bw], ref, 'conv+BN+act brick %d' % bi)
+
+
+def test_whole_network_step_and_eval_dice_vs_cpu_oracle_at_metric_size():
+    """BASELINE's metric: "... at 160x192x160 fp32; Dice vs CPU ref".  The shipped training step (fused head + softmax + Dice, split matrix
+    mode) and the eval path against oracle.steps.seg_step / nets.unet_forward on the SAME closed-form weights and structured batch at the
+    metric's own size, batch 2 -- the block bench.py emits as `parity_fullsize` (one CPU oracle step on the host cores: ~20 - 40 s).
+    Tolerance: north_star's 1e-4 relative fp32 for loss / logits / Dice; argmax exact away from the oracle's own near-ties."""
+    import bench
+    shape, batch, C = (160, 192, 160), 2, 32
+    base, ref = bench.cpu_baseline(shape, batch, C, budget_s=0.0, keep_reference=True)
+    assert base['value'] > 0
+    res = bench.parity_fullsize(ref, C, dev(), ['fp32_split', 'fp32'], train_steps=100)
+    assert res[0]['trained_loss'] < 0.9 * res[0]['loss'] and res[0]['eval_dice_mean'] > 0.05, res[0]      # a non-degenerate Dice to compare
+    for r in res:
+        assert r['loss_abs_diff'] <= 1e-4, r
+        assert r['logits_rel_l2'] <= 1e-4 and r['eval_logits_rel_l2'] <= 1e-4, r
+        assert r['flips_away_from_ties'] == 0 and r['nan_pattern_equal'], r
+        assert r['eval_dice_abs_diff'] <= 1e-4 and r['eval_dice_mean_abs_diff'] <= 1e-4, r
