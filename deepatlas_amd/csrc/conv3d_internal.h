@@ -45,6 +45,16 @@ int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, i
 int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
                       void* ws, size_t ws_bytes, hipStream_t st);
 
+// native stride-2 kernels in split matrix mode (conv3d_s2n.hip): one halo tile serves all 27 taps
+bool da_conv3_s2n_supported(int Cin, int Cout, int N, int D, int H, int W);
+size_t da_conv3_s2n_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int da_conv3_s2n_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
+                     int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st);
+int da_conv3_s2n_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, int N, int D, int H, int W, int Cout,
+                       void* ws, size_t ws_bytes, hipStream_t st);
+int da_conv3_s2n_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
+                       void* ws, size_t ws_bytes, hipStream_t st);
+
 // thin convs (Cout <= 4 or Cin <= 4) on the VALU from an LDS halo tile; flip_tr: `w` is the original layer's [27][Cout][Cin]
 // tensor and the data-gradient convolution is computed
 bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride);

@@ -82,6 +82,12 @@ static S2Plan s2_plan(int N, int D, int H, int W, int Cin, int Cout) {
     return p;
 }
 
+// split matrix mode: the native stride-2 kernels (conv3d_s2n.hip) take the shapes they support; DA_NO_S2N=1 keeps the masked route (A/B)
+bool s2_native(int Cin, int Cout, int N, int D, int H, int W) {
+    static int off = -1; if (off < 0) { const char* e = getenv("DA_NO_S2N"); off = (e && atoi(e)) ? 1 : 0; }
+    return !off && da_matrix_mode() == 2 && da_conv3_s2n_supported(Cin, Cout, N, D, H, W);
+}
+
 // DA_S2D_COPY=1: the earlier route through materialised space-to-depth tensors (A/B of the fused addressing)
 bool s2_fused() { static int v = -1; if (v < 0) { const char* e = getenv("DA_S2D_COPY"); v = (e && atoi(e)) ? 0 : 1; } return v == 1; }
 
@@ -91,12 +97,15 @@ bool da_conv3_s2_supported(int C1, int C2, int Cout) { return C2 == 0 && C1 % 16
 
 size_t da_conv3_s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
-    return p.s_bytes + 2 * p.we_bytes + p.inner_bytes;
+    size_t b = p.s_bytes + 2 * p.we_bytes + p.inner_bytes;
+    if (da_conv3_s2n_supported(Cin, Cout, N, D, H, W)) { const size_t nb = da_conv3_s2n_ws_bytes(N, D, H, W, Cin, Cout); if (nb > b) b = nb; }
+    return b;
 }
 
 // ws layout: [S (space-to-depth tensor or its gradient)] [W' expanded] [dW' expanded] [inner conv scratch]
 int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
                     int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (s2_native(Cin, Cout, N, D, H, W)) return da_conv3_s2n_fwd(in, Cin, w_tio, bias, out, N, D, H, W, Cout, slope, ws, ws_bytes, st);
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     float* S = (float*)ws; float* We = (float*)((char*)ws + p.s_bytes); char* inner = (char*)ws + p.s_bytes + 2 * p.we_bytes;
@@ -115,6 +124,7 @@ int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* b
 
 int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, int N, int D, int H, int W, int Cout,
                       void* ws, size_t ws_bytes, hipStream_t st) {
+    if (s2_native(Cin, Cout, N, D, H, W)) return da_conv3_s2n_dgrad(dy, w_tio, dx, Cin, N, D, H, W, Cout, ws, ws_bytes, st);
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     float* dS = (float*)ws; float* We = (float*)((char*)ws + p.s_bytes); char* inner = (char*)ws + p.s_bytes + 2 * p.we_bytes;
@@ -134,6 +144,7 @@ int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, i
 
 int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
                       void* ws, size_t ws_bytes, hipStream_t st) {
+    if (s2_native(Cin, Cout, N, D, H, W)) return da_conv3_s2n_wgrad(in, Cin, dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes, st);
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     float* S = (float*)ws; float* dWe = (float*)((char*)ws + p.s_bytes + p.we_bytes); char* inner = (char*)ws + p.s_bytes + 2 * p.we_bytes;

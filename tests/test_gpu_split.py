@@ -32,14 +32,14 @@ def rnd(shape, seed, scale=1.0, kind='uniform'):
     raise ValueError(kind)
 
 
-def _run(mode, x1, x2, w, b, go, slope=-1.0):
+def _run(mode, x1, x2, w, b, go, slope=-1.0, stride=1):
     from deepatlas_amd import ops
     prev = ops.set_matrix_precision(mode)
     try:
         a1 = cl(x1).requires_grad_(True)
         a2 = cl(x2).requires_grad_(True) if x2 is not None else None
         wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
-        y = ops.Conv3dK3Fn.apply(a1, a2, wg, bg, 1, slope)
+        y = ops.Conv3dK3Fn.apply(a1, a2, wg, bg, stride, slope)
         y.backward(cl(go))
         torch.cuda.synchronize()
         out = [y.detach().cpu(), a1.grad.cpu()] + ([a2.grad.cpu()] if a2 is not None else []) + [wg.grad.cpu(), bg.grad.cpu()]
@@ -94,6 +94,47 @@ def test_split_mode_is_fp32_accurate(case, kind):
     print('\n'.join('%-7s rel-l2 chain %.2e split %.2e | max-abs chain %.2e split %.2e' % r for r in record))
 
 
+S2_CASES = [
+    # Cin, Cout, (N, D, H, W): the registration encoder's stride-2 layers (voxel_morph.py:43-47) on the native kernels of conv3d_s2n.hip
+    (16, 32, (1, 20, 24, 20)),         # enc1 of the odd pyramid (10 x 12 x 10 out: ragged y / x tiles)
+    (32, 32, (2, 10, 12, 10)),         # enc2, two samples, 5 x 6 x 5 out
+    (32, 32, (1, 5, 6, 5)),            # odd input sizes: out = ceil(n / 2) = 3 x 3 x 3
+    (32, 32, (1, 3, 3, 3)),            # 2 x 2 x 2 out
+    (16, 32, (1, 9, 17, 35)),          # every axis odd, two x tiles, three y tiles
+    (16, 32, (1, 8, 16, 64)),          # exact tiles, two x tiles
+    (32, 64, (1, 8, 8, 40)),           # two 32-wide output groups
+    (16, 64, (1, 2, 2, 2)),            # a single output voxel
+]
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'lognormal'])
+@pytest.mark.parametrize('case', S2_CASES, ids=lambda c: 's2_c%d_o%d_%s' % (c[0], c[1], 'x'.join(str(v) for v in c[2])))
+def test_native_stride2_split_kernels_are_fp32_accurate(case, kind):
+    """Forward / data gradient / weight gradient / bias gradient of a stride-2 3x3x3 conv (+ fused ReLU, modules.py:56-58) in split mode
+    against torch-CPU in DOUBLE, next to the fp32 matrix instructions' error on the same inputs (the tap-masked space-to-depth route)."""
+    Cin, Cout, (N, D, H, W) = case
+    x = rnd((N, Cin, D, H, W), 11, kind=kind)
+    w = rnd((Cout, Cin, 3, 3, 3), 12, 0.2, kind=kind)
+    b = rnd((Cout,), 13, 0.1)
+    Do, Ho, Wo = (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    go = rnd((N, Cout, Do, Ho, Wo), 14, kind=kind)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.relu(F.conv3d(xr, wr, br, stride=2, padding=1))
+    yr.backward(go.double())
+    ref = [yr.detach(), xr.grad, wr.grad, br.grad]
+    native = _run('fp32', x, None, w, b, go, slope=0.0, stride=2)
+    split = _run('fp32_split', x, None, w, b, go, slope=0.0, stride=2)
+    for nm, r, a, s in zip(['fwd', 'dgrad', 'wgrad', 'bgrad'], ref, native, split):
+        r = r.numpy()
+        e_nat, e_sp = rel_l2(a.numpy().astype(np.float64), r), rel_l2(s.numpy().astype(np.float64), r)
+        m_nat, m_sp = max_abs_rel(a.numpy().astype(np.float64), r), max_abs_rel(s.numpy().astype(np.float64), r)
+        # (one fp32 ulp of slack, 2^-23: with log-normal magnitudes a sum is dominated by ONE product, the chain's error is below a single
+        # rounding and the split's six partial sums round once each)
+        assert e_sp <= 1.25 * e_nat + 1.2e-7, '%s: split rel-l2 %.3e vs fp32 chain %.3e' % (nm, e_sp, e_nat)
+        assert m_sp <= 1.5 * m_nat + 2.4e-7, '%s: split max-abs %.3e vs fp32 chain %.3e' % (nm, m_sp, m_nat)
+        assert e_sp < 1e-5 and m_sp < 1e-5, (nm, e_sp, m_sp)
+
+
 def test_split_mode_activation_bias_and_fp32_after_switching_back():
     """Fused bias + LeakyReLU epilogue in split mode, and the fp32 kernels are bit-identical before / after a visit to the mode."""
     C1, Cout, dims = 16, 16, (1, 8, 16, 32)
@@ -129,7 +170,8 @@ def _reruns():
         ('full_size_fused_bn_block_crops', lambda g: tf.test_full_size_fused_bn_block_crops_vs_torch_cpu()),
     ]
     for c in tf.CONV_LAYERS:
-        if c[4] == 1 and (c[1] + c[2]) % 8 == 0 and c[3] % 4 == 0 and c[3] >= 8:          # the layers the split kernels take
+        if ((c[4] == 1 and (c[1] + c[2]) % 8 == 0 and c[3] % 4 == 0 and c[3] >= 8)           # the layers the split kernels take
+                or (c[4] == 2 and c[2] == 0 and c[1] % 16 == 0 and c[3] % 32 == 0)):          # ... and the native stride-2 kernels
             runs.append(('full_size_conv_crops_' + c[0].replace(' ', '_'), lambda g, c=c: tf.test_full_size_conv_crops_vs_torch_cpu(*c)))
     return runs
 
