@@ -36,6 +36,11 @@ SIGNATURES = {
     'da_conv3d_k3_wgrad': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_conv3d_k3_fwd_pro': (I, [P, I, P, P, F, P, I, P, P, F, P, P, P, I, I, I, I, I, F, P, I, POINTER(c_int), P, SZ, P]),
     'da_conv3d_k3_wgrad_pro': (I, [P, I, P, P, F, P, I, P, P, F, P, P, I, I, I, I, I, P, SZ, P]),
+    'da_upconv3d_k3_supported': (I, [I, I, I]),
+    'da_upconv3d_k3_ws_bytes': (SZ, [I, I, I, I, I, I]),
+    'da_upconv3d_k3_fwd': (I, [P, I, P, I, P, P, P, I, I, I, I, I, F, P, SZ, P]),
+    'da_upconv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_upconv3d_k3_wgrad': (I, [P, I, P, I, P, P, I, I, I, I, I, P, SZ, P]),
     'da_set_conv_direct': (I, [I]),
     'da_set_matrix_bf16': (I, [I]),
     'da_set_matrix_mode': (I, [I]),
@@ -61,6 +66,8 @@ SIGNATURES = {
     'da_act_bwd': (I, [P, P, F, P, LL, P]),
     'da_act_bwd_add_dbias': (I, [P, P, P, F, P, P, LL, I, P, SZ, P]),
     'da_colsum': (I, [P, LL, I, P, P, SZ, P]),
+    'da_act_bwd_add_partial': (I, [P, P, P, F, P, LL, I, P, SZ, POINTER(c_int), P]),
+    'da_colsum_finish': (I, [P, I, I, P, I, P]),
     'da_maxpool2_fwd': (I, [P, P, I, I, I, I, I, P]),
     'da_maxpool2_fwd_pro': (I, [P, P, P, F, P, P, I, I, I, I, I, P]),
     'da_maxpool2_bwd': (I, [P, P, P, I, I, I, I, I, P]),

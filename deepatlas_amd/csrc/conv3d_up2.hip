@@ -1,0 +1,713 @@
+// Nearest x2 up-sampling folded into the 3x3x3 convolution that consumes it (the registration decoder: voxel_morph.py:72-80,
+// `F.interpolate(x, size=skip.shape)` followed by modules.convBlock), split matrix mode.
+//
+// U[u] = S[u >> 1] (exact x2, every axis even) and Y[u] = b + sum_{t in {0,1,2}^3} U[u + t - 1] . W[t].  A fine voxel u = 2 c + p only
+// ever sees the 2 x 2 x 2 coarse voxels c + p + j - 1 (j in {0,1}^3), so per output parity class p the layer is a 2 x 2 x 2-tap
+// convolution ON THE COARSE GRID with pre-summed weights (per axis: p 0: j 0 <- W[0], j 1 <- W[1] + W[2];  p 1: j 0 <- W[0] + W[1],
+// j 1 <- W[2]):   Y[2 c + p] = b + sum_j S[c + p + j - 1] . Weff[p][j].
+// 64 tap evaluations per coarse voxel instead of 216, and neither the up-sampled tensor (8 x the source) nor its gradient ever exists:
+//   forward   8 classes x 8 taps from one coarse halo tile (4 x 6 x 18 voxels per 8-channel chunk); a wave owns two classes and all
+//             8 M-tiles of the 2 x 4 x 16 coarse tile (= 4 x 8 x 32 fine outputs per workgroup), bias + ReLU fused, two source tensors
+//             (the decoder's concat of two up-sampled tensors, voxel_morph.py:74,76) as two pointers;
+//   dgrad     dS[c] = sum_{f in {-1..2}^3} dY[2 c + f] . K4[f]: the adjoint is ONE stride-2 convolution with a 4 x 4 x 4 kernel of summed
+//             weights (per axis f -1 <- W[2], 0 <- W[1] + W[2], 1 <- W[0] + W[1], 2 <- W[0]) over the fine gradient: the 8-to-1
+//             reduction of the up-sampling's backward happens inside the K loop.  Fine halo tile 6 x 10 x 34 per 8-channel chunk, x
+//             de-interleaved by parity as in conv3d_s2n.hip;
+//   wgrad     G[p][j] = sum_c S[c + p + j - 1]^T dY[2 c + p] (64 small GEMMs over COARSE voxels, one workgroup column per class p), then
+//             dW[t] = sum of the 8 (p, j) pairs that contain tap t, folded into the fixed-order double-precision partial reduction.
+// The weight sums are formed in double and rounded to fp32 once (one extra rounding per weight, the size of one fp32 product rounding),
+// then split exactly into three bf16 planes like every other split-mode operand.
+#include "common.h"
+#include "conv3d_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CTZ = 2, CTY = 4, CTX = 16;                       // coarse tile
+constexpr int SZ = CTZ + 2, SY = CTY + 2, SX = CTX + 2;         // coarse halo of the forward / weight gradient: 4 x 6 x 18
+constexpr int SV = SZ * SY * SX;                                // 432 voxels
+constexpr int SPLANE_B = SV * 16;                               // bytes per plane of one 8-channel chunk
+constexpr int S_NIT = (SV * 2 + 255) / 256;                     // 4 staging iterations (two 16-byte quads per voxel)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t up_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 up_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void up_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, off, 0, 0);
+}
+__device__ __forceinline__ unsigned up_bf16x2(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void up_split3(const float4 v, uint2& h, uint2& m, uint2& l) {      // exact: v = h + m + l (see conv3d_mfma.hip, da_split3)
+    h = make_uint2(up_bf16x2(v.x, v.y), up_bf16x2(v.z, v.w));
+    const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xFFFF0000u);
+    const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xFFFF0000u);
+    m = make_uint2(up_bf16x2(rx, ry), up_bf16x2(rz, rw));
+    const float sx = rx - __uint_as_float(m.x << 16), sy = ry - __uint_as_float(m.x & 0xFFFF0000u);
+    const float sz = rz - __uint_as_float(m.y << 16), sw = rw - __uint_as_float(m.y & 0xFFFF0000u);
+    l = make_uint2(up_bf16x2(sx, sy), up_bf16x2(sz, sw));
+}
+__device__ __forceinline__ void up_split3_scalar(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)v; const float r1 = v - (float)bh;
+    const __bf16 bm = (__bf16)r1; const float r2 = r1 - (float)bm;
+    h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, (__bf16)r2);
+}
+__device__ __forceinline__ float up_qx1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float up_qx2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ f32x4 up_quad_transpose(f32x4 a, int q) {      // (4 voxels x 1 channel) per lane -> (1 voxel x 4 channels)
+    float t0 = a[0], t1 = a[1], t2 = a[2], t3 = a[3];
+    {
+        const bool odd = (q & 1) != 0;
+        const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
+        const float r01 = up_qx1(s01), r23 = up_qx1(s23);
+        if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
+    }
+    {
+        const bool hi2 = (q & 2) != 0;
+        const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
+        const float r02 = up_qx2(s02), r13 = up_qx2(s13);
+        if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
+    }
+    return (f32x4){t0, t1, t2, t3};
+}
+__device__ __forceinline__ int up_xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, loc = bid / 8;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+#define UP_PLANE_PAIRS constexpr int kPA[6] = {0, 2, 1, 0, 1, 0}, kPB[6] = {2, 0, 1, 1, 0, 0}      // split products, smallest first
+
+// per axis: original taps that feed coarse tap j of parity p (forward / weight gradient)
+__host__ __device__ inline int up_taps_of(int p, int j, int* t) {
+    if (p == 0) { if (j == 0) { t[0] = 0; return 1; } t[0] = 1; t[1] = 2; return 2; }
+    if (j == 0) { t[0] = 0; t[1] = 1; return 2; }
+    t[0] = 2; return 1;
+}
+// per axis: original taps summed into the adjoint's tap f = fi - 1 (fi 0..3)
+__host__ __device__ inline int up_taps_of_f(int fi, int* t) {
+    if (fi == 0) { t[0] = 2; return 1; }
+    if (fi == 1) { t[0] = 1; t[1] = 2; return 2; }
+    if (fi == 2) { t[0] = 0; t[1] = 1; return 2; }
+    t[0] = 0; return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// coarse halo staging (forward, weight gradient): 432 voxels x 8 channels
+// ------------------------------------------------------------------------------------------------------------------------------
+struct SMap {
+    int hv[S_NIT]; int c4;
+    __device__ __forceinline__ void init() {
+        c4 = (int)threadIdx.x & 1;
+#pragma unroll
+        for (int it = 0; it < S_NIT; ++it) { const int v = ((int)threadIdx.x + it * 256) >> 1; hv[it] = v < SV ? v : -1; }
+    }
+    __device__ __forceinline__ unsigned offset(int it, int zb, int yb, int xb, int D, int H, int W, int Cs, int choff) const {
+        const int v = hv[it];
+        const int hx = v % SX, t = v / SX, hy = t % SY, hz = t / SY;
+        const int z = zb + hz, y = yb + hy, x = xb + hx;
+        const bool inb = v >= 0 && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        return inb ? (unsigned)((((z * H + y) * W + x) * Cs + choff + c4 * 4) * 4) : 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ void write(unsigned char* lds, const float4* pre) const {
+#pragma unroll
+        for (int it = 0; it < S_NIT; ++it) {
+            if (hv[it] >= 0) {
+                uint2 h, m, l; up_split3(pre[it], h, m, l);
+                uint2* o = reinterpret_cast<uint2*>(lds) + hv[it] * 2 + c4;
+                o[0] = h; o[SPLANE_B / 8] = m; o[2 * (SPLANE_B / 8)] = l;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------------------
+struct FwdP {
+    const float* s1; const float* s2; int C1, C2;
+    const unsigned char* wp; const float* bias; float* out;
+    int N, Dc, Hc, Wc, Cout, ntz, nty, ntx, nchunks, NTall;
+    float slope;
+};
+
+// packed B operand: [chunk][class][step 2][N-tile][plane][lane][8]; lane (g, n): coarse tap 4 step + g, cin chunk * 8 + e, cout 16 nt + n
+__global__ void up_pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int NT, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long long rest = idx >> 9;
+        const long long blk = rest;
+        const int nt = (int)(rest % NT); rest /= NT;
+        const int s = (int)(rest & 1); rest >>= 1;
+        const int cls = (int)(rest & 7); const int ch = (int)(rest >> 3);
+        const int g = lane >> 4, n = lane & 15;
+        const int jt = 4 * s + g, ci = ch * 8 + e, co = nt * 16 + n;
+        double acc = 0.0;
+        if (ci < Cin && co < Cout) {
+            int tz[2], ty[2], tx[2];
+            const int nz = up_taps_of((cls >> 2) & 1, (jt >> 2) & 1, tz), ny = up_taps_of((cls >> 1) & 1, (jt >> 1) & 1, ty), nx = up_taps_of(cls & 1, jt & 1, tx);
+            for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
+                acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
+        }
+        unsigned short h, m, l; up_split3_scalar((float)acc, h, m, l);
+        unsigned short* o = wp + blk * 1536 + lane * 8 + e;
+        o[0] = h; o[512] = m; o[1024] = l;
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4, q = lane & 3, a4 = (lane & 15) >> 2;
+    const int nt0 = blockIdx.y * NT;
+    int t = up_xcd_remap(blockIdx.x, gridDim.x);
+    const int tz = t % p.ntz; t /= p.ntz;
+    const int ty = t % p.nty; t /= p.nty;
+    const int tx = t % p.ntx; const int n = t / p.ntx;
+    const int z0 = tz * CTZ, y0 = ty * CTY, x0 = tx * CTX;
+    const long long vox = (long long)p.Dc * p.Hc * p.Wc;
+    const __amdgpu_buffer_rsrc_t r1 = up_rsrc(p.s1 + (long long)n * vox * p.C1, (unsigned)(vox * p.C1 * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t r2 = up_rsrc(p.C2 ? p.s2 + (long long)n * vox * p.C2 : p.s1, (unsigned)(p.C2 ? vox * p.C2 * sizeof(float) : 0));
+    const __amdgpu_buffer_rsrc_t rsw = up_rsrc(p.wp, (unsigned)((size_t)p.nchunks * 16 * p.NTall * 3072));
+    SMap sm; sm.init();
+    float4 pre[S_NIT];
+    auto issue = [&](int ch) {
+        const int cb = ch * 8;
+        const bool first = cb < p.C1;
+#pragma unroll
+        for (int it = 0; it < S_NIT; ++it)
+            pre[it] = up_load4(first ? r1 : r2, sm.offset(it, z0 - 1, y0 - 1, x0 - 1, p.Dc, p.Hc, p.Wc, first ? p.C1 : p.C2, first ? cb : cb - p.C1));
+    };
+    auto ld = [&](int off) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lds + off); };
+    UP_PLANE_PAIRS;
+    f32x4 acc[2][CTZ * CTY][NT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int m = 0; m < CTZ * CTY; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) acc[c][m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue(0);
+    sm.write(lds, pre);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool more = ch + 1 < p.nchunks;
+        if (more) issue(ch + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int cls = 2 * wave + c;
+            const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int jt = 4 * s + g;                        // this lane group's coarse tap
+                const int abase = (((pz + ((jt >> 2) & 1)) * SY + py + ((jt >> 1) & 1)) * SX + px + (jt & 1) + i) * 16;
+                bf16x8 B[NT][3];
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        B[nn][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u,
+                                        (unsigned)(((((ch * 8 + cls) * 2 + s) * p.NTall + nt0 + nn) * 3 + pl) * 1024), 0));
+#pragma unroll
+                for (int mz = 0; mz < CTZ; ++mz) {
+                    bf16x8 A[CTY][3];
+#pragma unroll
+                    for (int my = 0; my < CTY; ++my)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) A[my][pl] = ld(pl * SPLANE_B + abase + ((mz * SY + my) * SX) * 16);
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                            for (int my = 0; my < CTY; ++my)
+                                acc[c][mz * CTY + my][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[my][kPA[pr]], B[nn][kPB[pr]], acc[c][mz * CTY + my][nn], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            __syncthreads();
+            sm.write(lds, pre);
+            __syncthreads();
+        }
+    }
+    // epilogue: fine voxel (2 (z0 + mz) + pz, 2 (y0 + my) + py, 2 (x0 + 4 g + q) + px), couts 16 (nt0 + nn) + 4 a4 .. + 3
+    const int Df = 2 * p.Dc, Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+    const long long osample = (long long)Df * Hf * Wf * p.Cout;
+    const __amdgpu_buffer_rsrc_t ro = up_rsrc(p.out + (long long)n * osample, (unsigned)(osample * sizeof(float)));
+    const int xc = x0 + 4 * g + q;
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+        const int co0 = (nt0 + nn) * 16 + 4 * a4;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co0 + j < p.Cout) ? p.bias[co0 + j] : 0.f;
+        const bool cok = co0 + 3 < p.Cout && xc < p.Wc;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int cls = 2 * wave + c;
+            const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+#pragma unroll
+            for (int mz = 0; mz < CTZ; ++mz)
+#pragma unroll
+                for (int my = 0; my < CTY; ++my) {
+                    const f32x4 v = up_quad_transpose(acc[c][mz * CTY + my][nn], q);
+                    const f32x4 o = {da_act(v[0] + bv[0], p.slope), da_act(v[1] + bv[1], p.slope), da_act(v[2] + bv[2], p.slope), da_act(v[3] + bv[3], p.slope)};
+                    const int zc = z0 + mz, yc = y0 + my;
+                    const bool ok = cok && zc < p.Dc && yc < p.Hc;
+                    up_store4(ro, ok ? (unsigned)(((((2 * zc + pz) * Hf + 2 * yc + py) * Wf + 2 * xc + px) * p.Cout + co0) * 4) : 0xFFFFFFFFu, o);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// data gradient: stride-2 convolution of the fine gradient with the 4 x 4 x 4 summed kernel
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int FZ = 2 * CTZ + 2, FY = 2 * CTY + 2, FXV = 2 * CTX + 2;   // fine halo 6 x 10 x 34
+constexpr int FXS = 34;                                                // x slots: 17 even columns then 17 odd
+constexpr int FV = FZ * FY * FXV;                                      // 2040 voxels
+constexpr int FPLANE_B = FZ * FY * FXS * 16;
+constexpr int F_NIT = (FV * 2 + 255) / 256;                            // 16
+
+struct DgP {
+    const float* dy; const unsigned char* wp; float* dx1; float* dx2; int C1, C2;
+    int N, Dc, Hc, Wc, Cout, ntz, nty, ntx, nchunks, NTN;      // nchunks = Cout / 8 (K chunks), NTN = N-tiles over Cin
+};
+
+// packed B operand: [chunk (8 couts)][step 16][N-tile][plane][lane][8]; lane (g, n): adjoint tap 4 step + g (fz*16 + fy*4 + fx), K = cout chunk*8+e, N = cin 16 nt + n
+__global__ void up_pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int NTN, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long long rest = idx >> 9;
+        const long long blk = rest;
+        const int nt = (int)(rest % NTN); rest /= NTN;
+        const int s = (int)(rest & 15); const int ch = (int)(rest >> 4);
+        const int g = lane >> 4, n = lane & 15;
+        const int ft = 4 * s + g, co = ch * 8 + e, ci = nt * 16 + n;
+        double acc = 0.0;
+        if (ci < Cin && co < Cout) {
+            int tz[2], ty[2], tx[2];
+            const int nz = up_taps_of_f((ft >> 4) & 3, tz), ny = up_taps_of_f((ft >> 2) & 3, ty), nx = up_taps_of_f(ft & 3, tx);
+            for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
+                acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
+        }
+        unsigned short h, m, l; up_split3_scalar((float)acc, h, m, l);
+        unsigned short* o = wp + blk * 1536 + lane * 8 + e;
+        o[0] = h; o[512] = m; o[1024] = l;
+    }
+}
+
+template <int NTN>      // N-tiles over Cin: 1, 2 or 4; wave -> (N-tile w % NTN, M group w / NTN), 8 NTN / 4 M-tiles per wave
+__global__ void __launch_bounds__(256, 1) up_dgrad_kernel(DgP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int MPW = 2 * NTN;                                 // M-tiles per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4, q = lane & 3, a4 = (lane & 15) >> 2;
+    const int nt = wave % NTN, mg = wave / NTN;
+    int t = up_xcd_remap(blockIdx.x, gridDim.x);
+    const int tz = t % p.ntz; t /= p.ntz;
+    const int ty = t % p.nty; t /= p.nty;
+    const int tx = t % p.ntx; const int n = t / p.ntx;
+    const int z0 = tz * CTZ, y0 = ty * CTY, x0 = tx * CTX;
+    const int Df = 2 * p.Dc, Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+    const long long ysample = (long long)Df * Hf * Wf * p.Cout;
+    const __amdgpu_buffer_rsrc_t ry = up_rsrc(p.dy + (long long)n * ysample, (unsigned)(ysample * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rsw = up_rsrc(p.wp, (unsigned)((size_t)p.nchunks * 16 * NTN * 3072));
+    // staging map: iteration it covers halo voxel v = (tid + 256 it) / 2 = (hz, hy, hx), quad tid & 1; LDS slot de-interleaves x by parity
+    const int c4 = (int)threadIdx.x & 1;
+    unsigned pk[F_NIT]; int slot[F_NIT];
+#pragma unroll
+    for (int it = 0; it < F_NIT; ++it) {
+        const int v = ((int)threadIdx.x + it * 256) >> 1;
+        const int hx = v % FXV, t2 = v / FXV, hy = t2 % FY, hz = t2 / FY;
+        const bool ok = v < FV;
+        pk[it] = ok ? ((unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx) : 0xFFFF0000u;
+        const int xpos = (hx & 1) ? 17 + (hx >> 1) : (hx >> 1);
+        slot[it] = ok ? ((t2 * FXS + xpos) * 2 + c4) : -1;
+    }
+    // (two half-size register arrays: one 256-byte array is left in scratch memory by hipcc's alloca promotion)
+    constexpr int FH = F_NIT / 2;
+    float4 preA[FH], preB[FH];
+    auto issue = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < F_NIT; ++it) {
+            const int hz = (int)(pk[it] >> 16), hy = (int)((pk[it] >> 8) & 255u), hx = (int)(pk[it] & 255u);
+            const int z = 2 * z0 - 1 + hz, y = 2 * y0 - 1 + hy, x = 2 * x0 - 1 + hx;
+            const bool inb = hz != 0xFFFF && (unsigned)z < (unsigned)Df && (unsigned)y < (unsigned)Hf && (unsigned)x < (unsigned)Wf;
+            const float4 v = up_load4(ry, inb ? (unsigned)((((z * Hf + y) * Wf + x) * p.Cout + ch * 8 + c4 * 4) * 4) : 0xFFFFFFFFu);
+            if (it < FH) preA[it < FH ? it : 0] = v; else preB[it >= FH ? it - FH : 0] = v;
+        }
+    };
+    auto write = [&]() {
+#pragma unroll
+        for (int it = 0; it < F_NIT; ++it) {
+            if (slot[it] >= 0) {
+                uint2 h, m, l; up_split3(it < FH ? preA[it < FH ? it : 0] : preB[it >= FH ? it - FH : 0], h, m, l);
+                uint2* o = reinterpret_cast<uint2*>(lds) + slot[it];
+                o[0] = h; o[FPLANE_B / 8] = m; o[2 * (FPLANE_B / 8)] = l;
+            }
+        }
+    };
+    auto ld = [&](int off) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lds + off); };
+    UP_PLANE_PAIRS;
+    f32x4 acc[MPW];
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue(0);
+    write();
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool more = ch + 1 < p.nchunks;
+        if (more) issue(ch + 1);
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int ft = 4 * s + g;                            // adjoint tap of this lane group: fi = f + 1 per axis
+            const int fz = (ft >> 4) & 3, fy = (ft >> 2) & 3, fx = ft & 3;
+            const int xp = (fx & 1) ? 17 + (fx >> 1) : (fx >> 1);     // halo column 2 i + fx: even fx -> slot i + fx / 2, odd -> 17 + i + fx / 2
+            const int abase = ((fz * FY + fy) * FXS + xp + i) * 16;
+            bf16x8 B[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                B[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((ch * 16 + s) * NTN + nt) * 3 + pl) * 1024), 0));
+            bf16x8 A[MPW][3];
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) {
+                const int mt = mg * MPW + m, mz = mt / CTY, my = mt % CTY;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) A[m][pl] = ld(pl * FPLANE_B + abase + ((2 * mz * FY + 2 * my) * FXS) * 16);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int m = 0; m < MPW; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[m][kPA[pr]], B[kPB[pr]], acc[m], 0, 0, 0);
+        }
+        if (more) {
+            __syncthreads();
+            write();
+            __syncthreads();
+        }
+    }
+    // stores: coarse voxel (z0 + mz, y0 + my, x0 + 4 g + q), input channels 16 nt + 4 a4 .. + 3 of dx1 | dx2
+    const int ci0 = nt * 16 + 4 * a4;
+    const bool first = ci0 < p.C1;
+    const int Cd = first ? p.C1 : p.C2, cd = first ? ci0 : ci0 - p.C1;
+    const long long vox = (long long)p.Dc * p.Hc * p.Wc;
+    const __amdgpu_buffer_rsrc_t rd = up_rsrc((first ? p.dx1 : p.dx2) + (long long)n * vox * Cd, (unsigned)(vox * Cd * sizeof(float)));
+    const int xc = x0 + 4 * g + q;
+    const bool cok = ci0 + 3 < p.C1 + p.C2 && xc < p.Wc;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+        const int mt = mg * MPW + m, zc = z0 + mt / CTY, yc = y0 + mt % CTY;
+        const f32x4 v = up_quad_transpose(acc[m], q);
+        up_store4(rd, (cok && zc < p.Dc && yc < p.Hc) ? (unsigned)((((zc * p.Hc + yc) * p.Wc + xc) * Cd + cd) * 4) : 0xFFFFFFFFu, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// weight gradient: G[p][j][ci][co] per class, then dW[t] = sum of the (p, j) pairs containing tap t
+// ------------------------------------------------------------------------------------------------------------------------------
+struct WgP {
+    const float* s1; const float* s2; int C1, C2;
+    const float* dy; float* partial;
+    int N, Dc, Hc, Wc, Cout, ntz, nty, ntx, ntiles, nslabs, O;       // O = 64 * Cin * Cout (one partial set: [class][j][ci][co])
+};
+constexpr int YV = CTZ * CTY * CTX;                              // 128 dY voxels of one class per tile
+constexpr int YPLANE_B = YV * 32 * 2;                            // [voxel][32 couts] bf16
+
+__global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* ldsY = lds + 3 * SPLANE_B;
+    typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4, q = i & 3, vq = i >> 2;
+    const int ch = blockIdx.y, cls = blockIdx.z;
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    const int zi = g >> 1;
+    const int cb = ch * 8;
+    const bool first = cb < p.C1;
+    const float* src = first ? p.s1 : p.s2;
+    const int Cs = first ? p.C1 : p.C2, choff = first ? cb : cb - p.C1;
+    auto tr8 = [&](const unsigned char* a, int step_bytes) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step_bytes));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // S fragment of tap-pair slot s (taps 2 s, 2 s + 1; this lane: tap 2 s + (q >> 1), channel quad q & 1) for output row `wave`
+    int aoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int jt = 2 * s + (q >> 1);
+        aoff[s] = ((((zi + pz + ((jt >> 2) & 1)) * SY + wave + py + ((jt >> 1) & 1)) * SX + px + (jt & 1) + 8 * (g & 1) + vq) * 8 + (q & 1) * 4) * 2;
+    }
+    const int yoff = (((zi * CTY + wave) * CTX + 8 * (g & 1) + vq) * 32 + q * 4) * 2;
+    struct F3 { bf16x8 p[3]; };
+    auto loadF = [&](int s) -> F3 { F3 f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(lds + pl * SPLANE_B + aoff[s], 4 * 8 * 2);
+        return f; };
+    auto loadY = [&](int nn) -> F3 { F3 f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(ldsY + pl * YPLANE_B + yoff + nn * 32, 4 * 32 * 2);
+        return f; };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    SMap sm; sm.init();
+    float4 preA[S_NIT], preY[4];
+    const int yv0 = (int)threadIdx.x >> 3, yq = (int)threadIdx.x & 7;
+    const int Df = 2 * p.Dc, Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+    auto issue = [&](int pos) {
+        int t = pos;
+        const int tz = t % p.ntz; t /= p.ntz;
+        const int ty = t % p.nty; t /= p.nty;
+        const int tx = t % p.ntx; const int n = t / p.ntx;
+        const int z0 = tz * CTZ, y0 = ty * CTY, x0 = tx * CTX;
+        const long long vox = (long long)p.Dc * p.Hc * p.Wc;
+        const __amdgpu_buffer_rsrc_t rs = up_rsrc(src + (long long)n * vox * Cs, (unsigned)(vox * Cs * sizeof(float)));
+#pragma unroll
+        for (int it = 0; it < S_NIT; ++it) preA[it] = up_load4(rs, sm.offset(it, z0 - 1, y0 - 1, x0 - 1, p.Dc, p.Hc, p.Wc, Cs, choff));
+        const long long ysample = (long long)Df * Hf * Wf * p.Cout;
+        const __amdgpu_buffer_rsrc_t ry = up_rsrc(p.dy + (long long)n * ysample, (unsigned)(ysample * sizeof(float)));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = yv0 + 32 * u;
+            const int vx = v & 15, vy = (v >> 4) & 3, vz = v >> 6;
+            const int zc = z0 + vz, yc = y0 + vy, xc = x0 + vx, co = yq * 4;
+            const bool inb = zc < p.Dc && yc < p.Hc && xc < p.Wc && co < p.Cout;
+            preY[u] = up_load4(ry, inb ? (unsigned)(((((2 * zc + pz) * Hf + 2 * yc + py) * Wf + 2 * xc + px) * p.Cout + co) * 4) : 0xFFFFFFFFu);
+        }
+    };
+    auto write_lds = [&]() {
+        sm.write(lds, preA);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint2 h, m, l; up_split3(preY[u], h, m, l);
+            uint2* o = reinterpret_cast<uint2*>(ldsY) + (yv0 + 32 * u) * 8 + yq;
+            o[0] = h; o[YPLANE_B / 8] = m; o[2 * (YPLANE_B / 8)] = l;
+        }
+    };
+    UP_PLANE_PAIRS;
+    const int slab = blockIdx.x;
+    const int cnt = (p.ntiles > slab) ? (p.ntiles - slab + p.nslabs - 1) / p.nslabs : 0;
+    if (cnt > 0) { issue(slab); write_lds(); }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k) {
+        const bool more = k + 1 < cnt;
+        if (more) issue(slab + (k + 1) * p.nslabs);
+        const F3 Y0 = loadY(0), Y1 = loadY(1);
+        F3 F = loadF(0), Fn;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) Fn = loadF(s + 1);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.p[kPA[pr]], Y0.p[kPB[pr]], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.p[kPA[pr]], Y1.p[kPB[pr]], acc[s][1], 0, 0, 0);
+            }
+            if (s + 1 < 4) F = Fn;
+        }
+        if (more) {
+            __syncthreads();
+            write_lds();
+            __syncthreads();
+        }
+    }
+    // reduce the four waves (rows) through LDS, wave 0 writes G[cls][j][cb + ci][co] of this slab
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds);
+    if (wave > 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) red[(((wave - 1) * 4 + s) * 2 + nn) * 64 + lane] = make_float4(acc[s][nn][0], acc[s][nn][1], acc[s][nn][2], acc[s][nn][3]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int Cin = p.C1 + p.C2;
+        float* part = p.partial + (size_t)blockIdx.x * p.O + (size_t)cls * 8 * Cin * p.Cout;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                f32x4 a = acc[s][nn];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) { const float4 v = red[((w * 4 + s) * 2 + nn) * 64 + lane]; a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 4 * g + reg;
+                    const int jt = 2 * s + (row >> 3), ci = cb + (row & 7), co = nn * 16 + i;
+                    if (co < p.Cout) part[((size_t)jt * Cin + ci) * p.Cout + co] = a[reg];
+                }
+            }
+    }
+}
+
+// dW[t][ci][co] = sum over the 8 (class, coarse tap) pairs that contain original tap t and over the slabs, in double, fixed order
+__global__ void up_wgrad_reduce_kernel(const float* __restrict__ partial, int nslabs, int Cin, int Cout, float* __restrict__ dw) {
+    const int IO = Cin * Cout;
+    const int total = 27 * IO;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        const int tap = o / IO, r = o - tap * IO;
+        const int t3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+        // per axis the two (p, j) pairs holding tap t: t 0: (0,0) (1,0); t 1: (0,1) (1,0); t 2: (0,1) (1,1)
+        int pa[3][2], ja[3][2];
+        for (int a = 0; a < 3; ++a) {
+            pa[a][0] = 0; ja[a][0] = t3[a] == 0 ? 0 : 1;
+            pa[a][1] = 1; ja[a][1] = t3[a] == 2 ? 1 : 0;
+        }
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            const int kz = (k >> 2) & 1, ky = (k >> 1) & 1, kx = k & 1;
+            const int cls = pa[0][kz] * 4 + pa[1][ky] * 2 + pa[2][kx], jt = ja[0][kz] * 4 + ja[1][ky] * 2 + ja[2][kx];
+            const size_t off = (size_t)(cls * 8 + jt) * IO + r;
+            for (int b = 0; b < nslabs; ++b) s += (double)partial[(size_t)b * 64 * IO + off];
+        }
+        dw[o] = (float)s;
+    }
+}
+
+struct Plan { int ntz, nty, ntx, ntiles; };
+Plan up_plan(int N, int Dc, int Hc, int Wc) {
+    Plan q;
+    q.ntz = (Dc + CTZ - 1) / CTZ; q.nty = (Hc + CTY - 1) / CTY; q.ntx = (Wc + CTX - 1) / CTX;
+    q.ntiles = N * q.ntz * q.nty * q.ntx;
+    return q;
+}
+int up_wgrad_slabs(int ntiles, int nchunks) {
+    int s = 512 / (nchunks * 8);                                 // two workgroups per CU over (slab, chunk, class)
+    s = s / 8 * 8; if (s < 8) s = 8;
+    if (s > ntiles) s = ntiles;
+    return s < 1 ? 1 : s;
+}
+template <typename K> int up_set_lds(K kern, size_t bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+// C1 / C2: channels of the one or two COARSE source tensors (multiples of 8; C1 a multiple of 16 when C2 > 0 so that a 16-wide gradient
+// tile never straddles the two tensors); Cout a multiple of 8, at most 32; split matrix mode only (the arithmetic of these kernels).
+extern "C" int da_upconv3d_k3_supported(int C1, int C2, int Cout) {
+    if (da_matrix_mode() != 2) return 0;
+    if (C1 <= 0 || C2 < 0 || C1 % 8 || C2 % 8 || (C2 > 0 && C1 % 16) || C1 + C2 > 64) return 0;
+    if (Cout % 8 || Cout <= 0 || Cout > 32) return 0;
+    return 1;
+}
+
+extern "C" size_t da_upconv3d_k3_ws_bytes(int N, int Dc, int Hc, int Wc, int Cin, int Cout) {
+    const Plan q = up_plan(N, Dc, Hc, Wc);
+    const int NT = (Cout + 15) / 16, NTN = (Cin + 15) / 16;
+    const size_t pack_f = (size_t)(Cin / 8) * 16 * NT * 3072;
+    const size_t pack_d = (size_t)((Cout + 7) / 8) * 16 * (NTN == 3 ? 4 : NTN) * 3072;
+    const size_t part = (size_t)up_wgrad_slabs(q.ntiles, Cin / 8) * 64 * Cin * Cout * sizeof(float);
+    size_t m = pack_f > pack_d ? pack_f : pack_d;
+    if (part > m) m = part;
+    return da_align(m) + 256;
+}
+
+static bool up_sizes_ok(int N, int Dc, int Hc, int Wc, int Cin, int Cout) {
+    const long long fine = 8ll * Dc * Hc * Wc;
+    return fine * Cout * 4 < (1ll << 32) && (long long)Dc * Hc * Wc * Cin * 4 < (1ll << 32) && (long long)N * fine < (1ll << 31);
+}
+
+extern "C" int da_upconv3d_k3_fwd(const float* s1, int C1, const float* s2, int C2, const float* w_tio, const float* bias, float* out,
+                                  int N, int Dc, int Hc, int Wc, int Cout, float act_slope, void* ws, size_t ws_bytes, void* stream) {
+    if (!s1 || !w_tio || !out || (C2 > 0 && !s2) || N <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0) return DA_ERR_BADARG;
+    const int Cin = C1 + C2;
+    if (!da_upconv3d_k3_supported(C1, C2, Cout) || !up_sizes_ok(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_upconv3d_k3_ws_bytes(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    const Plan q = up_plan(N, Dc, Hc, Wc);
+    FwdP p;
+    p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.wp = (const unsigned char*)ws; p.bias = bias; p.out = out;
+    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
+    p.nchunks = Cin / 8; p.NTall = (Cout + 15) / 16; p.slope = act_slope;
+    const long long total = (long long)p.nchunks * 16 * p.NTall * 512;
+    hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(da_grid(total, 256, 256)), dim3(256), 0, st, w_tio, (unsigned short*)ws, Cin, Cout, p.NTall, total);
+    DA_LAUNCH_CHECK();
+    const size_t shm = 3 * SPLANE_B;
+    static bool a1 = false, a2 = false;
+    if (p.NTall == 1) {
+        if (!a1) { const int e = up_set_lds(up_fwd_kernel<1>, shm); if (e) return e; a1 = true; }
+        hipLaunchKernelGGL(up_fwd_kernel<1>, dim3(q.ntiles, 1), dim3(256), shm, st, p);
+    } else {
+        if (!a2) { const int e = up_set_lds(up_fwd_kernel<2>, shm); if (e) return e; a2 = true; }
+        hipLaunchKernelGGL(up_fwd_kernel<2>, dim3(q.ntiles, 1), dim3(256), shm, st, p);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_upconv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
+                                    int N, int Dc, int Hc, int Wc, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w_tio || !dx1 || (C2 > 0 && !dx2) || N <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0) return DA_ERR_BADARG;
+    const int Cin = C1 + C2;
+    if (!da_upconv3d_k3_supported(C1, C2, Cout) || !up_sizes_ok(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_upconv3d_k3_ws_bytes(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    const Plan q = up_plan(N, Dc, Hc, Wc);
+    DgP p;
+    p.dy = dy; p.wp = (const unsigned char*)ws; p.dx1 = dx1; p.dx2 = dx2; p.C1 = C1; p.C2 = C2;
+    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
+    p.nchunks = Cout / 8;
+    int NTN = (Cin + 15) / 16; if (NTN == 3) NTN = 4;            // (48 input channels: a fourth, empty tile)
+    p.NTN = NTN;
+    const long long total = (long long)p.nchunks * 16 * NTN * 512;
+    hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(da_grid(total, 256, 256)), dim3(256), 0, st, w_tio, (unsigned short*)ws, Cin, Cout, NTN, total);
+    DA_LAUNCH_CHECK();
+    const size_t shm = 3 * FPLANE_B;
+    static bool a[5] = {false, false, false, false, false};
+    int e = 0;
+    switch (NTN) {
+        case 1: if (!a[1]) { e = up_set_lds(up_dgrad_kernel<1>, shm); a[1] = true; } if (e) return e;
+                hipLaunchKernelGGL(up_dgrad_kernel<1>, dim3(q.ntiles), dim3(256), shm, st, p); break;
+        case 2: if (!a[2]) { e = up_set_lds(up_dgrad_kernel<2>, shm); a[2] = true; } if (e) return e;
+                hipLaunchKernelGGL(up_dgrad_kernel<2>, dim3(q.ntiles), dim3(256), shm, st, p); break;
+        case 4: if (!a[4]) { e = up_set_lds(up_dgrad_kernel<4>, shm); a[4] = true; } if (e) return e;
+                hipLaunchKernelGGL(up_dgrad_kernel<4>, dim3(q.ntiles), dim3(256), shm, st, p); break;
+        default: return DA_ERR_UNSUPPORTED;
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int da_upconv3d_k3_wgrad(const float* s1, int C1, const float* s2, int C2, const float* dy, float* dw_tio,
+                                    int N, int Dc, int Hc, int Wc, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!s1 || !dy || !dw_tio || (C2 > 0 && !s2) || N <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0) return DA_ERR_BADARG;
+    const int Cin = C1 + C2;
+    if (!da_upconv3d_k3_supported(C1, C2, Cout) || !up_sizes_ok(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_upconv3d_k3_ws_bytes(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    const Plan q = up_plan(N, Dc, Hc, Wc);
+    WgP p;
+    p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.dy = dy; p.partial = (float*)ws;
+    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles;
+    const int nchunks = Cin / 8;
+    p.nslabs = up_wgrad_slabs(q.ntiles, nchunks); p.O = 64 * Cin * Cout;
+    const size_t shm = (size_t)3 * SPLANE_B + 3 * YPLANE_B;
+    static bool attr = false;
+    if (!attr) { const int e = up_set_lds(up_wgrad_kernel, shm); if (e) return e; attr = true; }
+    hipLaunchKernelGGL(up_wgrad_kernel, dim3(p.nslabs, nchunks, 8), dim3(256), shm, st, p);
+    DA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(up_wgrad_reduce_kernel, dim3(da_grid(27 * Cin * Cout, 256, 1024)), dim3(256), 0, st, p.partial, p.nslabs, Cin, Cout, dw_tio);
+    DA_LAUNCH_CHECK();
+    return 0;
+}

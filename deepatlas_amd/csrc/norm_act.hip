@@ -297,12 +297,12 @@ __global__ void act_bwd_add_dbias_kernel(const float* __restrict__ g1, const flo
     }
 }
 
-__global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* out) {
+__global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* out, int accumulate) {
     const int c = blockIdx.x;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[((size_t)b * 2) * C + c];
     s = da_wave_sum(s);
-    if (threadIdx.x == 0) out[c] = (float)s;
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 template <int MODE>
@@ -416,7 +416,7 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, c
         hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, cq, C, fuse ? partial : nullptr);
         DA_LAUNCH_CHECK();
         if (fuse) {
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, grid, C, dxsum);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, grid, C, dxsum, 0);
             DA_LAUNCH_CHECK();
         } else if (dxsum != nullptr) {
             return da_colsum(dx, M, C, dxsum, ws, ws_bytes, stream);
@@ -451,9 +451,35 @@ extern "C" int da_act_bwd_add_dbias(const float* g1, const float* g2, const floa
     else hipLaunchKernelGGL((act_bwd_add_dbias_kernel<1>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
     DA_LAUNCH_CHECK();
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, C, dbias);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, C, dbias, 0);
         DA_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// The two halves of da_act_bwd_add_dbias as separate entries, for callers that keep the tiny per-channel finish off the stream the big
+// pass runs on (ops.py queues it on the weight-gradient side stream: a 32-workgroup kernel that must wait for a free CU slot behind
+// persistent matrix kernels costs the main stream 20 - 100 us per layer): `partial` is caller-owned, da_bn_ws_bytes(M, C) bytes.
+extern "C" int da_act_bwd_add_partial(const float* g1, const float* g2, const float* y, float act_slope, float* dx,
+                                      long long M, int C, void* partial, size_t partial_bytes, int* nparts, void* stream) {
+    if (!g1 || !dx || !partial || !nparts || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (partial_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    const float* yy = act_slope < 0.f ? nullptr : y;
+    if (act_slope >= 0.f && !y) return DA_ERR_BADARG;
+    const size_t shm = (size_t)p.rpi * C * sizeof(double);
+    hipStream_t st = da_stream(stream);
+    if (p.vec == 4) hipLaunchKernelGGL((act_bwd_add_dbias_kernel<4>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, (double*)partial);
+    else hipLaunchKernelGGL((act_bwd_add_dbias_kernel<1>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, (double*)partial);
+    DA_LAUNCH_CHECK();
+    *nparts = p.grid;
+    return 0;
+}
+
+extern "C" int da_colsum_finish(const void* partial, int nparts, int C, float* out, int accumulate, void* stream) {
+    if (!partial || !out || nparts <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), (const double*)partial, nparts, C, out, accumulate);
+    DA_LAUNCH_CHECK();
     return 0;
 }
 
@@ -464,7 +490,7 @@ extern "C" int da_colsum(const float* x, long long M, int C, float* out, void* w
     double* partial = (double*)ws;
     int rc = launch_partial<1>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, C, out, 0);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -233,10 +233,22 @@ class convBlock(nn.Module):
             raise NotImplementedError('HIP conv path covers kernel 3, padding 1, stride 1|2')
         self.stride = stride
 
-    def forward(self, x, skip=None, fork=False):
+    def up2_ok(self, x, skip, size):
+        """Can this block consume `F.interpolate(cat(x, skip), size=size)` (voxel_morph.py:72-80) with the up-sampling folded into its
+        convolution?  Exact x2 on every axis, no BatchNorm / residual, channel counts the folded kernels take, split matrix mode."""
+        if self.bn is not None or self.residual or self.stride != 1:
+            return False
+        if tuple(int(v) for v in size) != tuple(2 * int(v) for v in x.shape[2:]) or (skip is not None and skip.shape[2:] != x.shape[2:]):
+            return False
+        return ops.upconv_supported(x.shape[1], skip.shape[1] if skip is not None else 0, self.conv.weight.shape[0])
+
+    def forward(self, x, skip=None, fork=False, up2=False):
         """fork=True (no BatchNorm, no residual): returns the block's output twice -- for an output with two consumers (the
-        registration net's skip connections) the two gradients are then summed inside the activation-backward pass."""
+        registration net's skip connections) the two gradients are then summed inside the activation-backward pass.
+        up2=True (only after up2_ok): x / skip are the COARSE tensors; the block computes conv(nearest-upsample x2 (cat(x, skip)))."""
         slope = _slope_of(self.nonlinear)
+        if up2:
+            return ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, 1, slope, False, False, True)
         if fork and self.bn is None and not self.residual:
             return ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, slope, False, True)
         if fork:

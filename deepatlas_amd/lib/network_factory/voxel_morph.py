@@ -49,12 +49,19 @@ class VoxelMorphCVPR2018(nn.Module):
         e3, e3s = self.encoders[2](e2, fork=True)
         e4, e4s = self.encoders[3](e3, fork=True)
         e5 = self.encoders[4](e4)
-        d1 = self.decoders[0](up(e5, e4.shape[2:]))
-        # F.interpolate(cat(a, b)) == cat(F.interpolate(a), F.interpolate(b)) for nearest (voxel_morph.py:74,76)
-        d2 = self.decoders[1](up(d1, e3.shape[2:]), up(e4s, e3.shape[2:]))
-        d3 = self.decoders[2](up(d2, e2.shape[2:]), up(e3s, e2.shape[2:]))
+
+        def up_conv(block, size, a, b=None):
+            # conv(F.interpolate(cat(a, b), size)) (voxel_morph.py:72-80; interpolate of a concat = concat of the interpolates for 'nearest'):
+            # for an exact x2 the up-sampling is folded into the convolution (ops.Conv3dK3Fn up2, conv3d_up2.hip); odd pyramids and other
+            # matrix modes materialise the up-sampled tensors
+            if block.up2_ok(a, b, size):
+                return block(a, b, up2=True)
+            return block(up(a, size), up(b, size) if b is not None else None)
+        d1 = up_conv(self.decoders[0], e4.shape[2:], e5)
+        d2 = up_conv(self.decoders[1], e3.shape[2:], d1, e4s)
+        d3 = up_conv(self.decoders[2], e2.shape[2:], d2, e3s)
         d4 = self.decoders[3](d3, e2s)
-        d5 = self.decoders[4](up(d4, e1.shape[2:]))
+        d5 = up_conv(self.decoders[4], e1.shape[2:], d4)
         disp_field = self.flow(d5, e1s)
         warped_source, deform_field = ops.WarpFn.apply(source, disp_field)
         return disp_field, warped_source, deform_field

@@ -277,7 +277,10 @@ class Conv3dK3Fn(Function):
         # the two gradients then arrive separately and are summed inside the activation-backward pass instead of by autograd
         transposed = bool(extra[0]) if extra else False
         fork = bool(extra[1]) if len(extra) > 1 else False
-        ctx.n_extra, ctx.transposed, ctx.fork = len(extra), transposed, fork
+        # extra[2] (optional): up2 -- x1 / x2 are the COARSE tensors of `conv(F.interpolate(x, scale 2, nearest))` (voxel_morph.py:72-80): the
+        # up-sampling is folded into the convolution (conv3d_up2.hip), the up-sampled tensor and its gradient never exist
+        up2 = bool(extra[2]) if len(extra) > 2 else False
+        ctx.n_extra, ctx.transposed, ctx.fork, ctx.up2 = len(extra), transposed, fork, up2
         a1 = ndhwc(x1)
         a2 = ndhwc(x2) if x2 is not None else None
         N, D, H, W, C1 = a1.shape
@@ -287,19 +290,27 @@ class Conv3dK3Fn(Function):
             raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
         if transposed and stride != 1:
             raise NotImplementedError('transposed 3x3x3 conv: stride 1 only')
+        if up2 and (transposed or stride != 1 or not upconv_supported(C1, C2, Cout)):
+            raise NotImplementedError('folded up-sampling: plain stride-1 convolution, channel counts of ops.upconv_supported, split matrix mode')
         st = stream()
         w_tio = _empty((27, Cin, Cout), a1)
         if transposed:
             call('da_w_iok_flip_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 27, st)
         else:
             call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
-        Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
-        out = _empty((N, Do, Ho, Wo, Cout), a1)
-        wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
-        wp, wn = _ws(wsb, a1)
         b = bias.detach().contiguous() if bias is not None else None
-        call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(out),
-             N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
+        if up2:
+            out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a1)
+            wsb = nat.lib().da_upconv3d_k3_ws_bytes(N, D, H, W, Cin, Cout)
+            wp, wn = _ws(wsb, a1)
+            call('da_upconv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cout, float(act_slope), wp, wn, st)
+        else:
+            Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+            out = _empty((N, Do, Ho, Wo, Cout), a1)
+            wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
+            wp, wn = _ws(wsb, a1)
+            call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(out),
+                 N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
         ctx.dims = (N, D, H, W, C1, C2, Cout, stride, float(act_slope), wsb)
         ctx.has_bias = bias is not None
         ctx.wparam, ctx.bparam = weight, bias
@@ -312,7 +323,23 @@ class Conv3dK3Fn(Function):
     def backward(ctx, gout, *gmore):
         a1, a2, w_tio, out = ctx.saved_tensors
         N, D, H, W, C1, C2, Cout, stride, slope, wsb = ctx.dims
+        up2 = ctx.up2
         st = stream()
+        flops = 54.0 * (C1 + C2) * Cout * N * D * H * W * (8.0 if up2 else 1.0 / (stride ** 3))       # algorithmic (2 * 27 * Cin * Cout per output voxel)
+
+        def k_dgrad(g_, dx1_, dx2_, wp_, wn_, st_):
+            if up2:
+                call('da_upconv3d_k3_dgrad', ptr(g_), ptr(w_tio), ptr(dx1_), C1, ptr(dx2_), C2, N, D, H, W, Cout, wp_, wn_, st_)
+            else:
+                call('da_conv3d_k3_dgrad', ptr(g_), ptr(w_tio), ptr(dx1_), C1, ptr(dx2_), C2, N, D, H, W, Cout, stride, wp_, wn_, st_)
+
+        def k_wgrad(g_, dw_tio_, db_, wp_, wn_, st_):
+            if up2:
+                call('da_upconv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g_), ptr(dw_tio_), N, D, H, W, Cout, wp_, wn_, st_)
+                if db_ is not None:
+                    call('da_colsum', ptr(g_), g_.numel() // Cout, Cout, ptr(db_), wp_, wn_, st_)
+            else:
+                call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g_), ptr(dw_tio_), ptr(db_), N, D, H, W, Cout, stride, wp_, wn_, st_)
         g_b = gmore[0] if (ctx.fork and gmore) else None
         if gout is None:
             gout, g_b = g_b, None
@@ -321,28 +348,47 @@ class Conv3dK3Fn(Function):
         want_w = ctx.needs_input_grad[2]
         want_b = ctx.has_bias and ctx.needs_input_grad[3]
         db = None
+        db_partial = None            # (partial buffer, number of partial sets): bias gradient still to be finished, on the side stream
         if out is not None or gb2 is not None:
             # dy = (g [+ g']) * act'(y) and the bias gradient (column sums of dy) in one pass
             g2 = torch.empty_like(g)
             M = g.numel() // Cout
-            db = _empty((Cout,), a1) if want_b else None
-            bwp, bwn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(M, Cout)), a1)
-            call('da_act_bwd_add_dbias', ptr(g), ptr(gb2), ptr(out), slope if out is not None else -1.0, ptr(g2), ptr(db), M, Cout, bwp, bwn, st)
+            gbt0 = _async_target(ctx.bparam) if want_b else None
+            if gbt0 is not None:
+                # the per-channel finish of the column sums (a Cout-workgroup kernel) goes to the side stream and accumulates straight
+                # into the flat gradient bucket: behind persistent matrix kernels such a kernel waits 20 - 100 us for a CU slot, and
+                # nothing on the main stream needs its result
+                import ctypes
+                pbytes = nat.lib().da_bn_ws_bytes(M, Cout)
+                pbuf = torch.empty((pbytes,), dtype=torch.uint8, device=g.device)
+                npar = ctypes.c_int(0)
+                call('da_act_bwd_add_partial', ptr(g), ptr(gb2), ptr(out), slope if out is not None else -1.0, ptr(g2), M, Cout,
+                     ptr(pbuf), pbytes, ctypes.byref(npar), st)
+                db_partial = (pbuf, npar.value)
+            else:
+                db = _empty((Cout,), a1) if want_b else None
+                bwp, bwn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(M, Cout)), a1)
+                call('da_act_bwd_add_dbias', ptr(g), ptr(gb2), ptr(out), slope if out is not None else -1.0, ptr(g2), ptr(db), M, Cout, bwp, bwn, st)
             g = g2
         wp, wn = _ws(wsb, a1)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
             dx1 = _empty(a1.shape, a1)
             dx2 = _empty(a2.shape, a1) if a2 is not None else None
-            _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3), N * D * H * W)
-            call('da_conv3d_k3_dgrad', ptr(g), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, stride, wp, wn, st)
+            _serialize_matrix_kernels(flops, N * D * H * W)
+            k_dgrad(g, dx1, dx2, wp, wn, st)
         dw = None
-        need_db_in_wgrad = want_b and db is None
+        need_db_in_wgrad = want_b and db is None and db_partial is None
         gw = _async_target(ctx.wparam) if want_w else None
         gbt = _async_target(ctx.bparam) if want_b else None
+        if db_partial is not None and not (want_w and gw is not None):
+            def finish():                            # (frozen or non-bucket weight: the bias finish still goes to the side stream)
+                call('da_colsum_finish', ptr(db_partial[0]), db_partial[1], Cout, ptr(gbt), 1, stream())
+            _run_on_side(finish, (db_partial[0],))
+            db_partial = None
         if want_w and gw is not None and (not want_b or gbt is not None):
             global _last_side_flops
-            _last_side_flops = 54.0 * (C1 + C2) * Cout * N * D * H * W / (stride ** 3)
+            _last_side_flops = flops
             if db is not None:
                 gbt.add_(db)                         # the fused pass above already produced the bias gradient (main stream)
                 db = None
@@ -350,10 +396,13 @@ class Conv3dK3Fn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 sst = stream()
+                if db_partial is not None:
+                    call('da_colsum_finish', ptr(db_partial[0]), db_partial[1], Cout, ptr(gbt), 1, sst)
+                    _side_keep.append(db_partial[0])
                 dw_tio = torch.empty_like(w_tio)
                 dbs = _empty((Cout,), a1) if need_db_in_wgrad else None
-                swp, swn = _ws(wsb, a1)
-                call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(dbs), N, D, H, W, Cout, stride, swp, swn, sst)
+                swp, swn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(g.numel() // Cout, Cout)) if up2 else wsb, a1)
+                k_wgrad(g, dw_tio, dbs, swp, swn, sst)
                 dws = torch.empty_like(gw)
                 if ctx.transposed:
                     call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dws), C1 + C2, Cout, 27, sst)
@@ -366,7 +415,9 @@ class Conv3dK3Fn(Function):
         elif want_w or need_db_in_wgrad:
             dw_tio = torch.empty_like(w_tio)
             dbw = _empty((Cout,), a1) if need_db_in_wgrad else None
-            call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g), ptr(dw_tio), ptr(dbw), N, D, H, W, Cout, stride, wp, wn, st)
+            if up2 and dbw is not None:
+                wp, wn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(g.numel() // Cout, Cout)), a1)
+            k_wgrad(g, dw_tio, dbw, wp, wn, st)
             if dbw is not None:
                 db = dbw
             if want_w:
@@ -377,6 +428,12 @@ class Conv3dK3Fn(Function):
                     dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
                     call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None) + (None,) * ctx.n_extra
+
+
+def upconv_supported(C1, C2, Cout):
+    """Can `conv3x3x3(F.interpolate(cat(x1, x2), scale 2, nearest))` run with the up-sampling folded in (conv3d_up2.hip)?  Channel counts
+    as da_upconv3d_k3_supported documents; only in split matrix mode (the kernels' arithmetic)."""
+    return bool(nat.lib().da_upconv3d_k3_supported(int(C1), int(C2), int(Cout))) and os.environ.get('DA_NO_UPCONV') != '1'
 
 
 class Conv1x1Fn(Function):

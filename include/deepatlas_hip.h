@@ -97,6 +97,22 @@ int da_conv3d_k3_wgrad_pro(const float* in1, int C1, const float* pro1_scale, co
                            int N, int D, int H, int W, int Cout,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* ---- nearest x2 up-sampling folded into the 3x3x3 convolution that consumes it (row a8 + a7; voxel_morph.py:72-80: `F.interpolate(x,
+ * size=skip.shape)` -- default mode 'nearest' -- then modules.convBlock, modules.py:48,56-58).  s1 / s2: the one or two COARSE source
+ * tensors [N][Dc][Hc][Wc][C1|C2] (s2 / C2 = NULL / 0 for a single input; the reference concatenates, voxel_morph.py:73,75); out and dy
+ * live on the fine grid [N][2Dc][2Hc][2Wc][Cout]; w_tio / dw_tio [27][C1+C2][Cout] as for da_conv3d_k3_*.  Exact x2 only (callers use
+ * da_upsample_nearest_* + da_conv3d_k3_* otherwise), split matrix mode only (da_upconv3d_k3_supported returns 0 otherwise; the entry
+ * points then return DA_ERR_UNSUPPORTED).  Per output parity the layer is a 2x2x2-tap convolution on the coarse grid with summed weights
+ * (conv3d_up2.hip): neither the up-sampled tensor nor its gradient is materialised. */
+int da_upconv3d_k3_supported(int C1, int C2, int Cout);
+size_t da_upconv3d_k3_ws_bytes(int N, int Dc, int Hc, int Wc, int Cin, int Cout);
+int da_upconv3d_k3_fwd(const float* s1, int C1, const float* s2, int C2, const float* w_tio, const float* bias, float* out,
+                       int N, int Dc, int Hc, int Wc, int Cout, float act_slope, void* ws, size_t ws_bytes, void* stream);
+int da_upconv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
+                         int N, int Dc, int Hc, int Wc, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_upconv3d_k3_wgrad(const float* s1, int C1, const float* s2, int C2, const float* dy, float* dw_tio,
+                         int N, int Dc, int Hc, int Wc, int Cout, void* ws, size_t ws_bytes, void* stream);
+
 /* test/diagnostic knob: force the direct (VALU) kernels instead of the MFMA implicit-GEMM path (also env
  * DA_CONV_DIRECT=1); returns the previous setting.  Used by the GPU tests to A/B the two implementations. */
 int da_set_conv_direct(int on);
@@ -196,6 +212,12 @@ int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long
 int da_act_bwd_add_dbias(const float* g1, const float* g2, const float* y, float act_slope, float* dx, float* dbias,
                          long long M, int C, void* ws, size_t ws_bytes, void* stream);
 int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+/* da_act_bwd_add_dbias in two halves (same call site, modules.py:56-58): the big pass leaves its per-block double partial sums in the
+ * caller-owned `partial` (da_bn_ws_bytes(M, C) bytes; *nparts = number of partial sets written), and da_colsum_finish reduces them to
+ * out[C] (accumulate != 0: out[c] += sum) -- possibly on another stream, once the first call has completed there. */
+int da_act_bwd_add_partial(const float* g1, const float* g2, const float* y, float act_slope, float* dx,
+                           long long M, int C, void* partial, size_t partial_bytes, int* nparts, void* stream);
+int da_colsum_finish(const void* partial, int nparts, int C, float* out, int accumulate, void* stream);
 
 /* ---- MaxPool3d(2) (row a2; unets.py:230,267) ------------------------------------------------- */
 int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);

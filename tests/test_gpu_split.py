@@ -135,6 +135,68 @@ def test_native_stride2_split_kernels_are_fp32_accurate(case, kind):
         assert e_sp < 1e-5 and m_sp < 1e-5, (nm, e_sp, m_sp)
 
 
+UP_CASES = [
+    # C1, C2, Cout, (N, Dc, Hc, Wc) coarse: the registration decoder's `conv(F.interpolate(cat(a, b), x2))` layers (voxel_morph.py:72-80)
+    (32, 0, 32, (1, 5, 6, 5)),         # dec0: one source
+    (32, 32, 32, (1, 10, 12, 10)),     # dec1 / dec2: two up-sampled sources, ragged tiles
+    (32, 32, 32, (2, 4, 6, 20)),       # two samples, two x tiles
+    (8, 0, 8, (1, 8, 12, 20)),         # dec4: 8 -> 8 (half-empty N-tile)
+    (16, 0, 16, (1, 3, 5, 17)),        # every coarse axis odd
+    (16, 16, 24, (1, 2, 4, 16)),       # 24 output channels: two N-tiles, the second half empty
+    (32, 16, 32, (1, 1, 1, 1)),        # 48 input channels (three gradient tiles + an empty fourth), a single coarse voxel
+]
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'lognormal'])
+@pytest.mark.parametrize('case', UP_CASES, ids=lambda c: 'up_c%d+%d_o%d_%s' % (c[0], c[1], c[2], 'x'.join(str(v) for v in c[3])))
+def test_folded_upsampling_conv_is_fp32_accurate(case, kind):
+    """ops.Conv3dK3Fn(up2): conv3x3x3(nearest-upsample x2 (cat(a, b))) + ReLU with the up-sampling folded into the convolution
+    (conv3d_up2.hip: 8 parity classes x 2x2x2 summed taps on the coarse grid) against F.interpolate + F.conv3d in DOUBLE: forward, both
+    source gradients, weight and bias gradient -- and against the materialised route (UpsampleNearestFn + Conv3dK3Fn) in the same mode."""
+    from deepatlas_amd import ops
+    C1, C2, Cout, (N, D, H, W) = case
+    a = rnd((N, C1, D, H, W), 21, kind=kind)
+    b2 = rnd((N, C2, D, H, W), 22, kind=kind) if C2 else None
+    w = rnd((Cout, C1 + C2, 3, 3, 3), 23, 0.2, kind=kind)
+    bias = rnd((Cout,), 24, 0.1)
+    go = rnd((N, Cout, 2 * D, 2 * H, 2 * W), 25, kind=kind)
+    ar, wr, br = a.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    b2r = b2.double().requires_grad_(True) if C2 else None
+    xin = torch.cat((ar, b2r), 1) if C2 else ar
+    yr = F.relu(F.conv3d(F.interpolate(xin, scale_factor=2, mode='nearest'), wr, br, padding=1))
+    yr.backward(go.double())
+    ref = [yr.detach(), ar.grad] + ([b2r.grad] if C2 else []) + [wr.grad, br.grad]
+
+    def run(folded):
+        prev = ops.set_matrix_precision('fp32_split')
+        try:
+            a1 = cl(a).requires_grad_(True)
+            a2 = cl(b2).requires_grad_(True) if C2 else None
+            wg, bg = w.to(dev()).requires_grad_(True), bias.to(dev()).requires_grad_(True)
+            if folded:
+                assert ops.upconv_supported(C1, C2, Cout)
+                y = ops.Conv3dK3Fn.apply(a1, a2, wg, bg, 1, 0.0, False, False, True)
+            else:
+                size = (2 * D, 2 * H, 2 * W)
+                y = ops.Conv3dK3Fn.apply(ops.UpsampleNearestFn.apply(a1, size), ops.UpsampleNearestFn.apply(a2, size) if C2 else None, wg, bg, 1, 0.0)
+            y.backward(cl(go))
+            torch.cuda.synchronize()
+            return [y.detach().cpu(), a1.grad.cpu()] + ([a2.grad.cpu()] if C2 else []) + [wg.grad.cpu(), bg.grad.cpu()]
+        finally:
+            ops.set_matrix_precision(prev)
+    folded, plain = run(True), run(False)
+    names = ['fwd', 'dsrc1'] + (['dsrc2'] if C2 else []) + ['wgrad', 'bgrad']
+    for nm, r, f, m in zip(names, ref, folded, plain):
+        r = r.numpy()
+        e_f, e_m = rel_l2(f.numpy().astype(np.float64), r), rel_l2(m.numpy().astype(np.float64), r)
+        x_f, x_m = max_abs_rel(f.numpy().astype(np.float64), r), max_abs_rel(m.numpy().astype(np.float64), r)
+        # same error class as the materialised route (the two sum in different orders -- 64 summed-weight taps against 8 x 27 -- and the
+        # summed weights are rounded to fp32 once): within a small factor of it, and inside the package's 1e-5 criterion
+        assert e_f <= 3.0 * e_m + 2.4e-7, '%s: folded rel-l2 %.3e vs materialised %.3e' % (nm, e_f, e_m)
+        assert x_f <= 4.0 * x_m + 5e-7, '%s: folded max-abs %.3e vs materialised %.3e' % (nm, x_f, x_m)
+        assert e_f < 1e-5 and x_f < 1e-5, (nm, e_f, x_f)
+
+
 def test_split_mode_activation_bias_and_fp32_after_switching_back():
     """Fused bias + LeakyReLU epilogue in split mode, and the fp32 kernels are bit-identical before / after a visit to the mode."""
     C1, Cout, dims = 16, 16, (1, 8, 16, 32)
