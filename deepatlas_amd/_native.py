@@ -29,6 +29,9 @@ SIGNATURES = {
     'da_w_tio_to_iok': (I, [P, P, I, I, I, P]),
     'da_w_iok_flip_to_tio': (I, [P, P, I, I, I, P]),
     'da_w_tio_to_iok_flip': (I, [P, P, I, I, I, P]),
+    'da_w_tio_to_oik_acc': (I, [P, P, I, I, I, P]),
+    'da_w_tio_to_iok_acc': (I, [P, P, I, I, I, P]),
+    'da_w_tio_to_iok_flip_acc': (I, [P, P, I, I, I, P]),
     'da_conv3d_k3_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
     'da_conv3d_k3_fwd': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     'da_conv3d_k3_fwd_bnstats': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),

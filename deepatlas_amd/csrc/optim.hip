@@ -55,7 +55,8 @@ __global__ void tio_to_w_kernel(const float* __restrict__ src, float* __restrict
         const int Cin = aco ? B : A, Cout = aco ? A : B;
         const int ci = aco ? b : a, co = aco ? a : b;
         const int kk = (a_is_cout & 2) ? K - 1 - k : k;
-        dst[i] = src[((size_t)kk * Cin + ci) * Cout + co];
+        const float v = src[((size_t)kk * Cin + ci) * Cout + co];
+        dst[i] = (a_is_cout & 4) ? dst[i] + v : v;             // bit 2: accumulate (gradient straight into the optimiser's bucket)
     }
 }
 
@@ -151,3 +152,7 @@ extern "C" int da_w_tio_to_iok(const float* src, float* dst, int Cin, int Cout, 
 // ConvTranspose3d(k, stride 1, padding (k-1)/2) == Conv3d with the taps flipped and the channel axes swapped
 extern "C" int da_w_iok_flip_to_tio(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(w_to_tio_kernel, Cin, Cout, K3, 2); }
 extern "C" int da_w_tio_to_iok_flip(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cin, Cout, K3, 2); }
+// ... and accumulating: dst += layout(src) (one launch instead of a conversion + an add; dst is a view of FlatAdam's gradient bucket)
+extern "C" int da_w_tio_to_oik_acc(const float* src, float* dst, int Cout, int Cin, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cout, Cin, K3, 5); }
+extern "C" int da_w_tio_to_iok_acc(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cin, Cout, K3, 4); }
+extern "C" int da_w_tio_to_iok_flip_acc(const float* src, float* dst, int Cin, int Cout, int K3, void* stream) { DA_W_LAUNCH(tio_to_w_kernel, Cin, Cout, K3, 6); }

@@ -67,6 +67,7 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
 
         def weights_init(self):
             self.apply(init_conv_weights)
+            ops.bump_weights_epoch()          # `.data` writes do not move torch's version counters: drop the cached weight layouts
 
         @property
         def lazy_head(self):
@@ -178,6 +179,7 @@ class UNet(nn.Module):
                     nn.init.xavier_normal_(m.weight.data)
                 if not m.bias is None:
                     m.bias.data.zero_()
+        ops.bump_weights_epoch()
 
     def encoder(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True, batchnorm=False):
         return UNetEncBlock(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias, batchnorm=batchnorm)

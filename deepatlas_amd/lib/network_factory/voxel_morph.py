@@ -74,3 +74,4 @@ class VoxelMorphCVPR2018(nn.Module):
                     nn.init.xavier_normal_(m.weight.data)
                 if not m.bias is None:
                     m.bias.data.zero_()
+        ops.bump_weights_epoch()              # `.data` writes do not move torch's version counters: drop the cached weight layouts

@@ -191,6 +191,70 @@ def _async_target(param):
 
 
 # ------------------------------------------------------------------------------------------------
+# weight layouts, converted once per optimiser step
+# ------------------------------------------------------------------------------------------------
+# The kernels take weights tap-major ([k^3][Cin][Cout], "TIO"); the parameters keep the reference's state_dict layouts.  A weight only
+# changes when an optimiser steps (or a state_dict is loaded), so its TIO copy is cached ON the parameter object and rebuilt when
+#   * FlatAdam stepped (its HIP kernel writes through raw pointers, so torch's version counters do not move: bump_weights_epoch()),
+#   * the parameter or a registered flat parameter bucket was written in place (torch's _version), or its storage moved.
+# Inside a HIP-graph capture the cache is bypassed (the conversion kernel must be part of the graph).
+_weights_epoch = 0
+_flat_param_buckets = []          # weak references to every FlatAdam parameter bucket
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def register_flat_params(flat_p):
+    import weakref
+    _flat_param_buckets[:] = [r for r in _flat_param_buckets if r() is not None]
+    _flat_param_buckets.append(weakref.ref(flat_p))
+
+
+_TIO_ENTRY = {'oik': 'da_w_oik_to_tio', 'iok': 'da_w_iok_to_tio', 'iok_flip': 'da_w_iok_flip_to_tio'}
+_TIO_BACK = {'oik': 'da_w_tio_to_oik', 'iok': 'da_w_tio_to_iok', 'iok_flip': 'da_w_tio_to_iok_flip'}
+
+
+def weight_tio(weight, kind):
+    """[K3][Cin][Cout] copy of a conv weight.  kind 'oik': nn.Conv3d [Cout][Cin][k^3]; 'iok': nn.ConvTranspose3d [Cin][Cout][k^3];
+    'iok_flip': a k3/s1/p1 transposed conv used as a convolution (taps flipped)."""
+    a_, b_ = int(weight.shape[0]), int(weight.shape[1])
+    K3 = int(weight.shape[2] * weight.shape[3] * weight.shape[4])
+    Cin, Cout = (b_, a_) if kind == 'oik' else (a_, b_)
+    capturing = torch.cuda.is_current_stream_capturing()
+    stamp = None
+    if not capturing and os.environ.get('DA_NO_WEIGHT_CACHE') != '1':
+        stamp = (_weights_epoch, weight._version, weight.data_ptr(), kind,
+                 tuple(r()._version for r in _flat_param_buckets if r() is not None))
+        ent = getattr(weight, '_da_tio', None)
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+    w_tio = torch.empty((K3, Cin, Cout), dtype=torch.float32, device=weight.device)
+    call(_TIO_ENTRY[kind], ptr(weight.detach().contiguous()), ptr(w_tio), a_, b_, K3, stream())
+    if stamp is not None:
+        try:
+            weight._da_tio = (stamp, w_tio)
+        except AttributeError:
+            pass
+    return w_tio
+
+
+def grad_from_tio(dw_tio, kind, shape, acc=None):
+    """The gradient in the parameter's own layout from a [K3][Cin][Cout] gradient: a new tensor, or (acc given) accumulated into
+    `acc` by the same kernel."""
+    a_, b_ = int(shape[0]), int(shape[1])
+    K3 = int(dw_tio.shape[0])
+    if acc is not None:
+        call(_TIO_BACK[kind] + '_acc', ptr(dw_tio), ptr(acc), a_, b_, K3, stream())
+        return None
+    dw = torch.empty(tuple(shape), dtype=torch.float32, device=dw_tio.device)
+    call(_TIO_BACK[kind], ptr(dw_tio), ptr(dw), a_, b_, K3, stream())
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
 # deferred BatchNorm + activation
 # ------------------------------------------------------------------------------------------------
 # In Conv -> BatchNorm -> LeakyReLU -> Conv chains (unets.py:24-39, 259-278) the activated tensor only exists to be read by the next
@@ -293,11 +357,7 @@ class Conv3dK3Fn(Function):
         if up2 and (transposed or stride != 1 or not upconv_supported(C1, C2, Cout)):
             raise NotImplementedError('folded up-sampling: plain stride-1 convolution, channel counts of ops.upconv_supported, split matrix mode')
         st = stream()
-        w_tio = _empty((27, Cin, Cout), a1)
-        if transposed:
-            call('da_w_iok_flip_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 27, st)
-        else:
-            call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
+        w_tio = weight_tio(weight, 'iok_flip' if transposed else 'oik')
         b = bias.detach().contiguous() if bias is not None else None
         if up2:
             out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a1)
@@ -403,12 +463,7 @@ class Conv3dK3Fn(Function):
                 dbs = _empty((Cout,), a1) if need_db_in_wgrad else None
                 swp, swn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(g.numel() // Cout, Cout)) if up2 else wsb, a1)
                 k_wgrad(g, dw_tio, dbs, swp, swn, sst)
-                dws = torch.empty_like(gw)
-                if ctx.transposed:
-                    call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dws), C1 + C2, Cout, 27, sst)
-                else:
-                    call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
-                gw.add_(dws)
+                grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', gw.shape, acc=gw)
                 if dbs is not None:
                     gbt.add_(dbs)
             _side_keep.extend(t for t in (a1, a2, g) if t is not None)
@@ -421,12 +476,7 @@ class Conv3dK3Fn(Function):
             if dbw is not None:
                 db = dbw
             if want_w:
-                if ctx.transposed:
-                    dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
-                    call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
-                else:
-                    dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
-                    call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+                dw = grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', ctx.wparam.shape)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None) + (None,) * ctx.n_extra
 
 
@@ -447,8 +497,7 @@ class Conv1x1Fn(Function):
         N, D, H, W, Cin = a.shape
         Cout = weight.shape[0]
         st = stream()
-        w_io = _empty((Cin, Cout), a)
-        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_io), Cout, Cin, 1, st)
+        w_io = weight_tio(weight, 'oik').view(Cin, Cout)
         out = _empty((N, D, H, W, Cout), a)
         M = N * D * H * W
         b = bias.detach().contiguous() if bias is not None else None
@@ -503,8 +552,7 @@ class DeconvK2S2Fn(Function):
         if weight.shape[0] != Cin or tuple(weight.shape[2:]) != (2, 2, 2):
             raise ValueError('ConvTranspose3d weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
         st = stream()
-        w_tio = _empty((8, Cin, Cout), a)
-        call('da_w_iok_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 8, st)
+        w_tio = weight_tio(weight, 'iok')
         out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
@@ -550,8 +598,7 @@ class ConvK2S2Fn(Function):
             raise NotImplementedError('HIP strided-conv down-sampler: even spatial sizes and channels in multiples of 16')
         D, H, W = D2 // 2, H2 // 2, W2 // 2
         st = stream()
-        w_tio = _empty((8, Cin, Cout), a)
-        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 8, st)
+        w_tio = weight_tio(weight, 'oik')
         out = _empty((N, D, H, W, Cout), a)
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
@@ -742,11 +789,7 @@ class ConvBNActFn(Function):
         if Cin != C1 + C2 or tuple(weight.shape[2:]) != (3, 3, 3):
             raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
         st = stream()
-        w_tio = _empty((27, Cin, Cout), a1)
-        if transposed:
-            call('da_w_iok_flip_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 27, st)
-        else:
-            call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cout, Cin, 27, st)
+        w_tio = weight_tio(weight, 'iok_flip' if transposed else 'oik')
         y = _empty((N, D, H, W, Cout), a1)
         wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, 1)
         wp, wn = _ws(wsb, a1)
@@ -819,23 +862,13 @@ class ConvBNActFn(Function):
                 dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(wsb, a1)
                 _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, swp, swn, sst)
-                dws = torch.empty_like(gw)
-                if ctx.transposed:
-                    call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dws), C1 + C2, Cout, 27, sst)
-                else:
-                    call('da_w_tio_to_oik', ptr(dw_tio), ptr(dws), Cout, C1 + C2, 27, sst)
-                gw.add_(dws)
+                grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', gw.shape, acc=gw)
             _side_keep.extend(t for t in (a1, a2, dy, p1s, p1t, p2s, p2t) if t is not None)
             dw = None
         else:
             dw_tio = torch.empty_like(w_tio)
             _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, wp, wn, st)
-            if ctx.transposed:
-                dw = _empty((C1 + C2, Cout, 3, 3, 3), a1)
-                call('da_w_tio_to_iok_flip', ptr(dw_tio), ptr(dw), C1 + C2, Cout, 27, st)
-            else:
-                dw = _empty((Cout, C1 + C2, 3, 3, 3), a1)
-                call('da_w_tio_to_oik', ptr(dw_tio), ptr(dw), Cout, C1 + C2, 27, st)
+            dw = grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', ctx.wparam.shape)
         db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, db, dgamma, dbeta)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, dgamma, dbeta,
                 None, None, None, None, None, None) + (None,) * ctx.n_extra
@@ -854,8 +887,7 @@ class DeconvBNActFn(Function):
         if weight.shape[0] != Cin or tuple(weight.shape[2:]) != (2, 2, 2):
             raise ValueError('ConvTranspose3d weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
         st = stream()
-        w_tio = _empty((8, Cin, Cout), a)
-        call('da_w_iok_to_tio', ptr(weight.detach().contiguous()), ptr(w_tio), Cin, Cout, 8, st)
+        w_tio = weight_tio(weight, 'iok')
         y = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
@@ -903,9 +935,7 @@ class DeconvBNActFn(Function):
                 dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
                 call('da_deconv_k2s2_wgrad', ptr(a), ptr(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, swp, swn, stream())
-                dws = torch.empty_like(gw)
-                call('da_w_tio_to_iok', ptr(dw_tio), ptr(dws), Cin, Cout, 8, stream())
-                gw.add_(dws)
+                grad_from_tio(dw_tio, 'iok', gw.shape, acc=gw)
             _run_on_side(side_work, (a, dy))
             dw = None
         else:
@@ -1159,8 +1189,7 @@ class HeadDiceFn(Function):
         lab, lb = _labels(labels.reshape(N, -1))
         if lab.shape[1] != V:
             raise ValueError('label map and input must cover the same volume')
-        w_io = _empty((Cin, C), a)
-        call('da_w_oik_to_tio', ptr(weight.detach().contiguous()), ptr(w_io), C, Cin, 1, st)
+        w_io = weight_tio(weight, 'oik').view(Cin, C)
         b = bias.detach().contiguous() if bias is not None else None
         loss = _empty((1,), a)
         coef = _empty((2, N, C), a)

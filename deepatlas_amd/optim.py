@@ -35,6 +35,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         ops.register_flat_bucket(self.flat_g)
+        ops.register_flat_params(self.flat_p)
+        ops.bump_weights_epoch()                   # the parameters just moved into the bucket
         # device copy of this step's scalars for the graph-capturable update (da_adam_step_dev): refreshed before every replay
         self._dev_state = torch.zeros(6, dtype=torch.float32, device=dev)
         self.device_step = False          # True inside a captured step: step() launches da_adam_step_dev
@@ -64,6 +66,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def note_replayed_step(self):
         """Book-keeping of a step that ran inside a replayed graph (the host-side part of step())."""
+        ops.bump_weights_epoch()
         self._steps += 1
         for p, _, _ in self._slices:
             if p.requires_grad:
@@ -117,6 +120,7 @@ class FlatAdam(torch.optim.Optimizer):
                 raise RuntimeError('FlatAdam: a parameter no longer lives in the flat bucket (model.to()/.half() after constructing the '
                                    'optimiser?); build the optimiser after moving the model')
         mask = self._frozen_mask()
+        ops.bump_weights_epoch()                   # cached weight layouts (ops.weight_tio) are stale from here on
         if self.device_step:
             # being captured into a HIP graph (graphs.GraphedStep): step count and hyper-parameters come from device memory; the
             # host-side book-keeping happens per REPLAY in note_replayed_step()

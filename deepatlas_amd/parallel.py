@@ -49,6 +49,8 @@ def broadcast_parameters(optimizer, src=0, model=None):
     if not is_dist() or dist.get_world_size() == 1:
         return
     dist.broadcast(optimizer.flat_p, src=src)
+    from . import ops
+    ops.bump_weights_epoch()                        # the parameters changed under the cached weight layouts
     if hasattr(optimizer, 'flat_m'):
         dist.broadcast(optimizer.flat_m, src=src)
         dist.broadcast(optimizer.flat_v, src=src)

@@ -46,6 +46,10 @@ int da_w_tio_to_iok(const float* w_tio, float* w_iok, int Cin, int Cout, int K3,
  * flipped taps, so it runs on the da_conv3d_k3_* entries after this re-layout. */
 int da_w_iok_flip_to_tio(const float* w_iok, float* w_tio, int Cin, int Cout, int K3, void* stream);
 int da_w_tio_to_iok_flip(const float* w_tio, float* w_iok, int Cin, int Cout, int K3, void* stream);
+/* the three gradient conversions, accumulating: dst += layout(w_tio) (dst: the parameter's .grad inside the optimiser's flat bucket) */
+int da_w_tio_to_oik_acc(const float* w_tio, float* w_oik, int Cout, int Cin, int K3, void* stream);
+int da_w_tio_to_iok_acc(const float* w_tio, float* w_iok, int Cin, int Cout, int K3, void* stream);
+int da_w_tio_to_iok_flip_acc(const float* w_tio, float* w_iok, int Cin, int Cout, int K3, void* stream);
 
 /* ---- 3x3x3 convolution, padding 1, stride 1|2 (rows a1, a7, a9) ----------------------------- */
 /* replaces nn.Conv3d(k=3,p=1) forward: unets.py:30,36; modules.py:48,56; voxel_morph.py:57,82.
