@@ -212,7 +212,7 @@ def free_port():
 def self_spawn(n):
     """`python bench.py --gpus N` without a launcher: check the devices, then run N ranks of this script under torch.distributed.run."""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get('DA_BENCH_SHARE_DEVICE') != '1':
         sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; refusing to run fewer ranks '
                          'and label them as %d\n' % (n, have, n))
         sys.exit(2)
@@ -227,8 +227,9 @@ def self_spawn(n):
 class Workload:
     """One timed configuration: step() closure + what one step amounts to."""
 
-    def __init__(self, name, step, units, unit, flops_per_step, loss_of):
+    def __init__(self, name, step, units, unit, flops_per_step, loss_of, optimizers=()):
         self.name, self.step, self.units, self.unit, self.flops_per_step, self.loss_of = name, step, units, unit, flops_per_step, loss_of
+        self.optimizers = list(optimizers)          # the FlatAdam buckets this step all-reduces (one collective each)
 
 
 def make_workloads(args, dev, rank, which):
@@ -286,7 +287,7 @@ def make_workloads(args, dev, rank, which):
             nm = 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (SURVEY row f3, not a BASELINE config)' % (
                 args.batch, shape[0], shape[1], shape[2], prec)
             fl = None
-        out['seg'] = Workload(nm, seg_step, args.batch, 'volumes/s', fl, lambda r: r)
+        out['seg'] = Workload(nm, seg_step, args.batch, 'volumes/s', fl, lambda r: r, [opt])
     if 'reg' in which or 'joint' in which:
         from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
         reg = get_network('voxel_morph_cvpr')()
@@ -300,14 +301,14 @@ def make_workloads(args, dev, rank, which):
             rstep = RegistrationStep(reg, ropt)
             reg_fn = (lambda: rstep(im_m, im_t)[0]) if not args.graph else graphed(*rstep.segments(im_m, im_t), 'loss')
             out['reg'] = Workload('reg-only VoxelMorph + trilinear warp + NCC + bending + Adam, 1 pair/GPU, %dx%dx%d %s (BASELINE configs[2])'
-                                  % (shape + (prec,)), reg_fn, 1, 'pairs/s', REG_TRAIN_FLOP_PER_VOXEL * V, lambda r: r)
+                                  % (shape + (prec,)), reg_fn, 1, 'pairs/s', REG_TRAIN_FLOP_PER_VOXEL * V, lambda r: r, [ropt])
         if 'joint' in which:
             jstep = DeepAtlasJointStep(model, opt, reg, ropt, n_classes)
             joint_fn = (lambda: jstep(im_m, im_t, sm, st_)['loss_seg']) if not args.graph else graphed(*jstep.segments(im_m, im_t, sm, st_), 'loss_seg')
             out['joint'] = Workload('joint DeepAtlas alternating step (reg phase + seg phase, 32-ch seg warp), 1 pair/GPU, %dx%dx%d %s '
                                     '(BASELINE configs[3] per-GPU shape)' % (shape + (prec,)),
                                     joint_fn, 1, 'pairs/s',
-                                    (SEG_TRAIN_FLOP_PER_VOXEL + REG_TRAIN_FLOP_PER_VOXEL) * V if args.net == 'UNet_light' else None, lambda r: r)
+                                    (SEG_TRAIN_FLOP_PER_VOXEL + REG_TRAIN_FLOP_PER_VOXEL) * V if args.net == 'UNet_light' else None, lambda r: r, [ropt, opt])
     return out, n_classes
 
 
@@ -439,20 +440,28 @@ def main():
     if world != want:
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (want, world))
         sys.exit(2)
-    if torch.cuda.device_count() <= local_rank:
+    # DA_BENCH_SHARE_DEVICE=1 (tests only: tests/test_gpu_dp.py): the N ranks share the visible device(s) and talk over gloo, so the
+    # multi-rank code path (spawn, barriers, per-rank timing, the all-reduce leg) runs on a one-GPU box; the numbers mean nothing
+    share = os.environ.get('DA_BENCH_SHARE_DEVICE') == '1'
+    if torch.cuda.device_count() <= local_rank and not share:
         sys.stderr.write('bench.py: rank %d needs device %d but only %d GPU(s) are visible\n' % (rank, local_rank, torch.cuda.device_count()))
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     rccl = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        try:
-            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            rccl = 'unknown'
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            rccl = 'gloo (DA_BENCH_SHARE_DEVICE test mode)'
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            try:
+                rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = 'unknown'
 
     from deepatlas_amd import _native as nat, ops
     ops.enable_async_wgrad(not args.sync_wgrad)
@@ -463,9 +472,8 @@ def main():
     # Python's cyclic collector walks every live container each time it runs a full collection; with three models, their optimisers and
     # the autograd graphs of a step alive that costs the (host-bound) small-volume and bf16 legs milliseconds per step.  Standard
     # training-loop hygiene: move everything built so far out of the collector's reach.
-    import gc
-    gc.collect()
-    gc.freeze()
+    from deepatlas_amd import parallel as _par
+    pinned = _par.pin_host_resources(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))       # gc.freeze() + per-rank core slice
 
     # ---- headline: the timed region carries HIP-event timing of the FORWARD conv calls only.  The backward pass runs its weight
     # gradients on a second stream (ops.ASYNC_WGRAD): timing events recorded there serialise it against the main stream and
@@ -473,6 +481,22 @@ def main():
     head = wls[args.workload]
     dt, per_rank, final_loss, prof, launches = time_workload(head, args, world, dev, None if (args.no_profile or args.graph) else CONV_FWD_CALLS)
     head_res = result_of(head, dt, per_rank, world, args, launches)
+
+    allreduce = None
+    if world > 1:
+        # the step's only collective, timed on its own: the flat-bucket gradient all-reduce(s) of one step (seg 3.5 MB; reg 1.0 MB),
+        # 20 back-to-back calls between device synchronisations, maximum over the ranks
+        buckets = head.optimizers
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            for o in buckets:
+                _par.allreduce_gradients(o)
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allreduce = dict(ms_per_step=round(float(tt.item()), 4), collectives_per_step=len(buckets), bytes=[int(o.flat_g.numel() * 4) for o in buckets],
+                         note="the step's flat-bucket gradient all-reduce(s) (sum + in-place average) timed on their own: mean of 20, max over ranks")
 
     bwd_rows = []
     peak = SPLIT_MFMA_PEAK_TFLOPS if args.precision == 'fp32_split' else FP32_MFMA_PEAK_TFLOPS
@@ -564,7 +588,8 @@ def main():
                                 parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision,
                                 matrix_arithmetic=PRECISION_NOTE[args.precision],
                                 c_abi_launches_per_step=head_res['c_abi_launches_per_step'], hip_graph=bool(args.graph), rccl=rccl,
-                                ms_per_step_per_rank=head_res.get('ms_per_step_per_rank')),
+                                ms_per_step_per_rank=head_res.get('ms_per_step_per_rank'), allreduce=allreduce,
+                                host_cores_per_rank=pinned[1] if pinned else None),
                     roofline=roofline, extra=extra or None)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'seg' and args.net == 'UNet_light':
             # CPU leg: the oracle's step timed on the host cores; its first step is also the reference of the full-size parity block

@@ -122,6 +122,7 @@ class SegmentationExperiment(BaseExperiment):
         print("Training {}".format(self.exp_name))
         finished_epoch, self.best_score = self.initialize_model(self.model, self.optimizer, self.config['resume_dir'])
         parallel.broadcast_parameters(self.optimizer, model=self.model)
+        parallel.pin_host_resources()                 # per-rank core slice + gc.freeze(): the host launch loop is the DP scaling risk
         self.current_epoch = finished_epoch + 1
         for epoch in range(self.current_epoch, self.config['n_epochs'] + 1):
             self.train_one_epoch()

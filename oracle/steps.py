@@ -79,7 +79,7 @@ def reg_step(sd, opt, source, target, lam_reg=1.0):
 
 
 def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec, n_classes,
-               lam_sim=1.0, lam_reg=1.0, lam_anat=1.0, lam_sp=1.0):
+               lam_sim=1.0, lam_reg=1.0, lam_anat=1.0, lam_sp=1.0, reduce_grads=None):
     """Joint DeepAtlas alternating step (build-defined from the reference's parts).
 
     reg phase (seg net frozen): L = lam_sim*NCC(warp(Im), It) + lam_reg*Bending(disp)
@@ -87,6 +87,8 @@ def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec,
     seg phase (reg net frozen): L = lam_sp*Dice(S(Im), seg_m) + lam_anat*Dice(warp(softmax(S(Im)), phi.detach()), onehot(seg_t))
     seg_m=None (the moving image has no manual segmentation): the reg phase warps softmax(S(Im)).detach() -- the segmentation net in
     eval mode, no state change -- instead of onehot(seg_m), and the seg phase has no supervised term.
+    reduce_grads(grads, phase) (optional; phase 'reg' | 'seg'): applied to each phase's gradient dict right before its optimiser
+    step -- where data-parallel training averages the gradients over the replicas (tests/test_dp_gloo.py).
     Returns dict of losses (+ 'grads_reg' / 'grads_seg': the gradients each optimiser step consumed).
     """
     onehot_t = losses.mask_to_one_hot(seg_t.long().unsqueeze(1), n_classes)
@@ -108,6 +110,8 @@ def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec,
     g = _grads(loss_r, reg_sd, rn)
     for n in rn:
         reg_sd[n].requires_grad_(False)
+    if reduce_grads is not None:
+        g = reduce_grads(g, 'reg')
     reg_opt.step(reg_sd, g)
     deform = deform.detach()
     # ---- seg phase
@@ -124,6 +128,8 @@ def joint_step(seg_sd, seg_opt, reg_sd, reg_opt, im_m, im_t, seg_m, seg_t, spec,
     g2 = _grads(loss_s, seg_sd, sn)
     for n in sn:
         seg_sd[n].requires_grad_(False)
+    if reduce_grads is not None:
+        g2 = reduce_grads(g2, 'seg')
     seg_opt.step(seg_sd, g2)
     return dict(loss_reg=loss_r.detach(), loss_seg=loss_s.detach(), sim=l_sim.detach(), bend=l_reg.detach(),
                 anat_reg=l_anat.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach(), grads_reg=g, grads_seg=g2)

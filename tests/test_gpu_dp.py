@@ -86,6 +86,73 @@ def test_dp_two_ranks_one_gpu_matches_gradient_accumulation(tmp_path):
     assert np.max(np.abs(g0 - ref)) <= 1e-6 * np.max(np.abs(ref)), (float(np.max(np.abs(g0 - ref))), float(np.max(np.abs(ref))))
 
 
+def _joint_worker(rank, world, port, out_dir, graph):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import nets
+    from deepatlas_amd import parallel, ops
+    from deepatlas_amd.graphs import GraphedStep
+    from deepatlas_amd.optim import FlatAdam
+    from deepatlas_amd.lib.network_factory import get_network, unets
+    from deepatlas_amd.models.joint import DeepAtlasJointStep
+    ops.enable_async_wgrad(True)
+    ops.set_matrix_precision(ops.DEFAULT_MATRIX_PRECISION)
+    ops.set_deterministic(True)                          # the warp scatter's float atomics would make the two modes differ in the last bit
+    C, shape, d = 8, (16, 16, 32), 'cuda:0'
+    spec = nets.UNET_TINY
+    seg_sd = nets.closed_form_fill(nets.unet_param_shapes(1, C, spec['encoders'], spec['decoders']), seed=1)
+    reg_sd = nets.closed_form_fill(nets.voxelmorph_param_shapes(), seed=4)
+    seg = unets.UNet_generator(encoders=spec['encoders'], decoders=spec['decoders'], act='LeakyReLU')(in_channel=1, n_classes=C, bias=True, BN=True)
+    seg.load_state_dict({k: v.clone() for k, v in seg_sd.items()}, strict=True)
+    reg = get_network('voxel_morph_cvpr')()
+    reg.load_state_dict({k: v.clone() for k, v in reg_sd.items()}, strict=True)
+    seg.to(d); reg.to(d)
+    r = slice(rank, rank + 1)
+    im_m, im_t = nets.closed_form_volume((world, 1) + shape, seed=5)[r].to(d), nets.closed_form_volume((world, 1) + shape, seed=6)[r].to(d)
+    sm, st_ = nets.closed_form_labels((world,) + shape, C, seed=7)[r].to(d), nets.closed_form_labels((world,) + shape, C, seed=8)[r].to(d)
+    so, ro = FlatAdam(seg.parameters(), lr=1e-3), FlatAdam(reg.parameters(), lr=1e-3)
+    if rank == 1:
+        so.flat_p.mul_(1.25); ro.flat_p.mul_(0.75)       # replicas must end up with rank 0's weights
+    parallel.broadcast_parameters(so, src=0, model=seg)
+    parallel.broadcast_parameters(ro, src=0, model=reg)
+    jstep = DeepAtlasJointStep(seg, so, reg, ro, C)
+    sm_r = sm if rank == 0 else None                    # rank 1: unlabelled moving image (seg net in eval mode inside the reg phase)
+    if graph:
+        segs, betw, opts = jstep.segments(im_m, im_t, sm_r, st_)
+        g = GraphedStep(segs, opts, between=betw, warmup=1)
+        assert g.distributed
+        outs = [g() for _ in range(4)]                   # 1 eager, capture + replay, 2 replays
+        assert g.graphs is not None and len(g.graphs) == 3
+        loss = float(outs[-1]['loss_seg'].item())
+    else:
+        for _ in range(4):
+            out = jstep(im_m, im_t, sm_r, st_)
+        loss = float(out['loss_seg'].item())
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'jp_%d_%d.npy' % (int(graph), rank)), torch.cat([so.flat_p, ro.flat_p]).detach().cpu().numpy())
+    np.save(os.path.join(out_dir, 'jg_%d_%d.npy' % (int(graph), rank)), torch.cat([so.flat_g, ro.flat_g]).detach().cpu().numpy())
+    np.save(os.path.join(out_dir, 'jl_%d_%d.npy' % (int(graph), rank)), np.array([loss]))
+    dist.destroy_process_group()
+
+
+def test_dp_joint_step_two_ranks_eager_and_per_segment_graphs(tmp_path):
+    """The product's joint step under a real process group (two ranks on one device over gloo): two FlatAdam buckets, one all-reduce per
+    phase, rank 1 on the unlabelled branch.  Eager, and as graphs.GraphedStep with one HIP graph per segment and the all-reduces eager in
+    the gaps (what `bench.py --graph --gpus N` runs): replicas end bit-identical in parameters and in the averaged gradients, and the
+    graphed run reproduces the eager one bit for bit (deterministic mode)."""
+    world = 2
+    for graph in (False, True):
+        mp.spawn(_joint_worker, args=(world, _free_port(), str(tmp_path), graph), nprocs=world, join=True)
+    for graph in (0, 1):
+        p0, p1 = np.load(tmp_path / ('jp_%d_0.npy' % graph)), np.load(tmp_path / ('jp_%d_1.npy' % graph))
+        g0, g1 = np.load(tmp_path / ('jg_%d_0.npy' % graph)), np.load(tmp_path / ('jg_%d_1.npy' % graph))
+        assert np.array_equal(p0, p1) and np.array_equal(g0, g1) and np.isfinite(p0).all()
+    assert np.array_equal(np.load(tmp_path / 'jp_0_0.npy'), np.load(tmp_path / 'jp_1_0.npy'))          # graphed == eager
+    assert np.array_equal(np.load(tmp_path / 'jl_0_1.npy'), np.load(tmp_path / 'jl_1_1.npy'))
+
+
 def test_rccl_two_ranks_on_two_devices():
     """RCCL with more than one rank (the collectives bench.py / parallel.py issue): skipped on the one-GPU box, runs
     tools/rccl_smoke.py at world size 2 wherever two devices are visible (the 8-GPU node)."""
@@ -110,3 +177,24 @@ def test_bench_refuses_more_ranks_than_devices():
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and ('only %d GPU' % torch.cuda.device_count()) in out.stderr, out.stderr
+
+
+def test_bench_multi_rank_code_path_on_a_shared_device():
+    """`bench.py --gpus 2` end to end on the one-GPU box (DA_BENCH_SHARE_DEVICE=1: both ranks on device 0, gloo instead of RCCL): the
+    self-spawn, the barriers, max-over-ranks timing, per-rank ms and the separately timed all-reduce leg -- the code the driver runs at
+    N = 2, 4, 8 over RCCL.  Small volumes; only the structure of the JSON line is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['DA_BENCH_SHARE_DEVICE'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--shape', '32', '32', '32',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['parallelism'] == 'dp2' and line['config']['global_batch'] == 4
+    assert len(line['config']['ms_per_step_per_rank']) == 2 and line['ms_per_step'] >= max(line['config']['ms_per_step_per_rank']) - 1e-6
+    ar = line['config']['allreduce']
+    assert ar['collectives_per_step'] == 1 and ar['bytes'] == [874864 * 4] and ar['ms_per_step'] > 0
+    assert len(line['extra']['joint']['ms_per_step_per_rank']) == 2
