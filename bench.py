@@ -528,6 +528,26 @@ def main():
                                          matrix_arithmetic=PRECISION_NOTE['fp32'])
         ops.set_matrix_precision(args.precision)
 
+    if not args.no_extra and args.workload == 'seg' and args.net == 'UNet_light' and args.precision == 'fp32_split' and tuple(shape) == (160, 192, 160) and not args.graph:
+        # BASELINE configs[4]'s shape and precision, driver-timed: seg (batch 2) and the joint step (1 pair) at 192 x 224 x 192 with the 3x3x3
+        # convolutions' operands rounded to bf16 (HBM tensors stay fp32: bf16 STORAGE is not implemented), and the same two legs in the
+        # shipped fp32_split mode.  Fewer steps (the legs are 1.7x larger); fresh models.
+        a4 = argparse.Namespace(**dict(vars(args), shape=[192, 224, 192], steps=max(2, min(args.steps, 6)), warmup=2))
+        big = {}
+        for mode in ('bf16', 'fp32_split'):
+            ops.set_matrix_precision(mode)
+            am = argparse.Namespace(**dict(vars(a4), precision=mode))
+            w4, _ = make_workloads(am, dev, rank, ['seg', 'joint'])
+            for leg in ('seg', 'joint'):
+                edt, eper, eloss, _, elaunch = time_workload(w4[leg], am, world, dev, None)
+                big['%s_%s' % (leg, mode)] = dict(result_of(w4[leg], edt, eper, world, am, elaunch), final_loss=round(eloss, 6), steps=am.steps)
+            del w4
+            torch.cuda.empty_cache()
+        big['note'] = ("BASELINE configs[4] shape; 'bf16' = operands of the 3x3x3 convolutions rounded to bf16 (mixed precision in the matrix "
+                       "arithmetic only, not fp32-accurate); tensors in HBM are fp32 in both modes")
+        extra['configs4_192x224x192'] = big
+        ops.set_matrix_precision(args.precision)
+
     if rank == 0:
         roofline = None
         if prof is not None:

@@ -254,7 +254,10 @@ def warp_trilinear(source, deform):
 
 def _vm_conv(x, sd, prefix, stride):
     """modules.py:28-62 convBlock for the reg net: Conv3d(k3,p1,stride,bias) -> ReLU (no BN)."""
-    return F.relu(F.conv3d(x, sd[f'{prefix}.conv.weight'], sd[f'{prefix}.conv.bias'], stride=stride, padding=1))
+    w = sd[f'{prefix}.conv.weight']
+    if K3_OPERAND_ROUND is not None and w.shape[1] % 8 == 0 and w.shape[0] >= 8 and w.shape[0] % 4 == 0:      # (see K3_OPERAND_ROUND)
+        x, w = K3_OPERAND_ROUND(x), K3_OPERAND_ROUND(w)
+    return F.relu(F.conv3d(x, w, sd[f'{prefix}.conv.bias'], stride=stride, padding=1))
 
 
 def voxelmorph_forward(sd, source, target):
