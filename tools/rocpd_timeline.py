@@ -41,6 +41,8 @@ def main():
     prev = lo
     tm = tn = ti = 0
     exposed = defaultdict(float)
+    gaps = defaultdict(lambda: [0.0, 0])             # idle time by (kernel that ended before the gap -> kernel that started after it)
+    last_ended = '(start)'
     for t, kind, i in ev:
         dt = t - prev
         if dt > 0:
@@ -48,12 +50,15 @@ def main():
             elif active:
                 tn += dt
                 for j in active: exposed[rows[j][0]] += dt / len(active)
-            else: ti += dt
+            else:
+                ti += dt
+                if kind == 1:
+                    g = gaps[(last_ended, rows[i][0])]; g[0] += dt; g[1] += 1
         prev = t
         if kind == 1:
             active.add(i); nm += is_matrix(rows[i][0])
         else:
-            active.discard(i); nm -= is_matrix(rows[i][0])
+            active.discard(i); nm -= is_matrix(rows[i][0]); last_ended = rows[i][0]
     wall = prev - lo
     print('# %s: window %.3f ms = %d steps, queues %s' % (sys.argv[1], wall / 1e6, nsteps, sorted(set(r[3] for r in rows))))
     if nsteps:
@@ -65,6 +70,9 @@ def main():
     print('exposed time by kernel (no matrix kernel running beside it):')
     for k, v in sorted(exposed.items(), key=lambda kv: -kv[1])[:top]:
         print('  %-80s %8.3f ms  %5.1f %%' % (k, v / 1e6, 100 * v / wall))
+    print('idle gaps (nothing in flight) by the kernels on either side:')
+    for (a, b), (v, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
+        print('  %8.3f ms  %4d x  %-44s -> %s' % (v / 1e6, c, a[:44], b[:60]))
 
 
 def dump_last_step(path, min_us=150.0):
