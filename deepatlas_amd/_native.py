@@ -11,7 +11,7 @@ from ctypes import c_int, c_float, c_longlong, c_size_t, c_void_p, c_char_p, POI
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdeepatlas_hip.so')
+LIB_PATH = os.environ.get('DA_LIB') or os.path.join(_HERE, 'csrc', 'libdeepatlas_hip.so')     # DA_LIB: A/B builds of the same ABI (tools/)
 
 P = c_void_p
 I = c_int

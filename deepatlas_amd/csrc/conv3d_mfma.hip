@@ -70,6 +70,11 @@ __device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // roun
 // the running remainder (3 x 8 significand bits cover fp32's 24; the subtractions are exact in fp32).  Four values at a time, packed
 // like da_bf16x2 (element 0 in the low half).
 __device__ __forceinline__ void da_split3(const float4 v, uint2& h, uint2& m, uint2& l) {
+#ifdef DA_FAKE_SPLIT   // timing experiment only (never in the shipped library): no split arithmetic, wrong results, same data volume
+    h = make_uint2(__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u), __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u));
+    m = make_uint2(h.y, h.x); l = make_uint2(h.x ^ 0x00010001u, h.y);
+    return;
+#endif
     h = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
     const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xFFFF0000u);
     const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xFFFF0000u);
