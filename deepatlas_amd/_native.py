@@ -131,6 +131,20 @@ SIGNATURES = {
     'da_adam_step_dev': (I, [P, P, P, P, LL, P, P]),
 }
 
+# bf16 activation storage: `<name>_bf16` twins (include/deepatlas_hip.h, last section) have the argument list of `<name>`; the 3x3x3
+# convolution twins take one more argument, the bit mask of their bf16 activation arguments
+BF16_TWINS = ['da_bn_train_stats', 'da_bn_act_fwd', 'da_bn_act_bwd_dbias', 'da_act_bwd', 'da_act_bwd_add_dbias', 'da_act_bwd_add_partial', 'da_colsum',
+              'da_maxpool2_fwd', 'da_maxpool2_fwd_pro', 'da_maxpool2_bwd', 'da_maxpool2_bwd_add', 'da_upsample_nearest_fwd', 'da_upsample_nearest_bwd',
+              'da_deconv_k2s2_fwd', 'da_deconv_k2s2_fwd_bnstats', 'da_deconv_k2s2_dgrad', 'da_deconv_k2s2_wgrad',
+              'da_conv1x1_fwd', 'da_conv1x1_fwd_pro', 'da_conv1x1_dgrad', 'da_conv1x1_wgrad', 'da_conv1x1_wgrad_pro', 'da_head_dice_fwd', 'da_head_dice_bwd']
+BF16_MASKED_TWINS = ['da_conv3d_k3_fwd', 'da_conv3d_k3_fwd_bnstats', 'da_conv3d_k3_fwd_pro', 'da_conv3d_k3_wgrad_pro', 'da_conv3d_k3_dgrad', 'da_conv3d_k3_wgrad']
+for _n in BF16_TWINS:
+    SIGNATURES[_n + '_bf16'] = (SIGNATURES[_n][0], list(SIGNATURES[_n][1]))
+for _n in BF16_MASKED_TWINS:
+    SIGNATURES[_n + '_bf16'] = (SIGNATURES[_n][0], list(SIGNATURES[_n][1]) + [ctypes.c_uint])
+SIGNATURES['da_cast_f32_to_bf16'] = (I, [P, P, LL, P])
+SIGNATURES['da_cast_bf16_to_f32'] = (I, [P, P, LL, P])
+
 _lib = None
 
 

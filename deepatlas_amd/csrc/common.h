@@ -71,3 +71,36 @@ int da_reduce_partials(const float* partial, int nparts, int O, float* out, hipS
 // losses.hip: Dice loss / coefficients from per-block partial sums (shared with the fused label-warp Dice in warp.hip)
 int da_dice_finish(double* partial, int nblocks, int N, int C, int weight_type, int no_bg, float eps,
                    float* loss, float* coef, float* isc, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 ACTIVATION STORAGE (BASELINE configs[4]: "bf16 activations / MFMA, fp32 master weights, fp32 reductions").  The `_bf16` twins of
+// the C-ABI entry points take the network-internal activation / gradient tensors as bf16 in HBM (same NDHWC layout, 2 bytes per
+// element); everything a kernel computes with stays fp32 (or double for the reductions) and a value is rounded to nearest-even once,
+// when it is stored.  Kernels are templates over the storage type T in {float, da_bf16} and touch memory only through these helpers.
+// ---------------------------------------------------------------------------------------------------
+struct da_bf16 { unsigned short v; };
+template <typename T> struct DaEl;
+template <> struct DaEl<float>   { static constexpr int bytes = 4; static constexpr bool bf = false; };
+template <> struct DaEl<da_bf16> { static constexpr int bytes = 2; static constexpr bool bf = true; };
+
+__device__ __forceinline__ unsigned da_pack_bf16x2(float lo, float hi) {      // round-to-nearest-even, one v_cvt_pk_bf16_f32 (element 0 in the low half)
+    typedef float da_f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 da_bf16x2_t __attribute__((ext_vector_type(2)));
+    const da_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, da_bf16x2_t));
+}
+__device__ __forceinline__ float da_bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float da_bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ float4 da_unpack_bf16x4(uint2 u) { return make_float4(da_bf16_lo(u.x), da_bf16_hi(u.x), da_bf16_lo(u.y), da_bf16_hi(u.y)); }
+__device__ __forceinline__ uint2 da_pack_bf16x4(float4 v) { return make_uint2(da_pack_bf16x2(v.x, v.y), da_pack_bf16x2(v.z, v.w)); }
+
+// quad (4 consecutive channels) number q of a tensor: 16-byte (fp32) / 8-byte (bf16) access
+__device__ __forceinline__ float4 da_ldq(const float* p, long long q) { return reinterpret_cast<const float4*>(p)[q]; }
+__device__ __forceinline__ float4 da_ldq(const da_bf16* p, long long q) { return da_unpack_bf16x4(reinterpret_cast<const uint2*>(p)[q]); }
+__device__ __forceinline__ void da_stq(float* p, long long q, float4 v) { reinterpret_cast<float4*>(p)[q] = v; }
+__device__ __forceinline__ void da_stq(da_bf16* p, long long q, float4 v) { reinterpret_cast<uint2*>(p)[q] = da_pack_bf16x4(v); }
+// single elements
+__device__ __forceinline__ float da_ld1(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float da_ld1(const da_bf16* p, long long i) { return __uint_as_float((unsigned)p[i].v << 16); }
+__device__ __forceinline__ void da_st1(float* p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void da_st1(da_bf16* p, long long i, float v) { p[i].v = (unsigned short)(da_pack_bf16x2(v, 0.f) & 0xFFFFu); }

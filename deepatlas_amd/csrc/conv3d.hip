@@ -489,3 +489,95 @@ extern "C" int da_conv3d_k3_wgrad(const float* in1, int C1, const float* in2, in
     }
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 activation storage (common.h): twins of the entries above whose activation / gradient tensors are bf16 in HBM.  `bf16_mask` has
+// one bit per activation argument in signature order (bit set = that tensor is bf16).  Handled natively: all tensors bf16, stride 1, the
+// matrix-core kernels of the bf16 matrix mode (da_set_matrix_mode(1)).  Everything else returns DA_ERR_UNSUPPORTED and the caller
+// converts (da_cast_*) around the fp32 entry.  Weights, biases, statistics and weight gradients are always fp32.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int da_conv3d_k3_fwd_bf16(const void* in1, int C1, const void* in2, int C2,
+                                     const float* w_tio, const float* bias, void* out,
+                                     int N, int D, int H, int W, int Cout, int stride, float act_slope,
+                                     void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
+    if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
+        return DA_ERR_BADARG;
+    const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
+    if ((bf16_mask & want) != want || force_direct() || stride != 1 || !da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+    return da_conv3_mfma_fwd((const float*)in1, C1, (const float*)in2, C2, w_tio, 0, bias, (float*)out, Cout, nullptr, 0,
+                             N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, nullptr, nullptr, 1);
+}
+
+extern "C" int da_conv3d_k3_fwd_bnstats_bf16(const void* in1, int C1, const void* in2, int C2,
+                                             const float* w_tio, const float* bias, void* out,
+                                             int N, int D, int H, int W, int Cout, int stride,
+                                             double* stats_partial, int stats_capacity, int* stats_nparts,
+                                             void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
+    if (stats_nparts) *stats_nparts = 0;
+    if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
+        return DA_ERR_BADARG;
+    const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
+    if ((bf16_mask & want) != want || force_direct() || stride != 1 || !da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+    const bool stats = stats_partial && stats_capacity >= 512;
+    return da_conv3_mfma_fwd((const float*)in1, C1, (const float*)in2, C2, w_tio, 0, bias, (float*)out, Cout, nullptr, 0, N, D, H, W, Cout, stride, -1.f,
+                             ws, ws_bytes, da_stream(stream), 0, stats ? stats_partial : nullptr, stats ? stats_nparts : nullptr, nullptr, nullptr, 1);
+}
+
+extern "C" int da_conv3d_k3_fwd_pro_bf16(const void* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                                         const void* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                                         const float* w_tio, const float* bias, void* out,
+                                         int N, int D, int H, int W, int Cout, float act_slope,
+                                         double* stats_partial, int stats_capacity, int* stats_nparts,
+                                         void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
+    if (stats_nparts) *stats_nparts = 0;
+    if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 ||
+        (pro1_scale && !pro1_shift) || (pro2_scale && !pro2_shift))
+        return DA_ERR_BADARG;
+    const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
+    if ((bf16_mask & want) != want || force_direct() || !da_conv3_mfma_fwd_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)) return DA_ERR_WS_SMALL;
+    const DaPro pro = {pro1_scale, pro1_shift, pro1_slope, pro2_scale, pro2_shift, pro2_slope};
+    const bool stats = stats_partial && stats_capacity >= 512;
+    return da_conv3_mfma_fwd((const float*)in1, C1, (const float*)in2, C2, w_tio, 0, bias, (float*)out, Cout, nullptr, 0, N, D, H, W, Cout, 1, stats ? -1.f : act_slope,
+                             ws, ws_bytes, da_stream(stream), 0, stats ? stats_partial : nullptr, stats ? stats_nparts : nullptr, &pro, nullptr, 1);
+}
+
+extern "C" int da_conv3d_k3_wgrad_pro_bf16(const void* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                                           const void* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                                           const void* dy, float* dw_tio,
+                                           int N, int D, int H, int W, int Cout,
+                                           void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
+    if (!in1 || !dy || !dw_tio || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || Cout <= 0 ||
+        (pro1_scale && !pro1_shift) || (pro2_scale && !pro2_shift))
+        return DA_ERR_BADARG;
+    const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
+    if ((bf16_mask & want) != want || force_direct() || !da_conv3_mfma_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)) return DA_ERR_WS_SMALL;
+    const DaPro pro = {pro1_scale, pro1_shift, pro1_slope, pro2_scale, pro2_shift, pro2_slope};
+    return da_conv3_mfma_wgrad((const float*)in1, C1, (const float*)in2, C2, (const float*)dy, dw_tio, N, D, H, W, Cout, 1, ws, ws_bytes, da_stream(stream), 0, &pro, nullptr, 1);
+}
+
+extern "C" int da_conv3d_k3_dgrad_bf16(const void* dy, const float* w_tio, void* dx1, int C1, void* dx2, int C2,
+                                       int N, int D, int H, int W, int Cout, int stride,
+                                       void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
+    if (!dy || !w_tio || !dx1 || C1 <= 0 || C2 < 0 || (C2 > 0 && !dx2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
+    const int Cin = C1 + C2;
+    const unsigned want = 1u | 2u | (C2 > 0 ? 4u : 0u);
+    if ((bf16_mask & want) != want || force_direct() || stride != 1 || !da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)) return DA_ERR_WS_SMALL;
+    return da_conv3_mfma_fwd((const float*)dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, (float*)dx1, C1, (float*)dx2, C2,
+                             N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, nullptr, nullptr, 1);
+}
+
+extern "C" int da_conv3d_k3_wgrad_bf16(const void* in1, int C1, const void* in2, int C2, const void* dy,
+                                       float* dw_tio, float* dbias,
+                                       int N, int D, int H, int W, int Cout, int stride,
+                                       void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
+    if (!in1 || !dy || !dw_tio || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
+    const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
+    if ((bf16_mask & want) != want || force_direct() || stride != 1 || dbias || !da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+    return da_conv3_mfma_wgrad((const float*)in1, C1, (const float*)in2, C2, (const float*)dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, 1);
+}

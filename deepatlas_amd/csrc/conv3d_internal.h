@@ -24,12 +24,12 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
                       void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0, double* stats_partial = nullptr, int* stats_nparts = nullptr,
-                      const DaPro* pro = nullptr, const DaS2dFuse* s2f = nullptr);
+                      const DaPro* pro = nullptr, const DaS2dFuse* s2f = nullptr, int act_bf16 = 0);   // act_bf16: in1 / in2 / out1 / out2 are bf16 tensors (bf16 matrix mode only, else DA_ERR_UNSUPPORTED)
 
 bool da_conv3_mfma_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin = 0,
-                        const DaPro* pro = nullptr, const DaS2dFuse* s2f = nullptr);
+                        const DaPro* pro = nullptr, const DaS2dFuse* s2f = nullptr, int act_bf16 = 0);   // act_bf16: in1 / in2 / dy are bf16 tensors
 
 int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, const float* bias,
                         float* out1, int Cs1, float* out2, int Cs2,

@@ -86,15 +86,30 @@ __device__ __forceinline__ void da_split3(const float4 v, uint2& h, uint2& m, ui
 __device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// HB: the tensor is stored as bf16 (bf16 activation storage, common.h): a channel quad is 8 bytes and is widened to fp32 on arrival, so
+// everything behind the load (prologue arithmetic, the conversion into the bf16 LDS image -- exact for these values) is shared with the
+// fp32-storage kernels.  Only instantiated for the bf16 matrix mode (BF && !SP).
+template <bool HB> struct HbEl { static constexpr unsigned ES = HB ? 2u : 4u; };
+template <bool HB> __device__ __forceinline__ float4 da_buf_loadq(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    if constexpr (HB) {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+        return da_unpack_bf16x4(make_uint2(u[0], u[1]));
+    } else return da_buf_load4(r, byte_off);
+}
+// buffer descriptor over sample n of a tensor with `sample` elements per sample
+template <bool HB> __device__ __forceinline__ __amdgpu_buffer_rsrc_t da_rsrc_n(const float* base, long long n, long long sample) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + n * sample * (long long)HbEl<HB>::ES), 0, (unsigned)(sample * HbEl<HB>::ES), 0x00020000);
+}
 
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool HB = false>
 __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict__ src, int Cs, int choff,
                                            int n, int z0, int y0, int x0, int D, int H, int W, unsigned* vmask = nullptr) {
     constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
     constexpr int STEP = 256 / Q;                        // voxels per iteration
     constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
     const long long sample = (long long)D * H * W * Cs;
-    const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<HB>(src, n, sample);
     int idx = threadIdx.x + IT0 * 256;
     asm volatile("" : "+v"(idx));                       // keep the decomposition out of the persistent loop's invariants
     const int c4 = idx % Q; int hv = idx / Q;
@@ -105,8 +120,8 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
     for (int it = IT0; it < IT1; ++it) {
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
-        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * 4);
-        pre[it - IT0] = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * HbEl<HB>::ES);
+        pre[it - IT0] = da_buf_loadq<HB>(rs, inb ? off : 0xFFFFFFFFu);
         if (vmask) *vmask |= (inb ? 1u : 0u) << (it - IT0);
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
@@ -119,14 +134,14 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
 // S[q][r * cin + c] = X[2 q + r][c] (r = (rz, ry, rx) parity), and the loads go straight to X (cin channels, D0 x H0 x W0) -- the
 // space_to_depth2 copy pass and its 8 * cin-channel tensor disappear.  A chunk lies inside one parity (cin % CK == 0).
 struct S2dSrc { int cin, D0, H0, W0; };
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT>
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool HB = false>
 __device__ __forceinline__ void stage_load_s2d(float4* pre, const float* __restrict__ src, S2dSrc s2, int choff,
                                                int n, int z0, int y0, int x0, int D, int H, int W) {
     constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
     constexpr int STEP = 256 / Q;
     constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
     const long long sample = (long long)s2.D0 * s2.H0 * s2.W0 * s2.cin;
-    const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<HB>(src, n, sample);
     int idx = threadIdx.x + IT0 * 256;
     asm volatile("" : "+v"(idx));
     const int c4 = idx % Q; int hv = idx / Q;
@@ -141,8 +156,8 @@ __device__ __forceinline__ void stage_load_s2d(float4* pre, const float* __restr
         const int zs = 2 * z + rz, ys = 2 * y + ry, xs = 2 * x + rx;
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q)
                          && zs < s2.D0 && ys < s2.H0 && xs < s2.W0;
-        const unsigned off = (unsigned)((((zs * s2.H0 + ys) * s2.W0 + xs) * s2.cin + cofs) * 4);
-        pre[it - IT0] = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        const unsigned off = (unsigned)((((zs * s2.H0 + ys) * s2.W0 + xs) * s2.cin + cofs) * HbEl<HB>::ES);
+        pre[it - IT0] = da_buf_loadq<HB>(rs, inb ? off : 0xFFFFFFFFu);
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
         hy += SY + cx; const int cy = hy >= HY ? 1 : 0; hy -= cy * HY;
@@ -201,7 +216,7 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
 // The same staging loads, one at a time: a cursor that carries the incremental (hz, hy, hx) decomposition so the loads of the
 // NEXT work item can be spread over the K-steps of the current one.  `valid` = false turns every offset out of range (zeros, no
 // memory traffic), so the loads are issued on every item without a branch around them and hipcc's vmcnt bookkeeping stays exact.
-template <int CK, int HZ> struct StageCursor {
+template <int CK, int HZ, bool HB = false> struct StageCursor {
     __amdgpu_buffer_rsrc_t rs;
     int hv, hx, hy, hz, cofs;
     int z0, y0, x0, D, H, W, Cs;
@@ -210,7 +225,7 @@ template <int CK, int HZ> struct StageCursor {
                                          int D_, int H_, int W_, bool valid_) {
         constexpr int Q = StageGeom<CK, HZ>::Q;
         const long long sample = (long long)D_ * H_ * W_ * Cs_;
-        rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+        rs = da_rsrc_n<HB>(src, n, sample);
         int idx = threadIdx.x;
         asm volatile("" : "+v"(idx));
         const int c4 = idx % Q; hv = idx / Q;
@@ -225,8 +240,8 @@ template <int CK, int HZ> struct StageCursor {
         constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inb = valid && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
-        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * 4);
-        const float4 v = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * HbEl<HB>::ES);
+        const float4 v = da_buf_loadq<HB>(rs, inb ? off : 0xFFFFFFFFu);
         last_inb = inb;
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
@@ -275,6 +290,13 @@ template <int CK, int HZ> struct StageMap {
 };
 __device__ __forceinline__ void da_buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, byte_off, 0, 0);
+}
+template <bool HB> __device__ __forceinline__ void da_buf_storeq(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    if constexpr (HB) {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t u = {da_pack_bf16x2(v[0], v[1]), da_pack_bf16x2(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(u, r, byte_off, 0, 0);
+    } else da_buf_store4(r, byte_off, v);
 }
 template <bool B> struct BoolC { static constexpr bool value = B; };
 template <int V> struct IntC { static constexpr int value = V; };
@@ -362,8 +384,9 @@ struct FwdP {
 // dropped products are <= 2^-25 |a b| together, i.e. below the rounding of ONE fp32 multiply-add (tools/ubench/split_bf16.hip: the error
 // against double is smaller than that of the v_mfma_f32_16x16x4_f32 chain), at 6/16 of the matrix-pipe time.  LDS holds the three planes
 // (CK = 8: 3 x 17 KB, two workgroups per CU as before); fragments of the next two rows are read while the current two rows' 12 MFMAs issue.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores; HB: bf16 activation storage
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
+    static_assert(!HB || (BF && !SP && !DYN), "bf16 activation storage: bf16 matrix mode only");
     static_assert(S2F == 0 || MASKED, "fused space-to-depth addressing belongs to the tap-masked (stride-2) variants");
     // PAIR (split mode, one N-tile): two consecutive 8-channel chunks share every 64-byte sector of their input.  Staged one work item apart
     // the second one misses L2 (the launch turns its L2 over in about one item time): FETCH_SIZE 1.8x the algorithmic bytes.  With PAIR the
@@ -434,9 +457,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         int n, z0, y0, x0, ch;
         item_coords(item, n, z0, y0, x0, ch);
         const int cbase = ch * CK;
-        if constexpr (S2F == 1) stage_load_s2d<CK, HZ, 0, PRE>(pre, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
-        else if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
-        else stage_load<CK, HZ, 0, PRE>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W);
+        if constexpr (S2F == 1) stage_load_s2d<CK, HZ, 0, PRE, HB>(pre, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        else if (cbase < p.C1) stage_load<CK, HZ, 0, PRE, HB>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        else stage_load<CK, HZ, 0, PRE, HB>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W);
     };
     auto stage_rest = [&](int item) {                         // iterations [PRE, NIT): global -> LDS, in <= 3 batches
         if constexpr (PRE < NIT) {
@@ -448,14 +471,14 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             constexpr int R = NIT - PRE, B1 = PRE + (R + 2) / 3, B2 = PRE + 2 * ((R + 2) / 3) < NIT ? PRE + 2 * ((R + 2) / 3) : NIT;
             if constexpr (S2F == 1) {
                 {
-                    { float4 tmp[B1 - PRE]; stage_load_s2d<CK, HZ, PRE, B1>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
-                    if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load_s2d<CK, HZ, B1, B2>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
-                    if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load_s2d<CK, HZ, B2, NIT>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
+                    { float4 tmp[B1 - PRE]; stage_load_s2d<CK, HZ, PRE, B1, HB>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
+                    if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load_s2d<CK, HZ, B1, B2, HB>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
+                    if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load_s2d<CK, HZ, B2, NIT, HB>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
                 }
             } else {
-            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
-            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
-            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
+            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1, HB>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
+            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2, HB>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
+            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT, HB>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
             }
         }
     };
@@ -526,8 +549,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         int n, z0, y0, x0, ch;
         item_coords(0, n, z0, y0, x0, ch);
         const int cbase = ch * CK;
-        if (cbase < p.C1) stage_load<CK, HZ, 0, PRE>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W, &vm);
-        else stage_load<CK, HZ, 0, PRE>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W, &vm);
+        if (cbase < p.C1) stage_load<CK, HZ, 0, PRE, HB>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W, &vm);
+        else stage_load<CK, HZ, 0, PRE, HB>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W, &vm);
         load_pro(0);
         stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
     } else {
@@ -677,7 +700,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) bq[t % RB][nn][pl] = nb[t][nn][pl];
-        StageCursor<CK, HZ> cur;                              // next item's staging loads: cursor (fp32 / bf16 kernels) ...
+        StageCursor<CK, HZ, HB> cur;                          // next item's staging loads: cursor (fp32 / bf16 kernels) ...
         typename StageMap<CK, HZ>::Tile stile;                // ... or per-thread halo map (SP: registers to spare, ~60 % fewer instructions)
         __amdgpu_buffer_rsrc_t rsn;
         if constexpr (PRO) vm = 0;
@@ -866,23 +889,23 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                         const int rr = cb / p.s2out.cin, c0 = cb - rr * p.s2out.cin + 4 * a4;
                         const int zs = 2 * z + ((rr >> 2) & 1), xs = 2 * x + (rr & 1), ry = (rr >> 1) & 1;
                         const long long sample0 = (long long)p.s2out.D0 * p.s2out.H0 * p.s2out.W0 * p.s2out.cin;
-                        const __amdgpu_buffer_rsrc_t r0 = da_rsrc(p.out1 + (long long)n * sample0, (unsigned)(sample0 * sizeof(float)));
+                        const __amdgpu_buffer_rsrc_t r0 = da_rsrc_n<HB>(p.out1, n, sample0);
                         const bool ok0 = cok && zs < p.s2out.D0 && xs < p.s2out.W0;
 #pragma unroll
                         for (int r = 0; r < TY; ++r) {
                             const int ys = 2 * (y0 + r) + ry;
-                            const unsigned off = (unsigned)((((zs * p.s2out.H0 + ys) * p.s2out.W0 + xs) * p.s2out.cin + c0) * 4);
-                            da_buf_store4(r0, (ok0 && y0 + r < p.H && ys < p.s2out.H0) ? off : 0xFFFFFFFFu, acc[r][nn]);
+                            const unsigned off = (unsigned)((((zs * p.s2out.H0 + ys) * p.s2out.W0 + xs) * p.s2out.cin + c0) * HbEl<HB>::ES);
+                            da_buf_storeq<HB>(r0, (ok0 && y0 + r < p.H && ys < p.s2out.H0) ? off : 0xFFFFFFFFu, acc[r][nn]);
                         }
                     }
                 }
                 if constexpr (!scattered) {
                     const long long sample = (long long)p.D * p.H * p.W * Cd;
-                    const __amdgpu_buffer_rsrc_t ro = da_rsrc(dbase + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+                    const __amdgpu_buffer_rsrc_t ro = da_rsrc_n<HB>(dbase, n, sample);
 #pragma unroll
                     for (int r = 0; r < TY; ++r) {
-                        const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * Cd + cd) * 4);
-                        da_buf_store4(ro, (cok && y0 + r < p.H) ? off : 0xFFFFFFFFu, acc[r][nn]);
+                        const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * Cd + cd) * HbEl<HB>::ES);
+                        da_buf_storeq<HB>(ro, (cok && y0 + r < p.H) ? off : 0xFFFFFFFFu, acc[r][nn]);
                     }
                 }
             }
@@ -1184,9 +1207,10 @@ __global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx
 // SP (split mode, see conv3_mfma_fwd_kernel): x and dY are split exactly into three bf16 planes while they are staged; K = 32 = two
 // rows of 16 voxels per v_mfma_f32_16x16x32_bf16 (lane group g: row 2 rp + (g >> 1), voxels 8 (g & 1) .. + 7 = two transpose reads), six
 // products per (tap slot, N-tile, row pair); the fragments of the next two tap slots are read while the current two slots' MFMAs issue.
-template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets; PRO: input prologue (BN + act applied to x while staging)
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false, bool HB = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets; PRO: input prologue (BN + act applied to x while staging); HB: x and dY stored as bf16
 __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(!HB || (BF && !SP), "bf16 activation storage: bf16 matrix mode only");
     static_assert(!(BF && YS), "bf16 mode stages dY in channel quads");
     static_assert(!SP || (BF && !MASKED && CK == 8), "split mode: dense bf16 kernels on 8-channel chunks");
     constexpr int NP = SP ? 3 : 1;
@@ -1262,11 +1286,11 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     auto issue_loads = [&](int tile) {
         int n, z0, y0, x0;
         tile_coords(tile, n, z0, y0, x0);
-        if constexpr (PRO) { vmA = 0; stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W, &vmA); }
-        else if (MASKED && p.s2in.cin > 0) stage_load_s2d<CK, HZ>(preA, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
-        else stage_load<CK, HZ>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
+        if constexpr (PRO) { vmA = 0; stage_load<CK, HZ, 0, StageGeom<CK, HZ>::NIT, HB>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W, &vmA); }
+        else if (MASKED && p.s2in.cin > 0) stage_load_s2d<CK, HZ, 0, StageGeom<CK, HZ>::NIT, HB>(preA, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        else stage_load<CK, HZ, 0, StageGeom<CK, HZ>::NIT, HB>(preA, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W);
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
-        const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (long long)n * sampleY, (unsigned)(sampleY * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<HB>(p.dy, n, sampleY);
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             int idx = threadIdx.x + it * 256;
@@ -1275,9 +1299,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
             const int co = cg * CG + c4 * 4;
             const bool vin = idx < TVOX * QY && z < p.D && y < p.H && x < p.W;
-            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + co) * 4);
+            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + co) * HbEl<HB>::ES);
             if constexpr (!YS) {
-                preY[it] = da_buf_load4(ry, (vin && co < p.Cout) ? off : 0xFFFFFFFFu);
+                preY[it] = da_buf_loadq<HB>(ry, (vin && co < p.Cout) ? off : 0xFFFFFFFFu);
             } else {
                 float t[4];
 #pragma unroll
@@ -1904,10 +1928,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 3 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR>;
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR, HB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1964,12 +1988,13 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
                                const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                                int N, int D, int H, int W, int Cout, int stride, float slope,
                                void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f,
-                               int cout0, int CoutW);
+                               int cout0, int CoutW, bool hb);
 
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f, int act_bf16) {
+    if (act_bf16 && da_matrix_mode() != 1) return DA_ERR_UNSUPPORTED;          // bf16 activation storage goes with the bf16 matrix mode
     // Split mode, data gradient of a concat layer whose outputs are 32 + 16 channels (the 48 -> 16 decoder convolution: three N-tiles).  One
     // launch with one N-tile per workgroup stages dY three times; two launches -- two N-tiles sharing every dY fragment for the first output
     // tensor, one N-tile (paired staging) for the second -- stage it twice and write each output tensor from its own launch.
@@ -1977,20 +2002,20 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     if (!no2 && da_matrix_mode() == 2 && w_is_flipped_tr && s2d_cin == 0 && !stats_partial && !pro && Cs2 > 0 && Cs1 == 32 && Cs2 == 16 && Cout == 48 &&
         pick_ck(C1, C2) != 0) {
         int rc = conv3_mfma_fwd_impl(in1, C1, in2, C2, w_tio, 1, bias, out1, 32, nullptr, 0, N, D, H, W, 32, stride, slope, ws, ws_bytes, st, 0, nullptr, nullptr,
-                                     nullptr, nullptr, 0, Cout);
+                                     nullptr, nullptr, 0, Cout, false);
         if (rc) return rc;
         return conv3_mfma_fwd_impl(in1, C1, in2, C2, w_tio, 1, bias ? bias + 32 : nullptr, out2, 16, nullptr, 0, N, D, H, W, 16, stride, slope, ws, ws_bytes, st, 0,
-                                   nullptr, nullptr, nullptr, nullptr, 32, Cout);
+                                   nullptr, nullptr, nullptr, nullptr, 32, Cout, false);
     }
     return conv3_mfma_fwd_impl(in1, C1, in2, C2, w_tio, w_is_flipped_tr, bias, out1, Cs1, out2, Cs2, N, D, H, W, Cout, stride, slope, ws, ws_bytes, st, s2d_cin,
-                               stats_partial, stats_nparts, pro, s2f, 0, Cout);
+                               stats_partial, stats_nparts, pro, s2f, 0, Cout, act_bf16 != 0);
 }
 
 static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                                const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                                int N, int D, int H, int W, int Cout, int stride, float slope,
                                void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f,
-                               int cout0, int CoutW) {
+                               int cout0, int CoutW, bool hb) {
     (void)stride;
     const int Cin = C1 + C2;
     int CK = pick_ck(C1, C2);
@@ -2093,20 +2118,20 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     }
     if (stats_partial && p.maskmode == 0 && (CK == 16 || CK == 8) && NREP <= 2) {
         if (stats_nparts) *stats_nparts = p.nblocks;
-#define DA_ST_CASE(ck, nr) if (CK == ck && NREP == nr) return pro ? (bf ? launch_fwd_mfma<ck, nr, false, true, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true, false, true>(p, gy, st)) \
-                                                                  : (bf ? launch_fwd_mfma<ck, nr, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true>(p, gy, st))
+#define DA_ST_CASE(ck, nr) if (CK == ck && NREP == nr) return pro ? (hb ? launch_fwd_mfma<ck, nr, false, true, true, true, false, false, 0, false, true>(p, gy, st) : bf ? launch_fwd_mfma<ck, nr, false, true, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true, false, true>(p, gy, st)) \
+                                                                  : (hb ? launch_fwd_mfma<ck, nr, false, true, true, false, false, false, 0, false, true>(p, gy, st) : bf ? launch_fwd_mfma<ck, nr, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, true>(p, gy, st))
         DA_ST_CASE(16, 1); DA_ST_CASE(16, 2); DA_ST_CASE(8, 1); DA_ST_CASE(8, 2);
 #undef DA_ST_CASE
     }
     if (pro) {
-#define DA_PRO_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, false, false, true>(p, gy, st)
+#define DA_PRO_CASE(ck, nr) if (CK == ck && NREP == nr) return hb ? launch_fwd_mfma<ck, nr, false, false, true, true, false, false, 0, false, true>(p, gy, st) : bf ? launch_fwd_mfma<ck, nr, false, false, true, true>(p, gy, st) : launch_fwd_mfma<ck, nr, false, false, false, true>(p, gy, st)
         DA_PRO_CASE(16, 1); DA_PRO_CASE(16, 2); DA_PRO_CASE(8, 1); DA_PRO_CASE(8, 2);
 #undef DA_PRO_CASE
         return DA_ERR_UNSUPPORTED;
     }
     if (p.maskmode != 0) {
         const int s2f = p.s2in.cin > 0 ? 1 : (p.s2out.cin > 0 ? 2 : 0);
-#define DA_M_CASE(nr, f) if (NREP == nr && s2f == f) return bf ? launch_fwd_mfma<16, nr, true, false, true, false, false, false, f>(p, gy, st) : launch_fwd_mfma<16, nr, true, false, false, false, false, false, f>(p, gy, st)
+#define DA_M_CASE(nr, f) if (NREP == nr && s2f == f) return hb ? launch_fwd_mfma<16, nr, true, false, true, false, false, false, f, false, true>(p, gy, st) : bf ? launch_fwd_mfma<16, nr, true, false, true, false, false, false, f>(p, gy, st) : launch_fwd_mfma<16, nr, true, false, false, false, false, false, f>(p, gy, st)
         DA_M_CASE(1, 0); DA_M_CASE(1, 1); DA_M_CASE(1, 2); DA_M_CASE(2, 0); DA_M_CASE(2, 1); DA_M_CASE(2, 2);
 #undef DA_M_CASE
         return DA_ERR_UNSUPPORTED;
@@ -2117,6 +2142,9 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
 #undef DA_DYN_CASE
     }
 #define DA_FWD_CASE(ck, nr) if (CK == ck && NREP == nr) return bf ? launch_fwd_mfma<ck, nr, false, false, true>(p, gy, st) : launch_fwd_mfma<ck, nr>(p, gy, st)
+#define DA_FWD_CASE_HB(ck, nr) if (hb && CK == ck && NREP == nr) return launch_fwd_mfma<ck, nr, false, false, true, false, false, false, 0, false, true>(p, gy, st)
+    DA_FWD_CASE_HB(16, 1); DA_FWD_CASE_HB(16, 2); DA_FWD_CASE_HB(8, 1); DA_FWD_CASE_HB(8, 2);      // (bf16 mode: at most two N-tiles)
+#undef DA_FWD_CASE_HB
     DA_FWD_CASE(16, 1); DA_FWD_CASE(16, 2); DA_FWD_CASE(16, 3);          // pick_nrep never asks for more than 3 N-tiles
     DA_FWD_CASE(8, 1); DA_FWD_CASE(8, 2); DA_FWD_CASE(8, 3);
 #undef DA_FWD_CASE
@@ -2228,10 +2256,10 @@ __global__ void swapped_wgrad_place_kernel(const float* __restrict__ tmp, float*
     }
 }
 
-template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false>
+template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false, bool HB = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4) * (SP ? 3 : 1);
-    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF, PRO, SP>;
+    auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF, PRO, SP, HB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -2260,7 +2288,11 @@ static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
 static bool split_wgrad_v1() { static int v = -1; if (v < 0) { const char* e = getenv("DA_SPLIT_WGRAD_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
 
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f) {
+                        int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f, int act_bf16) {
+    const bool hb = act_bf16 != 0;
+    // bf16 activation storage: the matrix-core kernels of the bf16 matrix mode only (few-channel layers: the caller converts)
+    if (hb && (da_matrix_mode() != 1 || pick_ck(C1, C2) == 0 || Cout % 4 != 0 || Cout <= 4 || smallcin_ok(C1, C2, Cout, stride) ||
+               da_conv3_fewcin_wgrad_supported(C1, C2, Cout, stride))) return DA_ERR_UNSUPPORTED;
     if (pro && (stride != 1 || s2d_cin > 0 || C1 + C2 > kProMaxC || pick_ck(C1, C2) == 0 || Cout % 4 != 0 || Cout <= 4)) return DA_ERR_UNSUPPORTED;
     if (!pro && s2d_cin == 0 && da_conv3_fewcin_wgrad_supported(C1, C2, Cout, stride)) {
         static int off = -1; if (off < 0) { const char* e = getenv("DA_NO_FLOW_WGRAD"); off = (e && atoi(e)) ? 1 : 0; }
@@ -2353,7 +2385,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         int rcp = DA_ERR_UNSUPPORTED;
         if (split) rcp = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, true, true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
         else
-#define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
+#define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
         { DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2); }
 #undef DA_WP_CASE
         if (rcp) return rcp;
@@ -2363,15 +2395,16 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (split) rc = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, false, true>(p, q, st) : launch_split_wgrad<false>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
-        if (bf) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true>(p, q, st);
+        if (hb) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true, false, false, true>(p, q, st);
+        else if (bf) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true>(p, q, st);
         else rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true>(p, q, st);
     }
     else if (Cout % 4 != 0 && q.CK == 16) rc = launch_wgrad_mfma<16, 1, true>(p, q, st);
     else if (Cout % 4 != 0 && q.CK == 8) rc = launch_wgrad_mfma<8, 1, true>(p, q, st);
-    else if (q.CK == 16 && q.NREP == 1) rc = bf ? launch_wgrad_mfma<16, 1, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 1>(p, q, st);
-    else if (q.CK == 16 && q.NREP == 2) rc = bf ? launch_wgrad_mfma<16, 2, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2>(p, q, st);
-    else if (q.CK == 8 && q.NREP == 1) rc = bf ? launch_wgrad_mfma<8, 1, false, false, true>(p, q, st) : launch_wgrad_mfma<8, 1>(p, q, st);
-    else if (q.CK == 8 && q.NREP == 2) rc = bf ? launch_wgrad_mfma<8, 2, false, false, true>(p, q, st) : launch_wgrad_mfma<8, 2>(p, q, st);
+    else if (q.CK == 16 && q.NREP == 1) rc = hb ? launch_wgrad_mfma<16, 1, false, false, true, false, false, true>(p, q, st) : bf ? launch_wgrad_mfma<16, 1, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 1>(p, q, st);
+    else if (q.CK == 16 && q.NREP == 2) rc = hb ? launch_wgrad_mfma<16, 2, false, false, true, false, false, true>(p, q, st) : bf ? launch_wgrad_mfma<16, 2, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2>(p, q, st);
+    else if (q.CK == 8 && q.NREP == 1) rc = hb ? launch_wgrad_mfma<8, 1, false, false, true, false, false, true>(p, q, st) : bf ? launch_wgrad_mfma<8, 1, false, false, true>(p, q, st) : launch_wgrad_mfma<8, 1>(p, q, st);
+    else if (q.CK == 8 && q.NREP == 2) rc = hb ? launch_wgrad_mfma<8, 2, false, false, true, false, false, true>(p, q, st) : bf ? launch_wgrad_mfma<8, 2, false, false, true>(p, q, st) : launch_wgrad_mfma<8, 2>(p, q, st);
     if (rc) return rc;
     { const int rc2 = da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st); if (rc2) return rc2; }
     return 0;

@@ -220,3 +220,33 @@ extern "C" int da_synth_volume(float* img, unsigned char* labels, int N, int D, 
     DA_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 activation storage (common.h): conversions at the network boundary and around kernels that have no bf16 twin for a shape.
+// fp32 -> bf16 rounds to nearest-even (the one rounding a stored activation gets); bf16 -> fp32 is exact.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ x, da_bf16* __restrict__ y, long long n) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) da_stq(y, i, da_ldq(x, i));
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) da_st1(y, i, x[i]);
+}
+__global__ void cast_bf16_to_f32_kernel(const da_bf16* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) da_stq(y, i, da_ldq(x, i));
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = da_ld1(x, i);
+}
+}  // namespace
+
+extern "C" int da_cast_f32_to_bf16(const float* x, void* y, long long numel, void* stream) {
+    if (!x || !y || numel <= 0) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(da_grid(numel / 4 + 1, 256)), dim3(256), 0, da_stream(stream), x, (da_bf16*)y, numel);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int da_cast_bf16_to_f32(const void* x, float* y, long long numel, void* stream) {
+    if (!x || !y || numel <= 0) return DA_ERR_BADARG;
+    hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(da_grid(numel / 4 + 1, 256)), dim3(256), 0, da_stream(stream), (const da_bf16*)x, y, numel);
+    DA_LAUNCH_CHECK();
+    return 0;
+}

@@ -398,3 +398,93 @@ extern "C" int da_conv_k2s2_wgrad(const float* x, const float* dy, float* dw_toi
     if (dbias) return da_colsum(dy, (long long)N * D * H * W, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 activation storage (common.h).  Transposed conv k2 s2: input, output and their gradients are bf16.  1x1x1 head: its INPUT (and the
+// gradient with respect to it) is bf16, the logits and their gradient stay fp32 (they are the losses' operands).  Matrix-core shapes only
+// (channel counts in multiples of 16); anything else returns DA_ERR_UNSUPPORTED and the caller converts around the fp32 entry.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int da_deconv_k2s2_fwd_bf16(const void* in, const float* w_tio, const float* bias, void* out,
+                                       int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !w_tio || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm((const float*)in, w_tio, 0, bias, (float*)out, (long long)N * D * H * W, D, H, W, Cin, Cout, 8, 1, 0, ws, ws_bytes, da_stream(stream),
+                      nullptr, nullptr, nullptr, -1.f, 1, 1);
+}
+extern "C" int da_deconv_k2s2_fwd_bnstats_bf16(const void* in, const float* w_tio, const float* bias, void* out,
+                                               int N, int D, int H, int W, int Cin, int Cout,
+                                               double* stats_partial, int stats_capacity, int* stats_nparts,
+                                               void* ws, size_t ws_bytes, void* stream) {
+    if (stats_nparts) *stats_nparts = 0;
+    if (!in || !w_tio || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    const long long nvox = (long long)N * D * H * W, nblk = da_cdiv(nvox, 256);
+    const bool stats = stats_partial && stats_nparts && nblk <= stats_capacity;
+    const int rc = da_pw_gemm((const float*)in, w_tio, 0, bias, (float*)out, nvox, D, H, W, Cin, Cout, 8, 1, 0, ws, ws_bytes, da_stream(stream),
+                              stats ? stats_partial : nullptr, nullptr, nullptr, -1.f, 1, 1);
+    if (rc == 0 && stats) *stats_nparts = (int)nblk;
+    return rc;
+}
+extern "C" int da_deconv_k2s2_dgrad_bf16(const void* dy, const float* w_tio, void* dx,
+                                         int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w_tio || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cout, Cin)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm((const float*)dy, w_tio, 1, nullptr, (float*)dx, (long long)N * D * H * W, D, H, W, Cout, Cin, 8, 1, 1, ws, ws_bytes, da_stream(stream),
+                      nullptr, nullptr, nullptr, -1.f, 1, 1);
+}
+extern "C" int da_deconv_k2s2_wgrad_bf16(const void* in, const void* dy, float* dw_tio, float* dbias,
+                                         int N, int D, int H, int W, int Cin, int Cout,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !dy || !dw_tio || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    const int rc = da_pw_wgrad((const float*)in, (const float*)dy, dw_tio, (long long)N * D * H * W, D, H, W, Cin, Cout, 8, 1, ws, cs_off, da_stream(stream),
+                               nullptr, nullptr, -1.f, 1, 1);
+    if (rc) return rc;
+    if (dbias) return da_colsum_bf16(dy, (long long)N * D * H * W * 8, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
+    return 0;
+}
+
+extern "C" int da_conv1x1_fwd_bf16(const void* in, const float* w_io, const float* bias, float* out,
+                                   long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !w_io || !out || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm((const float*)in, w_io, 0, bias, out, M, 1, 1, 1, Cin, Cout, 1, 0, 0, ws, ws_bytes, da_stream(stream), nullptr, nullptr, nullptr, -1.f, 1, 0);
+}
+extern "C" int da_conv1x1_fwd_pro_bf16(const void* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                       const float* w_io, const float* bias, float* out,
+                                       long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !pro_scale || !pro_shift || !w_io || !out || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm((const float*)in, w_io, 0, bias, out, M, 1, 1, 1, Cin, Cout, 1, 0, 0, ws, ws_bytes, da_stream(stream), nullptr, pro_scale, pro_shift, pro_slope, 1, 0);
+}
+extern "C" int da_conv1x1_dgrad_bf16(const float* dy, const float* w_io, void* dx, long long M, int Cin, int Cout,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w_io || !dx || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cout, Cin)) return DA_ERR_UNSUPPORTED;
+    return da_pw_gemm(dy, w_io, 1, nullptr, (float*)dx, M, 1, 1, 1, Cout, Cin, 1, 0, 1, ws, ws_bytes, da_stream(stream), nullptr, nullptr, nullptr, -1.f, 0, 1);
+}
+extern "C" int da_conv1x1_wgrad_bf16(const void* in, const float* dy, float* dw_io, float* dbias,
+                                     long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !dy || !dw_io || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv1x1_wgrad_ws_bytes(M, Cin, Cout)) return DA_ERR_WS_SMALL;
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    const int rc = da_pw_wgrad((const float*)in, dy, dw_io, M, 1, 1, 1, Cin, Cout, 1, 0, ws, cs_off, da_stream(stream), nullptr, nullptr, -1.f, 1, 0);
+    if (rc) return rc;
+    if (dbias) return da_colsum(dy, M, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
+    return 0;
+}
+extern "C" int da_conv1x1_wgrad_pro_bf16(const void* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                         const float* dy, float* dw_io, float* dbias,
+                                         long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !pro_scale || !pro_shift || !dy || !dw_io || M <= 0 || Cin <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (!da_pw_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv1x1_wgrad_ws_bytes(M, Cin, Cout)) return DA_ERR_WS_SMALL;
+    const size_t cs_off = ((ws_bytes - da_bn_ws_bytes(0, Cout)) / 256) * 256;
+    const int rc = da_pw_wgrad((const float*)in, dy, dw_io, M, 1, 1, 1, Cin, Cout, 1, 0, ws, cs_off, da_stream(stream), pro_scale, pro_shift, pro_slope, 1, 0);
+    if (rc) return rc;
+    if (dbias) return da_colsum(dy, M, Cout, dbias, (char*)ws + cs_off, da_bn_ws_bytes(0, Cout), stream);
+    return 0;
+}

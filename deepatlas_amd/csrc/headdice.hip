@@ -53,8 +53,8 @@ __global__ void hd_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // the voxel's label is one load per tile, and in the backward pass the gradient with respect to the logits is already in the B-operand
 // layout of the data-gradient GEMM (no transpose through LDS), whose result comes out as 4 consecutive input channels per lane
 // (16-byte stores).  Returns probabilities in acc (0 for voxels past the end).
-template <int KC, int NT>
-__device__ __forceinline__ void hd_probs(const HdP& p, const float* __restrict__ xs, long long vbase, int i, int g,
+template <int KC, int NT, typename T = float>
+__device__ __forceinline__ void hd_probs(const HdP& p, const T* __restrict__ xs, long long vbase, int i, int g,
                                          const float4 (&wf)[NT][KC], const float (&bv)[NT][4], float4 (&a)[MT][KC], f32x4 (&acc)[MT][NT]) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -62,7 +62,7 @@ __device__ __forceinline__ void hd_probs(const HdP& p, const float* __restrict__
         const bool ok = vox < p.V;
 #pragma unroll
         for (int c = 0; c < KC; ++c)
-            a[t][c] = ok ? *reinterpret_cast<const float4*>(xs + vox * p.K + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[t][c] = ok ? da_ldq(xs, (vox * p.K + 16 * c + 4 * g) >> 2) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (p.ps) {
 #pragma unroll
@@ -125,13 +125,13 @@ __device__ __forceinline__ void hd_bias(const HdP& p, int g, float (&bv)[NT][4])
         for (int reg = 0; reg < 4; ++reg) bv[n][reg] = p.bias ? p.bias[16 * n + 4 * g + reg] : 0.f;
 }
 
-template <int KC, int NT>
+template <int KC, int NT, typename T = float>     // T: storage type of x / dx (da_bf16 = bf16 activation storage, common.h)
 __global__ void __launch_bounds__(256) head_dice_fwd_kernel(HdP p) {
     __shared__ double sred[4][3][NT * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int n_s = blockIdx.y;
-    const float* xs = p.x + (long long)n_s * p.V * p.K;
+    const T* xs = reinterpret_cast<const T*>(p.x) + (long long)n_s * p.V * p.K;
     const long long lbase = (long long)n_s * p.V;
     float4 wf[NT][KC]; float bv[NT][4];
     hd_bias<NT>(p, g, bv);
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) head_dice_fwd_kernel(HdP p) {
     for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
         const long long vbase = cb * 256 + wave * 64;
         float4 a[MT][KC]; f32x4 acc[MT][NT];
-        hd_probs<KC, NT>(p, xs, vbase, i, g, wf, bv, a, acc);
+        hd_probs<KC, NT, T>(p, xs, vbase, i, g, wf, bv, a, acc);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const long long vox = vbase + t * 16 + i;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) head_dice_fwd_kernel(HdP p) {
     }
 }
 
-template <int KC, int NT>
+template <int KC, int NT, typename T = float>
 __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
     constexpr int K = KC * 16, C = NT * 16, LDX = K + 4, LDD = C + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -217,13 +217,13 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
     for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
         const int n_s = (int)(cb / chunks_per_sample);
         const long long vbase = (cb - (long long)n_s * chunks_per_sample) * 256 + wave * 64;
-        const float* xs = p.x + (long long)n_s * p.V * p.K;
-        float* dxs = p.dx + (long long)n_s * p.V * p.K;
+        const T* xs = reinterpret_cast<const T*>(p.x) + (long long)n_s * p.V * p.K;
+        T* dxs = reinterpret_cast<T*>(p.dx) + (long long)n_s * p.V * p.K;
         const long long lbase = (long long)n_s * p.V;
         const float* c0 = p.coef + (size_t)n_s * p.C;                  // coef[0][n][c]
         const float* c1 = p.coef + (size_t)(p.N + n_s) * p.C;          // coef[1][n][c]
         float4 a[MT][KC]; f32x4 acc[MT][NT];
-        hd_probs<KC, NT>(p, xs, vbase, i, g, wf, bv, a, acc);
+        hd_probs<KC, NT, T>(p, xs, vbase, i, g, wf, bv, a, acc);
         // activated input tile -> LDS [voxel][cin] (A operand of the weight-gradient GEMM, read transposed)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
             if (vox < p.V) {
 #pragma unroll
                 for (int c = 0; c < KC; ++c)          // lane (voxel i, group g) holds input channels 16c + 4g .. + 3
-                    *reinterpret_cast<float4*>(dxs + vox * p.K + 16 * c + 4 * g) = make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]);
+                    da_stq(dxs, (vox * p.K + 16 * c + 4 * g) >> 2, make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]));
             }
         }
         __syncthreads();
@@ -334,16 +334,16 @@ extern "C" size_t da_head_dice_ws_bytes(int N, long long V, int Cin, int C) {
     return pack + (fwd > bwd ? fwd : bwd);
 }
 
-template <int KC, int NT>
+template <int KC, int NT, typename T>
 static int hd_launch_fwd(const HdP& p, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((head_dice_fwd_kernel<KC, NT>), dim3(nblocks, p.N), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((head_dice_fwd_kernel<KC, NT, T>), dim3(nblocks, p.N), dim3(256), 0, st, p);
     DA_LAUNCH_CHECK();
     return 0;
 }
-template <int KC, int NT>
+template <int KC, int NT, typename T>
 static int hd_launch_bwd(const HdP& p, int nblocks, hipStream_t st) {
     const size_t shm = (size_t)4 * (64 * (KC * 16 + 4) + 64 * (NT * 16 + 4)) * sizeof(float);
-    auto kern = head_dice_bwd_kernel<KC, NT>;
+    auto kern = head_dice_bwd_kernel<KC, NT, T>;
     static bool attr_set = false;
     if (!attr_set && shm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -355,10 +355,11 @@ static int hd_launch_bwd(const HdP& p, int nblocks, hipStream_t st) {
     return 0;
 }
 
-extern "C" int da_head_dice_fwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
-                                const float* w_io, const float* bias, const void* labels, int label_bytes,
-                                int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
-                                float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+static int head_dice_fwd_t(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                           const float* w_io, const float* bias, const void* labels, int label_bytes,
+                           int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
+                           float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w_io || !labels || !loss || !coef || N <= 0 || N > 64 || V <= 0 || (label_bytes != 1 && label_bytes != 8) ||
         ((pro_scale == nullptr) != (pro_shift == nullptr))) return DA_ERR_BADARG;
     if (!hd_shape_ok(Cin, C) || (pro_scale && pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
@@ -376,18 +377,31 @@ extern "C" int da_head_dice_fwd(const float* x, const float* pro_scale, const fl
     p.wp_fwd = wp; p.wp_bwd = nullptr; p.bias = bias; p.labels = labels; p.label_bytes = label_bytes;
     p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = partial; p.coef = nullptr; p.dloss = nullptr; p.dx = nullptr; p.wpartial = nullptr;
     int rc;
-    if (Cin == 16 && C == 32) rc = hd_launch_fwd<1, 2>(p, nblocks, st);
-    else if (Cin == 16 && C == 16) rc = hd_launch_fwd<1, 1>(p, nblocks, st);
-    else if (Cin == 64 && C == 32) rc = hd_launch_fwd<4, 2>(p, nblocks, st);
-    else rc = hd_launch_fwd<4, 1>(p, nblocks, st);
+    if (Cin == 16 && C == 32) rc = hd_launch_fwd<1, 2, T>(p, nblocks, st);
+    else if (Cin == 16 && C == 16) rc = hd_launch_fwd<1, 1, T>(p, nblocks, st);
+    else if (Cin == 64 && C == 32) rc = hd_launch_fwd<4, 2, T>(p, nblocks, st);
+    else rc = hd_launch_fwd<4, 1, T>(p, nblocks, st);
     if (rc) return rc;
     return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
 }
-
-extern "C" int da_head_dice_bwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+extern "C" int da_head_dice_fwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                                 const float* w_io, const float* bias, const void* labels, int label_bytes,
-                                const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
-                                int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
+                                int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
+                                float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+    return head_dice_fwd_t<float>(x, pro_scale, pro_shift, pro_slope, w_io, bias, labels, label_bytes, N, V, Cin, C, weight_type, no_bg, eps, loss, coef, ws, ws_bytes, stream);
+}
+extern "C" int da_head_dice_fwd_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                     const float* w_io, const float* bias, const void* labels, int label_bytes,
+                                     int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
+                                     float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+    return head_dice_fwd_t<da_bf16>((const float*)x, pro_scale, pro_shift, pro_slope, w_io, bias, labels, label_bytes, N, V, Cin, C, weight_type, no_bg, eps, loss, coef, ws, ws_bytes, stream);
+}
+
+template <typename T>
+static int head_dice_bwd_t(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                           const float* w_io, const float* bias, const void* labels, int label_bytes,
+                           const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
+                           int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w_io || !labels || !coef || !dloss || !dx || !dw_io || N <= 0 || V <= 0 || (label_bytes != 1 && label_bytes != 8) ||
         ((pro_scale == nullptr) != (pro_shift == nullptr))) return DA_ERR_BADARG;
     if (!hd_shape_ok(Cin, C) || (pro_scale && pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
@@ -408,10 +422,10 @@ extern "C" int da_head_dice_bwd(const float* x, const float* pro_scale, const fl
     p.wp_fwd = wpf; p.wp_bwd = wpb; p.bias = bias; p.labels = labels; p.label_bytes = label_bytes;
     p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = nullptr; p.coef = coef; p.dloss = dloss; p.dx = dx; p.wpartial = wpartial;
     int rc;
-    if (Cin == 16 && C == 32) rc = hd_launch_bwd<1, 2>(p, nblocks, st);
-    else if (Cin == 16 && C == 16) rc = hd_launch_bwd<1, 1>(p, nblocks, st);
-    else if (Cin == 64 && C == 32) rc = hd_launch_bwd<4, 2>(p, nblocks, st);
-    else rc = hd_launch_bwd<4, 1>(p, nblocks, st);
+    if (Cin == 16 && C == 32) rc = hd_launch_bwd<1, 2, T>(p, nblocks, st);
+    else if (Cin == 16 && C == 16) rc = hd_launch_bwd<1, 1, T>(p, nblocks, st);
+    else if (Cin == 64 && C == 32) rc = hd_launch_bwd<4, 2, T>(p, nblocks, st);
+    else rc = hd_launch_bwd<4, 1, T>(p, nblocks, st);
     if (rc) return rc;
     rc = da_reduce_partials(wpartial, nblocks, O, folded, st);
     if (rc) return rc;
@@ -419,4 +433,16 @@ extern "C" int da_head_dice_bwd(const float* x, const float* pro_scale, const fl
     if (e != hipSuccess) return (int)e;
     if (dbias) { e = hipMemcpyAsync(dbias, folded + (size_t)Cin * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
     return 0;
+}
+extern "C" int da_head_dice_bwd(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                const float* w_io, const float* bias, const void* labels, int label_bytes,
+                                const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
+                                int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
+    return head_dice_bwd_t<float>(x, pro_scale, pro_shift, pro_slope, w_io, bias, labels, label_bytes, coef, dloss, dx, dw_io, dbias, N, V, Cin, C, ws, ws_bytes, stream);
+}
+extern "C" int da_head_dice_bwd_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                                     const float* w_io, const float* bias, const void* labels, int label_bytes,
+                                     const float* coef, const float* dloss, void* dx, float* dw_io, float* dbias,
+                                     int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
+    return head_dice_bwd_t<da_bf16>((const float*)x, pro_scale, pro_shift, pro_slope, w_io, bias, labels, label_bytes, coef, dloss, (float*)dx, dw_io, dbias, N, V, Cin, C, ws, ws_bytes, stream);
 }

@@ -26,8 +26,8 @@ static RowPlan plan_rows(long long M, int C) {
 }
 
 // partial[b][k][C] doubles, k < NK.  MODE 0: (sum x, sum x^2); MODE 1: (sum x); MODE 2: BN backward sums
-template <int VEC, int MODE>
-__global__ void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int VEC, int MODE, typename T = float>
+__global__ void col_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                    const float* __restrict__ scale, const float* __restrict__ shift, float slope,
                                    long long M, int C, long long rows_per_block, double* __restrict__ partial) {
@@ -48,15 +48,15 @@ __global__ void col_partial_kernel(const float* __restrict__ x, const float* __r
     for (long long row = r0 + r; row < r1; row += rpi) {
         float xv[VEC], gv[VEC];
         if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(x + row * C + q * 4);
+            const float4 t = da_ldq(x, row * cq + q);
             xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             if (MODE == 2) {
-                const float4 g = *reinterpret_cast<const float4*>(dy + row * C + q * 4);
+                const float4 g = da_ldq(dy, row * cq + q);
                 gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
             }
         } else {
-            xv[0] = x[row * C + q];
-            if (MODE == 2) gv[0] = dy[row * C + q];
+            xv[0] = da_ld1(x, row * C + q);
+            if (MODE == 2) gv[0] = da_ld1(dy, row * C + q);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -118,9 +118,9 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     mean[c] = rm[c]; rstd[c] = rs; scale[c] = g * rs; shift[c] = b - rm[c] * g * rs;
 }
 
-template <int VEC>
-__global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, float slope, float* __restrict__ y,
+template <int VEC, typename T = float>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float slope, T* __restrict__ y,
                                   long long nvec, int cq) {
     // cq divides the block size for every channel count on the path (C/4 in {1,2,4,8,16}), so a thread always sees
     // the same channel quad: its constants are loaded once into registers
@@ -132,14 +132,14 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __re
     for (long long i = i0; i < nvec; i += stride) {
         if (VEC == 4) {
             if (!fixed_q) { const int q = (int)(i % cq); sc = reinterpret_cast<const float4*>(scale)[q]; sf = reinterpret_cast<const float4*>(shift)[q]; }
-            const float4 t = reinterpret_cast<const float4*>(x)[i];
+            const float4 t = da_ldq(x, i);
             float4 o;
             o.x = da_act(t.x * sc.x + sf.x, slope); o.y = da_act(t.y * sc.y + sf.y, slope);
             o.z = da_act(t.z * sc.z + sf.z, slope); o.w = da_act(t.w * sc.w + sf.w, slope);
-            reinterpret_cast<float4*>(y)[i] = o;
+            da_stq(y, i, o);
         } else {
             const int q = (int)(i % cq);
-            y[i] = da_act(x[i] * scale[q] + shift[q], slope);
+            da_st1(y, i, da_act(da_ld1(x, i) * scale[q] + shift[q], slope));
         }
     }
 }
@@ -158,12 +158,12 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
     cm[C + c] = (float)(s2 / (double)M);
 }
 
-template <int VEC>
-__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int VEC, typename T = float>
+__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ cm, float slope, int train,
-                                        float* __restrict__ dx, long long nvec, int cq, int C, double* __restrict__ dxsum_partial) {
+                                        T* __restrict__ dx, long long nvec, int cq, int C, double* __restrict__ dxsum_partial) {
     // Three 16-byte streams (dy, x -> dx).  The six per-channel constants of this thread's channel quad are hoisted
     // into registers (the grid stride is a multiple of cq, so the quad never changes); UNR load pairs in flight.
     constexpr int UNR = (VEC == 4) ? 2 : 1;
@@ -189,11 +189,11 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
             const long long i = i0 + u * stride;
             if (i < nvec) {
                 if (VEC == 4) {
-                    const float4 t = reinterpret_cast<const float4*>(x)[i];
-                    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+                    const float4 t = da_ldq(x, i);
+                    const float4 g = da_ldq(dy, i);
                     xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
                     gv[u][0] = g.x; gv[u][1] = g.y; gv[u][2] = g.z; gv[u][3] = g.w;
-                } else { xv[u][0] = x[i]; gv[u][0] = dy[i]; }
+                } else { xv[u][0] = da_ld1(x, i); gv[u][0] = da_ld1(dy, i); }
             }
         }
 #pragma unroll
@@ -213,8 +213,8 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
                     o[j] = k_sc[j] * dz;
                 }
             }
-            if (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
-            else dx[i] = o[0];
+            if (VEC == 4) da_stq(dx, i, make_float4(o[0], o[1], o[2], o[3]));
+            else da_st1(dx, i, o[0]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) colacc[j] += o[j];
         }
@@ -237,28 +237,29 @@ __global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const floa
     }
 }
 
-__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float slope,
-                               float* __restrict__ dx, long long n) {
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, float slope,
+                               T* __restrict__ dx, long long n) {
     const long long n4 = n / 4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const float4 g = reinterpret_cast<const float4*>(dy)[i];
-        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        const float4 g = da_ldq(dy, i);
+        const float4 v = da_ldq(y, i);
         float4 o;
         o.x = g.x * (v.x > 0.f ? 1.f : slope); o.y = g.y * (v.y > 0.f ? 1.f : slope);
         o.z = g.z * (v.z > 0.f ? 1.f : slope); o.w = g.w * (v.w > 0.f ? 1.f : slope);
-        reinterpret_cast<float4*>(dx)[i] = o;
+        da_stq(dx, i, o);
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        dx[i] = dy[i] * (y[i] > 0.f ? 1.f : slope);
+        da_st1(dx, i, da_ld1(dy, i) * (da_ld1(y, i) > 0.f ? 1.f : slope));
 }
 
 // Backward of a conv block WITHOUT BatchNorm (modules.convBlock, the registration net): dx = (g1 [+ g2]) * act'(y) and, in the same
 // pass, the per-channel column sums of dx = the convolution's bias gradient.  g2 is the second incoming gradient when the block's
 // output has two consumers (skip connection): the sum autograd would form in its own pass happens here.  Row-blocked like
 // col_partial_kernel: a thread keeps one channel quad, per-thread fp32 sums -> per-block doubles -> colsum_finalize_kernel.
-template <int VEC>
-__global__ void act_bwd_add_dbias_kernel(const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ y,
-                                         float slope, float* __restrict__ dx, long long M, int C, long long rows_per_block,
+template <int VEC, typename T = float>
+__global__ void act_bwd_add_dbias_kernel(const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ y,
+                                         float slope, T* __restrict__ dx, long long M, int C, long long rows_per_block,
                                          double* __restrict__ partial) {
     extern __shared__ double sh[];   // [rpi][C]
     const int cq = C / VEC;
@@ -272,19 +273,19 @@ __global__ void act_bwd_add_dbias_kernel(const float* __restrict__ g1, const flo
     for (long long row = r0 + r; row < r1; row += rpi) {
         float gv[VEC], yv[VEC];
         if (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(g1 + row * C + q * 4);
-            if (g2) { const float4 u = *reinterpret_cast<const float4*>(g2 + row * C + q * 4); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            float4 t = da_ldq(g1, row * cq + q);
+            if (g2) { const float4 u = da_ldq(g2, row * cq + q); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
             gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
-            if (y) { const float4 v = *reinterpret_cast<const float4*>(y + row * C + q * 4); yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w; }
+            if (y) { const float4 v = da_ldq(y, row * cq + q); yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w; }
         } else {
-            gv[0] = g1[row * C + q] + (g2 ? g2[row * C + q] : 0.f);
-            if (y) yv[0] = y[row * C + q];
+            gv[0] = da_ld1(g1, row * C + q) + (g2 ? da_ld1(g2, row * C + q) : 0.f);
+            if (y) yv[0] = da_ld1(y, row * C + q);
         }
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { o[j] = y ? gv[j] * (yv[j] > 0.f ? 1.f : slope) : gv[j]; a0[j] += o[j]; }
-        if (VEC == 4) *reinterpret_cast<float4*>(dx + row * C + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
-        else dx[row * C + q] = o[0];
+        if (VEC == 4) da_stq(dx, row * cq + q, make_float4(o[0], o[1], o[2], o[3]));
+        else da_st1(dx, row * C + q, o[0]);
     }
     if (!partial) return;
 #pragma unroll
@@ -305,14 +306,14 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int n
     if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
-template <int MODE>
-int launch_partial(const RowPlan& p, const float* x, const float* dy, const float* mean, const float* rstd,
+template <int MODE, typename T = float>
+int launch_partial(const RowPlan& p, const T* x, const T* dy, const float* mean, const float* rstd,
                    const float* scale, const float* shift, float slope, long long M, int C, double* partial, hipStream_t st) {
     const size_t shm = (size_t)2 * p.rpi * C * sizeof(double);
     if (p.vec == 4)
-        hipLaunchKernelGGL((col_partial_kernel<4, MODE>), dim3(p.grid), dim3(p.block), shm, st, x, dy, mean, rstd, scale, shift, slope, M, C, p.rows_per_block, partial);
+        hipLaunchKernelGGL((col_partial_kernel<4, MODE, T>), dim3(p.grid), dim3(p.block), shm, st, x, dy, mean, rstd, scale, shift, slope, M, C, p.rows_per_block, partial);
     else
-        hipLaunchKernelGGL((col_partial_kernel<1, MODE>), dim3(p.grid), dim3(p.block), shm, st, x, dy, mean, rstd, scale, shift, slope, M, C, p.rows_per_block, partial);
+        hipLaunchKernelGGL((col_partial_kernel<1, MODE, T>), dim3(p.grid), dim3(p.block), shm, st, x, dy, mean, rstd, scale, shift, slope, M, C, p.rows_per_block, partial);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -324,20 +325,33 @@ extern "C" size_t da_bn_ws_bytes(long long M, int C) {
     return da_align((size_t)kMaxBlocks * 2 * C * sizeof(double)) + da_align((size_t)2 * C * sizeof(float));
 }
 
-extern "C" int da_bn_train_stats(const float* x, long long M, int C, const float* gamma, const float* beta,
-                                 float eps, float momentum, float* running_mean, float* running_var,
-                                 float* mean, float* rstd, float* scale, float* shift,
-                                 void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+static int bn_train_stats_t(const T* x, long long M, int C, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var,
+                            float* mean, float* rstd, float* scale, float* shift,
+                            void* ws, size_t ws_bytes, void* stream) {
     if (!x || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
     if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
     const RowPlan p = plan_rows(M, C);
     double* partial = (double*)ws;
-    int rc = launch_partial<0>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
+    int rc = launch_partial<0, T>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, M, C,
                        gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
     DA_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int da_bn_train_stats(const float* x, long long M, int C, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 float* mean, float* rstd, float* scale, float* shift,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    return bn_train_stats_t<float>(x, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, ws, ws_bytes, stream);
+}
+extern "C" int da_bn_train_stats_bf16(const void* x, long long M, int C, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var,
+                                      float* mean, float* rstd, float* scale, float* shift,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    return bn_train_stats_t<da_bf16>((const da_bf16*)x, M, C, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, ws, ws_bytes, stream);
 }
 
 extern "C" int da_bn_train_stats_from_partials(const double* partial, int nparts, long long M, int C,
@@ -359,43 +373,45 @@ extern "C" int da_bn_eval_affine(const float* gamma, const float* beta, const fl
     return 0;
 }
 
-extern "C" int da_bn_act_fwd(const float* x, const float* scale, const float* shift, float act_slope, float* y,
-                             long long M, int C, void* stream) {
+template <typename T>
+static int bn_act_fwd_t(const T* x, const float* scale, const float* shift, float act_slope, T* y, long long M, int C, void* stream) {
     if (!x || !y || M <= 0 || C <= 0) return DA_ERR_BADARG;
     if (C % 4 == 0) {
         const long long nvec = M * C / 4;
-        hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(da_grid(nvec, 256)), dim3(256), 0, da_stream(stream), x, scale, shift, act_slope, y, nvec, C / 4);
+        hipLaunchKernelGGL((bn_act_fwd_kernel<4, T>), dim3(da_grid(nvec, 256)), dim3(256), 0, da_stream(stream), x, scale, shift, act_slope, y, nvec, C / 4);
     } else {
         const long long nvec = M * C;
-        hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(da_grid(nvec, 256)), dim3(256), 0, da_stream(stream), x, scale, shift, act_slope, y, nvec, C);
+        hipLaunchKernelGGL((bn_act_fwd_kernel<1, T>), dim3(da_grid(nvec, 256)), dim3(256), 0, da_stream(stream), x, scale, shift, act_slope, y, nvec, C);
     }
     DA_LAUNCH_CHECK();
     return 0;
 }
-
-static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd,
-                           const float* scale, const float* shift, float act_slope, int train,
-                           float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
-                           void* ws, size_t ws_bytes, void* stream);
-
-extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                             const float* scale, const float* shift, float act_slope, int train,
-                             float* dx, float* dgamma, float* dbeta, long long M, int C,
-                             void* ws, size_t ws_bytes, void* stream) {
-    (void)gamma;
-    return bn_act_bwd_impl(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, nullptr, M, C, ws, ws_bytes, stream);
+extern "C" int da_bn_act_fwd(const float* x, const float* scale, const float* shift, float act_slope, float* y,
+                             long long M, int C, void* stream) {
+    return bn_act_fwd_t<float>(x, scale, shift, act_slope, y, M, C, stream);
+}
+extern "C" int da_bn_act_fwd_bf16(const void* x, const float* scale, const float* shift, float act_slope, void* y,
+                                  long long M, int C, void* stream) {
+    return bn_act_fwd_t<da_bf16>((const da_bf16*)x, scale, shift, act_slope, (da_bf16*)y, M, C, stream);
 }
 
-extern "C" int da_bn_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd,
-                                   const float* scale, const float* shift, float act_slope, int train,
-                                   float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
-                                   void* ws, size_t ws_bytes, void* stream) {
-    return bn_act_bwd_impl(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, dxsum, M, C, ws, ws_bytes, stream);
+template <typename T>
+static int colsum_t(const T* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    double* partial = (double*)ws;
+    int rc = launch_partial<1, T>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, C, out, 0);
+    DA_LAUNCH_CHECK();
+    return 0;
 }
 
-static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd,
+template <typename T>
+static int bn_act_bwd_impl(const T* dy, const T* x, const float* mean, const float* rstd,
                            const float* scale, const float* shift, float act_slope, int train,
-                           float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                           T* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
                            void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !dx || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
     if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
@@ -403,7 +419,7 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, c
     double* partial = (double*)ws;
     float* cm = (float*)((char*)ws + da_align((size_t)kMaxBlocks * 2 * C * sizeof(double)));
     hipStream_t st = da_stream(stream);
-    int rc = launch_partial<2>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
+    int rc = launch_partial<2, T>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm);
     DA_LAUNCH_CHECK();
@@ -413,48 +429,93 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* mean, c
         const int cq = C / 4;
         const bool fuse = dxsum != nullptr && (256 % cq) == 0;
         const int grid = fuse ? da_grid(nvec, 256, kMaxBlocks) : da_grid(nvec, 256);
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, cq, C, fuse ? partial : nullptr);
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4, T>), dim3(grid), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, cq, C, fuse ? partial : nullptr);
         DA_LAUNCH_CHECK();
         if (fuse) {
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, grid, C, dxsum, 0);
             DA_LAUNCH_CHECK();
         } else if (dxsum != nullptr) {
-            return da_colsum(dx, M, C, dxsum, ws, ws_bytes, stream);
+            return colsum_t<T>(dx, M, C, dxsum, ws, ws_bytes, stream);
         }
     } else {
         const long long nvec = M * C;
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<1>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C, C, nullptr);
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<1, T>), dim3(da_grid(nvec, 256)), dim3(256), 0, st, dy, x, mean, rstd, scale, shift, cm, act_slope, train, dx, nvec, C, C, nullptr);
         DA_LAUNCH_CHECK();
-        if (dxsum != nullptr) return da_colsum(dx, M, C, dxsum, ws, ws_bytes, stream);
+        if (dxsum != nullptr) return colsum_t<T>(dx, M, C, dxsum, ws, ws_bytes, stream);
     }
     return 0;
 }
 
-extern "C" int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream) {
+extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* scale, const float* shift, float act_slope, int train,
+                             float* dx, float* dgamma, float* dbeta, long long M, int C,
+                             void* ws, size_t ws_bytes, void* stream) {
+    (void)gamma;
+    return bn_act_bwd_impl<float>(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, nullptr, M, C, ws, ws_bytes, stream);
+}
+extern "C" int da_bn_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd,
+                                   const float* scale, const float* shift, float act_slope, int train,
+                                   float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    return bn_act_bwd_impl<float>(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, dxsum, M, C, ws, ws_bytes, stream);
+}
+extern "C" int da_bn_act_bwd_dbias_bf16(const void* dy, const void* x, const float* mean, const float* rstd,
+                                        const float* scale, const float* shift, float act_slope, int train,
+                                        void* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    return bn_act_bwd_impl<da_bf16>((const da_bf16*)dy, (const da_bf16*)x, mean, rstd, scale, shift, act_slope, train, (da_bf16*)dx, dgamma, dbeta, dxsum, M, C, ws, ws_bytes, stream);
+}
+
+template <typename T>
+static int act_bwd_t(const T* dy, const T* y, float act_slope, T* dx, long long numel, void* stream) {
     if (!dy || !y || !dx || numel <= 0) return DA_ERR_BADARG;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(da_grid(numel / 4 + 1, 256)), dim3(256), 0, da_stream(stream), dy, y, act_slope < 0.f ? 1.f : act_slope, dx, numel);
+    hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(da_grid(numel / 4 + 1, 256)), dim3(256), 0, da_stream(stream), dy, y, act_slope < 0.f ? 1.f : act_slope, dx, numel);
     DA_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream) {
+    return act_bwd_t<float>(dy, y, act_slope, dx, numel, stream);
+}
+extern "C" int da_act_bwd_bf16(const void* dy, const void* y, float act_slope, void* dx, long long numel, void* stream) {
+    return act_bwd_t<da_bf16>((const da_bf16*)dy, (const da_bf16*)y, act_slope, (da_bf16*)dx, numel, stream);
+}
 
-extern "C" int da_act_bwd_add_dbias(const float* g1, const float* g2, const float* y, float act_slope, float* dx, float* dbias,
-                                    long long M, int C, void* ws, size_t ws_bytes, void* stream) {
+// `partial` == nullptr: no bias gradient.  Returns the number of per-block partials through *nparts (when given).
+template <typename T>
+static int act_bwd_add_t(const T* g1, const T* g2, const T* y, float act_slope, T* dx, long long M, int C, double* partial, int* nparts, void* stream) {
     if (!g1 || !dx || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
-    if (dbias && ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
     const RowPlan p = plan_rows(M, C);
-    double* partial = dbias ? (double*)ws : nullptr;
-    const float* yy = act_slope < 0.f ? nullptr : y;          // no activation: dx = g1 + g2
+    const T* yy = act_slope < 0.f ? nullptr : y;          // no activation: dx = g1 + g2
     if (act_slope >= 0.f && !y) return DA_ERR_BADARG;
     const size_t shm = (size_t)p.rpi * C * sizeof(double);
     hipStream_t st = da_stream(stream);
-    if (p.vec == 4) hipLaunchKernelGGL((act_bwd_add_dbias_kernel<4>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
-    else hipLaunchKernelGGL((act_bwd_add_dbias_kernel<1>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
+    if (p.vec == 4) hipLaunchKernelGGL((act_bwd_add_dbias_kernel<4, T>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
+    else hipLaunchKernelGGL((act_bwd_add_dbias_kernel<1, T>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, partial);
     DA_LAUNCH_CHECK();
+    if (nparts) *nparts = p.grid;
+    return 0;
+}
+template <typename T>
+static int act_bwd_add_dbias_t(const T* g1, const T* g2, const T* y, float act_slope, T* dx, float* dbias,
+                               long long M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (dbias && ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    int np = 0;
+    const int rc = act_bwd_add_t<T>(g1, g2, y, act_slope, dx, M, C, dbias ? (double*)ws : nullptr, &np, stream);
+    if (rc) return rc;
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, C, dbias, 0);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), (const double*)ws, np, C, dbias, 0);
         DA_LAUNCH_CHECK();
     }
     return 0;
+}
+extern "C" int da_act_bwd_add_dbias(const float* g1, const float* g2, const float* y, float act_slope, float* dx, float* dbias,
+                                    long long M, int C, void* ws, size_t ws_bytes, void* stream) {
+    return act_bwd_add_dbias_t<float>(g1, g2, y, act_slope, dx, dbias, M, C, ws, ws_bytes, stream);
+}
+extern "C" int da_act_bwd_add_dbias_bf16(const void* g1, const void* g2, const void* y, float act_slope, void* dx, float* dbias,
+                                         long long M, int C, void* ws, size_t ws_bytes, void* stream) {
+    return act_bwd_add_dbias_t<da_bf16>((const da_bf16*)g1, (const da_bf16*)g2, (const da_bf16*)y, act_slope, (da_bf16*)dx, dbias, M, C, ws, ws_bytes, stream);
 }
 
 // The two halves of da_act_bwd_add_dbias as separate entries, for callers that keep the tiny per-channel finish off the stream the big
@@ -462,18 +523,15 @@ extern "C" int da_act_bwd_add_dbias(const float* g1, const float* g2, const floa
 // persistent matrix kernels costs the main stream 20 - 100 us per layer): `partial` is caller-owned, da_bn_ws_bytes(M, C) bytes.
 extern "C" int da_act_bwd_add_partial(const float* g1, const float* g2, const float* y, float act_slope, float* dx,
                                       long long M, int C, void* partial, size_t partial_bytes, int* nparts, void* stream) {
-    if (!g1 || !dx || !partial || !nparts || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (!partial || !nparts || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
     if (partial_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
-    const RowPlan p = plan_rows(M, C);
-    const float* yy = act_slope < 0.f ? nullptr : y;
-    if (act_slope >= 0.f && !y) return DA_ERR_BADARG;
-    const size_t shm = (size_t)p.rpi * C * sizeof(double);
-    hipStream_t st = da_stream(stream);
-    if (p.vec == 4) hipLaunchKernelGGL((act_bwd_add_dbias_kernel<4>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, (double*)partial);
-    else hipLaunchKernelGGL((act_bwd_add_dbias_kernel<1>), dim3(p.grid), dim3(p.block), shm, st, g1, g2, yy, act_slope, dx, M, C, p.rows_per_block, (double*)partial);
-    DA_LAUNCH_CHECK();
-    *nparts = p.grid;
-    return 0;
+    return act_bwd_add_t<float>(g1, g2, y, act_slope, dx, M, C, (double*)partial, nparts, stream);
+}
+extern "C" int da_act_bwd_add_partial_bf16(const void* g1, const void* g2, const void* y, float act_slope, void* dx,
+                                           long long M, int C, void* partial, size_t partial_bytes, int* nparts, void* stream) {
+    if (!partial || !nparts || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (partial_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    return act_bwd_add_t<da_bf16>((const da_bf16*)g1, (const da_bf16*)g2, (const da_bf16*)y, act_slope, (da_bf16*)dx, M, C, (double*)partial, nparts, stream);
 }
 
 extern "C" int da_colsum_finish(const void* partial, int nparts, int C, float* out, int accumulate, void* stream) {
@@ -484,13 +542,8 @@ extern "C" int da_colsum_finish(const void* partial, int nparts, int C, float* o
 }
 
 extern "C" int da_colsum(const float* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !out || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
-    if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
-    const RowPlan p = plan_rows(M, C);
-    double* partial = (double*)ws;
-    int rc = launch_partial<1>(p, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, C, partial, da_stream(stream));
-    if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, da_stream(stream), partial, p.grid, C, out, 0);
-    DA_LAUNCH_CHECK();
-    return 0;
+    return colsum_t<float>(x, M, C, out, ws, ws_bytes, stream);
+}
+extern "C" int da_colsum_bf16(const void* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+    return colsum_t<da_bf16>((const da_bf16*)x, M, C, out, ws, ws_bytes, stream);
 }

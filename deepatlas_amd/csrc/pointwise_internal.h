@@ -9,8 +9,9 @@ size_t da_pw_packed_bytes(int ntaps, int K, int N);
 int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
                long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
                void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial = nullptr,   // stats_partial: [cdiv(M,256)][2][N] BatchNorm sums (scatter form)
-               const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f);   // input prologue: act(a * scale + shift) is consumed
+               const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f,   // input prologue: act(a * scale + shift) is consumed
+               int a_bf16 = 0, int out_bf16 = 0);     // bf16 activation storage: `a` / `out` point to bf16 tensors
 size_t da_pw_wgrad_ws_bytes(long long M, int ntaps, int Cin, int Cout);
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
                 int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st,
-                const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f);
+                const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f, int in_bf16 = 0, int dy_bf16 = 0);

@@ -46,9 +46,13 @@ __device__ __forceinline__ long long tapoff(int t, int H, int W) {
 // GATHER  (GATHER == true) : out[v][n]        = sum_t sum_k A[map(v,t)][k] * B_t[k][n]   (conv1x1 dgrad, deconv dgrad)
 // STATS (SCATTER only): the epilogue also accumulates the BatchNorm sums of everything this workgroup writes (per-lane fp32 over
 // the <= 16 values of a tap, then double), so the transposed conv + BatchNorm3d of unets.py:49-51 needs no statistics pass over y.
-template <int KC, int NT, bool GATHER, bool STATS = false>
+// TA / TO: storage type of the A operand / of the output (float, or da_bf16 = bf16 activation storage, common.h; the struct's pointers are
+// then bf16 tensors behind a float* and lda / ldo still count ELEMENTS).  Arithmetic, bias, statistics: fp32 / double either way.
+template <int KC, int NT, bool GATHER, bool STATS = false, typename TA = float, typename TO = float>
 __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
     static_assert(!(STATS && GATHER), "statistics are an epilogue of the scatter form");
+    const TA* __restrict__ pa = reinterpret_cast<const TA*>(p.a);
+    TO* __restrict__ po = reinterpret_cast<TO*>(p.out);
     constexpr int MT = 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
         for (int r = 0; r < MT; ++r)
 #pragma unroll
             for (int c = 0; c < KC; ++c)
-                a[r][c] = aval[r] ? *reinterpret_cast<const float4*>(p.a + arow[r] * p.lda + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[r][c] = aval[r] ? da_ldq(pa, (arow[r] * p.lda + 16 * c + 4 * g) >> 2) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.ps) {      // deferred BatchNorm + activation of the producer (rows past M are never stored, so they need no mask)
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -114,9 +118,9 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         if (orow[r][reg] < 0) continue;
-                        const float* o = p.out + (orow[r][reg] + toff) * p.ldo + i;
+                        const long long o = (orow[r][reg] + toff) * p.ldo + i;
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) acc[r][n][reg] = o[16 * n];
+                        for (int n = 0; n < NT; ++n) acc[r][n][reg] = da_ld1(po, o + 16 * n);
                     }
             }
 #pragma unroll
@@ -137,9 +141,9 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     if (orow[r][reg] < 0) continue;
-                    float* o = p.out + (orow[r][reg] + toff) * p.ldo + i;
+                    const long long o = (orow[r][reg] + toff) * p.ldo + i;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
+                    for (int n = 0; n < NT; ++n) da_st1(po, o + 16 * n, acc[r][n][reg]);
                 }
             if constexpr (STATS) {
 #pragma unroll
@@ -187,9 +191,9 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                 for (int reg = 0; reg < 4; ++reg) {
                     const long long v = vbase + r * 16 + 4 * g + reg;
                     if (v >= p.M) continue;
-                    const float* o = p.out + v * p.ldo + i;
+                    const long long o = v * p.ldo + i;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[r][n][reg] = o[16 * n];
+                    for (int n = 0; n < NT; ++n) acc[r][n][reg] = da_ld1(po, o + 16 * n);
                 }
         }
 #pragma unroll 1
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                 float4 a[MT];
 #pragma unroll
                 for (int r = 0; r < MT; ++r)
-                    a[r] = aval[r] ? *reinterpret_cast<const float4*>(p.a + (arow[r] + toff) * p.lda + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    a[r] = aval[r] ? da_ldq(pa, ((arow[r] + toff) * p.lda + 16 * c + 4 * g) >> 2) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const float4 b = wp4[(((size_t)t * NT + n) * KC + c) * 64];
@@ -220,9 +224,9 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
             for (int reg = 0; reg < 4; ++reg) {
                 const long long v = vbase + r * 16 + 4 * g + reg;
                 if (v >= p.M) continue;
-                float* o = p.out + v * p.ldo + i;
+                const long long o = v * p.ldo + i;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) o[16 * n] = acc[r][n][reg];
+                for (int n = 0; n < NT; ++n) da_st1(po, o + 16 * n, acc[r][n][reg]);
             }
     }
 }
@@ -256,8 +260,14 @@ struct PwWgP {
     const float* ps; const float* pt; float pslope;      // optional input prologue on `in` (see PwP)
 };
 
-template <int CIT, int COT, int TPB>
+template <typename T> __device__ __forceinline__ float pw_buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    if constexpr (DaEl<T>::bf) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0) << 16);
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+// TI / TY: storage types of `in` and `dy` (see pw_mfma_kernel); ldi / ldy count elements
+template <int CIT, int COT, int TPB, typename TI = float, typename TY = float>
 __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
+    constexpr unsigned EI = DaEl<TI>::bytes, EY = DaEl<TY>::bytes;
     extern __shared__ __attribute__((aligned(16))) float red[];      // [CIT*TPB*COT][64][4] per-block reduction
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -287,10 +297,10 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     const long long slice0 = p.up ? vblk / ((long long)p.H * p.W) : 0;          // n*D + d of the first voxel
     const long long fbase = p.up ? slice0 * 2 * (2ll * p.H) * (2ll * p.W) : vblk;   // first dy voxel the descriptor covers
     auto clip32 = [](unsigned long long b) -> unsigned { return b > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)b; };
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + vblk * p.ldi), 0,
-                                           clip32((unsigned long long)(p.M - vblk) * p.ldi * 4ull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + fbase * p.ldy), 0,
-                                           clip32((unsigned long long)(p.M * fine_mult - fbase) * p.ldy * 4ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.in) + vblk * p.ldi * (long long)EI), 0,
+                                           clip32((unsigned long long)(p.M - vblk) * p.ldi * (unsigned long long)EI), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.dy) + fbase * p.ldy * (long long)EY), 0,
+                                           clip32((unsigned long long)(p.M * fine_mult - fbase) * p.ldy * (unsigned long long)EY), 0x00020000);
     // this lane's voxel (v0 + g, then += 4 per K-step) tracked as (w, h, rest = n*D + d - slice0) with carries
     int cw = 0, chh = 0; long long crest = 0;
     if (p.up) {
@@ -300,7 +310,7 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     }
     unsigned toffb[TPB];
 #pragma unroll
-    for (int t = 0; t < TPB; ++t) toffb[t] = (unsigned)(toffs[t] * p.ldy * 4);
+    for (int t = 0; t < TPB; ++t) toffb[t] = (unsigned)(toffs[t] * p.ldy * EY);
     float psc[CIT], psf[CIT];
 #pragma unroll
     for (int a = 0; a < CIT; ++a) { psc[a] = p.ps ? p.ps[i + 16 * a] : 1.f; psf[a] = p.ps ? p.pt[i + 16 * a] : 0.f; }
@@ -309,22 +319,22 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
         const long long v = vb + g;
         const bool ok = v < v1;
         okout = ok;
-        const unsigned offa = ok ? (unsigned)(((v - vblk) * p.ldi + i) * 4) : 0xFFFFFFFFu;
+        const unsigned offa = ok ? (unsigned)(((v - vblk) * p.ldi + i) * EI) : 0xFFFFFFFFu;
 #pragma unroll
         for (int a = 0; a < CIT; ++a)
-            av[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? offa + 64u * a : 0xFFFFFFFFu, 0, 0));
+            av[a] = pw_buf_ld1<TI>(rin, ok ? offa + 16u * EI * a : 0xFFFFFFFFu);
         long long fv = v - vblk;
         if (p.up) {
             fv = ((crest * 2) * (2 * p.H) + 2 * chh) * (long long)(2 * p.W) + 2 * cw;
             cw += 4;
             while (cw >= p.W) { cw -= p.W; if (++chh >= p.H) { chh = 0; ++crest; } }
         }
-        const unsigned offb = (unsigned)((fv * p.ldy + i) * 4);
+        const unsigned offb = (unsigned)((fv * p.ldy + i) * EY);
 #pragma unroll
         for (int t = 0; t < TPB; ++t)
 #pragma unroll
             for (int c = 0; c < COT; ++c)
-                bv[t][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ok ? offb + toffb[t] + 64u * c : 0xFFFFFFFFu, 0, 0));
+                bv[t][c] = pw_buf_ld1<TY>(rdy, ok ? offb + toffb[t] + 16u * EY * c : 0xFFFFFFFFu);
     };
     // the deferred activation is applied when a fragment is USED (one K-step after its loads were issued), never at fetch time
     auto apply_pro = [&](float* av, bool ok) {
@@ -399,14 +409,21 @@ __global__ void pw_reduce_kernel(const float* __restrict__ partial, int nparts, 
     }
 }
 
-template <int KC, int NT>
-int launch_pw(const PwP& p, bool gather, hipStream_t st) {
+template <int KC, int NT, typename TA, typename TO>
+int launch_pw_t(const PwP& p, bool gather, hipStream_t st) {
     const unsigned grid = (unsigned)da_cdiv(p.M, 256);
-    if (gather) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, true>), dim3(grid), dim3(256), 0, st, p);
-    else if (p.stats) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false, true>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false>), dim3(grid), dim3(256), 0, st, p);
+    if (gather) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, true, false, TA, TO>), dim3(grid), dim3(256), 0, st, p);
+    else if (p.stats) hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false, true, TA, TO>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_mfma_kernel<KC, NT, false, false, TA, TO>), dim3(grid), dim3(256), 0, st, p);
     DA_LAUNCH_CHECK();
     return 0;
+}
+template <int KC, int NT>
+int launch_pw(const PwP& p, bool gather, hipStream_t st, int a_bf, int o_bf) {
+    if (a_bf && o_bf) return launch_pw_t<KC, NT, da_bf16, da_bf16>(p, gather, st);
+    if (a_bf) return launch_pw_t<KC, NT, da_bf16, float>(p, gather, st);
+    if (o_bf) return launch_pw_t<KC, NT, float, da_bf16>(p, gather, st);
+    return launch_pw_t<KC, NT, float, float>(p, gather, st);
 }
 
 }  // namespace
@@ -422,7 +439,7 @@ size_t da_pw_packed_bytes(int ntaps, int K, int N) { return da_align((size_t)nta
 // accumulated into it in stream order (accum: the accumulators start from the current output instead of the bias).
 int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias, float* out,
                long long M, int D, int H, int W, int K, int N, int ntaps, int up, int gather,
-               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial, const float* pro_scale, const float* pro_shift, float pro_slope) {
+               void* ws, size_t ws_bytes, hipStream_t st, double* stats_partial, const float* pro_scale, const float* pro_shift, float pro_slope, int a_bf, int o_bf) {
     if (!da_pw_supported(K, N)) return DA_ERR_UNSUPPORTED;
     if ((stats_partial || pro_scale) && gather) return DA_ERR_BADARG;
     if (pro_scale && (!pro_shift || pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
@@ -436,13 +453,14 @@ int da_pw_gemm(const float* a, const float* w, int transposed, const float* bias
             hipLaunchKernelGGL(pw_pack_kernel, dim3(da_grid(total, 256, 512)), dim3(256), 0, st, w, wp, ntaps, kk, nn, transposed, K, N, k0, n0);
             DA_LAUNCH_CHECK();
             PwP p;
-            p.a = a + k0; p.wp = wp; p.bias = bias ? bias + n0 : nullptr; p.out = out + n0; p.M = M; p.D = D; p.H = H; p.W = W;
+            p.a = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a) + (size_t)k0 * (a_bf ? 2 : 4)); p.wp = wp; p.bias = bias ? bias + n0 : nullptr;
+            p.out = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (size_t)n0 * (o_bf ? 2 : 4)); p.M = M; p.D = D; p.H = H; p.W = W;
             p.K = kk; p.Nc = nn; p.lda = K; p.ldo = N; p.accum = k0 > 0 ? 1 : 0; p.ntaps = ntaps; p.up = up;
             p.stats = (stats_partial && k0 + 64 >= K) ? stats_partial + n0 : nullptr; p.stats_ld = N;      // statistics of the FINAL values: last K slice
             p.ps = pro_scale ? pro_scale + k0 : nullptr; p.pt = pro_scale ? pro_shift + k0 : nullptr; p.pslope = pro_slope < 0.f ? 1.f : pro_slope;
             const int KC = kk / 16, NT = nn / 16;
             int rc = DA_ERR_UNSUPPORTED;
-#define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) rc = launch_pw<kc, nt>(p, gather != 0, st)
+#define DA_PW_CASE(kc, nt) if (KC == kc && NT == nt) rc = launch_pw<kc, nt>(p, gather != 0, st, a_bf, o_bf)
             DA_PW_CASE(1, 1); DA_PW_CASE(1, 2); DA_PW_CASE(2, 1); DA_PW_CASE(2, 2); DA_PW_CASE(4, 4);
             DA_PW_CASE(1, 4); DA_PW_CASE(4, 1); DA_PW_CASE(2, 4); DA_PW_CASE(4, 2);
             DA_PW_CASE(3, 3); DA_PW_CASE(1, 3); DA_PW_CASE(3, 1); DA_PW_CASE(2, 3); DA_PW_CASE(3, 2); DA_PW_CASE(3, 4); DA_PW_CASE(4, 3);
@@ -478,10 +496,11 @@ __global__ void pw_place_kernel(const float* __restrict__ src, float* __restrict
     }
 }
 
-template <int CIT, int COT, int TPB>
-static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
+static int g_wg_in_bf = 0, g_wg_dy_bf = 0;      // storage types of the weight-gradient call being dispatched (set by da_pw_wgrad; one host thread drives the launches)
+template <int CIT, int COT, int TPB, typename TI, typename TY>
+static int launch_pw_wgrad_t(const PwWgP& p, int nblocks, hipStream_t st) {
     const size_t shm = (size_t)CIT * TPB * COT * 64 * 4 * sizeof(float);
-    auto kern = pw_mfma_wgrad_kernel<CIT, COT, TPB>;
+    auto kern = pw_mfma_wgrad_kernel<CIT, COT, TPB, TI, TY>;
     static bool attr_set = false;
     if (!attr_set && shm > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -492,14 +511,22 @@ static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
     DA_LAUNCH_CHECK();
     return 0;
 }
+template <int CIT, int COT, int TPB>
+static int launch_pw_wgrad(const PwWgP& p, int nblocks, hipStream_t st) {
+    if (g_wg_in_bf && g_wg_dy_bf) return launch_pw_wgrad_t<CIT, COT, TPB, da_bf16, da_bf16>(p, nblocks, st);
+    if (g_wg_in_bf) return launch_pw_wgrad_t<CIT, COT, TPB, da_bf16, float>(p, nblocks, st);
+    if (g_wg_dy_bf) return DA_ERR_UNSUPPORTED;          // (fp32 input with a bf16 gradient does not occur)
+    return launch_pw_wgrad_t<CIT, COT, TPB, float, float>(p, nblocks, st);
+}
 
 struct PwPro { const float* s; const float* t; float slope; };
 static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout, int ldi, int ldy,
                           int ntaps, int up, void* ws, hipStream_t st, const PwPro& pro, int ci0);
 
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
-                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st, const float* pro_scale, const float* pro_shift, float pro_slope) {
+                int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st, const float* pro_scale, const float* pro_shift, float pro_slope, int in_bf, int dy_bf) {
     if (!da_pw_supported(Cin, Cout) || (ntaps != 1 && ntaps != 8)) return DA_ERR_UNSUPPORTED;
+    g_wg_in_bf = in_bf; g_wg_dy_bf = dy_bf;
     if (pro_scale && (!pro_shift || pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
     const PwPro pro = {pro_scale, pro_shift, pro_slope < 0.f ? 1.f : pro_slope};
     if (ws_bytes < da_pw_wgrad_ws_bytes(M, ntaps, Cin, Cout)) return DA_ERR_WS_SMALL;
@@ -512,7 +539,9 @@ int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D,
     for (int ci0 = 0; ci0 < Cin; ci0 += 64)
         for (int co0 = 0; co0 < Cout; co0 += 64) {
             const int cic = (Cin - ci0) < 64 ? (Cin - ci0) : 64, coc = (Cout - co0) < 64 ? (Cout - co0) : 64;
-            const int rc = pw_wgrad_slice(in + ci0, dy + co0, tmp, M, D, H, W, cic, coc, Cin, Cout, ntaps, up, ws, st, pro, ci0);
+            const int rc = pw_wgrad_slice(reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (size_t)ci0 * (in_bf ? 2 : 4)),
+                                          reinterpret_cast<const float*>(reinterpret_cast<const char*>(dy) + (size_t)co0 * (dy_bf ? 2 : 4)),
+                                          tmp, M, D, H, W, cic, coc, Cin, Cout, ntaps, up, ws, st, pro, ci0);
             if (rc) return rc;
             hipLaunchKernelGGL(pw_place_kernel, dim3(da_grid((long long)ntaps * cic * coc, 256, 256)), dim3(256), 0, st, tmp, dw, ntaps, cic, coc, Cin, Cout, ci0, co0);
             DA_LAUNCH_CHECK();

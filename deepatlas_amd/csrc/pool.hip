@@ -5,8 +5,8 @@
 
 namespace {
 
-template <int VEC>
-__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <int VEC, typename T = float>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                     int N, int D, int H, int W, int C) {
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
     const long long total = (long long)N * Do * Ho * Wo * cq;
@@ -21,27 +21,28 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
-            const float* p = x + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+            const long long po = ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
             if (VEC == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(p);
+                const float4 a = da_ldq(x, po >> 2);
                 // PyTorch: update if (val > max) || isnan(val)
                 m[0] = (a.x > m[0] || a.x != a.x) ? a.x : m[0]; m[1] = (a.y > m[1] || a.y != a.y) ? a.y : m[1];
                 m[2] = (a.z > m[2] || a.z != a.z) ? a.z : m[2]; m[3] = (a.w > m[3] || a.w != a.w) ? a.w : m[3];
             } else {
-                const float a = *p; m[0] = (a > m[0] || a != a) ? a : m[0];
+                const float a = da_ld1(x, po); m[0] = (a > m[0] || a != a) ? a : m[0];
             }
         }
-        float* o = y + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
-        if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
-        else *o = m[0];
+        const long long oo = ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+        if (VEC == 4) da_stq(y, oo >> 2, make_float4(m[0], m[1], m[2], m[3]));
+        else da_st1(y, oo, m[0]);
     }
 }
 
 // MaxPool3d(2) whose input is a RAW producer output (deferred BatchNorm + activation, ops.LazyAct): one pass reads the raw window,
 // writes the activated voxels (the skip tensor of unets.py:266, which has to exist anyway) and their maximum.  Same arithmetic as
 // bn_act_fwd_kernel followed by maxpool2_fwd_kernel: act(z) = max(z, z * s) with s in [0, 1) (s = 1: no activation).  Even D, H, W.
-__global__ void maxpool2_fwd_pro_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, float s,
-                                        float* __restrict__ act, float* __restrict__ y, int N, int D, int H, int W, int C) {
+template <typename T>
+__global__ void maxpool2_fwd_pro_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, float s,
+                                        T* __restrict__ act, T* __restrict__ y, int N, int D, int H, int W, int C) {
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / 4;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -55,7 +56,7 @@ __global__ void maxpool2_fwd_pro_kernel(const float* __restrict__ x, const float
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
-            a[t] = *reinterpret_cast<const float4*>(x + ((((long long)n * D + d) * H + h) * W + w) * C + q * 4);
+            a[t] = da_ldq(x, (((((long long)n * D + d) * H + h) * W + w) * C + q * 4) >> 2);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -63,20 +64,21 @@ __global__ void maxpool2_fwd_pro_kernel(const float* __restrict__ x, const float
             float4 z;
             z.x = a[t].x * sc.x + sf.x; z.y = a[t].y * sc.y + sf.y; z.z = a[t].z * sc.z + sf.z; z.w = a[t].w * sc.w + sf.w;
             z.x = fmaxf(z.x, z.x * s); z.y = fmaxf(z.y, z.y * s); z.z = fmaxf(z.z, z.z * s); z.w = fmaxf(z.w, z.w * s);
-            *reinterpret_cast<float4*>(act + ((((long long)n * D + d) * H + h) * W + w) * C + q * 4) = z;
+            if constexpr (DaEl<T>::bf) z = da_unpack_bf16x4(da_pack_bf16x4(z));     // the maximum is taken over the STORED (rounded) values
+            da_stq(act, (((((long long)n * D + d) * H + h) * W + w) * C + q * 4) >> 2, z);
             m[0] = (z.x > m[0] || z.x != z.x) ? z.x : m[0]; m[1] = (z.y > m[1] || z.y != z.y) ? z.y : m[1];
             m[2] = (z.z > m[2] || z.z != z.z) ? z.z : m[2]; m[3] = (z.w > m[3] || z.w != z.w) ? z.w : m[3];
         }
-        *reinterpret_cast<float4*>(y + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * 4) = make_float4(m[0], m[1], m[2], m[3]);
+        da_stq(y, (((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * 4) >> 2, make_float4(m[0], m[1], m[2], m[3]));
     }
 }
 
 // One thread per OUTPUT window and channel group: recompute the arg-max (first maximum in scan order),
 // write all eight input-gradient positions (dense stores, no atomics).  Voxels of odd trailing planes
 // (floor mode) are zeroed by the caller's memset when D/H/W are odd.
-template <int VEC>
-__global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
-                                    int N, int D, int H, int W, int C, const float* __restrict__ add) {
+template <int VEC, typename T = float>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                    int N, int D, int H, int W, int C, const T* __restrict__ add) {
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -87,16 +89,16 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* _
         float m[VEC], g[VEC]; int am[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = 0; }
-        const float* gp = dy + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
-        if (VEC == 4) { const float4 a = *reinterpret_cast<const float4*>(gp); g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; }
-        else g[0] = *gp;
+        const long long go = ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+        if (VEC == 4) { const float4 a = da_ldq(dy, go >> 2); g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; }
+        else g[0] = da_ld1(dy, go);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
-            const float* p = x + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+            const long long po = ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
             float a[VEC];
-            if (VEC == 4) { const float4 b = *reinterpret_cast<const float4*>(p); a[0] = b.x; a[1] = b.y; a[2] = b.z; a[3] = b.w; }
-            else a[0] = *p;
+            if (VEC == 4) { const float4 b = da_ldq(x, po >> 2); a[0] = b.x; a[1] = b.y; a[2] = b.z; a[3] = b.w; }
+            else a[0] = da_ld1(x, po);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) if (a[j] > m[j] || a[j] != a[j]) { m[j] = a[j]; am[j] = t; }
         }
@@ -104,14 +106,13 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* _
         for (int t = 0; t < 8; ++t) {
             const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
             const long long off = ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
-            float* p = dx + off;
             // `add`: the gradient that reaches x through its other consumer (the skip connection), fused here instead of a
             // separate accumulation pass by autograd
             if (VEC == 4) {
                 float4 o = make_float4(am[0] == t ? g[0] : 0.f, am[1] == t ? g[1] : 0.f, am[2] == t ? g[2] : 0.f, am[3] == t ? g[3] : 0.f);
-                if (add) { const float4 e = *reinterpret_cast<const float4*>(add + off); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
-                *reinterpret_cast<float4*>(p) = o;
-            } else *p = ((am[0] == t) ? g[0] : 0.f) + (add ? add[off] : 0.f);
+                if (add) { const float4 e = da_ldq(add, off >> 2); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+                da_stq(dx, off >> 2, o);
+            } else da_st1(dx, off, ((am[0] == t) ? g[0] : 0.f) + (add ? da_ld1(add, off) : 0.f));
         }
     }
 }
@@ -123,8 +124,8 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out, float scale
     return s < in - 1 ? s : in - 1;
 }
 
-template <int VEC>
-__global__ void upsample_nearest_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <int VEC, typename T = float>
+__global__ void upsample_nearest_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                             int N, int D, int H, int W, int C, int Do, int Ho, int Wo) {
     const int cq = C / VEC;
     const float sd = (float)D / (float)Do, sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
@@ -135,16 +136,15 @@ __global__ void upsample_nearest_fwd_kernel(const float* __restrict__ x, float* 
         const int oh = (int)(v % Ho); v /= Ho;
         const int od = (int)(v % Do); const int n = (int)(v / Do);
         const int d = nearest_src(od, D, Do, sd), h = nearest_src(oh, H, Ho, sh), w = nearest_src(ow, W, Wo, sw);
-        const float* p = x + ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
-        float* o = y + i * VEC;
-        if (VEC == 4) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(p);
-        else *o = *p;
+        const long long po = ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
+        if (VEC == 4) da_stq(y, i, da_ldq(x, po >> 2));
+        else da_st1(y, i, da_ld1(x, po));
     }
 }
 
 // gather form of the backward: every input voxel sums the output voxels that map onto it.
-template <int VEC>
-__global__ void upsample_nearest_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+template <int VEC, typename T = float>
+__global__ void upsample_nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
                                             int N, int D, int H, int W, int C, int Do, int Ho, int Wo) {
     const int cq = C / VEC;
     const float sd = (float)D / (float)Do, sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
@@ -167,15 +167,14 @@ __global__ void upsample_nearest_bwd_kernel(const float* __restrict__ dy, float*
                 if (nearest_src(oh, H, Ho, sh) != h) continue;
                 for (int ow = w0; ow <= w1; ++ow) {
                     if (nearest_src(ow, W, Wo, sw) != w) continue;
-                    const float* p = dy + ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
-                    if (VEC == 4) { const float4 a = *reinterpret_cast<const float4*>(p); acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; }
-                    else acc[0] += *p;
+                    const long long po = ((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * VEC;
+                    if (VEC == 4) { const float4 a = da_ldq(dy, po >> 2); acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; }
+                    else acc[0] += da_ld1(dy, po);
                 }
             }
         }
-        float* o = dx + i * VEC;
-        if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        else *o = acc[0];
+        if (VEC == 4) da_stq(dx, i, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        else da_st1(dx, i, acc[0]);
     }
 }
 
@@ -264,62 +263,92 @@ __global__ void upsample_tri2_bwd_kernel(const float* __restrict__ dy, float* __
         else hipLaunchKernelGGL((KERNEL<1>), dim3(da_grid((total), 256)), dim3(256), 0, da_stream(stream), __VA_ARGS__);                 \
         DA_LAUNCH_CHECK();                                                                                        \
     } while (0)
+#define DA_VEC_DISPATCH_T(KERNEL, T, total, ...)                                                                  \
+    do {                                                                                                          \
+        if (C % 4 == 0) hipLaunchKernelGGL((KERNEL<4, T>), dim3(da_grid((total) / 4, 256)), dim3(256), 0, da_stream(stream), __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<1, T>), dim3(da_grid((total), 256)), dim3(256), 0, da_stream(stream), __VA_ARGS__);                 \
+        DA_LAUNCH_CHECK();                                                                                        \
+    } while (0)
 
-extern "C" int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream) {
+template <typename T> static int maxpool2_fwd_t(const T* x, T* y, int N, int D, int H, int W, int C, void* stream) {
     if (!x || !y || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    DA_VEC_DISPATCH(maxpool2_fwd_kernel, total, x, y, N, D, H, W, C);
+    DA_VEC_DISPATCH_T(maxpool2_fwd_kernel, T, total, x, y, N, D, H, W, C);
     return 0;
 }
+extern "C" int da_maxpool2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream) { return maxpool2_fwd_t<float>(x, y, N, D, H, W, C, stream); }
+extern "C" int da_maxpool2_fwd_bf16(const void* x, void* y, int N, int D, int H, int W, int C, void* stream) { return maxpool2_fwd_t<da_bf16>((const da_bf16*)x, (da_bf16*)y, N, D, H, W, C, stream); }
 
-extern "C" int da_maxpool2_fwd_pro(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope, float* act, float* y,
-                                   int N, int D, int H, int W, int C, void* stream) {
+template <typename T> static int maxpool2_fwd_pro_t(const T* x, const float* pro_scale, const float* pro_shift, float pro_slope, T* act, T* y,
+                                                    int N, int D, int H, int W, int C, void* stream) {
     if (!x || !pro_scale || !pro_shift || !act || !y || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
     if (((D | H | W) & 1) || C % 4 != 0 || pro_slope >= 1.f) return DA_ERR_UNSUPPORTED;       // odd trailing planes / odd channel counts: materialise + da_maxpool2_fwd
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_fwd_pro_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), x, pro_scale, pro_shift,
+    hipLaunchKernelGGL((maxpool2_fwd_pro_kernel<T>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), x, pro_scale, pro_shift,
                        pro_slope < 0.f ? 1.f : pro_slope, act, y, N, D, H, W, C);
     DA_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int da_maxpool2_fwd_pro(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope, float* act, float* y,
+                                   int N, int D, int H, int W, int C, void* stream) {
+    return maxpool2_fwd_pro_t<float>(x, pro_scale, pro_shift, pro_slope, act, y, N, D, H, W, C, stream);
+}
+extern "C" int da_maxpool2_fwd_pro_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope, void* act, void* y,
+                                        int N, int D, int H, int W, int C, void* stream) {
+    return maxpool2_fwd_pro_t<da_bf16>((const da_bf16*)x, pro_scale, pro_shift, pro_slope, (da_bf16*)act, (da_bf16*)y, N, D, H, W, C, stream);
+}
 
-extern "C" int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream) {
+// gskip == nullptr: plain backward.  Else dx = gskip + maxpool_bwd(dy): x feeds both the pool and a skip connection (unets.py:266-267,275),
+// so its gradient is the sum of the two
+template <typename T> static int maxpool2_bwd_t(const T* dy, const T* x, const T* gskip, T* dx, int N, int D, int H, int W, int C, void* stream) {
     if (!dy || !x || !dx || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
-    if ((D | H | W) & 1) {   // floor mode leaves trailing planes without gradient
-        hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * D * H * W * C * sizeof(float), da_stream(stream));
+    if ((D | H | W) & 1) {   // floor mode: trailing planes are outside every pooling window (no gradient / only the skip gradient)
+        const size_t bytes = (size_t)N * D * H * W * C * sizeof(T);
+        hipError_t e = gskip ? hipMemcpyAsync(dx, gskip, bytes, hipMemcpyDeviceToDevice, da_stream(stream)) : hipMemsetAsync(dx, 0, bytes, da_stream(stream));
         if (e != hipSuccess) return (int)e;
     }
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    DA_VEC_DISPATCH(maxpool2_bwd_kernel, total, dy, x, dx, N, D, H, W, C, (const float*)nullptr);
+    DA_VEC_DISPATCH_T(maxpool2_bwd_kernel, T, total, dy, x, dx, N, D, H, W, C, gskip);
     return 0;
 }
-
-// dx = gskip + maxpool_bwd(dy): x feeds both the pool and a skip connection (unets.py:266-267,275), so its gradient is the sum of the two
+extern "C" int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream) {
+    return maxpool2_bwd_t<float>(dy, x, nullptr, dx, N, D, H, W, C, stream);
+}
 extern "C" int da_maxpool2_bwd_add(const float* dy, const float* x, const float* gskip, float* dx, int N, int D, int H, int W, int C, void* stream) {
-    if (!dy || !x || !gskip || !dx || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
-    if ((D | H | W) & 1) {   // trailing planes are outside every pooling window: they only carry the skip gradient
-        hipError_t e = hipMemcpyAsync(dx, gskip, (size_t)N * D * H * W * C * sizeof(float), hipMemcpyDeviceToDevice, da_stream(stream));
-        if (e != hipSuccess) return (int)e;
-    }
-    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    DA_VEC_DISPATCH(maxpool2_bwd_kernel, total, dy, x, dx, N, D, H, W, C, gskip);
-    return 0;
+    if (!gskip) return DA_ERR_BADARG;
+    return maxpool2_bwd_t<float>(dy, x, gskip, dx, N, D, H, W, C, stream);
+}
+extern "C" int da_maxpool2_bwd_bf16(const void* dy, const void* x, void* dx, int N, int D, int H, int W, int C, void* stream) {
+    return maxpool2_bwd_t<da_bf16>((const da_bf16*)dy, (const da_bf16*)x, nullptr, (da_bf16*)dx, N, D, H, W, C, stream);
+}
+extern "C" int da_maxpool2_bwd_add_bf16(const void* dy, const void* x, const void* gskip, void* dx, int N, int D, int H, int W, int C, void* stream) {
+    if (!gskip) return DA_ERR_BADARG;
+    return maxpool2_bwd_t<da_bf16>((const da_bf16*)dy, (const da_bf16*)x, (const da_bf16*)gskip, (da_bf16*)dx, N, D, H, W, C, stream);
 }
 
-extern "C" int da_upsample_nearest_fwd(const float* x, float* y, int N, int D, int H, int W, int C,
-                                       int Do, int Ho, int Wo, void* stream) {
+template <typename T> static int upsample_nearest_fwd_t(const T* x, T* y, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream) {
     if (!x || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return DA_ERR_BADARG;
     const long long total = (long long)N * Do * Ho * Wo * C;
-    DA_VEC_DISPATCH(upsample_nearest_fwd_kernel, total, x, y, N, D, H, W, C, Do, Ho, Wo);
+    DA_VEC_DISPATCH_T(upsample_nearest_fwd_kernel, T, total, x, y, N, D, H, W, C, Do, Ho, Wo);
     return 0;
 }
-
-extern "C" int da_upsample_nearest_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C,
-                                       int Do, int Ho, int Wo, void* stream) {
+template <typename T> static int upsample_nearest_bwd_t(const T* dy, T* dx, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream) {
     if (!dy || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return DA_ERR_BADARG;
     const long long total = (long long)N * D * H * W * C;
-    DA_VEC_DISPATCH(upsample_nearest_bwd_kernel, total, dy, dx, N, D, H, W, C, Do, Ho, Wo);
+    DA_VEC_DISPATCH_T(upsample_nearest_bwd_kernel, T, total, dy, dx, N, D, H, W, C, Do, Ho, Wo);
     return 0;
+}
+extern "C" int da_upsample_nearest_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream) {
+    return upsample_nearest_fwd_t<float>(x, y, N, D, H, W, C, Do, Ho, Wo, stream);
+}
+extern "C" int da_upsample_nearest_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream) {
+    return upsample_nearest_bwd_t<float>(dy, dx, N, D, H, W, C, Do, Ho, Wo, stream);
+}
+extern "C" int da_upsample_nearest_fwd_bf16(const void* x, void* y, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream) {
+    return upsample_nearest_fwd_t<da_bf16>((const da_bf16*)x, (da_bf16*)y, N, D, H, W, C, Do, Ho, Wo, stream);
+}
+extern "C" int da_upsample_nearest_bwd_bf16(const void* dy, void* dx, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream) {
+    return upsample_nearest_bwd_t<da_bf16>((const da_bf16*)dy, (da_bf16*)dx, N, D, H, W, C, Do, Ho, Wo, stream);
 }
 
 extern "C" int da_upsample_trilinear2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream) {

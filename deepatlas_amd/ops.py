@@ -22,8 +22,8 @@ from ._native import call, call_supported, ptr, stream, workspace
 def ndhwc(x):
     """N x C x D x H x W (any strides) -> dense N x D x H x W x C tensor (a view when already channels-last)."""
     nat.require_cuda(x)
-    if x.dtype != torch.float32:
-        raise nat.NativeError('deepatlas_amd kernels are fp32; got %s' % x.dtype)
+    if x.dtype != torch.float32 and x.dtype != torch.bfloat16:
+        raise nat.NativeError('deepatlas_amd kernels take fp32 tensors (bf16 for the activations of the bf16 storage mode); got %s' % x.dtype)
     xp = x.permute(0, 2, 3, 4, 1)
     return xp if xp.is_contiguous() else xp.contiguous()
 
@@ -33,8 +33,106 @@ def ncdhw(t):
     return t.permute(0, 4, 1, 2, 3)
 
 
-def _empty(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 activation storage (BASELINE configs[4]; include/deepatlas_hip.h, last section)
+# ------------------------------------------------------------------------------------------------
+# 'fp32': every tensor fp32 (the reference's arithmetic).  'bf16': the tensors BETWEEN the layers of a network -- convolution / transposed
+# convolution outputs, BatchNorm + activation outputs, pooled / up-sampled tensors and all their gradients -- are stored as bf16; network
+# inputs, logits, displacement fields, everything the losses see, parameters, their gradients, statistics and every accumulation stay fp32.
+# Goes with set_matrix_precision('bf16').  A kernel without a bf16 twin for some shape is bridged by conversion passes (call_act).
+ACT_STORAGE_MODES = ('fp32', 'bf16')
+ACT_STORAGE = 'fp32'
+
+
+def set_activation_storage(mode):
+    """Process-wide storage type of the network-internal activations; returns the previous mode."""
+    global ACT_STORAGE
+    if mode not in ACT_STORAGE_MODES:
+        raise ValueError("activation storage must be one of %r, got %r" % (ACT_STORAGE_MODES, mode))
+    prev, ACT_STORAGE = ACT_STORAGE, mode
+    return prev
+
+
+def _act_dtype(channels=None):
+    """dtype of a network-internal activation with `channels` channels (thin outputs -- the 3-channel displacement field -- stay fp32)."""
+    if ACT_STORAGE == 'bf16' and (channels is None or (channels >= 8 and channels % 4 == 0)):
+        return torch.bfloat16
+    return torch.float32
+
+
+class A(object):
+    """Marks an activation / gradient tensor among the arguments of call_act (out=True: the kernel writes it)."""
+    __slots__ = ('t', 'out')
+
+    def __init__(self, t, out=False):
+        self.t, self.out = t, out
+
+
+def O(t):
+    return A(t, True)
+
+
+# bf16 twins whose activation arguments are not all bf16: expected pattern over the non-None activation arguments, in signature order
+_TWIN_PATTERN = {'da_conv1x1_fwd': (1, 0), 'da_conv1x1_fwd_pro': (1, 0), 'da_conv1x1_dgrad': (0, 1), 'da_conv1x1_wgrad': (1, 0),
+                 'da_conv1x1_wgrad_pro': (1, 0)}
+BF16_FORCE_BRIDGE = False       # tests: take the conversion route even where a bf16 twin exists (A/B of every twin at network level)
+bridged_calls = {}       # name -> number of calls that went through conversion passes (diagnostics: tests / bench report it)
+
+
+def call_act(name, *args, may_decline=False):
+    """call() for entry points with activation arguments (wrapped in A / O).  All fp32: the plain entry.  Some bf16: the `_bf16` twin when it
+    exists and takes this combination natively; otherwise the bf16 tensors are converted to fp32 scratch tensors around the plain entry
+    (inputs before, outputs after -- the stored values are the same, only passes are added).  may_decline: like call_supported."""
+    acts = [a for a in args if isinstance(a, A) and a.t is not None]
+    plain = lambda: [(ptr(a.t) if isinstance(a, A) else a) for a in args]
+    if not any(a.t.dtype == torch.bfloat16 for a in acts):
+        if may_decline:
+            return call_supported(name, *plain())
+        call(name, *plain())
+        return True
+    twin = name + '_bf16'
+    pattern = tuple(1 if a.t.dtype == torch.bfloat16 else 0 for a in acts)
+    if twin in nat.SIGNATURES and not BF16_FORCE_BRIDGE:
+        if name in nat.BF16_MASKED_TWINS:
+            mask, k = 0, 0
+            for a in args:
+                if isinstance(a, A):
+                    if a.t is not None and a.t.dtype == torch.bfloat16:
+                        mask |= 1 << k
+                    k += 1
+            if call_supported(twin, *(plain() + [mask])):
+                return True
+        elif pattern == _TWIN_PATTERN.get(name, (1,) * len(acts)):
+            if call_supported(twin, *plain()):
+                return True
+    # bridge
+    st = stream()
+    conv, outs = [], []
+    for a in args:
+        if isinstance(a, A) and a.t is not None and a.t.dtype == torch.bfloat16:
+            t32 = torch.empty(a.t.shape, dtype=torch.float32, device=a.t.device)
+            if a.out:
+                outs.append((a.t, t32))
+            else:
+                call('da_cast_bf16_to_f32', ptr(a.t), ptr(t32), a.t.numel(), st)
+            conv.append(ptr(t32))
+        elif isinstance(a, A):
+            conv.append(ptr(a.t))
+        else:
+            conv.append(a)
+    bridged_calls[name] = bridged_calls.get(name, 0) + 1
+    if may_decline:
+        if not call_supported(name, *conv):
+            return False
+    else:
+        call(name, *conv)
+    for t, t32 in outs:
+        call('da_cast_f32_to_bf16', ptr(t32), ptr(t), t.numel(), st)
+    return True
 
 
 def _ws(nbytes, like):
@@ -301,7 +399,7 @@ class ApplyAffineActFn(Function):
         a = ndhwc(raw)
         C = a.shape[-1]
         out = torch.empty_like(a)
-        call('da_bn_act_fwd', ptr(a), ptr(scale), ptr(shift), float(slope), ptr(out), a.numel() // C, C, stream())
+        call_act('da_bn_act_fwd', A(a), ptr(scale), ptr(shift), float(slope), O(out), a.numel() // C, C, stream())
         return ncdhw(out)
 
     @staticmethod
@@ -322,7 +420,7 @@ def _apply_pro(a, pro, st):
         return a
     C = a.shape[-1]
     out = torch.empty_like(a)
-    call('da_bn_act_fwd', ptr(a), ptr(pro[0]), ptr(pro[1]), float(pro[2]), ptr(out), a.numel() // C, C, st)
+    call_act('da_bn_act_fwd', A(a), ptr(pro[0]), ptr(pro[1]), float(pro[2]), O(out), a.numel() // C, C, st)
     return out
 
 
@@ -360,17 +458,17 @@ class Conv3dK3Fn(Function):
         w_tio = weight_tio(weight, 'iok_flip' if transposed else 'oik')
         b = bias.detach().contiguous() if bias is not None else None
         if up2:
-            out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a1)
+            out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a1, _act_dtype(Cout))
             wsb = nat.lib().da_upconv3d_k3_ws_bytes(N, D, H, W, Cin, Cout)
             wp, wn = _ws(wsb, a1)
-            call('da_upconv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cout, float(act_slope), wp, wn, st)
+            call_act('da_upconv3d_k3_fwd', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(out), N, D, H, W, Cout, float(act_slope), wp, wn, st)
         else:
             Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
-            out = _empty((N, Do, Ho, Wo, Cout), a1)
+            out = _empty((N, Do, Ho, Wo, Cout), a1, _act_dtype(Cout))
             wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
             wp, wn = _ws(wsb, a1)
-            call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(out),
-                 N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
+            call_act('da_conv3d_k3_fwd', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(out),
+                     N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
         ctx.dims = (N, D, H, W, C1, C2, Cout, stride, float(act_slope), wsb)
         ctx.has_bias = bias is not None
         ctx.wparam, ctx.bparam = weight, bias
@@ -389,17 +487,20 @@ class Conv3dK3Fn(Function):
 
         def k_dgrad(g_, dx1_, dx2_, wp_, wn_, st_):
             if up2:
-                call('da_upconv3d_k3_dgrad', ptr(g_), ptr(w_tio), ptr(dx1_), C1, ptr(dx2_), C2, N, D, H, W, Cout, wp_, wn_, st_)
+                call_act('da_upconv3d_k3_dgrad', A(g_), ptr(w_tio), O(dx1_), C1, O(dx2_), C2, N, D, H, W, Cout, wp_, wn_, st_)
             else:
-                call('da_conv3d_k3_dgrad', ptr(g_), ptr(w_tio), ptr(dx1_), C1, ptr(dx2_), C2, N, D, H, W, Cout, stride, wp_, wn_, st_)
+                call_act('da_conv3d_k3_dgrad', A(g_), ptr(w_tio), O(dx1_), C1, O(dx2_), C2, N, D, H, W, Cout, stride, wp_, wn_, st_)
 
         def k_wgrad(g_, dw_tio_, db_, wp_, wn_, st_):
             if up2:
-                call('da_upconv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g_), ptr(dw_tio_), N, D, H, W, Cout, wp_, wn_, st_)
+                call_act('da_upconv3d_k3_wgrad', A(a1), C1, A(a2), C2, A(g_), ptr(dw_tio_), N, D, H, W, Cout, wp_, wn_, st_)
                 if db_ is not None:
-                    call('da_colsum', ptr(g_), g_.numel() // Cout, Cout, ptr(db_), wp_, wn_, st_)
+                    call_act('da_colsum', A(g_), g_.numel() // Cout, Cout, ptr(db_), wp_, wn_, st_)
+            elif db_ is not None and g_.dtype == torch.bfloat16:          # (the bf16 twin leaves the bias gradient to its own pass)
+                call_act('da_conv3d_k3_wgrad', A(a1), C1, A(a2), C2, A(g_), ptr(dw_tio_), None, N, D, H, W, Cout, stride, wp_, wn_, st_)
+                call_act('da_colsum', A(g_), g_.numel() // Cout, Cout, ptr(db_), wp_, wn_, st_)
             else:
-                call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(g_), ptr(dw_tio_), ptr(db_), N, D, H, W, Cout, stride, wp_, wn_, st_)
+                call_act('da_conv3d_k3_wgrad', A(a1), C1, A(a2), C2, A(g_), ptr(dw_tio_), ptr(db_), N, D, H, W, Cout, stride, wp_, wn_, st_)
         g_b = gmore[0] if (ctx.fork and gmore) else None
         if gout is None:
             gout, g_b = g_b, None
@@ -422,19 +523,19 @@ class Conv3dK3Fn(Function):
                 pbytes = nat.lib().da_bn_ws_bytes(M, Cout)
                 pbuf = torch.empty((pbytes,), dtype=torch.uint8, device=g.device)
                 npar = ctypes.c_int(0)
-                call('da_act_bwd_add_partial', ptr(g), ptr(gb2), ptr(out), slope if out is not None else -1.0, ptr(g2), M, Cout,
-                     ptr(pbuf), pbytes, ctypes.byref(npar), st)
+                call_act('da_act_bwd_add_partial', A(g), A(gb2), A(out), slope if out is not None else -1.0, O(g2), M, Cout,
+                         ptr(pbuf), pbytes, ctypes.byref(npar), st)
                 db_partial = (pbuf, npar.value)
             else:
                 db = _empty((Cout,), a1) if want_b else None
                 bwp, bwn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(M, Cout)), a1)
-                call('da_act_bwd_add_dbias', ptr(g), ptr(gb2), ptr(out), slope if out is not None else -1.0, ptr(g2), ptr(db), M, Cout, bwp, bwn, st)
+                call_act('da_act_bwd_add_dbias', A(g), A(gb2), A(out), slope if out is not None else -1.0, O(g2), ptr(db), M, Cout, bwp, bwn, st)
             g = g2
         wp, wn = _ws(wsb, a1)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
-            dx1 = _empty(a1.shape, a1)
-            dx2 = _empty(a2.shape, a1) if a2 is not None else None
+            dx1 = torch.empty_like(a1)
+            dx2 = torch.empty_like(a2) if a2 is not None else None
             _serialize_matrix_kernels(flops, N * D * H * W)
             k_dgrad(g, dx1, dx2, wp, wn, st)
         dw = None
@@ -502,11 +603,11 @@ class Conv1x1Fn(Function):
         M = N * D * H * W
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(1, Cin, Cout), a)
-        if pro is not None and not call_supported('da_conv1x1_fwd_pro', ptr(a), ptr(pro[0]), ptr(pro[1]), float(pro[2]), ptr(w_io), ptr(b), ptr(out),
-                                                  M, Cin, Cout, wp, wn, st):
+        if pro is not None and not call_act('da_conv1x1_fwd_pro', A(a), ptr(pro[0]), ptr(pro[1]), float(pro[2]), ptr(w_io), ptr(b), O(out),
+                                            M, Cin, Cout, wp, wn, st, may_decline=True):
             a, pro = _apply_pro(a, pro, st), None
         if pro is None:
-            call('da_conv1x1_fwd', ptr(a), ptr(w_io), ptr(b), ptr(out), M, Cin, Cout, wp, wn, st)
+            call_act('da_conv1x1_fwd', A(a), ptr(w_io), ptr(b), O(out), M, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
         ctx.pro_slope = pro[2] if pro is not None else None
         ctx.save_for_backward(a, w_io, pro[0] if pro is not None else None, pro[1] if pro is not None else None)
@@ -523,7 +624,7 @@ class Conv1x1Fn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
             wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(1, Cin, Cout), a)
-            call('da_conv1x1_dgrad', ptr(g), ptr(w_io), ptr(dx), M, Cin, Cout, wp, wn, st)
+            call_act('da_conv1x1_dgrad', A(g), ptr(w_io), O(dx), M, Cin, Cout, wp, wn, st)
         # (the head's weight gradient stays on the main stream: it is the first backward kernel, HBM-bound like its neighbours --
         # on the side stream it only competed with them: 39.2 -> 41.5 ms)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -531,11 +632,11 @@ class Conv1x1Fn(Function):
             db = _empty((Cout,), a) if ctx.has_bias else None
             wp, wn = _ws(nat.lib().da_conv1x1_wgrad_ws_bytes(M, Cin, Cout), a)
             if ps is not None:
-                if not call_supported('da_conv1x1_wgrad_pro', ptr(a), ptr(ps), ptr(pt), float(ctx.pro_slope), ptr(g), ptr(dw_io), ptr(db),
-                                      M, Cin, Cout, wp, wn, st):
-                    call('da_conv1x1_wgrad', ptr(_apply_pro(a, (ps, pt, ctx.pro_slope), st)), ptr(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
+                if not call_act('da_conv1x1_wgrad_pro', A(a), ptr(ps), ptr(pt), float(ctx.pro_slope), A(g), ptr(dw_io), ptr(db),
+                                M, Cin, Cout, wp, wn, st, may_decline=True):
+                    call_act('da_conv1x1_wgrad', A(_apply_pro(a, (ps, pt, ctx.pro_slope), st)), A(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
             else:
-                call('da_conv1x1_wgrad', ptr(a), ptr(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
+                call_act('da_conv1x1_wgrad', A(a), A(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
             dw = _empty((Cout, Cin, 1, 1, 1), a)
             call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), Cout, Cin, 1, st)
         return ((ncdhw(dx) if dx is not None else None), dw, db) + (None,) * ctx.n_extra
@@ -553,10 +654,10 @@ class DeconvK2S2Fn(Function):
             raise ValueError('ConvTranspose3d weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
         st = stream()
         w_tio = weight_tio(weight, 'iok')
-        out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
+        out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a, _act_dtype(Cout))
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
-        call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cin, Cout, wp, wn, st)
+        call_act('da_deconv_k2s2_fwd', A(a), ptr(w_tio), ptr(b), O(out), N, D, H, W, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(a, w_tio)
         return ncdhw(out)
@@ -572,12 +673,12 @@ class DeconvK2S2Fn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
             wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
-            call('da_deconv_k2s2_dgrad', ptr(g), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_deconv_k2s2_dgrad', A(g), ptr(w_tio), O(dx), N, D, H, W, Cin, Cout, wp, wn, st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw_tio = torch.empty_like(w_tio)
             db = _empty((Cout,), a) if ctx.has_bias else None
             wp, wn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
-            call('da_deconv_k2s2_wgrad', ptr(a), ptr(g), ptr(dw_tio), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_deconv_k2s2_wgrad', A(a), A(g), ptr(dw_tio), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
             dw = _empty((Cin, Cout, 2, 2, 2), a)
             call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
         return (ncdhw(dx) if dx is not None else None), dw, db
@@ -599,10 +700,10 @@ class ConvK2S2Fn(Function):
         D, H, W = D2 // 2, H2 // 2, W2 // 2
         st = stream()
         w_tio = weight_tio(weight, 'oik')
-        out = _empty((N, D, H, W, Cout), a)
+        out = _empty((N, D, H, W, Cout), a, _act_dtype(Cout))
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
-        call('da_conv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(out), N, D, H, W, Cin, Cout, wp, wn, st)
+        call_act('da_conv_k2s2_fwd', A(a), ptr(w_tio), ptr(b), O(out), N, D, H, W, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(a, w_tio)
         return ncdhw(out)
@@ -619,12 +720,12 @@ class ConvK2S2Fn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
             wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cout, Cin), a)
-            call('da_conv_k2s2_dgrad', ptr(g), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_conv_k2s2_dgrad', A(g), ptr(w_tio), O(dx), N, D, H, W, Cin, Cout, wp, wn, st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw_toi = _empty((8, Cout, Cin), a)
             db = _empty((Cout,), a) if ctx.has_bias else None
             wp, wn = _ws(nat.lib().da_conv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
-            call('da_conv_k2s2_wgrad', ptr(a), ptr(g), ptr(dw_toi), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_conv_k2s2_wgrad', A(a), A(g), ptr(dw_toi), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
             dw = _empty((Cout, Cin, 2, 2, 2), a)
             call('da_w_tio_to_iok', ptr(dw_toi), ptr(dw), Cout, Cin, 8, st)          # [8][Cout][Cin] -> [Cout][Cin][8]
         return (ncdhw(dx) if dx is not None else None), dw, db
@@ -637,8 +738,8 @@ class UpsampleTrilinear2Fn(Function):
     def forward(ctx, x):
         a = ndhwc(x)
         N, D, H, W, C = a.shape
-        out = _empty((N, 2 * D, 2 * H, 2 * W, C), a)
-        call('da_upsample_trilinear2_fwd', ptr(a), ptr(out), N, D, H, W, C, stream())
+        out = _empty((N, 2 * D, 2 * H, 2 * W, C), a, a.dtype)
+        call_act('da_upsample_trilinear2_fwd', A(a), O(out), N, D, H, W, C, stream())
         ctx.dims = (N, D, H, W, C)
         return ncdhw(out)
 
@@ -646,8 +747,8 @@ class UpsampleTrilinear2Fn(Function):
     def backward(ctx, gout):
         N, D, H, W, C = ctx.dims
         g = ndhwc(gout)
-        dx = _empty((N, D, H, W, C), g)
-        call('da_upsample_trilinear2_bwd', ptr(g), ptr(dx), N, D, H, W, C, stream())
+        dx = _empty((N, D, H, W, C), g, g.dtype)
+        call_act('da_upsample_trilinear2_bwd', A(g), O(dx), N, D, H, W, C, stream())
         return ncdhw(dx)
 
 
@@ -670,13 +771,13 @@ class BNActFn(Function):
         wsb = nat.lib().da_bn_ws_bytes(M, C)
         if training or running_mean is None:
             wp, wn = _ws(wsb, a)
-            call('da_bn_train_stats', ptr(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
-                 ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
+            call_act('da_bn_train_stats', A(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
+                     ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
         else:
             call('da_bn_eval_affine', ptr(g), ptr(b), ptr(running_mean), ptr(running_var), float(eps), C,
                  ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
         out = torch.empty_like(a)
-        call('da_bn_act_fwd', ptr(a), ptr(stats[2]), ptr(stats[3]), float(slope), ptr(out), M, C, st)
+        call_act('da_bn_act_fwd', A(a), ptr(stats[2]), ptr(stats[3]), float(slope), O(out), M, C, st)
         ctx.cfg = (M, C, float(slope), bool(training or running_mean is None), wsb)
         ctx.save_for_backward(a, stats, g)
         return ncdhw(out)
@@ -690,8 +791,8 @@ class BNActFn(Function):
         dx = torch.empty_like(a)
         dgb = _empty((2, C), a)
         wp, wn = _ws(wsb, a)
-        call('da_bn_act_bwd', ptr(go), ptr(a), ptr(stats[0]), ptr(stats[1]), ptr(g), ptr(stats[2]), ptr(stats[3]),
-             slope, 1 if train else 0, ptr(dx), ptr(dgb[0]), ptr(dgb[1]), M, C, wp, wn, st)
+        call_act('da_bn_act_bwd', A(go), A(a), ptr(stats[0]), ptr(stats[1]), ptr(g), ptr(stats[2]), ptr(stats[3]),
+                 slope, 1 if train else 0, O(dx), ptr(dgb[0]), ptr(dgb[1]), M, C, wp, wn, st)
         return ncdhw(dx), dgb[0], dgb[1], None, None, None, None, None, None
 
 
@@ -710,15 +811,15 @@ def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, e
              ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
     elif train:
         wp, wn = _ws(wsb, a)
-        call('da_bn_train_stats', ptr(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
-             ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
+        call_act('da_bn_train_stats', A(a), M, C, ptr(g), ptr(b), float(eps), float(momentum),
+                 ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), wp, wn, st)
     else:
         call('da_bn_eval_affine', ptr(g), ptr(b), ptr(running_mean), ptr(running_var), float(eps), C,
              ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), st)
     out = None
     if apply:
         out = torch.empty_like(a)
-        call('da_bn_act_fwd', ptr(a), ptr(stats[2]), ptr(stats[3]), float(slope), ptr(out), M, C, st)
+        call_act('da_bn_act_fwd', A(a), ptr(stats[2]), ptr(stats[3]), float(slope), O(out), M, C, st)
     return out, stats, g, (M, C, float(slope), train, wsb)
 
 
@@ -729,8 +830,8 @@ def _bn_backward(go, y, stats, cfg, want_dbias, st):
     dy = torch.empty_like(y)
     dgb = _empty((3, C), y)                   # rows: producer bias, gamma, beta -- the order the parameters have in a block
     wp, wn = _ws(wsb, y)
-    call('da_bn_act_bwd_dbias', ptr(go), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-         slope, 1 if train else 0, ptr(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, wp, wn, st)
+    call_act('da_bn_act_bwd_dbias', A(go), A(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             slope, 1 if train else 0, O(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, wp, wn, st)
     return dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None)
 
 
@@ -759,12 +860,12 @@ def _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, wp
     if pro1 is not None or pro2 is not None:
         s1, t1, sl1 = _pro_args(pro1)
         s2, t2, sl2 = _pro_args(pro2)
-        if call_supported('da_conv3d_k3_wgrad_pro', ptr(a1), C1, s1, t1, sl1, ptr(a2), C2, s2, t2, sl2, ptr(dy), ptr(dw_tio),
-                          N, D, H, W, Cout, wp, wn, st):
+        if call_act('da_conv3d_k3_wgrad_pro', A(a1), C1, s1, t1, sl1, A(a2), C2, s2, t2, sl2, A(dy), ptr(dw_tio),
+                    N, D, H, W, Cout, wp, wn, st, may_decline=True):
             return
         a1 = _apply_pro(a1, pro1, st)
         a2 = _apply_pro(a2, pro2, st) if a2 is not None else None
-    call('da_conv3d_k3_wgrad', ptr(a1), C1, ptr(a2), C2, ptr(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
+    call_act('da_conv3d_k3_wgrad', A(a1), C1, A(a2), C2, A(dy), ptr(dw_tio), None, N, D, H, W, Cout, 1, wp, wn, st)
 
 
 class ConvBNActFn(Function):
@@ -790,7 +891,7 @@ class ConvBNActFn(Function):
             raise ValueError('weight %s does not match input channels %d+%d' % (tuple(weight.shape), C1, C2))
         st = stream()
         w_tio = weight_tio(weight, 'iok_flip' if transposed else 'oik')
-        y = _empty((N, D, H, W, Cout), a1)
+        y = _empty((N, D, H, W, Cout), a1, _act_dtype(Cout))
         wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, 1)
         wp, wn = _ws(wsb, a1)
         b = bias.detach().contiguous() if bias is not None else None
@@ -804,17 +905,17 @@ class ConvBNActFn(Function):
         if pro1 is not None or pro2 is not None:
             s1, t1, sl1 = _pro_args(pro1)
             s2, t2, sl2 = _pro_args(pro2)
-            done = call_supported('da_conv3d_k3_fwd_pro', ptr(a1), C1, s1, t1, sl1, ptr(a2), C2, s2, t2, sl2, ptr(w_tio), ptr(b), ptr(y),
-                                  N, D, H, W, Cout, -1.0, ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st)
+            done = call_act('da_conv3d_k3_fwd_pro', A(a1), C1, s1, t1, sl1, A(a2), C2, s2, t2, sl2, ptr(w_tio), ptr(b), O(y),
+                            N, D, H, W, Cout, -1.0, ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st, may_decline=True)
             if not done:           # shape not taken by the prologue kernels: apply the deferred activation as its own pass
                 a1, a2, pro1, pro2 = _apply_pro(a1, pro1, st), (_apply_pro(a2, pro2, st) if a2 is not None else None), None, None
         if not done:
             if train_stats:
                 # the MFMA epilogue accumulates the BatchNorm partial sums, so the statistics need no pass over y
-                call('da_conv3d_k3_fwd_bnstats', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1,
-                     ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st)
+                call_act('da_conv3d_k3_fwd_bnstats', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(y), N, D, H, W, Cout, 1,
+                         ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st)
             else:
-                call('da_conv3d_k3_fwd', ptr(a1), C1, ptr(a2), C2, ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
+                call_act('da_conv3d_k3_fwd', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(y), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
         if train_stats:
             partials = (pbuf, npar.value)
         out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials,
@@ -845,10 +946,10 @@ class ConvBNActFn(Function):
         wp, wn = _ws(wsb, a1)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
-            dx1 = _empty(a1.shape, a1)
-            dx2 = _empty(a2.shape, a1) if a2 is not None else None
+            dx1 = torch.empty_like(a1)
+            dx2 = torch.empty_like(a2) if a2 is not None else None
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
-            call('da_conv3d_k3_dgrad', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
+            call_act('da_conv3d_k3_dgrad', A(dy), ptr(w_tio), O(dx1), C1, O(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
         gw = _async_target(ctx.wparam) if ctx.needs_input_grad[2] else None
         if not ctx.needs_input_grad[2]:
             dw = None                                  # frozen weight: no weight-gradient kernel at all
@@ -888,7 +989,7 @@ class DeconvBNActFn(Function):
             raise ValueError('ConvTranspose3d weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
         st = stream()
         w_tio = weight_tio(weight, 'iok')
-        y = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a)
+        y = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a, _act_dtype(Cout))
         b = bias.detach().contiguous() if bias is not None else None
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
         partials = None
@@ -898,10 +999,10 @@ class DeconvBNActFn(Function):
             nblk = (N * D * H * W + 255) // 256
             pbuf = torch.empty((nblk, 2, Cout), dtype=torch.float64, device=a.device)
             npar = ctypes.c_int(0)
-            call('da_deconv_k2s2_fwd_bnstats', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, ptr(pbuf), nblk, ctypes.byref(npar), wp, wn, st)
+            call_act('da_deconv_k2s2_fwd_bnstats', A(a), ptr(w_tio), ptr(b), O(y), N, D, H, W, Cin, Cout, ptr(pbuf), nblk, ctypes.byref(npar), wp, wn, st)
             partials = (pbuf, npar.value)
         else:
-            call('da_deconv_k2s2_fwd', ptr(a), ptr(w_tio), ptr(b), ptr(y), N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_deconv_k2s2_fwd', A(a), ptr(w_tio), ptr(b), O(y), N, D, H, W, Cin, Cout, wp, wn, st)
         out, stats, g, cfg = _bn_forward(y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, st, partials, apply=not lazy_out)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
@@ -926,7 +1027,7 @@ class DeconvBNActFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
             wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
-            call('da_deconv_k2s2_dgrad', ptr(dy), ptr(w_tio), ptr(dx), N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_deconv_k2s2_dgrad', A(dy), ptr(w_tio), O(dx), N, D, H, W, Cin, Cout, wp, wn, st)
         gw = _async_target(ctx.wparam) if ctx.needs_input_grad[1] else None
         if not ctx.needs_input_grad[1]:
             dw = None                                  # frozen weight
@@ -934,14 +1035,14 @@ class DeconvBNActFn(Function):
             def side_work():                        # HBM-bound: overlaps the MFMA-bound conv data gradients on the main stream
                 dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
-                call('da_deconv_k2s2_wgrad', ptr(a), ptr(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, swp, swn, stream())
+                call_act('da_deconv_k2s2_wgrad', A(a), A(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, swp, swn, stream())
                 grad_from_tio(dw_tio, 'iok', gw.shape, acc=gw)
             _run_on_side(side_work, (a, dy))
             dw = None
         else:
             dw_tio = torch.empty_like(w_tio)
             wp, wn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
-            call('da_deconv_k2s2_wgrad', ptr(a), ptr(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, wp, wn, st)
+            call_act('da_deconv_k2s2_wgrad', A(a), A(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, wp, wn, st)
             dw = _empty((Cin, Cout, 2, 2, 2), a)
             call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
         db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, db, dgamma, dbeta)
@@ -958,7 +1059,7 @@ class ActFn(Function):
         ones = torch.ones(C, dtype=torch.float32, device=a.device)
         zeros = torch.zeros(C, dtype=torch.float32, device=a.device)
         out = torch.empty_like(a)
-        call('da_bn_act_fwd', ptr(a), ptr(ones), ptr(zeros), float(slope), ptr(out), a.numel() // C, C, stream())
+        call_act('da_bn_act_fwd', A(a), ptr(ones), ptr(zeros), float(slope), O(out), a.numel() // C, C, stream())
         ctx.slope = float(slope)
         ctx.save_for_backward(out)
         return ncdhw(out)
@@ -968,7 +1069,7 @@ class ActFn(Function):
         out, = ctx.saved_tensors
         g = ndhwc(gout)
         dx = torch.empty_like(out)
-        call('da_act_bwd', ptr(g), ptr(out), ctx.slope, ptr(dx), g.numel(), stream())
+        call_act('da_act_bwd', A(g), A(out), ctx.slope, O(dx), g.numel(), stream())
         return ncdhw(dx), None
 
 
@@ -982,8 +1083,8 @@ class MaxPool2Fn(Function):
     def forward(ctx, x):
         a = ndhwc(x)
         N, D, H, W, C = a.shape
-        out = _empty((N, D // 2, H // 2, W // 2, C), a)
-        call('da_maxpool2_fwd', ptr(a), ptr(out), N, D, H, W, C, stream())
+        out = _empty((N, D // 2, H // 2, W // 2, C), a, a.dtype)
+        call_act('da_maxpool2_fwd', A(a), O(out), N, D, H, W, C, stream())
         ctx.save_for_backward(a)
         return ncdhw(out)
 
@@ -993,7 +1094,7 @@ class MaxPool2Fn(Function):
         N, D, H, W, C = a.shape
         g = ndhwc(gout)
         dx = torch.empty_like(a)
-        call('da_maxpool2_bwd', ptr(g), ptr(a), ptr(dx), N, D, H, W, C, stream())
+        call_act('da_maxpool2_bwd', A(g), A(a), O(dx), N, D, H, W, C, stream())
         return ncdhw(dx)
 
 
@@ -1008,16 +1109,16 @@ class MaxPool2SkipFn(Function):
         ctx.n_extra = len(extra)
         a = ndhwc(x)
         N, D, H, W, C = a.shape
-        out = _empty((N, D // 2, H // 2, W // 2, C), a)
+        out = _empty((N, D // 2, H // 2, W // 2, C), a, a.dtype)
         st = stream()
         if extra:
             act = torch.empty_like(a)
-            if not call_supported('da_maxpool2_fwd_pro', ptr(a), ptr(extra[0]), ptr(extra[1]), float(extra[2]), ptr(act), ptr(out), N, D, H, W, C, st):
+            if not call_act('da_maxpool2_fwd_pro', A(a), ptr(extra[0]), ptr(extra[1]), float(extra[2]), O(act), O(out), N, D, H, W, C, st, may_decline=True):
                 act = _apply_pro(a, extra, st)
-                call('da_maxpool2_fwd', ptr(act), ptr(out), N, D, H, W, C, st)
+                call_act('da_maxpool2_fwd', A(act), O(out), N, D, H, W, C, st)
             a = act
         else:
-            call('da_maxpool2_fwd', ptr(a), ptr(out), N, D, H, W, C, st)
+            call_act('da_maxpool2_fwd', A(a), O(out), N, D, H, W, C, st)
         ctx.save_for_backward(a)
         return ncdhw(a), ncdhw(out)
 
@@ -1030,9 +1131,9 @@ class MaxPool2SkipFn(Function):
         g = ndhwc(gpool)
         dx = torch.empty_like(a)
         if gskip is None:
-            call('da_maxpool2_bwd', ptr(g), ptr(a), ptr(dx), N, D, H, W, C, stream())
+            call_act('da_maxpool2_bwd', A(g), A(a), O(dx), N, D, H, W, C, stream())
         else:
-            call('da_maxpool2_bwd_add', ptr(g), ptr(a), ptr(ndhwc(gskip)), ptr(dx), N, D, H, W, C, stream())
+            call_act('da_maxpool2_bwd_add', A(g), A(a), A(ndhwc(gskip)), O(dx), N, D, H, W, C, stream())
         return (ncdhw(dx),) + (None,) * ctx.n_extra
 
 
@@ -1044,8 +1145,8 @@ class UpsampleNearestFn(Function):
         a = ndhwc(x)
         N, D, H, W, C = a.shape
         Do, Ho, Wo = int(size[0]), int(size[1]), int(size[2])
-        out = _empty((N, Do, Ho, Wo, C), a)
-        call('da_upsample_nearest_fwd', ptr(a), ptr(out), N, D, H, W, C, Do, Ho, Wo, stream())
+        out = _empty((N, Do, Ho, Wo, C), a, a.dtype)
+        call_act('da_upsample_nearest_fwd', A(a), O(out), N, D, H, W, C, Do, Ho, Wo, stream())
         ctx.dims = (N, D, H, W, C, Do, Ho, Wo)
         return ncdhw(out)
 
@@ -1053,8 +1154,8 @@ class UpsampleNearestFn(Function):
     def backward(ctx, gout):
         N, D, H, W, C, Do, Ho, Wo = ctx.dims
         g = ndhwc(gout)
-        dx = _empty((N, D, H, W, C), g)
-        call('da_upsample_nearest_bwd', ptr(g), ptr(dx), N, D, H, W, C, Do, Ho, Wo, stream())
+        dx = _empty((N, D, H, W, C), g, g.dtype)
+        call_act('da_upsample_nearest_bwd', A(g), O(dx), N, D, H, W, C, Do, Ho, Wo, stream())
         return ncdhw(dx), None
 
 
@@ -1196,8 +1297,8 @@ class HeadDiceFn(Function):
         wsb = nat.lib().da_head_dice_ws_bytes(N, V, Cin, C)
         wp, wn = _ws(wsb, a)
         ps, pt, sl = _pro_args(pro)
-        call('da_head_dice_fwd', ptr(a), ps, pt, sl, ptr(w_io), ptr(b), ptr(lab), lb, N, V, Cin, C, _WEIGHT_TYPES[weight_type], 1 if no_bg else 0,
-             float(eps), ptr(loss), ptr(coef), wp, wn, st)
+        call_act('da_head_dice_fwd', A(a), ps, pt, sl, ptr(w_io), ptr(b), ptr(lab), lb, N, V, Cin, C, _WEIGHT_TYPES[weight_type], 1 if no_bg else 0,
+                 float(eps), ptr(loss), ptr(coef), wp, wn, st)
         ctx.cfg = (N, V, Cin, C, lb, wsb, pro[2] if pro is not None else -1.0, bias is not None)
         ctx.save_for_backward(a, w_io, b, lab, coef, pro[0] if pro is not None else None, pro[1] if pro is not None else None)
         return loss.reshape(())
@@ -1212,8 +1313,8 @@ class HeadDiceFn(Function):
         dw_io = torch.empty_like(w_io)
         db = _empty((C,), a) if has_bias else None
         wp, wn = _ws(wsb, a)
-        call('da_head_dice_bwd', ptr(a), ptr(ps), ptr(pt), float(sl), ptr(w_io), ptr(b), ptr(lab), lb, ptr(coef), ptr(gl),
-             ptr(dx), ptr(dw_io), ptr(db), N, V, Cin, C, wp, wn, st)
+        call_act('da_head_dice_bwd', A(a), ptr(ps), ptr(pt), float(sl), ptr(w_io), ptr(b), ptr(lab), lb, ptr(coef), ptr(gl),
+                 O(dx), ptr(dw_io), ptr(db), N, V, Cin, C, wp, wn, st)
         dw = _empty((C, Cin, 1, 1, 1), a)
         call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), C, Cin, 1, st)
         return (ncdhw(dx), dw, db, None, None, None, None) + (None,) * ctx.n_extra

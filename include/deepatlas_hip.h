@@ -420,6 +420,93 @@ int da_adam_step(float* p, const float* g, float* m, float* v, long long n,
 int da_adam_host_state(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* state6_host);
 int da_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float* state6, void* stream);
 
+/* =====================================================================================================================
+ * bf16 ACTIVATION STORAGE (BASELINE.json configs[4]: "bf16 mixed precision"; SURVEY.md 8(d) config 5: "bf16 activations / MFMA, fp32
+ * master weights, fp32 reductions").  The reference has no such mode (train_seg.py is fp32-only); these are the `_bf16` twins of the
+ * entries above for a network whose INTERNAL activation and gradient tensors are stored as bf16 (same NDHWC layout, 2 bytes per element).
+ * `void*` arguments are those bf16 tensors; every `float*` keeps its meaning (weights, biases, statistics, scale / shift, weight and bias
+ * gradients, logits and their gradient, losses).  Arithmetic is fp32 (double in the reductions); a value is rounded to nearest-even once,
+ * when it is stored.  BatchNorm statistics fused into a producer's epilogue are those of the fp32 values before that rounding.
+ * The convolution twins need the bf16 matrix mode (da_set_matrix_mode(1)) and the matrix-core shapes; DA_ERR_UNSUPPORTED otherwise -- the
+ * caller then converts with da_cast_* around the fp32 entry (deepatlas_amd/ops.py: call_act).
+ * ===================================================================================================================== */
+int da_cast_f32_to_bf16(const float* x, void* y, long long numel, void* stream);
+int da_cast_bf16_to_f32(const void* x, float* y, long long numel, void* stream);
+/* norm_act.hip */
+int da_bn_train_stats_bf16(const void* x, long long M, int C, const float* gamma, const float* beta,
+                           float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* rstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+int da_bn_act_fwd_bf16(const void* x, const float* scale, const float* shift, float act_slope, void* y, long long M, int C, void* stream);
+int da_bn_act_bwd_dbias_bf16(const void* dy, const void* x, const float* mean, const float* rstd,
+                             const float* scale, const float* shift, float act_slope, int train,
+                             void* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                             void* ws, size_t ws_bytes, void* stream);
+int da_act_bwd_bf16(const void* dy, const void* y, float act_slope, void* dx, long long numel, void* stream);
+int da_act_bwd_add_dbias_bf16(const void* g1, const void* g2, const void* y, float act_slope, void* dx, float* dbias,
+                              long long M, int C, void* ws, size_t ws_bytes, void* stream);
+int da_act_bwd_add_partial_bf16(const void* g1, const void* g2, const void* y, float act_slope, void* dx,
+                                long long M, int C, void* partial, size_t partial_bytes, int* nparts, void* stream);
+int da_colsum_bf16(const void* x, long long M, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+/* pool.hip */
+int da_maxpool2_fwd_bf16(const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
+int da_maxpool2_fwd_pro_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope, void* act, void* y,
+                             int N, int D, int H, int W, int C, void* stream);      /* the maximum is taken over the ROUNDED activations */
+int da_maxpool2_bwd_bf16(const void* dy, const void* x, void* dx, int N, int D, int H, int W, int C, void* stream);
+int da_maxpool2_bwd_add_bf16(const void* dy, const void* x, const void* gskip, void* dx, int N, int D, int H, int W, int C, void* stream);
+int da_upsample_nearest_fwd_bf16(const void* x, void* y, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream);
+int da_upsample_nearest_bwd_bf16(const void* dy, void* dx, int N, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream);
+/* conv3d.hip / conv3d_mfma.hip: `bf16_mask` = one bit per activation argument in signature order (set = bf16).  Native: all set. */
+int da_conv3d_k3_fwd_bf16(const void* in1, int C1, const void* in2, int C2, const float* w_tio, const float* bias, void* out,
+                          int N, int D, int H, int W, int Cout, int stride, float act_slope,
+                          void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask);
+int da_conv3d_k3_fwd_bnstats_bf16(const void* in1, int C1, const void* in2, int C2, const float* w_tio, const float* bias, void* out,
+                                  int N, int D, int H, int W, int Cout, int stride,
+                                  double* stats_partial, int stats_capacity, int* stats_nparts,
+                                  void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask);
+int da_conv3d_k3_fwd_pro_bf16(const void* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                              const void* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                              const float* w_tio, const float* bias, void* out,
+                              int N, int D, int H, int W, int Cout, float act_slope,
+                              double* stats_partial, int stats_capacity, int* stats_nparts,
+                              void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask);
+int da_conv3d_k3_wgrad_pro_bf16(const void* in1, int C1, const float* pro1_scale, const float* pro1_shift, float pro1_slope,
+                                const void* in2, int C2, const float* pro2_scale, const float* pro2_shift, float pro2_slope,
+                                const void* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
+                                void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask);
+int da_conv3d_k3_dgrad_bf16(const void* dy, const float* w_tio, void* dx1, int C1, void* dx2, int C2,
+                            int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask);
+int da_conv3d_k3_wgrad_bf16(const void* in1, int C1, const void* in2, int C2, const void* dy, float* dw_tio, float* dbias,
+                            int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask);
+/* deconv.hip / pointwise_mfma.hip: transposed conv k2 s2 (input, output, their gradients bf16); 1x1x1 head (input and its gradient
+ * bf16; logits and their gradient fp32) */
+int da_deconv_k2s2_fwd_bf16(const void* in, const float* w_tio, const float* bias, void* out,
+                            int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_deconv_k2s2_fwd_bnstats_bf16(const void* in, const float* w_tio, const float* bias, void* out,
+                                    int N, int D, int H, int W, int Cin, int Cout,
+                                    double* stats_partial, int stats_capacity, int* stats_nparts, void* ws, size_t ws_bytes, void* stream);
+int da_deconv_k2s2_dgrad_bf16(const void* dy, const float* w_tio, void* dx,
+                              int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_deconv_k2s2_wgrad_bf16(const void* in, const void* dy, float* dw_tio, float* dbias,
+                              int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_fwd_bf16(const void* in, const float* w_io, const float* bias, float* out,
+                        long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_fwd_pro_bf16(const void* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                            const float* w_io, const float* bias, float* out, long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_dgrad_bf16(const float* dy, const float* w_io, void* dx, long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_wgrad_bf16(const void* in, const float* dy, float* dw_io, float* dbias,
+                          long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int da_conv1x1_wgrad_pro_bf16(const void* in, const float* pro_scale, const float* pro_shift, float pro_slope,
+                              const float* dy, float* dw_io, float* dbias, long long M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* headdice.hip: fused head + softmax + Dice with a bf16 input x and a bf16 gradient dx */
+int da_head_dice_fwd_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                          const float* w_io, const float* bias, const void* labels, int label_bytes,
+                          int N, long long V, int Cin, int C, int weight_type, int no_bg, float eps,
+                          float* loss, float* coef, void* ws, size_t ws_bytes, void* stream);
+int da_head_dice_bwd_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                          const float* w_io, const float* bias, const void* labels, int label_bytes,
+                          const float* coef, const float* dloss, void* dx, float* dw_io, float* dbias,
+                          int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,6 +168,72 @@ def closed_form_labels(shape, n_classes, seed=0):
 # Cout >= 8, Cout % 4 == 0) are passed through it before the fp32 convolution, e.g. lambda t: t.bfloat16().float().
 K3_OPERAND_ROUND = None
 
+# Optional emulation of the product's bf16 ACTIVATION STORAGE (ops.set_activation_storage('bf16'); not a reference feature).  When set to a
+# callable (e.g. lambda t: t.bfloat16().float()) every tensor the product stores between two layers -- convolution / transposed-convolution
+# outputs and BatchNorm + activation outputs with >= 8 channels -- passes through it, and so does every gradient tensor the product stores
+# (the gradient arriving at each consumer's input, and the summed gradient of a stored tensor).  BatchNorm then follows the product's
+# arithmetic: batch statistics from the fp32 convolution result BEFORE it is rounded (they are accumulated in the convolution's epilogue;
+# layers with <= 4 input channels run their statistics as a pass over the stored tensor), normalisation and backward on the ROUNDED tensor.
+ACT_STORE_ROUND = None
+
+
+class _StoreRound(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ACT_STORE_ROUND(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ACT_STORE_ROUND(g)
+
+
+def _store(t, channels=None):
+    """A stored tensor / a consumer's input edge under ACT_STORE_ROUND (identity otherwise; thin tensors -- the 1- or 2-channel network
+    inputs, the 3-channel displacement field -- stay fp32 in the product)."""
+    c = t.shape[1] if channels is None else channels
+    if ACT_STORE_ROUND is None or not (c >= 8 and c % 4 == 0):
+        return t
+    return _StoreRound.apply(t)
+
+
+class _BNGivenStats(torch.autograd.Function):
+    """(x - mean) * rstd * gamma + beta with batch statistics computed elsewhere; the backward is the standard BatchNorm backward evaluated
+    on x (norm_act.hip: bn_act_bwd_apply_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, rstd, gamma, beta):
+        sh = (1, -1, 1, 1, 1)
+        xh = (x - mean.view(sh)) * rstd.view(sh)
+        ctx.save_for_backward(xh, rstd, gamma)
+        return xh * gamma.view(sh) + beta.view(sh)
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, rstd, gamma = ctx.saved_tensors
+        sh = (1, -1, 1, 1, 1)
+        dims = (0, 2, 3, 4)
+        M = g.numel() // g.shape[1]
+        s1 = g.sum(dims); s2 = (g * xh).sum(dims)
+        dx = (gamma * rstd).view(sh) * (g - (s1 / M).view(sh) - xh * (s2 / M).view(sh))
+        return dx, None, None, s2, s1
+
+
+def _bn_train_stored(y, sd, prefix, momentum, eps, stats_from_stored):
+    """Training-mode BatchNorm of a convolution result under ACT_STORE_ROUND (see there); returns the normalised ROUNDED tensor."""
+    yr = _store(y)
+    src = (yr if stats_from_stored else y).detach()
+    dims = (0, 2, 3, 4)
+    M = src.numel() // src.shape[1]
+    mean = src.double().mean(dims)
+    var = (src.double() ** 2).mean(dims) - mean ** 2
+    var = var.clamp_min(0.0)
+    rstd = (1.0 / torch.sqrt(var + eps)).float()
+    rm, rv = sd[f'{prefix}.BN.running_mean'], sd[f'{prefix}.BN.running_var']
+    with torch.no_grad():
+        rm.mul_(1 - momentum).add_(momentum * mean.float())
+        rv.mul_(1 - momentum).add_(momentum * (var * (M / max(M - 1, 1))).float())
+    return _BNGivenStats.apply(yr, mean.float(), rstd, sd[f'{prefix}.BN.weight'], sd[f'{prefix}.BN.bias'])
+
 
 def _conv_bn_act(x, sd, prefix, slope, training, conv_name='conv', stride=1, padding=1, momentum=0.1, eps=1e-5):
     """unets.py:24-39 convBlock: Conv3d -> BatchNorm3d -> LeakyReLU(0.01)."""
@@ -175,26 +241,32 @@ def _conv_bn_act(x, sd, prefix, slope, training, conv_name='conv', stride=1, pad
     b = sd.get(f'{prefix}.{conv_name}.bias')
     if K3_OPERAND_ROUND is not None and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[1] % 8 == 0 and w.shape[0] >= 8 and w.shape[0] % 4 == 0:
         x, w = K3_OPERAND_ROUND(x), K3_OPERAND_ROUND(w)
-    y = F.conv3d(x, w, b, stride=stride, padding=padding)
+    y = F.conv3d(_store(x), w, b, stride=stride, padding=padding)
     if f'{prefix}.BN.weight' in sd:
-        y = F.batch_norm(y, sd[f'{prefix}.BN.running_mean'], sd[f'{prefix}.BN.running_var'],
-                         sd[f'{prefix}.BN.weight'], sd[f'{prefix}.BN.bias'], training, momentum, eps)
+        if ACT_STORE_ROUND is not None and training:
+            y = _bn_train_stored(y, sd, prefix, momentum, eps, stats_from_stored=w.shape[1] <= 4)
+        else:
+            y = F.batch_norm(_store(y), sd[f'{prefix}.BN.running_mean'], sd[f'{prefix}.BN.running_var'],
+                             sd[f'{prefix}.BN.weight'], sd[f'{prefix}.BN.bias'], training, momentum, eps)
         if training:
             sd[f'{prefix}.BN.num_batches_tracked'] += 1
-    return F.leaky_relu(y, slope) if slope else F.relu(y)
+    return _store(F.leaky_relu(y, slope) if slope else F.relu(y))
 
 
 def _deconv_bn_act(x, sd, prefix, slope, training, momentum=0.1, eps=1e-5):
     """unets.py:42-58 deconvBlock: ConvTranspose3d(k2,s2) -> BN -> act."""
     w = sd[f'{prefix}.deconv.weight']
     b = sd.get(f'{prefix}.deconv.bias')
-    y = F.conv_transpose3d(x, w, b, stride=2)
+    y = F.conv_transpose3d(_store(x), w, b, stride=2)
     if f'{prefix}.BN.weight' in sd:
-        y = F.batch_norm(y, sd[f'{prefix}.BN.running_mean'], sd[f'{prefix}.BN.running_var'],
-                         sd[f'{prefix}.BN.weight'], sd[f'{prefix}.BN.bias'], training, momentum, eps)
+        if ACT_STORE_ROUND is not None and training:
+            y = _bn_train_stored(y, sd, prefix, momentum, eps, stats_from_stored=False)
+        else:
+            y = F.batch_norm(_store(y), sd[f'{prefix}.BN.running_mean'], sd[f'{prefix}.BN.running_var'],
+                             sd[f'{prefix}.BN.weight'], sd[f'{prefix}.BN.bias'], training, momentum, eps)
         if training:
             sd[f'{prefix}.BN.num_batches_tracked'] += 1
-    return F.leaky_relu(y, slope) if slope else F.relu(y)
+    return _store(F.leaky_relu(y, slope) if slope else F.relu(y))
 
 
 def unet_forward(sd, x, spec, training=True):
@@ -216,7 +288,7 @@ def unet_forward(sd, x, spec, training=True):
         if i < levels - 1:
             temp.append(x)
             if maxpool:
-                x = F.max_pool3d(x, 2)                               # unets.py:230,267
+                x = F.max_pool3d(_store(x), 2)                       # unets.py:230,267
             else:                                                    # strided conv k2 s2 p0, no BN / act (unets.py:231-233)
                 x = F.conv3d(x, sd[f'down_samplers.{i}.weight'], sd.get(f'down_samplers.{i}.bias'), stride=2)
     nconv_dec = len(encoders[-1]) - (0 if levels == 1 else 1)        # leaked `enc` quirk unets.py:247
@@ -225,11 +297,11 @@ def unet_forward(sd, x, spec, training=True):
             x = F.interpolate(x, scale_factor=2, mode='trilinear', align_corners=False)
         else:
             x = _deconv_bn_act(x, sd, f'up_samplers.{j}', slope, training)
-        y = torch.cat((x, temp.pop()), dim=1)                         # up-sampled first, skip second (:275)
+        y = torch.cat((_store(x), _store(temp.pop())), dim=1)         # up-sampled first, skip second (:275)
         for k in range(nconv_dec):
             y = _conv_bn_act(y, sd, f'decoders.decBlock{j}.{k}', slope, training)
         if j == len(decoders) - 1:                                    # 1x1x1 head, no BN / act (:249-250)
-            y = F.conv3d(y, sd[f'decoders.decBlock{j}.{nconv_dec}.weight'],
+            y = F.conv3d(_store(y), sd[f'decoders.decBlock{j}.{nconv_dec}.weight'],
                          sd.get(f'decoders.decBlock{j}.{nconv_dec}.bias'))
         x = (y + x) if res else y                                     # (:275)
     return x
@@ -257,7 +329,7 @@ def _vm_conv(x, sd, prefix, stride):
     w = sd[f'{prefix}.conv.weight']
     if K3_OPERAND_ROUND is not None and w.shape[1] % 8 == 0 and w.shape[0] >= 8 and w.shape[0] % 4 == 0:      # (see K3_OPERAND_ROUND)
         x, w = K3_OPERAND_ROUND(x), K3_OPERAND_ROUND(w)
-    return F.relu(F.conv3d(x, w, sd[f'{prefix}.conv.bias'], stride=stride, padding=1))
+    return _store(F.relu(F.conv3d(_store(x), w, sd[f'{prefix}.conv.bias'], stride=stride, padding=1)))
 
 
 def voxelmorph_forward(sd, source, target):
@@ -272,7 +344,7 @@ def voxelmorph_forward(sd, source, target):
     d3 = _vm_conv(F.interpolate(torch.cat((d2, e3), 1), size=e2.shape[2:]), sd, 'decoders.2', 1)
     d4 = _vm_conv(torch.cat((d3, e2), 1), sd, 'decoders.3', 1)
     d5 = _vm_conv(F.interpolate(d4, size=e1.shape[2:]), sd, 'decoders.4', 1)
-    disp = F.conv3d(torch.cat((d5, e1), 1), sd['flow.weight'], sd['flow.bias'], padding=1)
+    disp = F.conv3d(_store(torch.cat((d5, e1), 1)), sd['flow.weight'], sd['flow.bias'], padding=1)
     deform = disp + identity_transform(source.shape[2:], disp.dtype)
     warped = warp_trilinear(source, deform)
     return disp, warped, deform

@@ -23,6 +23,8 @@ def _reset_process_wide_switches():
         mod.enable_async_wgrad(False)
         mod.set_deterministic(False)
         mod.set_matrix_precision('fp32')          # experiments switch to 'fp32_split'; the library default is the fp32 matrix instructions
+        mod.set_activation_storage('fp32')
+        mod.BF16_FORCE_BRIDGE = False
 
 
 @pytest.fixture(scope='session')
