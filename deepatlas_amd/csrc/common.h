@@ -91,6 +91,7 @@ __device__ __forceinline__ unsigned da_pack_bf16x2(float lo, float hi) {      //
 }
 __device__ __forceinline__ float da_bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float da_bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ float da_round_bf16(float v) { return da_bf16_lo(da_pack_bf16x2(v, 0.f)); }      // the value a bf16 store + load round trip yields
 __device__ __forceinline__ float4 da_unpack_bf16x4(uint2 u) { return make_float4(da_bf16_lo(u.x), da_bf16_hi(u.x), da_bf16_lo(u.y), da_bf16_hi(u.y)); }
 __device__ __forceinline__ uint2 da_pack_bf16x4(float4 v) { return make_uint2(da_pack_bf16x2(v.x, v.y), da_pack_bf16x2(v.z, v.w)); }
 

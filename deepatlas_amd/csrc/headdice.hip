@@ -72,6 +72,7 @@ __device__ __forceinline__ void hd_probs(const HdP& p, const T* __restrict__ xs,
             for (int t = 0; t < MT; ++t) {
                 a[t][c].x = hd_act01(a[t][c].x * sc.x + sf.x, p.pslope); a[t][c].y = hd_act01(a[t][c].y * sc.y + sf.y, p.pslope);
                 a[t][c].z = hd_act01(a[t][c].z * sc.z + sf.z, p.pslope); a[t][c].w = hd_act01(a[t][c].w * sc.w + sf.w, p.pslope);
+                if constexpr (DaEl<T>::bf) a[t][c] = da_unpack_bf16x4(da_pack_bf16x4(a[t][c]));      // bf16 storage: what a stored activation would hold
             }
         }
     }

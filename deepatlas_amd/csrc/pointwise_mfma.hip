@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                 for (int r = 0; r < MT; ++r) {
                     a[r][c].x = pw_act01(a[r][c].x * sc.x + sf.x, p.pslope); a[r][c].y = pw_act01(a[r][c].y * sc.y + sf.y, p.pslope);
                     a[r][c].z = pw_act01(a[r][c].z * sc.z + sf.z, p.pslope); a[r][c].w = pw_act01(a[r][c].w * sc.w + sf.w, p.pslope);
+                    // bf16 storage: the consumer sees what a materialised (stored) activation would hold
+                    if constexpr (DaEl<TA>::bf) a[r][c] = da_unpack_bf16x4(da_pack_bf16x4(a[r][c]));
                 }
             }
         }
@@ -340,7 +342,10 @@ __global__ void __launch_bounds__(256) pw_mfma_wgrad_kernel(PwWgP p) {
     auto apply_pro = [&](float* av, bool ok) {
         if (pro) {
 #pragma unroll
-            for (int a = 0; a < CIT; ++a) av[a] = ok ? pw_act01(av[a] * psc[a] + psf[a], p.pslope) : 0.f;
+            for (int a = 0; a < CIT; ++a) {
+                av[a] = ok ? pw_act01(av[a] * psc[a] + psf[a], p.pslope) : 0.f;
+                if constexpr (DaEl<TI>::bf) av[a] = da_round_bf16(av[a]);      // (see pw_mfma_kernel)
+            }
         }
     };
     float avA[CIT], bvA[TPB][COT], avB[CIT], bvB[TPB][COT];

@@ -111,10 +111,11 @@ def call_act(name, *args, may_decline=False):
                 return True
     # bridge
     st = stream()
-    conv, outs = [], []
+    conv, outs, keep = [], [], []          # keep: the fp32 scratch tensors stay referenced until the entry has been queued
     for a in args:
         if isinstance(a, A) and a.t is not None and a.t.dtype == torch.bfloat16:
             t32 = torch.empty(a.t.shape, dtype=torch.float32, device=a.t.device)
+            keep.append(t32)
             if a.out:
                 outs.append((a.t, t32))
             else:
@@ -132,6 +133,7 @@ def call_act(name, *args, may_decline=False):
         call(name, *conv)
     for t, t32 in outs:
         call('da_cast_f32_to_bf16', ptr(t32), ptr(t), t.numel(), st)
+    del keep
     return True
 
 

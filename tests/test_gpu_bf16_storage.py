@@ -17,6 +17,19 @@ def _bf16(t):
     return t.bfloat16().float()
 
 
+class _RoundSTE(torch.autograd.Function):
+    """bf16 rounding of a matrix operand whose GRADIENT passes unrounded (autograd through .bfloat16().float() would round the weight
+    gradient to bf16 as well; the product keeps it in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 @pytest.fixture()
 def bf16_storage():
     from deepatlas_amd import ops
@@ -65,7 +78,7 @@ def _device_seg_step(model, x, y, n_classes, fused_head):
 def _oracle_seg_step(sd, spec, x, y, n_classes, store_round, operand_round=True):
     from oracle import nets, steps
     sd = {k: v.clone() for k, v in sd.items()}
-    nets.K3_OPERAND_ROUND = _bf16 if operand_round else None
+    nets.K3_OPERAND_ROUND = _RoundSTE.apply if operand_round else None
     nets.ACT_STORE_ROUND = _bf16 if store_round else None
     try:
         loss, logits, grads = steps.seg_step(sd, steps.Adam(steps.trainable(sd)), x, y, spec, n_classes)
@@ -75,26 +88,136 @@ def _oracle_seg_step(sd, spec, x, y, n_classes, store_round, operand_round=True)
     return float(loss.item()), logits, grads
 
 
+def _block_records(model, x, y, n_classes):
+    """One device training step with LAZY_BN off; per block (3x3x3 conv block, transposed-conv block, head): the device's inputs, output,
+    gradient of the output and gradients of the inputs, all as fp32 CPU tensors."""
+    from deepatlas_amd import ops
+    from deepatlas_amd.lib.loss import get_loss_function
+    from deepatlas_amd.lib.network_factory import modules
+    rec = {}
+    order = []
+
+    def fhook(name):
+        def h(mod, inp, out):
+            r = rec.setdefault(name, {})
+            ins = [t for t in inp if torch.is_tensor(t)]
+            r['in'] = [t.detach().float().cpu() for t in ins]
+            r['out'] = out.detach().float().cpu()
+            r['gin'] = [None] * len(ins)
+            out.register_hook(lambda g: r.__setitem__('gout', g.detach().float().cpu()))
+            for k, t in enumerate(ins):
+                if t.requires_grad:
+                    t.register_hook(lambda g, k=k: r['gin'].__setitem__(k, g.detach().float().cpu()))
+            order.append(name)
+        return h
+    hooks = [m.register_forward_hook(fhook(n)) for n, m in model.named_modules()
+             if isinstance(m, (modules.SegBlock, modules.SegUpBlock, modules.HeadConv))]
+    crit = get_loss_function('dice')(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+    model.train()
+    model.lazy_head = False
+    model.zero_grad()
+    out = model(x.to(dev()))
+    loss = crit(out, y.to(dev()).long())
+    loss.backward()
+    ops.join_side_stream()
+    for h in hooks:
+        h.remove()
+    grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+    return rec, order, grads, float(loss.item())
+
+
 @pytest.mark.parametrize('spec_name,n_classes,shape', [('UNET_LIGHT', 32, (32, 32, 32)), ('UNET_TINY', 5, (16, 24, 32))])
-def test_seg_step_bf16_storage_vs_rounding_oracle(bf16_storage, spec_name, n_classes, shape):
+def test_every_block_bf16_storage_vs_rounding_oracle(bf16_storage, spec_name, n_classes, shape):
+    """Block by block with the DEVICE's own tensors as inputs ("teacher forcing"): the oracle block (bf16 rounding of the matrix operands and
+    of every stored tensor, statistics from the unrounded convolution result) on the device's input must reproduce the device's output, and
+    its autograd on the device's incoming gradient must reproduce the device's input / weight / bias / gamma / beta gradients.  With identical
+    inputs the only differences are bf16 rounding decisions of values that straddle a rounding boundary (one 2^-8 relative step on that
+    element).  Whole-network comparisons are not meaningful at this tolerance: this 18-block BatchNorm'd net on closed-form weights amplifies
+    an fp32 rounding difference ~1000x from input to logits, i.e. two valid bf16-storage evaluations differ by ~10 % at the logits
+    (tests/debug_bf16_layers.py prints the growth per block)."""
+    from oracle import nets
+    import torch.nn.functional as F
+    ops = bf16_storage
+    prev_lazy, ops.LAZY_BN = ops.LAZY_BN, False
+    try:
+        model, sd, spec, x, y = _seg_setup(spec_name, n_classes, shape)
+        rec, order, grads, loss = _block_records(model, x, y, n_classes)
+    finally:
+        ops.LAZY_BN = prev_lazy
+    slope = spec['slope']
+    nets.K3_OPERAND_ROUND = _RoundSTE.apply
+    nets.ACT_STORE_ROUND = _bf16
+    worst = {}
+    try:
+        for name in order:
+            r = rec[name]
+            osd = {k: v.clone() for k, v in sd.items() if k.startswith(name + '.')}
+            pnames = [k for k in osd if k.endswith(('.weight', '.bias')) and 'running' not in k]
+            for k in pnames:
+                osd[k].requires_grad_(True)
+            ins = [t.clone().requires_grad_(r['gin'][k] is not None) for k, t in enumerate(r['in'])]
+            xin = torch.cat([nets._store(t) for t in ins], dim=1) if len(ins) > 1 else ins[0]
+            if name + '.deconv.weight' in osd:
+                out = nets._deconv_bn_act(xin, osd, name, slope, True)
+            elif name + '.conv.weight' in osd:
+                out = nets._conv_bn_act(xin, osd, name, slope, True)
+            else:                                     # head: 1x1x1 convolution, fp32 logits
+                out = F.conv3d(nets._store(xin), osd[name + '.weight'], osd.get(name + '.bias'))
+            e_out = rel_l2(r['out'].numpy(), out.detach().numpy())
+            wanted = [t for t in ins if t.requires_grad] + [osd[k] for k in pnames]
+            got = torch.autograd.grad(out, wanted, grad_outputs=r['gout'], allow_unused=True)
+            errs = {'out': e_out}
+            gi = [g for g in r['gin'] if g is not None]
+            for k, g in enumerate(gi):
+                errs['dx%d' % k] = rel_l2(g.numpy(), got[k].numpy())
+            for k, pn in enumerate(pnames):
+                o = got[len(gi) + k]
+                d = grads[pn]
+                if o is None:
+                    continue
+                # conv bias in front of BatchNorm: its true gradient is zero, both sides hold rounding noise
+                if pn.endswith('conv.bias') or pn.endswith('deconv.bias'):
+                    scale = float(r['gout'].abs().sum())
+                    errs[pn.rsplit('.', 2)[-2] + '.bias'] = float((d - o).abs().max()) / max(scale, 1e-30)
+                else:
+                    errs[pn[len(name) + 1:]] = rel_l2(d.numpy(), o.detach().numpy())
+            worst[name] = errs
+    finally:
+        nets.K3_OPERAND_ROUND = None
+        nets.ACT_STORE_ROUND = None
+    for name in order:
+        print('%-24s %s' % (name, '  '.join('%s %.1e' % kv for kv in worst[name].items())))
+    for name in order:
+        for k, v in worst[name].items():
+            # outputs / data gradients: a handful of one-step flips among 1e4 - 1e6 elements; weight-type gradients: sums over all voxels of
+            # products of two bf16-rounded tensors, compared with the same sums of the oracle's (identically rounded) tensors
+            tol = 2e-3 if k in ('out', 'dx0', 'dx1') else (1e-3 if k.endswith('.bias') and k.split('.')[0] in ('conv', 'deconv') else 2e-3)
+            assert v < tol, (name, k, v, worst[name])
+
+
+@pytest.mark.parametrize('spec_name,n_classes,shape', [('UNET_LIGHT', 32, (32, 32, 32))])
+def test_seg_step_bf16_storage_network_level(bf16_storage, spec_name, n_classes, shape):
+    """Whole step: the loss agrees with the rounding oracle; the logits only at the level at which two valid bf16-storage evaluations agree
+    with each other (see test_every_block_...), which is what the oracle with and without the storage rounding shows as well; deferred
+    BatchNorm (the shipped path: activations applied in the consumer's staging) and materialised BatchNorm give the same step."""
     ops = bf16_storage
     model, sd, spec, x, y = _seg_setup(spec_name, n_classes, shape)
     loss, logits, grads = _device_seg_step(model, x, y, n_classes, fused_head=False)
     o_loss, o_logits, o_grads = _oracle_seg_step(sd, spec, x, y, n_classes, store_round=True)
     p_loss, p_logits, p_grads = _oracle_seg_step(sd, spec, x, y, n_classes, store_round=False)
-    e_logits, e_plain = rel_l2(logits.numpy(), o_logits.numpy()), rel_l2(logits.numpy(), p_logits.numpy())
-    a = np.concatenate([grads[n].numpy().reshape(-1) for n in grads])
-    b = np.concatenate([o_grads[n].numpy().reshape(-1) for n in grads])
-    c = np.concatenate([p_grads[n].numpy().reshape(-1) for n in grads])
-    e_g, e_gp = rel_l2(a, b), rel_l2(a, c)
-    print('bf16 storage %s: loss %.6f oracle %.6f (plain %.6f); logits rel-l2 %.2e (oracle without storage rounding %.2e); grads %.2e (%.2e); bridged %r'
-          % (spec_name, loss, o_loss, p_loss, e_logits, e_plain, e_g, e_gp, dict(ops.bridged_calls)))
-    # a bf16 rounding decision flips wherever the two fp32 computations straddle a rounding boundary (a 2^-9 relative step on that element);
-    # those flips, not the arithmetic, set the floor of this comparison
+    e_logits, e_oo = rel_l2(logits.numpy(), o_logits.numpy()), rel_l2(o_logits.numpy(), p_logits.numpy())
+    print('bf16 storage %s: loss %.6f oracle %.6f (without storage rounding %.6f); logits rel-l2 device-oracle %.2e, oracle with-without storage rounding %.2e; bridged %r'
+          % (spec_name, loss, o_loss, p_loss, e_logits, e_oo, dict(ops.bridged_calls)))
     assert abs(loss - o_loss) < 2e-4 * max(1.0, abs(o_loss))
-    assert e_logits < 4e-3, e_logits
-    assert e_plain > 2 * e_logits, (e_plain, e_logits)          # the emulation is what makes them agree
-    assert e_g < 5e-2, e_g
+    assert e_logits < 2.0 * e_oo + 1e-2, (e_logits, e_oo)
+    prev_lazy, ops.LAZY_BN = ops.LAZY_BN, False
+    try:
+        model2, _, _, _, _ = _seg_setup(spec_name, n_classes, shape)
+        loss2, logits2, grads2 = _device_seg_step(model2, x, y, n_classes, fused_head=False)
+    finally:
+        ops.LAZY_BN = prev_lazy
+    assert abs(loss - loss2) < 1e-6 * max(1.0, abs(loss)), (loss, loss2)
+    assert rel_l2(logits.numpy(), logits2.numpy()) < 1e-6
 
 
 def test_bf16_twins_equal_the_conversion_route(bf16_storage):
@@ -102,17 +225,24 @@ def test_bf16_twins_equal_the_conversion_route(bf16_storage):
     ops.BF16_FORCE_BRIDGE must produce the same loss and gradients (same kernels on the same values; only the staging differs)."""
     ops = bf16_storage
     res = []
-    for force in (False, True):
-        ops.BF16_FORCE_BRIDGE = force
-        ops.bridged_calls.clear()
-        model, sd, spec, x, y = _seg_setup('UNET_LIGHT', 32, (32, 32, 32))
-        res.append(_device_seg_step(model, x, y, 32, fused_head=True) + (dict(ops.bridged_calls),))
-    ops.BF16_FORCE_BRIDGE = False
+    # (materialised BatchNorm: an activation that is applied inside a consumer's staging is never stored, so the conversion route -- fp32
+    # kernels between conversions -- cannot round it the way the twins do; that route is covered by the deferred-vs-materialised check above)
+    prev_lazy, ops.LAZY_BN = ops.LAZY_BN, False
+    try:
+        for force in (False, True):
+            ops.BF16_FORCE_BRIDGE = force
+            ops.bridged_calls.clear()
+            model, sd, spec, x, y = _seg_setup('UNET_LIGHT', 32, (32, 32, 32))
+            res.append(_device_seg_step(model, x, y, 32, fused_head=True) + (dict(ops.bridged_calls),))
+    finally:
+        ops.LAZY_BN = prev_lazy
+        ops.BF16_FORCE_BRIDGE = False
     (l0, _, g0, b0), (l1, _, g1, b1) = res
     assert sum(b1.values()) > sum(b0.values()) + 20, (b0, b1)          # the forced run really took the conversion route
     assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l1)), (l0, l1)
-    a = np.concatenate([g0[n].numpy().reshape(-1) for n in g0])
-    b = np.concatenate([g1[n].numpy().reshape(-1) for n in g0])
+    names = [n for n in g0 if not n.endswith(('conv.bias', 'deconv.bias'))]      # (a bias in front of BatchNorm: true gradient zero, rounding noise)
+    a = np.concatenate([g0[n].numpy().reshape(-1) for n in names])
+    b = np.concatenate([g1[n].numpy().reshape(-1) for n in names])
     assert rel_l2(a, b) < 1e-5, rel_l2(a, b)
 
 
