@@ -38,8 +38,16 @@ PRECISION_NOTE = {
     'fp32_split': 'fp32 tensors; in the 3x3x3 convolutions every operand is split EXACTLY into three bf16 terms and a product is the sum of six '
                   'bf16 x bf16 partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate -- error against double not larger than the '
                   'fmaf chain (tests/test_gpu_split.py); everything else is plain fp32',
-    'bf16': 'operands of the 3x3x3 convolutions ROUNDED to bf16, fp32 accumulate (BASELINE configs[4]); fp32 elsewhere',
+    'bf16': 'operands of the 3x3x3 convolutions ROUNDED to bf16, fp32 accumulate; every tensor in HBM fp32 (the A/B of bf16_storage)',
+    'bf16_storage': 'BASELINE configs[4] mixed precision: activations and their gradients between the layers STORED as bf16, bf16 x bf16 -> fp32 '
+                    'matrix products, fp32 statistics / reductions / master weights / weight gradients / losses',
 }
+
+
+def set_precision(ops, mode):
+    """matrix arithmetic + activation storage of a bench leg"""
+    ops.set_matrix_precision('bf16' if mode == 'bf16_storage' else mode)
+    ops.set_activation_storage('bf16' if mode == 'bf16_storage' else 'fp32')
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
 
 # SURVEY.md section 8(d): algorithmic conv FLOPs per voxel of one TRAINING pass (forward + data gradient + weight gradient = 3 x forward)
@@ -72,13 +80,14 @@ def conv_flops(key):
 
 
 def conv_bytes(key):
-    """Algorithmic HBM bytes of one da_conv3d_k3_fwd* call: the input read once + the output written once, fp32 (weights are KBs)."""
+    """Algorithmic HBM bytes of one da_conv3d_k3_fwd* call: the input read once + the output written once (weights are KBs)."""
     d = conv_dims(key)
     if d is None or key[0] not in CONV_FWD_CALLS:
         return 0
     C1, C2, N, D, H, W, Cout, stride = d
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
-    return 4.0 * N * ((C1 + C2) * D * H * W + Cout * Do * Ho * Wo)
+    es = 2.0 if key[1] and key[1][-1] == 'bf16' else 4.0              # bf16 activation storage (the twin's key carries the flag)
+    return es * N * ((C1 + C2) * D * H * W + Cout * Do * Ho * Wo)
 
 
 def cpu_baseline(shape, batch, n_classes, budget_s=20.0, keep_reference=False):
@@ -276,12 +285,12 @@ def make_workloads(args, dev, rank, which):
     if args.graph:
         seg_step = graphed([seg_grads, lambda: opt.step()], [lambda: parallel.allreduce_gradients(opt)], [opt], 'loss')
 
-    prec = {'fp32': 'fp32', 'fp32_split': 'fp32', 'bf16': 'bf16 matrix mode'}[args.precision]
+    prec = {'fp32': 'fp32', 'fp32_split': 'fp32', 'bf16': 'bf16 matrix mode', 'bf16_storage': 'bf16 activations + bf16 matrix mode'}[args.precision]
     out = {}
     if 'seg' in which:
         if args.net == 'UNet_light':
             nm = 'seg-only UNet_light + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (BASELINE configs[1]%s)' % (
-                args.batch, shape[0], shape[1], shape[2], prec, '' if args.precision != 'bf16' else " shape with configs[4]'s precision")
+                args.batch, shape[0], shape[1], shape[2], prec, '' if not args.precision.startswith('bf16') else " shape with configs[4]'s precision")
             fl = SEG_TRAIN_FLOP_PER_VOXEL * V * args.batch
         else:
             nm = 'seg-only full UNet (32-512 ch) + softmax-Dice + Adam training step, batch %d/GPU, %dx%dx%d %s (SURVEY row f3, not a BASELINE config)' % (
@@ -351,7 +360,7 @@ def result_of(wl, dt, per_rank, world, args, launches):
              c_abi_launches_per_step=round(launches, 1))
     if wl.flops_per_step:
         r['step_tflops'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12, 2)
-        if args.precision != 'bf16':
+        if not args.precision.startswith('bf16'):
             r['step_frac_of_fp32_mfma_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
         if args.precision == 'fp32_split':
             r['step_frac_of_split_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / SPLIT_MFMA_PEAK_TFLOPS, 4)
@@ -416,7 +425,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
     ap.add_argument('--no-extra', action='store_true', help="skip the reg / joint legs and the post-run backward-kernel timing pass")
-    ap.add_argument('--precision', default='fp32_split', choices=['fp32_split', 'fp32', 'bf16'],
+    ap.add_argument('--precision', default='fp32_split', choices=['fp32_split', 'fp32', 'bf16', 'bf16_storage'],
                     help="matrix arithmetic of the 3x3x3 convolutions.  'fp32_split' (headline): fp32 operands split exactly into three bf16 "
                          "terms, six partial products per multiply on the bf16 pipe, fp32 accumulate -- fp32-accurate; 'fp32': the fp32 matrix "
                          "instructions (one fmaf per product; also timed by the default run, under extra.native_fp32_mfma); 'bf16': operands "
@@ -465,7 +474,7 @@ def main():
 
     from deepatlas_amd import _native as nat, ops
     ops.enable_async_wgrad(not args.sync_wgrad)
-    ops.set_matrix_precision(args.precision)
+    set_precision(ops, args.precision)
     shape = tuple(args.shape)
     extra_legs = [] if (args.no_extra or args.workload != 'seg' or args.net != 'UNet_light') else ['reg', 'joint']
     wls, n_classes = make_workloads(args, dev, rank, [args.workload] + extra_legs)
@@ -500,7 +509,7 @@ def main():
 
     bwd_rows = []
     peak = SPLIT_MFMA_PEAK_TFLOPS if args.precision == 'fp32_split' else FP32_MFMA_PEAK_TFLOPS
-    if prof is not None and not args.no_extra and args.precision != 'bf16':
+    if prof is not None and not args.no_extra and not args.precision.startswith('bf16'):
         # post-run pass: 3 steps with every conv call timed and the weight gradients on the MAIN stream (nothing overlaps: clean
         # per-kernel durations of the data / weight gradients).  Not part of `value`.
         ops.enable_async_wgrad(False)
@@ -521,12 +530,12 @@ def main():
         extra[leg] = dict(result_of(wls[leg], edt, eper, world, args, elaunch), final_loss=round(eloss, 6))
     if args.precision == 'fp32_split' and not args.no_extra and not args.graph:
         # the same headline workload on the fp32 matrix instructions (mode 'fp32'), same --steps / --warmup: the A/B of the split mode
-        ops.set_matrix_precision('fp32')
+        set_precision(ops, 'fp32')
         a2 = argparse.Namespace(**dict(vars(args), precision='fp32'))
         edt, eper, eloss, _, elaunch = time_workload(head, a2, world, dev, None)
         extra['native_fp32_mfma'] = dict(result_of(head, edt, eper, world, a2, elaunch), final_loss=round(eloss, 6),
                                          matrix_arithmetic=PRECISION_NOTE['fp32'])
-        ops.set_matrix_precision(args.precision)
+        set_precision(ops, args.precision)
 
     if not args.no_extra and args.workload == 'seg' and args.net == 'UNet_light' and args.precision == 'fp32_split' and tuple(shape) == (160, 192, 160) and not args.graph:
         # BASELINE configs[4]'s shape and precision, driver-timed: seg (batch 2) and the joint step (1 pair) at 192 x 224 x 192 with the 3x3x3
@@ -534,8 +543,8 @@ def main():
         # shipped fp32_split mode.  Fewer steps (the legs are 1.7x larger); fresh models.
         a4 = argparse.Namespace(**dict(vars(args), shape=[192, 224, 192], steps=max(2, min(args.steps, 6)), warmup=2))
         big = {}
-        for mode in ('bf16', 'fp32_split'):
-            ops.set_matrix_precision(mode)
+        for mode in ('bf16_storage', 'bf16', 'fp32_split'):
+            set_precision(ops, mode)
             am = argparse.Namespace(**dict(vars(a4), precision=mode))
             w4, _ = make_workloads(am, dev, rank, ['seg', 'joint'])
             for leg in ('seg', 'joint'):
@@ -543,10 +552,11 @@ def main():
                 big['%s_%s' % (leg, mode)] = dict(result_of(w4[leg], edt, eper, world, am, elaunch), final_loss=round(eloss, 6), steps=am.steps)
             del w4
             torch.cuda.empty_cache()
-        big['note'] = ("BASELINE configs[4] shape; 'bf16' = operands of the 3x3x3 convolutions rounded to bf16 (mixed precision in the matrix "
-                       "arithmetic only, not fp32-accurate); tensors in HBM are fp32 in both modes")
+        big['note'] = ("BASELINE configs[4] shape; 'bf16_storage' = configs[4]'s mixed precision (bf16 activations / gradients in HBM + bf16 matrix "
+                       "operands, fp32 everything else); 'bf16' = only the matrix operands rounded, every tensor fp32 in HBM; neither is fp32-accurate")
+        big['bf16_storage_conversion_bridges'] = dict(ops.bridged_calls)      # entry points that ran through conversion passes (no bf16 twin for the shape)
         extra['configs4_192x224x192'] = big
-        ops.set_matrix_precision(args.precision)
+        set_precision(ops, args.precision)
 
     if rank == 0:
         roofline = None
@@ -555,7 +565,7 @@ def main():
             tot_fl = sum(r['_fl'] * r['launches'] for r in rows)
             tot_ms = sum(r['total_ms'] for r in rows)
             top = rows[0]                                                       # forward call with the most time in the timed region
-            if args.precision == 'bf16':     # bf16 matrix mode: the convolutions are no longer matrix-bound -> price the call against HBM
+            if args.precision.startswith('bf16'):     # bf16 matrix mode: the convolutions are no longer matrix-bound -> price the call against HBM
                 gbs = conv_bytes(top['_key']) * top['launches'] / (top['total_ms'] * 1e-3) / 1e9
                 rl_head = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
             elif args.precision == 'fp32_split':
@@ -573,11 +583,11 @@ def main():
                             traffic_source=None, profiled_calls=CONV_FWD_CALLS,
                             all_profiled=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
                                               frac_of_step=round(tot_ms / args.steps / head_res['ms_per_step'], 3)))
-            if args.precision != 'bf16':
+            if not args.precision.startswith('bf16'):
                 pm = pmc_traffic_for(top['call'], args.precision)
                 if pm:
                     roofline.update(pm)
-            if head.flops_per_step and args.precision != 'bf16':
+            if head.flops_per_step and not args.precision.startswith('bf16'):
                 # algorithmic conv FLOPs per step / ms_per_step / the peak of the mode
                 roofline['step_frac'] = head_res['step_frac_of_split_peak' if args.precision == 'fp32_split' else 'step_frac_of_fp32_mfma_peak']
                 roofline['step_frac_of_fp32_mfma_peak'] = head_res['step_frac_of_fp32_mfma_peak']
@@ -598,12 +608,12 @@ def main():
                     all_conv_calls=dict(tflops=round(sum(r['_fl'] * r['launches'] for r in bwd_rows) / (sum(r['total_ms'] for r in bwd_rows) * 1e-3) / 1e12, 2),
                                         ms_per_step=round(sum(r['total_ms'] for r in bwd_rows) / 3, 3)))
         metric = 'training volumes/sec at 160x192x160 fp32; Dice vs CPU ref'          # BASELINE.json's metric (the default invocation)
-        if shape != (160, 192, 160) or args.precision == 'bf16':
-            metric = 'training volumes/sec at %dx%dx%d %s' % (shape[0], shape[1], shape[2], 'fp32' if args.precision != 'bf16' else 'bf16 matrix mode')
+        if shape != (160, 192, 160) or args.precision.startswith('bf16'):
+            metric = 'training volumes/sec at %dx%dx%d %s' % (shape[0], shape[1], shape[2], 'fp32' if not args.precision.startswith('bf16') else ('bf16 matrix mode' if args.precision == 'bf16' else 'bf16 activations + bf16 matrix mode'))
         line = dict(metric=metric, value=head_res['value'], unit='volumes/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head_res['ms_per_step'],
                     higher_is_better=True, scaling='weak', vs_baseline=None,
-                    dtype='f32' if args.precision != 'bf16' else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
+                    dtype='f32' if not args.precision.startswith('bf16') else 'bf16 x bf16 -> f32 in the 3x3x3 convolutions, f32 elsewhere', data='synthetic',
                     config=dict(workload=head.name, global_batch=world * head.units, volume=list(shape), n_classes=n_classes,
                                 parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision,
                                 matrix_arithmetic=PRECISION_NOTE[args.precision],

@@ -503,8 +503,22 @@ extern "C" int da_conv3d_k3_fwd_bf16(const void* in1, int C1, const void* in2, i
     if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
         return DA_ERR_BADARG;
     const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
-    if ((bf16_mask & want) != want || force_direct() || stride != 1 || !da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
+    if (force_direct()) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+    {   // thin layers on the VALU kernel: fp32 network inputs -> bf16 (first layers), bf16 -> fp32 displacement field (flow conv)
+        const unsigned inm = 1u | (C2 > 0 ? 2u : 0u), in_bits = bf16_mask & inm;
+        if (stride == 1 && (in_bits == 0 || in_bits == inm) && !da_conv3_mfma_fwd_supported(C1, C2, Cout, stride) && da_conv3_thin_supported(C1, C2, Cout, stride) && !getenv("DA_NO_THIN")) {
+            const int rc = da_conv3_thin_fwd((const float*)in1, C1, (const float*)in2, C2, w_tio, 0, bias, (float*)out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope,
+                                             ws, ws_bytes, da_stream(stream), in_bits != 0, (bf16_mask & 4u) != 0);
+            if (rc != DA_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    if ((bf16_mask & want) != want) return DA_ERR_UNSUPPORTED;
+    if (stride == 2) {
+        if (!da_conv3_s2_supported(C1, C2, Cout) || s2_prefers_direct(N, D, H, W)) return DA_ERR_UNSUPPORTED;
+        return da_conv3_s2_fwd((const float*)in1, C1, w_tio, bias, (float*)out, N, D, H, W, Cout, act_slope, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, da_stream(stream), 1);
+    }
+    if (!da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
     return da_conv3_mfma_fwd((const float*)in1, C1, (const float*)in2, C2, w_tio, 0, bias, (float*)out, Cout, nullptr, 0,
                              N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, nullptr, nullptr, 1);
 }
@@ -518,7 +532,9 @@ extern "C" int da_conv3d_k3_fwd_bnstats_bf16(const void* in1, int C1, const void
     if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
         return DA_ERR_BADARG;
     const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
-    if ((bf16_mask & want) != want || force_direct() || stride != 1 || !da_conv3_mfma_fwd_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
+    if (force_direct()) return DA_ERR_UNSUPPORTED;
+    if ((bf16_mask & want) != want || stride != 1 || !da_conv3_mfma_fwd_supported(C1, C2, Cout, stride))      // no fused statistics (*stats_nparts = 0): thin / stride-2 routes
+        return da_conv3d_k3_fwd_bf16(in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, stride, -1.f, ws, ws_bytes, stream, bf16_mask);
     if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
     const bool stats = stats_partial && stats_capacity >= 512;
     return da_conv3_mfma_fwd((const float*)in1, C1, (const float*)in2, C2, w_tio, 0, bias, (float*)out, Cout, nullptr, 0, N, D, H, W, Cout, stride, -1.f,
@@ -565,8 +581,22 @@ extern "C" int da_conv3d_k3_dgrad_bf16(const void* dy, const float* w_tio, void*
     if (!dy || !w_tio || !dx1 || C1 <= 0 || C2 < 0 || (C2 > 0 && !dx2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
     const int Cin = C1 + C2;
     const unsigned want = 1u | 2u | (C2 > 0 ? 4u : 0u);
-    if ((bf16_mask & want) != want || force_direct() || stride != 1 || !da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) return DA_ERR_UNSUPPORTED;
+    if (force_direct()) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)) return DA_ERR_WS_SMALL;
+    {   // data gradient of the flow conv: fp32 gradient of the displacement field -> bf16 gradients of its two inputs
+        const unsigned outm = 2u | (C2 > 0 ? 4u : 0u), out_bits = bf16_mask & outm;
+        if (stride == 1 && (out_bits == 0 || out_bits == outm) && !da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2) && da_conv3_thin_supported(Cout, 0, Cin, 1)) {
+            const int rc = da_conv3_thin_fwd((const float*)dy, Cout, nullptr, 0, w_tio, 1, nullptr, (float*)dx1, C1, (float*)dx2, C2, N, D, H, W, Cin, -1.f, ws, ws_bytes, da_stream(stream),
+                                             (bf16_mask & 1u) != 0, out_bits != 0);
+            if (rc != DA_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    if ((bf16_mask & want) != want) return DA_ERR_UNSUPPORTED;
+    if (stride == 2) {
+        if (!da_conv3_s2_supported(C1, C2, Cout) || s2_prefers_direct(N, D, H, W)) return DA_ERR_UNSUPPORTED;
+        return da_conv3_s2_dgrad((const float*)dy, w_tio, (float*)dx1, C1, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, da_stream(stream), 1);
+    }
+    if (!da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) return DA_ERR_UNSUPPORTED;
     return da_conv3_mfma_fwd((const float*)dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, (float*)dx1, C1, (float*)dx2, C2,
                              N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, nullptr, nullptr, 1);
 }
@@ -577,7 +607,21 @@ extern "C" int da_conv3d_k3_wgrad_bf16(const void* in1, int C1, const void* in2,
                                        void* ws, size_t ws_bytes, void* stream, unsigned bf16_mask) {
     if (!in1 || !dy || !dw_tio || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
     const unsigned want = 1u | (C2 > 0 ? 2u : 0u) | 4u;
-    if ((bf16_mask & want) != want || force_direct() || stride != 1 || dbias || !da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
+    if (force_direct() || dbias) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
+    {   // thin layers: first layers (fp32 network input, bf16 output gradient) and the flow conv (bf16 inputs, fp32 gradient of the field)
+        const unsigned inm = 1u | (C2 > 0 ? 2u : 0u), in_bits = bf16_mask & inm;
+        const bool dy_bf = (bf16_mask & 4u) != 0;
+        if (stride == 1 && in_bits == 0 && dy_bf && da_conv3_fewcin_wgrad_supported(C1, C2, Cout, stride))
+            return da_conv3_fewcin_wgrad((const float*)in1, C1, (const float*)in2, C2, (const float*)dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes, da_stream(stream), 1);
+        if (stride == 1 && in_bits == inm && !dy_bf && da_conv3_flow_wgrad_supported(C1, C2, Cout, stride) && ws_bytes >= da_conv3_flow_wgrad_ws_bytes(C1 + C2, Cout))
+            return da_conv3_flow_wgrad((const float*)in1, C1, (const float*)in2, C2, (const float*)dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes, da_stream(stream), 1);
+    }
+    if ((bf16_mask & want) != want) return DA_ERR_UNSUPPORTED;
+    if (stride == 2) {
+        if (!da_conv3_s2_supported(C1, C2, Cout) || s2_prefers_direct(N, D, H, W)) return DA_ERR_UNSUPPORTED;
+        return da_conv3_s2_wgrad((const float*)in1, C1, (const float*)dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, da_stream(stream), 1);
+    }
+    if (!da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
     return da_conv3_mfma_wgrad((const float*)in1, C1, (const float*)in2, C2, (const float*)dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, 1);
 }

@@ -34,8 +34,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const float* base, u
 }
 
 // MT: M-tiles of 16 (tap, cout) rows; TWO: a second N-tile for in1; S1: LDS row stride (floats) of the in1 tile, 8 or 16
-template <int MT, bool TWO, int S1>
+// XB: the "x" operand (in1 / in2) is stored as bf16 (bf16 activation storage, common.h); the "dy" operand is fp32 in every use (the
+// displacement field's gradient, or -- roles exchanged -- the fp32 network input)
+template <int MT, bool TWO, int S1, bool XB = false>
 __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
+    constexpr unsigned EX = XB ? 2u : 4u;
     constexpr int NTT = TWO ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xa = lds;                               // in2 tile  [TVOX][16]
@@ -78,8 +81,15 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
         const int tz = t % p.ntz; const int n = t / p.ntz;
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         const unsigned long long vol = (unsigned long long)p.D * p.H * p.W;
-        const __amdgpu_buffer_rsrc_t r2 = flow_rsrc(p.C2 > 0 ? p.in2 + (size_t)n * vol * p.C2 : p.dy, p.C2 > 0 ? (unsigned)(vol * p.C2 * 4ull) : 0u);
-        const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p.C1 > 0 ? p.in1 + (size_t)n * vol * p.C1 : p.dy, p.C1 > 0 ? (unsigned)(vol * p.C1 * 4ull) : 0u);
+        const __amdgpu_buffer_rsrc_t r2 = flow_rsrc(p.C2 > 0 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in2) + (size_t)n * vol * p.C2 * EX) : p.dy, p.C2 > 0 ? (unsigned)(vol * p.C2 * EX) : 0u);
+        const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p.C1 > 0 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in1) + (size_t)n * vol * p.C1 * EX) : p.dy, p.C1 > 0 ? (unsigned)(vol * p.C1 * EX) : 0u);
+        auto ldx = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float4 {
+            if constexpr (XB) {
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+                return da_unpack_bf16x4(make_uint2(u[0], u[1]));
+            } else return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        };
         const int Cd2 = Cout - p.Cd1;
         const __amdgpu_buffer_rsrc_t ry = flow_rsrc(p.dy + (size_t)n * vol * p.Cd1, (unsigned)(vol * p.Cd1 * 4ull));
         const __amdgpu_buffer_rsrc_t ry2 = flow_rsrc(Cd2 > 0 ? p.dyb + (size_t)n * vol * Cd2 : p.dy, Cd2 > 0 ? (unsigned)(vol * Cd2 * 4ull) : 0u);
@@ -90,13 +100,13 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
                 const int c4 = Q2 > 0 ? idx % Q2 : 0, v = Q2 > 0 ? idx / Q2 : TVOX;
                 const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
                 const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
-                pa[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * 4) : 0xFFFFFFFFu, 0, 0));
+                pa[it] = ldx(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * EX) : 0xFFFFFFFFu);
             }
             if (TWO) {   // in1: Q1 quads per voxel
                 const int c4 = Q1 > 0 ? idx % Q1 : 0, v = Q1 > 0 ? idx / Q1 : TVOX;
                 const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
                 const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
-                pb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C1 + c4 * 4) * 4) : 0xFFFFFFFFu, 0, 0));
+                pb[it] = ldx(r1, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C1 + c4 * 4) * EX) : 0xFFFFFFFFu);
             }
         }
 #pragma unroll
@@ -202,17 +212,22 @@ bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride) {
 
 size_t da_conv3_flow_wgrad_ws_bytes(int Cin, int Cout) { return da_align((size_t)kFlowBlocks * 27 * Cin * Cout * sizeof(float)); }
 
-template <int MTT, bool TWO, int S1>
-static int flow_launch(const FlowWgP& p, int nb, hipStream_t st) {
+template <int MTT, bool TWO, int S1, bool XB>
+static int flow_launch_t(const FlowWgP& p, int nb, hipStream_t st) {
     const size_t red_bytes = (size_t)MTT * (TWO ? 2 : 1) * 64 * sizeof(float4);
     size_t shm = ((size_t)TVOX * 16 + (TWO ? (size_t)TVOX * S1 : 0) + (size_t)HVOX * p.Cout) * sizeof(float);
     if (shm < red_bytes) shm = red_bytes;
-    auto kern = flow_wgrad_kernel<MTT, TWO, S1>;
+    auto kern = flow_wgrad_kernel<MTT, TWO, S1, XB>;
     static bool attr_set = false;
     if (!attr_set) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return (int)e; attr_set = true; }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), shm, st, p);
     DA_LAUNCH_CHECK();
     return 0;
+}
+
+template <int MTT, bool TWO, int S1>
+static int flow_launch(const FlowWgP& p, int nb, hipStream_t st, int x_bf16) {
+    return x_bf16 ? flow_launch_t<MTT, TWO, S1, true>(p, nb, st) : flow_launch_t<MTT, TWO, S1, false>(p, nb, st);
 }
 
 static void flow_geom(FlowWgP& p, int N, int D, int H, int W, int* nb) {
@@ -223,7 +238,7 @@ static void flow_geom(FlowWgP& p, int N, int D, int H, int W, int* nb) {
 }
 
 int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st, int in_bf16) {
     if (!da_conv3_flow_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
     const int Cin = C1 + C2, O = 27 * Cin * Cout;
     if (ws_bytes < da_conv3_flow_wgrad_ws_bytes(Cin, Cout)) return DA_ERR_WS_SMALL;
@@ -236,9 +251,9 @@ int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     int nb;
     flow_geom(p, N, D, H, W, &nb);
     int rc;
-    if (p.C1 == 0) rc = flow_launch<MT_MAX, false, 8>(p, nb, st);
-    else if (p.C1 <= 8) rc = flow_launch<MT_MAX, true, 8>(p, nb, st);
-    else rc = flow_launch<MT_MAX, true, 16>(p, nb, st);
+    if (p.C1 == 0) rc = flow_launch<MT_MAX, false, 8>(p, nb, st, in_bf16);
+    else if (p.C1 <= 8) rc = flow_launch<MT_MAX, true, 8>(p, nb, st, in_bf16);
+    else rc = flow_launch<MT_MAX, true, 16>(p, nb, st, in_bf16);
     if (rc) return rc;
     // the kernel's ci order is the conv's own (in1's channels first); with the single-tensor swap above C1 == 0 keeps it that way
     return da_reduce_partials(p.partial, nb, O, dw_tio, st);
@@ -261,7 +276,7 @@ bool da_conv3_fewcin_wgrad_supported(int C1, int C2, int Cout, int stride) {
 }
 
 int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st, int dy_bf16) {
     if (!da_conv3_fewcin_wgrad_supported(C1, C2, Cout, 1)) return DA_ERR_UNSUPPORTED;
     const int Cin = C1 + C2, O = 27 * Cin * Cout;
     if (ws_bytes < da_align((size_t)kFlowBlocks * O * sizeof(float)) + da_align((size_t)O * sizeof(float))) return DA_ERR_WS_SMALL;
@@ -272,7 +287,7 @@ int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, co
     p.partial = (float*)ws;
     int nb;
     flow_geom(p, N, D, H, W, &nb);
-    const int rc = Cin == 1 ? flow_launch<2, false, 8>(p, nb, st) : flow_launch<4, false, 8>(p, nb, st);
+    const int rc = Cin == 1 ? flow_launch<2, false, 8>(p, nb, st, dy_bf16) : flow_launch<4, false, 8>(p, nb, st, dy_bf16);
     if (rc) return rc;
     float* tmp = (float*)((char*)ws + da_align((size_t)kFlowBlocks * O * sizeof(float)));
     const int rc2 = da_reduce_partials(p.partial, nb, O, tmp, st);

@@ -39,11 +39,11 @@ int da_conv3_direct_fwd(const float* in1, int C1, const float* in2, int C2, cons
 bool da_conv3_s2_supported(int C1, int C2, int Cout);
 size_t da_conv3_s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
 int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
-                    int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st);
+                    int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st, int act_bf16 = 0);
 int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, int N, int D, int H, int W, int Cout,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, int act_bf16 = 0);
 int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, int act_bf16 = 0);      // act_bf16: activation / gradient tensors are bf16 (common.h)
 
 // native stride-2 kernels in split matrix mode (conv3d_s2n.hip): one halo tile serves all 27 taps
 bool da_conv3_s2n_supported(int Cin, int Cout, int N, int D, int H, int W);
@@ -60,15 +60,15 @@ int da_conv3_s2n_wgrad(const float* in, int Cin, const float* dy, float* dw_tio,
 bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
                       float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, int in_bf16 = 0, int out_bf16 = 0);   // bf16 activation storage: inputs / outputs are bf16 tensors
 
 // weight gradient of a conv with <= 3 output channels and <= 16 + 16 input channels (the 24 -> 3 flow conv): LDS-tiled MFMA GEMM
 // with M = (tap, cout) (conv3d_flow.hip)
 bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride);
 size_t da_conv3_flow_wgrad_ws_bytes(int Cin, int Cout);
 int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st, int in_bf16 = 0);      // in_bf16: in1 / in2 are bf16 tensors (dy fp32)
 // ... and with the operands' roles exchanged for <= 2 input channels (first layers: seg 1 -> 8, reg 1 + 1 -> 16)
 bool da_conv3_fewcin_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
-                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st, int dy_bf16 = 0);     // dy_bf16: dy is a bf16 tensor (in1 / in2 fp32)

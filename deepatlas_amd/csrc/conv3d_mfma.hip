@@ -985,6 +985,7 @@ struct ThinP {
     const float* w;                                      // zero-padded [27][CinP][CT] (thin_pack_kernel), read through the scalar cache
     const float* bias; float* out1; float* out2; int Cs1, Cs2;
     int N, D, H, W, Cout, ntz, nty, ntx, ntiles, flip_tr; float slope;
+    int in_bf, out_bf;                                   // bf16 activation storage (common.h): in1 / in2, out1 / out2 are bf16 tensors (runtime: the kernel is VALU-bound)
 };
 
 // weights [27][Cin][Cout] (flip_tr: original [27][Cout][Cin], taps flipped) -> zero-padded [27][CinP][CT]: the thin kernel's inner loops
@@ -1039,7 +1040,8 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
         if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
         const int cvalid = (Cs - choff) < CL ? (Cs - choff) : CL;           // real channels in this chunk
         const long long sample = (long long)p.D * p.H * p.W * Cs;
-        const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
+        const unsigned ES = p.in_bf ? 2u : 4u;
+        const __amdgpu_buffer_rsrc_t rs = p.in_bf ? da_rsrc_n<true>(src, n, sample) : da_rsrc_n<false>(src, n, sample);
         __syncthreads();
         if (CL % 4 == 0 && cvalid == CL && Cs % 4 == 0) {                   // 16-byte staging
             constexpr int Q = CL / 4 > 0 ? CL / 4 : 1;
@@ -1049,8 +1051,8 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
                 const int hy = tt % HY; const int hz = tt / HY;
                 const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
                 const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + q * 4) * 4);
-                *reinterpret_cast<float4*>(lds + idx * 4) = da_buf_load4(rs, inb ? off : 0xFFFFFFFFu);
+                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + q * 4) * ES);
+                *reinterpret_cast<float4*>(lds + idx * 4) = p.in_bf ? da_buf_loadq<true>(rs, inb ? off : 0xFFFFFFFFu) : da_buf_loadq<false>(rs, inb ? off : 0xFFFFFFFFu);
             }
         } else {
             for (int idx = threadIdx.x; idx < HVOX * CL; idx += 256) {
@@ -1059,8 +1061,9 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
                 const int hy = tt % HY; const int hz = tt / HY;
                 const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
                 const bool inb = c < cvalid && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + c) * 4);
-                lds[idx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, inb ? off : 0xFFFFFFFFu, 0, 0));
+                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + c) * ES);
+                lds[idx] = p.in_bf ? __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, inb ? off : 0xFFFFFFFFu, 0, 0) << 16)
+                                   : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, inb ? off : 0xFFFFFFFFu, 0, 0));
             }
         }
         __syncthreads();
@@ -1115,8 +1118,9 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
                 if (j < p.Cout) {
                     const float4 o = make_float4(da_act(acc[v][j], p.slope), da_act(acc[v][j + 1], p.slope),
                                                  da_act(acc[v][j + 2], p.slope), da_act(acc[v][j + 3], p.slope));
-                    float* dst = j < p.Cs1 ? p.out1 + vox * p.Cs1 + j : p.out2 + vox * p.Cs2 + (j - p.Cs1);
-                    *reinterpret_cast<float4*>(dst) = o;
+                    float* base = j < p.Cs1 ? p.out1 : p.out2;
+                    const long long e = j < p.Cs1 ? vox * p.Cs1 + j : vox * p.Cs2 + (j - p.Cs1);
+                    if (p.out_bf) da_stq(reinterpret_cast<da_bf16*>(base), e >> 2, o); else *reinterpret_cast<float4*>(base + e) = o;
                 }
             }
         } else {
@@ -1124,7 +1128,9 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
             for (int j = 0; j < CT; ++j) {
                 if (j < p.Cout) {
                     const float o = da_act(acc[v][j], p.slope);
-                    if (j < p.Cs1) p.out1[vox * p.Cs1 + j] = o; else p.out2[vox * p.Cs2 + (j - p.Cs1)] = o;
+                    float* base = j < p.Cs1 ? p.out1 : p.out2;
+                    const long long e = j < p.Cs1 ? vox * p.Cs1 + j : vox * p.Cs2 + (j - p.Cs1);
+                    if (p.out_bf) da_st1(reinterpret_cast<da_bf16*>(base), e, o); else base[e] = o;
                 }
             }
         }
@@ -2218,7 +2224,7 @@ static int thin_few_inputs(ThinP& p, const float* w_src, float* wq, hipStream_t 
 
 int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const float* w, int flip_tr, const float* bias,
                       float* out1, int Cs1, float* out2, int Cs2, int N, int D, int H, int W, int Cout, float slope,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int in_bf16, int out_bf16) {
     if ((unsigned long long)D * H * W * (C1 > C2 ? C1 : C2) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < kThinPackBytes) return DA_ERR_WS_SMALL;
     float* wq = (float*)ws;
@@ -2226,6 +2232,7 @@ int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const 
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.Cs1 = Cs1; p.Cs2 = Cs2;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.flip_tr = flip_tr; p.slope = slope;
     p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
+    p.in_bf = in_bf16; p.out_bf = out_bf16;
     const int Cin = C1 + C2;
     int rc = 0;
     if (Cout <= 4) rc = thin_launch<8, 4, 2>(p, w, wq, st);      // (skipping the padded fourth output, JR = 3, was measured 1.7x SLOWER: 0.38 -> 0.63 ms)

@@ -104,7 +104,8 @@ size_t da_conv3_s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
 
 // ws layout: [S (space-to-depth tensor or its gradient)] [W' expanded] [dW' expanded] [inner conv scratch]
 int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
-                    int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st) {
+                    int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st, int act_bf16) {
+    if (act_bf16 && (da_matrix_mode() != 1 || !s2_fused())) return DA_ERR_UNSUPPORTED;      // bf16 activation storage: fused addressing, bf16 matrix mode
     if (s2_native(Cin, Cout, N, D, H, W)) return da_conv3_s2n_fwd(in, Cin, w_tio, bias, out, N, D, H, W, Cout, slope, ws, ws_bytes, st);
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
@@ -119,11 +120,12 @@ int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* b
     DA_LAUNCH_CHECK();
     const DaS2dFuse f = {D, H, W, 1, 0};
     return da_conv3_mfma_fwd(fused ? in : S, 8 * Cin, nullptr, 0, We, 0, bias, out, Cout, nullptr, 0, N, p.Dq, p.Hq, p.Wq, Cout, 1, slope,
-                             inner, p.inner_bytes, st, Cin, nullptr, nullptr, nullptr, fused ? &f : nullptr);
+                             inner, p.inner_bytes, st, Cin, nullptr, nullptr, nullptr, fused ? &f : nullptr, act_bf16);
 }
 
 int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, int N, int D, int H, int W, int Cout,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int act_bf16) {
+    if (act_bf16 && (da_matrix_mode() != 1 || !s2_fused())) return DA_ERR_UNSUPPORTED;
     if (s2_native(Cin, Cout, N, D, H, W)) return da_conv3_s2n_dgrad(dy, w_tio, dx, Cin, N, D, H, W, Cout, ws, ws_bytes, st);
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
@@ -134,7 +136,7 @@ int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, i
     const bool fused = s2_fused();
     const DaS2dFuse f = {D, H, W, 0, 1};
     int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, We, 1, nullptr, fused ? dx : dS, 8 * Cin, nullptr, 0, N, p.Dq, p.Hq, p.Wq, 8 * Cin, 1, -1.f,
-                               inner, p.inner_bytes, st, Cin, nullptr, nullptr, nullptr, fused ? &f : nullptr);
+                               inner, p.inner_bytes, st, Cin, nullptr, nullptr, nullptr, fused ? &f : nullptr, act_bf16);
     if (rc || fused) return rc;
     const long long tot = (long long)N * D * H * W * (Cin / 4);
     hipLaunchKernelGGL(depth_to_space2_kernel, dim3(da_grid(tot, 256)), dim3(256), 0, st, dS, dx, N, D, H, W, Cin, p.Dq, p.Hq, p.Wq);
@@ -143,7 +145,8 @@ int da_conv3_s2_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, i
 }
 
 int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int act_bf16) {
+    if (act_bf16 && (da_matrix_mode() != 1 || !s2_fused())) return DA_ERR_UNSUPPORTED;
     if (s2_native(Cin, Cout, N, D, H, W)) return da_conv3_s2n_wgrad(in, Cin, dy, dw_tio, N, D, H, W, Cout, ws, ws_bytes, st);
     const S2Plan p = s2_plan(N, D, H, W, Cin, Cout);
     if (ws_bytes < da_conv3_s2_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
@@ -155,7 +158,7 @@ int da_conv3_s2_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, 
         DA_LAUNCH_CHECK();
     }
     const DaS2dFuse f = {D, H, W, 1, 0};
-    int rc = da_conv3_mfma_wgrad(fused ? in : S, 8 * Cin, nullptr, 0, dy, dWe, N, p.Dq, p.Hq, p.Wq, Cout, 1, inner, p.inner_bytes, st, Cin, nullptr, fused ? &f : nullptr);
+    int rc = da_conv3_mfma_wgrad(fused ? in : S, 8 * Cin, nullptr, 0, dy, dWe, N, p.Dq, p.Hq, p.Wq, Cout, 1, inner, p.inner_bytes, st, Cin, nullptr, fused ? &f : nullptr, act_bf16);
     if (rc) return rc;
     hipLaunchKernelGGL(extract_wgrad_s2d_kernel, dim3(da_grid(27 * Cin * Cout, 256, 512)), dim3(256), 0, st, dWe, dw_tio, Cin, Cout);
     DA_LAUNCH_CHECK();

@@ -498,7 +498,7 @@ class Conv3dK3Fn(Function):
                 call_act('da_upconv3d_k3_wgrad', A(a1), C1, A(a2), C2, A(g_), ptr(dw_tio_), N, D, H, W, Cout, wp_, wn_, st_)
                 if db_ is not None:
                     call_act('da_colsum', A(g_), g_.numel() // Cout, Cout, ptr(db_), wp_, wn_, st_)
-            elif db_ is not None and g_.dtype == torch.bfloat16:          # (the bf16 twin leaves the bias gradient to its own pass)
+            elif db_ is not None and (g_.dtype == torch.bfloat16 or a1.dtype == torch.bfloat16):          # (the bf16 twins leave the bias gradient to its own pass)
                 call_act('da_conv3d_k3_wgrad', A(a1), C1, A(a2), C2, A(g_), ptr(dw_tio_), None, N, D, H, W, Cout, stride, wp_, wn_, st_)
                 call_act('da_colsum', A(g_), g_.numel() // Cout, Cout, ptr(db_), wp_, wn_, st_)
             else:

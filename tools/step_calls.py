@@ -21,7 +21,7 @@ class A:
 a = A()
 a.graph, a.shape, a.batch, a.net, a.precision, a.no_fused_head = False, shape, 2, 'UNet_light', os.environ.get('PRECISION', 'fp32_split'), os.environ.get('NO_FUSED_HEAD') == '1'
 ops.enable_async_wgrad(False)
-ops.set_matrix_precision(a.precision)
+bench.set_precision(ops, a.precision)
 dev = torch.device('cuda', 0)
 wl = bench.make_workloads(a, dev, 0, [which])[0][which]
 for _ in range(3):
@@ -42,3 +42,5 @@ tot = sum(r[0] for r in rows)
 print('%s step %s: %.3f ms per step wall (events add overhead), %.3f ms in C-ABI calls, %d calls per step' % (which, shape, t0.elapsed_time(t1) / K, tot, sum(r[1] for r in rows)))
 for ms, n, (name, ints) in rows[:70]:
     print('%8.3f ms %5.1f x  %-28s %s' % (ms, n, name, list(ints)[:12]))
+if ops.bridged_calls:
+    print('conversion bridges (calls over all steps):', dict(ops.bridged_calls))
