@@ -261,17 +261,24 @@ def make_workloads(args, dev, rank, which):
     from deepatlas_amd.lib.datasets import synthetic_batch_on_device
     x, y = synthetic_batch_on_device(args.batch, shape, n_classes, seed=230 + rank, device=dev)
 
+    from deepatlas_amd import trace        # roctx ranges (DA_ROCTX=1): phases of the step in a rocprofv3 --marker-trace
+
     def seg_grads():
         opt.zero_grad()
-        out = model(x)
-        loss = crit(out, y)
-        loss.backward()
+        with trace.range('seg/forward'):
+            out = model(x)
+        with trace.range('seg/loss'):
+            loss = crit(out, y)
+        with trace.range('seg/backward'):
+            loss.backward()
         return dict(loss=loss.detach())
 
     def seg_step():
         loss = seg_grads()['loss']
-        parallel.allreduce_gradients(opt)
-        opt.step()
+        with trace.range('seg/allreduce'):
+            parallel.allreduce_gradients(opt)
+        with trace.range('seg/adam'):
+            opt.step()
         return loss
 
     def graphed(segments, between, optimizers, key):

@@ -190,8 +190,10 @@ class L2Loss(nn.Module):
 
 class SoftCrossEntropy(nn.Module):
     """lib/loss.py:100-154 (registry 'soft_cross_entropy'): cross entropy against a class-probability target B x C x D x M x N.
-    The reference's index-target branch multiplies the un-flattened B x D x M x N mask into B x C x D x M x N log-probabilities
-    (`target`, not `target_flat`, :151-153) and fails to broadcast; that call raises here too."""
+    The reference's index-target branch multiplies the un-flattened B x D x M x N mask (`target`, not the one-hot `target_flat`, :151-153)
+    into the B x C x D x M x N log-probabilities.  At the reference's batch size 1 that right-aligns and broadcasts the label VALUE over
+    the class axis -- mean_v sum_c -label[v] log p[c, v] -- which is reproduced here (as a probability target whose every class entry is
+    the label value); for B > 1 the reference's multiplication does not broadcast and the call raises, here as there."""
 
     def __init__(self, n_class=None, weight_type='Simple', no_bg=False, softmax=False):
         super(SoftCrossEntropy, self).__init__()
@@ -203,8 +205,10 @@ class SoftCrossEntropy(nn.Module):
     def forward(self, pred, target):
         shape = list(pred.shape)
         if len(target.shape) == len(shape) - 1:
-            raise RuntimeError("SoftCrossEntropy: an index target does not broadcast against the predictions in the reference "
-                               "(lib/loss.py:151-153 use `target`, not the one-hot `target_flat`); pass class probabilities B x C x ...")
+            if shape[0] != 1:
+                raise RuntimeError("SoftCrossEntropy: an index target does not broadcast against the predictions in the reference for B > 1 "
+                                   "(lib/loss.py:151-153 use `target`, not the one-hot `target_flat`); pass class probabilities B x C x ...")
+            target = target.to(pred.dtype).unsqueeze(1).expand(shape).contiguous()        # the reference's broadcast at B = 1 (see the class docstring)
         if target.shape[1] != shape[1]:
             raise ValueError("Incorrect size of target tensor: {}, should be {} or []".format(target.shape, shape,
                                                                                              shape[:1] + [1, ] + shape[2:]))

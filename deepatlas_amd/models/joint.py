@@ -13,7 +13,7 @@ compare against:
 """
 import torch
 
-from .. import ops, parallel
+from .. import ops, parallel, trace
 from ..lib.loss import DiceLossMultiClass, NormalizedCrossCorrelationLoss, BendingEnergyLoss
 
 
@@ -28,11 +28,14 @@ class RegistrationStep:
         """zero_grad -> forward -> losses -> backward (device work only: capturable in a HIP graph, graphs.GraphedStep)."""
         self.model.train()
         self.opt.zero_grad()
-        disp, warped, deform = self.model(source, target)
-        l_sim = self.ncc(warped, target)
-        l_reg = self.bend(disp)
-        loss = l_sim + self.lam_reg * l_reg
-        loss.backward()
+        with trace.range('reg/forward'):
+            disp, warped, deform = self.model(source, target)
+        with trace.range('reg/loss'):
+            l_sim = self.ncc(warped, target)
+            l_reg = self.bend(disp)
+            loss = l_sim + self.lam_reg * l_reg
+        with trace.range('reg/backward'):
+            loss.backward()
         return dict(loss=loss.detach(), disp=disp.detach(), warped=warped.detach(), deform=deform.detach(), sim=l_sim.detach(), bend=l_reg.detach())
 
     def segments(self, source, target):
@@ -42,8 +45,10 @@ class RegistrationStep:
 
     def __call__(self, source, target):
         r = self.gradients(source, target)
-        parallel.allreduce_gradients(self.opt)
-        self.opt.step()
+        with trace.range('reg/allreduce'):
+            parallel.allreduce_gradients(self.opt)
+        with trace.range('reg/adam'):
+            self.opt.step()
         return r['loss'], (r['disp'], r['warped'], r['deform']), (r['sim'], r['bend'])
 
 
@@ -99,8 +104,10 @@ class DeepAtlasJointStep:
             with torch.no_grad():
                 self.seg.eval()
                 prob_m = ops.SoftmaxFn.apply(ops.materialize_logits(self.seg(im_m)))
-        disp, warped, deform = self.reg(im_m, im_t)
+        with trace.range('joint/reg_phase/forward'):
+            disp, warped, deform = self.reg(im_m, im_t)
         fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
+        trace.mark('joint/reg_phase/losses')
         l_sim = self.ncc(warped, im_t)
         l_reg = self.bend(disp)
         if seg_m is not None and fused:
@@ -113,7 +120,8 @@ class DeepAtlasJointStep:
                 warped_seg, _ = ops.WarpFn.apply(prob_m, disp)                          # gradient flows to disp only (prob_m is a constant)
             l_anat = self.dice_prob(warped_seg, seg_t)
         loss_r = lam['sim'] * l_sim + lam['reg'] * l_reg + lam['anat'] * l_anat
-        loss_r.backward()
+        with trace.range('joint/reg_phase/backward'):
+            loss_r.backward()
         return dict(loss_reg=loss_r.detach(), sim=l_sim.detach(), bend=l_reg.detach(), anat_reg=l_anat.detach(), disp=disp.detach())
 
     def seg_gradients(self, im_m, seg_m, seg_t, disp):
@@ -122,7 +130,9 @@ class DeepAtlasJointStep:
         fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
         self.seg.train()
         self.seg_opt.zero_grad()
-        logits = ops.materialize_logits(self.seg(im_m))
+        with trace.range('joint/seg_phase/forward'):
+            logits = ops.materialize_logits(self.seg(im_m))
+        trace.mark('joint/seg_phase/losses')
         if fused and not ops.DETERMINISTIC:
             # both Dice terms as one node: structured adjoint warp + one pass to the logit gradient (ops.SegPhaseLossFn); its scatter
             # uses float atomics, so deterministic runs take the composed path below (fixed-point accumulation in WarpFn)
@@ -133,5 +143,6 @@ class DeepAtlasJointStep:
             warped_prob, _ = ops.WarpFn.apply(prob, disp)
             l_anat2 = self.dice_prob(warped_prob, seg_t)
         loss_s = lam['sp'] * l_sp + lam['anat'] * l_anat2
-        loss_s.backward()
+        with trace.range('joint/seg_phase/backward'):
+            loss_s.backward()
         return dict(loss_seg=loss_s.detach(), sup=l_sp.detach(), anat_seg=l_anat2.detach())

@@ -26,6 +26,7 @@ from ..lib.param_dict import save_dict_to_json
 from ..optim import FlatAdam
 from .. import ops
 from .. import parallel
+from .. import trace
 
 try:
     from tensorboardX import SummaryWriter
@@ -135,12 +136,18 @@ class SegmentationExperiment(BaseExperiment):
     def train_step(self, images, truths):
         """One optimisation step (models/segmentation.py:141-157)."""
         self.model.train()
-        self.optimizer.zero_grad()
-        output = self.model(images.to(self.device, non_blocking=True))
-        loss = self.criterion(output, truths.to(self.device, non_blocking=True))
-        loss.backward()
-        parallel.allreduce_gradients(self.optimizer)
-        self.optimizer.step()
+        with trace.range('seg/zero_grad'):
+            self.optimizer.zero_grad()
+        with trace.range('seg/forward'):
+            output = self.model(images.to(self.device, non_blocking=True))
+        with trace.range('seg/loss'):
+            loss = self.criterion(output, truths.to(self.device, non_blocking=True))
+        with trace.range('seg/backward'):
+            loss.backward()
+        with trace.range('seg/allreduce'):
+            parallel.allreduce_gradients(self.optimizer)
+        with trace.range('seg/adam'):
+            self.optimizer.step()
         return loss, output
 
     def train_one_epoch(self):

@@ -189,6 +189,7 @@ def set_matrix_precision(mode):
 # warp's gradient with respect to its SOURCE (only the joint step's 32-channel probability warp needs it), which uses float atomics.
 # DETERMINISTIC switches that one to an order-independent fixed-point accumulation, making whole training steps run-to-run bit-identical.
 DETERMINISTIC = os.environ.get('DA_DETERMINISTIC') == '1'
+CHECK_LABELS = os.environ.get('DA_CHECK_LABELS') == '1'      # validate index targets of the cross-entropy family like torch does (host sync per call)
 
 
 def set_deterministic(flag=True):
@@ -1554,6 +1555,12 @@ class XentFn(Function):
             lab, lab_bytes = _labels(labels.reshape(-1))
             if lab.numel() != M:
                 raise ValueError('target has %d elements for %d voxels' % (lab.numel(), M))
+            if CHECK_LABELS:
+                # torch.nn.CrossEntropyLoss raises on a target outside [0, C) that is not ignore_index; the kernels skip such voxels (zero loss,
+                # zero gradient, not counted).  The check costs a device synchronisation, hence the switch (DA_CHECK_LABELS=1).
+                bad = (lab != int(ignore_index)) & ((lab < 0) | (lab >= C)) if lab.dtype == torch.int64 else (lab >= C)
+                if bool(bad.any()):
+                    raise IndexError('Target %d is out of bounds.' % int(lab[bad][0].item()))
         al = alpha.detach().to(a.device, torch.float32).reshape(-1).contiguous() if alpha is not None else None
         loss, denom = _empty((1,), a), _empty((1,), a)
         wp, wn = _ws(nat.lib().da_xent_ws_bytes(), a)

@@ -901,8 +901,19 @@ def test_registry_cross_entropy_family_golden(golden):
     t = cl(T(g['xent/soft_target']))
     run('soft_softmax', SCE(n_class=5, softmax=True), g['xent/logits'], t)
     run('soft_nosoftmax', SCE(n_class=5, softmax=False), g['xent/prob_clamped_in'], t)
-    with pytest.raises(RuntimeError):                                       # the reference's index-target branch fails to broadcast
+    with pytest.raises(RuntimeError):                                       # the reference's index-target branch fails to broadcast for B > 1
         SCE(n_class=5, softmax=True)(cl(T(g['xent/logits'])), y.long())
+    # ... and at the reference's batch size 1 it broadcasts the label VALUE over the class axis (lib/loss.py:151): same expression on torch-CPU
+    x1 = T(g['xent/logits'])[:1].clone()
+    y1 = y[:1].long().cpu()
+    xr = x1.clone().requires_grad_(True)
+    lr_ = torch.mean(torch.sum(-y1 * torch.nn.functional.log_softmax(xr, 1), 1))
+    lr_.backward()
+    xg = cl(x1).requires_grad_(True)
+    lg = SCE(n_class=5, softmax=True)(xg, y1.to(dev()))
+    lg.backward()
+    assert abs(lg.item() - lr_.item()) < 1e-5 * max(1.0, abs(lr_.item()))
+    check(xg.grad, xr.grad, what='soft cross entropy, index target at B = 1')
 
 
 def test_cross_entropy_c32_vs_torch():

@@ -180,3 +180,24 @@ def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_accurate():
     with np.errstate(over='ignore'):
         fp32_rounding = np.abs((x * y).astype(np.float64) - exact)[ok] / np.abs(exact)[ok]      # one fp32 multiply for comparison
     assert np.sqrt(np.mean(rel ** 2)) < np.sqrt(np.mean(fp32_rounding[np.isfinite(fp32_rounding)] ** 2))
+
+
+def test_asan_build_recipe_and_roctx_ranges(tmp_path):
+    """SURVEY.md section 5 build notes: the -fsanitize=address variant compiles (one small source: host + device instrumentation for
+    gfx950:xnack+), and the roctx range helper is inert when disabled and pushes / pops through the ROCm roctx library when enabled."""
+    import subprocess
+    import __graft_entry__ as g
+    lib = g.build_asan(sources=['optim.hip'])
+    syms = subprocess.check_output(['nm', '-D', lib]).decode()
+    assert 'da_adam_step' in syms and '__asan_init' in syms
+    from deepatlas_amd import trace
+    prev = trace.enable(False)
+    with trace.range('off'):
+        pass
+    trace.enable(True)
+    try:
+        if trace.available():
+            with trace.range('seg/forward'):
+                trace.mark('inside')
+    finally:
+        trace.enable(prev)
