@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--layer', default='32,16,16,2,160,192,160')
     ap.add_argument('--what', default='fwd,fwdstats,dgrad,wgrad')
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--bf16-storage', action='store_true', help='bf16 activation storage: the _bf16 twins on bf16 tensors (needs DA_MATRIX_MODE=1)')
     a = ap.parse_args()
     C1, C2, Cout, N, D, H, W = [int(v) for v in a.layer.split(',')]
     dev = torch.device('cuda:0')
@@ -27,6 +28,10 @@ def main():
     if os.environ.get('DA_ZERO') == '1':          # power experiment: same instruction stream on all-zero operands (no toggling in the multipliers)
         x1.zero_(); w.zero_(); dy.zero_()
         if C2: x2.zero_()
+    sfx, extra = '', ()
+    if a.bf16_storage:
+        x1 = x1.bfloat16(); x2 = x2.bfloat16() if C2 else None; dy = dy.bfloat16()
+        sfx, extra = '_bf16', (7,)
     out = torch.empty_like(dy)
     dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
     dw = torch.empty_like(w)
@@ -40,24 +45,24 @@ def main():
     for what in a.what.split(','):
         def run():
             if what == 'fwd':
-                call('da_conv3d_k3_fwd', ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1, -1.0, wp, wn, st)
+                call('da_conv3d_k3_fwd' + sfx, ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1, -1.0, wp, wn, st, *extra)
             elif what == 'fwdstats':
                 import ctypes
                 npar = ctypes.c_int(0)
-                call('da_conv3d_k3_fwd_bnstats', ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1,
-                     ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st)
+                call('da_conv3d_k3_fwd_bnstats' + sfx, ptr(x1), C1, ptr(x2), C2, ptr(w), None, ptr(out), N, D, H, W, Cout, 1,
+                     ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st, *extra)
             elif what in ('fwdpro', 'fwdpro12'):          # input prologue on in1 (and in2): deferred BatchNorm + LeakyReLU
                 import ctypes
                 npar = ctypes.c_int(0)
                 both = what == 'fwdpro12' and C2
-                call('da_conv3d_k3_fwd_pro', ptr(x1), C1, ptr(sc1), ptr(sh1), 0.01, ptr(x2), C2, ptr(sc2) if both else None, ptr(sh2) if both else None, 0.01,
-                     ptr(w), None, ptr(out), N, D, H, W, Cout, -1.0, ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st)
+                call('da_conv3d_k3_fwd_pro' + sfx, ptr(x1), C1, ptr(sc1), ptr(sh1), 0.01, ptr(x2), C2, ptr(sc2) if both else None, ptr(sh2) if both else None, 0.01,
+                     ptr(w), None, ptr(out), N, D, H, W, Cout, -1.0, ptr(pbuf), 512, ctypes.byref(npar), wp, wn, st, *extra)
             elif what == 'wgradpro':
-                call('da_conv3d_k3_wgrad_pro', ptr(x1), C1, ptr(sc1), ptr(sh1), 0.01, ptr(x2), C2, None, None, -1.0, ptr(dy), ptr(dw), N, D, H, W, Cout, wp, wn, st)
+                call('da_conv3d_k3_wgrad_pro' + sfx, ptr(x1), C1, ptr(sc1), ptr(sh1), 0.01, ptr(x2), C2, None, None, -1.0, ptr(dy), ptr(dw), N, D, H, W, Cout, wp, wn, st, *extra)
             elif what == 'dgrad':
-                call('da_conv3d_k3_dgrad', ptr(dy), ptr(w), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
+                call('da_conv3d_k3_dgrad' + sfx, ptr(dy), ptr(w), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st, *extra)
             else:
-                call('da_conv3d_k3_wgrad', ptr(x1), C1, ptr(x2), C2, ptr(dy), ptr(dw), None, N, D, H, W, Cout, 1, wp, wn, st)
+                call('da_conv3d_k3_wgrad' + sfx, ptr(x1), C1, ptr(x2), C2, ptr(dy), ptr(dw), None, N, D, H, W, Cout, 1, wp, wn, st, *extra)
         for _ in range(max(3, a.iters)):       # warm-up: the first launches of a process run at ramping clocks / cold TLBs (10 % slow)
             run()
         torch.cuda.synchronize()

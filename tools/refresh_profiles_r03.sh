@@ -15,6 +15,24 @@ timeout 600 python bench.py --no-cpu-baseline --precision fp32 > $O/bench_fp32_m
 grep '"metric"' $O/bench_fp32_mfma.log | tail -1 > $O/bench_fp32_mfma.json
 timeout 600 python bench.py --no-cpu-baseline --precision bf16 > $O/bench_bf16.log 2>&1 < /dev/null
 grep '"metric"' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
+timeout 600 python bench.py --no-cpu-baseline --precision bf16_storage > $O/bench_bf16_storage.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_bf16_storage.log | tail -1 > $O/bench_bf16_storage.json
+timeout 600 python bench.py --no-cpu-baseline --no-extra --precision bf16_storage --shape 192 224 192 --steps 6 --warmup 2 > $O/bench_bf16_storage_192x224x192.log 2>&1 < /dev/null
+grep '"metric"' $O/bench_bf16_storage_192x224x192.log | tail -1 > $O/bench_bf16_storage_192x224x192.json
+for w in seg reg joint; do
+  PRECISION=bf16_storage timeout 600 python tools/step_calls.py $w 2>&1 | grep -v amdgpu.ids > $O/${w}_bf16_storage_calls.txt
+done
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_segh -- python bench.py --workload seg --precision bf16_storage --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/prof_segh.log 2>&1 < /dev/null
+f=$(ls $O/prof_segh/*/*.db 2>/dev/null | head -1)
+if [ -n "$f" ]; then
+  python tools/rocpd_summary.py "$f" --top 40 > $O/seg_bf16_storage_kernel_stats.txt 2>&1 < /dev/null
+  python tools/rocpd_timeline.py "$f" > $O/seg_bf16_storage_timeline.txt 2>&1 < /dev/null
+fi
+rm -rf $O/prof_segh
+echo "# bf16 activation storage (DA_MATRIX_MODE=1, --bf16-storage) and the ablation of the 48 -> 16 forward / data gradient (DA_ABLATE: 1 no staging loads, 2 no epilogue, 4 no LDS writes + barriers)" > $O/conv_layers_bf16_storage.txt
+bash tools/ab/exp2.sh >> $O/conv_layers_bf16_storage.txt 2>&1
+echo "# split-arithmetic ablation: the shipped library vs a build whose da_split3 does no arithmetic (tools/ab/libda_fakesplit.so, -DDA_FAKE_SPLIT; wrong results, same data volume)" > $O/conv_layers_fake_split.txt
+if [ -f tools/ab/libda_fakesplit.so ]; then bash tools/ab/exp1.sh >> $O/conv_layers_fake_split.txt 2>&1; fi
 timeout 600 python bench.py --no-cpu-baseline --graph > $O/bench_graph.log 2>&1 < /dev/null
 grep '"metric"' $O/bench_graph.log | tail -1 > $O/bench_graph.json
 timeout 600 python bench.py --no-cpu-baseline --shape 32 32 32 --steps 20 --warmup 5 --no-profile > $O/bench_host_floor_32.log 2>&1 < /dev/null
