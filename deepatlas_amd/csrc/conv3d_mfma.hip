@@ -269,12 +269,12 @@ template <int CK, int HZ> struct StageMap {
     }
     // tile-level part (wave-uniform): is the whole halo inside the volume, voxel index of the halo's corner
     struct Tile { bool interior, valid; int z0, y0, x0, basev, H, W, D, Cs4, cofs4; };
-    __device__ __forceinline__ Tile tile(int z0, int y0, int x0, int D, int H, int W, int Cs, int choff, bool valid) const {
+    __device__ __forceinline__ Tile tile(int z0, int y0, int x0, int D, int H, int W, int Cs, int choff, bool valid, int es = 4) const {      // es: bytes per stored element
         Tile t;
         t.valid = valid; t.z0 = z0; t.y0 = y0; t.x0 = x0; t.D = D; t.H = H; t.W = W;
         t.interior = valid && z0 >= 1 && z0 + HZ - 2 < D && y0 >= 1 && y0 + HY - 2 < H && x0 >= 1 && x0 + HX - 2 < W;
         t.basev = ((z0 - 1) * H + (y0 - 1)) * W + (x0 - 1);
-        t.Cs4 = Cs * 4; t.cofs4 = (choff + c4x4) * 4;
+        t.Cs4 = Cs * es; t.cofs4 = (choff + c4x4) * es;
         return t;
     }
     __device__ __forceinline__ unsigned offset(const Tile& t, int it) const {
@@ -1508,13 +1508,19 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 // LDS reads per MFMA fall from ~1.3 to ~0.7 ds_read_b64_tr_b16, all four waves carry the same load, and the accumulators (per-wave
 // partial sums over the wave's rows) are reduced across the waves through LDS once, at the end of the persistent loop.
 // ---------------------------------------------------------------------------------------------------
-template <bool PRO>
+// NPL = 3: split mode (six products per fragment pair).  NPL = 1: bf16 matrix mode -- operands rounded to bf16, ONE product; the same LDS
+// geometry and accumulator layout at a sixth of the matrix work, i.e. bound by its staging (the older bf16 weight-gradient kernel issues
+// v_mfma_f32_16x16x16_bf16, half the rate of the K = 32 form).  HB: x and dY stored as bf16 (bf16 activation storage; NPL = 1 only).
+template <bool PRO, int NPL = 3, bool HB = false>
 __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
+    static_assert(!HB || NPL == 1, "bf16 activation storage goes with the bf16 matrix mode");
+    constexpr bool SPL = NPL == 3;
+    constexpr unsigned ES = HbEl<HB>::ES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CK = 8, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
     constexpr int PLA = HZ * HY * HX * CK, PLY = TVOX * CG;                 // elements per plane
     float* ldsA = lds;
-    float* ldsY = lds + PLA / 2 * 3;
+    float* ldsY = lds + PLA / 2 * NPL;
     typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
     const short* ldsAh = reinterpret_cast<const short*>(ldsA);
     const short* ldsYh = reinterpret_cast<const short*>(ldsY);
@@ -1547,17 +1553,17 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    struct F3 { bf16x8 p[3]; };
+    struct F3 { bf16x8 p[NPL]; };
     auto loadF = [&](int c, int h) -> F3 {                                  // x fragment of class c, halo row 2 wave + h
         F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * CK);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
+        for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
         return f;
     };
     auto loadY = [&](int r) -> F3 {                                         // dY fragment of output row 2 wave + r
         F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(a + pl * PLY, 4 * CG);
+        for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLY, 4 * CG);
         return f;
     };
     f32x4 acc[5][3];
@@ -1580,18 +1586,18 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         const int n = t.x, z0 = t.y, y0 = t.z, x0 = t.w;
         {
             const long long sample = (long long)p.D * p.H * p.W * Cs;
-            const __amdgpu_buffer_rsrc_t rs = da_rsrc(src + (long long)n * sample, (unsigned)(sample * sizeof(float)));
-            const typename StageMap<CK, HZ>::Tile st = smap.tile(z0, y0, x0, p.D, p.H, p.W, Cs, choff, true);
+            const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<HB>(src, n, sample);
+            const typename StageMap<CK, HZ>::Tile st = smap.tile(z0, y0, x0, p.D, p.H, p.W, Cs, choff, true, (int)ES);
             if constexpr (PRO) vmA = 0;
 #pragma unroll
             for (int it = 0; it < NITA; ++it) {
                 const unsigned so = smap.offset(st, it);
-                preA[it] = da_buf_load4(rs, so);
+                preA[it] = da_buf_loadq<HB>(rs, so);
                 if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
             }
         }
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
-        const __amdgpu_buffer_rsrc_t ry = da_rsrc(p.dy + (long long)n * sampleY, (unsigned)(sampleY * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<HB>(p.dy, n, sampleY);
         const bool inside = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;      // wave-uniform: the whole dY tile exists
         const int basev = (z0 * p.H + y0) * p.W + x0;
 #pragma unroll
@@ -1599,30 +1605,33 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             const int v = yv0 + it * (256 / QY);
             const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
             unsigned off;
-            if (inside) off = (unsigned)(((basev + (vz * p.H + vy) * p.W + vx) * p.Cout + yq4) * 4);
+            if (inside) off = (unsigned)(((basev + (vz * p.H + vy) * p.W + vx) * p.Cout + yq4) * ES);
             else {
                 const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
                 const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
-                off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * 4) : 0xFFFFFFFFu;
+                off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * ES) : 0xFFFFFFFFu;
             }
-            preY[it] = da_buf_load4(ry, off);
+            preY[it] = da_buf_loadq<HB>(ry, off);
         }
     };
     auto write_lds = [&]() {
-        if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, true>(ldsA, preA, vmA, psc, psf, pslope);
-        else stage_write<CK, HZ, 0, NITA, true, true>(ldsA, preA);
+        if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, SPL>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, NITA, true, SPL>(ldsA, preA);
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             const int idx = threadIdx.x + it * 256;
             if (idx < TVOX * QY) {
-                uint2 h, m, l; da_split3(preY[it], h, m, l);
-                reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
+                if constexpr (SPL) {
+                    uint2 h, m, l; da_split3(preY[it], h, m, l);
+                    reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
+                } else reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));
             }
         }
     };
     if (tw.cnt > 0) { issue_loads(0); write_lds(); }
     __syncthreads();
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // (x, dY) plane pairs, smallest products first
+    constexpr int NPR = SPL ? 6 : 1;
+    constexpr int PA[6] = {SPL ? 0 : 0, 2, 1, 0, 1, 0}, PB[6] = {SPL ? 2 : 0, 0, 1, 1, 0, 0};      // (x, dY) plane pairs, smallest products first (one plane: the single product)
     const int prio_rank = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) / 256u);
 #pragma unroll 1
     for (int tile = 0; tile < tw.cnt; ++tile) {
@@ -1636,7 +1645,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             Fd = loadF(c, 3);
             if (c < 4) Na = loadF(c + 1, 0);
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {                    // output row 2 wave: halo rows 0, 1, 2 <-> dy 0, 1, 2
+            for (int pr = 0; pr < NPR; ++pr) {                  // output row 2 wave: halo rows 0, 1, 2 <-> dy 0, 1, 2
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa.p[PA[pr]], Y0.p[PB[pr]], acc[c][0], 0, 0, 0);
                 acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y0.p[PB[pr]], acc[c][1], 0, 0, 0);
                 acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y0.p[PB[pr]], acc[c][2], 0, 0, 0);
@@ -1644,7 +1653,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             __builtin_amdgcn_sched_barrier(0);
             if (c < 4) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); }
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {                    // output row 2 wave + 1: halo rows 1, 2, 3
+            for (int pr = 0; pr < NPR; ++pr) {                  // output row 2 wave + 1: halo rows 1, 2, 3
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y1.p[PB[pr]], acc[c][0], 0, 0, 0);
                 acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y1.p[PB[pr]], acc[c][1], 0, 0, 0);
                 acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd.p[PA[pr]], Y1.p[PB[pr]], acc[c][2], 0, 0, 0);
@@ -2278,10 +2287,11 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     return 0;
 }
 
-template <bool PRO>
+template <bool PRO, int NPL = 3, bool HB = false>
 static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
-    const size_t shm = (size_t)(4 * HY * HX * 8 + 2 * TY * TX * 16) * 2 * 3;
-    auto kern = conv3_split_wgrad_kernel<PRO>;
+    size_t shm = (size_t)(4 * HY * HX * 8 + 2 * TY * TX * 16) * 2 * NPL;
+    if (shm < (size_t)2 * 15 * 64 * sizeof(float4)) shm = (size_t)2 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tiles' LDS
+    auto kern = conv3_split_wgrad_kernel<PRO, NPL, HB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -2356,18 +2366,24 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         return 0;
     }
     const bool split = da_matrix_mode() == 2 && s2d_cin == 0 && Cout % 4 == 0 && pick_ck(C1, C2) != 0;
-    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split);
+    // bf16 matrix mode: the row-owner kernel with one operand plane (K = 32 MFMAs, a sixth of the split mode's matrix work); DA_BF16_WGRAD_V1=1
+    // keeps the older tap-owner kernel (v_mfma_f32_16x16x16_bf16) for A/B
+    static int bfv1 = -1; if (bfv1 < 0) { const char* e = getenv("DA_BF16_WGRAD_V1"); bfv1 = (e && atoi(e)) ? 1 : 0; }
+    // (measured, 2 x 160 x 192 x 160: bf16 storage 48 -> 16 1.23 -> 1.09 ms, 16 -> 16 0.42 -> 0.38; NOT for more than one cout tile -- 96 -> 32: 0.44 ->
+    // 0.70 ms, the kernel re-stages x per 16-cout group -- and not with fp32 tensors, 1.21 -> 1.94 ms: there the staging conversions dominate)
+    const bool rows1 = !bfv1 && hb && da_matrix_mode() == 1 && s2d_cin == 0 && Cout % 4 == 0 && Cout <= 16 && pick_ck(C1, C2) != 0;
+    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
-    if (ws_bytes < q.partial_bytes + (split ? wg_tile_table_bytes(N, D, H, W) : 0)) return DA_ERR_WS_SMALL;
+    if (ws_bytes < q.partial_bytes + ((split || rows1) ? wg_tile_table_bytes(N, D, H, W) : 0)) return DA_ERR_WS_SMALL;
     WgP p;
     p.tiles = nullptr;
     p.s2in = (s2f && s2d_cin > 0 && s2f->fuse_in) ? S2dSrc{s2d_cin, s2f->D0, s2f->H0, s2f->W0} : S2dSrc{0, 0, 0, 0};
     { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
       const int resident = (q.nslabs * q.nchunks * q.ngroups + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident);
       static int phase = -1; if (phase < 0) { const char* e = getenv("DA_PHASE_PRIO"); phase = (e && atoi(e)) ? 1 : 0; } if (phase) p.prio_ranks = -1; }
-    if (split && !split_wgrad_v1()) {
+    if ((split && !split_wgrad_v1()) || rows1) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
         hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
         DA_LAUNCH_CHECK();
@@ -2391,6 +2407,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
         if (split) rcp = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, true, true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
+        else if (rows1) rcp = launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
         { DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2); }
@@ -2400,6 +2417,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     }
     int rc = DA_ERR_UNSUPPORTED;
     if (split) rc = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, false, true>(p, q, st) : launch_split_wgrad<false>(p, q, st);
+    else if (rows1) rc = launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
         if (hb) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true, false, false, true>(p, q, st);
