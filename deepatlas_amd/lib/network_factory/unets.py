@@ -64,6 +64,7 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
                 if i == len(decoders) - 1:
                     blocks.append(HeadConv(dec[-1], n_classes, kernel_size=1, stride=1, padding=0, bias=bias))
                 self.decoders.add_module('decBlock{}'.format(i), nn.Sequential(*blocks))
+            ops.tag_conv_layouts(self)          # FlatAdam keeps tagged conv weights tap-major (the kernels' layout); see ops.tag_conv_layouts
 
         def weights_init(self):
             self.apply(init_conv_weights)
@@ -159,6 +160,7 @@ class UNet(nn.Module):
         self.dc2 = self.decoder(64 + 128, 64, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
         self.dc1 = self.decoder(64, 64, kernel_size=3, stride=1, padding=1, bias=bias, batchnorm=BN)
         self.dc0 = HeadConv(64, n_classes, kernel_size=1, stride=1, padding=0, bias=bias)
+        ops.tag_conv_layouts(self)
 
     @property
     def lazy_head(self):

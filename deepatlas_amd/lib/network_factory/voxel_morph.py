@@ -38,6 +38,7 @@ class VoxelMorphCVPR2018(nn.Module):
                 self.decoders.append(convBlock(dec_filters[i - 1], dec_filters[i], stride=1, bias=True))
         self.flow = FlowConv(dec_filters[-1] + enc_filters[0], output_channel, kernel_size=3, stride=1, padding=1, bias=True)
         self.id_transform = None      # kept for attribute parity; the identity grid is generated inside the warp kernel
+        ops.tag_conv_layouts(self)    # FlatAdam keeps tagged conv weights tap-major (the kernels' layout); see ops.tag_conv_layouts
 
     def forward(self, source, target):
         up = ops.UpsampleNearestFn.apply

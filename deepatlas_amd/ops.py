@@ -284,7 +284,9 @@ def _async_target(param):
     if not ASYNC_WGRAD or param is None or not isinstance(param, torch.nn.Parameter) or not param.requires_grad:
         return None
     g = param.grad
-    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+    if g is None or not g.is_cuda or g.dtype != torch.float32:
+        return None
+    if not g.is_contiguous() and _tio_native(g, getattr(param, '_da_kind', None)) is None:      # (a tap-major native gradient view is dense too)
         return None
     if not _in_flat_bucket(g):
         return None
@@ -317,6 +319,105 @@ def register_flat_params(flat_p):
 _TIO_ENTRY = {'oik': 'da_w_oik_to_tio', 'iok': 'da_w_iok_to_tio', 'iok_flip': 'da_w_iok_flip_to_tio'}
 _TIO_BACK = {'oik': 'da_w_tio_to_oik', 'iok': 'da_w_tio_to_iok', 'iok_flip': 'da_w_tio_to_iok_flip'}
 
+# TAP-MAJOR NATIVE STORAGE.  FlatAdam lays the convolution weights (and their gradients / moments) out in its flat buckets tap-major --
+# the kernels' [k^3][Cin][Cout] -- and hands the modules STRIDED VIEWS of the reference's shapes ([Cout][Cin][k,k,k] / [Cin][Cout][k,k,k]):
+# state_dict keys, shapes and values are the reference's, Adam is elementwise (layout-agnostic), and the per-step layout conversions
+# (one launch per weight each way) do not exist.  A parameter's kind comes from tag_conv_layouts(); a parameter without an optimiser
+# (or with another one) stays contiguous in the reference layout and takes the conversion kernels + cache below.
+NATIVE_TIO = os.environ.get('DA_NO_NATIVE_TIO') != '1'
+
+
+def tag_conv_layouts(module):
+    """Mark the conv weights of `module` with the layout kind the kernels read them in ('oik': nn.Conv3d, 'iok': nn.ConvTranspose3d with
+    kernel 2; the k3 transposed convs of the full UNet are read tap-FLIPPED, which no view expresses: untagged).  Called by the networks'
+    constructors; FlatAdam reads the tag."""
+    for m in module.modules():
+        w = getattr(m, 'weight', None)
+        if isinstance(m, torch.nn.ConvTranspose3d):
+            if w is not None and tuple(w.shape[2:]) == (2, 2, 2):
+                w._da_kind = 'iok'
+        elif isinstance(m, torch.nn.Conv3d) and w is not None:
+            w._da_kind = 'oik'
+
+
+def param_view(buf, off, p):
+    """View of buf[off : off + p.numel()] with p's logical shape: tap-major storage for tagged conv weights, plain otherwise."""
+    k = p.numel()
+    flat = buf[off:off + k]
+    kind = getattr(p, '_da_kind', None) if NATIVE_TIO else None
+    if kind is not None and p.dim() == 5:
+        s0, s1, a, b, c = (int(v) for v in p.shape)
+        if kind == 'oik':
+            return flat.view(a, b, c, s1, s0).permute(4, 3, 0, 1, 2)
+        if kind == 'iok':
+            return flat.view(a, b, c, s0, s1).permute(3, 4, 0, 1, 2)
+    return flat.view(p.shape)
+
+
+def _tio_native(t, kind):
+    """[K3][Cin][Cout] VIEW of a parameter-layout tensor whose storage already is tap-major, else None."""
+    if t is None or t.dim() != 5 or kind not in ('oik', 'iok'):
+        return None
+    v = t.permute(2, 3, 4, 1, 0) if kind == 'oik' else t.permute(2, 3, 4, 0, 1)
+    if not v.is_contiguous():
+        return None
+    return v.reshape(v.shape[0] * v.shape[1] * v.shape[2], v.shape[3], v.shape[4])
+
+
+def _from_tio_view(dw_tio, kind, shape):
+    """Parameter-layout strided VIEW of a [K3][Cin][Cout] tensor (no kernel)."""
+    s0, s1, a, b, c = (int(v) for v in shape)
+    if kind == 'oik':
+        return dw_tio.view(a, b, c, s1, s0).permute(4, 3, 0, 1, 2)
+    return dw_tio.view(a, b, c, s0, s1).permute(3, 4, 0, 1, 2)
+
+
+class WgradTarget(object):
+    """Where an ASYNCHRONOUS weight-gradient kernel of a parameter writes.  `gw` is the parameter's gradient tensor in the flat bucket (None:
+    take the synchronous autograd path).  out() -- called INSIDE the stream context the kernel runs in, so that a scratch tensor belongs to
+    that stream's allocator pool -- returns the [K3][Cin][Cout] tensor to hand to the kernel; finish() folds it into the bucket:
+      * tap-major native bucket, not written since FlatAdam.zero_grad(): the bucket slice itself (writing over zeros == accumulating),
+      * native, already written this step: scratch, then one add into the slice,
+      * reference-layout gradient: scratch, then the converting accumulate kernel."""
+    __slots__ = ('gw', 'kind', 'like', 'direct', 'view', 'tmp')
+
+    def __init__(self, param, kind, w_tio):
+        self.gw = _async_target(param)
+        self.kind, self.like, self.direct, self.view, self.tmp = kind, w_tio, False, None, None
+        if self.gw is not None:
+            self.view = _tio_native(self.gw, kind)
+            if self.view is not None and getattr(param, '_da_gz', False) and os.environ.get('DA_NO_DIRECT_WGRAD') != '1':
+                param._da_gz = False
+                self.direct = True
+
+    def out(self):
+        if self.direct:
+            return self.view
+        self.tmp = torch.empty_like(self.like)
+        return self.tmp
+
+    def finish(self):
+        if self.direct:
+            return
+        if self.view is not None:
+            self.view.add_(self.tmp)
+        else:
+            grad_from_tio(self.tmp, self.kind, self.gw.shape, acc=self.gw)
+        self.tmp = None
+
+
+_NO_WGRAD_TARGET = type('NoTarget', (), {'gw': None})()
+
+
+def grad_for_autograd(dw_tio, kind, param):
+    """The gradient tensor handed to autograd for `param` from its [K3][Cin][Cout] gradient: a strided view when the parameter lives
+    tap-major (no kernel), else the layout conversion."""
+    if isinstance(param, torch.nn.Parameter):
+        param._da_gz = False                        # autograd is about to accumulate into .grad
+    if kind in ('oik', 'iok') and _tio_native(param.detach(), kind) is not None:
+        return _from_tio_view(dw_tio, kind, param.shape)
+    return grad_from_tio(dw_tio, kind, param.shape)
+
 
 def weight_tio(weight, kind):
     """[K3][Cin][Cout] copy of a conv weight.  kind 'oik': nn.Conv3d [Cout][Cin][k^3]; 'iok': nn.ConvTranspose3d [Cin][Cout][k^3];
@@ -324,6 +425,9 @@ def weight_tio(weight, kind):
     a_, b_ = int(weight.shape[0]), int(weight.shape[1])
     K3 = int(weight.shape[2] * weight.shape[3] * weight.shape[4])
     Cin, Cout = (b_, a_) if kind == 'oik' else (a_, b_)
+    nv = _tio_native(weight.detach(), kind)
+    if nv is not None:                         # tap-major native storage (FlatAdam): the kernels read the parameter's own memory
+        return nv
     capturing = torch.cuda.is_current_stream_capturing()
     stamp = None
     if not capturing and os.environ.get('DA_NO_WEIGHT_CACHE') != '1':
@@ -543,7 +647,9 @@ class Conv3dK3Fn(Function):
             k_dgrad(g, dx1, dx2, wp, wn, st)
         dw = None
         need_db_in_wgrad = want_b and db is None and db_partial is None
-        gw = _async_target(ctx.wparam) if want_w else None
+        kind_w = 'iok_flip' if ctx.transposed else 'oik'
+        wt = WgradTarget(ctx.wparam, kind_w, w_tio) if want_w else _NO_WGRAD_TARGET
+        gw = wt.gw
         gbt = _async_target(ctx.bparam) if want_b else None
         if db_partial is not None and not (want_w and gw is not None):
             def finish():                            # (frozen or non-bucket weight: the bias finish still goes to the side stream)
@@ -563,11 +669,10 @@ class Conv3dK3Fn(Function):
                 if db_partial is not None:
                     call('da_colsum_finish', ptr(db_partial[0]), db_partial[1], Cout, ptr(gbt), 1, sst)
                     _side_keep.append(db_partial[0])
-                dw_tio = torch.empty_like(w_tio)
                 dbs = _empty((Cout,), a1) if need_db_in_wgrad else None
                 swp, swn = _ws(max(wsb, nat.lib().da_bn_ws_bytes(g.numel() // Cout, Cout)) if up2 else wsb, a1)
-                k_wgrad(g, dw_tio, dbs, swp, swn, sst)
-                grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', gw.shape, acc=gw)
+                k_wgrad(g, wt.out(), dbs, swp, swn, sst)
+                wt.finish()
                 if dbs is not None:
                     gbt.add_(dbs)
             _side_keep.extend(t for t in (a1, a2, g) if t is not None)
@@ -580,7 +685,7 @@ class Conv3dK3Fn(Function):
             if dbw is not None:
                 db = dbw
             if want_w:
-                dw = grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', ctx.wparam.shape)
+                dw = grad_for_autograd(dw_tio, kind_w, ctx.wparam)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, None, None) + (None,) * ctx.n_extra
 
 
@@ -612,6 +717,7 @@ class Conv1x1Fn(Function):
         if pro is None:
             call_act('da_conv1x1_fwd', A(a), ptr(w_io), ptr(b), O(out), M, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
+        ctx.wparam = weight
         ctx.pro_slope = pro[2] if pro is not None else None
         ctx.save_for_backward(a, w_io, pro[0] if pro is not None else None, pro[1] if pro is not None else None)
         return ncdhw(out)
@@ -640,8 +746,7 @@ class Conv1x1Fn(Function):
                     call_act('da_conv1x1_wgrad', A(_apply_pro(a, (ps, pt, ctx.pro_slope), st)), A(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
             else:
                 call_act('da_conv1x1_wgrad', A(a), A(g), ptr(dw_io), ptr(db), M, Cin, Cout, wp, wn, st)
-            dw = _empty((Cout, Cin, 1, 1, 1), a)
-            call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), Cout, Cin, 1, st)
+            dw = grad_for_autograd(dw_io.view(1, Cin, Cout), 'oik', ctx.wparam)
         return ((ncdhw(dx) if dx is not None else None), dw, db) + (None,) * ctx.n_extra
 
 
@@ -662,6 +767,7 @@ class DeconvK2S2Fn(Function):
         wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
         call_act('da_deconv_k2s2_fwd', A(a), ptr(w_tio), ptr(b), O(out), N, D, H, W, Cin, Cout, wp, wn, st)
         ctx.has_bias = bias is not None
+        ctx.wparam = weight
         ctx.save_for_backward(a, w_tio)
         return ncdhw(out)
 
@@ -682,8 +788,7 @@ class DeconvK2S2Fn(Function):
             db = _empty((Cout,), a) if ctx.has_bias else None
             wp, wn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
             call_act('da_deconv_k2s2_wgrad', A(a), A(g), ptr(dw_tio), ptr(db), N, D, H, W, Cin, Cout, wp, wn, st)
-            dw = _empty((Cin, Cout, 2, 2, 2), a)
-            call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
+            dw = grad_for_autograd(dw_tio, 'iok', ctx.wparam)
         return (ncdhw(dx) if dx is not None else None), dw, db
 
 
@@ -953,7 +1058,9 @@ class ConvBNActFn(Function):
             dx2 = torch.empty_like(a2) if a2 is not None else None
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
             call_act('da_conv3d_k3_dgrad', A(dy), ptr(w_tio), O(dx1), C1, O(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
-        gw = _async_target(ctx.wparam) if ctx.needs_input_grad[2] else None
+        kind_w = 'iok_flip' if ctx.transposed else 'oik'
+        wt = WgradTarget(ctx.wparam, kind_w, w_tio) if ctx.needs_input_grad[2] else _NO_WGRAD_TARGET
+        gw = wt.gw
         if not ctx.needs_input_grad[2]:
             dw = None                                  # frozen weight: no weight-gradient kernel at all
         elif gw is not None:
@@ -963,16 +1070,15 @@ class ConvBNActFn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 sst = stream()
-                dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(wsb, a1)
-                _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, swp, swn, sst)
-                grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', gw.shape, acc=gw)
+                _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, wt.out(), N, D, H, W, Cout, swp, swn, sst)
+                wt.finish()
             _side_keep.extend(t for t in (a1, a2, dy, p1s, p1t, p2s, p2t) if t is not None)
             dw = None
         else:
             dw_tio = torch.empty_like(w_tio)
             _wgrad_with_pro(a1, C1, pro1, a2, C2, pro2, dy, dw_tio, N, D, H, W, Cout, wp, wn, st)
-            dw = grad_from_tio(dw_tio, 'iok_flip' if ctx.transposed else 'oik', ctx.wparam.shape)
+            dw = grad_for_autograd(dw_tio, kind_w, ctx.wparam)
         db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, db, dgamma, dbeta)
         return (ncdhw(dx1) if dx1 is not None else None, ncdhw(dx2) if dx2 is not None else None, dw, db, dgamma, dbeta,
                 None, None, None, None, None, None) + (None,) * ctx.n_extra
@@ -1031,23 +1137,22 @@ class DeconvBNActFn(Function):
             dx = torch.empty_like(a)
             wp, wn = _ws(nat.lib().da_pointwise_ws_bytes(8, Cin, Cout), a)
             call_act('da_deconv_k2s2_dgrad', A(dy), ptr(w_tio), O(dx), N, D, H, W, Cin, Cout, wp, wn, st)
-        gw = _async_target(ctx.wparam) if ctx.needs_input_grad[1] else None
+        wt = WgradTarget(ctx.wparam, 'iok', w_tio) if ctx.needs_input_grad[1] else _NO_WGRAD_TARGET
+        gw = wt.gw
         if not ctx.needs_input_grad[1]:
             dw = None                                  # frozen weight
         elif gw is not None:
             def side_work():                        # HBM-bound: overlaps the MFMA-bound conv data gradients on the main stream
-                dw_tio = torch.empty_like(w_tio)
                 swp, swn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
-                call_act('da_deconv_k2s2_wgrad', A(a), A(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, swp, swn, stream())
-                grad_from_tio(dw_tio, 'iok', gw.shape, acc=gw)
+                call_act('da_deconv_k2s2_wgrad', A(a), A(dy), ptr(wt.out()), None, N, D, H, W, Cin, Cout, swp, swn, stream())
+                wt.finish()
             _run_on_side(side_work, (a, dy))
             dw = None
         else:
             dw_tio = torch.empty_like(w_tio)
             wp, wn = _ws(nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, D, H, W, Cin, Cout), a)
             call_act('da_deconv_k2s2_wgrad', A(a), A(dy), ptr(dw_tio), None, N, D, H, W, Cin, Cout, wp, wn, st)
-            dw = _empty((Cin, Cout, 2, 2, 2), a)
-            call('da_w_tio_to_iok', ptr(dw_tio), ptr(dw), Cin, Cout, 8, st)
+            dw = grad_for_autograd(dw_tio, 'iok', ctx.wparam)
         db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, db, dgamma, dbeta)
         return ((ncdhw(dx) if dx is not None else None), dw, db, dgamma, dbeta, None, None, None, None, None, None) + (None,) * ctx.n_extra
 
@@ -1302,6 +1407,7 @@ class HeadDiceFn(Function):
         ps, pt, sl = _pro_args(pro)
         call_act('da_head_dice_fwd', A(a), ps, pt, sl, ptr(w_io), ptr(b), ptr(lab), lb, N, V, Cin, C, _WEIGHT_TYPES[weight_type], 1 if no_bg else 0,
                  float(eps), ptr(loss), ptr(coef), wp, wn, st)
+        ctx.wparam = weight
         ctx.cfg = (N, V, Cin, C, lb, wsb, pro[2] if pro is not None else -1.0, bias is not None)
         ctx.save_for_backward(a, w_io, b, lab, coef, pro[0] if pro is not None else None, pro[1] if pro is not None else None)
         return loss.reshape(())
@@ -1318,8 +1424,7 @@ class HeadDiceFn(Function):
         wp, wn = _ws(wsb, a)
         call_act('da_head_dice_bwd', A(a), ptr(ps), ptr(pt), float(sl), ptr(w_io), ptr(b), ptr(lab), lb, ptr(coef), ptr(gl),
                  O(dx), ptr(dw_io), ptr(db), N, V, Cin, C, wp, wn, st)
-        dw = _empty((C, Cin, 1, 1, 1), a)
-        call('da_w_tio_to_oik', ptr(dw_io), ptr(dw), C, Cin, 1, st)
+        dw = grad_for_autograd(dw_io.view(1, Cin, C), 'oik', ctx.wparam)
         return (ncdhw(dx), dw, db, None, None, None, None) + (None,) * ctx.n_extra
 
 

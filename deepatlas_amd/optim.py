@@ -43,14 +43,16 @@ class FlatAdam(torch.optim.Optimizer):
         self._steps = 0
         self._slices = []
         off = 0
+        # Tagged convolution weights (ops.tag_conv_layouts) are stored TAP-MAJOR in all four buckets -- the kernels' own layout -- and the
+        # module sees a strided view of the reference's shape (ops.param_view): no per-step layout conversion in either direction.
         for p in ps:
             k = p.numel()
-            self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
-            p.data = self.flat_p[off:off + k].view(p.shape)
-            p.grad = self.flat_g[off:off + k].view(p.shape)
+            ops.param_view(self.flat_p, off, p).copy_(p.detach())
+            p.data = ops.param_view(self.flat_p, off, p)
+            p.grad = ops.param_view(self.flat_g, off, p)
             self.state[p] = {'step': torch.tensor(0.0),
-                             'exp_avg': self.flat_m[off:off + k].view(p.shape),
-                             'exp_avg_sq': self.flat_v[off:off + k].view(p.shape)}
+                             'exp_avg': ops.param_view(self.flat_m, off, p),
+                             'exp_avg_sq': ops.param_view(self.flat_v, off, p)}
             self._slices.append((p, off, k))
             off += k
 
@@ -89,15 +91,16 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_g.zero_()
         for p, off, k in self._slices:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
-                p.grad = self.flat_g[off:off + k].view(p.shape)
+                p.grad = ops.param_view(self.flat_g, off, p)
+            p._da_gz = True                         # this parameter's gradient slice is all zeros: its first weight gradient may be WRITTEN there
 
     def _gather_stray_grads(self):
         ops.join_side_stream()                      # weight gradients accumulated on the side stream (ops.ASYNC_WGRAD)
         # autograd may have replaced a .grad view (e.g. first backward after set_to_none); fold it back
         for p, off, k in self._slices:
             if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
-                self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
-                p.grad = self.flat_g[off:off + k].view(p.shape)
+                ops.param_view(self.flat_g, off, p).copy_(p.grad)
+                p.grad = ops.param_view(self.flat_g, off, p)
 
     def _frozen_mask(self):
         """1.0 for elements whose parameter takes part in the update, 0.0 for frozen ones (requires_grad=False or no gradient this
@@ -150,8 +153,8 @@ class FlatAdam(torch.optim.Optimizer):
             st = sd['state'].get(i)
             if st is None:
                 continue
-            self.flat_m[off:off + k].copy_(st['exp_avg'].reshape(-1))
-            self.flat_v[off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+            ops.param_view(self.flat_m, off, p).copy_(st['exp_avg'])
+            ops.param_view(self.flat_v, off, p).copy_(st['exp_avg_sq'])
             self.state[p]['step'] = torch.tensor(float(st['step']))
             self._steps = int(float(st['step']))
         for grp, sg in zip(self.param_groups, sd['param_groups']):
