@@ -27,6 +27,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));      // four bf16 (the A / B fragment of v_mfma_f32_16x16x16_bf16)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));    // eight bf16 (the A / B fragment of v_mfma_f32_16x16x32_bf16)
 #include <type_traits>
+#ifndef DA_BF16_SMAP
+#define DA_BF16_SMAP 1   // bf16 matrix-mode forward kernels: staging offsets from the per-thread halo map (0: the cursor; A/B builds)
+#endif
 #ifndef DA_PIN
 #define DA_PIN 1   // pin the m-outer MFMA order (keeps hipcc from chaining 4 dependent MFMAs on one accumulator)
 #endif
@@ -565,7 +568,12 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     const AElem* abase = K32 ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + ((CK == 16) ? (g & 1) * 8 : 0)
                        : (CK == 16) ? reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + g * 4
                                     : reinterpret_cast<const AElem*>(lds) + ((wave * HY) * HX + i) * CK + (g & 1) * 4;
-    StageMap<CK, HZ> smap; if constexpr (SP) smap.init();
+    // SMAP: the next item's staging offsets from the per-thread halo map (7 VALU operations per load for an interior tile) instead of the
+    // carry-stepping cursor with its per-load bounds checks (~20).  Split mode always; the bf16 matrix-mode kernels too when the whole next
+    // tile is parked in registers (PRE == NIT): their 8 MFMAs per K-step leave the VALU as the busiest pipe (SQ counters: 7 VALU instructions
+    // per MFMA with the cursor, profiles/r03_pmc_sq_conv3d_48to16.txt)
+    constexpr bool SMAP = SP || (K32 && PRE == NIT && NREP == 1 && DA_BF16_SMAP);      // (two N-tiles: measured 10 % slower with the map's 17 extra registers)
+    StageMap<CK, HZ> smap; if constexpr (SMAP) smap.init();
     const bool hi = (g >> 1) != 0;
     auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
     auto a_off8 = [&](int s) -> int {                                                              // CK8: two taps per step
@@ -712,10 +720,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const bool first = cbase < p.C1;
             const int Csn = first ? p.C1 : p.C2;
             if constexpr (SP && PH == 1) { (void)Csn; }
-            else if constexpr (SP) {
+            else if constexpr (SMAP) {
                 const long long sample = (long long)p.D * p.H * p.W * Csn;
-                rsn = da_rsrc((first ? p.in1 : p.in2) + (long long)n2 * sample, (unsigned)(sample * sizeof(float)));
-                stile = smap.tile(z2, y2, x2, p.D, p.H, p.W, Csn, first ? cbase : cbase - p.C1, has_next && !(p.ablate & 1));
+                rsn = da_rsrc_n<HB>(first ? p.in1 : p.in2, n2, sample);
+                stile = smap.tile(z2, y2, x2, p.D, p.H, p.W, Csn, first ? cbase : cbase - p.C1, has_next && !(p.ablate & 1), (int)HbEl<HB>::ES);
             } else cur.init(first ? p.in1 : p.in2, Csn, first ? cbase : cbase - p.C1, n2, z2, y2, x2, p.D, p.H, p.W, has_next && !(p.ablate & 1));
         }
         Frag A0[HALF], A1[HALF];
@@ -747,9 +755,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             for (int j = 0; j < PRE; ++j)
                 if (j * (NSTEPS - TAIL) / (PRE > 0 ? PRE : 1) == s) {
                     if constexpr (SP && PH == 1) { }
-                    else if constexpr (SP) {
+                    else if constexpr (SMAP) {
                         const unsigned so = smap.offset(stile, j);
-                        pre[j] = da_buf_load4(rsn, so);
+                        pre[j] = da_buf_loadq<HB>(rsn, so);
                         if constexpr (PH == 2) pre2[j] = da_buf_load4(rsn, so == 0xFFFFFFFFu ? so : so + CK * 4u);      // the same voxel's next 8 channels
                         if constexpr (PRO) vm |= (so != 0xFFFFFFFFu ? 1u : 0u) << j;
                     } else { pre[j] = cur.next(); if constexpr (PRO) vm |= (cur.last_inb ? 1u : 0u) << j; }
