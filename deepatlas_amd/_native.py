@@ -83,7 +83,7 @@ SIGNATURES = {
     'da_label_warp_dice_fwd': (I, [P, I, P, I, P, I, I, I, I, I, I, I, F, P, P, P, SZ, P]),
     'da_label_warp_dice_bwd': (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, P]),
     'da_warp_adjoint_labels': (I, [P, I, P, P, P, I, I, I, I, I, P]),
-    'da_seg_anat_dlogits': (I, [P, P, I, P, P, P, P, P, P, I, LL, I, P]),
+    'da_seg_anat_dlogits': (I, [P, P, I, P, P, P, P, P, P, P, I, LL, I, P]),
     'da_warp_bwd_dsrc_det_ws_bytes': (SZ, [I, I, I, I, I]),
     'da_warp_bwd_dsrc_det': (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
     'da_identity_grid': (I, [P, I, I, I, I, P]),

@@ -105,3 +105,65 @@ __device__ __forceinline__ float da_ld1(const float* p, long long i) { return p[
 __device__ __forceinline__ float da_ld1(const da_bf16* p, long long i) { return __uint_as_float((unsigned)p[i].v << 16); }
 __device__ __forceinline__ void da_st1(float* p, long long i, float v) { p[i] = v; }
 __device__ __forceinline__ void da_st1(da_bf16* p, long long i, float v) { p[i].v = (unsigned short)(da_pack_bf16x2(v, 0.f) & 0xFFFFu); }
+
+// All-reduce over the four 16-lane rows of a wave (lane = 16 g + i: same i, every g) on the VALU.  v_permlane16_swap exchanges the odd
+// rows of one register with the even rows of the other, v_permlane32_swap the upper half with the lower half (gfx950): called with the
+// same value twice they return (even-row copy, odd-row copy) / (lower copy, upper copy), so one swap + one add is the xor-16 / xor-32
+// butterfly step -- the same pairing, hence bit-identical sums, as two ds_bpermute shuffles at ~100 cycles each on the LDS path.
+typedef unsigned da_u32x2 __attribute__((ext_vector_type(2)));
+// (through inline asm: hipcc 7.2 folds r[0] + r[1] of __builtin_amdgcn_permlane16_swap(v, v) into r[0] + r[0] --
+// tools/ubench/permlane_swap.hip; the s_nop cover the VALU-write -> swap and swap -> VALU-read hazards the compiler would have padded)
+__device__ __forceinline__ void da_swap16(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void da_swap32(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float da_rows_sum(float v) {
+    float a, b;
+    da_swap16(v, a, b); v = a + b;
+    da_swap32(v, a, b); return a + b;
+}
+__device__ __forceinline__ float da_rows_max(float v) {
+    float a, b;
+    da_swap16(v, a, b); v = fmaxf(a, b);
+    da_swap32(v, a, b); return fmaxf(a, b);
+}
+
+// Linear voxel index -> coordinates.  In 32-bit arithmetic whenever the index fits: a 64-bit integer division costs the VALU roughly ten
+// times the instructions of a 32-bit one, and the gather kernels (warps, label warps) did three per lane.
+__device__ __forceinline__ void da_vox4(long long v, int D, int H, int W, int& n, int& d, int& h, int& w) {
+    if (v < 0x7FFFFFFFLL) {
+        unsigned r = (unsigned)v;
+        const unsigned q1 = r / (unsigned)W; w = (int)(r - q1 * (unsigned)W);
+        const unsigned q2 = q1 / (unsigned)H; h = (int)(q1 - q2 * (unsigned)H);
+        const unsigned q3 = q2 / (unsigned)D; d = (int)(q2 - q3 * (unsigned)D);
+        n = (int)q3;
+    } else {
+        long long r = v;
+        w = (int)(r % W); r /= W;
+        h = (int)(r % H); r /= H;
+        d = (int)(r % D); n = (int)(r / D);
+    }
+}
+// i -> (i / m, i % m) for a small positive m (lanes per voxel, channels): shift / mask for a power of two, 32-bit when the index fits
+__device__ __forceinline__ void da_divmod(long long i, int m, long long& quot, int& rem) {
+    if ((m & (m - 1)) == 0) { quot = i >> (__ffs(m) - 1); rem = (int)(i & (long long)(m - 1)); }
+    else if (i < 0x7FFFFFFFLL) { const unsigned r = (unsigned)i, qq = r / (unsigned)m; quot = (long long)qq; rem = (int)(r - qq * (unsigned)m); }
+    else { quot = i / m; rem = (int)(i % m); }
+}
+__device__ __forceinline__ void da_vox3(long long v, int H, int W, int& d, int& h, int& w) {
+    if (v < 0x7FFFFFFFLL) {
+        const unsigned r = (unsigned)v;
+        const unsigned q1 = r / (unsigned)W; w = (int)(r - q1 * (unsigned)W);
+        const unsigned q2 = q1 / (unsigned)H; h = (int)(q1 - q2 * (unsigned)H);
+        d = (int)q2;
+    } else {
+        long long r = v;
+        w = (int)(r % W); r /= W;
+        h = (int)(r % H); d = (int)(r / H);
+    }
+}
+

@@ -101,13 +101,13 @@ __device__ __forceinline__ void hd_probs(const HdP& p, const T* __restrict__ xs,
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) m = fmaxf(m, acc[t][n][reg]);
-        m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        m = da_rows_max(m);
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) { acc[t][n][reg] = __expf(acc[t][n][reg] - m); s += acc[t][n][reg]; }      // v_exp_f32: arguments <= 0, relative error ~1e-6
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = da_rows_sum(s);
         const float inv = valid ? 1.f / s : 0.f;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) { gg[n][reg] = k0[n][reg] * (rel == 16 * n + reg ? 1.f : 0.f) + k1[n][reg]; dot += gg[n][reg] * acc[t][n][reg]; }
-            dot += __shfl_xor(dot, 16); dot += __shfl_xor(dot, 32);
+            dot = da_rows_sum(dot);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
                     da_stq(dxs, (vox * p.K + 16 * c + 4 * g) >> 2, make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]));
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();       // xl / dl are this wave's own tiles and a wave's LDS accesses execute in order: no workgroup barrier
         // weight gradient: dW[k][c] += sum_voxels xa[voxel][k] dl[voxel][c]   (K dimension = the 64 voxels of this wave's chunk)
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) wacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bw[n], wacc[c][n], 0, 0, 0);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     // per-workgroup partials: dW [K][C] then dbias [C]; the four waves are folded through LDS in a fixed order
     __syncthreads();

@@ -11,10 +11,8 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int ow = (int)(v % Wo); v /= Wo;
-        const int oh = (int)(v % Ho); v /= Ho;
-        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, od, oh, ow; da_vox4(v, Do, Ho, Wo, n, od, oh, ow);
         float m[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
@@ -46,10 +44,8 @@ __global__ void maxpool2_fwd_pro_kernel(const T* __restrict__ x, const float* __
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / 4;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int ow = (int)(v % Wo); v /= Wo;
-        const int oh = (int)(v % Ho); v /= Ho;
-        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, od, oh, ow; da_vox4(v, Do, Ho, Wo, n, od, oh, ow);
         const float4 sc = reinterpret_cast<const float4*>(scale)[q], sf = reinterpret_cast<const float4*>(shift)[q];
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         float4 a[8];
@@ -82,10 +78,8 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ dy, const T* __restric
     const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / VEC;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int ow = (int)(v % Wo); v /= Wo;
-        const int oh = (int)(v % Ho); v /= Ho;
-        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, od, oh, ow; da_vox4(v, Do, Ho, Wo, n, od, oh, ow);
         float m[VEC], g[VEC]; int am[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = 0; }
@@ -131,10 +125,8 @@ __global__ void upsample_nearest_fwd_kernel(const T* __restrict__ x, T* __restri
     const float sd = (float)D / (float)Do, sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int ow = (int)(v % Wo); v /= Wo;
-        const int oh = (int)(v % Ho); v /= Ho;
-        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, od, oh, ow; da_vox4(v, Do, Ho, Wo, n, od, oh, ow);
         const int d = nearest_src(od, D, Do, sd), h = nearest_src(oh, H, Ho, sh), w = nearest_src(ow, W, Wo, sw);
         const long long po = ((((long long)n * D + d) * H + h) * W + w) * C + q * VEC;
         if (VEC == 4) da_stq(y, i, da_ldq(x, po >> 2));
@@ -150,10 +142,8 @@ __global__ void upsample_nearest_bwd_kernel(const T* __restrict__ dy, T* __restr
     const float sd = (float)D / (float)Do, sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
     const long long total = (long long)N * D * H * W * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int w = (int)(v % W); v /= W;
-        const int h = (int)(v % H); v /= H;
-        const int d = (int)(v % D); const int n = (int)(v / D);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         // candidate output range per axis: [floor(i*out/in) - 1, floor((i+1)*out/in) + 1]
         const int d0 = max(0, (int)((long long)d * Do / D) - 1), d1 = min(Do - 1, (int)((long long)(d + 1) * Do / D) + 1);
         const int h0 = max(0, (int)((long long)h * Ho / H) - 1), h1 = min(Ho - 1, (int)((long long)(h + 1) * Ho / H) + 1);
@@ -193,10 +183,8 @@ __global__ void upsample_tri2_fwd_kernel(const float* __restrict__ x, float* __r
     const int cq = C / VEC, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const long long total = (long long)N * Do * Ho * Wo * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int ow = (int)(v % Wo); v /= Wo;
-        const int oh = (int)(v % Ho); v /= Ho;
-        const int od = (int)(v % Do); const int n = (int)(v / Do);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, od, oh, ow; da_vox4(v, Do, Ho, Wo, n, od, oh, ow);
         int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
         tri2_src(od, D, d0, d1, ld); tri2_src(oh, H, h0, h1, lh); tri2_src(ow, W, w0, w1, lw);
         float acc[VEC];
@@ -223,10 +211,8 @@ __global__ void upsample_tri2_bwd_kernel(const float* __restrict__ dy, float* __
     const int cq = C / VEC, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const long long total = (long long)N * D * H * W * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq); long long v = i / cq;
-        const int w = (int)(v % W); v /= W;
-        const int h = (int)(v % H); v /= H;
-        const int d = (int)(v % D); const int n = (int)(v / D);
+        int q; long long v; da_divmod(i, cq, v, q);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         float acc[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.f;

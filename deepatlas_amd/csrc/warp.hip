@@ -44,12 +44,8 @@ __global__ void warp_fwd_kernel(const float* __restrict__ src, const float* __re
     const long long nvox = (long long)N * D * H * W;
     const long long total = nvox * lpv;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % lpv);
-        const long long v = i / lpv;
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int q; long long v; da_divmod(i, lpv, v, q);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -96,12 +92,8 @@ __global__ void warp_bwd_kernel(const float* __restrict__ dout, const float* __r
     const long long total = nvox * lpv;
     // total is padded by the launcher to a multiple of lpv*...; every lane of a voxel group runs the same trip count
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % lpv);
-        const long long v = i / lpv;
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int q; long long v; da_divmod(i, lpv, v, q);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -164,12 +156,8 @@ __global__ void warp_bwd_dsrc_lane_kernel(const float* __restrict__ dout, const 
                                           int N, int D, int H, int W, int C) {
     const long long total = (long long)N * D * H * W * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long long v = i / C;
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int c; long long v; da_divmod(i, C, v, c);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -217,12 +205,8 @@ __global__ void warp_bwd_dsrc_fixed_kernel(const float* __restrict__ dout, const
     const float scale = fixed_scale_from_max(max_bits[0]);
     const long long total = (long long)N * D * H * W * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long long v = i / C;
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int c; long long v; da_divmod(i, C, v, c);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -263,12 +247,8 @@ __global__ void warp_labels_fwd_kernel(const void* __restrict__ labels, int labe
     const int cq = C / VEC;                                    // lanes per voxel, VEC channels each (16-byte stores for VEC = 4)
     const long long total = (long long)N * D * H * W * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cq) * VEC;
-        const long long v = i / cq;
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int c0; long long v; da_divmod(i, cq, v, c0); c0 *= VEC;
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -300,10 +280,7 @@ __global__ void warp_labels_bwd_kernel(const float* __restrict__ dout, const voi
                                        const float* __restrict__ disp, float* __restrict__ d_disp, int N, int D, int H, int W, int C) {
     const long long nvox = (long long)N * D * H * W;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -333,9 +310,7 @@ __global__ void warp_labels_bwd_kernel(const float* __restrict__ dout, const voi
 __global__ void identity_grid_kernel(float* __restrict__ out, int D, int H, int W, int normalize) {
     const long long V = (long long)D * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long long)gridDim.x * blockDim.x) {
-        long long r = i;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); const int d = (int)(r / H);
+        int d, h, w; da_vox3(i, H, W, d, h, w);
         out[i] = normalize ? id_coord(w, W) : (float)w;           // channel 0: W axis (x)
         out[V + i] = normalize ? id_coord(h, H) : (float)h;       // channel 1: H axis (y)
         out[2 * V + i] = normalize ? id_coord(d, D) : (float)d;   // channel 2: D axis (z)
@@ -353,72 +328,104 @@ __global__ void identity_grid_kernel(float* __restrict__ out, int D, int H, int 
 //    collapses to  W^T g = b[c] * A[u] + a[c] * B[u][c]  with  A = W^T 1  (one channel) and  B = W^T onehot(St)  (8 atomics per
 //    voxel land in channel St[v] only): 16 atomics per voxel instead of 256.
 // ------------------------------------------------------------------------------------------------
-template <int CPL>   // classes per lane; lpv = C / CPL lanes share a voxel
-__global__ void label_warp_dice_partial_kernel(const void* __restrict__ lab_m, int bm, const void* __restrict__ lab_t, int bt,
-                                               const float* __restrict__ disp, int D, int H, int W, int C, int lpv,
-                                               double* __restrict__ partial /* [N][gridDim.x][3][C] : I, S, T */) {
-    __shared__ double sred[4][3 * 64];
+// One lane per voxel.  The three per-class sums are histograms keyed by a label: S by the 8 corner labels of the moving map (value = the
+// corner's weight), I and T by the target label (values: the weight that landed on corners carrying that label, and 1).  Label maps are
+// piecewise constant, so the 64 voxels of a wave see one to three distinct keys: the wave loops over the DISTINCT keys present, sums the
+// lanes that carry the key with a fixed-order butterfly and lane 0 adds the sum to the wave's double-precision table in LDS -- no
+// atomics, a fixed summation order, and ~40 cross-lane operations per 64 voxels instead of 8 corners x C compares per voxel.  (The earlier
+// form gave every voxel C / 8 lanes that each re-derived the taps and compared every corner label against their 8 classes: VALU-bound at
+// 0.02 of the HBM rate.)
+__device__ __forceinline__ float lwd_wave_sum(float v) {
+    // rotations inside each row of 16 lanes (DPP: a few cycles each, where a ds_bpermute shuffle is a ~100-cycle LDS round trip and six of
+    // them in a dependent chain cost more than the rest of the iteration), then the four row sums through scalar registers
+#define DA_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xF, 0xF, false))
+    v += DA_ROR(v, 8); v += DA_ROR(v, 4); v += DA_ROR(v, 2); v += DA_ROR(v, 1);
+#undef DA_ROR
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__global__ void __launch_bounds__(256) label_warp_dice_partial_kernel(const void* __restrict__ lab_m, int bm, const void* __restrict__ lab_t, int bt,
+                                                                      const float* __restrict__ disp, int D, int H, int W, int C,
+                                                                      double* __restrict__ partial /* [N][gridDim.x][3][C] : I, S, T */) {
+    __shared__ double acc[4][3][64];
     const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 3 * 64; i += 256) (&acc[0][0][0])[i] = 0.0;
+    __syncthreads();
+    double* const aI = acc[wave][0];
+    double* const aS = acc[wave][1];
+    double* const aT = acc[wave][2];
     const long long V = (long long)D * H * W;
-    const long long total = V * lpv;
-    float aS[CPL], aI[CPL], aT[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) { aS[j] = 0.f; aI[j] = 0.f; aT[j] = 0.f; }
-    double dS[CPL], dI[CPL], dT[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) { dS[j] = 0.0; dI[j] = 0.0; dT[j] = 0.0; }
-    int cnt = 0;
     const long long sb = (long long)n * V;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % lpv);
-        const long long v = i / lpv;
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); const int d = (int)(r / H);
-        const float* u = disp + (sb + v) * 3;
+    const long long stride = (long long)gridDim.x * 256;
+    // add `val` of the lanes whose key is the same class into table[key], one distinct key at a time (key < 0: lane takes no part)
+    auto hist_add = [&](double* table, int key, float val) {
+        unsigned long long todo = __ballot(key >= 0);
+        while (todo) {
+            const int c = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
+            const bool m = key == c;
+            const float s = lwd_wave_sum(m ? val : 0.f);
+            if (lane == 0) table[c] += (double)s;
+            todo &= ~__ballot(m);
+        }
+    };
+    for (long long base = (long long)blockIdx.x * 256 + wave * 64; base < V; base += stride) {      // wave-uniform trip count
+        const long long v = base + lane;
+        const bool live = v < V;
+        const long long vv = live ? v : V - 1;
+        int d, h, w; da_vox3(vv, H, W, d, h, w);
+        const float* u = disp + (sb + vv) * 3;
         const float gx = u[0] + id_coord(w, W), gy = u[1] + id_coord(h, H), gz = u[2] + id_coord(d, D);
         const bool fin = is_finite_coord(gx, gy, gz);
         const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
-        const int c0 = q * CPL;
-        const int tl = warp_label_at(lab_t, bt, sb + v) - c0;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) aT[j] += (tl == j) ? 1.f : 0.f;
+        int tl = warp_label_at(lab_t, bt, sb + vv);
+        if (!live || tl < 0 || tl >= C) tl = -1;
+        int lab[8]; float wk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
             const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
-            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
-                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
-                const int rel = warp_label_at(lab_m, bm, sb + ((long long)z * H + y) * W + x) - c0;
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    const float hit = (rel == j) ? wgt : 0.f;
-                    aS[j] += hit;
-                    aI[j] += (tl == j) ? hit : 0.f;
-                }
+            lab[k] = -1; wk[k] = 0.f;
+            if (live && x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                wk[k] = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                const int l = warp_label_at(lab_m, bm, sb + ((long long)z * H + y) * W + x);
+                lab[k] = (l >= 0 && l < C) ? l : -1;
             }
         }
-        if (++cnt == 16) {
+        // T and I: keyed by the target label
+        float wi = 0.f;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) { dS[j] += (double)aS[j]; dI[j] += (double)aI[j]; dT[j] += (double)aT[j]; aS[j] = aI[j] = aT[j] = 0.f; }
-            cnt = 0;
+        for (int k = 0; k < 8; ++k) wi += (lab[k] == tl) ? wk[k] : 0.f;          // (tl = -1 never matches a weight that counts: hist_add skips the lane)
+        {
+            unsigned long long todo = __ballot(tl >= 0);
+            while (todo) {
+                const int c = __builtin_amdgcn_readlane(tl, __ffsll((long long)todo) - 1);
+                const bool m = tl == c;
+                const unsigned long long mm = __ballot(m);
+                const float s = lwd_wave_sum(m ? wi : 0.f);
+                if (lane == 0) { aI[c] += (double)s; aT[c] += (double)__popcll(mm); }
+                todo &= ~mm;
+            }
+        }
+        // S: the corners that share the first corner's label go in one pass; the others (label boundaries) corner by corner
+        const int key0 = lab[0];
+        float s0 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s0 += (lab[k] == key0) ? wk[k] : 0.f;
+        hist_add(aS, key0, s0);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const int key = (lab[k] != key0) ? lab[k] : -1;
+            if (__ballot(key >= 0)) hist_add(aS, key, wk[k]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) { dS[j] += (double)aS[j]; dI[j] += (double)aI[j]; dT[j] += (double)aT[j]; }
-    // lanes with the same q (= lane % lpv; 256 and 64 are multiples of lpv) hold the same classes: fixed-order xor tree over the others
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        double a = dI[j], b = dS[j], c = dT[j];
-        for (int o = lpv; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
-        if (lane < lpv) { const int cls = lane * CPL + j; sred[wave][cls] = a; sred[wave][64 + cls] = b; sred[wave][128 + cls] = c; }
-    }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 3 * C; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < 3 * C; idx += 256) {
         const int k = idx / C, c = idx % C;
-        const double s = sred[0][k * 64 + c] + sred[1][k * 64 + c] + sred[2][k * 64 + c] + sred[3][k * 64 + c];
-        partial[(((size_t)n * gridDim.x + blockIdx.x) * 3 + k) * C + c] = s;
+        partial[(((size_t)n * gridDim.x + blockIdx.x) * 3 + k) * C + c] = acc[0][k][c] + acc[1][k][c] + acc[2][k][c] + acc[3][k][c];
     }
 }
 
@@ -430,10 +437,7 @@ __global__ void label_warp_dice_bwd_kernel(const void* __restrict__ lab_m, int b
     const float gl = dloss[0];
     const int NC = N * C;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -462,17 +466,17 @@ __global__ void label_warp_dice_bwd_kernel(const void* __restrict__ lab_m, int b
     }
 }
 
-// B[n][u][St[v]] += w over the 8 taps of every voxel v  (B zero-filled by the launcher).  A = W^T 1 needs no scatter of its own: every
-// weight lands in exactly one class channel, so A[u] = sum_c B[u][c] (formed by the consumer from the row it reads anyway); voxels whose
-// target label is outside [0, C) put their weights into the separate array A_extra (NULL when the caller knows there are none).
+// B[n][St[v]][u] += w over the 8 taps of every voxel v  (B zero-filled by the launcher).  B is CLASS-MAJOR ([N][C][V], one plane per class):
+// label maps are piecewise constant and a registration field is smooth, so the 64 lanes of a wave (64 voxels along x) add into 64
+// consecutive floats of one plane -- the atomics of one instruction fall into two or three 128-byte lines instead of 64 (voxel-major
+// rows: one line per lane; 1.94 -> 0.54 ms at 160x192x160, profiles/r03_gather_kernels.txt).  A = W^T 1 needs no scatter of its own:
+// every weight lands in exactly one class plane, so A[u] = sum_c B[c][u] (formed by the consumer from the values it reads anyway); voxels
+// whose target label is outside [0, C) put their weights into the separate array A_extra (NULL when the caller knows there are none).
 __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int bt, const float* __restrict__ disp,
                                            float* __restrict__ A_extra, float* __restrict__ B, int N, int D, int H, int W, int C) {
     const long long V = (long long)D * H * W, nvox = V * N;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
-        long long r = v;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int d = (int)(r % D); const int n = (int)(r / D);
+        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
         const float gz = disp[v * 3 + 2] + id_coord(d, D);
@@ -488,44 +492,105 @@ __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int b
             if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
                 const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
                 const long long uu = sbase + ((long long)z * H + y) * W + x;
-                if (lok) atomicAdd(B + uu * C + lab, wgt);
+                if (wgt == 0.f) continue;                                    // (an integer coordinate: four of the eight weights are exact zeros)
+                if (lok) atomicAdd(B + ((long long)n * C + lab) * V + (uu - sbase), wgt);
                 else if (A_extra) atomicAdd(A_extra + uu, wgt);
             }
         }
     }
 }
 
-// dlogits[u][j] = p[u][j] (g[u][j] - sum_c g[u][c] p[u][c]),  g = gl_a (b_a[c] A[u] + a_a[c] B[u][c]) + gl_s (a_s[c] [Sm[u] == c] + b_s[c]),
-// p = softmax(logits) given as `prob`; written IN PLACE over B.  lpv = C / 4 lanes per voxel.
-__global__ void seg_anat_dlogits_kernel(const float* __restrict__ prob, const void* __restrict__ lab_m, int bm,
-                                        const float* __restrict__ A, float* __restrict__ B,
-                                        const float* __restrict__ coef_s, const float* __restrict__ coef_a,
-                                        const float* __restrict__ gl_s, const float* __restrict__ gl_a,
-                                        int N, long long V, int C, int lpv) {
-    const long long total = (long long)N * V * lpv;
-    const int NC = N * C;
+// dlogits[u][j] = p[u][j] (g[u][j] - sum_c g[u][c] p[u][c]),  g = gl_a (b_a[c] A[u] + a_a[c] B[c][u]) + gl_s (a_s[c] [Sm[u] == c] + b_s[c]),
+// p = softmax(logits) given as `prob` ([N][V][C]); B class-major ([N][C][V], see above); dlogits [N][V][C].  A workgroup takes `tv`
+// consecutive voxels: the C planes' segments are read coalesced into an LDS tile [C][tv + 1], then lpv = C / 4 lanes per voxel form the
+// row (16-byte accesses on prob / dlogits).
+__global__ void __launch_bounds__(256) seg_anat_dlogits_kernel(const float* __restrict__ prob, const void* __restrict__ lab_m, int bm,
+                                                               const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dlogits,
+                                                               const float* __restrict__ coef_s, const float* __restrict__ coef_a,
+                                                               const float* __restrict__ gl_s, const float* __restrict__ gl_a,
+                                                               int N, long long V, int C, int lpv, int tv) {
+    extern __shared__ float tile[];                                        // [C][tv + 1]
+    const int NC = N * C, ts = tv + 1;
+    const int ltv = __ffs(tv) - 1, llp = __ffs(lpv) - 1;                   // tv, lpv: powers of two
     const float gs = (coef_s && gl_s) ? gl_s[0] : 0.f, ga = gl_a ? gl_a[0] : 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % lpv);
-        const long long row = i / lpv;
-        const int n = (int)(row / V);
-        const float4 pv = *reinterpret_cast<const float4*>(prob + row * C + q * 4);
-        const float4 bv = *reinterpret_cast<const float4*>(B + row * C + q * 4);
-        float a = bv.x + bv.y + bv.z + bv.w;                            // A[u] = sum_c B[u][c] (+ the out-of-range-label weights)
-        for (int k = 1; k < lpv; k <<= 1) a += __shfl_xor(a, k);
-        if (A) a += A[row];
-        const float p[4] = {pv.x, pv.y, pv.z, pv.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
-        const int lab = (coef_s && lab_m) ? warp_label_at(lab_m, bm, row) - q * 4 : -1;
-        float g[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = n * C + q * 4 + j;
-            g[j] = ga * (coef_a[NC + c] * a + coef_a[c] * b[j]);
-            if (coef_s) g[j] += gs * (coef_s[c] * (lab == j ? 1.f : 0.f) + coef_s[NC + c]);
+    const long long tps = (V + tv - 1) / tv, ntiles = tps * N;
+    for (long long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        const int n = (int)(tix / tps);
+        const long long u0 = (tix - (long long)n * tps) * tv;
+        __syncthreads();                                                   // the previous tile has been consumed
+        const float* Bn = B + (long long)n * C * V;
+        for (int idx = threadIdx.x; idx < C * tv; idx += 256) {
+            const int c = idx >> ltv, t = idx & (tv - 1);
+            const long long u = u0 + t;
+            tile[c * ts + t] = (u < V) ? Bn[(long long)c * V + u] : 0.f;
         }
-        float dot = g[0] * p[0] + g[1] * p[1] + g[2] * p[2] + g[3] * p[3];
-        for (int k = 1; k < lpv; k <<= 1) dot += __shfl_xor(dot, k);
-        *reinterpret_cast<float4*>(B + row * C + q * 4) = make_float4(p[0] * (g[0] - dot), p[1] * (g[1] - dot), p[2] * (g[2] - dot), p[3] * (g[3] - dot));
+        __syncthreads();
+        for (int item = threadIdx.x; item < tv * lpv; item += 256) {       // (256 % lpv == 0: the lanes of a voxel share a wave and a trip)
+            const int t = item >> llp, q = item & (lpv - 1);
+            const long long u = u0 + t;
+            if (u >= V) continue;                                          // whole voxel groups drop out together
+            const long long row = (long long)n * V + u;
+            const float4 pv = *reinterpret_cast<const float4*>(prob + row * C + q * 4);
+            const float b[4] = {tile[(q * 4 + 0) * ts + t], tile[(q * 4 + 1) * ts + t], tile[(q * 4 + 2) * ts + t], tile[(q * 4 + 3) * ts + t]};
+            float a = b[0] + b[1] + b[2] + b[3];                           // A[u] = sum_c B[c][u] (+ the out-of-range-label weights)
+            for (int k = 1; k < lpv; k <<= 1) a += __shfl_xor(a, k);
+            if (A) a += A[row];
+            const float p[4] = {pv.x, pv.y, pv.z, pv.w};
+            const int lab = (coef_s && lab_m) ? warp_label_at(lab_m, bm, row) - q * 4 : -1;
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = n * C + q * 4 + j;
+                g[j] = ga * (coef_a[NC + c] * a + coef_a[c] * b[j]);
+                if (coef_s) g[j] += gs * (coef_s[c] * (lab == j ? 1.f : 0.f) + coef_s[NC + c]);
+            }
+            float dot = g[0] * p[0] + g[1] * p[1] + g[2] * p[2] + g[3] * p[3];
+            for (int k = 1; k < lpv; k <<= 1) dot += __shfl_xor(dot, k);
+            *reinterpret_cast<float4*>(dlogits + row * C + q * 4) = make_float4(p[0] * (g[0] - dot), p[1] * (g[1] - dot), p[2] * (g[2] - dot), p[3] * (g[3] - dot));
+        }
+    }
+}
+
+// The same pass with ONE lane per voxel (C a compile-time constant <= 32): the C class planes are read directly -- lane = voxel, so every
+// plane access is coalesced and needs no LDS tile, no shuffle and no barrier -- and the lane walks its own 128-byte rows of prob / dlogits
+// in 16-byte pieces (eight accesses to the same line: the first one brings it into the CU's cache).
+template <int CC>
+__global__ void __launch_bounds__(256) seg_anat_dlogits_lane_kernel(const float* __restrict__ prob, const void* __restrict__ lab_m, int bm,
+                                                                    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dlogits,
+                                                                    const float* __restrict__ coef_s, const float* __restrict__ coef_a,
+                                                                    const float* __restrict__ gl_s, const float* __restrict__ gl_a, int N, long long V) {
+    const int NC = N * CC;
+    const float gs = (coef_s && gl_s) ? gl_s[0] : 0.f, ga = gl_a ? gl_a[0] : 0.f;
+    const long long bps = (V + 255) / 256, nb = bps * N;                   // a workgroup never straddles two samples: n is uniform
+    for (long long bix = blockIdx.x; bix < nb; bix += gridDim.x) {
+        const int n = (int)(bix / bps);
+        const long long u = (bix - (long long)n * bps) * 256 + threadIdx.x;
+        if (u >= V) continue;
+        const long long row = (long long)n * V + u;
+        const float* Bn = B + (long long)n * CC * V + u;
+        float b[CC], p[CC];
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) { b[c] = Bn[(long long)c * V]; a += b[c]; }
+        if (A) a += A[row];
+#pragma unroll
+        for (int q = 0; q < CC / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(prob + row * CC + q * 4);
+            p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+        }
+        const int lab = (coef_s && lab_m) ? warp_label_at(lab_m, bm, row) : -1;
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float g = ga * (coef_a[NC + n * CC + c] * a + coef_a[n * CC + c] * b[c]);
+            if (coef_s) g += gs * (coef_s[n * CC + c] * (lab == c ? 1.f : 0.f) + coef_s[NC + n * CC + c]);
+            b[c] = g;
+            dot += g * p[c];
+        }
+#pragma unroll
+        for (int q = 0; q < CC / 4; ++q)
+            *reinterpret_cast<float4*>(dlogits + row * CC + q * 4) = make_float4(p[4 * q] * (b[4 * q] - dot), p[4 * q + 1] * (b[4 * q + 1] - dot),
+                                                                                 p[4 * q + 2] * (b[4 * q + 2] - dot), p[4 * q + 3] * (b[4 * q + 3] - dot));
     }
 }
 
@@ -621,7 +686,7 @@ extern "C" int da_warp_bwd_dsrc_det(const float* dout, const float* disp, float*
 }
 
 // ---- fused anatomy losses (joint step) -------------------------------------------------------------------------------------
-static const int kLwdBlocks = 1024;
+static const int kLwdBlocks = 4096;          // (a gather kernel hides its two dependent memory latencies with waves: 16 workgroups per CU)
 
 extern "C" size_t da_label_warp_dice_ws_bytes(int N, int C) {
     return da_align((size_t)N * kLwdBlocks * 3 * C * sizeof(double)) + da_align((size_t)3 * N * C * sizeof(float));
@@ -632,20 +697,14 @@ extern "C" int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const 
                                       float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
     if (!lab_m || !lab_t || !disp || !loss || !coef || N <= 0 || N > 64 || D < 2 || H < 2 || W < 2 || C <= 0 ||
         (lab_m_bytes != 1 && lab_m_bytes != 8) || (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
-    if (C > 64 || C % 4 != 0) return DA_ERR_UNSUPPORTED;                 // callers fall back to warp(one-hot) + Dice
+    if (C > 64) return DA_ERR_UNSUPPORTED;                               // callers fall back to warp(one-hot) + Dice
     if (ws_bytes < da_label_warp_dice_ws_bytes(N, C)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
     double* partial = (double*)ws;
     float* isc = (float*)((char*)ws + da_align((size_t)N * kLwdBlocks * 3 * C * sizeof(double)));
     const long long V = (long long)D * H * W;
-    // classes per lane: 8 when that leaves a power-of-two number of lanes per voxel, else 4
-    int cpl = 4;
-    if (C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0) cpl = 8;
-    const int lpv = C / cpl;
-    if (lpv > 64 || (lpv & (lpv - 1)) != 0) return DA_ERR_UNSUPPORTED;
-    int nblocks = (int)da_cdiv(V * lpv, 256 * 4); if (nblocks > kLwdBlocks) nblocks = kLwdBlocks; if (nblocks < 1) nblocks = 1;
-    if (cpl == 8) hipLaunchKernelGGL((label_warp_dice_partial_kernel<8>), dim3(nblocks, N), dim3(256), 0, st, lab_m, lab_m_bytes, lab_t, lab_t_bytes, disp, D, H, W, C, lpv, partial);
-    else hipLaunchKernelGGL((label_warp_dice_partial_kernel<4>), dim3(nblocks, N), dim3(256), 0, st, lab_m, lab_m_bytes, lab_t, lab_t_bytes, disp, D, H, W, C, lpv, partial);
+    int nblocks = (int)da_cdiv(V, 256 * 2); if (nblocks > kLwdBlocks) nblocks = kLwdBlocks; if (nblocks < 1) nblocks = 1;
+    hipLaunchKernelGGL(label_warp_dice_partial_kernel, dim3(nblocks, N), dim3(256), 0, st, lab_m, lab_m_bytes, lab_t, lab_t_bytes, disp, D, H, W, C, partial);
     DA_LAUNCH_CHECK();
     return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
 }
@@ -674,15 +733,24 @@ extern "C" int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const 
     return 0;
 }
 
-extern "C" int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, float* B_dlogits,
+extern "C" int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, const float* B, float* dlogits,
                                    const float* coef_sup, const float* coef_anat, const float* dloss_sup, const float* dloss_anat,
                                    int N, long long V, int C, void* stream) {
-    if (!prob || !B_dlogits || !coef_anat || !dloss_anat || N <= 0 || V <= 0 || C <= 0) return DA_ERR_BADARG;
+    if (!prob || !B || !dlogits || !coef_anat || !dloss_anat || N <= 0 || V <= 0 || C <= 0) return DA_ERR_BADARG;
     if (coef_sup && (!lab_m || !dloss_sup || (lab_m_bytes != 1 && lab_m_bytes != 8))) return DA_ERR_BADARG;
     int lpv; if (!vec_ok(C, &lpv)) return DA_ERR_UNSUPPORTED;
-    const long long total = (long long)N * V * lpv;
-    hipLaunchKernelGGL(seg_anat_dlogits_kernel, dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), prob, lab_m, lab_m_bytes, A, B_dlogits,
-                       coef_sup, coef_anat, dloss_sup, dloss_anat, N, V, C, lpv);
+    if (C == 32 && !getenv("DA_DLOGITS_TILE")) {
+        const long long nb = ((V + 255) / 256) * N;
+        hipLaunchKernelGGL((seg_anat_dlogits_lane_kernel<32>), dim3(da_grid(nb * 256, 256)), dim3(256), 0, da_stream(stream), prob, lab_m, lab_m_bytes, A, B, dlogits,
+                           coef_sup, coef_anat, dloss_sup, dloss_anat, N, V);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
+    const int tv = C <= 32 ? 256 : (C <= 64 ? 128 : 32);                  // LDS tile [C][tv + 1] floats <= 33 KB
+    const long long ntiles = ((V + tv - 1) / tv) * N;
+    const size_t shm = (size_t)C * (tv + 1) * sizeof(float);
+    hipLaunchKernelGGL(seg_anat_dlogits_kernel, dim3(da_grid(ntiles * 256, 256)), dim3(256), shm, da_stream(stream), prob, lab_m, lab_m_bytes, A, B, dlogits,
+                       coef_sup, coef_anat, dloss_sup, dloss_anat, N, V, C, lpv, tv);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -1501,7 +1501,7 @@ class SegPhaseLossFn(Function):
         coef_a = _empty((2, N, C), a)
         call('da_dice_fwd', ptr(warped), ptr(lt), bt, None, N, V, C, 0, wt, nb, float(eps), ptr(loss_a), ptr(coef_a), wp, wn, st)
         ctx.cfg = (N, D, H, W, C, bm, bt)
-        ctx.scratch = warped                       # dead after the Dice sums: reused as B / the logit gradient in backward
+        ctx.scratch = warped                       # dead after the Dice sums: reused as B (W^T onehot, class-major) in backward
         ctx.save_for_backward(prob, u, lm, lt, coef_s, coef_a)
         return loss_s.reshape(()), loss_a.reshape(())
 
@@ -1519,9 +1519,10 @@ class SegPhaseLossFn(Function):
         # with C = 256 cannot have any, everything else gets the array
         A = None if (bt == 1 and C >= 256) else _empty((N, D * H * W), prob)
         call('da_warp_adjoint_labels', ptr(lt), bt, ptr(u), ptr(A), ptr(B), N, D, H, W, C, st)
-        call('da_seg_anat_dlogits', ptr(prob), ptr(lm), bm, ptr(A), ptr(B), ptr(coef_s), ptr(coef_a), ptr(gs) if coef_s is not None else None,
-             ptr(ga), N, D * H * W, C, st)
-        return ncdhw(B), None, None, None, None, None, None
+        dlogits = torch.empty_like(prob)          # B is class-major ([N][C][V]): the gradient cannot be formed in place
+        call('da_seg_anat_dlogits', ptr(prob), ptr(lm), bm, ptr(A), ptr(B), ptr(dlogits), ptr(coef_s), ptr(coef_a),
+             ptr(gs) if coef_s is not None else None, ptr(ga), N, D * H * W, C, st)
+        return ncdhw(dlogits), None, None, None, None, None, None
 
 
 class DiceFn(Function):

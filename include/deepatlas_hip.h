@@ -265,9 +265,10 @@ int da_identity_grid(float* out, int D, int H, int W, int normalize, void* strea
  *  registration phase: loss = Dice(warp(onehot(lab_m), id + disp), onehot(lab_t)) straight from the two label maps (no warped
  *    one-hot, no gradient tensor); bwd writes d loss / d disp.
  *  segmentation phase: the adjoint warp of g is coef[1][c] A[u] + coef[0][c] B[u][c] with A = W^T 1 ([N][V]) and
- *    B = W^T onehot(lab_t) ([N][V][C]) -- da_warp_adjoint_labels zero-fills and scatters B (8 float atomics per voxel instead of 8 C);
+ *    B = W^T onehot(lab_t), stored CLASS-MAJOR ([N][C][V]: the atomics of a wave then fall into consecutive floats of one plane) --
+ *    da_warp_adjoint_labels zero-fills and scatters B (8 float atomics per voxel instead of 8 C);
  *    A[u] = sum_c B[u][c] is formed on the fly, the optional array A only collects the weights of voxels whose target label is outside
- *    [0, C) (pass NULL when the labels are known to be valid) -- and da_seg_anat_dlogits turns B IN PLACE into d(loss_sup + loss_anat) / d logits through the softmax Jacobian
+ *    [0, C) (pass NULL when the labels are known to be valid) -- and da_seg_anat_dlogits forms dlogits ([N][V][C]) = d(loss_sup + loss_anat) / d logits from prob and B through the softmax Jacobian
  *    (prob = softmax(logits); coef_sup / lab_m / dloss_sup NULL when there is no supervised Dice term). */
 size_t da_label_warp_dice_ws_bytes(int N, int C);
 int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,
@@ -277,7 +278,7 @@ int da_label_warp_dice_bwd(const void* lab_m, int lab_m_bytes, const void* lab_t
                            const float* coef, const float* dloss, float* d_disp, int N, int D, int H, int W, int C, void* stream);
 int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const float* disp, float* A, float* B,
                            int N, int D, int H, int W, int C, void* stream);
-int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, float* B_dlogits,
+int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, const float* B, float* dlogits,
                         const float* coef_sup, const float* coef_anat, const float* dloss_sup, const float* dloss_anat,
                         int N, long long V, int C, void* stream);
 /* deterministic d_src (parity runs): the same scatter as da_warp_bwd's d_src, accumulated in 64-bit fixed point with integer atomics
