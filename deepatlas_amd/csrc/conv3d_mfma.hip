@@ -175,13 +175,14 @@ __device__ __forceinline__ float da_act01(float z, float s) { return fmaxf(z, z 
 // Input prologue (PRO variants): the staged tensor is a RAW convolution output whose BatchNorm + LeakyReLU has not been applied
 // yet; it is applied here, on the way into LDS, with exactly the expression of bn_act_fwd_kernel (norm_act.hip) so the result is
 // bit-identical to materialising the activated tensor first.  Padding (out-of-volume voxels, mask bit clear) stays zero.
-template <int CK, int HZ, int IT0, int IT1, bool BF, bool SP = false>
+template <int CK, int HZ, int IT0, int IT1, bool BF, bool SP = false, int ZPAD = 0>     // ZPAD: quads of padding after every z plane of the LDS image (bank spreading)
 __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const float4* pre, unsigned vmask, float4 sc, float4 sf, float slope) {
-    constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
+    constexpr int TOTAL0 = StageGeom<CK, HZ>::TOTAL, TOTAL = TOTAL0 + HZ * ZPAD;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
-        const int idx = threadIdx.x + it * 256;
-        if (idx < TOTAL) {
+        const int idx0 = threadIdx.x + it * 256;
+        const int idx = ZPAD ? idx0 + ZPAD * (idx0 / (HY * HX * StageGeom<CK, HZ>::Q)) : idx0;
+        if (idx0 < TOTAL0) {
             const float4 t = pre[it - IT0];
             const bool ok = ((vmask >> (it - IT0)) & 1u) != 0;
             float4 v;
@@ -198,13 +199,14 @@ __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const f
 
 // BF: the LDS image holds bf16 (same [voxel][CK] order, 8 bytes per channel quad): converted once here instead of at every tap
 // SP: three bf16 planes (h, m, l of da_split3), each in the BF layout, TOTAL quads apart
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false, bool SP = false>
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false, bool SP = false, int ZPAD = 0>
 __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
-    constexpr int TOTAL = StageGeom<CK, HZ>::TOTAL;
+    constexpr int TOTAL0 = StageGeom<CK, HZ>::TOTAL, TOTAL = TOTAL0 + HZ * ZPAD;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
-        const int idx = threadIdx.x + it * 256;
-        if (idx < TOTAL) {
+        const int idx0 = threadIdx.x + it * 256;
+        const int idx = ZPAD ? idx0 + ZPAD * (idx0 / (HY * HX * StageGeom<CK, HZ>::Q)) : idx0;
+        if (idx0 < TOTAL0) {
             if constexpr (SP) {
                 uint2 h, m, l; da_split3(pre[it - IT0], h, m, l);
                 reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = m; reinterpret_cast<uint2*>(lds)[idx + 2 * TOTAL] = l;
@@ -1519,6 +1521,12 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 // NPL = 3: split mode (six products per fragment pair).  NPL = 1: bf16 matrix mode -- operands rounded to bf16, ONE product; the same LDS
 // geometry and accumulator layout at a sixth of the matrix work, i.e. bound by its staging (the older bf16 weight-gradient kernel issues
 // v_mfma_f32_16x16x16_bf16, half the rate of the K = 32 form).  HB: x and dY stored as bf16 (bf16 activation storage; NPL = 1 only).
+// Quads of padding after every z plane of the x tile.  The fragment read of the tap-pair class that mixes two z planes (combos 2 and 3:
+// lanes q < 2 read plane dz, lanes q >= 2 plane dz + 1) then starts 16 banks apart instead of 8 within each half wave: 48 -> 16 weight
+// gradient 2.438 -> 2.395 ms, 96 -> 32 1.431 -> 1.406 (2 and 8 quads: less; 0 = the unpadded image).
+#ifndef DA_WG_ZPAD
+#define DA_WG_ZPAD 4
+#endif
 template <bool PRO, int NPL = 3, bool HB = false>
 __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     static_assert(!HB || NPL == 1, "bf16 activation storage goes with the bf16 matrix mode");
@@ -1526,7 +1534,8 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     constexpr unsigned ES = HbEl<HB>::ES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CK = 8, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
-    constexpr int PLA = HZ * HY * HX * CK, PLY = TVOX * CG;                 // elements per plane
+    constexpr int ZPQ = DA_WG_ZPAD, ZPE = 4 * ZPQ;                         // padding after every z plane of the x tile: quads / elements
+    constexpr int PLA = HZ * (HY * HX * CK + ZPE), PLY = TVOX * CG;        // elements per plane
     float* ldsA = lds;
     float* ldsY = lds + PLA / 2 * NPL;
     typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
@@ -1548,12 +1557,12 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
     }
     // transpose-read source of this lane: voxel 8 (g & 1) + vq [+ 4] of plane g >> 1, channel quad q = (tap half q >> 1, cin quad q & 1)
-    const int laneA = ((((g >> 1) * HY) + 2 * wave) * HX + 8 * (g & 1) + vq) * CK + (q & 1) * 4;
+    const int laneA = ((((g >> 1) * HY) + 2 * wave) * HX + 8 * (g & 1) + vq) * CK + (q & 1) * 4 + (g >> 1) * ZPE;
     int offC[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         const int combo = (c < 4) ? 2 * c + (q >> 1) : 8;                   // (class 4, upper tap half: re-reads tap 8; its rows are never written)
-        offC[c] = ((combo / 3) * HY * HX + combo % 3) * CK;
+        offC[c] = ((combo / 3) * HY * HX + combo % 3) * CK + (combo / 3) * ZPE;
     }
     const int laneY = ((((g >> 1) * TY) + 2 * wave) * TX + 8 * (g & 1) + vq) * CG + q * 4;
     auto tr8 = [&](const short* a, int step) -> bf16x8 {
@@ -1623,8 +1632,8 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         }
     };
     auto write_lds = [&]() {
-        if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, SPL>(ldsA, preA, vmA, psc, psf, pslope);
-        else stage_write<CK, HZ, 0, NITA, true, SPL>(ldsA, preA);
+        if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, SPL, ZPQ>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, NITA, true, SPL, ZPQ>(ldsA, preA);
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             const int idx = threadIdx.x + it * 256;
@@ -2297,7 +2306,7 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
 
 template <bool PRO, int NPL = 3, bool HB = false>
 static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
-    size_t shm = (size_t)(4 * HY * HX * 8 + 2 * TY * TX * 16) * 2 * NPL;
+    size_t shm = (size_t)(4 * (HY * HX * 8 + 4 * DA_WG_ZPAD) + 2 * TY * TX * 16) * 2 * NPL;
     if (shm < (size_t)2 * 15 * 64 * sizeof(float4)) shm = (size_t)2 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tiles' LDS
     auto kern = conv3_split_wgrad_kernel<PRO, NPL, HB>;
     static bool attr_set = false;
