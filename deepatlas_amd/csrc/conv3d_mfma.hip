@@ -93,11 +93,14 @@ __device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigne
 // everything behind the load (prologue arithmetic, the conversion into the bf16 LDS image -- exact for these values) is shared with the
 // fp32-storage kernels.  Only instantiated for the bf16 matrix mode (BF && !SP).
 template <bool HB> struct HbEl { static constexpr unsigned ES = HB ? 2u : 4u; };
-template <bool HB> __device__ __forceinline__ float4 da_buf_loadq(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+// RAW (bf16 storage, no arithmetic between the load and the bf16 LDS image): the eight bytes travel untouched in .x / .y -- widening them to
+// fp32 only to round them back was ~7 VALU instructions per staged quad in a kernel whose busiest pipe is the VALU.
+template <bool HB, bool RAW = false> __device__ __forceinline__ float4 da_buf_loadq(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     if constexpr (HB) {
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
-        return da_unpack_bf16x4(make_uint2(u[0], u[1]));
+        if constexpr (RAW) return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), 0.f, 0.f);
+        else return da_unpack_bf16x4(make_uint2(u[0], u[1]));
     } else return da_buf_load4(r, byte_off);
 }
 // buffer descriptor over sample n of a tensor with `sample` elements per sample
@@ -105,7 +108,7 @@ template <bool HB> __device__ __forceinline__ __amdgpu_buffer_rsrc_t da_rsrc_n(c
     return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + n * sample * (long long)HbEl<HB>::ES), 0, (unsigned)(sample * HbEl<HB>::ES), 0x00020000);
 }
 
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool HB = false>
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool HB = false, bool RAW = false>
 __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict__ src, int Cs, int choff,
                                            int n, int z0, int y0, int x0, int D, int H, int W, unsigned* vmask = nullptr) {
     constexpr int Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
@@ -124,7 +127,7 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
         const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * HbEl<HB>::ES);
-        pre[it - IT0] = da_buf_loadq<HB>(rs, inb ? off : 0xFFFFFFFFu);
+        pre[it - IT0] = da_buf_loadq<HB, RAW>(rs, inb ? off : 0xFFFFFFFFu);
         if (vmask) *vmask |= (inb ? 1u : 0u) << (it - IT0);
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
@@ -199,8 +202,9 @@ __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const f
 
 // BF: the LDS image holds bf16 (same [voxel][CK] order, 8 bytes per channel quad): converted once here instead of at every tap
 // SP: three bf16 planes (h, m, l of da_split3), each in the BF layout, TOTAL quads apart
-template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false, bool SP = false, int ZPAD = 0>
+template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false, bool SP = false, int ZPAD = 0, bool RAW = false>
 __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
+    static_assert(!RAW || (BF && !SP), "raw staging: bf16 storage into the one-plane bf16 image");
     constexpr int TOTAL0 = StageGeom<CK, HZ>::TOTAL, TOTAL = TOTAL0 + HZ * ZPAD;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
@@ -210,6 +214,8 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
             if constexpr (SP) {
                 uint2 h, m, l; da_split3(pre[it - IT0], h, m, l);
                 reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = m; reinterpret_cast<uint2*>(lds)[idx + 2 * TOTAL] = l;
+            } else if constexpr (RAW) {
+                reinterpret_cast<uint2*>(lds)[idx] = make_uint2(__float_as_uint(pre[it - IT0].x), __float_as_uint(pre[it - IT0].y));
             } else if constexpr (BF) {
                 const float4 v = pre[it - IT0];
                 reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
@@ -221,7 +227,7 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
 // The same staging loads, one at a time: a cursor that carries the incremental (hz, hy, hx) decomposition so the loads of the
 // NEXT work item can be spread over the K-steps of the current one.  `valid` = false turns every offset out of range (zeros, no
 // memory traffic), so the loads are issued on every item without a branch around them and hipcc's vmcnt bookkeeping stays exact.
-template <int CK, int HZ, bool HB = false> struct StageCursor {
+template <int CK, int HZ, bool HB = false, bool RAW = false> struct StageCursor {
     __amdgpu_buffer_rsrc_t rs;
     int hv, hx, hy, hz, cofs;
     int z0, y0, x0, D, H, W, Cs;
@@ -246,7 +252,7 @@ template <int CK, int HZ, bool HB = false> struct StageCursor {
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inb = valid && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
         const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * HbEl<HB>::ES);
-        const float4 v = da_buf_loadq<HB>(rs, inb ? off : 0xFFFFFFFFu);
+        const float4 v = da_buf_loadq<HB, RAW>(rs, inb ? off : 0xFFFFFFFFu);
         last_inb = inb;
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
@@ -401,6 +407,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(!DYN || (!STATS && !MASKED && !PRO), "dynamic tile walk: plain forward / data-gradient variants only");
     static_assert(!SP || (BF && !MASKED && !DYN && CK == 8), "split mode: dense bf16 K = 32 kernels on 8-channel chunks");
     constexpr int NP = SP ? 3 : 1;                                  // operand planes
+    constexpr bool RAW = HB && BF && !SP && !PRO && !MASKED && S2F == 0;       // bf16 tensors copied straight into the bf16 LDS image (da_buf_loadq)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // K32: the dense bf16 kernels use v_mfma_f32_16x16x32_bf16 (K = 32 = two taps x 16 cin, or four taps x 8 cin; 16 cycles per
     // SIMD for twice the K of the 16x16x16 form, which gfx950 issues at ~32 cycles); the sparse-tap variant keeps one tap per step.
@@ -463,8 +470,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         item_coords(item, n, z0, y0, x0, ch);
         const int cbase = ch * CK;
         if constexpr (S2F == 1) stage_load_s2d<CK, HZ, 0, PRE, HB>(pre, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W);
-        else if (cbase < p.C1) stage_load<CK, HZ, 0, PRE, HB>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
-        else stage_load<CK, HZ, 0, PRE, HB>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W);
+        else if (cbase < p.C1) stage_load<CK, HZ, 0, PRE, HB, RAW>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W);
+        else stage_load<CK, HZ, 0, PRE, HB, RAW>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W);
     };
     auto stage_rest = [&](int item) {                         // iterations [PRE, NIT): global -> LDS, in <= 3 batches
         if constexpr (PRE < NIT) {
@@ -481,9 +488,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                     if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load_s2d<CK, HZ, B2, NIT, HB>(tmp, p.in1, p.s2in, cbase, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
                 }
             } else {
-            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1, HB>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP>(lds, tmp); }
-            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2, HB>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP>(lds, tmp); }
-            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT, HB>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP>(lds, tmp); }
+            { float4 tmp[B1 - PRE]; stage_load<CK, HZ, PRE, B1, HB, RAW>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, PRE, B1, BF, SP, 0, RAW>(lds, tmp); }
+            if constexpr (B2 > B1) { float4 tmp[B2 - B1]; stage_load<CK, HZ, B1, B2, HB, RAW>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B1, B2, BF, SP, 0, RAW>(lds, tmp); }
+            if constexpr (NIT > B2) { float4 tmp[NIT - B2]; stage_load<CK, HZ, B2, NIT, HB, RAW>(tmp, src, Cs, choff, n, z0, y0, x0, p.D, p.H, p.W); stage_write<CK, HZ, B2, NIT, BF, SP, 0, RAW>(lds, tmp); }
             }
         }
     };
@@ -560,7 +567,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
     } else {
     issue_stage(0, pre);
-    stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);
+    stage_write<CK, HZ, 0, PRE, BF, SP, 0, RAW>(lds, pre);
     stage_rest(0);
     if constexpr (PAIR) stage_load<CK, HZ, 0, PRE>(pre2, p.in1, p.C1, CK, cN, cZ, cY, cX, p.D, p.H, p.W);      // item 1 = chunk 1 of the first tile
     }
@@ -710,7 +717,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) bq[t % RB][nn][pl] = nb[t][nn][pl];
-        StageCursor<CK, HZ, HB> cur;                          // next item's staging loads: cursor (fp32 / bf16 kernels) ...
+        StageCursor<CK, HZ, HB, RAW> cur;                     // next item's staging loads: cursor (fp32 / bf16 kernels) ...
         typename StageMap<CK, HZ>::Tile stile;                // ... or per-thread halo map (SP: registers to spare, ~60 % fewer instructions)
         __amdgpu_buffer_rsrc_t rsn;
         if constexpr (PRO) vm = 0;
@@ -759,7 +766,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                     if constexpr (SP && PH == 1) { }
                     else if constexpr (SMAP) {
                         const unsigned so = smap.offset(stile, j);
-                        pre[j] = da_buf_loadq<HB>(rsn, so);
+                        pre[j] = da_buf_loadq<HB, RAW>(rsn, so);
                         if constexpr (PH == 2) pre2[j] = da_buf_load4(rsn, so == 0xFFFFFFFFu ? so : so + CK * 4u);      // the same voxel's next 8 channels
                         if constexpr (PRO) vm |= (so != 0xFFFFFFFFu ? 1u : 0u) << j;
                     } else { pre[j] = cur.next(); if constexpr (PRO) vm |= (cur.last_inb ? 1u : 0u) << j; }
@@ -939,7 +946,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             __syncthreads();                       // every wave is done reading this item's LDS tile
             if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
             else if constexpr (PH == 1) stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre2);
-            else stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
+            else stage_write<CK, HZ, 0, PRE, BF, SP, 0, RAW>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
             if constexpr (!PRO) stage_rest(1);
             __syncthreads();
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(2);
@@ -1531,6 +1538,7 @@ template <bool PRO, int NPL = 3, bool HB = false>
 __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     static_assert(!HB || NPL == 1, "bf16 activation storage goes with the bf16 matrix mode");
     constexpr bool SPL = NPL == 3;
+    constexpr bool RAWA = HB && !SPL && !PRO, RAWY = HB && !SPL;       // bf16 tensors copied straight into the bf16 LDS image (da_buf_loadq)
     constexpr unsigned ES = HbEl<HB>::ES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CK = 8, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
@@ -1609,7 +1617,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
 #pragma unroll
             for (int it = 0; it < NITA; ++it) {
                 const unsigned so = smap.offset(st, it);
-                preA[it] = da_buf_loadq<HB>(rs, so);
+                preA[it] = da_buf_loadq<HB, RAWA>(rs, so);
                 if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
             }
         }
@@ -1628,12 +1636,12 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                 const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
                 off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * ES) : 0xFFFFFFFFu;
             }
-            preY[it] = da_buf_loadq<HB>(ry, off);
+            preY[it] = da_buf_loadq<HB, RAWY>(ry, off);
         }
     };
     auto write_lds = [&]() {
         if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, SPL, ZPQ>(ldsA, preA, vmA, psc, psf, pslope);
-        else stage_write<CK, HZ, 0, NITA, true, SPL, ZPQ>(ldsA, preA);
+        else stage_write<CK, HZ, 0, NITA, true, SPL, ZPQ, RAWA>(ldsA, preA);
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             const int idx = threadIdx.x + it * 256;
@@ -1641,7 +1649,8 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                 if constexpr (SPL) {
                     uint2 h, m, l; da_split3(preY[it], h, m, l);
                     reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
-                } else reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));
+                } else if constexpr (RAWY) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(__float_as_uint(preY[it].x), __float_as_uint(preY[it].y));
+                else reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));
             }
         }
     };
