@@ -28,6 +28,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));      // four bf16 (the 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));    // eight bf16 (the A / B fragment of v_mfma_f32_16x16x32_bf16)
 #include <type_traits>
 #ifndef DA_BF16_SMAP
+#ifndef DA_BF16_SMAP2
+#define DA_BF16_SMAP2 0  // ... also in the two-N-tile kernels when the tensors are bf16 (raw staging: half the parked registers): 96 -> 32 forward 0.316 -> 0.308 ms but + statistics 0.262 -> 0.317; off
+#endif
 #define DA_BF16_SMAP 1   // bf16 matrix-mode forward kernels: staging offsets from the per-thread halo map (0: the cursor; A/B builds)
 #endif
 #ifndef DA_PIN
@@ -581,7 +584,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // carry-stepping cursor with its per-load bounds checks (~20).  Split mode always; the bf16 matrix-mode kernels too when the whole next
     // tile is parked in registers (PRE == NIT): their 8 MFMAs per K-step leave the VALU as the busiest pipe (SQ counters: 7 VALU instructions
     // per MFMA with the cursor, profiles/r03_pmc_sq_conv3d_48to16.txt)
-    constexpr bool SMAP = SP || (K32 && PRE == NIT && NREP == 1 && DA_BF16_SMAP);      // (two N-tiles: measured 10 % slower with the map's 17 extra registers)
+    constexpr bool SMAP = SP || (K32 && PRE == NIT && (NREP == 1 || (RAW && DA_BF16_SMAP2)) && DA_BF16_SMAP);      // (two N-tiles with fp32 tensors: measured 10 % slower with the map's 17 extra registers; raw bf16 staging parks half the registers)
     StageMap<CK, HZ> smap; if constexpr (SMAP) smap.init();
     const bool hi = (g >> 1) != 0;
     auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
