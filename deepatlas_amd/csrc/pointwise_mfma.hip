@@ -33,10 +33,8 @@ struct PwP {
 __device__ __forceinline__ float pw_act01(float z, float s) { return fmaxf(z, z * s); }
 
 __device__ __forceinline__ long long fine0(long long v, int D, int H, int W) {
-    const int w = (int)(v % W); long long r = v / W;
-    const int h = (int)(r % H); r /= H;
-    const int d = (int)(r % D); const long long n = r / D;
-    return ((n * (2 * D) + 2 * d) * (2 * H) + 2 * h) * (long long)(2 * W) + 2 * w;
+    int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);           // (32-bit divisions when the index fits: this runs 16 + 4 times per lane and chunk)
+    return (((long long)n * (2 * D) + 2 * d) * (2 * H) + 2 * h) * (long long)(2 * W) + 2 * w;
 }
 __device__ __forceinline__ long long tapoff(int t, int H, int W) {
     return ((long long)(t >> 2) * (2 * H) + ((t >> 1) & 1)) * (2 * W) + (t & 1);
