@@ -57,5 +57,6 @@ DA_MATRIX_MODE=2 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_conv --
 f=$(ls $O/prof_conv/*/*.db 2>/dev/null | head -1)
 if [ -n "$f" ]; then python tools/rocpd_summary.py "$f" > $O/conv3d_48to16_kernel_stats.txt 2>&1 < /dev/null; fi
 rm -rf $O/prof_conv
+timeout 300 python tools/bench_warp.py 2>&1 | grep -v amdgpu.ids > $O/gather_kernels_now.txt
 rm -f $O/*.log
 ls -la $O
