@@ -443,6 +443,68 @@ def run_registry_losses(ref, out):
     out['onehot/seg'], out['onehot/segmentation_onehot'] = np32(seg), np32(smp['segmentation_onehot'])
 
 
+def run_joint(ref, out):
+    """First joint DeepAtlas step composed from the REFERENCE's own parts -- its UNet generator, its VoxelMorph,
+    F.grid_sample as at voxel_morph.py:90-91, its NCC / bending-energy / Dice modules, torch.optim.Adam -- in fp32 and as an fp64 twin:
+    the seven loss terms and every gradient of both phases.  The twin calibrates the device tolerances per tensor (tests/test_gpu_nets.py)
+    and the fp32 run pins oracle/steps.py::joint_step (tests/test_oracle_golden.py)."""
+    import torch.nn.functional as F
+    from oracle import nets
+    shape = (16, 16, 32)
+    tiny_cls = ref.unets.UNet_generator(encoders=nets.UNET_TINY['encoders'], decoders=nets.UNET_TINY['decoders'],
+                                        act='LeakyReLU', maxpool=True, upsample=False, res=False)
+    for tag0, C, labelled in (('c8', 8, True), ('c32', 32, True), ('c8_unlabelled_moving', 8, False)):
+        for dtype in (torch.float32, torch.float64):
+            tag = 'joint/' + tag0 + ('' if dtype == torch.float32 else '_f64')
+            seg_sd = nets.closed_form_fill(nets.unet_param_shapes(1, C, nets.UNET_TINY['encoders'], nets.UNET_TINY['decoders']), seed=1)
+            reg_sd = nets.closed_form_fill(nets.voxelmorph_param_shapes(), seed=4)
+            seg = tiny_cls(in_channel=1, n_classes=C, bias=True, BN=True)
+            load_sd(seg, seg_sd)
+            reg = ref.nf.get_network('voxel_morph_cvpr')()
+            load_sd(reg, reg_sd)
+            seg, reg = seg.to(dtype), reg.to(dtype)
+            im_m = nets.closed_form_volume((1, 1) + shape, seed=5).to(dtype)
+            im_t = nets.closed_form_volume((1, 1) + shape, seed=6).to(dtype)
+            sm = nets.closed_form_labels((1,) + shape, C, seed=7)
+            st_ = nets.closed_form_labels((1,) + shape, C, seed=8)
+            ncc = ref.loss.get_loss_function('ncc')()
+            bend = ref.loss.get_loss_function('bendingEnergy')()
+            dice_prob = ref.loss.get_loss_function('dice')(n_class=C, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)
+            dice_logit = ref.loss.get_loss_function('dice')(n_class=C, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
+            warp = lambda src, grid: F.grid_sample(src, grid=grid.permute([0, 2, 3, 4, 1]), mode='bilinear', padding_mode='zeros', align_corners=True)
+            onehot_t = ref.loss.mask_to_one_hot(st_.long().unsqueeze(1), C).to(dtype)
+            if labelled:
+                onehot_m = ref.loss.mask_to_one_hot(sm.long().unsqueeze(1), C).to(dtype)
+            else:
+                seg.eval()
+                with torch.no_grad():
+                    onehot_m = F.softmax(seg(im_m), dim=1)
+            # registration phase (segmentation net frozen)
+            ropt = torch.optim.Adam(reg.parameters(), lr=1e-3)
+            ropt.zero_grad()
+            disp, warped, deform = reg(im_m, im_t)
+            l_sim, l_reg = ncc(warped, im_t), bend(disp)
+            l_anat = dice_prob(warp(onehot_m, deform), onehot_t)
+            loss_r = l_sim + l_reg + l_anat
+            loss_r.backward()
+            for n, p in reg.named_parameters():
+                out[f'{tag}/grad_reg/{n}'] = np32(p.grad.float()) if p.numel() <= 4096 else summary(p.grad)      # (fp64 values stored rounded to fp32: 6e-8, far below any floor)
+            ropt.step()
+            # segmentation phase (registration net frozen; the deformation of the un-stepped net, detached)
+            sopt = torch.optim.Adam(seg.parameters(), lr=1e-3)
+            sopt.zero_grad()
+            seg.train()
+            logits = seg(im_m)
+            l_sp = dice_logit(logits, sm.long()) if labelled else torch.zeros((), dtype=dtype)
+            l_anat2 = dice_prob(warp(F.softmax(logits, dim=1), deform.detach()), onehot_t)
+            loss_s = l_sp + l_anat2
+            loss_s.backward()
+            for n, p in seg.named_parameters():
+                out[f'{tag}/grad_seg/{n}'] = np32(p.grad.float())
+            for k, v in (('sim', l_sim), ('bend', l_reg), ('anat_reg', l_anat), ('sup', l_sp), ('anat_seg', l_anat2), ('loss_reg', loss_r), ('loss_seg', loss_s)):
+                out[f'{tag}/{k}'] = np.float64(float(v.detach()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -450,6 +512,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     from oracle import nets
 
+    out = {}
+    run_joint(ref, out)
+    np.savez_compressed(os.path.join(OUT, 'joint.npz'), **out)
+    print('joint.npz', len(out))
+    if os.environ.get('GOLDEN_ONLY') == 'joint':
+        return
     out = {}
     run_registry_losses(ref, out)
     np.savez_compressed(os.path.join(OUT, 'registry_losses.npz'), **out)

@@ -196,6 +196,35 @@ def test_reg_three_steps(golden, tag, shape):
                     assert abs(summary_of(v)[2] - ref[2]) <= 1e-6 * ref[2], (s, n)
 
 
+@pytest.mark.parametrize('tag,C,labelled', [('c8', 8, True), ('c32', 32, True), ('c8_unlabelled_moving', 8, False)])
+def test_joint_step_oracle_vs_reference_parts(golden, tag, C, labelled):
+    """oracle/steps.py::joint_step (the build-defined joint DeepAtlas step, SURVEY.md 8 a14) against the same step composed from the
+    REFERENCE's own modules (oracle/make_golden.py::run_joint: its UNet generator, VoxelMorph, grid_sample, NCC / bending / Dice, Adam's
+    inputs): the seven loss terms and every gradient of both phases; per tensor no further from the reference's fp32 run than three times
+    the reference's own fp32-vs-fp64 distance (never tighter than 1e-5)."""
+    g = golden('joint')
+    shape = (16, 16, 32)
+    spec = nets.UNET_TINY
+    seg_sd = nets.closed_form_fill(nets.unet_param_shapes(1, C, spec['encoders'], spec['decoders']), seed=1)
+    reg_sd = nets.closed_form_fill(nets.voxelmorph_param_shapes(), seed=4)
+    im_m, im_t = nets.closed_form_volume((1, 1) + shape, seed=5), nets.closed_form_volume((1, 1) + shape, seed=6)
+    sm, st_ = nets.closed_form_labels((1,) + shape, C, seed=7), nets.closed_form_labels((1,) + shape, C, seed=8)
+    ref = steps.joint_step(seg_sd, steps.Adam(steps.trainable(seg_sd)), reg_sd, steps.Adam(steps.trainable(reg_sd)), im_m, im_t,
+                           sm if labelled else None, st_, spec, C)
+    for k in ('sim', 'bend', 'anat_reg', 'sup', 'anat_seg', 'loss_reg', 'loss_seg'):
+        assert abs(ref[k].item() - float(g[f'joint/{tag}/{k}'])) < 2e-6 * max(1.0, abs(float(g[f'joint/{tag}/{k}']))), (k, ref[k].item())
+    for phase, grads in (('seg', ref['grads_seg']), ('reg', ref['grads_reg'])):
+        for n, gr in grads.items():
+            g32, g64 = g[f'joint/{tag}/grad_{phase}/{n}'], g[f'joint/{tag}_f64/grad_{phase}/{n}']
+            if phase == 'seg' and (n.endswith('conv.bias') or n.endswith('deconv.bias')):
+                continue                                   # zero analytic gradient in front of a BatchNorm: rounding noise on both sides
+            if gr.numel() <= 4096 or phase == 'seg':
+                floor = rel_l2(g32, g64)
+                assert rel_l2(gr.numpy(), g32) < max(3 * floor, 1e-5), (phase, n, rel_l2(gr.numpy(), g32), floor)
+            else:
+                assert abs(summary_of(gr)[2] - g32[2]) <= 1e-5 * g32[2], (phase, n)
+
+
 # ---- SURVEY.md row f1: label-map eval metrics ---------------------------------------------------------------------------
 def test_eval_label_metrics_oracle_vs_reference(golden):
     """oracle.losses.{multiclass_dice, dice_loss_on_label, multi_metric} == lib/evalMetrics.py:103-217, lib/loss.py:348-391."""
