@@ -54,6 +54,9 @@ def set_activation_storage(mode):
     if mode not in ACT_STORAGE_MODES:
         raise ValueError("activation storage must be one of %r, got %r" % (ACT_STORAGE_MODES, mode))
     prev, ACT_STORAGE = ACT_STORAGE, mode
+    if _LAZY_UP_ENV is None:
+        global LAZY_BN_UPSAMPLER
+        LAZY_BN_UPSAMPLER = mode == 'bf16'
     return prev
 
 
@@ -474,7 +477,8 @@ def grad_from_tio(dw_tio, kind, shape, acc=None):
 # (DA_LAZY_BN_UPSAMPLER=1; off by default) saves another 0.2 ms/step but moves the bench's roofline call onto the prologue variant of
 # the 48 -> 16 forward (0.757 instead of 0.778 of the fp32 matrix peak for the same algorithmic FLOPs).
 LAZY_BN = os.environ.get('DA_LAZY_BN', '1') != '0'
-LAZY_BN_UPSAMPLER = os.environ.get('DA_LAZY_BN_UPSAMPLER') == '1'
+_LAZY_UP_ENV = os.environ.get('DA_LAZY_BN_UPSAMPLER')          # '1' / '0' force the up-sampler link on / off; unset: on with bf16 activation storage
+LAZY_BN_UPSAMPLER = _LAZY_UP_ENV == '1'                         # (bf16 storage: the prologue is cheaper there -- seg step 13.04 -> 12.61 ms; fp32: 27.70 -> 27.70 - 27.78)
 
 
 class LazyAct(object):

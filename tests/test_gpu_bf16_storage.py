@@ -138,12 +138,12 @@ def test_every_block_bf16_storage_vs_rounding_oracle(bf16_storage, spec_name, n_
     from oracle import nets
     import torch.nn.functional as F
     ops = bf16_storage
-    prev_lazy, ops.LAZY_BN = ops.LAZY_BN, False
+    prev_lazy, prev_up, ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER = ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER, False, False      # (bf16 storage defers the up-sampler link too)
     try:
         model, sd, spec, x, y = _seg_setup(spec_name, n_classes, shape)
         rec, order, grads, loss = _block_records(model, x, y, n_classes)
     finally:
-        ops.LAZY_BN = prev_lazy
+        ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER = prev_lazy, prev_up
     slope = spec['slope']
     nets.K3_OPERAND_ROUND = _RoundSTE.apply
     nets.ACT_STORE_ROUND = _bf16
@@ -210,12 +210,12 @@ def test_seg_step_bf16_storage_network_level(bf16_storage, spec_name, n_classes,
           % (spec_name, loss, o_loss, p_loss, e_logits, e_oo, dict(ops.bridged_calls)))
     assert abs(loss - o_loss) < 2e-4 * max(1.0, abs(o_loss))
     assert e_logits < 2.0 * e_oo + 1e-2, (e_logits, e_oo)
-    prev_lazy, ops.LAZY_BN = ops.LAZY_BN, False
+    prev_lazy, prev_up, ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER = ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER, False, False      # (bf16 storage defers the up-sampler link too)
     try:
         model2, _, _, _, _ = _seg_setup(spec_name, n_classes, shape)
         loss2, logits2, grads2 = _device_seg_step(model2, x, y, n_classes, fused_head=False)
     finally:
-        ops.LAZY_BN = prev_lazy
+        ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER = prev_lazy, prev_up
     assert abs(loss - loss2) < 1e-6 * max(1.0, abs(loss)), (loss, loss2)
     assert rel_l2(logits.numpy(), logits2.numpy()) < 1e-6
 
@@ -227,7 +227,7 @@ def test_bf16_twins_equal_the_conversion_route(bf16_storage):
     res = []
     # (materialised BatchNorm: an activation that is applied inside a consumer's staging is never stored, so the conversion route -- fp32
     # kernels between conversions -- cannot round it the way the twins do; that route is covered by the deferred-vs-materialised check above)
-    prev_lazy, ops.LAZY_BN = ops.LAZY_BN, False
+    prev_lazy, prev_up, ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER = ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER, False, False      # (bf16 storage defers the up-sampler link too)
     try:
         for force in (False, True):
             ops.BF16_FORCE_BRIDGE = force
@@ -235,7 +235,7 @@ def test_bf16_twins_equal_the_conversion_route(bf16_storage):
             model, sd, spec, x, y = _seg_setup('UNET_LIGHT', 32, (32, 32, 32))
             res.append(_device_seg_step(model, x, y, 32, fused_head=True) + (dict(ops.bridged_calls),))
     finally:
-        ops.LAZY_BN = prev_lazy
+        ops.LAZY_BN, ops.LAZY_BN_UPSAMPLER = prev_lazy, prev_up
         ops.BF16_FORCE_BRIDGE = False
     (l0, _, g0, b0), (l1, _, g1, b1) = res
     assert sum(b1.values()) > sum(b0.values()) + 20, (b0, b1)          # the forced run really took the conversion route
