@@ -80,6 +80,9 @@ SIGNATURES = {
     'da_warp_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
     'da_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, I, P]),
     'da_label_warp_dice_ws_bytes': (SZ, [I, I]),
+    'da_warp_dice_ws_bytes': (SZ, [I, I]),
+    'da_warp_dice_fwd': (I, [P, P, P, I, I, I, I, I, I, I, I, F, P, P, P, SZ, P]),
+    'da_softmax_dice_fwd': (I, [P, P, I, P, I, LL, I, I, I, F, P, P, P, SZ, P]),
     'da_label_warp_dice_fwd': (I, [P, I, P, I, P, I, I, I, I, I, I, I, F, P, P, P, SZ, P]),
     'da_label_warp_dice_bwd': (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, P]),
     'da_warp_adjoint_labels': (I, [P, I, P, P, P, I, I, I, I, I, P]),

@@ -36,7 +36,9 @@ __device__ __forceinline__ void group_softmax4(float (&x)[4], int lpv) {
 // ------------------------------------------------------------------------------------------------
 __global__ void dice_partial_vec_kernel(const float* __restrict__ src, const void* __restrict__ labels, int label_bytes,
                                         const float* __restrict__ soft, long long V, int C, int lpv, int softmax,
-                                        double* __restrict__ partial) {
+                                        double* __restrict__ partial, float* __restrict__ prob_out = nullptr) {
+    // prob_out (with softmax): the probabilities are also WRITTEN ([N][V][C]) -- the joint step's segmentation phase needs softmax(logits)
+    // for the warp and the supervised Dice sums of the same logits; one pass over the logits instead of two (da_softmax_dice_fwd)
     extern __shared__ float shf[];   // [3][slots][C]
     const int n = blockIdx.y;
     const int slots = blockDim.x / lpv;
@@ -47,9 +49,10 @@ __global__ void dice_partial_vec_kernel(const float* __restrict__ src, const voi
     long long v1 = v0 + vpb; if (v1 > V) v1 = V;
     // every lane of a voxel group runs the same trip count (v depends on s only).  Two voxels per iteration: both 16-byte loads
     // (and label bytes) are in flight before the first softmax's shuffles, which doubles the bytes in flight per wave.
-    auto accumulate = [&](float4 a, const float* tt) {
+    auto accumulate = [&](float4 a, const float* tt, long long row) {
         float p[4] = {a.x, a.y, a.z, a.w};
         if (softmax) group_softmax4(p, lpv);
+        if (prob_out) *reinterpret_cast<float4*>(prob_out + row * C + q * 4) = make_float4(p[0], p[1], p[2], p[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { aI[j] += p[j] * tt[j]; aS[j] += p[j]; aT[j] += tt[j]; }
     };
@@ -70,14 +73,14 @@ __global__ void dice_partial_vec_kernel(const float* __restrict__ src, const voi
         const float4 a1 = *reinterpret_cast<const float4*>(src + r1 * C + q * 4);
         float t0[4], t1[4];
         target(r0, t0); target(r1, t1);
-        accumulate(a0, t0); accumulate(a1, t1);
+        accumulate(a0, t0, r0); accumulate(a1, t1, r1);
     }
     for (; v < v1; v += slots) {
         const long long r0 = (long long)n * V + v;
         const float4 a0 = *reinterpret_cast<const float4*>(src + r0 * C + q * 4);
         float t0[4];
         target(r0, t0);
-        accumulate(a0, t0);
+        accumulate(a0, t0, r0);
     }
     float* sI = shf; float* sS = shf + (size_t)slots * C; float* sT = shf + (size_t)2 * slots * C;
 #pragma unroll
@@ -694,6 +697,26 @@ extern "C" int da_dice_fwd(const float* src, const void* labels, int label_bytes
     hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, 1, N, C, weight_type, no_bg, eps, loss, coef, isc);
     DA_LAUNCH_CHECK();
     return 0;
+}
+
+// Dice(softmax(src), labels) exactly as da_dice_fwd(softmax = 1) AND prob = softmax(src) written out, in one pass over src.
+extern "C" int da_softmax_dice_fwd(const float* src, const void* labels, int label_bytes, float* prob,
+                                   int N, long long V, int C, int weight_type, int no_bg, float eps,
+                                   float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+    if (!src || !labels || !prob || !loss || !coef || N <= 0 || N > 64 || V <= 0 || C <= 0 || C > 256) return DA_ERR_BADARG;
+    if (label_bytes != 1 && label_bytes != 8) return DA_ERR_BADARG;
+    const int lpv = lpv_for(C);
+    if (lpv <= 0) return DA_ERR_UNSUPPORTED;                               // callers run da_dice_fwd + da_softmax_fwd
+    if (ws_bytes < da_dice_ws_bytes(N, V, C)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    double* partial = (double*)ws;
+    float* isc = (float*)((char*)ws + da_align((size_t)N * kDiceBlocks * 3 * C * sizeof(double)));
+    int nblocks = (int)da_cdiv(V, 256); if (nblocks > kDiceBlocks) nblocks = kDiceBlocks;
+    const int slots = 256 / lpv;
+    hipLaunchKernelGGL(dice_partial_vec_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
+                       src, labels, label_bytes, (const float*)nullptr, V, C, lpv, 1, partial, prob);
+    DA_LAUNCH_CHECK();
+    return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
 }
 
 // Dice from per-block partial sums [N][nblocks][3][C] (I, S, T) produced by another kernel (the fused label-warp Dice, warp.hip):

@@ -328,6 +328,56 @@ __global__ void identity_grid_kernel(float* __restrict__ out, int D, int H, int 
 //    collapses to  W^T g = b[c] * A[u] + a[c] * B[u][c]  with  A = W^T 1  (one channel) and  B = W^T onehot(St)  (8 atomics per
 //    voxel land in channel St[v] only): 16 atomics per voxel instead of 256.
 // ------------------------------------------------------------------------------------------------
+// Dice(warp(src, identity + disp), onehot(lab_t)) without writing the warped tensor: warp_fwd_kernel<4>'s gather (C / 4 lanes per voxel,
+// 4 channels each) with the three Dice sums of the lane's channels accumulated in registers instead of the 16-byte store; per-block partials
+// [N][gridDim.x][3][C] in the layout of dice_partial_vec_kernel (losses.hip), finished by da_dice_finish.
+__global__ void __launch_bounds__(256) warp_dice_partial_kernel(const float* __restrict__ src, const float* __restrict__ disp,
+                                                                const void* __restrict__ lab_t, int bt,
+                                                                int D, int H, int W, int C, int lpv, double* __restrict__ partial) {
+    extern __shared__ float shf[];   // [3][slots][C]
+    const int n = blockIdx.y;
+    const int slots = 256 / lpv;
+    const int q = threadIdx.x % lpv, s = threadIdx.x / lpv;
+    const long long V = (long long)D * H * W;
+    const long long vpb = da_cdiv(V, (long long)gridDim.x);
+    const long long v0 = (long long)blockIdx.x * vpb;
+    long long v1 = v0 + vpb; if (v1 > V) v1 = V;
+    const float* sb = src + (long long)n * V * C;
+    float aI[4] = {0, 0, 0, 0}, aS[4] = {0, 0, 0, 0}, aT[4] = {0, 0, 0, 0};
+    for (long long v = v0 + s; v < v1; v += slots) {
+        int d, h, w; da_vox3(v, H, W, d, h, w);
+        const float* u = disp + ((long long)n * V + v) * 3;
+        const float gx = u[0] + id_coord(w, W), gy = u[1] + id_coord(h, H), gz = u[2] + id_coord(d, D);
+        const bool fin = is_finite_coord(gx, gy, gz);
+        const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+                const float4 a = *reinterpret_cast<const float4*>(sb + (((long long)z * H + y) * W + x) * C + q * 4);
+                acc.x += a.x * wgt; acc.y += a.y * wgt; acc.z += a.z * wgt; acc.w += a.w * wgt;
+            }
+        }
+        const int rel = warp_label_at(lab_t, bt, (long long)n * V + v) - q * 4;
+        const float pv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float tt = (rel == j) ? 1.f : 0.f; aI[j] += pv[j] * tt; aS[j] += pv[j]; aT[j] += tt; }
+    }
+    float* sI = shf; float* sS = shf + (size_t)slots * C; float* sT = shf + (size_t)2 * slots * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sI[s * C + q * 4 + j] = aI[j]; sS[s * C + q * 4 + j] = aS[j]; sT[s * C + q * 4 + j] = aT[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double tI = 0, tS = 0, tT = 0;
+        for (int k = 0; k < slots; ++k) { tI += sI[k * C + c]; tS += sS[k * C + c]; tT += sT[k * C + c]; }
+        double* o = partial + (((size_t)n * gridDim.x + blockIdx.x) * 3) * C;
+        o[c] = tI; o[C + c] = tS; o[2 * C + c] = tT;
+    }
+}
+
 // One lane per voxel.  The three per-class sums are histograms keyed by a label: S by the 8 corner labels of the moving map (value = the
 // corner's weight), I and T by the target label (values: the weight that landed on corners carrying that label, and 1).  Label maps are
 // piecewise constant, so the 64 voxels of a wave see one to three distinct keys: the wave loops over the DISTINCT keys present, sums the
@@ -705,6 +755,29 @@ extern "C" int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const 
     const long long V = (long long)D * H * W;
     int nblocks = (int)da_cdiv(V, 256 * 2); if (nblocks > kLwdBlocks) nblocks = kLwdBlocks; if (nblocks < 1) nblocks = 1;
     hipLaunchKernelGGL(label_warp_dice_partial_kernel, dim3(nblocks, N), dim3(256), 0, st, lab_m, lab_m_bytes, lab_t, lab_t_bytes, disp, D, H, W, C, partial);
+    DA_LAUNCH_CHECK();
+    return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
+}
+
+extern "C" size_t da_warp_dice_ws_bytes(int N, int C) { return da_label_warp_dice_ws_bytes(N, C); }
+
+/* loss = Dice(warp(src, identity + disp), onehot(lab_t)) (src = probabilities, softmax = 0 in da_dice_fwd's terms) and its backward
+ * coefficients, the warped tensor never written: what da_warp_fwd + da_dice_fwd compute, minus one write and one read of N V C floats */
+extern "C" int da_warp_dice_fwd(const float* src, const float* disp, const void* lab_t, int lab_t_bytes,
+                                int N, int D, int H, int W, int C, int weight_type, int no_bg, float eps,
+                                float* loss, float* coef, void* ws, size_t ws_bytes, void* stream) {
+    if (!src || !disp || !lab_t || !loss || !coef || N <= 0 || N > 64 || D < 2 || H < 2 || W < 2 || C <= 0 ||
+        (lab_t_bytes != 1 && lab_t_bytes != 8)) return DA_ERR_BADARG;
+    int lpv; if (!vec_ok(C, &lpv) || C > 64) return DA_ERR_UNSUPPORTED;       // callers run da_warp_fwd + da_dice_fwd
+    if (ws_bytes < da_warp_dice_ws_bytes(N, C)) return DA_ERR_WS_SMALL;
+    hipStream_t st = da_stream(stream);
+    double* partial = (double*)ws;
+    float* isc = (float*)((char*)ws + da_align((size_t)N * kLwdBlocks * 3 * C * sizeof(double)));
+    const long long V = (long long)D * H * W;
+    const int slots = 256 / lpv;
+    int nblocks = (int)da_cdiv(V, (long long)slots * 4); if (nblocks > kLwdBlocks) nblocks = kLwdBlocks; if (nblocks < 1) nblocks = 1;
+    hipLaunchKernelGGL(warp_dice_partial_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
+                       src, disp, lab_t, lab_t_bytes, D, H, W, C, lpv, partial);
     DA_LAUNCH_CHECK();
     return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
 }

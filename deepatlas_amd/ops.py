@@ -1493,19 +1493,30 @@ class SegPhaseLossFn(Function):
         bm = 0
         loss_s = torch.zeros((1,), dtype=torch.float32, device=a.device)
         wp, wn = _ws(nat.lib().da_dice_ws_bytes(N, V, C), a)
+        prob = torch.empty_like(a)
+        fused_fwd = os.environ.get('DA_NO_FUSED_SEGPHASE_FWD') != '1'
         if labels_m is not None:
             lm, bm = _labels(labels_m.reshape(N, -1))
             coef_s = _empty((2, N, C), a)
-            call('da_dice_fwd', ptr(a), ptr(lm), bm, None, N, V, C, 1, wt, nb, float(eps), ptr(loss_s), ptr(coef_s), wp, wn, st)
-        prob = torch.empty_like(a)
-        call('da_softmax_fwd', ptr(a), ptr(prob), N * V, C, st)
-        warped = torch.empty_like(a)
-        call('da_warp_fwd', ptr(prob), ptr(u), None, ptr(warped), N, D, H, W, C, st)
+            # supervised Dice sums and softmax(logits) from ONE pass over the logits (da_softmax_dice_fwd) ...
+            if not (fused_fwd and call_supported('da_softmax_dice_fwd', ptr(a), ptr(lm), bm, ptr(prob), N, V, C, wt, nb, float(eps),
+                                                 ptr(loss_s), ptr(coef_s), wp, wn, st)):
+                call('da_dice_fwd', ptr(a), ptr(lm), bm, None, N, V, C, 1, wt, nb, float(eps), ptr(loss_s), ptr(coef_s), wp, wn, st)
+                call('da_softmax_fwd', ptr(a), ptr(prob), N * V, C, st)
+        else:
+            call('da_softmax_fwd', ptr(a), ptr(prob), N * V, C, st)
         loss_a = _empty((1,), a)
         coef_a = _empty((2, N, C), a)
-        call('da_dice_fwd', ptr(warped), ptr(lt), bt, None, N, V, C, 0, wt, nb, float(eps), ptr(loss_a), ptr(coef_a), wp, wn, st)
+        # ... and the anatomy Dice of the WARPED probabilities without writing the warped tensor (da_warp_dice_fwd)
+        wp2, wn2 = _ws(nat.lib().da_warp_dice_ws_bytes(N, C), a)
+        warped = None
+        if not (fused_fwd and call_supported('da_warp_dice_fwd', ptr(prob), ptr(u), ptr(lt), bt, N, D, H, W, C, wt, nb, float(eps),
+                                             ptr(loss_a), ptr(coef_a), wp2, wn2, st)):
+            warped = torch.empty_like(a)
+            call('da_warp_fwd', ptr(prob), ptr(u), None, ptr(warped), N, D, H, W, C, st)
+            call('da_dice_fwd', ptr(warped), ptr(lt), bt, None, N, V, C, 0, wt, nb, float(eps), ptr(loss_a), ptr(coef_a), wp, wn, st)
         ctx.cfg = (N, D, H, W, C, bm, bt)
-        ctx.scratch = warped                       # dead after the Dice sums: reused as B (W^T onehot, class-major) in backward
+        ctx.scratch = warped                       # (separate route: dead after the Dice sums, reused as B in backward)
         ctx.save_for_backward(prob, u, lm, lt, coef_s, coef_a)
         return loss_s.reshape(()), loss_a.reshape(())
 

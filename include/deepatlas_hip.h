@@ -276,6 +276,17 @@ int da_label_warp_dice_fwd(const void* lab_m, int lab_m_bytes, const void* lab_t
                            float* loss, float* coef /*[2][N][C]*/, void* ws, size_t ws_bytes, void* stream);
 int da_label_warp_dice_bwd(const void* lab_m, int lab_m_bytes, const void* lab_t, int lab_t_bytes, const float* disp,
                            const float* coef, const float* dloss, float* d_disp, int N, int D, int H, int W, int C, void* stream);
+/* segmentation phase, forward: (a) Dice(softmax(src), labels) as da_dice_fwd(softmax = 1) AND prob = softmax(src) written in the same pass
+ * (the warp below needs the probabilities: one pass over the logits instead of da_dice_fwd + da_softmax_fwd); (b) Dice(warp(prob, id + disp),
+ * onehot(lab_t)) without writing the warped tensor (da_warp_fwd + da_dice_fwd minus one write and one read of N V C floats).  Both return
+ * DA_ERR_UNSUPPORTED for class counts whose 4-channel groups are not a power of two; callers then run the separate entries. */
+int da_softmax_dice_fwd(const float* src, const void* labels, int label_bytes, float* prob,
+                        int N, long long V, int C, int weight_type, int no_bg, float eps,
+                        float* loss, float* coef /*[2][N][C]*/, void* ws /* da_dice_ws_bytes */, size_t ws_bytes, void* stream);
+size_t da_warp_dice_ws_bytes(int N, int C);
+int da_warp_dice_fwd(const float* src, const float* disp, const void* lab_t, int lab_t_bytes,
+                     int N, int D, int H, int W, int C, int weight_type, int no_bg, float eps,
+                     float* loss, float* coef /*[2][N][C]*/, void* ws, size_t ws_bytes, void* stream);
 int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const float* disp, float* A, float* B,
                            int N, int D, int H, int W, int C, void* stream);
 int da_seg_anat_dlogits(const float* prob, const void* lab_m, int lab_m_bytes, const float* A, const float* B, float* dlogits,
