@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Generate golden vectors by IMPORTING THE REFERENCE (/root/reference) in the build container.
 
-Run:  python -m oracle.make_golden            (writes tests/golden/*.npz)
+Run:  python -m oracle.make_golden            (writes tests/golden/*.npz: 11 fixtures incl. joint.npz, the joint step and its fp64 twin)
 
 The reference's Python files never travel: only inputs/outputs (data) are committed.  Inputs and
 weights are closed-form (oracle/nets.py closed_form_*), so fixtures stay small; big tensors are
@@ -24,6 +24,8 @@ import torch
 REF = os.environ.get('DEEPATLAS_REFERENCE', '/root/reference')
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+if os.path.dirname(HERE) not in sys.path:          # `python oracle/make_golden.py` works like `python -m oracle.make_golden`
+    sys.path.insert(0, os.path.dirname(HERE))
 
 
 def import_reference():
