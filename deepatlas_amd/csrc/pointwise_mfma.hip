@@ -102,6 +102,11 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                 const long long v = vbase + r * 16 + 4 * g + reg;
                 orow[r][reg] = (v < p.M) ? (p.up ? fine0(v, p.D, p.H, p.W) : v) : -1;
             }
+        long long obase[MT][4];       // element offset of this lane's output column in row orow (computed once, not once per tap)
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) obase[r][reg] = orow[r][reg] * p.ldo + i;
         float bv[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) bv[n] = (p.bias && !p.accum) ? p.bias[16 * n + i] : 0.f;
@@ -136,15 +141,17 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwP p) {
                         acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][c].w, b.w, acc[r][n], 0, 0, 0);
                     }
                 }
+            {
+                TO* const pot = po + toff * p.ldo;                 // the tap's offset is wave-uniform: folded into the (scalar) base pointer
 #pragma unroll
-            for (int r = 0; r < MT; ++r)
+                for (int r = 0; r < MT; ++r)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    if (orow[r][reg] < 0) continue;
-                    const long long o = (orow[r][reg] + toff) * p.ldo + i;
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (orow[r][reg] < 0) continue;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) da_st1(po, o + 16 * n, acc[r][n][reg]);
-                }
+                        for (int n = 0; n < NT; ++n) da_st1(pot, obase[r][reg] + 16 * n, acc[r][n][reg]);
+                    }
+            }
             if constexpr (STATS) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
