@@ -1588,6 +1588,15 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
         return f;
     };
+    // class 4 (the unpaired combo 8): its idle upper tap half takes the SAME combo one halo row further down, i.e. dy + 1 -- fragment of
+    // halo rows (2 wave + h | 2 wave + h + 1).  Its three dy then need two accumulators instead of three: 14 instead of 15 MFMA groups per
+    // row pair (27 taps in 28 slots instead of 30).
+    auto loadG = [&](int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA + offC[4] + (h + (q >> 1)) * (HX * CK);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
+        return f;
+    };
     auto loadY = [&](int r) -> F3 {                                         // dY fragment of output row 2 wave + r
         F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
 #pragma unroll
@@ -1670,9 +1679,9 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         F3 Y0 = loadY(0), Y1 = loadY(1);
         F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < 4; ++c) {
             Fd = loadF(c, 3);
-            if (c < 4) Na = loadF(c + 1, 0);
+            Na = (c < 3) ? loadF(c + 1, 0) : loadG(0);
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {                  // output row 2 wave: halo rows 0, 1, 2 <-> dy 0, 1, 2
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa.p[PA[pr]], Y0.p[PB[pr]], acc[c][0], 0, 0, 0);
@@ -1680,7 +1689,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                 acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y0.p[PB[pr]], acc[c][2], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (c < 4) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); }
+            if (c < 3) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); } else { Nb = loadG(1); Nc = loadF(4, 2); }
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {                  // output row 2 wave + 1: halo rows 1, 2, 3
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y1.p[PB[pr]], acc[c][0], 0, 0, 0);
@@ -1688,7 +1697,22 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                 acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd.p[PA[pr]], Y1.p[PB[pr]], acc[c][2], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (c < 4) { Fa = Na; Fb = Nb; Fc = Nc; }
+            Fa = Na; Fb = Nb; Fc = Nc;
+        }
+        {   // class 4: Fa = rows (0 | 1), Fb = rows (1 | 2), Fc = row 2, Fd = row 3 of combo 8; acc[4][0] = (dy 0 | dy 1), acc[4][1] = (dy 2 | -)
+            Fd = loadF(4, 3);
+#pragma unroll
+            for (int pr = 0; pr < NPR; ++pr) {
+                acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa.p[PA[pr]], Y0.p[PB[pr]], acc[4][0], 0, 0, 0);
+                acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y0.p[PB[pr]], acc[4][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < NPR; ++pr) {
+                acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y1.p[PB[pr]], acc[4][0], 0, 0, 0);
+                acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd.p[PA[pr]], Y1.p[PB[pr]], acc[4][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (has_next) {
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(0);
@@ -1734,9 +1758,11 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int row = 4 * g + reg;
-                    const int combo = 2 * c + (row >> 3);
-                    const int tap = (combo / 3) * 9 + d * 3 + combo % 3, ci = row & 7;
-                    if (combo < 9 && co < p.Cout) part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[c][d][reg];
+                    // classes 0 - 3: (combo 2c | 2c + 1) at dy = d; class 4: combo 8 at dy = (0 | 1) in accumulator 0, dy = (2 | -) in accumulator 1
+                    const int combo = c < 4 ? 2 * c + (row >> 3) : 8;
+                    const int dyt = c < 4 ? d : 2 * d + (row >> 3);
+                    const int tap = (combo / 3) * 9 + dyt * 3 + combo % 3, ci = row & 7;
+                    if (dyt < 3 && (c < 4 || d < 2) && co < p.Cout) part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[c][d][reg];
                 }
     }
 }
