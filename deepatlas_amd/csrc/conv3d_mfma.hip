@@ -72,23 +72,50 @@ __device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // roun
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-// Split mode (SP): x = h + m + l EXACTLY, each term a bf16 -- h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even of
-// the running remainder (3 x 8 significand bits cover fp32's 24; the subtractions are exact in fp32).  Four values at a time, packed
-// like da_bf16x2 (element 0 in the low half).
-__device__ __forceinline__ void da_split3(const float4 v, uint2& h, uint2& m, uint2& l) {
-#ifdef DA_FAKE_SPLIT   // timing experiment only (never in the shipped library): no split arithmetic, wrong results, same data volume
-    h = make_uint2(__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u), __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u));
-    m = make_uint2(h.y, h.x); l = make_uint2(h.x ^ 0x00010001u, h.y);
-    return;
-#endif
-    h = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
-    const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xFFFF0000u);
-    const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xFFFF0000u);
-    m = make_uint2(da_bf16x2(rx, ry), da_bf16x2(rz, rw));
-    const float sx = rx - __uint_as_float(m.x << 16), sy = ry - __uint_as_float(m.x & 0xFFFF0000u);
-    const float sz = rz - __uint_as_float(m.y << 16), sw = rw - __uint_as_float(m.y & 0xFFFF0000u);
-    l = make_uint2(da_bf16x2(sx, sy), da_bf16x2(sz, sw));
+// Split mode (SP): fp32 products on the fp16 matrix pipe.  A staged tile is scaled by a power of two s (exact) so that its largest magnitude
+// lies in [2^14, 2^15), then every value is split into two fp16 terms: h = fp16(x s), l = fp16(x s - h), both round-to-nearest-even, the
+// subtraction exact in fp32.  h carries 11 significand bits, l the next 11 (plus the sign of the remainder): x s = h + l up to 2^-23 |x s|
+// for every element within 2^-18 of the tile's maximum (below that l leaves fp16's normal range and the ABSOLUTE error stays at
+// 2^-40 of the tile maximum).  A product is three MFMAs, a.h b.l + a.l b.h + a.h b.h (smallest first, fp32 accumulate); the dropped
+// a.l b.l is <= 2^-22 |a b|.  Measured against double the sum is more accurate than the fp32 matrix instructions' fmaf chain and than
+// the three-term bf16 split it replaces (fewer roundings per K-step; tools/ubench/split_f16.hip, tests/test_gpu_split.py).
+// Four values at a time, packed pairwise (element 0 in the low half).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));    // eight fp16 (the A / B fragment of v_mfma_f32_16x16x32_f16)
+__device__ __forceinline__ void da_split2(const float4 v, const float s, uint2& h, uint2& l) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t a = {v.x * s, v.y * s}, b = {v.z * s, v.w * s};
+    const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);      // v_cvt_pk_f16_f32 (RNE)
+    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
+    const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
+    h = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+    l = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
+// largest magnitude of a quad, folded into a running maximum (NaN operands are ignored by v_max: they still propagate through the split)
+__device__ __forceinline__ float da_absmax4(float m, const float4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// wave-wide maximum of non-negative floats (their bit patterns order like integers): two quad permutes, half-row and row mirrors (DPP, VALU
+// only), then the four rows through v_readlane -- the result is wave-uniform (SGPR)
+__device__ __forceinline__ float da_wave_max_nonneg(float m) {
+    int v = __float_as_int(m);
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));     // row_mirror
+    const int r = max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    return __int_as_float(r);
+}
+// Power-of-two scale exponent of a tile whose largest magnitude is m: m 2^e in [2^14, 2^15) (fp16 overflows at 65504), clamped to +-100;
+// an all-zero (or denormal) tile gets +100, i.e. it counts as "very small" and never constrains the exponents of its neighbours.
+// da_pow2(e) = 2^e for e in [-126, 127].
+constexpr int kSplitEmax = 100;
+__device__ __forceinline__ int da_scale_exp(float m) {
+    const int ef = (__float_as_int(m) >> 23) & 255;
+    const int e = 141 - ef;
+    return ef == 0 ? kSplitEmax : (e > kSplitEmax ? kSplitEmax : (e < -kSplitEmax ? -kSplitEmax : e));
+}
+__device__ __forceinline__ float da_pow2(int e) { e = e < -126 ? -126 : (e > 127 ? 127 : e); return __int_as_float((e + 127) << 23); }
 __device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
@@ -181,9 +208,9 @@ __device__ __forceinline__ float da_act01(float z, float s) { return fmaxf(z, z 
 // Input prologue (PRO variants): the staged tensor is a RAW convolution output whose BatchNorm + LeakyReLU has not been applied
 // yet; it is applied here, on the way into LDS, with exactly the expression of bn_act_fwd_kernel (norm_act.hip) so the result is
 // bit-identical to materialising the activated tensor first.  Padding (out-of-volume voxels, mask bit clear) stays zero.
-template <int CK, int HZ, int IT0, int IT1, bool BF, bool SP = false, int ZPAD = 0>     // ZPAD: quads of padding after every z plane of the LDS image (bank spreading)
+template <int CK, int HZ, int IT0, int IT1, bool BF, int ZPAD = 0>     // ZPAD: quads of padding after every z plane of the LDS image (bank spreading)
 __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const float4* pre, unsigned vmask, float4 sc, float4 sf, float slope) {
-    constexpr int TOTAL0 = StageGeom<CK, HZ>::TOTAL, TOTAL = TOTAL0 + HZ * ZPAD;
+    constexpr int TOTAL0 = StageGeom<CK, HZ>::TOTAL;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
         const int idx0 = threadIdx.x + it * 256;
@@ -194,19 +221,27 @@ __device__ __forceinline__ void stage_write_pro(float* __restrict__ lds, const f
             float4 v;
             v.x = ok ? da_act01(t.x * sc.x + sf.x, slope) : 0.f; v.y = ok ? da_act01(t.y * sc.y + sf.y, slope) : 0.f;
             v.z = ok ? da_act01(t.z * sc.z + sf.z, slope) : 0.f; v.w = ok ? da_act01(t.w * sc.w + sf.w, slope) : 0.f;
-            if constexpr (SP) {
-                uint2 h, m, l; da_split3(v, h, m, l);
-                reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = m; reinterpret_cast<uint2*>(lds)[idx + 2 * TOTAL] = l;
-            } else if constexpr (BF) reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
+            if constexpr (BF) reinterpret_cast<uint2*>(lds)[idx] = make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
             else reinterpret_cast<float4*>(lds)[idx] = v;
         }
     }
 }
+// the same prologue applied IN PLACE to the parked quads (split mode: the tile's largest magnitude must be known before anything is written)
+template <int IT0, int IT1>
+__device__ __forceinline__ void stage_pro_apply(float4* pre, unsigned vmask, float4 sc, float4 sf, float slope) {
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        const float4 t = pre[it - IT0];
+        const bool ok = ((vmask >> (it - IT0)) & 1u) != 0;
+        pre[it - IT0].x = ok ? da_act01(t.x * sc.x + sf.x, slope) : 0.f; pre[it - IT0].y = ok ? da_act01(t.y * sc.y + sf.y, slope) : 0.f;
+        pre[it - IT0].z = ok ? da_act01(t.z * sc.z + sf.z, slope) : 0.f; pre[it - IT0].w = ok ? da_act01(t.w * sc.w + sf.w, slope) : 0.f;
+    }
+}
 
 // BF: the LDS image holds bf16 (same [voxel][CK] order, 8 bytes per channel quad): converted once here instead of at every tap
-// SP: three bf16 planes (h, m, l of da_split3), each in the BF layout, TOTAL quads apart
+// SP: two fp16 planes (h, l of da_split2 at the tile's scale `sps`), each in the BF layout, TOTAL quads apart
 template <int CK, int HZ, int IT0 = 0, int IT1 = StageGeom<CK, HZ>::NIT, bool BF = false, bool SP = false, int ZPAD = 0, bool RAW = false>
-__device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre) {
+__device__ __forceinline__ void stage_write(float* __restrict__ lds, const float4* pre, const float sps = 1.f) {
     static_assert(!RAW || (BF && !SP), "raw staging: bf16 storage into the one-plane bf16 image");
     constexpr int TOTAL0 = StageGeom<CK, HZ>::TOTAL, TOTAL = TOTAL0 + HZ * ZPAD;
 #pragma unroll
@@ -215,8 +250,8 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
         const int idx = ZPAD ? idx0 + ZPAD * (idx0 / (HY * HX * StageGeom<CK, HZ>::Q)) : idx0;
         if (idx0 < TOTAL0) {
             if constexpr (SP) {
-                uint2 h, m, l; da_split3(pre[it - IT0], h, m, l);
-                reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = m; reinterpret_cast<uint2*>(lds)[idx + 2 * TOTAL] = l;
+                uint2 h, l; da_split2(pre[it - IT0], sps, h, l);
+                reinterpret_cast<uint2*>(lds)[idx] = h; reinterpret_cast<uint2*>(lds)[idx + TOTAL] = l;
             } else if constexpr (RAW) {
                 reinterpret_cast<uint2*>(lds)[idx] = make_uint2(__float_as_uint(pre[it - IT0].x), __float_as_uint(pre[it - IT0].y));
             } else if constexpr (BF) {
@@ -225,6 +260,14 @@ __device__ __forceinline__ void stage_write(float* __restrict__ lds, const float
             } else reinterpret_cast<float4*>(lds)[idx] = pre[it - IT0];
         }
     }
+}
+// largest magnitude among the quads a thread parks for one tile (iterations past the tile hold zeros: their offsets were out of range)
+template <int NITS>
+__device__ __forceinline__ float stage_absmax(const float4* pre) {
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < NITS; ++it) m = da_absmax4(m, pre[it]);
+    return m;
 }
 
 // The same staging loads, one at a time: a cursor that carries the incremental (hz, hy, hx) decomposition so the loads of the
@@ -381,6 +424,7 @@ struct FwdP {
                          // reads one entry per item through the scalar cache instead of decomposing the position (~10 integer divisions)
     int prio_ranks;  // co-resident workgroups per CU taking turns at the top wave priority (0: off)
     S2dSrc s2in;     // MASKED forward: in1 is the ORIGINAL tensor of a stride-2 layer, read as its space-to-depth view (cin > 0)
+    const int* wexp; // SP: power-of-two exponent of every channel chunk of the packed weights (pack_split_weights_kernel)
     S2dSrc s2out;    // MASKED data gradient: the 8 * cin output channels are scattered to the original-resolution gradient (cin > 0)
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
 };
@@ -392,12 +436,14 @@ struct FwdP {
 // next position from that XCD's counter (one atomic per tile by thread 0, two tiles ahead, handed to the other waves through a
 // 4-entry LDS ring), so a kernel whose workgroups start at different times -- behind another persistent kernel on the other stream
 // -- still finishes together.  Not for the STATS variant: its per-workgroup partial sums would then depend on the draw order.
-// SP: split mode (da_set_matrix_mode(2)) -- fp32 products on the bf16 matrix pipe.  Both operands are split exactly into three bf16 terms
-// (da_split3: activations while they are staged, weights in the pack kernel) and a K-step of an (M-tile, N-tile) pair is six
-// v_mfma_f32_16x16x32_bf16: a.l b.h + a.h b.l + a.m b.m + a.h b.m + a.m b.h + a.h b.h, smallest terms first, fp32 accumulate.  The three
-// dropped products are <= 2^-25 |a b| together, i.e. below the rounding of ONE fp32 multiply-add (tools/ubench/split_bf16.hip: the error
-// against double is smaller than that of the v_mfma_f32_16x16x4_f32 chain), at 6/16 of the matrix-pipe time.  LDS holds the three planes
-// (CK = 8: 3 x 17 KB, two workgroups per CU as before); fragments of the next two rows are read while the current two rows' 12 MFMAs issue.
+// SP: split mode (da_set_matrix_mode(2)) -- fp32 products on the fp16 matrix pipe (da_split2).  Both operands are scaled by a power of two
+// and split into two fp16 terms (activations while they are staged, at the scale of their (tile, channel chunk); weights in the pack kernel,
+// at the scale of their channel chunk) and a K-step of an (M-tile, N-tile) pair is three v_mfma_f32_16x16x32_f16: a.h b.l + a.l b.h + a.h b.h,
+// small terms first, fp32 accumulate -- 3/16 of the fp32 matrix instructions' pipe time.  The accumulators of an output tile live in the
+// unit 2^E of the item being accumulated (E = activation exponent + weight exponent): at the start of every item they are multiplied by
+// 2^(E - E_previous) (exact), in the epilogue by 2^-E.  E of a later chunk is capped at 40 above the smallest E the tile has seen, so the
+// rescaled sums cannot overflow (a chunk 2^40 below its neighbours does not reach the fp32 sum anyway).  LDS holds the two planes (CK = 8:
+// 2 x 17 KB); fragments of the next two rows are read while the current two rows' 6 MFMAs issue.
 template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores; HB: bf16 activation storage
 __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(!HB || (BF && !SP && !DYN), "bf16 activation storage: bf16 matrix mode only");
@@ -409,14 +455,14 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(!PAIR || (SP && NREP == 1 && !PRO), "paired staging: split mode, one N-tile, no input prologue");
     static_assert(!DYN || (!STATS && !MASKED && !PRO), "dynamic tile walk: plain forward / data-gradient variants only");
     static_assert(!SP || (BF && !MASKED && !DYN && CK == 8), "split mode: dense bf16 K = 32 kernels on 8-channel chunks");
-    constexpr int NP = SP ? 3 : 1;                                  // operand planes
+    constexpr int NP = SP ? 2 : 1;                                  // operand planes
     constexpr bool RAW = HB && BF && !SP && !PRO && !MASKED && S2F == 0;       // bf16 tensors copied straight into the bf16 LDS image (da_buf_loadq)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // K32: the dense bf16 kernels use v_mfma_f32_16x16x32_bf16 (K = 32 = two taps x 16 cin, or four taps x 8 cin; 16 cycles per
     // SIMD for twice the K of the 16x16x16 form, which gfx950 issues at ~32 cycles); the sparse-tap variant keeps one tap per step.
     constexpr bool K32 = BF && !MASKED;
     using AElem = std::conditional_t<BF, short, float>;
-    using Frag = std::conditional_t<K32, bf16x8, std::conditional_t<BF, s16x4, f32x4>>;   // A / B fragment: 4 (8) consecutive cin of one voxel / one cout
+    using Frag = std::conditional_t<SP, f16x8, std::conditional_t<K32, bf16x8, std::conditional_t<BF, s16x4, f32x4>>>;   // A / B fragment: 4 (8) consecutive cin of one voxel / one cout
     constexpr int EB = BF ? 2 : 4;                               // bytes per staged element
     constexpr int TZ = 4, HZ = TZ + 2;
     constexpr int NSTEPS = K32 ? (CK == 16 ? 14 : 7) : (27 * CK + 15) / 16;          // 27 (CK = 16) | 14 (CK = 8: two taps per K-step); K32: 14 | 7
@@ -560,6 +606,24 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             pslope = first ? p.pslope1 : p.pslope2;
         }
     };
+    // SP: scale bookkeeping, all wave-uniform.  The accumulators hold (true sum) x 2^Eacc; the item in LDS was staged at 2^(Ecur - its weight
+    // exponent); Emin = smallest E of the current output tile so far.  The four waves' tile maxima meet in a 16-byte strip behind the tile.
+    float* smax = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (size_t)StageGeom<CK, HZ>::TOTAL * 4 * EB * NP + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0));
+    int Ecur = 0, Eacc = 0, Emin = 0, Enext = 0;
+    auto sp_publish = [&](const float4* q) {                 // before the barrier that retires the current tile
+        const float m = da_wave_max_nonneg(stage_absmax<PRE>(q));
+        if (lane == 0) smax[wave] = m;
+    };
+    auto sp_scale = [&](int chn) -> float {                  // after it: the activation scale of the tile about to be written (chunk chn); sets Enext
+        const float4 mm = *reinterpret_cast<const float4*>(smax);
+        const int mi = __builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(mm.x, mm.y), fmaxf(mm.z, mm.w))));
+        const int ew = p.wexp[chn];
+        int E = da_scale_exp(__int_as_float(mi)) + ew;
+        if (chn != 0) E = min(E, Emin + 40);
+        Emin = (chn == 0) ? E : min(Emin, E);
+        Enext = E;
+        return da_pow2(E - ew);
+    };
     if constexpr (PRO) {
         int n, z0, y0, x0, ch;
         item_coords(0, n, z0, y0, x0, ch);
@@ -567,10 +631,19 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         if (cbase < p.C1) stage_load<CK, HZ, 0, PRE, HB>(pre, p.in1, p.C1, cbase, n, z0, y0, x0, p.D, p.H, p.W, &vm);
         else stage_load<CK, HZ, 0, PRE, HB>(pre, p.in2, p.C2, cbase - p.C1, n, z0, y0, x0, p.D, p.H, p.W, &vm);
         load_pro(0);
-        stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
+        if constexpr (SP) {
+            stage_pro_apply<0, PRE>(pre, vm, psc, psf, pslope);
+            sp_publish(pre); __syncthreads();
+            const float s0 = sp_scale(0); Ecur = Eacc = Enext;
+            stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre, s0);
+        } else stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
     } else {
     issue_stage(0, pre);
-    stage_write<CK, HZ, 0, PRE, BF, SP, 0, RAW>(lds, pre);
+    if constexpr (SP) {
+        sp_publish(pre); __syncthreads();
+        const float s0 = sp_scale(0); Ecur = Eacc = Enext;
+        stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre, s0);
+    } else stage_write<CK, HZ, 0, PRE, BF, SP, 0, RAW>(lds, pre);
     stage_rest(0);
     if constexpr (PAIR) stage_load<CK, HZ, 0, PRE>(pre2, p.in1, p.C1, CK, cN, cZ, cY, cX, p.D, p.H, p.W);      // item 1 = chunk 1 of the first tile
     }
@@ -613,14 +686,15 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // lanes) is expressed as out-of-range buffer offsets, so hipcc's s_waitcnt vmcnt(N) stay exact instead of collapsing to 0.
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)(nchunks * NSTEPS * p.NT * (K32 ? 1024 * NP : 256 * EB)), 0x00020000);
     auto wb = [&](int chunk, int step, int nn, int pl = 0) -> Frag {
-        if constexpr (SP) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 3 + pl) * 1024), 0));
+        if constexpr (SP) return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 2 + pl) * 1024), 0));
         else if constexpr (K32) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
         else if constexpr (BF) return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rsw, (unsigned)lane * 8u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 512), 0));
         else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((chunk * NSTEPS + step) * p.NT + nt0 + nn) * 1024), 0));
     };
     // one K-step of one (M-tile, N-tile) pair
     auto mma_bf = [&](f32x4 c, const Frag& a, const Frag& b) -> f32x4 {
-        if constexpr (K32) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        if constexpr (SP) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+        else if constexpr (K32) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
         else if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
         else return c;
     };
@@ -657,6 +731,14 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         item_coords(0, n, z0, y0, x0, ch);
         const bool has_next = PH == 1 ? true : DYN ? ((ch + 1 < nchunks) || tile_pos(cK + 1) < xhi) : (item + 1 < nitems);
         const bool last = (ch == nchunks - 1);
+        if constexpr (SP) {          // bring the running sums into this item's unit (exact: a power of two; zero sums on a tile's first chunk)
+            const float f = da_pow2(Ecur - Eacc);
+#pragma unroll
+            for (int r = 0; r < TY; ++r)
+#pragma unroll
+                for (int nn = 0; nn < NREP; ++nn) acc[r][nn] = acc[r][nn] * f;
+            Eacc = Ecur;
+        }
         if constexpr (DYN) {       // on a tile's first chunk: draw the position of the tile after next; published below, before the barriers
             if (threadIdx.x == 0 && ch == 0) sp[(cK + 2) & 3] = xlo + atomicAdd(ctr, 1);
         }
@@ -787,9 +869,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             }
             const AElem* ap = step_ptr(s);
             if constexpr (SP) {
-                // row pairs: the three planes' fragments of the NEXT pair (or of the next K-step's first pair) are read while the 12 * NREP
-                // MFMAs of the current pair issue.  Products smallest first: (a, b) plane pairs (h, l) (l, h) (m, m) (h, m) (m, h) (h, h).
-                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                // row pairs: the two planes' fragments of the NEXT pair (or of the next K-step's first pair) are read while the 6 * NREP
+                // MFMAs of the current pair issue.  Products small terms first: (a, b) plane pairs (h, l) (l, h) (h, h).
+                constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
                 const AElem* anx = (s + 1 < NSTEPS) ? step_ptr(s + 1) : ap;
 #pragma unroll
                 for (int qd = 0; qd < TY / 2; ++qd) {
@@ -800,7 +882,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                         for (int rr = 0; rr < 2; ++rr) AN[pl][rr] = *reinterpret_cast<const Frag*>(src + pl * PLANE_E + rr * (HX * CK));
 #pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
+                    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                         for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
@@ -866,6 +948,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             const int z = z0 + wave;
             const int x = x0 + 4 * g + q;
             const bool do_ep = last && !(p.ablate & 2);
+            const float inv1 = SP ? da_pow2(-(Ecur / 2)) : 1.f, inv2 = SP ? da_pow2(-(Ecur - Ecur / 2)) : 1.f;
             if (do_ep) {
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) {
@@ -885,6 +968,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                             if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
                         }
                         // now (t0..t3) = couts co0..co0+3 of voxel (z, y0 + r, x)
+                        if constexpr (SP) { t0 = t0 * inv1 * inv2; t1 = t1 * inv1 * inv2; t2 = t2 * inv1 * inv2; t3 = t3 * inv1 * inv2; }      // back to the true unit (two exact factors: |E| may exceed 127)
                         const float v0 = t0 + bvv[nn][0], v1 = t1 + bvv[nn][1], v2 = t2 + bvv[nn][2], v3 = t3 + bvv[nn][3];
                         if (STATS) {
                             const float m = (z < p.D && y0 + r < p.H && x < p.W) ? 1.f : 0.f;
@@ -946,15 +1030,23 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         if constexpr (DYN) { if (!has_next) return false; }
         if (has_next && !(p.ablate & 4)) {
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(0);       // DA_PHASE_PRIO: the staging phase yields to the co-resident workgroup's K loop
+            if constexpr (SP) {                    // the next tile's largest magnitude (after its prologue), one value per wave
+                if constexpr (PRO && !PRO_IN) stage_pro_apply<0, PRE>(pre, vm, psc, psf, pslope);
+                sp_publish(PH == 1 ? pre2 : pre);
+            }
             __syncthreads();                       // every wave is done reading this item's LDS tile
-            if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF, SP>(lds, pre, vm, psc, psf, pslope);
-            else if constexpr (PH == 1) stage_write<CK, HZ, 0, PRE, BF, SP>(lds, pre2);
+            if constexpr (SP) {
+                const float sn = sp_scale(nCh);
+                stage_write<CK, HZ, 0, PRE, BF, SP>(lds, PH == 1 ? pre2 : pre, sn);
+            }
+            else if constexpr (PRO && !PRO_IN) stage_write_pro<CK, HZ, 0, PRE, BF>(lds, pre, vm, psc, psf, pslope);
             else stage_write<CK, HZ, 0, PRE, BF, SP, 0, RAW>(lds, pre);     // (PRO_IN: already transformed inside the K loop)
             if constexpr (!PRO) stage_rest(1);
             __syncthreads();
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(2);
         }
         cK = nK; cCh = nCh; cN = nN; cZ = nZ; cY = nY; cX = nX;
+        if constexpr (SP) Ecur = Enext;
         advance();
         return true;
     };
@@ -1187,12 +1279,7 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
                 float v2 = 0.f;
                 if (tp < 27 && cout < Cout && ci < Cin)
                     v2 = flipped ? w[((size_t)(26 - tp) * CoutW + cout0 + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * CoutW + cout0 + cout];
-                if (bf == 3) {      // split mode: three planes (h, m, l) of 1 KiB per (chunk, step, N-tile), the same exact split as da_split3
-                    unsigned short* o = reinterpret_cast<unsigned short*>(wp) + (idx >> 8) * 1536 + lane * 8 + e;
-                    const __bf16 bh = (__bf16)v2; const float r1 = v2 - (float)bh;
-                    const __bf16 bm = (__bf16)r1; const float r2 = r1 - (float)bm;
-                    o[0] = __builtin_bit_cast(unsigned short, bh); o[512] = __builtin_bit_cast(unsigned short, bm); o[1024] = __builtin_bit_cast(unsigned short, (__bf16)r2);
-                } else reinterpret_cast<unsigned short*>(wp)[idx * 2 + h] = __builtin_bit_cast(unsigned short, (__bf16)v2);
+                reinterpret_cast<unsigned short*>(wp)[idx * 2 + h] = __builtin_bit_cast(unsigned short, (__bf16)v2);
             }
             continue;
         }
@@ -1201,6 +1288,48 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
             v = flipped ? w[((size_t)(26 - tap) * CoutW + cout0 + cout) * Cin + cin] : w[((size_t)tap * Cin + cin) * CoutW + cout0 + cout];
         if (bf) reinterpret_cast<unsigned short*>(wp)[idx] = __builtin_bit_cast(unsigned short, (__bf16)v);      // same [..][lane][m] order, 2 bytes each
         else wp[idx] = v;
+    }
+}
+
+// Split mode: the packed B operand of one 8-channel chunk -- two fp16 planes (h, l of da_split2) of 1 KiB per (K-step, N-tile), at the chunk's own
+// power-of-two scale (largest |w| of the chunk in [2^14, 2^15); the exponent goes to wexp[chunk] for the kernel's accumulator bookkeeping).
+// Grid (chunks, PY): every workgroup of a chunk finds the chunk's maximum (27 x 8 x Cout values, L2-resident) and packs its share of the
+// (step, N-tile, lane) units with one 16-byte store per plane.  Also writes the tile table of the launch that follows (pack_fwd_weights_kernel).
+__global__ void __launch_bounds__(256) pack_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout,
+                                                                 int NTpad, int flipped, int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz, int cout0, int CoutW) {
+    __shared__ float wmax[4];
+    const int nb = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    for (int pos = bid * 256 + threadIdx.x; pos < ntiles; pos += nb * 256) {
+        int n, tx, ty, tz;
+        brick_tile<2, 4, 8>(pos, ntx, nty, ntz, n, tx, ty, tz);                                 // brick = 32^3 voxels
+        tiles[pos] = make_int4(n, tz * 4, ty * TY, tx * TX);
+    }
+    const int ch = blockIdx.x;
+    auto wat = [&](int tp, int ci, int cout) -> float {
+        if (tp >= 27 || cout >= Cout || ci >= Cin) return 0.f;
+        return flipped ? w[((size_t)(26 - tp) * CoutW + cout0 + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * CoutW + cout0 + cout];
+    };
+    float m = 0.f;
+    if (flipped) { for (int idx = threadIdx.x; idx < 27 * Cout * 8; idx += 256) { const int e = idx & 7, r = idx >> 3; m = fmaxf(m, fabsf(wat(r / Cout, ch * 8 + e, r % Cout))); } }
+    else { for (int idx = threadIdx.x; idx < 27 * 8 * Cout; idx += 256) { const int co = idx % Cout, r = idx / Cout; m = fmaxf(m, fabsf(wat(r >> 3, ch * 8 + (r & 7), co))); } }
+    m = da_wave_max_nonneg(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const int ew = da_scale_exp(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+    if (blockIdx.y == 0 && threadIdx.x == 0) wexp[ch] = ew;
+    const float sc = da_pow2(ew);
+    const int units = 7 * NTpad * 64;
+    for (int u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+        const int lane = u & 63, nt = (u >> 6) % NTpad, st = (u >> 6) / NTpad;
+        const int tp = 4 * st + (lane >> 4), cout = nt * 16 + (lane & 15);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = wat(tp, ch * 8 + e, cout);
+        uint2 h0, l0, h1, l1;
+        da_split2(make_float4(v[0], v[1], v[2], v[3]), sc, h0, l0);
+        da_split2(make_float4(v[4], v[5], v[6], v[7]), sc, h1, l1);
+        uint4* o = reinterpret_cast<uint4*>(wp + ((size_t)((ch * 7 + st) * NTpad + nt) * 2) * 512) + lane;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -1238,8 +1367,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(!HB || (BF && !SP), "bf16 activation storage: bf16 matrix mode only");
     static_assert(!(BF && YS), "bf16 mode stages dY in channel quads");
-    static_assert(!SP || (BF && !MASKED && CK == 8), "split mode: dense bf16 kernels on 8-channel chunks");
-    constexpr int NP = SP ? 3 : 1;
+    static_assert(!SP, "split mode has its own weight-gradient kernel (conv3_split_wgrad_kernel)");
+    constexpr int NP = 1;
     constexpr int TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
     constexpr int CG = NREP * 16;
     constexpr int TPW = (CK == 16) ? 7 : 4;                     // tap slots per wave (CK = 8: tap PAIRS, 14 in total)
@@ -1338,8 +1467,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         }
     };
     auto write_lds = [&]() {
-        if constexpr (PRO) stage_write_pro<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF, SP>(ldsA, preA, vmA, psc, psf, pslope);
-        else stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF, SP>(ldsA, preA);
+        if constexpr (PRO) stage_write_pro<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, StageGeom<CK, HZ>::NIT, BF>(ldsA, preA);
         // dY tile [TVOX][CG] (channel halves XOR-swizzled by voxel parity when CG % 32 == 0)
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
@@ -1348,10 +1477,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             int c = c4 * 4;
             if (SWZ) c ^= (v & 1) << 4;
             if (idx < TVOX * QY) {
-                if constexpr (SP) {
-                    uint2 h, m, l; da_split3(preY[it], h, m, l);
-                    reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
-                } else if constexpr (BF) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));   // linear [v][CG] in bf16
+                if constexpr (BF) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));   // linear [v][CG] in bf16
                 else *reinterpret_cast<float4*>(ldsY + v * CG + c) = preY[it];
             }
         }
@@ -1368,72 +1494,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
         // steps use compile-time offsets (ds_read immediates), so the VALU work per 28*NREP MFMAs is a handful of adds.
         // Fragments of step j+1 are read while the MFMAs of step j issue (hipcc otherwise serialises read->wait->mfma).
         const int swz = SWZ ? ((g & 1) << 4) : 0;             // voxel parity == g & 1 (row base and 4*j are even)
-        if constexpr (SP) {
-            typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
-            const short* ldsAh = reinterpret_cast<const short*>(ldsA);
-            const short* ldsYh = reinterpret_cast<const short*>(ldsY);
-            constexpr int PLA = HZ * HY * HX * CK, PLY = TVOX * CG;            // elements per plane
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // (x, dY) plane pairs, smallest products first
-            constexpr int NU = (TVOX / 32) * 2;                                    // units: (row pair, tap-slot pair)
-            // lane (i, g): source address of the transpose reads = voxel 8 (g & 1) + (i >> 2) [+ 4] of row 2 rp + (g >> 1), channel quad i & 3
-            auto tr8 = [&](const short* q, int step) -> bf16x8 {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)q);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(q + step));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
-                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            };
-            auto rowA = [&](int rp) -> const short* {
-                const int row = 2 * rp + (g >> 1);
-                return ldsAh + (((row >> 3) * HY + (row & 7)) * HX + 8 * (g & 1) + (i >> 2)) * CK;
-            };
-            auto rowY = [&](int rp) -> const short* {
-                const int row = 2 * rp + (g >> 1);
-                return ldsYh + (row * 16 + 8 * (g & 1) + (i >> 2)) * CG + (i & 3) * 4;
-            };
-            auto loadA = [&](int u, bf16x8 (&a)[2][NP]) {
-                const short* ar = rowA(u >> 1);
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) a[kk][pl] = tr8(ar + offA[2 * (u & 1) + kk] + pl * PLA, 4 * CK);
-            };
-            auto loadB = [&](int rp, bf16x8 (&b)[NREP][NP]) {
-                const short* yr = rowY(rp);
-#pragma unroll
-                for (int nn = 0; nn < NREP; ++nn)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) b[nn][pl] = tr8(yr + nn * 16 + pl * PLY, 4 * CG);
-            };
-            const bool slot3 = wave + 12 < 14;                                     // waves 2, 3 own three tap pairs, not four
-            bf16x8 aC[2][NP], bC[NREP][NP];
-            loadB(0, bC); loadA(0, aC);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                bf16x8 aN[2][NP], bN[NREP][NP];
-                if (u + 1 < NU) { loadA(u + 1, aN); if ((u & 1) == 1) loadB((u + 1) >> 1, bN); }
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                    for (int nn = 0; nn < NREP; ++nn) {
-                        acc[2 * (u & 1)][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aC[0][PA[pr] % NP], bC[nn][PB[pr] % NP], acc[2 * (u & 1)][nn], 0, 0, 0);
-                        if ((u & 1) == 0 || slot3)
-                            acc[2 * (u & 1) + 1][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aC[1][PA[pr] % NP], bC[nn][PB[pr] % NP], acc[2 * (u & 1) + 1][nn], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < NU) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int pl = 0; pl < NP; ++pl) aC[kk][pl] = aN[kk][pl];
-                    if ((u & 1) == 1) {
-#pragma unroll
-                        for (int nn = 0; nn < NREP; ++nn)
-#pragma unroll
-                            for (int pl = 0; pl < NP; ++pl) bC[nn][pl] = bN[nn][pl];
-                    }
-                }
-            }
-        } else if constexpr (BF) {
+        if constexpr (BF) {
             typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
             const short* ldsAh = reinterpret_cast<const short*>(ldsA);
             const short* ldsYh = reinterpret_cast<const short*>(ldsY);
@@ -1528,19 +1589,24 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 // LDS reads per MFMA fall from ~1.3 to ~0.7 ds_read_b64_tr_b16, all four waves carry the same load, and the accumulators (per-wave
 // partial sums over the wave's rows) are reduced across the waves through LDS once, at the end of the persistent loop.
 // ---------------------------------------------------------------------------------------------------
-// NPL = 3: split mode (six products per fragment pair).  NPL = 1: bf16 matrix mode -- operands rounded to bf16, ONE product; the same LDS
-// geometry and accumulator layout at a sixth of the matrix work, i.e. bound by its staging (the older bf16 weight-gradient kernel issues
-// v_mfma_f32_16x16x16_bf16, half the rate of the K = 32 form).  HB: x and dY stored as bf16 (bf16 activation storage; NPL = 1 only).
+// NPL = 2: split mode (da_split2: two fp16 planes of x and of dY at the tile's own power-of-two scales, three products per fragment pair; the
+// accumulators live in the unit 2^E of the tile being accumulated, E = x exponent + dY exponent capped at 40 above the smallest E of the
+// slab so far, and are rescaled by the exact factor 2^(E - E_previous) between tiles).  NPL = 1: bf16 matrix mode -- operands rounded to
+// bf16, ONE product; the same LDS geometry and accumulator layout at a third of the matrix work, i.e. bound by its staging (the older bf16
+// weight-gradient kernel issues v_mfma_f32_16x16x16_bf16, half the rate of the K = 32 form).  HB: x and dY stored as bf16 (bf16 activation
+// storage; NPL = 1 only).
 // Quads of padding after every z plane of the x tile.  The fragment read of the tap-pair class that mixes two z planes (combos 2 and 3:
 // lanes q < 2 read plane dz, lanes q >= 2 plane dz + 1) then starts 16 banks apart instead of 8 within each half wave: 48 -> 16 weight
 // gradient 2.438 -> 2.395 ms, 96 -> 32 1.431 -> 1.406 (2 and 8 quads: less; 0 = the unpadded image).
 #ifndef DA_WG_ZPAD
 #define DA_WG_ZPAD 4
 #endif
-template <bool PRO, int NPL = 3, bool HB = false>
+template <bool PRO, int NPL = 2, bool HB = false>
 __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     static_assert(!HB || NPL == 1, "bf16 activation storage goes with the bf16 matrix mode");
-    constexpr bool SPL = NPL == 3;
+    static_assert(NPL == 1 || NPL == 2, "one bf16 plane or the two fp16 planes of the split mode");
+    constexpr bool SPL = NPL == 2;
+    using WFrag = std::conditional_t<SPL, f16x8, bf16x8>;
     constexpr bool RAWA = HB && !SPL && !PRO, RAWY = HB && !SPL;       // bf16 tensors copied straight into the bf16 LDS image (da_buf_loadq)
     constexpr unsigned ES = HbEl<HB>::ES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1576,12 +1642,16 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         offC[c] = ((combo / 3) * HY * HX + combo % 3) * CK + (combo / 3) * ZPE;
     }
     const int laneY = ((((g >> 1) * TY) + 2 * wave) * TX + 8 * (g & 1) + vq) * CG + q * 4;
-    auto tr8 = [&](const short* a, int step) -> bf16x8 {
+    auto tr8 = [&](const short* a, int step) -> WFrag {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(WFrag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    struct F3 { bf16x8 p[NPL]; };
+    auto mma = [&](f32x4 c, const WFrag& a, const WFrag& b) -> f32x4 {
+        if constexpr (SPL) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
+    struct F3 { WFrag p[NPL]; };
     auto loadF = [&](int c, int h) -> F3 {                                  // x fragment of class c, halo row 2 wave + h
         F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * CK);
 #pragma unroll
@@ -1651,31 +1721,62 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             preY[it] = da_buf_loadq<HB, RAWY>(ry, off);
         }
     };
+    // SPL: scale bookkeeping (wave-uniform).  The accumulators hold (true sums) x 2^Eacc; Emin = smallest E of this slab so far.
+    float* smax = ldsY + PLY / 2 * NPL;                       // [2][4]: the four waves' largest |x| and |dY| of the tile about to be written
+    int Eacc = 0, Emin = 0, Enext = 0; bool first_tile = true;
+    auto publish_max = [&]() {                                // before the barrier that retires the current tile
+        if constexpr (SPL) {
+            if constexpr (PRO) stage_pro_apply<0, NITA>(preA, vmA, psc, psf, pslope);
+            const float ma = da_wave_max_nonneg(stage_absmax<NITA>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+            if (lane == 0) { smax[wave] = ma; smax[4 + wave] = my; }
+        }
+    };
     auto write_lds = [&]() {
-        if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, SPL, ZPQ>(ldsA, preA, vmA, psc, psf, pslope);
-        else stage_write<CK, HZ, 0, NITA, true, SPL, ZPQ, RAWA>(ldsA, preA);
+        float sa = 1.f, sy = 1.f;
+        if constexpr (SPL) {
+            const float4 ma = *reinterpret_cast<const float4*>(smax), my = *reinterpret_cast<const float4*>(smax + 4);
+            const int ea = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w))))));
+            const int ey = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(my.x, my.y), fmaxf(my.z, my.w))))));
+            int E = ea + ey;
+            if (!first_tile) E = min(E, Emin + 40);
+            Emin = first_tile ? E : min(Emin, E);
+            first_tile = false;
+            Enext = E;
+            sy = da_pow2(ey); sa = da_pow2(E - ey);
+            stage_write<CK, HZ, 0, NITA, true, true, ZPQ>(ldsA, preA, sa);
+        }
+        else if constexpr (PRO) stage_write_pro<CK, HZ, 0, NITA, true, ZPQ>(ldsA, preA, vmA, psc, psf, pslope);
+        else stage_write<CK, HZ, 0, NITA, true, false, ZPQ, RAWA>(ldsA, preA);
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             const int idx = threadIdx.x + it * 256;
             if (idx < TVOX * QY) {
                 if constexpr (SPL) {
-                    uint2 h, m, l; da_split3(preY[it], h, m, l);
-                    reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = m; reinterpret_cast<uint2*>(ldsY)[idx + 2 * TVOX * QY] = l;
+                    uint2 h, l; da_split2(preY[it], sy, h, l);
+                    reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + TVOX * QY] = l;
                 } else if constexpr (RAWY) reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(__float_as_uint(preY[it].x), __float_as_uint(preY[it].y));
                 else reinterpret_cast<uint2*>(ldsY)[idx] = make_uint2(da_bf16x2(preY[it].x, preY[it].y), da_bf16x2(preY[it].z, preY[it].w));
             }
         }
     };
-    if (tw.cnt > 0) { issue_loads(0); write_lds(); }
+    if (tw.cnt > 0) { issue_loads(0); publish_max(); if constexpr (SPL) __syncthreads(); write_lds(); }
     __syncthreads();
-    constexpr int NPR = SPL ? 6 : 1;
-    constexpr int PA[6] = {SPL ? 0 : 0, 2, 1, 0, 1, 0}, PB[6] = {SPL ? 2 : 0, 0, 1, 1, 0, 0};      // (x, dY) plane pairs, smallest products first (one plane: the single product)
+    constexpr int NPR = SPL ? 3 : 1;
+    constexpr int PA[3] = {0, SPL ? 1 : 0, 0}, PB[3] = {SPL ? 1 : 0, 0, 0};      // (x, dY) plane pairs, small terms first (one plane: the single product)
     const int prio_rank = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) / 256u);
 #pragma unroll 1
     for (int tile = 0; tile < tw.cnt; ++tile) {
         if (p.prio_ranks > 1) da_setprio((prio_rank + tile) % p.prio_ranks);
         const bool has_next = tile + 1 < tw.cnt;
         if (has_next) issue_loads(tile + 1);                    // next tile's global loads fly during this tile's MFMAs
+        if constexpr (SPL) {                                    // bring the running sums into this tile's unit (exact: a power of two)
+            const float f = da_pow2(Enext - Eacc);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * f;
+            Eacc = Enext;
+        }
         F3 Y0 = loadY(0), Y1 = loadY(1);
         F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
 #pragma unroll
@@ -1684,17 +1785,17 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             Na = (c < 3) ? loadF(c + 1, 0) : loadG(0);
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {                  // output row 2 wave: halo rows 0, 1, 2 <-> dy 0, 1, 2
-                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa.p[PA[pr]], Y0.p[PB[pr]], acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y0.p[PB[pr]], acc[c][1], 0, 0, 0);
-                acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y0.p[PB[pr]], acc[c][2], 0, 0, 0);
+                acc[c][0] = mma(acc[c][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
+                acc[c][1] = mma(acc[c][1], Fb.p[PA[pr]], Y0.p[PB[pr]]);
+                acc[c][2] = mma(acc[c][2], Fc.p[PA[pr]], Y0.p[PB[pr]]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (c < 3) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); } else { Nb = loadG(1); Nc = loadF(4, 2); }
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {                  // output row 2 wave + 1: halo rows 1, 2, 3
-                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y1.p[PB[pr]], acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y1.p[PB[pr]], acc[c][1], 0, 0, 0);
-                acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd.p[PA[pr]], Y1.p[PB[pr]], acc[c][2], 0, 0, 0);
+                acc[c][0] = mma(acc[c][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
+                acc[c][1] = mma(acc[c][1], Fc.p[PA[pr]], Y1.p[PB[pr]]);
+                acc[c][2] = mma(acc[c][2], Fd.p[PA[pr]], Y1.p[PB[pr]]);
             }
             __builtin_amdgcn_sched_barrier(0);
             Fa = Na; Fb = Nb; Fc = Nc;
@@ -1703,24 +1804,32 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             Fd = loadF(4, 3);
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
-                acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa.p[PA[pr]], Y0.p[PB[pr]], acc[4][0], 0, 0, 0);
-                acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fc.p[PA[pr]], Y0.p[PB[pr]], acc[4][1], 0, 0, 0);
+                acc[4][0] = mma(acc[4][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
+                acc[4][1] = mma(acc[4][1], Fc.p[PA[pr]], Y0.p[PB[pr]]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
-                acc[4][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fb.p[PA[pr]], Y1.p[PB[pr]], acc[4][0], 0, 0, 0);
-                acc[4][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd.p[PA[pr]], Y1.p[PB[pr]], acc[4][1], 0, 0, 0);
+                acc[4][0] = mma(acc[4][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
+                acc[4][1] = mma(acc[4][1], Fd.p[PA[pr]], Y1.p[PB[pr]]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (has_next) {
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(0);
+            publish_max();
             __syncthreads();
             write_lds();
             __syncthreads();
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(2);
         }
+    }
+    if constexpr (SPL) {                                        // back to the true unit (two exact factors: |E| may exceed 127)
+        const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * inv1 * inv2;
     }
     // reduce the four waves' partial sums through LDS (two rounds of <= 30 KB), then wave 0 writes this slab's partial dW
     __syncthreads();
@@ -1931,13 +2040,13 @@ static int pick_ck(int C1, int C2) {
 // one-item-ahead prefetch hides).
 static int pick_nrep(int NT) { return NT <= 3 ? NT : (NT % 2 == 0 ? 2 : (NT % 3 == 0 ? 3 : 2)); }
 
-static const int kDynCtrInts = 256;          // tile counters [<= 32 cout groups][8 XCDs] behind the packed weights
+static const int kDynCtrInts = 256;          // tile counters [<= 32 cout groups][8 XCDs] behind the packed weights; split mode: the chunks' weight exponents (<= 256 chunks)
 static size_t packed_bytes(int Cin, int Cout, int CK) {
     const int NT = (Cout + 15) / 16, NREP = pick_nrep(NT);
     const int NTpad = ((NT + NREP - 1) / NREP * NREP + 1) & ~1;      // (even: the bf16 / split modes use <= 2 N-tiles per workgroup)
     const int NSTEPS = (27 * CK + 15) / 16;
     size_t b = (size_t)(Cin / CK) * NSTEPS * NTpad * 256 * sizeof(float);
-    const size_t sp = (size_t)(Cin / 8) * 7 * NTpad * 3072;           // split mode: 8-channel chunks, 7 K-steps of 32, three 1 KiB planes
+    const size_t sp = (size_t)(Cin / 8) * 7 * NTpad * 2048;           // split mode: 8-channel chunks, 7 K-steps of 32, two 1 KiB planes
     if (Cin % 8 == 0 && sp > b) b = sp;
     return da_align(b) + da_align(kDynCtrInts * sizeof(int));
 }
@@ -2000,7 +2109,7 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
 
 template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
-    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 3 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + (DYN ? 16 : 0);
+    const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 2 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + ((DYN || SP) ? 16 : 0);
     auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR, HB>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2130,6 +2239,11 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     FwdP p;
     p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx;
+    if (split) {
+        if (Cin / 8 > kDynCtrInts) return DA_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(pack_split_weights_kernel, dim3(Cin / 8, 8), dim3(256), 0, st, w_tio, reinterpret_cast<unsigned short*>(wp), dyn_ctr, Cin, Cout, NTpad, w_is_flipped_tr,
+                           tiles, p.ntiles, p.ntx, p.nty, p.ntz, cout0, CoutW);
+    } else
     hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total > p.ntiles ? total : p.ntiles, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode,
                        dyn ? dyn_ctr : nullptr, gy * 8, tiles, p.ntiles, p.ntx, p.nty, p.ntz, cout0, CoutW);
     DA_LAUNCH_CHECK();
@@ -2165,7 +2279,7 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     p.stats_partial = stats_partial;
     if (stats_nparts) *stats_nparts = 0;
     p.ps1 = p.pt1 = p.ps2 = p.pt2 = nullptr; p.pslope1 = p.pslope2 = -1.f;
-    p.dyn_ctr = dyn_ctr;
+    p.dyn_ctr = dyn_ctr; p.wexp = dyn_ctr;
     if (pro) {
         const float *ones, *zeros;
         if (const int rc = pro_identity(&ones, &zeros)) return rc;
@@ -2329,7 +2443,7 @@ __global__ void swapped_wgrad_place_kernel(const float* __restrict__ tmp, float*
 
 template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false, bool HB = false>
 static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
-    const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4) * (SP ? 3 : 1);
+    const size_t shm = (size_t)(4 * HY * HX * CK + 2 * TY * TX * NREP * 16) * (BF ? 2 : 4);
     auto kern = conv3_mfma_wgrad_kernel<CK, NREP, YS, MASKED, BF, PRO, SP, HB>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2342,9 +2456,9 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
     return 0;
 }
 
-template <bool PRO, int NPL = 3, bool HB = false>
+template <bool PRO, int NPL = 2, bool HB = false>
 static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
-    size_t shm = (size_t)(4 * (HY * HX * 8 + 4 * DA_WG_ZPAD) + 2 * TY * TX * 16) * 2 * NPL;
+    size_t shm = (size_t)(4 * (HY * HX * 8 + 4 * DA_WG_ZPAD) + 2 * TY * TX * 16) * 2 * NPL + 32;      // + the waves' tile maxima (split mode)
     if (shm < (size_t)2 * 15 * 64 * sizeof(float4)) shm = (size_t)2 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tiles' LDS
     auto kern = conv3_split_wgrad_kernel<PRO, NPL, HB>;
     static bool attr_set = false;
@@ -2357,7 +2471,6 @@ static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
     DA_LAUNCH_CHECK();
     return 0;
 }
-static bool split_wgrad_v1() { static int v = -1; if (v < 0) { const char* e = getenv("DA_SPLIT_WGRAD_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
 
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f, int act_bf16) {
@@ -2438,7 +2551,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     { static int norot = -1; if (norot < 0) { const char* e = getenv("DA_PRIO_ROT"); norot = (e && atoi(e)) ? 0 : 1; }
       const int resident = (q.nslabs * q.nchunks * q.ngroups + 255) / 256; p.prio_ranks = (norot || resident < 2) ? 0 : (resident > 4 ? 4 : resident);
       static int phase = -1; if (phase < 0) { const char* e = getenv("DA_PHASE_PRIO"); phase = (e && atoi(e)) ? 1 : 0; } if (phase) p.prio_ranks = -1; }
-    if ((split && !split_wgrad_v1()) || rows1) {
+    if (split || rows1) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
         hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
         DA_LAUNCH_CHECK();
@@ -2461,7 +2574,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
-        if (split) rcp = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, true, true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
+        if (split) rcp = launch_split_wgrad<true>(p, q, st);
         else if (rows1) rcp = launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
@@ -2471,7 +2584,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (split) rc = split_wgrad_v1() ? launch_wgrad_mfma<8, 1, false, false, true, false, true>(p, q, st) : launch_split_wgrad<false>(p, q, st);
+    if (split) rc = launch_split_wgrad<false>(p, q, st);
     else if (rows1) rc = launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
