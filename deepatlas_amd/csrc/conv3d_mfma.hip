@@ -33,6 +33,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));    // eight bf16 (the
 #endif
 #define DA_BF16_SMAP 1   // bf16 matrix-mode forward kernels: staging offsets from the per-thread halo map (0: the cursor; A/B builds)
 #endif
+#ifndef DA_SP_LB
+#define DA_SP_LB 1   // split mode, one N-tile: K-steps of weight-fragment lookahead
+#endif
+#ifndef DA_RPB4
+#define DA_RPB4 0   // split mode, one N-tile: row blocks of four instead of two (no gain measured: 48 -> 16 forward 1.60 -> 1.62 ms, +16 registers)
+#endif
 #ifndef DA_PIN
 #define DA_PIN 1   // pin the m-outer MFMA order (keeps hipcc from chaining 4 dependent MFMAs on one accumulator)
 #endif
@@ -92,8 +98,12 @@ __device__ __forceinline__ void da_split2(const float4 v, const float s, uint2& 
     l = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 // largest magnitude of a quad, folded into a running maximum (NaN operands are ignored by v_max: they still propagate through the split)
+// (two v_max3_f32 with |.| source modifiers; fmaxf(fabsf()) compiles to seven instructions per quad: a canonicalising v_max per operand)
 __device__ __forceinline__ float da_absmax4(float m, const float4 v) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(v.x), "v"(v.y), "v"(m));
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(m) : "v"(v.z), "v"(v.w), "v"(r));
+    return m;
 }
 // wave-wide maximum of non-negative floats (their bit patterns order like integers): two quad permutes, half-row and row mirrors (DPP, VALU
 // only), then the four rows through v_readlane -- the result is wave-uniform (SGPR)
@@ -311,33 +321,39 @@ template <int CK, int HZ, bool HB = false, bool RAW = false> struct StageCursor 
 // halo voxel (hz, hy, hx) = pk[it] >> 16, (pk[it] >> 8) & 255, pk[it] & 255 and channel quad threadIdx.x % Q.  The byte offsets of one
 // item's NIT loads are computed in one go at the top of the item: 7 VALU operations per load for a tile whose whole halo lies
 // inside the volume (the common case, a wave-uniform branch around pure arithmetic), bounds checks only on boundary tiles.
-template <int CK, int HZ> struct StageMap {
+template <int CK, int HZ, bool VO = true> struct StageMap {      // VO = false: no vo[] (kernels without NIT registers to spare): the interior offsets are recomputed from pk[]
     static constexpr int NIT = StageGeom<CK, HZ>::NIT, Q = StageGeom<CK, HZ>::Q, TOTAL = StageGeom<CK, HZ>::TOTAL;
     unsigned pk[NIT];
+    int vo[VO ? NIT : 1]; // voxel index of the halo voxel relative to the halo's corner, (hz H + hy) W + hx: constant for the whole launch
     int c4x4;
-    __device__ __forceinline__ void init() {
+    bool small;           // 6 H W < 2^24: the offsets of an interior tile are one v_mad_u32_u24 per load
+    __device__ __forceinline__ void init(int H, int W) {
         c4x4 = ((int)threadIdx.x % Q) * 4;
+        small = (long long)HZ * H * W < (1ll << 24);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int hv = ((int)threadIdx.x + it * 256) / Q;
             const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
             pk[it] = (hv < TOTAL / Q) ? ((unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx) : 0xFFFF0000u;     // past the tile: hz = 65535 is never inside
+            if constexpr (VO) vo[it] = (hv < TOTAL / Q) ? (hz * H + hy) * W + hx : 0;
         }
     }
-    // tile-level part (wave-uniform): is the whole halo inside the volume, voxel index of the halo's corner
-    struct Tile { bool interior, valid; int z0, y0, x0, basev, H, W, D, Cs4, cofs4; };
+    // tile-level part (wave-uniform): is the whole halo inside the volume; per-thread base (bytes) of an interior tile's offsets
+    struct Tile { bool interior, valid; int z0, y0, x0, H, W, D, Cs4, cofs4; unsigned base; };
     __device__ __forceinline__ Tile tile(int z0, int y0, int x0, int D, int H, int W, int Cs, int choff, bool valid, int es = 4) const {      // es: bytes per stored element
         Tile t;
         t.valid = valid; t.z0 = z0; t.y0 = y0; t.x0 = x0; t.D = D; t.H = H; t.W = W;
-        t.interior = valid && z0 >= 1 && z0 + HZ - 2 < D && y0 >= 1 && y0 + HY - 2 < H && x0 >= 1 && x0 + HX - 2 < W;
-        t.basev = ((z0 - 1) * H + (y0 - 1)) * W + (x0 - 1);
+        t.interior = small && valid && z0 >= 1 && z0 + HZ - 2 < D && y0 >= 1 && y0 + HY - 2 < H && x0 >= 1 && x0 + HX - 2 < W;
         t.Cs4 = Cs * es; t.cofs4 = (choff + c4x4) * es;
+        t.base = (unsigned)(((z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (unsigned)t.Cs4 + (unsigned)t.cofs4;
         return t;
     }
     __device__ __forceinline__ unsigned offset(const Tile& t, int it) const {
         const int hz = (int)(pk[it] >> 16), hy = (int)((pk[it] >> 8) & 255u), hx = (int)(pk[it] & 255u);
         if (t.interior) {
-            const unsigned o = (unsigned)((t.basev + (hz * t.H + hy) * t.W + hx) * t.Cs4 + t.cofs4);
+            unsigned o;
+            if constexpr (VO) o = __umul24((unsigned)vo[it], (unsigned)t.Cs4) + t.base;
+            else o = (unsigned)((hz * t.H + hy) * t.W + hx) * (unsigned)t.Cs4 + t.base;
             return ((it + 1) * 256 <= TOTAL || hz != 0xFFFF) ? o : 0xFFFFFFFFu;
         }
         const int z = t.z0 - 1 + hz, y = t.y0 - 1 + hy, x = t.x0 - 1 + hx;
@@ -444,8 +460,8 @@ struct FwdP {
 // 2^(E - E_previous) (exact), in the epilogue by 2^-E.  E of a later chunk is capped at 40 above the smallest E the tile has seen, so the
 // rescaled sums cannot overflow (a chunk 2^40 below its neighbours does not reach the fp32 sum anyway).  LDS holds the two planes (CK = 8:
 // 2 x 17 KB); fragments of the next two rows are read while the current two rows' 6 MFMAs issue.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores; HB: bf16 activation storage
-__global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false, int WPE = 2>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores; HB: bf16 activation storage; WPE: waves per SIMD the register allocation must leave room for
+__global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(!HB || (BF && !SP && !DYN), "bf16 activation storage: bf16 matrix mode only");
     static_assert(S2F == 0 || MASKED, "fused space-to-depth addressing belongs to the tap-masked (stride-2) variants");
     // PAIR (split mode, one N-tile): two consecutive 8-channel chunks share every 64-byte sector of their input.  Staged one work item apart
@@ -570,10 +586,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                     double a = (double)st1[nn][j], b = (double)st2[nn][j];     // lane-to-lane tree in double
                     a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
                     a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
-                    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-                    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-                    if ((lane & 3) == 0 && (lane >> 4) == 0) {
-                        const int c = nn * 16 + 4 * ((lane & 15) >> 2) + j;
+                    a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+                    a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+                    if ((lane & 15) == 0) {
+                        const int c = nn * 16 + 4 * (lane >> 4) + j;
                         sred[(wave * 2 + 0) * (NREP * 16) + c] = a;
                         sred[(wave * 2 + 1) * (NREP * 16) + c] = b;
                     }
@@ -658,7 +674,8 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     // tile is parked in registers (PRE == NIT): their 8 MFMAs per K-step leave the VALU as the busiest pipe (SQ counters: 7 VALU instructions
     // per MFMA with the cursor, profiles/r03_pmc_sq_conv3d_48to16.txt)
     constexpr bool SMAP = SP || (K32 && PRE == NIT && (NREP == 1 || (RAW && DA_BF16_SMAP2)) && DA_BF16_SMAP);      // (two N-tiles with fp32 tensors: measured 10 % slower with the map's 17 extra registers; raw bf16 staging parks half the registers)
-    StageMap<CK, HZ> smap; if constexpr (SMAP) smap.init();
+    constexpr bool SMVO = SP && !(NREP == 2 && STATS);            // the launch-constant voxel offsets cost NIT registers
+    StageMap<CK, HZ, SMVO> smap; if constexpr (SMAP) smap.init(p.H, p.W);
     const bool hi = (g >> 1) != 0;
     auto a_off = [&](int s) -> int { return (((s / 9) * HY + (s / 3) % 3) * HX + s % 3) * CK; };   // CK16, s = tap
     auto a_off8 = [&](int s) -> int {                                                              // CK8: two taps per step
@@ -693,12 +710,12 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
     };
     // one K-step of one (M-tile, N-tile) pair
     auto mma_bf = [&](f32x4 c, const Frag& a, const Frag& b) -> f32x4 {
-        if constexpr (SP) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-        else if constexpr (K32) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-        else if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+        if constexpr (SP) return __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c, 0, 0, 0);          // (weights as A, activations as B: see bvv)
+        else if constexpr (K32) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+        else if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b, a, c, 0, 0, 0);
         else return c;
     };
-    constexpr int LB = SP ? 1 : (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2; a split-mode K-step is 6 x 8 MFMAs long)
+    constexpr int LB = SP ? (NREP == 1 ? DA_SP_LB : 1) : (NREP == 1) ? 4 : ((NREP == 2 && !STATS) ? 2 : 1);   // B lookahead in K-steps (the statistics variant of NREP = 2 would spill at 2; a split-mode K-step is 6 x 8 MFMAs long)
     constexpr int RB = LB + 1;                          // ring slots
     constexpr int TAIL = SP ? 2 : 5;                    // K-steps at the end of an item without staging loads (they must land before stage_write)
     constexpr int PRO_DELAY = SP ? 1 : 3;               // K-steps between a staging load and its prologue arithmetic (< TAIL)
@@ -713,8 +730,10 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) nb[t][nn][pl] = wb(0, t, nn, pl);     // item 0 is chunk 0
     }
-    // bias of this lane's 4 couts after the epilogue transpose (constant for the whole launch)
-    const int q = lane & 3, a4 = (lane & 15) >> 2;
+    // bias of this lane's 4 couts (constant for the whole launch).  The MFMAs take the WEIGHT fragment as their A operand and the activation
+    // fragment as B (both have the same per-lane layout), so D = [cout][voxel]: lane (i, g) holds voxel x0 + i and the four consecutive
+    // couts 4 g .. 4 g + 3 -- one 16-byte store per M-tile with no transpose in the epilogue.
+    const int a4 = g;
     float bvv[NREP][4];
 #pragma unroll
     for (int nn = 0; nn < NREP; ++nn)
@@ -778,7 +797,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                             for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                                 for (int r = 0; r < TY; ++r)
-                                    acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r][m], bb[nn][m], acc[r][nn], 0, 0, 0);
+                                    acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[nn][m], aa[r][m], acc[r][nn], 0, 0, 0);
                     }
                     if (!more) break;
 #pragma unroll
@@ -803,7 +822,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) bq[t % RB][nn][pl] = nb[t][nn][pl];
         StageCursor<CK, HZ, HB, RAW> cur;                     // next item's staging loads: cursor (fp32 / bf16 kernels) ...
-        typename StageMap<CK, HZ>::Tile stile;                // ... or per-thread halo map (SP: registers to spare, ~60 % fewer instructions)
+        typename StageMap<CK, HZ, SMVO>::Tile stile;                // ... or per-thread halo map (SP: registers to spare, ~60 % fewer instructions)
         __amdgpu_buffer_rsrc_t rsn;
         if constexpr (PRO) vm = 0;
         if constexpr (PRO_IN) load_pro(has_next ? 1 : 0);               // constants of the tile staged during this item
@@ -822,13 +841,16 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
         }
         Frag A0[HALF], A1[HALF];
         constexpr int PLANE_E = StageGeom<CK, HZ>::TOTAL * 4;             // elements per operand plane (SP)
-        Frag AC[NP][2];                                                     // SP: fragments of the current row pair
+        // SP: rows per block of MFMAs -- a block issues its products plane pair by plane pair over RPB x NREP accumulators, so two MFMAs on the same
+        // accumulator are four apart (two apart, one N-tile and row pairs, cost 2 - 5 wait states per MFMA: its latency is two issue slots)
+        constexpr int RPB = (SP && NREP == 1 && WPE == 2 && DA_RPB4) ? 4 : 2;
+        Frag AC[NP][RPB];                                                   // SP: fragments of the current row block
         if constexpr (SP) {
             const AElem* ap = step_ptr(0);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) AC[pl][rr] = *reinterpret_cast<const Frag*>(ap + pl * PLANE_E + rr * (HX * CK));
+                for (int rr = 0; rr < RPB; ++rr) AC[pl][rr] = *reinterpret_cast<const Frag*>(ap + pl * PLANE_E + rr * (HX * CK));
         } else {
             const AElem* ap = step_ptr(0);
 #pragma unroll
@@ -869,30 +891,30 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
             }
             const AElem* ap = step_ptr(s);
             if constexpr (SP) {
-                // row pairs: the two planes' fragments of the NEXT pair (or of the next K-step's first pair) are read while the 6 * NREP
-                // MFMAs of the current pair issue.  Products small terms first: (a, b) plane pairs (h, l) (l, h) (h, h).
+                // row blocks: the two planes' fragments of the NEXT block (or of the next K-step's first block) are read while the 3 * RPB * NREP
+                // MFMAs of the current block issue.  Products small terms first: (a, b) plane pairs (h, l) (l, h) (h, h).
                 constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
                 const AElem* anx = (s + 1 < NSTEPS) ? step_ptr(s + 1) : ap;
 #pragma unroll
-                for (int qd = 0; qd < TY / 2; ++qd) {
-                    Frag AN[NP][2];
-                    const AElem* src = (qd + 1 < TY / 2) ? ap + (2 * qd + 2) * (HX * CK) : anx;
+                for (int qd = 0; qd < TY / RPB; ++qd) {
+                    Frag AN[NP][RPB];
+                    const AElem* src = (qd + 1 < TY / RPB) ? ap + (RPB * qd + RPB) * (HX * CK) : anx;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) AN[pl][rr] = *reinterpret_cast<const Frag*>(src + pl * PLANE_E + rr * (HX * CK));
+                        for (int rr = 0; rr < RPB; ++rr) AN[pl][rr] = *reinterpret_cast<const Frag*>(src + pl * PLANE_E + rr * (HX * CK));
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                         for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
-                            for (int rr = 0; rr < 2; ++rr)
-                                acc[2 * qd + rr][nn] = mma_bf(acc[2 * qd + rr][nn], AC[PA[pr] % NP][rr], bq[s % RB][nn][PB[pr] % NP]);
+                            for (int rr = 0; rr < RPB; ++rr)
+                                acc[RPB * qd + rr][nn] = mma_bf(acc[RPB * qd + rr][nn], AC[PA[pr] % NP][rr], bq[s % RB][nn][PB[pr] % NP]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) AC[pl][rr] = AN[pl][rr];
+                        for (int rr = 0; rr < RPB; ++rr) AC[pl][rr] = AN[pl][rr];
                 }
                 continue;
             }
@@ -910,7 +932,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                 for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                     for (int r = 0; r < HALF; ++r)
-                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r][m], bq[s % RB][nn][0][m], acc[r][nn], 0, 0, 0);
+                        acc[r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s % RB][nn][0][m], A0[r][m], acc[r][nn], 0, 0, 0);
                 if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
             }
             }
@@ -931,22 +953,21 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                 for (int nn = 0; nn < NREP; ++nn)
 #pragma unroll
                     for (int r = 0; r < HALF; ++r)
-                        acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r][m], bq[s % RB][nn][0][m], acc[HALF + r][nn], 0, 0, 0);
+                        acc[HALF + r][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s % RB][nn][0][m], A1[r][m], acc[HALF + r][nn], 0, 0, 0);
                 if (DA_PIN) __builtin_amdgcn_sched_barrier(0);
             }
             }
         }
         }
 
-        // epilogue.  C/D layout of 16x16x4: col (N = cout) = lane & 15, row (M = voxel x) = 4 * (lane >> 4) + reg.
-        // A 4x4 transpose across each lane quad (2 DPP butterfly stages) turns the fragment (4 voxels x 1 cout per lane)
-        // into (1 voxel x 4 couts per lane): one 16-byte store per M-tile, 1 KiB contiguous per wave instruction for
-        // Cout = 16.  The arithmetic runs on the last chunk only; the STORES are issued on every item through a buffer
+        // epilogue.  C/D layout of the 16x16 MFMAs: col (N) = lane & 15, row (M) = 4 * (lane >> 4) + reg.  With the weights as the A operand
+        // M = cout and N = voxel x: a lane holds 1 voxel x 4 consecutive couts = one 16-byte store per M-tile, 1 KiB contiguous per wave
+        // instruction for Cout = 16, and no transpose.  The arithmetic runs on the last chunk only; the STORES are issued on every item through a buffer
         // descriptor, with the offset out of range (dropped by the hardware) when this is not the last chunk or the lane is
         // outside the volume -- no vector-memory instruction sits in a branch (see above).
         {
             const int z = z0 + wave;
-            const int x = x0 + 4 * g + q;
+            const int x = x0 + i;
             const bool do_ep = last && !(p.ablate & 2);
             const float inv1 = SP ? da_pow2(-(Ecur / 2)) : 1.f, inv2 = SP ? da_pow2(-(Ecur - Ecur / 2)) : 1.f;
             if (do_ep) {
@@ -954,20 +975,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                 for (int nn = 0; nn < NREP; ++nn) {
 #pragma unroll
                     for (int r = 0; r < TY; ++r) {
-                        float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];
-                        {   // stage 1: partner = lane ^ 1, register pairs (0,1) and (2,3)
-                            const bool odd = (q & 1) != 0;
-                            const float s01 = odd ? t0 : t1, s23 = odd ? t2 : t3;
-                            const float r01 = da_quad_xor1(s01), r23 = da_quad_xor1(s23);
-                            if (odd) { t0 = r01; t2 = r23; } else { t1 = r01; t3 = r23; }
-                        }
-                        {   // stage 2: partner = lane ^ 2, register pairs (0,2) and (1,3)
-                            const bool hi2 = (q & 2) != 0;
-                            const float s02 = hi2 ? t0 : t2, s13 = hi2 ? t1 : t3;
-                            const float r02 = da_quad_xor2(s02), r13 = da_quad_xor2(s13);
-                            if (hi2) { t0 = r02; t1 = r13; } else { t2 = r02; t3 = r13; }
-                        }
-                        // now (t0..t3) = couts co0..co0+3 of voxel (z, y0 + r, x)
+                        float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];      // couts co0..co0+3 of voxel (z, y0 + r, x)
                         if constexpr (SP) { t0 = t0 * inv1 * inv2; t1 = t1 * inv1 * inv2; t2 = t2 * inv1 * inv2; t3 = t3 * inv1 * inv2; }      // back to the true unit (two exact factors: |E| may exceed 127)
                         const float v0 = t0 + bvv[nn][0], v1 = t1 + bvv[nn][1], v2 = t2 + bvv[nn][2], v3 = t3 + bvv[nn][3];
                         if (STATS) {
@@ -976,6 +984,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_fwd_kernel(FwdP p) {
                             st2[nn][0] += m * v0 * v0; st2[nn][1] += m * v1 * v1; st2[nn][2] += m * v2 * v2; st2[nn][3] += m * v3 * v3;
                         }
                         acc[r][nn] = (f32x4){da_act(v0, p.slope), da_act(v1, p.slope), da_act(v2, p.slope), da_act(v3, p.slope)};
+                        if constexpr (STATS) __builtin_amdgcn_sched_barrier(0);      // one M-tile at a time (interleaving all of them spills the statistics variants)
                     }
                 }
             }
@@ -1684,13 +1693,21 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     float4 preA[NITA], preY[NITY];
     // Per-thread constants of the two staging patterns (the tile coordinates come from the table the launcher's tile kernel wrote):
     // x halo: StageMap; dY: iteration `it` covers voxel v = it * 64 + threadIdx.x / 4, cout quad threadIdx.x % 4.
-    StageMap<CK, HZ> smap; smap.init();
+    StageMap<CK, HZ> smap; smap.init(p.H, p.W);
     const int yq4 = (cg * CG + ((int)threadIdx.x % QY) * 4);
     const int yv0 = (int)threadIdx.x / QY;
-    auto issue_loads = [&](int tile) {
+    int voY[NITY];                                            // dY voxel index relative to the tile's corner: constant for the whole launch
+    const bool smallY = (long long)TZ * p.H * p.W < (1ll << 24) && (long long)p.Cout * ES < (1ll << 24);
+#pragma unroll
+    for (int it = 0; it < NITY; ++it) { const int v = yv0 + it * (256 / QY); voY[it] = ((v >> 7) * p.H + ((v >> 4) & 7)) * p.W + (v & 15); }
+    // The tile table is read with a vector load (hipcc does not prove the table invariant): an entry is requested one tile before the
+    // staging loads that need it, so its latency never sits in front of them.
+    auto fetch_tile = [&](int tile) -> int4 {
         int pos = tw.lo + tile * tw.J; pos = pos < p.ntiles ? pos : p.ntiles - 1;
-        const int4 t = p.tiles[__builtin_amdgcn_readfirstlane(pos)];
-        const int n = t.x, z0 = t.y, y0 = t.z, x0 = t.w;
+        return p.tiles[__builtin_amdgcn_readfirstlane(pos)];
+    };
+    auto issue_loads = [&](const int4 tv) {
+        const int n = __builtin_amdgcn_readfirstlane(tv.x), z0 = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
         {
             const long long sample = (long long)p.D * p.H * p.W * Cs;
             const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<HB>(src, n, sample);
@@ -1705,14 +1722,15 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         }
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
         const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<HB>(p.dy, n, sampleY);
-        const bool inside = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;      // wave-uniform: the whole dY tile exists
+        const bool inside = smallY && z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;      // wave-uniform: the whole dY tile exists
         const int basev = (z0 * p.H + y0) * p.W + x0;
+        const unsigned baseY = ((unsigned)basev * (unsigned)p.Cout + (unsigned)yq4) * ES;
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             const int v = yv0 + it * (256 / QY);
             const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
             unsigned off;
-            if (inside) off = (unsigned)(((basev + (vz * p.H + vy) * p.W + vx) * p.Cout + yq4) * ES);
+            if (inside) off = __umul24((unsigned)voY[it], (unsigned)p.Cout * ES) + baseY;
             else {
                 const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
                 const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
@@ -1759,7 +1777,8 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             }
         }
     };
-    if (tw.cnt > 0) { issue_loads(0); publish_max(); if constexpr (SPL) __syncthreads(); write_lds(); }
+    int4 tnext = fetch_tile(1);
+    if (tw.cnt > 0) { issue_loads(fetch_tile(0)); publish_max(); if constexpr (SPL) __syncthreads(); write_lds(); }
     __syncthreads();
     constexpr int NPR = SPL ? 3 : 1;
     constexpr int PA[3] = {0, SPL ? 1 : 0, 0}, PB[3] = {SPL ? 1 : 0, 0, 0};      // (x, dY) plane pairs, small terms first (one plane: the single product)
@@ -1768,7 +1787,8 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     for (int tile = 0; tile < tw.cnt; ++tile) {
         if (p.prio_ranks > 1) da_setprio((prio_rank + tile) % p.prio_ranks);
         const bool has_next = tile + 1 < tw.cnt;
-        if (has_next) issue_loads(tile + 1);                    // next tile's global loads fly during this tile's MFMAs
+        if (has_next) issue_loads(tnext);                       // next tile's global loads fly during this tile's MFMAs
+        tnext = fetch_tile(tile + 2);
         if constexpr (SPL) {                                    // bring the running sums into this tile's unit (exact: a power of two)
             const float f = da_pow2(Enext - Eacc);
 #pragma unroll
@@ -2107,10 +2127,10 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false>
+template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false, int WPE = 2>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 2 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + ((DYN || SP) ? 16 : 0);
-    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR, HB>;
+    auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR, HB, WPE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -2264,7 +2284,8 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
         // (a third workgroup per CU for the split kernels -- 168 VGPRs, 3 x 52 KB of LDS -- was measured and dropped: in split mode the
         // matrix pipe is already busy ~100 % of the shader cycles and the clock is set by the power limit)
         static int nres = -1; if (nres < 0) { const char* e = getenv("DA_FWD_BLOCKS"); nres = e ? atoi(e) : 512; }
-        int nblk = nres / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
+        static int wg3 = -1; if (wg3 < 0) { const char* e = getenv("DA_FWD_WG3"); wg3 = (e && atoi(e)) ? 1 : 0; }
+        int nblk = ((wg3 && split && NREP == 1) ? 768 : nres) / gy; if (nblk < 1) nblk = 1; if (nblk > p.ntiles) nblk = p.ntiles;
         if (nblk >= 8) nblk &= ~7;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
         p.nblocks = nblk;
     }
@@ -2291,6 +2312,10 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
         if (stats_partial && stats_nparts) *stats_nparts = p.nblocks;
         // paired staging (one sector fetch per two chunks): one N-tile, an even number of 8-channel chunks that pair up inside in1 / in2
         static int nopair = -1; if (nopair < 0) { const char* e = getenv("DA_NO_PAIR"); nopair = (e && atoi(e)) ? 1 : 0; }
+        static int wg3s = -1; if (wg3s < 0) { const char* e = getenv("DA_FWD_WG3"); wg3s = (e && atoi(e)) ? 1 : 0; }
+        if (wg3s && NREP == 1)      // experiment: three workgroups per CU (<= 168 VGPRs), no paired staging
+            return stats_partial ? (pro ? launch_fwd_mfma<8, 1, false, true, true, true, false, true, 0, false, false, 3>(p, gy, st) : launch_fwd_mfma<8, 1, false, true, true, false, false, true, 0, false, false, 3>(p, gy, st))
+                                 : (pro ? launch_fwd_mfma<8, 1, false, false, true, true, false, true, 0, false, false, 3>(p, gy, st) : launch_fwd_mfma<8, 1, false, false, true, false, false, true, 0, false, false, 3>(p, gy, st));
         if (!nopair && NREP == 1 && !pro && C1 % 16 == 0 && C2 % 16 == 0)
             return stats_partial ? launch_fwd_mfma<8, 1, false, true, true, false, false, true, 0, true>(p, gy, st)
                                  : launch_fwd_mfma<8, 1, false, false, true, false, false, true, 0, true>(p, gy, st);

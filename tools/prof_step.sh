@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel summary + two-stream timeline + per-C-ABI-call table of one workload.
-#   tools/prof_step.sh <seg|reg|joint> <tag>   ->  gpurun_out/r03/<tag>_{kernel_stats,timeline,calls}.txt
+#   tools/prof_step.sh <seg|reg|joint> <tag>   ->  gpurun_out/r04/<tag>_{kernel_stats,timeline,calls}.txt
 w=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/${ROUND:-r04}; mkdir -p $O
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -- python bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/prof_$tag.log 2>&1 < /dev/null
 f=$(ls $O/prof_$tag/*/*.db 2>/dev/null | head -1)
 if [ -n "$f" ]; then
