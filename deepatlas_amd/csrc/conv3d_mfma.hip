@@ -22,6 +22,7 @@
 // Roofline: both are MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); algorithmic FLOPs = 2*27*Cin*Cout per output voxel.
 #include "common.h"
 #include "conv3d_internal.h"
+#include "split_f16.h"      // da_split2, da_absmax4, da_wave_max_nonneg, da_scale_exp, da_pow2: the two-term fp16 split of the SP kernels
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));      // four bf16 (the A / B fragment of v_mfma_f32_16x16x16_bf16)
@@ -78,54 +79,6 @@ __device__ __forceinline__ unsigned da_bf16x2(float lo, float hi) {      // roun
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-// Split mode (SP): fp32 products on the fp16 matrix pipe.  A staged tile is scaled by a power of two s (exact) so that its largest magnitude
-// lies in [2^14, 2^15), then every value is split into two fp16 terms: h = fp16(x s), l = fp16(x s - h), both round-to-nearest-even, the
-// subtraction exact in fp32.  h carries 11 significand bits, l the next 11 (plus the sign of the remainder): x s = h + l up to 2^-23 |x s|
-// for every element within 2^-18 of the tile's maximum (below that l leaves fp16's normal range and the ABSOLUTE error stays at
-// 2^-40 of the tile maximum).  A product is three MFMAs, a.h b.l + a.l b.h + a.h b.h (smallest first, fp32 accumulate); the dropped
-// a.l b.l is <= 2^-22 |a b|.  Measured against double the sum is more accurate than the fp32 matrix instructions' fmaf chain and than
-// the three-term bf16 split it replaces (fewer roundings per K-step; tools/ubench/split_f16.hip, tests/test_gpu_split.py).
-// Four values at a time, packed pairwise (element 0 in the low half).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));    // eight fp16 (the A / B fragment of v_mfma_f32_16x16x32_f16)
-__device__ __forceinline__ void da_split2(const float4 v, const float s, uint2& h, uint2& l) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t a = {v.x * s, v.y * s}, b = {v.z * s, v.w * s};
-    const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);      // v_cvt_pk_f16_f32 (RNE)
-    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
-    const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
-    h = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-    l = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
-}
-// largest magnitude of a quad, folded into a running maximum (NaN operands are ignored by v_max: they still propagate through the split)
-// (two v_max3_f32 with |.| source modifiers; fmaxf(fabsf()) compiles to seven instructions per quad: a canonicalising v_max per operand)
-__device__ __forceinline__ float da_absmax4(float m, const float4 v) {
-    float r;
-    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(v.x), "v"(v.y), "v"(m));
-    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(m) : "v"(v.z), "v"(v.w), "v"(r));
-    return m;
-}
-// wave-wide maximum of non-negative floats (their bit patterns order like integers): two quad permutes, half-row and row mirrors (DPP, VALU
-// only), then the four rows through v_readlane -- the result is wave-uniform (SGPR)
-__device__ __forceinline__ float da_wave_max_nonneg(float m) {
-    int v = __float_as_int(m);
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));     // row_half_mirror
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));     // row_mirror
-    const int r = max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-    return __int_as_float(r);
-}
-// Power-of-two scale exponent of a tile whose largest magnitude is m: m 2^e in [2^14, 2^15) (fp16 overflows at 65504), clamped to +-100;
-// an all-zero (or denormal) tile gets +100, i.e. it counts as "very small" and never constrains the exponents of its neighbours.
-// da_pow2(e) = 2^e for e in [-126, 127].
-constexpr int kSplitEmax = 100;
-__device__ __forceinline__ int da_scale_exp(float m) {
-    const int ef = (__float_as_int(m) >> 23) & 255;
-    const int e = 141 - ef;
-    return ef == 0 ? kSplitEmax : (e > kSplitEmax ? kSplitEmax : (e < -kSplitEmax ? -kSplitEmax : e));
-}
-__device__ __forceinline__ float da_pow2(int e) { e = e < -126 ? -126 : (e > 127 ? 127 : e); return __int_as_float((e + 127) << 23); }
 __device__ __forceinline__ float4 da_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
@@ -1318,8 +1271,24 @@ __global__ void __launch_bounds__(256) pack_split_weights_kernel(const float* __
         if (tp >= 27 || cout >= Cout || ci >= Cin) return 0.f;
         return flipped ? w[((size_t)(26 - tp) * CoutW + cout0 + cout) * Cin + ci] : w[((size_t)tp * Cin + ci) * CoutW + cout0 + cout];
     };
+    // the chunk's largest magnitude: 16-byte loads, four in flight per thread (the weights are cold in L2 at the first call of a step)
     float m = 0.f;
-    if (flipped) { for (int idx = threadIdx.x; idx < 27 * Cout * 8; idx += 256) { const int e = idx & 7, r = idx >> 3; m = fmaxf(m, fabsf(wat(r / Cout, ch * 8 + e, r % Cout))); } }
+    const bool vec = (Cout % 4 == 0) && (CoutW % 4 == 0) && (cout0 % 4 == 0) && (Cin % 8 == 0) && ((reinterpret_cast<size_t>(w) & 15) == 0);
+    if (vec && flipped) {                 // runs of 8 consecutive ci per (tap, cout)
+        const int nq = 27 * Cout * 2;
+#pragma unroll 4
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const int r = q >> 1, tp = r / Cout, co = r - tp * Cout;
+            m = da_absmax4(m, *reinterpret_cast<const float4*>(w + ((size_t)tp * CoutW + cout0 + co) * Cin + ch * 8 + (q & 1) * 4));
+        }
+    } else if (vec) {                     // runs of Cout consecutive couts per (tap, ci)
+        const int qc = Cout / 4, nq = 27 * 8 * qc;
+#pragma unroll 4
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const int r = q / qc, c4 = q - r * qc;
+            m = da_absmax4(m, *reinterpret_cast<const float4*>(w + ((size_t)(r >> 3) * Cin + ch * 8 + (r & 7)) * CoutW + cout0 + c4 * 4));
+        }
+    } else if (flipped) { for (int idx = threadIdx.x; idx < 27 * Cout * 8; idx += 256) { const int e = idx & 7, r = idx >> 3; m = fmaxf(m, fabsf(wat(r / Cout, ch * 8 + e, r % Cout))); } }
     else { for (int idx = threadIdx.x; idx < 27 * 8 * Cout; idx += 256) { const int co = idx % Cout, r = idx / Cout; m = fmaxf(m, fabsf(wat(r >> 3, ch * 8 + (r & 7), co))); } }
     m = da_wave_max_nonneg(m);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;

@@ -1,12 +1,13 @@
 // Native stride-2 3x3x3 convolution (padding 1) for the registration encoder (voxel_morph.py:43-47, modules.py:48) in SPLIT matrix
-// mode: forward, data gradient and weight gradient as implicit GEMMs on v_mfma_f32_16x16x32_bf16 with both operands split exactly
-// into three bf16 planes (x = h + m + l, six partial products per multiply, fp32 accumulate: see conv3d_mfma.hip, "SP").
+// mode: forward, data gradient and weight gradient as implicit GEMMs on v_mfma_f32_16x16x32_f16 with both operands scaled by a power of
+// two and split into two fp16 planes (x s = h + l, three partial products per multiply, fp32 accumulate: split_f16.h and conv3d_mfma.hip,
+// "SP"; the scale is per staged tile for activations / gradients, per channel chunk (forward) or per tensor (data gradient) for weights).
 //
 // Why its own kernels: the space-to-depth route (conv3d_s2.hip) stages a 69 KB stride-1 halo tile per (parity, 16 channels) for 1 - 8 of
 // the 27 taps; here one halo tile serves all 27 taps.
 //   out[z][y][x][co] = b[co] + sum_{dz,dy,dx,ci} in[2z + dz - 1][2y + dy - 1][2x + dx - 1][ci] * W[dz][dy][dx][ci][co]
 //
-// LDS layout of an input halo tile (forward, weight gradient): [plane h|m|l][hz][hy][xpos][8 channels] bf16, where the halo's x axis is
+// LDS layout of an input halo tile (forward, weight gradient): [plane h|l][hz][hy][xpos][8 channels] fp16, where the halo's x axis is
 // DE-INTERLEAVED by parity: halo column hx (input x = 2 x0 - 1 + hx) sits at xpos = hx / 2 for even hx, 17 + hx / 2 for odd hx.  The 16
 // output voxels of an M-tile read columns hx = 2 i + dx, i.e. xpos = i (dx 0), 17 + i (dx 1), i + 1 (dx 2): consecutive lanes read
 // consecutive 16-byte rows, exactly like the stride-1 kernels (no 2-way bank conflict from the 32-byte lane stride).
@@ -25,12 +26,12 @@
 // (16 -> 32 at 160 x 192 x 160: 17 GFLOP, 315 MB in + 79 MB out) the forward and the data gradient are HBM/L2-bound.
 #include "common.h"
 #include "conv3d_internal.h"
+#include "split_f16.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TZ = 2, TY = 4, TX = 16;                          // output tile (forward / wgrad), dY-grid tile (dgrad)
 constexpr int HZ = 2 * TZ + 1, HY = 2 * TY + 1, HXV = 2 * TX + 1;     // input halo voxels: 5 x 9 x 33
@@ -47,22 +48,6 @@ __device__ __forceinline__ float4 s2n_load4(__amdgpu_buffer_rsrc_t r, unsigned o
 }
 __device__ __forceinline__ void s2n_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, off, 0, 0);
-}
-__device__ __forceinline__ unsigned s2n_bf16x2(float lo, float hi) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-// exact three-way split of four fp32 values (the same arithmetic as da_split3 in conv3d_mfma.hip)
-__device__ __forceinline__ void s2n_split3(const float4 v, uint2& h, uint2& m, uint2& l) {
-    h = make_uint2(s2n_bf16x2(v.x, v.y), s2n_bf16x2(v.z, v.w));
-    const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xFFFF0000u);
-    const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xFFFF0000u);
-    m = make_uint2(s2n_bf16x2(rx, ry), s2n_bf16x2(rz, rw));
-    const float sx = rx - __uint_as_float(m.x << 16), sy = ry - __uint_as_float(m.x & 0xFFFF0000u);
-    const float sz = rz - __uint_as_float(m.y << 16), sw = rw - __uint_as_float(m.y & 0xFFFF0000u);
-    l = make_uint2(s2n_bf16x2(sx, sy), s2n_bf16x2(sz, sw));
 }
 __device__ __forceinline__ float s2n_qx1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }   // lane ^ 1
 __device__ __forceinline__ float s2n_qx2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }   // lane ^ 2
@@ -89,8 +74,16 @@ __device__ __forceinline__ int s2n_xcd_remap(int bid, int nwg) {        // conse
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + loc;
 }
-// products of a split multiply, smallest first: (a plane, b plane) = (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
-#define S2N_PLANE_PAIRS constexpr int kPA[6] = {0, 2, 1, 0, 1, 0}, kPB[6] = {2, 0, 1, 1, 0, 0}
+// products of a split multiply, small terms first: (a plane, b plane) = (h,l) (l,h) (h,h)
+#define S2N_PLANE_PAIRS constexpr int kPA[3] = {0, 1, 0}, kPB[3] = {1, 0, 0}
+constexpr int NPLN = 2;                                         // operand planes (h, l)
+// largest |w| of a whole weight tensor (n floats, n % 4 == 0, 16-byte aligned), by one 256-thread workgroup; `red` = 4 floats of LDS
+__device__ __forceinline__ float s2n_tensor_absmax(const float* __restrict__ w, int n, float* red) {
+    float m = 0.f;
+#pragma unroll 4
+    for (int q = threadIdx.x; q < n / 4; q += 256) m = da_absmax4(m, reinterpret_cast<const float4*>(w)[q]);
+    return da_block_max4(m, red, (int)threadIdx.x >> 6, (int)threadIdx.x & 63);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // halo staging shared by forward and weight gradient: 5 x 9 x 33 voxels x 8 channels (two 16-byte quads per voxel), 12 iterations
@@ -121,15 +114,21 @@ struct HaloMap {
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && hz != 0xFFFF;
         return inb ? (unsigned)((((z * H + y) * W + x) * Cs + choff + c4 * 4) * 4) : 0xFFFFFFFFu;
     }
-    __device__ __forceinline__ void write(unsigned char* lds, const float4* pre) const {
+    __device__ __forceinline__ void write(unsigned char* lds, const float4* pre, const float scale) const {
 #pragma unroll
         for (int it = 0; it < HALO_NIT; ++it) {
             if (ldsq[it] >= 0) {
-                uint2 h, m, l; s2n_split3(pre[it], h, m, l);
+                uint2 h, l; da_split2(pre[it], scale, h, l);
                 uint2* p = reinterpret_cast<uint2*>(lds) + ldsq[it];
-                p[0] = h; p[PLANE_B / 8] = m; p[2 * (PLANE_B / 8)] = l;
+                p[0] = h; p[PLANE_B / 8] = l;
             }
         }
+    }
+    __device__ __forceinline__ float absmax(const float4* pre) const {      // (quads past the tile were loaded out of range: zeros)
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < HALO_NIT; ++it) m = da_absmax4(m, pre[it]);
+        return m;
     }
 };
 
@@ -137,27 +136,38 @@ struct HaloMap {
 // forward
 // ------------------------------------------------------------------------------------------------------------------------------
 struct FwdP {
-    const float* in; const unsigned char* wp; const float* bias; float* out;
+    const float* in; const unsigned char* wp; const int* wexp; const float* bias; float* out;
     int N, D, H, W, Cin, Cout, Do, Ho, Wo, ntz, nty, ntx, nchunks, NT;
     float slope;
 };
 
-// packed B operand of the forward: [chunk][step][N-tile][plane][lane][8 bf16]; lane (g, j): tap 4 step + g, cin chunk * 8 + e, cout 16 nt + j
-__global__ void s2n_pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int NT, long long total) {
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
-        long long rest = idx >> 9;
-        const long long blk = rest;
-        const int nt = (int)(rest % NT); rest /= NT;
-        const int s = (int)(rest % NSTEPS); const int ch = (int)(rest / NSTEPS);
-        const int g = lane >> 4, j = lane & 15;
-        const int tap = 4 * s + g, ci = ch * 8 + e, co = nt * 16 + j;
-        float v = 0.f;
-        if (tap < 27 && co < Cout && ci < Cin) v = w[((size_t)tap * Cin + ci) * Cout + co];
-        const __bf16 bh = (__bf16)v; const float r1 = v - (float)bh;
-        const __bf16 bm = (__bf16)r1; const float r2 = r1 - (float)bm;
-        unsigned short* o = wp + blk * 1536 + lane * 8 + e;
-        o[0] = __builtin_bit_cast(unsigned short, bh); o[512] = __builtin_bit_cast(unsigned short, bm); o[1024] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+// packed B operand of the forward: [chunk][step][N-tile][plane][lane][8 fp16]; lane (g, j): tap 4 step + g, cin chunk * 8 + e, cout 16 nt + j.
+// Grid (chunks, PY): every workgroup of a chunk finds the chunk's largest |w| (its scale exponent goes to wexp[chunk]) and packs its share.
+__global__ void __launch_bounds__(256) s2n_pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout, int NT) {
+    __shared__ float red[4];
+    const int ch = blockIdx.x;
+    float m = 0.f;
+    const int qc = Cout / 4, nq = 27 * 8 * qc;                  // runs of Cout consecutive couts per (tap, ci); Cout % 32 == 0
+#pragma unroll 4
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const int r = q / qc, c4 = q - r * qc;
+        m = da_absmax4(m, *reinterpret_cast<const float4*>(w + ((size_t)(r >> 3) * Cin + ch * 8 + (r & 7)) * Cout + c4 * 4));
+    }
+    const int ew = da_scale_exp(da_block_max4(m, red, (int)threadIdx.x >> 6, (int)threadIdx.x & 63));
+    if (blockIdx.y == 0 && threadIdx.x == 0) wexp[ch] = ew;
+    const float sc = da_pow2(ew);
+    const int units = NSTEPS * NT * 64;
+    for (int u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+        const int lane = u & 63, nt = (u >> 6) % NT, st = (u >> 6) / NT;
+        const int tap = 4 * st + (lane >> 4), co = nt * 16 + (lane & 15);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (tap < 27 && co < Cout) ? w[((size_t)tap * Cin + ch * 8 + e) * Cout + co] : 0.f;
+        uint2 h0, l0, h1, l1;
+        da_split2(make_float4(v[0], v[1], v[2], v[3]), sc, h0, l0);
+        da_split2(make_float4(v[4], v[5], v[6], v[7]), sc, h1, l1);
+        uint4* o = reinterpret_cast<uint4*>(wp + ((size_t)((ch * NSTEPS + st) * NT + nt) * NPLN) * 512) + lane;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -176,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) s2n_fwd_kernel(FwdP p) {
     const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
     const long long sample = (long long)p.D * p.H * p.W * p.Cin;
     const __amdgpu_buffer_rsrc_t rs = s2n_rsrc(p.in + (long long)n * sample, (unsigned)(sample * sizeof(float)));
-    const __amdgpu_buffer_rsrc_t rsw = s2n_rsrc(p.wp, (unsigned)((size_t)p.nchunks * NSTEPS * p.NT * 3072));
+    const __amdgpu_buffer_rsrc_t rsw = s2n_rsrc(p.wp, (unsigned)((size_t)p.nchunks * NSTEPS * p.NT * NPLN * 1024));
     HaloMap hm; hm.init();
     float4 pre[HALO_NIT];
     auto issue = [&](int ch) {
@@ -193,59 +203,82 @@ __global__ void __launch_bounds__(256, 2) s2n_fwd_kernel(FwdP p) {
         aoff[s] = ((dz * HY + dy) * XS + xp) * 16;
     }
     const int abase = ((2 * zi * HY) * XS + i) * 16;
-    auto wb = [&](int ch, int s, int pl) -> bf16x8 {
-        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((ch * NSTEPS + s) * p.NT + nt) * 3 + pl) * 1024), 0));
+    auto wb = [&](int ch, int s, int pl) -> f16x8 {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((ch * NSTEPS + s) * p.NT + nt) * NPLN + pl) * 1024), 0));
     };
-    auto ld = [&](int off) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lds + off); };
+    auto ld = [&](int off) -> f16x8 { return *reinterpret_cast<const f16x8*>(lds + off); };
+    // scale bookkeeping (wave-uniform; conv3d_mfma.hip "SP"): the accumulators hold (true sums) x 2^Eacc, chunk ch was staged at 2^(E - wexp[ch]),
+    // E of a later chunk is capped at 40 above the smallest E so far
+    float* smax = reinterpret_cast<float*>(lds + NPLN * PLANE_B);
+    int Eacc = 0, Emin = 0;
+    auto stage = [&](int ch) -> int {                            // publish the tile's largest magnitude, barrier, split + write; returns the chunk's E
+        const float m = da_block_max4(hm.absmax(pre), smax, wave, lane);
+        const int ew = p.wexp[ch];
+        int E = da_scale_exp(m) + ew;
+        if (ch != 0) E = min(E, Emin + 40);
+        Emin = (ch == 0) ? E : min(Emin, E);
+        hm.write(lds, pre, da_pow2(E - ew));
+        return E;
+    };
 
     S2N_PLANE_PAIRS;
     f32x4 acc[TY];
 #pragma unroll
     for (int r = 0; r < TY; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     issue(0);
-    hm.write(lds, pre);
+    int Ecur = stage(0);
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue(ch + 1);                                 // next chunk's loads fly under this chunk's MFMAs
-        bf16x8 B[3], Bn[3], A[TY][3], An[TY][3];
+        {
+            const float f = da_pow2(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) B[pl] = wb(ch, 0, pl);
+            for (int r = 0; r < TY; ++r) acc[r] = acc[r] * f;
+            Eacc = Ecur;
+        }
+        f16x8 B[NPLN], Bn[NPLN], A[TY][NPLN], An[TY][NPLN];
+#pragma unroll
+        for (int pl = 0; pl < NPLN; ++pl) B[pl] = wb(ch, 0, pl);
 #pragma unroll
         for (int r = 0; r < TY; ++r)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) A[r][pl] = ld(pl * PLANE_B + abase + aoff[0] + r * (2 * XS * 16));
+            for (int pl = 0; pl < NPLN; ++pl) A[r][pl] = ld(pl * PLANE_B + abase + aoff[0] + r * (2 * XS * 16));
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
             if (s + 1 < NSTEPS) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Bn[pl] = wb(ch, s + 1, pl);
+                for (int pl = 0; pl < NPLN; ++pl) Bn[pl] = wb(ch, s + 1, pl);
 #pragma unroll
                 for (int r = 0; r < TY; ++r)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) An[r][pl] = ld(pl * PLANE_B + abase + aoff[s + 1] + r * (2 * XS * 16));
+                    for (int pl = 0; pl < NPLN; ++pl) An[r][pl] = ld(pl * PLANE_B + abase + aoff[s + 1] + r * (2 * XS * 16));
             }
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                 for (int r = 0; r < TY; ++r)
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r][kPA[pr]], B[kPB[pr]], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r][kPA[pr]], B[kPB[pr]], acc[r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < NSTEPS) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) B[pl] = Bn[pl];
+                for (int pl = 0; pl < NPLN; ++pl) B[pl] = Bn[pl];
 #pragma unroll
                 for (int r = 0; r < TY; ++r)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) A[r][pl] = An[r][pl];
+                    for (int pl = 0; pl < NPLN; ++pl) A[r][pl] = An[r][pl];
             }
         }
         if (more) {
-            __syncthreads();
-            hm.write(lds, pre);
+            Ecur = stage(ch + 1);                                // (its barrier: every wave is done reading this chunk's tile)
             __syncthreads();
         }
+    }
+    {
+        const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));      // back to the true unit
+#pragma unroll
+        for (int r = 0; r < TY; ++r) acc[r] = acc[r] * inv1 * inv2;
     }
     // epilogue: lane -> voxel x0 + 4 g + q, couts 16 nt + 4 a4 .. + 3
     const int co0 = nt * 16 + 4 * a4;
@@ -272,7 +305,7 @@ constexpr int GZ = TZ + 1, GY = TY + 1, GX = TX + 1;           // dY halo: 3 x 5
 constexpr int GV = GZ * GY * GX;                                // 255
 
 struct DgP {
-    const float* dy; const unsigned char* wp; float* dx;
+    const float* dy; const unsigned char* wp; const int* wexp; float* dx;
     int N, D, H, W, Cin, Cout, Do, Ho, Wo, ntz, nty, ntx, KS, NTN;   // KS = Cout / 32 K-steps per tap, NTN = Cin / 16 N-tiles
 };
 
@@ -288,26 +321,33 @@ __host__ __device__ inline void s2n_class_tap(int c, int k, int& tap, int& oz, i
 }
 __host__ __device__ inline int s2n_class_base(int c) { int b = 0; for (int k = 0; k < c; ++k) b += s2n_class_taps(k); return b; }    // in taps
 
-// packed B operand of the data gradient: [class-major step q = (class base + k) * KS + ks][N-tile][plane][lane][8 bf16];
-// lane (g, j): K index = cout ks * 32 + g * 8 + e, N index = cin 16 nt + j
-__global__ void s2n_pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int KS, int NTN, long long total) {
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
-        long long rest = idx >> 9;
-        const long long blk = rest;
-        const int nt = (int)(rest % NTN); rest /= NTN;
-        const int ks = (int)(rest % KS); const int tq = (int)(rest / KS);        // tq = class base + k, 0 .. 26
+// packed B operand of the data gradient: [class-major step q = (class base + k) * KS + ks][N-tile][plane][lane][8 fp16];
+// lane (g, j): K index = cout ks * 32 + g * 8 + e, N index = cin 16 nt + j.  ONE scale for the whole tensor (every tap and channel of a
+// parity class accumulates into the same sums): each workgroup finds it (the tensor is a few hundred KB, L2-resident), block 0 stores its
+// exponent in wexp[0].
+__global__ void __launch_bounds__(256) s2n_pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout, int KS, int NTN) {
+    __shared__ float red[4];
+    const int ew = da_scale_exp(s2n_tensor_absmax(w, 27 * Cin * Cout, red));
+    if (blockIdx.x == 0 && threadIdx.x == 0) wexp[0] = ew;
+    const float sc = da_pow2(ew);
+    const int units = 27 * KS * NTN * 64;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+        const int lane = u & 63, blk = u >> 6;
+        const int nt = blk % NTN, ks = (blk / NTN) % KS, tq = blk / (NTN * KS);      // tq = class base + k, 0 .. 26
         int c = 0, base = 0;
         while (base + s2n_class_taps(c) <= tq) { base += s2n_class_taps(c); ++c; }
         int tap, oz, oy, ox; s2n_class_tap(c, tq - base, tap, oz, oy, ox);
         const int g = lane >> 4, j = lane & 15;
-        const int co = ks * 32 + g * 8 + e, ci = nt * 16 + j;
-        float v = 0.f;
-        if (co < Cout && ci < Cin) v = w[((size_t)tap * Cin + ci) * Cout + co];
-        const __bf16 bh = (__bf16)v; const float r1 = v - (float)bh;
-        const __bf16 bm = (__bf16)r1; const float r2 = r1 - (float)bm;
-        unsigned short* o = wp + blk * 1536 + lane * 8 + e;
-        o[0] = __builtin_bit_cast(unsigned short, bh); o[512] = __builtin_bit_cast(unsigned short, bm); o[1024] = __builtin_bit_cast(unsigned short, (__bf16)r2);
+        const int co0 = ks * 32 + g * 8, ci = nt * 16 + j;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (ci < Cin && co0 + 7 < Cout) {                         // 8 consecutive couts
+            const float* q = w + ((size_t)tap * Cin + ci) * Cout + co0;
+            v0 = *reinterpret_cast<const float4*>(q); v1 = *reinterpret_cast<const float4*>(q + 4);
+        }
+        uint2 h0, l0, h1, l1;
+        da_split2(v0, sc, h0, l0); da_split2(v1, sc, h1, l1);
+        uint4* o = reinterpret_cast<uint4*>(wp + (size_t)blk * NPLN * 512) + lane;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -324,43 +364,52 @@ __global__ void __launch_bounds__(256, 2) s2n_dgrad_kernel(DgP p) {
     const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
     const int nch = p.Cout / 8;                                  // 8-channel chunks of dY: LDS [plane][chunk][voxel][8]
     const int planeB = nch * GV * 16;
-    // ---- stage the dY halo tile (all channels), split into three planes
+    // ---- stage the dY halo tile (all channels) at the tile's own scale, split into two planes.  All of it is parked in registers first
+    // (<= 16 quads per thread for Cout <= 64: the accumulators are not live yet) because the scale needs the tile's largest magnitude.
+    int E = 0;
     {
         const long long ysample = (long long)p.Do * p.Ho * p.Wo * p.Cout;
         const __amdgpu_buffer_rsrc_t ry = s2n_rsrc(p.dy + (long long)n * ysample, (unsigned)(ysample * sizeof(float)));
         const int qpv = p.Cout / 4;                              // quads per voxel
         const int total = GV * qpv;
-        for (int base = 0; base < total; base += 256 * 4) {
-            float4 v[4]; int li[4];
+        constexpr int MAXU = 16;                                 // GV * 16 quads / 256 threads
+        float4 v[MAXU]; int li[MAXU];
+        float m = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 256 + (int)threadIdx.x;
-                const int c4 = idx % qpv, hv = idx / qpv;
-                const int hx = hv % GX, t2 = hv / GX, hy = t2 % GY, hz = t2 / GY;
-                const int z = z0 + hz, y = y0 + hy, x = x0 + hx;
-                const bool inb = idx < total && z < p.Do && y < p.Ho && x < p.Wo;
-                v[u] = s2n_load4(ry, inb ? (unsigned)((((z * p.Ho + y) * p.Wo + x) * p.Cout + c4 * 4) * 4) : 0xFFFFFFFFu);
-                li[u] = idx < total ? (((c4 >> 1) * GV + hv) * 2 + (c4 & 1)) : -1;
-            }
+        for (int u = 0; u < MAXU; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;
+            const int c4 = idx % qpv, hv = idx / qpv;
+            const int hx = hv % GX, t2 = hv / GX, hy = t2 % GY, hz = t2 / GY;
+            const int z = z0 + hz, y = y0 + hy, x = x0 + hx;
+            const bool inb = idx < total && z < p.Do && y < p.Ho && x < p.Wo;
+            v[u] = s2n_load4(ry, inb ? (unsigned)((((z * p.Ho + y) * p.Wo + x) * p.Cout + c4 * 4) * 4) : 0xFFFFFFFFu);
+            li[u] = idx < total ? (((c4 >> 1) * GV + hv) * 2 + (c4 & 1)) : -1;
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (li[u] >= 0) {
-                    uint2 h, m, l; s2n_split3(v[u], h, m, l);
-                    uint2* o = reinterpret_cast<uint2*>(lds) + li[u];
-                    o[0] = h; o[planeB / 8] = m; o[2 * (planeB / 8)] = l;
-                }
+        for (int u = 0; u < MAXU; ++u) m = da_absmax4(m, v[u]);
+        float* smax = reinterpret_cast<float*>(lds + NPLN * planeB);
+        const int ey = da_scale_exp(da_block_max4(m, smax, wave, lane));
+        E = ey + p.wexp[0];
+        const float sy = da_pow2(ey);
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            if (li[u] >= 0) {
+                uint2 h, l; da_split2(v[u], sy, h, l);
+                uint2* o = reinterpret_cast<uint2*>(lds) + li[u];
+                o[0] = h; o[planeB / 8] = l;
             }
         }
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rsw = s2n_rsrc(p.wp, (unsigned)((size_t)27 * p.KS * NTN * 3072));
+    const float inv1 = da_pow2(-(E / 2)), inv2 = da_pow2(-(E - E / 2));      // the sums back to the true unit (two exact factors)
+    const __amdgpu_buffer_rsrc_t rsw = s2n_rsrc(p.wp, (unsigned)((size_t)27 * p.KS * NTN * NPLN * 1024));
     const long long xsample = (long long)p.D * p.H * p.W * p.Cin;
     const __amdgpu_buffer_rsrc_t rx = s2n_rsrc(p.dx + (long long)n * xsample, (unsigned)(xsample * sizeof(float)));
     // class groups per wave role (rotated by workgroup so that the 8-tap class does not always sit on the same SIMD)
     const int role = (wave + blockIdx.x) & 3;
     const int ncls = role == 0 ? 1 : (role == 1 ? 3 : 2);
     auto cls_of = [&](int k) -> int { return role == 0 ? 7 : (role == 1 ? (k == 0 ? 6 : (k == 1 ? 4 : 0)) : (role == 2 ? (k == 0 ? 5 : 2) : (k == 0 ? 3 : 1))); };
-    auto ld = [&](int off) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lds + off); };
+    auto ld = [&](int off) -> f16x8 { return *reinterpret_cast<const f16x8*>(lds + off); };
     S2N_PLANE_PAIRS;
 #pragma unroll 1
     for (int kc = 0; kc < ncls; ++kc) {
@@ -378,27 +427,27 @@ __global__ void __launch_bounds__(256, 2) s2n_dgrad_kernel(DgP p) {
 #pragma unroll 1
             for (int ks = 0; ks < p.KS; ++ks) {
                 const int step = (cbase + k) * p.KS + ks;
-                bf16x8 B[NTN][3];
+                f16x8 B[NTN][NPLN];
 #pragma unroll
                 for (int nn = 0; nn < NTN; ++nn)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        B[nn][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((step * NTN + nn) * 3 + pl) * 1024), 0));
+                    for (int pl = 0; pl < NPLN; ++pl)
+                        B[nn][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)(((step * NTN + nn) * NPLN + pl) * 1024), 0));
                 const int abase = (((ks * 4 + g) * GV) + (oz * GY + oy) * GX + ox + i) * 16;
 #pragma unroll
                 for (int mz = 0; mz < TZ; ++mz) {
-                    bf16x8 A[TY][3];
+                    f16x8 A[TY][NPLN];
 #pragma unroll
                     for (int my = 0; my < TY; ++my)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) A[my][pl] = ld(pl * planeB + abase + ((mz * GY + my) * GX) * 16);
+                        for (int pl = 0; pl < NPLN; ++pl) A[my][pl] = ld(pl * planeB + abase + ((mz * GY + my) * GX) * 16);
 #pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
+                    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                         for (int nn = 0; nn < NTN; ++nn)
 #pragma unroll
                             for (int my = 0; my < TY; ++my)
-                                acc[mz * TY + my][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[my][kPA[pr]], B[nn][kPB[pr]], acc[mz * TY + my][nn], 0, 0, 0);
+                                acc[mz * TY + my][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[my][kPA[pr]], B[nn][kPB[pr]], acc[mz * TY + my][nn], 0, 0, 0);
                 }
             }
         }
@@ -413,7 +462,7 @@ __global__ void __launch_bounds__(256, 2) s2n_dgrad_kernel(DgP p) {
                 const bool ok = zin < p.D && yin < p.H && xin < p.W;
 #pragma unroll
                 for (int nn = 0; nn < NTN; ++nn) {
-                    const f32x4 v = s2n_quad_transpose(acc[mz * TY + my][nn], q);
+                    const f32x4 v = s2n_quad_transpose(acc[mz * TY + my][nn] * inv1 * inv2, q);
                     s2n_store4(rx, ok ? (unsigned)((((zin * p.H + yin) * p.W + xin) * p.Cin + nn * 16 + 4 * a4) * 4) : 0xFFFFFFFFu, v);
                 }
             }
@@ -434,7 +483,7 @@ constexpr int YPLANE_B = YV * 32 * 2;                           // bytes per dY 
 
 __global__ void __launch_bounds__(256, 1) s2n_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* ldsY = lds + 3 * PLANE_B;
+    unsigned char* ldsY = lds + NPLN * PLANE_B;
     typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -443,10 +492,10 @@ __global__ void __launch_bounds__(256, 1) s2n_wgrad_kernel(WgP p) {
     const int zi = g >> 1;                                       // z plane of the tile this lane group's 8 voxels belong to
     // transposing reads (ds_read_b64_tr_b16): inside a 16-lane group lane (vq, q) supplies the address of (voxel vq of 4, 4-channel quad q)
     // and receives 4 voxels of channel 4 q' + e ... i.e. fragment row i = (tap half i >> 3, cin i & 7) for x, cout i for dY.
-    auto tr8 = [&](const unsigned char* a, int step_bytes) -> bf16x8 {
+    auto tr8 = [&](const unsigned char* a, int step_bytes) -> f16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step_bytes));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // x fragment of tap-pair slot s for this wave's output row: lane supplies voxel (z plane zi, row, x2 = 8 (g & 1) + vq [+ 4]) of tap
     // 2 s + (q >> 1), channel quad q & 1
@@ -459,17 +508,17 @@ __global__ void __launch_bounds__(256, 1) s2n_wgrad_kernel(WgP p) {
         aoff[s] = ((((2 * zi + dz) * HY + 2 * wave + dy) * XS + xp + 8 * (g & 1) + vq) * 8 + (q & 1) * 4) * 2;
     }
     const int yoff = (((zi * TY + wave) * TX + 8 * (g & 1) + vq) * 32 + q * 4) * 2;
-    struct F3 { bf16x8 p[3]; };
+    struct F3 { f16x8 p[NPLN]; };
     auto loadF = [&](int s) -> F3 {
         F3 f;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(lds + pl * PLANE_B + aoff[s], 4 * 8 * 2);
+        for (int pl = 0; pl < NPLN; ++pl) f.p[pl] = tr8(lds + pl * PLANE_B + aoff[s], 4 * 8 * 2);
         return f;
     };
     auto loadY = [&](int nn) -> F3 {
         F3 f;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(ldsY + pl * YPLANE_B + yoff + nn * 32, 4 * 32 * 2);
+        for (int pl = 0; pl < NPLN; ++pl) f.p[pl] = tr8(ldsY + pl * YPLANE_B + yoff + nn * 32, 4 * 32 * 2);
         return f;
     };
     f32x4 acc[WG_SLOTS][2];
@@ -500,13 +549,33 @@ __global__ void __launch_bounds__(256, 1) s2n_wgrad_kernel(WgP p) {
             preY[u] = s2n_load4(ry, inb ? (unsigned)((((z * p.Ho + y) * p.Wo + x) * p.Cout + co) * 4) : 0xFFFFFFFFu);
         }
     };
-    auto write_lds = [&]() {
-        hm.write(lds, preA);
+    // scale bookkeeping (wave-uniform; conv3d_mfma.hip, conv3_split_wgrad_kernel): the accumulators hold (true sums) x 2^Eacc; a tile is staged at
+    // E = x exponent + dY exponent, capped at 40 above the smallest E of this workgroup's walk so far
+    float* smax = reinterpret_cast<float*>(ldsY + NPLN * YPLANE_B);      // [2][4]
+    int Eacc = 0, Emin = 0, Enext = 0; bool first_tile = true;
+    auto write_lds = [&]() {                                     // (starts with the barrier that retires the tile in LDS)
+        float my = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) my = da_absmax4(my, preY[u]);
+        const float ma = da_wave_max_nonneg(hm.absmax(preA));
+        my = da_wave_max_nonneg(my);
+        if (lane == 0) { smax[wave] = ma; smax[4 + wave] = my; }
+        __syncthreads();
+        const float4 a4 = *reinterpret_cast<const float4*>(smax), y4 = *reinterpret_cast<const float4*>(smax + 4);
+        const int ea = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(a4.x, a4.y), fmaxf(a4.z, a4.w))))));
+        const int ey = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(y4.x, y4.y), fmaxf(y4.z, y4.w))))));
+        int E = ea + ey;
+        if (!first_tile) E = min(E, Emin + 40);
+        Emin = first_tile ? E : min(Emin, E);
+        first_tile = false;
+        Enext = E;
+        const float sy = da_pow2(ey);
+        hm.write(lds, preA, da_pow2(E - ey));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            uint2 h, m, l; s2n_split3(preY[u], h, m, l);
+            uint2 h, l; da_split2(preY[u], sy, h, l);
             uint2* o = reinterpret_cast<uint2*>(ldsY) + (yv0 + 32 * u) * 8 + yq;
-            o[0] = h; o[YPLANE_B / 8] = m; o[2 * (YPLANE_B / 8)] = l;
+            o[0] = h; o[YPLANE_B / 8] = l;
         }
     };
     S2N_PLANE_PAIRS;
@@ -518,24 +587,34 @@ __global__ void __launch_bounds__(256, 1) s2n_wgrad_kernel(WgP p) {
     for (int k = 0; k < cnt; ++k) {
         const bool more = k + 1 < cnt;
         if (more) issue(slab + (k + 1) * p.nslabs);              // next tile's global loads fly during this tile's MFMAs
+        {
+            const float f = da_pow2(Enext - Eacc);               // the running sums into this tile's unit (exact)
+#pragma unroll
+            for (int s = 0; s < WG_SLOTS; ++s) { acc[s][0] = acc[s][0] * f; acc[s][1] = acc[s][1] * f; }
+            Eacc = Enext;
+        }
         const F3 Y0 = loadY(0), Y1 = loadY(1);
         F3 F = loadF(0), Fn;
 #pragma unroll
         for (int s = 0; s < WG_SLOTS; ++s) {
             if (s + 1 < WG_SLOTS) Fn = loadF(s + 1);
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.p[kPA[pr]], Y0.p[kPB[pr]], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.p[kPA[pr]], Y1.p[kPB[pr]], acc[s][1], 0, 0, 0);
+            for (int pr = 0; pr < 3; ++pr) {
+                acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.p[kPA[pr]], Y0.p[kPB[pr]], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.p[kPA[pr]], Y1.p[kPB[pr]], acc[s][1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < WG_SLOTS) F = Fn;
         }
         if (more) {
-            __syncthreads();
             write_lds();
             __syncthreads();
         }
+    }
+    {
+        const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));      // back to the true unit
+#pragma unroll
+        for (int s = 0; s < WG_SLOTS; ++s) { acc[s][0] = acc[s][0] * inv1 * inv2; acc[s][1] = acc[s][1] * inv1 * inv2; }
     }
     // reduce the four waves' partial sums through LDS (2 rounds), then wave 0 writes this workgroup's partial dW
     __syncthreads();
@@ -607,12 +686,12 @@ bool da_conv3_s2n_supported(int Cin, int Cout, int N, int D, int H, int W) {
 
 size_t da_conv3_s2n_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
     const Plan q = s2n_plan(N, D, H, W);
-    const size_t pack_f = (size_t)(Cin / 8) * NSTEPS * (Cout / 16) * 3072;
-    const size_t pack_d = (size_t)27 * (Cout / 32) * (Cin / 16) * 3072;
+    const size_t pack_f = (size_t)(Cin / 8) * NSTEPS * (Cout / 16) * NPLN * 1024;
+    const size_t pack_d = (size_t)27 * (Cout / 32) * (Cin / 16) * NPLN * 1024;
     const size_t part = (size_t)s2n_wgrad_slabs(q.ntiles, Cin / 8, Cout / 32) * 27 * Cin * Cout * sizeof(float);
     size_t m = pack_f > pack_d ? pack_f : pack_d;
     if (part > m) m = part;
-    return da_align(m) + 256;
+    return da_align(m) + 256;        // (+ 256: the weight scale exponents in front of the packed operand)
 }
 
 int da_conv3_s2n_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
@@ -620,15 +699,14 @@ int da_conv3_s2n_fwd(const float* in, int Cin, const float* w_tio, const float* 
     if (ws_bytes < da_conv3_s2n_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     const Plan q = s2n_plan(N, D, H, W);
     FwdP p;
-    p.in = in; p.wp = (const unsigned char*)ws; p.bias = bias; p.out = out;
+    p.in = in; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.bias = bias; p.out = out;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Do = q.Do; p.Ho = q.Ho; p.Wo = q.Wo;
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.nchunks = Cin / 8; p.NT = Cout / 16; p.slope = slope;
-    const long long total = (long long)p.nchunks * NSTEPS * p.NT * 512;
-    hipLaunchKernelGGL(s2n_pack_fwd_kernel, dim3(da_grid(total, 256, 256)), dim3(256), 0, st, w_tio, (unsigned short*)ws, Cin, Cout, p.NT, total);
+    hipLaunchKernelGGL(s2n_pack_fwd_kernel, dim3(p.nchunks, 4), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.NT);
     DA_LAUNCH_CHECK();
     static bool attr = false;
-    if (!attr) { const int e = s2n_set_lds(s2n_fwd_kernel, 3 * PLANE_B); if (e) return e; attr = true; }
-    hipLaunchKernelGGL(s2n_fwd_kernel, dim3(q.ntiles, Cout / 32), dim3(256), 3 * PLANE_B, st, p);
+    if (!attr) { const int e = s2n_set_lds(s2n_fwd_kernel, NPLN * PLANE_B + 16); if (e) return e; attr = true; }
+    hipLaunchKernelGGL(s2n_fwd_kernel, dim3(q.ntiles, Cout / 32), dim3(256), NPLN * PLANE_B + 16, st, p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -638,19 +716,18 @@ int da_conv3_s2n_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, 
     if (ws_bytes < da_conv3_s2n_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     const Plan q = s2n_plan(N, D, H, W);
     DgP p;
-    p.dy = dy; p.wp = (const unsigned char*)ws; p.dx = dx;
+    p.dy = dy; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.dx = dx;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Do = q.Do; p.Ho = q.Ho; p.Wo = q.Wo;
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.KS = Cout / 32; p.NTN = Cin / 16;
-    const long long total = (long long)27 * p.KS * p.NTN * 512;
-    hipLaunchKernelGGL(s2n_pack_dgrad_kernel, dim3(da_grid(total, 256, 256)), dim3(256), 0, st, w_tio, (unsigned short*)ws, Cin, Cout, p.KS, p.NTN, total);
+    hipLaunchKernelGGL(s2n_pack_dgrad_kernel, dim3(da_grid((long long)27 * p.KS * p.NTN * 64, 256, 32)), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.KS, p.NTN);
     DA_LAUNCH_CHECK();
-    const size_t shm = (size_t)3 * (Cout / 8) * GV * 16;
+    const size_t shm = (size_t)NPLN * (Cout / 8) * GV * 16 + 16;
     static bool attr[3] = {false, false, false};
     int e = 0;
     switch (p.NTN) {
-        case 1: if (!attr[1]) { e = s2n_set_lds(s2n_dgrad_kernel<1>, 98304); attr[1] = true; } if (e) return e;
+        case 1: if (!attr[1]) { e = s2n_set_lds(s2n_dgrad_kernel<1>, 98304); if (e) return e; attr[1] = true; }
                 hipLaunchKernelGGL(s2n_dgrad_kernel<1>, dim3(q.ntiles), dim3(256), shm, st, p); break;
-        case 2: if (!attr[2]) { e = s2n_set_lds(s2n_dgrad_kernel<2>, 98304); attr[2] = true; } if (e) return e;
+        case 2: if (!attr[2]) { e = s2n_set_lds(s2n_dgrad_kernel<2>, 98304); if (e) return e; attr[2] = true; }
                 hipLaunchKernelGGL(s2n_dgrad_kernel<2>, dim3(q.ntiles), dim3(256), shm, st, p); break;
         default: return DA_ERR_UNSUPPORTED;
     }
@@ -670,7 +747,7 @@ int da_conv3_s2n_wgrad(const float* in, int Cin, const float* dy, float* dw_tio,
     p.nslabs = s2n_wgrad_slabs(q.ntiles, nchunks, ngroups); p.O = 27 * Cin * Cout;
     // every (chunk, group) workgroup of a slab writes its own (tap, cin chunk, cout group) block of the slab's partial: the blocks are
     // disjoint and together cover all O entries, so the partial needs no zero fill
-    const size_t shm = (size_t)3 * PLANE_B + 3 * YPLANE_B;
+    const size_t shm = (size_t)NPLN * PLANE_B + NPLN * YPLANE_B + 32;
     static bool attr = false;
     if (!attr) { const int e = s2n_set_lds(s2n_wgrad_kernel, shm); if (e) return e; attr = true; }
     hipLaunchKernelGGL(s2n_wgrad_kernel, dim3(p.nslabs, nchunks, ngroups), dim3(256), shm, st, p);

@@ -16,15 +16,16 @@
 //   wgrad     G[p][j] = sum_c S[c + p + j - 1]^T dY[2 c + p] (64 small GEMMs over COARSE voxels, one workgroup column per class p), then
 //             dW[t] = sum of the 8 (p, j) pairs that contain tap t, folded into the fixed-order double-precision partial reduction.
 // The weight sums are formed in double and rounded to fp32 once (one extra rounding per weight, the size of one fp32 product rounding),
-// then split exactly into three bf16 planes like every other split-mode operand.
+// then scaled and split into two fp16 planes like every other split-mode operand (split_f16.h; conv3d_mfma.hip "SP": per-tile power-of-two
+// scales for activations / gradients, per-chunk scales for the summed weights, accumulators rescaled by exact factors between chunks).
 #include "common.h"
 #include "conv3d_internal.h"
+#include "split_f16.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CTZ = 2, CTY = 4, CTX = 16;                       // coarse tile
 constexpr int SZ = CTZ + 2, SY = CTY + 2, SX = CTX + 2;         // coarse halo of the forward / weight gradient: 4 x 6 x 18
@@ -40,26 +41,6 @@ __device__ __forceinline__ float4 up_load4(__amdgpu_buffer_rsrc_t r, unsigned of
 }
 __device__ __forceinline__ void up_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, off, 0, 0);
-}
-__device__ __forceinline__ unsigned up_bf16x2(float lo, float hi) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ void up_split3(const float4 v, uint2& h, uint2& m, uint2& l) {      // exact: v = h + m + l (see conv3d_mfma.hip, da_split3)
-    h = make_uint2(up_bf16x2(v.x, v.y), up_bf16x2(v.z, v.w));
-    const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xFFFF0000u);
-    const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xFFFF0000u);
-    m = make_uint2(up_bf16x2(rx, ry), up_bf16x2(rz, rw));
-    const float sx = rx - __uint_as_float(m.x << 16), sy = ry - __uint_as_float(m.x & 0xFFFF0000u);
-    const float sz = rz - __uint_as_float(m.y << 16), sw = rw - __uint_as_float(m.y & 0xFFFF0000u);
-    l = make_uint2(up_bf16x2(sx, sy), up_bf16x2(sz, sw));
-}
-__device__ __forceinline__ void up_split3_scalar(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const __bf16 bh = (__bf16)v; const float r1 = v - (float)bh;
-    const __bf16 bm = (__bf16)r1; const float r2 = r1 - (float)bm;
-    h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, (__bf16)r2);
 }
 __device__ __forceinline__ float up_qx1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float up_qx2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
@@ -85,7 +66,8 @@ __device__ __forceinline__ int up_xcd_remap(int bid, int nwg) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + loc;
 }
-#define UP_PLANE_PAIRS constexpr int kPA[6] = {0, 2, 1, 0, 1, 0}, kPB[6] = {2, 0, 1, 1, 0, 0}      // split products, smallest first
+#define UP_PLANE_PAIRS constexpr int kPA[3] = {0, 1, 0}, kPB[3] = {1, 0, 0}      // split products, small terms first: (h,l) (l,h) (h,h)
+constexpr int NPLN = 2;                                         // operand planes (h, l)
 
 // per axis: original taps that feed coarse tap j of parity p (forward / weight gradient)
 __host__ __device__ inline int up_taps_of(int p, int j, int* t) {
@@ -118,15 +100,21 @@ struct SMap {
         const bool inb = v >= 0 && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         return inb ? (unsigned)((((z * H + y) * W + x) * Cs + choff + c4 * 4) * 4) : 0xFFFFFFFFu;
     }
-    __device__ __forceinline__ void write(unsigned char* lds, const float4* pre) const {
+    __device__ __forceinline__ void write(unsigned char* lds, const float4* pre, const float scale) const {
 #pragma unroll
         for (int it = 0; it < S_NIT; ++it) {
             if (hv[it] >= 0) {
-                uint2 h, m, l; up_split3(pre[it], h, m, l);
+                uint2 h, l; da_split2(pre[it], scale, h, l);
                 uint2* o = reinterpret_cast<uint2*>(lds) + hv[it] * 2 + c4;
-                o[0] = h; o[SPLANE_B / 8] = m; o[2 * (SPLANE_B / 8)] = l;
+                o[0] = h; o[SPLANE_B / 8] = l;
             }
         }
+    }
+    __device__ __forceinline__ float absmax(const float4* pre) const {      // (quads past the tile were loaded out of range: zeros)
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < S_NIT; ++it) m = da_absmax4(m, pre[it]);
+        return m;
     }
 };
 
@@ -135,32 +123,47 @@ struct SMap {
 // ------------------------------------------------------------------------------------------------------------------------------
 struct FwdP {
     const float* s1; const float* s2; int C1, C2;
-    const unsigned char* wp; const float* bias; float* out;
+    const unsigned char* wp; const int* wexp; const float* bias; float* out;
     int N, Dc, Hc, Wc, Cout, ntz, nty, ntx, nchunks, NTall;
     float slope;
 };
 
-// packed B operand: [chunk][class][step 2][N-tile][plane][lane][8]; lane (g, n): coarse tap 4 step + g, cin chunk * 8 + e, cout 16 nt + n
-__global__ void up_pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int NT, long long total) {
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
-        long long rest = idx >> 9;
-        const long long blk = rest;
-        const int nt = (int)(rest % NT); rest /= NT;
-        const int s = (int)(rest & 1); rest >>= 1;
-        const int cls = (int)(rest & 7); const int ch = (int)(rest >> 3);
+// Scale exponent of a chunk of SUMMED weights from the largest original |w| of the chunk: a sum has at most 8 terms, so 8 max|w| bounds it
+// (the three bits of headroom this costs come out of the 18 spare binades of the two-term split).
+__device__ __forceinline__ int up_sum_exp(float maxw) { return da_scale_exp(maxw * 8.f); }
+
+// packed B operand: [chunk][class][step 2][N-tile][plane][lane][8]; lane (g, n): coarse tap 4 step + g, cin chunk * 8 + e, cout 16 nt + n.
+// Grid (chunks, PY): every workgroup of a chunk finds the chunk's largest |w| (scale exponent -> wexp[chunk]) and packs its share.
+__global__ void __launch_bounds__(256) up_pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout, int NT) {
+    __shared__ float red[4];
+    const int ch = blockIdx.x;
+    float m = 0.f;
+    for (int idx = threadIdx.x; idx < 27 * 8 * Cout; idx += 256) { const int co = idx % Cout, r = idx / Cout; m = fmaxf(m, fabsf(w[((size_t)(r >> 3) * Cin + ch * 8 + (r & 7)) * Cout + co])); }
+    const int ew = up_sum_exp(da_block_max4(m, red, (int)threadIdx.x >> 6, (int)threadIdx.x & 63));
+    if (blockIdx.y == 0 && threadIdx.x == 0) wexp[ch] = ew;
+    const float sc = da_pow2(ew);
+    const int units = 16 * NT * 64;                              // (class, step, N-tile, lane)
+    for (int u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+        const int lane = u & 63, nt = (u >> 6) % NT, cs = (u >> 6) / NT, s = cs & 1, cls = cs >> 1;
         const int g = lane >> 4, n = lane & 15;
-        const int jt = 4 * s + g, ci = ch * 8 + e, co = nt * 16 + n;
-        double acc = 0.0;
-        if (ci < Cin && co < Cout) {
-            int tz[2], ty[2], tx[2];
-            const int nz = up_taps_of((cls >> 2) & 1, (jt >> 2) & 1, tz), ny = up_taps_of((cls >> 1) & 1, (jt >> 1) & 1, ty), nx = up_taps_of(cls & 1, jt & 1, tx);
-            for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
-                acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
+        const int jt = 4 * s + g, co = nt * 16 + n;
+        int tz[2], ty[2], tx[2];
+        const int nz = up_taps_of((cls >> 2) & 1, (jt >> 2) & 1, tz), ny = up_taps_of((cls >> 1) & 1, (jt >> 1) & 1, ty), nx = up_taps_of(cls & 1, jt & 1, tx);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = ch * 8 + e;
+            double acc = 0.0;
+            if (ci < Cin && co < Cout)
+                for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
+                    acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
+            v[e] = (float)acc;
         }
-        unsigned short h, m, l; up_split3_scalar((float)acc, h, m, l);
-        unsigned short* o = wp + blk * 1536 + lane * 8 + e;
-        o[0] = h; o[512] = m; o[1024] = l;
+        uint2 h0, l0, h1, l1;
+        da_split2(make_float4(v[0], v[1], v[2], v[3]), sc, h0, l0);
+        da_split2(make_float4(v[4], v[5], v[6], v[7]), sc, h1, l1);
+        uint4* o = reinterpret_cast<uint4*>(wp + ((size_t)(((ch * 8 + cls) * 2 + s) * NT + nt) * NPLN) * 512) + lane;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
     const long long vox = (long long)p.Dc * p.Hc * p.Wc;
     const __amdgpu_buffer_rsrc_t r1 = up_rsrc(p.s1 + (long long)n * vox * p.C1, (unsigned)(vox * p.C1 * sizeof(float)));
     const __amdgpu_buffer_rsrc_t r2 = up_rsrc(p.C2 ? p.s2 + (long long)n * vox * p.C2 : p.s1, (unsigned)(p.C2 ? vox * p.C2 * sizeof(float) : 0));
-    const __amdgpu_buffer_rsrc_t rsw = up_rsrc(p.wp, (unsigned)((size_t)p.nchunks * 16 * p.NTall * 3072));
+    const __amdgpu_buffer_rsrc_t rsw = up_rsrc(p.wp, (unsigned)((size_t)p.nchunks * 16 * p.NTall * NPLN * 1024));
     SMap sm; sm.init();
     float4 pre[S_NIT];
     auto issue = [&](int ch) {
@@ -189,7 +192,19 @@ __global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
         for (int it = 0; it < S_NIT; ++it)
             pre[it] = up_load4(first ? r1 : r2, sm.offset(it, z0 - 1, y0 - 1, x0 - 1, p.Dc, p.Hc, p.Wc, first ? p.C1 : p.C2, first ? cb : cb - p.C1));
     };
-    auto ld = [&](int off) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lds + off); };
+    auto ld = [&](int off) -> f16x8 { return *reinterpret_cast<const f16x8*>(lds + off); };
+    // scale bookkeeping (wave-uniform; conv3d_mfma.hip "SP")
+    float* smax = reinterpret_cast<float*>(lds + NPLN * SPLANE_B);
+    int Eacc = 0, Emin = 0;
+    auto stage = [&](int ch) -> int {                            // publish the tile's largest magnitude, barrier, split + write; returns the chunk's E
+        const float m = da_block_max4(sm.absmax(pre), smax, wave, lane);
+        const int ew = p.wexp[ch];
+        int E = da_scale_exp(m) + ew;
+        if (ch != 0) E = min(E, Emin + 40);
+        Emin = (ch == 0) ? E : min(Emin, E);
+        sm.write(lds, pre, da_pow2(E - ew));
+        return E;
+    };
     UP_PLANE_PAIRS;
     f32x4 acc[2][CTZ * CTY][NT];
 #pragma unroll
@@ -199,12 +214,22 @@ __global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) acc[c][m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
     issue(0);
-    sm.write(lds, pre);
+    int Ecur = stage(0);
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue(ch + 1);
+        {
+            const float f = da_pow2(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int m = 0; m < CTZ * CTY; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) acc[c][m][nn] = acc[c][m][nn] * f;
+            Eacc = Ecur;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int cls = 2 * wave + c;
@@ -213,36 +238,36 @@ __global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
             for (int s = 0; s < 2; ++s) {
                 const int jt = 4 * s + g;                        // this lane group's coarse tap
                 const int abase = (((pz + ((jt >> 2) & 1)) * SY + py + ((jt >> 1) & 1)) * SX + px + (jt & 1) + i) * 16;
-                bf16x8 B[NT][3];
+                f16x8 B[NT][NPLN];
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        B[nn][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u,
-                                        (unsigned)(((((ch * 8 + cls) * 2 + s) * p.NTall + nt0 + nn) * 3 + pl) * 1024), 0));
+                    for (int pl = 0; pl < NPLN; ++pl)
+                        B[nn][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u,
+                                        (unsigned)(((((ch * 8 + cls) * 2 + s) * p.NTall + nt0 + nn) * NPLN + pl) * 1024), 0));
 #pragma unroll
                 for (int mz = 0; mz < CTZ; ++mz) {
-                    bf16x8 A[CTY][3];
+                    f16x8 A[CTY][NPLN];
 #pragma unroll
                     for (int my = 0; my < CTY; ++my)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) A[my][pl] = ld(pl * SPLANE_B + abase + ((mz * SY + my) * SX) * 16);
+                        for (int pl = 0; pl < NPLN; ++pl) A[my][pl] = ld(pl * SPLANE_B + abase + ((mz * SY + my) * SX) * 16);
 #pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
+                    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
                             for (int my = 0; my < CTY; ++my)
-                                acc[c][mz * CTY + my][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[my][kPA[pr]], B[nn][kPB[pr]], acc[c][mz * CTY + my][nn], 0, 0, 0);
+                                acc[c][mz * CTY + my][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[my][kPA[pr]], B[nn][kPB[pr]], acc[c][mz * CTY + my][nn], 0, 0, 0);
                 }
             }
         }
         if (more) {
-            __syncthreads();
-            sm.write(lds, pre);
+            Ecur = stage(ch + 1);                                // (its barrier: every wave is done reading this chunk's tile)
             __syncthreads();
         }
     }
+    const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));      // the sums back to the true unit (two exact factors)
     // epilogue: fine voxel (2 (z0 + mz) + pz, 2 (y0 + my) + py, 2 (x0 + 4 g + q) + px), couts 16 (nt0 + nn) + 4 a4 .. + 3
     const int Df = 2 * p.Dc, Hf = 2 * p.Hc, Wf = 2 * p.Wc;
     const long long osample = (long long)Df * Hf * Wf * p.Cout;
@@ -263,7 +288,7 @@ __global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
             for (int mz = 0; mz < CTZ; ++mz)
 #pragma unroll
                 for (int my = 0; my < CTY; ++my) {
-                    const f32x4 v = up_quad_transpose(acc[c][mz * CTY + my][nn], q);
+                    const f32x4 v = up_quad_transpose(acc[c][mz * CTY + my][nn] * inv1 * inv2, q);
                     const f32x4 o = {da_act(v[0] + bv[0], p.slope), da_act(v[1] + bv[1], p.slope), da_act(v[2] + bv[2], p.slope), da_act(v[3] + bv[3], p.slope)};
                     const int zc = z0 + mz, yc = y0 + my;
                     const bool ok = cok && zc < p.Dc && yc < p.Hc;
@@ -283,30 +308,42 @@ constexpr int FPLANE_B = FZ * FY * FXS * 16;
 constexpr int F_NIT = (FV * 2 + 255) / 256;                            // 16
 
 struct DgP {
-    const float* dy; const unsigned char* wp; float* dx1; float* dx2; int C1, C2;
+    const float* dy; const unsigned char* wp; const int* wexp; float* dx1; float* dx2; int C1, C2;
     int N, Dc, Hc, Wc, Cout, ntz, nty, ntx, nchunks, NTN;      // nchunks = Cout / 8 (K chunks), NTN = N-tiles over Cin
 };
 
-// packed B operand: [chunk (8 couts)][step 16][N-tile][plane][lane][8]; lane (g, n): adjoint tap 4 step + g (fz*16 + fy*4 + fx), K = cout chunk*8+e, N = cin 16 nt + n
-__global__ void up_pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int NTN, long long total) {
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
-        long long rest = idx >> 9;
-        const long long blk = rest;
-        const int nt = (int)(rest % NTN); rest /= NTN;
-        const int s = (int)(rest & 15); const int ch = (int)(rest >> 4);
+// packed B operand: [chunk (8 couts)][step 16][N-tile][plane][lane][8]; lane (g, n): adjoint tap 4 step + g (fz*16 + fy*4 + fx), K = cout chunk*8+e, N = cin 16 nt + n.
+// Grid (chunks, PY), per-chunk scale exponent in wexp[chunk] as in up_pack_fwd_kernel.
+__global__ void __launch_bounds__(256) up_pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout, int NTN) {
+    __shared__ float red[4];
+    const int ch = blockIdx.x;
+    float m = 0.f;
+    for (int idx = threadIdx.x; idx < 27 * Cin * 8; idx += 256) { const int e = idx & 7, r = idx >> 3; const int co = ch * 8 + e; if (co < Cout) m = fmaxf(m, fabsf(w[(size_t)r * Cout + co])); }
+    const int ew = up_sum_exp(da_block_max4(m, red, (int)threadIdx.x >> 6, (int)threadIdx.x & 63));
+    if (blockIdx.y == 0 && threadIdx.x == 0) wexp[ch] = ew;
+    const float sc = da_pow2(ew);
+    const int units = 16 * NTN * 64;                             // (step, N-tile, lane)
+    for (int u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+        const int lane = u & 63, nt = (u >> 6) % NTN, st = (u >> 6) / NTN;
         const int g = lane >> 4, n = lane & 15;
-        const int ft = 4 * s + g, co = ch * 8 + e, ci = nt * 16 + n;
-        double acc = 0.0;
-        if (ci < Cin && co < Cout) {
-            int tz[2], ty[2], tx[2];
-            const int nz = up_taps_of_f((ft >> 4) & 3, tz), ny = up_taps_of_f((ft >> 2) & 3, ty), nx = up_taps_of_f(ft & 3, tx);
-            for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
-                acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
+        const int ft = 4 * st + g, ci = nt * 16 + n;
+        int tz[2], ty[2], tx[2];
+        const int nz = up_taps_of_f((ft >> 4) & 3, tz), ny = up_taps_of_f((ft >> 2) & 3, ty), nx = up_taps_of_f(ft & 3, tx);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = ch * 8 + e;
+            double acc = 0.0;
+            if (ci < Cin && co < Cout)
+                for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
+                    acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
+            v[e] = (float)acc;
         }
-        unsigned short h, m, l; up_split3_scalar((float)acc, h, m, l);
-        unsigned short* o = wp + blk * 1536 + lane * 8 + e;
-        o[0] = h; o[512] = m; o[1024] = l;
+        uint2 h0, l0, h1, l1;
+        da_split2(make_float4(v[0], v[1], v[2], v[3]), sc, h0, l0);
+        da_split2(make_float4(v[4], v[5], v[6], v[7]), sc, h1, l1);
+        uint4* o = reinterpret_cast<uint4*>(wp + ((size_t)((ch * 16 + st) * NTN + nt) * NPLN) * 512) + lane;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -326,7 +363,7 @@ __global__ void __launch_bounds__(256, 1) up_dgrad_kernel(DgP p) {
     const int Df = 2 * p.Dc, Hf = 2 * p.Hc, Wf = 2 * p.Wc;
     const long long ysample = (long long)Df * Hf * Wf * p.Cout;
     const __amdgpu_buffer_rsrc_t ry = up_rsrc(p.dy + (long long)n * ysample, (unsigned)(ysample * sizeof(float)));
-    const __amdgpu_buffer_rsrc_t rsw = up_rsrc(p.wp, (unsigned)((size_t)p.nchunks * 16 * NTN * 3072));
+    const __amdgpu_buffer_rsrc_t rsw = up_rsrc(p.wp, (unsigned)((size_t)p.nchunks * 16 * NTN * NPLN * 1024));
     // staging map: iteration it covers halo voxel v = (tid + 256 it) / 2 = (hz, hy, hx), quad tid & 1; LDS slot de-interleaves x by parity
     const int c4 = (int)threadIdx.x & 1;
     unsigned pk[F_NIT]; int slot[F_NIT];
@@ -352,57 +389,76 @@ __global__ void __launch_bounds__(256, 1) up_dgrad_kernel(DgP p) {
             if (it < FH) preA[it < FH ? it : 0] = v; else preB[it >= FH ? it - FH : 0] = v;
         }
     };
-    auto write = [&]() {
+    // scale bookkeeping (wave-uniform; conv3d_mfma.hip "SP"): chunk = 8 output channels of dY
+    float* smax = reinterpret_cast<float*>(lds + NPLN * FPLANE_B);
+    int Eacc = 0, Emin = 0;
+    auto stage = [&](int ch) -> int {                            // publish the tile's largest magnitude, barrier, split + write; returns the chunk's E
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < FH; ++it) { m = da_absmax4(m, preA[it]); m = da_absmax4(m, preB[it]); }
+        m = da_block_max4(m, smax, wave, lane);
+        const int ew = p.wexp[ch];
+        int E = da_scale_exp(m) + ew;
+        if (ch != 0) E = min(E, Emin + 40);
+        Emin = (ch == 0) ? E : min(Emin, E);
+        const float sy = da_pow2(E - ew);
 #pragma unroll
         for (int it = 0; it < F_NIT; ++it) {
             if (slot[it] >= 0) {
-                uint2 h, m, l; up_split3(it < FH ? preA[it < FH ? it : 0] : preB[it >= FH ? it - FH : 0], h, m, l);
+                uint2 h, l; da_split2(it < FH ? preA[it < FH ? it : 0] : preB[it >= FH ? it - FH : 0], sy, h, l);
                 uint2* o = reinterpret_cast<uint2*>(lds) + slot[it];
-                o[0] = h; o[FPLANE_B / 8] = m; o[2 * (FPLANE_B / 8)] = l;
+                o[0] = h; o[FPLANE_B / 8] = l;
             }
         }
+        return E;
     };
-    auto ld = [&](int off) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lds + off); };
+    auto ld = [&](int off) -> f16x8 { return *reinterpret_cast<const f16x8*>(lds + off); };
     UP_PLANE_PAIRS;
     f32x4 acc[MPW];
 #pragma unroll
     for (int m = 0; m < MPW; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     issue(0);
-    write();
+    int Ecur = stage(0);
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue(ch + 1);
+        {
+            const float f = da_pow2(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) acc[m] = acc[m] * f;
+            Eacc = Ecur;
+        }
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
             const int ft = 4 * s + g;                            // adjoint tap of this lane group: fi = f + 1 per axis
             const int fz = (ft >> 4) & 3, fy = (ft >> 2) & 3, fx = ft & 3;
             const int xp = (fx & 1) ? 17 + (fx >> 1) : (fx >> 1);     // halo column 2 i + fx: even fx -> slot i + fx / 2, odd -> 17 + i + fx / 2
             const int abase = ((fz * FY + fy) * FXS + xp + i) * 16;
-            bf16x8 B[3];
+            f16x8 B[NPLN];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                B[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((ch * 16 + s) * NTN + nt) * 3 + pl) * 1024), 0));
-            bf16x8 A[MPW][3];
+            for (int pl = 0; pl < NPLN; ++pl)
+                B[pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)lane * 16u, (unsigned)((((ch * 16 + s) * NTN + nt) * NPLN + pl) * 1024), 0));
+            f16x8 A[MPW][NPLN];
 #pragma unroll
             for (int m = 0; m < MPW; ++m) {
                 const int mt = mg * MPW + m, mz = mt / CTY, my = mt % CTY;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) A[m][pl] = ld(pl * FPLANE_B + abase + ((2 * mz * FY + 2 * my) * FXS) * 16);
+                for (int pl = 0; pl < NPLN; ++pl) A[m][pl] = ld(pl * FPLANE_B + abase + ((2 * mz * FY + 2 * my) * FXS) * 16);
             }
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                 for (int m = 0; m < MPW; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[m][kPA[pr]], B[kPB[pr]], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[m][kPA[pr]], B[kPB[pr]], acc[m], 0, 0, 0);
         }
         if (more) {
-            __syncthreads();
-            write();
+            Ecur = stage(ch + 1);                                // (its barrier: every wave is done reading this chunk's tile)
             __syncthreads();
         }
     }
+    const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));      // the sums back to the true unit (two exact factors)
     // stores: coarse voxel (z0 + mz, y0 + my, x0 + 4 g + q), input channels 16 nt + 4 a4 .. + 3 of dx1 | dx2
     const int ci0 = nt * 16 + 4 * a4;
     const bool first = ci0 < p.C1;
@@ -414,7 +470,7 @@ __global__ void __launch_bounds__(256, 1) up_dgrad_kernel(DgP p) {
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
         const int mt = mg * MPW + m, zc = z0 + mt / CTY, yc = y0 + mt % CTY;
-        const f32x4 v = up_quad_transpose(acc[m], q);
+        const f32x4 v = up_quad_transpose(acc[m] * inv1 * inv2, q);
         up_store4(rd, (cok && zc < p.Dc && yc < p.Hc) ? (unsigned)((((zc * p.Hc + yc) * p.Wc + xc) * Cd + cd) * 4) : 0xFFFFFFFFu, v);
     }
 }
@@ -432,7 +488,7 @@ constexpr int YPLANE_B = YV * 32 * 2;                            // [voxel][32 c
 
 __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* ldsY = lds + 3 * SPLANE_B;
+    unsigned char* ldsY = lds + NPLN * SPLANE_B;
     typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -444,10 +500,10 @@ __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
     const bool first = cb < p.C1;
     const float* src = first ? p.s1 : p.s2;
     const int Cs = first ? p.C1 : p.C2, choff = first ? cb : cb - p.C1;
-    auto tr8 = [&](const unsigned char* a, int step_bytes) -> bf16x8 {
+    auto tr8 = [&](const unsigned char* a, int step_bytes) -> f16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step_bytes));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // S fragment of tap-pair slot s (taps 2 s, 2 s + 1; this lane: tap 2 s + (q >> 1), channel quad q & 1) for output row `wave`
     int aoff[4];
@@ -457,14 +513,14 @@ __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
         aoff[s] = ((((zi + pz + ((jt >> 2) & 1)) * SY + wave + py + ((jt >> 1) & 1)) * SX + px + (jt & 1) + 8 * (g & 1) + vq) * 8 + (q & 1) * 4) * 2;
     }
     const int yoff = (((zi * CTY + wave) * CTX + 8 * (g & 1) + vq) * 32 + q * 4) * 2;
-    struct F3 { bf16x8 p[3]; };
+    struct F3 { f16x8 p[NPLN]; };
     auto loadF = [&](int s) -> F3 { F3 f;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(lds + pl * SPLANE_B + aoff[s], 4 * 8 * 2);
+        for (int pl = 0; pl < NPLN; ++pl) f.p[pl] = tr8(lds + pl * SPLANE_B + aoff[s], 4 * 8 * 2);
         return f; };
     auto loadY = [&](int nn) -> F3 { F3 f;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) f.p[pl] = tr8(ldsY + pl * YPLANE_B + yoff + nn * 32, 4 * 32 * 2);
+        for (int pl = 0; pl < NPLN; ++pl) f.p[pl] = tr8(ldsY + pl * YPLANE_B + yoff + nn * 32, 4 * 32 * 2);
         return f; };
     f32x4 acc[4][2];
 #pragma unroll
@@ -494,13 +550,32 @@ __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
             preY[u] = up_load4(ry, inb ? (unsigned)(((((2 * zc + pz) * Hf + 2 * yc + py) * Wf + 2 * xc + px) * p.Cout + co) * 4) : 0xFFFFFFFFu);
         }
     };
-    auto write_lds = [&]() {
-        sm.write(lds, preA);
+    // scale bookkeeping (wave-uniform; conv3d_mfma.hip, conv3_split_wgrad_kernel)
+    float* smax = reinterpret_cast<float*>(ldsY + NPLN * YPLANE_B);      // [2][4]
+    int Eacc = 0, Emin = 0, Enext = 0; bool first_tile = true;
+    auto write_lds = [&]() {                                     // (starts with the barrier that retires the tile in LDS)
+        float my = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) my = da_absmax4(my, preY[u]);
+        const float ma = da_wave_max_nonneg(sm.absmax(preA));
+        my = da_wave_max_nonneg(my);
+        if (lane == 0) { smax[wave] = ma; smax[4 + wave] = my; }
+        __syncthreads();
+        const float4 a4 = *reinterpret_cast<const float4*>(smax), y4 = *reinterpret_cast<const float4*>(smax + 4);
+        const int ea = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(a4.x, a4.y), fmaxf(a4.z, a4.w))))));
+        const int ey = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(y4.x, y4.y), fmaxf(y4.z, y4.w))))));
+        int E = ea + ey;
+        if (!first_tile) E = min(E, Emin + 40);
+        Emin = first_tile ? E : min(Emin, E);
+        first_tile = false;
+        Enext = E;
+        const float sy = da_pow2(ey);
+        sm.write(lds, preA, da_pow2(E - ey));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            uint2 h, m, l; up_split3(preY[u], h, m, l);
+            uint2 h, l; da_split2(preY[u], sy, h, l);
             uint2* o = reinterpret_cast<uint2*>(ldsY) + (yv0 + 32 * u) * 8 + yq;
-            o[0] = h; o[YPLANE_B / 8] = m; o[2 * (YPLANE_B / 8)] = l;
+            o[0] = h; o[YPLANE_B / 8] = l;
         }
     };
     UP_PLANE_PAIRS;
@@ -512,23 +587,33 @@ __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
     for (int k = 0; k < cnt; ++k) {
         const bool more = k + 1 < cnt;
         if (more) issue(slab + (k + 1) * p.nslabs);
+        {
+            const float f = da_pow2(Enext - Eacc);               // the running sums into this tile's unit (exact)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { acc[s][0] = acc[s][0] * f; acc[s][1] = acc[s][1] * f; }
+            Eacc = Enext;
+        }
         const F3 Y0 = loadY(0), Y1 = loadY(1);
         F3 F = loadF(0), Fn;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s + 1 < 4) Fn = loadF(s + 1);
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.p[kPA[pr]], Y0.p[kPB[pr]], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.p[kPA[pr]], Y1.p[kPB[pr]], acc[s][1], 0, 0, 0);
+            for (int pr = 0; pr < 3; ++pr) {
+                acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.p[kPA[pr]], Y0.p[kPB[pr]], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.p[kPA[pr]], Y1.p[kPB[pr]], acc[s][1], 0, 0, 0);
             }
             if (s + 1 < 4) F = Fn;
         }
         if (more) {
-            __syncthreads();
             write_lds();
             __syncthreads();
         }
+    }
+    {
+        const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));      // back to the true unit
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { acc[s][0] = acc[s][0] * inv1 * inv2; acc[s][1] = acc[s][1] * inv1 * inv2; }
     }
     // reduce the four waves (rows) through LDS, wave 0 writes G[cls][j][cb + ci][co] of this slab
     __syncthreads();
@@ -615,12 +700,12 @@ extern "C" int da_upconv3d_k3_supported(int C1, int C2, int Cout) {
 extern "C" size_t da_upconv3d_k3_ws_bytes(int N, int Dc, int Hc, int Wc, int Cin, int Cout) {
     const Plan q = up_plan(N, Dc, Hc, Wc);
     const int NT = (Cout + 15) / 16, NTN = (Cin + 15) / 16;
-    const size_t pack_f = (size_t)(Cin / 8) * 16 * NT * 3072;
-    const size_t pack_d = (size_t)((Cout + 7) / 8) * 16 * (NTN == 3 ? 4 : NTN) * 3072;
+    const size_t pack_f = (size_t)(Cin / 8) * 16 * NT * NPLN * 1024;
+    const size_t pack_d = (size_t)((Cout + 7) / 8) * 16 * (NTN == 3 ? 4 : NTN) * NPLN * 1024;
     const size_t part = (size_t)up_wgrad_slabs(q.ntiles, Cin / 8) * 64 * Cin * Cout * sizeof(float);
     size_t m = pack_f > pack_d ? pack_f : pack_d;
     if (part > m) m = part;
-    return da_align(m) + 256;
+    return da_align(m) + 256;        // (+ 256: the weight scale exponents in front of the packed operand)
 }
 
 static bool up_sizes_ok(int N, int Dc, int Hc, int Wc, int Cin, int Cout) {
@@ -637,13 +722,12 @@ extern "C" int da_upconv3d_k3_fwd(const float* s1, int C1, const float* s2, int 
     hipStream_t st = da_stream(stream);
     const Plan q = up_plan(N, Dc, Hc, Wc);
     FwdP p;
-    p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.wp = (const unsigned char*)ws; p.bias = bias; p.out = out;
+    p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.bias = bias; p.out = out;
     p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
     p.nchunks = Cin / 8; p.NTall = (Cout + 15) / 16; p.slope = act_slope;
-    const long long total = (long long)p.nchunks * 16 * p.NTall * 512;
-    hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(da_grid(total, 256, 256)), dim3(256), 0, st, w_tio, (unsigned short*)ws, Cin, Cout, p.NTall, total);
+    hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(p.nchunks, 8), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.NTall);
     DA_LAUNCH_CHECK();
-    const size_t shm = 3 * SPLANE_B;
+    const size_t shm = NPLN * SPLANE_B + 16;
     static bool a1 = false, a2 = false;
     if (p.NTall == 1) {
         if (!a1) { const int e = up_set_lds(up_fwd_kernel<1>, shm); if (e) return e; a1 = true; }
@@ -665,23 +749,22 @@ extern "C" int da_upconv3d_k3_dgrad(const float* dy, const float* w_tio, float* 
     hipStream_t st = da_stream(stream);
     const Plan q = up_plan(N, Dc, Hc, Wc);
     DgP p;
-    p.dy = dy; p.wp = (const unsigned char*)ws; p.dx1 = dx1; p.dx2 = dx2; p.C1 = C1; p.C2 = C2;
+    p.dy = dy; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.dx1 = dx1; p.dx2 = dx2; p.C1 = C1; p.C2 = C2;
     p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
     p.nchunks = Cout / 8;
     int NTN = (Cin + 15) / 16; if (NTN == 3) NTN = 4;            // (48 input channels: a fourth, empty tile)
     p.NTN = NTN;
-    const long long total = (long long)p.nchunks * 16 * NTN * 512;
-    hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(da_grid(total, 256, 256)), dim3(256), 0, st, w_tio, (unsigned short*)ws, Cin, Cout, NTN, total);
+    hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(p.nchunks, 8), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, NTN);
     DA_LAUNCH_CHECK();
-    const size_t shm = 3 * FPLANE_B;
+    const size_t shm = NPLN * FPLANE_B + 16;
     static bool a[5] = {false, false, false, false, false};
     int e = 0;
     switch (NTN) {
-        case 1: if (!a[1]) { e = up_set_lds(up_dgrad_kernel<1>, shm); a[1] = true; } if (e) return e;
+        case 1: if (!a[1]) { e = up_set_lds(up_dgrad_kernel<1>, shm); if (e) return e; a[1] = true; }
                 hipLaunchKernelGGL(up_dgrad_kernel<1>, dim3(q.ntiles), dim3(256), shm, st, p); break;
-        case 2: if (!a[2]) { e = up_set_lds(up_dgrad_kernel<2>, shm); a[2] = true; } if (e) return e;
+        case 2: if (!a[2]) { e = up_set_lds(up_dgrad_kernel<2>, shm); if (e) return e; a[2] = true; }
                 hipLaunchKernelGGL(up_dgrad_kernel<2>, dim3(q.ntiles), dim3(256), shm, st, p); break;
-        case 4: if (!a[4]) { e = up_set_lds(up_dgrad_kernel<4>, shm); a[4] = true; } if (e) return e;
+        case 4: if (!a[4]) { e = up_set_lds(up_dgrad_kernel<4>, shm); if (e) return e; a[4] = true; }
                 hipLaunchKernelGGL(up_dgrad_kernel<4>, dim3(q.ntiles), dim3(256), shm, st, p); break;
         default: return DA_ERR_UNSUPPORTED;
     }
@@ -702,7 +785,7 @@ extern "C" int da_upconv3d_k3_wgrad(const float* s1, int C1, const float* s2, in
     p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles;
     const int nchunks = Cin / 8;
     p.nslabs = up_wgrad_slabs(q.ntiles, nchunks); p.O = 64 * Cin * Cout;
-    const size_t shm = (size_t)3 * SPLANE_B + 3 * YPLANE_B;
+    const size_t shm = (size_t)NPLN * SPLANE_B + NPLN * YPLANE_B + 32;
     static bool attr = false;
     if (!attr) { const int e = up_set_lds(up_wgrad_kernel, shm); if (e) return e; attr = true; }
     hipLaunchKernelGGL(up_wgrad_kernel, dim3(p.nslabs, nchunks, 8), dim3(256), shm, st, p);

@@ -191,9 +191,12 @@ def test_folded_upsampling_conv_is_fp32_accurate(case, kind):
         e_f, e_m = rel_l2(f.numpy().astype(np.float64), r), rel_l2(m.numpy().astype(np.float64), r)
         x_f, x_m = max_abs_rel(f.numpy().astype(np.float64), r), max_abs_rel(m.numpy().astype(np.float64), r)
         # same error class as the materialised route (the two sum in different orders -- 64 summed-weight taps against 8 x 27 -- and the
-        # summed weights are rounded to fp32 once): within a small factor of it, and inside the package's 1e-5 criterion
-        assert e_f <= 3.0 * e_m + 2.4e-7, '%s: folded rel-l2 %.3e vs materialised %.3e' % (nm, e_f, e_m)
-        assert x_f <= 4.0 * x_m + 5e-7, '%s: folded max-abs %.3e vs materialised %.3e' % (nm, x_f, x_m)
+        # summed weights are rounded to fp32 once): within a small factor of it, and inside the package's 1e-5 criterion.  Additive slack =
+        # the two-term split's own bound PER PRODUCT, 2^-21 + 2^-22 = 7e-7 (each operand is h + l to 2^-22, the l.l' term is dropped): with
+        # log-normal magnitudes a sum is dominated by ONE product and that bound shows directly (uniform data: accumulation rounding dominates
+        # and both routes sit at 1 - 3e-7)
+        assert e_f <= 3.0 * e_m + 7.2e-7, '%s: folded rel-l2 %.3e vs materialised %.3e' % (nm, e_f, e_m)
+        assert x_f <= 4.0 * x_m + 1.0e-6, '%s: folded max-abs %.3e vs materialised %.3e' % (nm, x_f, x_m)
         assert e_f < 1e-5 and x_f < 1e-5, (nm, e_f, x_f)
 
 

@@ -10,4 +10,8 @@ for row in pp.get('roofline_layer', []):
     print('   ', row['call'], row['avg_ms'], 'ms', row['tflops'], 'TFLOP/s', row['frac'])
 print('    all conv calls', pp.get('all_conv_calls'))
 for k, v in (d.get('extra') or {}).items():
-    print('extra', k, v['value'], v['unit'], v['ms_per_step'], 'ms')
+    if isinstance(v, dict) and 'value' in v:
+        print('extra', k, v['value'], v['unit'], v['ms_per_step'], 'ms')
+    elif isinstance(v, dict):
+        for k2, v2 in v.items():
+            if isinstance(v2, dict) and 'value' in v2: print('extra', k, k2, v2['value'], v2['unit'], v2['ms_per_step'], 'ms')
