@@ -31,14 +31,14 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 matrix peak
-# 'fp32_split' (the headline's matrix mode): every fp32 product is six bf16 x bf16 partial products on the bf16 pipe, so the ceiling of
-# the ALGORITHMIC (2 * 27 * Cin * Cout per voxel) rate is the bf16 peak / 6
-SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+# 'fp32_split' (the headline's matrix mode): every fp32 product is three fp16 x fp16 partial products on the fp16 pipe (same dense peak as
+# bf16), so the ceiling of the ALGORITHMIC (2 * 27 * Cin * Cout per voxel) rate is that peak / 3
+SPLIT_MFMA_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 PRECISION_NOTE = {
     'fp32': 'fp32 operands on v_mfma_f32_16x16x4_f32 (one fmaf per product)',
-    'fp32_split': 'fp32 tensors; in the 3x3x3 convolutions every operand is split EXACTLY into three bf16 terms and a product is the sum of six '
-                  'bf16 x bf16 partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate -- error against double not larger than the '
-                  'fmaf chain (tests/test_gpu_split.py); everything else is plain fp32',
+    'fp32_split': 'fp32 tensors; in the 3x3x3 convolutions every operand is scaled by a per-tile power of two and split into two fp16 terms '
+                  '(h + l, 22 significand bits) and a product is the sum of three fp16 x fp16 partial products on v_mfma_f32_16x16x32_f16, fp32 '
+                  'accumulate -- error against double not larger than the fmaf chain (tests/test_gpu_split.py); everything else is plain fp32',
     'bf16': 'operands of the 3x3x3 convolutions ROUNDED to bf16, fp32 accumulate; every tensor in HBM fp32 (the A/B of bf16_storage)',
     'bf16_storage': 'BASELINE configs[4] mixed precision: activations and their gradients between the layers STORED as bf16, bf16 x bf16 -> fp32 '
                     'matrix products, fp32 statistics / reductions / master weights / weight gradients / losses',
@@ -111,17 +111,28 @@ def cpu_baseline(shape, batch, n_classes, budget_s=20.0, keep_reference=False):
     warm = time.time() - t0
     if keep_reference:
         ref.update(loss=float(loss0.item()), logits=logits0)
+        # the yardstick of the logits comparison: the reference arithmetic's OWN fp32-vs-fp64 distance on this network, batch and size
+        # (train-mode forward in double: BatchNorm over batch statistics amplifies rounding ~2.5x per block)
+        with torch.no_grad():
+            sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in ref['sd0'].items()}
+            l64 = nets.unet_forward(sd64, x.double(), spec, training=True)
+            d = logits0.double() - l64
+            ref.update(fp32_floor_rel_l2=float(d.norm() / l64.norm()), fp32_floor_max_abs=float(d.abs().max() / l64.abs().max()), logits64=l64)
+            del sd64, d
     del logits0
     n, t0 = 0, time.time()
-    while True:
+    while n < 2 or (time.time() - t0 < budget_s and n < 4):       # at least two timed steps (~20 s each at the metric's size)
         steps.seg_step(sd, opt, x, y, spec, n_classes)
         n += 1
-        if time.time() - t0 > budget_s or n >= 2:
-            break
     dt = (time.time() - t0) / n
-    base = dict(value=batch / dt, unit='volumes/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d timed step(s) of the same workload (batch %d, %dx%dx%d) after 1 warm-up step of %.1f s; %.2f s/step'
-                       % (n, batch, shape[0], shape[1], shape[2], warm, dt))
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or torch.get_num_threads()
+    except ImportError:
+        phys = torch.get_num_threads()
+    base = dict(value=batch / dt, unit='volumes/s', cores=int(phys), threads=torch.get_num_threads(), kind='port',
+                sample='%d timed steps of the same workload (batch %d, %dx%dx%d) after 1 warm-up step of %.1f s; %.2f s/step; torch intra-op '
+                       'threads = %d on %d physical cores' % (n, batch, shape[0], shape[1], shape[2], warm, dt, torch.get_num_threads(), int(phys)))
     return (base, ref) if keep_reference else base
 
 
@@ -160,6 +171,12 @@ def parity_fullsize(ref, n_classes, dev, modes, train_steps=150):
                 logits = ops.materialize_logits(twin(x))
             num, den = float((logits - o).double().norm()), float(o.double().norm())
             mx = float((logits - o).abs().max() / o.abs().max())
+            vs64 = {}
+            if ref.get('logits64') is not None:                 # the device against the fp64 evaluation, next to the fp32 oracle's own distance from it
+                d64 = logits.double().cpu() - ref['logits64']
+                vs64 = dict(logits_rel_l2_vs_fp64=float(d64.norm() / ref['logits64'].norm()), logits_max_abs_vs_fp64=float(d64.abs().max() / ref['logits64'].abs().max()),
+                            oracle_fp32_rel_l2_vs_fp64=ref['fp32_floor_rel_l2'], oracle_fp32_max_abs_vs_fp64=ref['fp32_floor_max_abs'])
+                del d64
             del twin, logits
             model = fresh(ref['sd0']).train()
             model.lazy_head = True
@@ -170,7 +187,7 @@ def parity_fullsize(ref, n_classes, dev, modes, train_steps=150):
             opt.step()
             loss = float(loss.item())
             out.append(dict(matrix_precision=mode, loss=loss, oracle_loss=ref['loss'], loss_abs_diff=abs(loss - ref['loss']),
-                            logits_rel_l2=num / den, logits_max_abs_over_max=mx))
+                            logits_rel_l2=num / den, logits_max_abs_over_max=mx, **vs64))
             if trained is None:
                 for _ in range(train_steps):
                     opt.zero_grad()
@@ -434,8 +451,8 @@ def main():
     ap.add_argument('--no-profile', action='store_true', help='skip per-call HIP-event timing')
     ap.add_argument('--no-extra', action='store_true', help="skip the reg / joint legs and the post-run backward-kernel timing pass")
     ap.add_argument('--precision', default='fp32_split', choices=['fp32_split', 'fp32', 'bf16', 'bf16_storage'],
-                    help="matrix arithmetic of the 3x3x3 convolutions.  'fp32_split' (headline): fp32 operands split exactly into three bf16 "
-                         "terms, six partial products per multiply on the bf16 pipe, fp32 accumulate -- fp32-accurate; 'fp32': the fp32 matrix "
+                    help="matrix arithmetic of the 3x3x3 convolutions.  'fp32_split' (headline): fp32 operands scaled per tile and split into two fp16 "
+                         "terms, three partial products per multiply on the fp16 pipe, fp32 accumulate -- fp32-accurate; 'fp32': the fp32 matrix "
                          "instructions (one fmaf per product; also timed by the default run, under extra.native_fp32_mfma); 'bf16': operands "
                          "ROUNDED to bf16 (BASELINE configs[4]'s mixed precision; not fp32-accurate, never the headline)")
     ap.add_argument('--graph', action='store_true', help='capture each step once as HIP graph(s) and replay it (one host call per step; per-call '
@@ -502,6 +519,16 @@ def main():
     head = wls[args.workload]
     dt, per_rank, final_loss, prof, launches = time_workload(head, args, world, dev, None if (args.no_profile or args.graph) else CONV_FWD_CALLS)
     head_res = result_of(head, dt, per_rank, world, args, launches)
+    # the same K steps with the host reading the loss every step, as SegmentationExperiment.train_one_epoch does (models/segmentation.py:160
+    # of the reference: `loss.item()` per iteration): one device synchronisation per step
+    sync_ms = None
+    if world == 1 and not args.no_extra:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            float(head.step().item())
+        torch.cuda.synchronize()
+        sync_ms = round((time.perf_counter() - t0) / args.steps * 1e3, 3)
 
     allreduce = None
     if world > 1:
@@ -587,12 +614,12 @@ def main():
                 rl_head = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
             elif args.precision == 'fp32_split':
                 rl_head = dict(bound='mfma', achieved=top['tflops'], peak=round(SPLIT_MFMA_PEAK_TFLOPS, 1), unit='TFLOP/s', frac=top['frac'], traffic=None,
-                               peak_note='algorithmic fp32 FLOPs (2*27*Cin*Cout per voxel) against the dense bf16 matrix peak / 6: the split mode '
-                                         'issues six bf16 MFMA products per fp32 multiply',
+                               peak_note='algorithmic fp32 FLOPs (2*27*Cin*Cout per voxel) against the dense fp16 matrix peak / 3: the split mode '
+                                         'issues three fp16 MFMA products per fp32 multiply',
                                frac_of_fp32_mfma_peak=round(top['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4),
-                               bound_note='power: the same binary on all-zero operands runs 1.33x faster at a 2.16 instead of 1.55 - 1.6 GHz shader '
-                                          'clock (DESIGN.md 4.8, profiles/r02_conv3d_layers_isolated.txt); the six-MFMA K loop with its LDS reads alone '
-                                          'sustains 308 TFLOP/s on random operands (profiles/r02_ubench_mfma_power.txt)')
+                               bound_note='power-limited clock: the matrix pipe alone sustains 659 TFLOP/s of this arithmetic at 1.90 GHz on random '
+                                          'operands, the K loop with its LDS fragment reads 525 - 580 at 1.6 - 1.75 GHz (profiles/r04_ubench_f16_kloop.txt); '
+                                          'the kernel adds staging loads (25 %) and LDS writes + barriers (10 %), profiles/r04_conv_fwd_ablation.txt')
             else:
                 rl_head = dict(bound='mfma', achieved=top['tflops'], peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=top['frac'], traffic=None)
             roofline = dict(rl_head, kernel=top['call'], avg_ms=top['avg_ms'], launches=top['launches'], flops_per_launch=top['_fl'],
@@ -616,6 +643,20 @@ def main():
                 same = [r for r in bwd_rows if conv_dims(r['_key']) == lay]
                 slow = bwd_rows[0]
                 strip = lambda r: {k: v for k, v in r.items() if not k.startswith('_')}
+                # `kernel` / `achieved` / `frac` = the DOMINANT kernel of the training step (most time over forward + backward: a weight
+                # gradient, which the timed region runs on the side stream); the forward call timed inside the timed region stays as `forward`
+                roofline['forward'] = dict(kernel=roofline['kernel'], achieved=roofline['achieved'], frac=roofline['frac'], avg_ms=roofline['avg_ms'],
+                                           launches=roofline['launches'], measured=roofline['measured'])
+                roofline.update(kernel=slow['call'], achieved=slow['tflops'], frac=slow['frac'], avg_ms=slow['avg_ms'], launches=slow['launches'],
+                                flops_per_launch=slow['_fl'],
+                                measured='HIP events on the launch stream, post-run pass of 3 steps right after the timed region with the weight gradients '
+                                         'on the main stream (inside the timed region they overlap other kernels on a side stream); the call with the '
+                                         'most time over forward + backward')
+                if args.precision == 'fp32_split':
+                    roofline['frac_of_fp32_mfma_peak'] = round(slow['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)
+                pm2 = pmc_traffic_for(slow['call'], args.precision)
+                roofline['traffic'] = pm2['traffic'] if pm2 else None
+                roofline['traffic_source'] = pm2['traffic_source'] if pm2 else None
                 roofline['post_run_pass'] = dict(
                     note='3 extra steps after the timed region, weight gradients on the main stream, every conv call timed with HIP events',
                     roofline_layer=[strip(r) for r in same],
@@ -651,6 +692,22 @@ def main():
                                            other_modes=par[1:] or None)
         else:
             line['cpu_baseline'] = None
+        # flat copies of the numbers a reader of the driver's record needs (its parser keeps top-level scalars only)
+        if sync_ms is not None:
+            line['ms_per_step_with_loss_item'] = sync_ms
+        for leg in ('reg', 'joint'):
+            if leg in extra:
+                line['%s_ms_per_step' % leg] = extra[leg]['ms_per_step']
+        if 'native_fp32_mfma' in extra:
+            line['native_fp32_mfma_ms_per_step'] = extra['native_fp32_mfma']['ms_per_step']
+        pf = line.get('parity_fullsize')
+        if pf:
+            if 'logits_max_abs_vs_fp64' in pf:
+                line.update(parity_logits_max_abs_vs_fp64=pf['logits_max_abs_vs_fp64'], parity_oracle_fp32_max_abs_vs_fp64=pf['oracle_fp32_max_abs_vs_fp64'])
+            line.update(parity_loss_abs_diff=pf['loss_abs_diff'], parity_logits_rel_l2=pf['logits_rel_l2'], parity_logits_max_abs=pf['logits_max_abs_over_max'],
+                        parity_eval_dice_abs_diff=pf['eval_dice_abs_diff'], argmax_flips_away_from_ties=pf['flips_away_from_ties'])
+        if roofline:
+            line.update(roofline_kernel=roofline['kernel'], roofline_frac=roofline['frac'], roofline_avg_ms=roofline['avg_ms'])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -10,7 +10,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
 // w_is_flipped_tr != 0: `w_tio` is the ORIGINAL layer's [27][Cout][C1] tensor and the kernel runs the data-gradient
 // convolution (taps flipped, channels transposed) -- i.e. logical Cin = C1, logical Cout = `Cout`.
 bool da_matrix_bf16();                 // bf16 matrix mode switch (da_set_matrix_bf16)
-int da_matrix_mode();                  // 0 fp32 MFMA | 1 bf16-rounded operands | 2 exact three-way bf16 split (da_set_matrix_mode)
+int da_matrix_mode();                  // 0 fp32 MFMA | 1 bf16-rounded operands | 2 two-term fp16 split (da_set_matrix_mode, split_f16.h)
 // Input prologue: in1 / in2 are RAW outputs of a producer whose per-channel affine (BatchNorm scale / shift) and activation
 // (slope as in da_conv3d_k3_fwd: < 0 identity, 0 ReLU, > 0 LeakyReLU) are applied while the tile is staged.  A null scale
 // pointer = that input is already activated.

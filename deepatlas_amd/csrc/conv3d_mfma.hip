@@ -1337,7 +1337,7 @@ __global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx
 // Its fragments need 4 consecutive VOXELS of one channel per lane while the tiles are channel-contiguous, which is exactly
 // what ds_read_b64_tr_b16 delivers: in each 16-lane group lane s supplies the address of (voxel 4g + s/4, channel quad s%4)
 // and receives (voxels 4g .. 4g+3, channel s) -- checked in tools/ubench/ds_read_tr16.hip.
-// SP (split mode, see conv3_mfma_fwd_kernel): x and dY are split exactly into three bf16 planes while they are staged; K = 32 = two
+// (split mode has its own weight-gradient kernel, conv3_split_wgrad_kernel; the description that follows is the bf16 matrix mode's) K = 32 = two
 // rows of 16 voxels per v_mfma_f32_16x16x32_bf16 (lane group g: row 2 rp + (g >> 1), voxels 8 (g & 1) .. + 7 = two transpose reads), six
 // products per (tap slot, N-tile, row pair); the fragments of the next two tap slots are read while the current two slots' MFMAs issue.
 template <int CK, int NREP, bool YS = false, bool MASKED = false, bool BF = false, bool PRO = false, bool SP = false, bool HB = false>   // YS: dY staged with dword loads (Cout % 4 != 0, e.g. the 24 -> 3 flow conv); MASKED: sparse tap sets; PRO: input prologue (BN + act applied to x while staging); HB: x and dY stored as bf16
@@ -2046,7 +2046,7 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
     q.CK = pick_ck(C1, C2);
     const int NT = (Cout + 15) / 16;
     q.NREP = NT >= 2 ? 2 : 1;
-    if (split && q.CK) { q.CK = 8; q.NREP = 1; }             // split mode: three bf16 planes of x and dY in LDS -> 8-channel chunks, one cout tile
+    if (split && q.CK) { q.CK = 8; q.NREP = 1; }             // split mode: two fp16 planes of x and dY in LDS -> 8-channel chunks, one cout tile
     q.ngroups = (NT + q.NREP - 1) / q.NREP;
     q.nchunks = q.CK ? (C1 + C2) / q.CK : 1;
     q.ntz = (D + 1) / 2; q.nty = (H + TY - 1) / TY; q.ntx = (W + TX - 1) / TX;
@@ -2332,7 +2332,7 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
 // matrix mode of the 3x3x3 convolutions: process-wide switch (like da_set_conv_direct); the setters return the previous setting.
 //   0  fp32 operands on v_mfma_f32_16x16x4_f32 (an fmaf chain)
 //   1  operands ROUNDED to bf16 (BASELINE configs[4]'s precision; not fp32-accurate)
-//   2  fp32 operands split exactly into three bf16 terms, six partial products per multiply on the bf16 pipe, fp32 accumulate
+//   2  fp32 operands scaled per tile and split into two fp16 terms, three partial products per multiply on the fp16 pipe, fp32 accumulate
 static int g_matrix_mode = -1;          // -1: not decided yet (env DA_MATRIX_MODE=0|1|2, or the older DA_MATRIX_BF16=1, for tools)
 int da_matrix_mode() {
     if (g_matrix_mode < 0) {

@@ -22,12 +22,53 @@ def dice_from_counts(counts):
         return 2.0 * c[..., 2] / (c[..., 0] + c[..., 1])
 
 
-def metricEval(eval_metric, logits, truth, num_labels=None):
-    """Per-class Dice for classes 1..C-1 of every volume in the batch: ndarray [N][C-1]."""
-    if eval_metric != 'dice':
-        raise NotImplementedError("only 'dice' is on the accelerated eval path")
-    counts, _ = eval_dice_counts(logits, truth)
-    return dice_from_counts(counts)[:, 1:]
+def _as_device_labels(a):
+    """numpy / torch label map (bool masks included) -> one flattened uint8 / int64 sample on the current device."""
+    t = a if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a))
+    if t.dtype == torch.bool:
+        t = t.to(torch.uint8)
+    elif t.dtype.is_floating_point:
+        t = t.to(torch.int64)
+    if not t.is_cuda:
+        t = t.to(torch.device('cuda', torch.cuda.current_device()))
+    return t.reshape(1, -1)
+
+
+def metricEval(eval_metric, output, gt, num_labels=None):
+    """lib/evalMetrics.py:17-100.  Two call forms:
+      * the accelerated evaluation loop (models/segmentation.py:188-194 collapsed into one kernel): metricEval('dice', logits N x C x D x H x W,
+        truth N x D x H x W) -> per-class Dice of classes 1..C-1 for every volume, ndarray [N][C-1];
+      * the reference's own signature on LABEL MAPS (numpy or torch, bool masks included), `output` and `gt` squeezed and flattened as one
+        volume: 'iou' = mean over the num_labels labels of |P & T| / |P | T| (0 for a label absent from gt; lib/evalMetrics.py:36-57);
+        'dice' (num_labels == 2) = 2 |P & T| / (|P| + |T|) of the non-zero voxels (1 - scipy dice, :59-68; NaN when both are empty);
+        'recall' = TP / |T|, 'precision' = TP / |P| of label 1 (:73-100; ZeroDivisionError when the denominator is empty, as there).
+      All four come from the three integer counts per label of ONE pass over the two maps (da_label_overlap_counts)."""
+    if eval_metric == 'dice' and torch.is_tensor(output) and output.dtype.is_floating_point and output.dim() == 5:
+        counts, _ = eval_dice_counts(output, gt)
+        return dice_from_counts(counts)[:, 1:]
+    if eval_metric not in ('iou', 'dice', 'recall', 'precision'):
+        raise ValueError('Invalid evaluation metric value: %r' % (eval_metric,))
+    if num_labels is None:
+        raise ValueError('num_labels is required for label-map metrics')
+    if eval_metric != 'iou' and num_labels != 2:
+        raise NotImplementedError('%s evaluation score is only implemented for 2 labels' % eval_metric)
+    p, t = _as_device_labels(output), _as_device_labels(gt)
+    if p.shape != t.shape:
+        raise AssertionError('pred shape %s gt shape %s' % (tuple(p.shape), tuple(t.shape)))
+    c = ops.label_overlap_counts(p, t, num_labels)[0].cpu().numpy().astype(np.float64)      # [num_labels][3] = (|P|, |T|, |P & T|)
+    if eval_metric == 'iou':
+        union = c[:, 0] + c[:, 1] - c[:, 2]
+        present = c[:, 1] != 0
+        per = np.zeros(num_labels)
+        per[present] = c[present, 2] / union[present]
+        return float(per.sum() / float(num_labels))
+    n_p, n_t, tp = c[1]
+    if eval_metric == 'dice':
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return float(np.float64(2.0 * tp) / np.float64(n_p + n_t))
+    if eval_metric == 'recall':
+        return tp / n_t if n_t != 0 else (_ for _ in ()).throw(ZeroDivisionError('float division by zero'))
+    return tp / n_p if n_p != 0 else (_ for _ in ()).throw(ZeroDivisionError('float division by zero'))
 
 
 def _n_class_of(*masks):

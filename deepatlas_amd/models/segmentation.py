@@ -38,29 +38,37 @@ class SegmentationExperiment(BaseExperiment):
     def __init__(self, config):
         super(SegmentationExperiment, self).__init__(config)
         self.device = torch.device(self.config.get('device', 'cuda'))
-        if self.config['debug_mode']:
+        cfg = self.config
+        if cfg['debug_mode']:                                    # debug runs print and validate every second batch / epoch
             print("Debug mode")
-            self.config['print_batch_period'] = 2
-            self.config['valid_epoch_period'] = 2
-        self.exp_name = \
-            'Seg_{}{}{}{}{}{}{}{}'.format(
-                '{}{}{}_'.format(self.config['model'], '_bias' if self.config['model_settings']['bias'] else '',
-                                 '_BN' if self.config['model_settings']['BN'] else ''),
-                os.path.basename(self.config['data_dir']),
-                '_{}samples'.format(self.config["num_samples"]),
-                '_batch_{}'.format(self.config['batch_size']),
-                '_{}epochs'.format(self.config['n_epochs']),
-                '_{}_{}'.format(self.config['loss'], self.config['loss_settings']['weight_type']),
-                '_lr_{}'.format(self.config['learning_rate']),
-                '_scheduler_{}'.format(self.config['lr_mode']) if not self.config['lr_mode'] == 'const' else '')
-        self.ckpoint_dir = os.path.join(self.config['log_dir'],
-                                        self.exp_name if not self.config['debug_mode'] else "debug_seg",
-                                        str(self.config['random_seed']))
+            cfg['print_batch_period'] = cfg['valid_epoch_period'] = 2
+        self.exp_name = self.experiment_name(cfg)
+        # <log_dir>/<experiment name | "debug_seg">/<seed>: the directory layout the reference's checkpoints and resume_dir use
+        # (models/segmentation.py:40-42), so runs of either code base can resume each other's checkpoints
+        run_dir = "debug_seg" if cfg['debug_mode'] else self.exp_name
+        self.ckpoint_dir = os.path.join(cfg['log_dir'], run_dir, str(cfg['random_seed']))
         self.writer = None
         self.global_step = 0
         self.training_data_loader = self.config.get('training_data_loader')
         self.validation_data_loader = self.config.get('validation_data_loader')
         print("Init experiment {} seed {}".format(self.exp_name, self.config['random_seed']))
+
+    @staticmethod
+    def experiment_name(cfg):
+        """The run's name, field by field as the reference composes it (models/segmentation.py:27-38) -- it is part of the checkpoint path:
+        Seg_<model>[_bias][_BN]_<data dir name>_<n>samples_batch_<b>_<e>epochs_<loss>_<weighting>_lr_<lr>[_scheduler_<mode>]."""
+        ms = cfg['model_settings']
+        parts = ['Seg_', cfg['model']]
+        if ms['bias']:
+            parts.append('_bias')
+        if ms['BN']:
+            parts.append('_BN')
+        parts += ['_', os.path.basename(cfg['data_dir']),
+                  '_%ssamples' % cfg['num_samples'], '_batch_%s' % cfg['batch_size'], '_%sepochs' % cfg['n_epochs'],
+                  '_%s_%s' % (cfg['loss'], cfg['loss_settings']['weight_type']), '_lr_%s' % cfg['learning_rate']]
+        if cfg['lr_mode'] != 'const':
+            parts.append('_scheduler_%s' % cfg['lr_mode'])
+        return ''.join(str(v) for v in parts)
 
     # ---- setup ---------------------------------------------------------------------------------
     def setup_log(self):
@@ -104,18 +112,24 @@ class SegmentationExperiment(BaseExperiment):
         # conv weight gradients on a second stream, accumulated into the optimiser's flat bucket (joined in zero_grad / step)
         ops.enable_async_wgrad(bool(self.config.get('async_wgrad', True)))
         # matrix mode of the 3x3x3 convolutions: 'fp32_split' (default, and what bench.py measures: fp32-accurate products from an exact
-        # three-way bf16 split on the bf16 matrix pipe), 'fp32' (the fp32 matrix instructions, the A/B) or 'bf16' (operands rounded,
+        # two-term fp16 split on the fp16 matrix pipe), 'fp32' (the fp32 matrix instructions, the A/B) or 'bf16' (operands rounded,
         # BASELINE config 5)
         ops.set_matrix_precision(self.config.get('matrix_precision') or ops.DEFAULT_MATRIX_PRECISION)
-        if self.config['lr_mode'] == 'plateau':
-            self.scheduler = lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='max',
-                                                            patience=100 // self.config['valid_epoch_period'],
-                                                            factor=0.2, threshold_mode='abs', threshold=0.003, min_lr=1e-5)
-        elif self.config['lr_mode'] == 'multiStep':
-            self.config['milestones'] = [int(ratio * self.config['n_epochs']) for ratio in self.config['milestones']]
-            self.scheduler = lr_scheduler.MultiStepLR(self.optimizer, self.config['milestones'], gamma=self.config['gamma'])
-        else:
-            self.scheduler = None
+        self.scheduler = self.make_scheduler(self.optimizer, self.config)
+
+    @staticmethod
+    def make_scheduler(optimizer, cfg):
+        """Learning-rate schedule of the reference (models/segmentation.py:93-111).  'plateau': x 0.2 when the validation score (maximised)
+        has not improved by 0.003 (absolute) for 100 epochs' worth of validations, never below 1e-5.  'multiStep': x gamma at the given
+        fractions of n_epochs (the config's `milestones` are replaced by the epoch numbers, as the reference does).  Anything else: constant."""
+        mode = cfg['lr_mode']
+        if mode == 'plateau':
+            validations = 100 // cfg['valid_epoch_period']
+            return lr_scheduler.ReduceLROnPlateau(optimizer, mode='max', factor=0.2, patience=validations, threshold=0.003, threshold_mode='abs', min_lr=1e-5)
+        if mode == 'multiStep':
+            cfg['milestones'] = [int(frac * cfg['n_epochs']) for frac in cfg['milestones']]
+            return lr_scheduler.MultiStepLR(optimizer, cfg['milestones'], gamma=cfg['gamma'])
+        return None
 
     # ---- training ------------------------------------------------------------------------------
     def train(self):

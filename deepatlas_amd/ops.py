@@ -177,9 +177,9 @@ DEFAULT_MATRIX_PRECISION = 'fp32_split'
 def set_matrix_precision(mode):
     """Arithmetic of the 3x3x3 convolutions on the matrix cores (process-wide; returns the previous mode):
     'fp32'        fp32 operands on the fp32 matrix instructions (one fmaf per product, like the reference's CPU convolution);
-    'fp32_split'  fp32 operands split exactly into three bf16 terms, six partial products per multiply on the bf16 matrix pipe with fp32
-                  accumulation: fp32-accurate (error against double not larger than 'fp32', tests/test_gpu_split.py) at 6/16 of the
-                  matrix time;
+    'fp32_split'  fp32 operands scaled by a per-tile power of two and split into two fp16 terms (22 significand bits), three partial products
+                  per multiply on the fp16 matrix pipe with fp32 accumulation: fp32-accurate (error against double not larger than 'fp32',
+                  tests/test_gpu_split.py; csrc/split_f16.h states the bounds) at 3/16 of the matrix time;
     'bf16'        operands ROUNDED to bf16 (BASELINE config 5); everything else stays fp32."""
     if mode not in MATRIX_MODES:
         raise ValueError("matrix precision must be one of %r, got %r" % (MATRIX_MODES, mode))

@@ -130,10 +130,12 @@ int da_set_matrix_bf16(int on);
  *   0  fp32 operands on v_mfma_f32_16x16x4_f32 -- one fmaf per product, the arithmetic of the reference's nn.Conv3d on the CPU
  *      (lib/network_factory/modules.py:48);
  *   1  = da_set_matrix_bf16(1): operands ROUNDED to bf16 (not fp32-accurate);
- *   2  "split": every fp32 operand is decomposed EXACTLY into three bf16 terms (x = h + m + l) and a product is formed from six of the
- *      nine partial products (h h, h m, m h, m m, h l, l h) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The dropped terms are
- *      below 2^-25 |x y|, i.e. below the rounding of one fp32 multiply-add: results are fp32-accurate (measured against double: not worse
- *      than mode 0, tests/test_gpu_split.py), at 6/16 of the matrix-pipe time.  Tensors in HBM stay fp32. */
+ *   2  "split": every staged tile is scaled by a power of two (its largest magnitude into [2^14, 2^15)) and every fp32 operand split into
+ *      two fp16 terms (x s = h + l to 2^-22 |x s|); a product is formed from three of the four partial products (h l', l h', h h') on
+ *      v_mfma_f32_16x16x32_f16 with fp32 accumulation, the accumulators rescaled by exact powers of two between tiles.  Per product the
+ *      error bound is 2^-21 + 2^-22 |x y| (typically one fp32 rounding); over the sums of a convolution the result is closer to double
+ *      than mode 0's fmaf chain (tests/test_gpu_split.py), at 3/16 of the matrix-pipe time.  Tensors in HBM stay fp32
+ *      (deepatlas_amd/csrc/split_f16.h). */
 int da_set_matrix_mode(int mode);
 
 /* ---- 1x1x1 convolution (segmentation head, row a5; unets.py:249-250) ------------------------- */

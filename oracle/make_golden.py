@@ -253,6 +253,23 @@ def run_eval(ref, out):
         for grp in ('multi_metric_res', 'label_avg_res', 'batch_avg_res'):
             for m, v in r[grp].items():
                 out['eval/multi_metric/%s/%s/%s' % (tag, grp, m)] = np.asarray(v, dtype=np.float64)
+    # lib/evalMetrics.py:17-100 metricEval: 'iou' over all labels of one volume; 'dice' / 'recall' / 'precision' on the binary masks of one
+    # class (the way models/segmentation.py:191-194 calls it).  NaN where the reference divides by zero (class absent).
+    # (a prediction that agrees with the truth on two voxels out of three: the two closed-form label maps above hardly overlap)
+    keep = (torch.arange(pred.numel()).view(pred.shape) % 3) != 0
+    pred2 = torch.where(keep, truth, pred)
+    out['eval/metricEval/pred'] = np32(pred2)
+    for b in range(2):
+        out['eval/metricEval/iou_n5/%d' % b] = np.float64(ref.metrics.metricEval('iou', pred2[b].numpy(), truth[b].numpy(), 5))
+        for m in ('dice', 'recall', 'precision'):
+            vals = []
+            for c in range(1, 5):
+                try:
+                    with np.errstate(invalid='ignore', divide='ignore'):
+                        vals.append(float(ref.metrics.metricEval(m, pred2[b].numpy() == c, truth[b].numpy() == c, num_labels=2)))
+                except ZeroDivisionError:
+                    vals.append(float('nan'))
+            out['eval/metricEval/%s_binary/%d' % (m, b)] = np.asarray(vals, dtype=np.float64)
 
 
 def run_reglosses(ref, out):

@@ -134,7 +134,7 @@ def test_every_block_bf16_storage_vs_rounding_oracle(bf16_storage, spec_name, n_
     inputs the only differences are bf16 rounding decisions of values that straddle a rounding boundary (one 2^-8 relative step on that
     element).  Whole-network comparisons are not meaningful at this tolerance: this 18-block BatchNorm'd net on closed-form weights amplifies
     an fp32 rounding difference ~1000x from input to logits, i.e. two valid bf16-storage evaluations differ by ~10 % at the logits
-    (tests/debug_bf16_layers.py prints the growth per block)."""
+    (tools/debug/debug_bf16_layers.py prints the growth per block)."""
     from oracle import nets
     import torch.nn.functional as F
     ops = bf16_storage

@@ -249,5 +249,72 @@ def test_whole_network_step_and_eval_dice_vs_cpu_oracle_at_metric_size():
     for r in res:
         assert r['loss_abs_diff'] <= 1e-4, r
         assert r['logits_rel_l2'] <= 1e-4 and r['eval_logits_rel_l2'] <= 1e-4, r
+        # max norm of the train-mode logits: north_star's 1e-4, or -- where the reference arithmetic itself is further than that from the
+        # exact result -- twice the fp32 oracle's own measured distance from the fp64 evaluation of the same network on the same batch
+        floor = r['oracle_fp32_max_abs_vs_fp64']
+        assert r['logits_max_abs_vs_fp64'] <= max(1e-4, 2.0 * floor), (r['logits_max_abs_vs_fp64'], floor)
+        assert r['logits_max_abs_over_max'] <= max(1e-4, 3.0 * floor), (r['logits_max_abs_over_max'], floor)
+        print('%s: logits max-abs vs oracle fp32 %.3e, vs fp64 %.3e; oracle fp32 vs fp64 (the floor) %.3e' % (r['matrix_precision'], r['logits_max_abs_over_max'], r['logits_max_abs_vs_fp64'], floor))
         assert r['flips_away_from_ties'] == 0 and r['nan_pattern_equal'], r
         assert r['eval_dice_abs_diff'] <= 1e-4 and r['eval_dice_mean_abs_diff'] <= 1e-4, r
+
+
+def test_reg_and_joint_steps_vs_cpu_oracle_at_metric_size():
+    """BASELINE configs[2] and configs[3]'s per-GPU shape as WHOLE steps at 1 x 160 x 192 x 160 (not only inside bench.py): the shipped
+    registration step (VoxelMorph + trilinear warp + NCC + bending + Adam; voxel_morph.py:62-92, lib/loss.py:493-501, 687-730) against
+    oracle.steps.reg_step, and the shipped joint DeepAtlas step (UNet_light, 32 classes, fused anatomy losses) against
+    oracle.steps.joint_step, on the same closed-form weights and structured synthetic pair: every loss term, the displacement field and
+    the warped image within north_star's 1e-4 (relative, l2 and max norm)."""
+    from oracle import nets, steps
+    from deepatlas_amd import ops
+    from deepatlas_amd.lib.datasets import SyntheticSegDataset
+    from deepatlas_amd.lib.network_factory import get_network
+    from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
+    from deepatlas_amd.optim import FlatAdam
+    shape, C, d = (160, 192, 160), 32, dev()
+    ds = SyntheticSegDataset(2, shape, C, seed=230)
+    im_m, sm = ds[0][0][None], ds[0][1][None]
+    im_t, st_ = ds[1][0][None], ds[1][1][None]
+    spec = nets.UNET_LIGHT
+    seg_sd = nets.closed_form_fill(nets.unet_param_shapes(1, C, spec['encoders'], spec['decoders']), seed=1)
+    reg_sd = nets.closed_form_fill(nets.voxelmorph_param_shapes(), seed=4)
+
+    def fresh_reg():
+        m = get_network('voxel_morph_cvpr')()
+        m.load_state_dict({k: v.clone() for k, v in reg_sd.items()}, strict=True)
+        return m.to(d)
+
+    def close(name, got, ref, tol=1e-4):
+        got, ref = got.detach().cpu().double(), ref.double()
+        e2, em = float((got - ref).norm() / ref.norm().clamp_min(1e-30)), float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        print('%-10s rel-l2 %.3e  max-abs %.3e' % (name, e2, em))
+        assert e2 <= tol and em <= tol, (name, e2, em)
+
+    prev = ops.set_matrix_precision(ops.DEFAULT_MATRIX_PRECISION)
+    try:
+        # ---- registration step
+        reg = fresh_reg()
+        rstep = RegistrationStep(reg, FlatAdam(reg.parameters(), lr=1e-3))
+        loss, (disp, warped, deform), (l_sim, l_bend) = rstep(im_m.to(d), im_t.to(d))
+        torch.cuda.synchronize()
+        o_sd = {k: v.clone() for k, v in reg_sd.items()}
+        o_loss, (o_disp, o_warped, o_deform), _, (o_sim, o_bend) = steps.reg_step(o_sd, steps.Adam(steps.trainable(o_sd)), im_m, im_t)
+        for nm, a, b in (('loss', loss, o_loss), ('ncc', l_sim, o_sim), ('bending', l_bend, o_bend)):
+            assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (nm, float(a), float(b))
+        close('disp', disp, o_disp); close('warped', warped, o_warped); close('deform', deform, o_deform)
+        del reg, rstep, disp, warped, deform, o_disp, o_warped, o_deform
+        # ---- joint step (labelled pair)
+        seg = get_network('UNet_light')(in_channel=1, n_classes=C, bias=True, BN=True)
+        seg.load_state_dict({k: v.clone() for k, v in seg_sd.items()}, strict=True)
+        seg.to(d)
+        reg = fresh_reg()
+        jstep = DeepAtlasJointStep(seg, FlatAdam(seg.parameters(), lr=1e-3), reg, FlatAdam(reg.parameters(), lr=1e-3), C)
+        out = jstep(im_m.to(d), im_t.to(d), sm.to(d), st_.to(d))
+        torch.cuda.synchronize()
+        s_sd, r_sd = {k: v.clone() for k, v in seg_sd.items()}, {k: v.clone() for k, v in reg_sd.items()}
+        ref = steps.joint_step(s_sd, steps.Adam(steps.trainable(s_sd)), r_sd, steps.Adam(steps.trainable(r_sd)), im_m, im_t, sm, st_, spec, C)
+        for k in ('sim', 'bend', 'anat_reg', 'sup', 'anat_seg', 'loss_reg', 'loss_seg'):
+            print('%-9s device %.7f oracle %.7f' % (k, out[k].item(), ref[k].item()))
+            assert abs(out[k].item() - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, out[k].item(), ref[k].item())
+    finally:
+        ops.set_matrix_precision(prev)

@@ -728,6 +728,29 @@ def test_label_overlap_counts_bit_exact(dtype):
         assert np.array_equal(c[n], ref)
 
 
+def test_metric_eval_label_map_forms_golden(golden):
+    """lib/evalMetrics.py:17-100 metricEval('iou' | 'dice' | 'recall' | 'precision') on label maps / binary class masks, served by
+    da_label_overlap_counts, vs the reference's own outputs (NaN = the reference raised ZeroDivisionError: so must we)."""
+    from deepatlas_amd.lib import evalMetrics as em
+    g = golden('eval')
+    pred, truth = g['eval/metricEval/pred'].astype(np.int64), g['eval/truth'].astype(np.int64)
+    for b in range(2):
+        assert abs(em.metricEval('iou', pred[b], torch.from_numpy(truth[b]).cuda(), 5) - float(g['eval/metricEval/iou_n5/%d' % b])) < 1e-12
+        for m in ('dice', 'recall', 'precision'):
+            ref = g['eval/metricEval/%s_binary/%d' % (m, b)]
+            for c in range(1, 5):
+                if np.isnan(ref[c - 1]) and m != 'dice':
+                    with pytest.raises(ZeroDivisionError):
+                        em.metricEval(m, pred[b] == c, truth[b] == c, num_labels=2)
+                else:
+                    v = em.metricEval(m, pred[b] == c, truth[b] == c, num_labels=2)
+                    assert (np.isnan(v) and np.isnan(ref[c - 1])) or abs(v - ref[c - 1]) < 1e-12, (m, b, c, v, ref[c - 1])
+    with pytest.raises(NotImplementedError):
+        em.metricEval('recall', pred[0], truth[0], num_labels=5)
+    with pytest.raises(ValueError):
+        em.metricEval('f1', pred[0], truth[0], num_labels=2)
+
+
 def test_full_size_label_metrics_properties():
     """160x192x160: Dice(x, x) = 1 for every present class, counts conserve the voxel count, multi-metric of identical maps = 1."""
     from deepatlas_amd.lib import evalMetrics as em

@@ -1,5 +1,5 @@
-"""Split matrix mode ('fp32_split', da_set_matrix_mode(2)): fp32 operands decomposed exactly into three bf16 terms, six partial products
-per multiply on the bf16 matrix pipe, fp32 accumulation.  The claim to pin is ACCURACY: against a double-precision evaluation of the
+"""Split matrix mode ('fp32_split', da_set_matrix_mode(2)): fp32 operands scaled by a per-tile power of two and split into two fp16 terms,
+three partial products per multiply on the fp16 matrix pipe, fp32 accumulation (deepatlas_amd/csrc/split_f16.h).  The claim to pin is ACCURACY: against a double-precision evaluation of the
 reference's convolution (nn.Conv3d, lib/network_factory/modules.py:48) the split must not be worse than the fp32 fmaf chain of mode
 'fp32' (v_mfma_f32_16x16x4_f32) -- i.e. it is an fp32 convolution, not a reduced-precision one -- on well-conditioned, badly
 conditioned (wide dynamic range) and cancelling inputs; and it must pass the same 1e-5 criteria as the exact kernels."""
@@ -86,7 +86,7 @@ def test_split_mode_is_fp32_accurate(case, kind):
         e_nat, e_sp = rel_l2(a.numpy().astype(np.float64), r), rel_l2(s.numpy().astype(np.float64), r)
         m_nat, m_sp = max_abs_rel(a.numpy().astype(np.float64), r), max_abs_rel(s.numpy().astype(np.float64), r)
         # not worse than the fmaf chain beyond half an fp32 ulp (2^-24 = 6e-8: where the chain's own error is below one rounding -- sums
-        # dominated by a single product -- the split's six partial sums each round once), and far inside the 1e-5 of the exact-kernel tests
+        # dominated by a single product -- the split's three partial sums each round once and a single product carries up to 2^-21), and far inside the 1e-5 of the exact-kernel tests
         assert e_sp <= 1.25 * e_nat + 6e-8, '%s: split rel-l2 %.3e vs fp32 chain %.3e' % (nm, e_sp, e_nat)
         assert m_sp <= 1.5 * m_nat + 1.2e-7, '%s: split max-abs %.3e vs fp32 chain %.3e' % (nm, m_sp, m_nat)
         assert e_sp < 1e-5 and m_sp < 1e-5, (nm, e_sp, m_sp)
@@ -129,7 +129,7 @@ def test_native_stride2_split_kernels_are_fp32_accurate(case, kind):
         e_nat, e_sp = rel_l2(a.numpy().astype(np.float64), r), rel_l2(s.numpy().astype(np.float64), r)
         m_nat, m_sp = max_abs_rel(a.numpy().astype(np.float64), r), max_abs_rel(s.numpy().astype(np.float64), r)
         # (one fp32 ulp of slack, 2^-23: with log-normal magnitudes a sum is dominated by ONE product, the chain's error is below a single
-        # rounding and the split's six partial sums round once each)
+        # rounding and the split's three partial sums round once each)
         assert e_sp <= 1.25 * e_nat + 1.2e-7, '%s: split rel-l2 %.3e vs fp32 chain %.3e' % (nm, e_sp, e_nat)
         assert m_sp <= 1.5 * m_nat + 2.4e-7, '%s: split max-abs %.3e vs fp32 chain %.3e' % (nm, m_sp, m_nat)
         assert e_sp < 1e-5 and m_sp < 1e-5, (nm, e_sp, m_sp)

@@ -104,7 +104,7 @@ def test_matrix_precision_switch_round_trip():
     try:
         assert prev in ops.MATRIX_MODES
         assert ops.set_matrix_precision('fp32') == 'bf16'
-        assert ops.set_matrix_precision('fp32_split') == 'fp32'            # the exact three-way split (da_set_matrix_mode(2))
+        assert ops.set_matrix_precision('fp32_split') == 'fp32'            # the two-term fp16 split (da_set_matrix_mode(2))
         assert ops.set_matrix_precision('fp32') == 'fp32_split'
         assert ops.set_matrix_precision('fp32') == 'fp32'
         with pytest.raises(ValueError):
@@ -142,44 +142,73 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     assert L.da_maxpool2_fwd(fake, fake, 0, 8, 8, 8, 16, None) == BAD
 
 
-def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_accurate():
-    """The arithmetic behind the split matrix mode, restated in numpy: x = h + m + l EXACTLY with h = bf16(x), m = bf16(x - h),
-    l = bf16(x - h - m) (round-to-nearest-even), for normal, huge and wide-dynamic-range fp32 values (|x| >= 2^-100; absolute error <= 2^-133 below); and the six partial products
-    h h' + h m' + m h' + m m' + h l' + l h' reproduce x y to better than one fp32 rounding (the dropped terms are <= 2^-23 |x y|)."""
+def test_two_term_fp16_split_bounds_and_sums_are_fp32_accurate():
+    """The arithmetic behind the split matrix mode (deepatlas_amd/csrc/split_f16.h), restated in numpy.  A tile is scaled by a
+    power of two so that its largest magnitude lies in [2^14, 2^15); h = fp16(x s), l = fp16(x s - h) (round-to-nearest-even, the subtraction
+    exact in fp32).  Pinned here: (1) |x s - h - l| <= 2^-22 |x s| for every element within 2^-18 of the tile maximum and <= 2^-25 (absolute,
+    scaled units: 2^-39 of the maximum) below; (2) the three products h h' + h l' + l h' are within 2^-21 + 2^-22 of x y, typically at the
+    size of one fp32 rounding; (3) a K = 432 dot product accumulated the way the matrix cores do (32 products per fp32 rounding, three
+    roundings per K-step) is closer to the double-precision value than the fp32 fmaf chain, on uniform and on wide-dynamic-range data."""
     import numpy as np
 
-    def bf16(a):                                  # fp32 -> bf16 (round to nearest even) -> fp32
-        u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)
-        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-        return r.astype(np.uint32).view(np.float32)
+    def scale_exp(m):                              # da_scale_exp: m 2^e in [2^14, 2^15), clamped to +-100; zero -> +100
+        if m == 0:
+            return 100
+        return int(np.clip(14 - np.floor(np.log2(m)), -100, 100))
+
+    def split2(x, e):
+        xs = (x.astype(np.float32) * np.float32(2.0 ** e)).astype(np.float32)       # exact (power of two; no overflow by construction)
+        h = xs.astype(np.float16)
+        r = (xs - h.astype(np.float32)).astype(np.float32)
+        assert np.array_equal(r.astype(np.float64), xs.astype(np.float64) - h.astype(np.float64)), 'the remainder is exact in fp32'
+        return xs, h.astype(np.float32), r.astype(np.float16).astype(np.float32)
 
     rng = np.random.default_rng(7)
-    x = np.concatenate([rng.standard_normal(200000), rng.standard_normal(50000) * np.exp(8 * rng.standard_normal(50000)),
-                        [1.0, -1.0, 3.0e38, -3.0e38, 1.2e-38, 2.0 ** -100, 1.0 + 2.0 ** -23, 255.99998]]).astype(np.float32)
-    h = bf16(x)
-    r1 = (x - h).astype(np.float32)               # exact: |r1| <= ulp_bf16(x) / 2 has at most 16 significant bits
-    assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - h.astype(np.float64))
-    m = bf16(r1)
-    r2 = (r1 - m).astype(np.float32)
-    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - m.astype(np.float64))
-    l = bf16(r2)
-    big = np.abs(x) >= 2.0 ** -100                # below ~2^-109 the last term enters bf16's denormal range (absolute error <= 2^-133 there)
-    assert np.array_equal(l[big], r2[big]), 'the second remainder has at most 8 significant bits'
-    assert np.array_equal((h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64))[big], x.astype(np.float64)[big])
-    assert np.all(np.abs(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64) - x.astype(np.float64)) <= 2.0 ** -133)
-    assert np.all(np.abs(m) <= np.abs(x) * 2.0 ** -8) and np.all(np.abs(l)[big] <= np.abs(x)[big] * 2.0 ** -16)
-    # six of the nine partial products against the exact product (float64 holds both exactly)
-    y = rng.permutation(x)
-    hy = bf16(y); my = bf16((y - hy).astype(np.float32)); ly = ((y - hy).astype(np.float32) - my).astype(np.float32)
-    H, M, L, Hy, My, Ly = [a.astype(np.float64) for a in (h, m, l, hy, my, ly)]
-    six = H * Hy + H * My + M * Hy + M * My + H * Ly + L * Hy
-    exact = x.astype(np.float64) * y.astype(np.float64)
-    ok = np.isfinite(exact) & (np.abs(x) >= 2.0 ** -60) & (np.abs(y) >= 2.0 ** -60) & (np.abs(exact) < 1e300)
-    rel = np.abs(six - exact)[ok] / np.abs(exact)[ok]
-    assert rel.max() <= 2.0 ** -23 and np.sqrt(np.mean(rel ** 2)) < 2.0 ** -26, (rel.max(), np.sqrt(np.mean(rel ** 2)))
-    with np.errstate(over='ignore'):
-        fp32_rounding = np.abs((x * y).astype(np.float64) - exact)[ok] / np.abs(exact)[ok]      # one fp32 multiply for comparison
-    assert np.sqrt(np.mean(rel ** 2)) < np.sqrt(np.mean(fp32_rounding[np.isfinite(fp32_rounding)] ** 2))
+    x = np.concatenate([rng.standard_normal(200000), rng.standard_normal(50000) * np.exp(4 * rng.standard_normal(50000)),
+                        [1.0, -1.0, 1.0 + 2.0 ** -23, 255.99998, 3.0e-6, 65504.0, 1.0e-30]]).astype(np.float32)
+    e = scale_exp(float(np.abs(x).max()))
+    xs, h, l = split2(x, e)
+    assert np.all(np.isfinite(h)) and np.abs(xs).max() < 2.0 ** 15 and np.abs(xs).max() >= 2.0 ** 14
+    err = np.abs(xs.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
+    window = np.abs(xs) >= 2.0 ** -3               # l stays a normal fp16 (|l| >= 2^-14) for |x s| >= 2^-3, i.e. within 2^-18 of the maximum
+    assert np.all(err[window] <= 2.0 ** -22 * np.abs(xs[window]))
+    assert np.all(err <= np.maximum(2.0 ** -22 * np.abs(xs), 2.0 ** -25))
+    # (2) three of the four partial products against the exact product, both operands inside their windows
+    a = rng.uniform(0.25, 2.0, 200000).astype(np.float32) * rng.choice([-1.0, 1.0], 200000).astype(np.float32)
+    b = rng.permutation(a)
+    ea, eb = scale_exp(float(np.abs(a).max())), scale_exp(float(np.abs(b).max()))
+    _, ha, la = split2(a, ea)
+    _, hb, lb = split2(b, eb)
+    three = (ha.astype(np.float64) * lb + la.astype(np.float64) * hb + ha.astype(np.float64) * hb) * 2.0 ** -(ea + eb)
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    rel = np.abs(three - exact) / np.abs(exact)
+    fp32_rounding = np.abs((a * b).astype(np.float64) - exact) / np.abs(exact)      # one fp32 multiply for comparison
+    assert rel.max() <= 2.0 ** -21 + 2.0 ** -22 and np.sqrt(np.mean(rel ** 2)) < 4 * np.sqrt(np.mean(fp32_rounding ** 2)), (rel.max(), np.sqrt(np.mean(rel ** 2)))
+    # (3) K = 432 (16 input channels x 27 taps) dot products: MFMA-style accumulation of the split against the fmaf chain, both against double
+    for kind in ('uniform', 'wide'):
+        M, K = 400, 432
+        if kind == 'uniform':
+            xv = rng.uniform(-1, 1, (M, K)).astype(np.float32); wv = rng.uniform(-0.1, 0.1, (M, K)).astype(np.float32)
+        else:
+            xv = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-12, 0, (M, K)))).astype(np.float32)
+            wv = (rng.standard_normal((M, K)) * 0.05 * np.exp(rng.uniform(-6, 0, (M, K)))).astype(np.float32)
+        ref = (xv.astype(np.float64) * wv.astype(np.float64)).sum(-1)
+        chain = np.zeros(M, np.float32)
+        for k in range(K):
+            chain = (chain.astype(np.float64) + xv[:, k].astype(np.float64) * wv[:, k].astype(np.float64)).astype(np.float32)      # fmaf: one rounding per product
+        sp = np.zeros(M, np.float64)
+        for r in range(M):                         # per-row scales stand in for the per-tile scales
+            ex, ew = scale_exp(float(np.abs(xv[r]).max())), scale_exp(float(np.abs(wv[r]).max()))
+            _, hx, lx = split2(xv[r], ex)
+            _, hw, lw = split2(wv[r], ew)
+            acc = np.float32(0)
+            for k0 in range(0, K, 32):             # one v_mfma_f32_16x16x32_f16 per plane pair: 32 exact products, summed, one fp32 rounding
+                for pa, pb in ((hx, lw), (lx, hw), (hx, hw)):
+                    acc = np.float32(np.float64(acc) + (pa[k0:k0 + 32].astype(np.float64) * pb[k0:k0 + 32].astype(np.float64)).sum())
+            sp[r] = np.float64(acc) * 2.0 ** -(ex + ew)
+        den = np.sqrt(np.mean(ref ** 2))
+        e_chain, e_split = np.sqrt(np.mean((chain - ref) ** 2)) / den, np.sqrt(np.mean((sp - ref) ** 2)) / den
+        assert e_split < e_chain and e_split < 3e-7, (kind, e_chain, e_split)
 
 
 def test_asan_build_recipe_and_roctx_ranges(tmp_path):

@@ -42,14 +42,14 @@ def main():
         pass
     if mode == 2:
         # (the data gradient 16 -> 48 runs the forward kernel with one N-tile per workgroup and three cout groups: 168 x 3 workgroups)
-        sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true, 0, true, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_split_wgrad_kernel<false, 3, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+        sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false, 2>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true, 0, true, false, 2>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false, 2>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_split_wgrad_kernel<false, 2, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     else:
-        sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false, 0, false, false>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false, 0, false, false>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false, 0, false, false>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+        sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
     # data gradient: collected in its own process (tools/pmc_conv.sh); per call = the sum over its conv kernels (split mode: two launches)
     dg_calls = 6.0                                   # bench_conv.py --iters 3: 3 warm-up + 3 timed calls

@@ -60,7 +60,7 @@ def main(argv=None):
     parser.add_argument('--shape', nargs=3, type=int, default=[64, 64, 64], help='synthetic volume size D H W (multiples of 8)')
     parser.add_argument('--matrix-precision', default=None, choices=['fp32', 'fp32_split', 'bf16'],
                         help="arithmetic of the 3x3x3 convolutions: 'fp32_split' (default; what bench.py measures) fp32-accurate products from an exact "
-                             "three-way bf16 split on the bf16 matrix pipe; 'fp32' the fp32 matrix instructions (A/B, ~1.35x slower); 'bf16' operands "
+                             "two-term fp16 split on the fp16 matrix pipe; 'fp32' the fp32 matrix instructions (A/B, ~1.35x slower); 'bf16' operands "
                              "rounded to bf16 (not fp32-accurate)")
     args = parser.parse_args(argv)
     exp = SegmentationExperiment(build_config(args))
