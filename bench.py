@@ -362,6 +362,7 @@ def time_workload(wl, args, world, dev, prof_names=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = wl.step()
+    t_issued = time.perf_counter()                 # the host has queued every launch of the K steps; the device is still working them off
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -369,13 +370,15 @@ def time_workload(wl, args, world, dev, prof_names=None):
     dt = time.perf_counter() - t0
     nat.profiler = None
     launches = (nat.n_calls - n0) / max(args.steps, 1)
-    per_rank = [dt]
+    per_rank, host_rank = [dt], [t_issued - t0]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, t_issued - t0], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        per_rank = [float(v.item()) for v in allt]
+        per_rank = [float(v[0].item()) for v in allt]
+        host_rank = [float(v[1].item()) for v in allt]
         dt = max(per_rank)
+    time_workload.host_issue = host_rank           # (read by result_of: seconds each rank's Python loop took to ISSUE the K steps)
     return dt, per_rank, float(loss.item()), prof, launches
 
 
@@ -389,8 +392,16 @@ def result_of(wl, dt, per_rank, world, args, launches):
             r['step_frac_of_fp32_mfma_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
         if args.precision == 'fp32_split':
             r['step_frac_of_split_peak'] = round(wl.flops_per_step / (ms * 1e-3) / 1e12 / SPLIT_MFMA_PEAK_TFLOPS, 4)
+    # host-side issue time of a step (Python + ctypes + HIP launch calls) next to the step time: a rank whose issue time approaches its step
+    # time is host-bound -- with N launch loops on one host that is the first thing to look at when the scaling curve bends
+    hi = getattr(time_workload, 'host_issue', None)
+    if hi:
+        r['host_issue_ms_per_step'] = round(max(hi) / args.steps * 1e3, 3)
+        r['host_issue_frac_of_step'] = round(max(hi) / dt, 3)
     if world > 1:
         r['ms_per_step_per_rank'] = [round(t / args.steps * 1e3, 3) for t in per_rank]
+        if hi:
+            r['host_issue_ms_per_step_per_rank'] = [round(t / args.steps * 1e3, 3) for t in hi]
     return r
 
 
@@ -544,7 +555,7 @@ def main():
         tt = torch.tensor([(time.perf_counter() - t0) / 20 * 1e3], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         allreduce = dict(ms_per_step=round(float(tt.item()), 4), collectives_per_step=len(buckets), bytes=[int(o.flat_g.numel() * 4) for o in buckets],
-                         note="the step's flat-bucket gradient all-reduce(s) (sum + in-place average) timed on their own: mean of 20, max over ranks")
+                         note="the step's flat-bucket gradient all-reduce(s) (average inside the collective on RCCL) timed on their own: mean of 20, max over ranks")
 
     bwd_rows = []
     peak = SPLIT_MFMA_PEAK_TFLOPS if args.precision == 'fp32_split' else FP32_MFMA_PEAK_TFLOPS
@@ -676,7 +687,8 @@ def main():
                                 parallelism='dp%d' % world, final_loss=round(final_loss, 6), matrix_precision=args.precision,
                                 matrix_arithmetic=PRECISION_NOTE[args.precision],
                                 c_abi_launches_per_step=head_res['c_abi_launches_per_step'], hip_graph=bool(args.graph), rccl=rccl,
-                                ms_per_step_per_rank=head_res.get('ms_per_step_per_rank'), allreduce=allreduce,
+                                ms_per_step_per_rank=head_res.get('ms_per_step_per_rank'), host_issue_ms_per_step=head_res.get('host_issue_ms_per_step'),
+                                host_issue_ms_per_step_per_rank=head_res.get('host_issue_ms_per_step_per_rank'), allreduce=allreduce,
                                 host_cores_per_rank=pinned[1] if pinned else None),
                     roofline=roofline, extra=extra or None)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'seg' and args.net == 'UNet_light':
@@ -695,6 +707,8 @@ def main():
         # flat copies of the numbers a reader of the driver's record needs (its parser keeps top-level scalars only)
         if sync_ms is not None:
             line['ms_per_step_with_loss_item'] = sync_ms
+        if head_res.get('host_issue_ms_per_step') is not None:
+            line['host_issue_ms_per_step'] = head_res['host_issue_ms_per_step']
         for leg in ('reg', 'joint'):
             if leg in extra:
                 line['%s_ms_per_step' % leg] = extra[leg]['ms_per_step']

@@ -4,6 +4,8 @@ Hot path: 'dice' -> DiceLossMultiClass, 'ncc' -> Normali
 'bendingEnergy' -> BendingEnergyLoss; SURVEY.md §8f f2: 'lncc' -> VoxelMorphLNCC, 'gradient' -> gradientLoss (reglosses.hip).
 'mse' / 'L2' are one-line compositions; 'focal' / 'cross_entropy' / 'soft_cross_entropy' share one voxelwise HIP kernel pair (xent.hip).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -205,9 +207,15 @@ class SoftCrossEntropy(nn.Module):
     def forward(self, pred, target):
         shape = list(pred.shape)
         if len(target.shape) == len(shape) - 1:
+            # (B == C > 1 is the one other shape the reference's right-aligned multiplication accepts -- it then pairs target[b] with CLASS b
+            # of every sample, which no caller can mean: rejected here on purpose like every other B > 1)
             if shape[0] != 1:
                 raise RuntimeError("SoftCrossEntropy: an index target does not broadcast against the predictions in the reference for B > 1 "
                                    "(lib/loss.py:151-153 use `target`, not the one-hot `target_flat`); pass class probabilities B x C x ...")
+            if os.environ.get('DA_CHECK_LABELS') == '1' and self.n_class is not None:       # the reference one-hots the labels first (mask_to_one_hot raises on out-of-range)
+                lo, hi = int(target.min().item()), int(target.max().item())
+                if lo < 0 or hi >= self.n_class:
+                    raise RuntimeError('SoftCrossEntropy: label out of range [0, %d): min %d max %d' % (self.n_class, lo, hi))
             target = target.to(pred.dtype).unsqueeze(1).expand(shape).contiguous()        # the reference's broadcast at B = 1 (see the class docstring)
         if target.shape[1] != shape[1]:
             raise ValueError("Incorrect size of target tensor: {}, should be {} or []".format(target.shape, shape,

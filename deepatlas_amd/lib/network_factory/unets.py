@@ -20,7 +20,7 @@ def init_conv_weights(m):
     classname = m.__class__.__name__
     if classname.find('Conv') != -1:
         if not m.weight is None:
-            nn.init.xavier_normal_(m.weight.data)
+            ops.init_into(m.weight, nn.init.xavier_normal_)
         if not m.bias is None:
             m.bias.data.zero_()
 
@@ -178,7 +178,7 @@ class UNet(nn.Module):
             classname = m.__class__.__name__
             if classname.find('Conv') != -1:
                 if not m.weight is None:
-                    nn.init.xavier_normal_(m.weight.data)
+                    ops.init_into(m.weight, nn.init.xavier_normal_)
                 if not m.bias is None:
                     m.bias.data.zero_()
         ops.bump_weights_epoch()

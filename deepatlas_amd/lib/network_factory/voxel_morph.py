@@ -72,7 +72,7 @@ class VoxelMorphCVPR2018(nn.Module):
             classname = m.__class__.__name__
             if classname.find('Conv') != -1:
                 if not m.weight is None:
-                    nn.init.xavier_normal_(m.weight.data)
+                    ops.init_into(m.weight, nn.init.xavier_normal_)
                 if not m.bias is None:
                     m.bias.data.zero_()
         ops.bump_weights_epoch()              # `.data` writes do not move torch's version counters: drop the cached weight layouts

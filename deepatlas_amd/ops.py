@@ -195,6 +195,21 @@ DETERMINISTIC = os.environ.get('DA_DETERMINISTIC') == '1'
 CHECK_LABELS = os.environ.get('DA_CHECK_LABELS') == '1'      # validate index targets of the cross-entropy family like torch does (host sync per call)
 
 
+def init_into(param, init_fn):
+    """Fill a parameter with `init_fn` (an nn.init.*_ function) in the element order of a CONTIGUOUS tensor of its shape.  Tagged convolution
+    weights are strided views of FlatAdam's tap-major buckets once an optimiser exists; a random fill of the view itself would walk
+    memory order and hand the same random stream to different elements than the reference's contiguous parameter gets
+    (lib/network_factory/unets.py:61-67): same seed, different weights.  Drawing into a contiguous temporary and copying keeps
+    seed-for-seed reproducibility against the reference and against DA_NO_NATIVE_TIO=1."""
+    with torch.no_grad():
+        if param.data.is_contiguous():
+            init_fn(param.data)
+        else:
+            tmp = torch.empty(param.shape, dtype=param.dtype, device=param.device)
+            init_fn(tmp)
+            param.data.copy_(tmp)
+
+
 def set_deterministic(flag=True):
     global DETERMINISTIC
     prev, DETERMINISTIC = DETERMINISTIC, bool(flag)
@@ -1492,7 +1507,8 @@ class SegPhaseLossFn(Function):
         lm = coef_s = None
         bm = 0
         loss_s = torch.zeros((1,), dtype=torch.float32, device=a.device)
-        wp, wn = _ws(nat.lib().da_dice_ws_bytes(N, V, C), a)
+        # ONE workspace for both Dice entries (a second, larger _ws request on the same stream would replace -- and free -- the first)
+        wp, wn = _ws(max(nat.lib().da_dice_ws_bytes(N, V, C), nat.lib().da_warp_dice_ws_bytes(N, C)), a)
         prob = torch.empty_like(a)
         fused_fwd = os.environ.get('DA_NO_FUSED_SEGPHASE_FWD') != '1'
         if labels_m is not None:
@@ -1508,7 +1524,7 @@ class SegPhaseLossFn(Function):
         loss_a = _empty((1,), a)
         coef_a = _empty((2, N, C), a)
         # ... and the anatomy Dice of the WARPED probabilities without writing the warped tensor (da_warp_dice_fwd)
-        wp2, wn2 = _ws(nat.lib().da_warp_dice_ws_bytes(N, C), a)
+        wp2, wn2 = wp, wn
         warped = None
         if not (fused_fwd and call_supported('da_warp_dice_fwd', ptr(prob), ptr(u), ptr(lt), bt, N, D, H, W, C, wt, nb, float(eps),
                                              ptr(loss_a), ptr(coef_a), wp2, wn2, st)):

@@ -101,6 +101,16 @@ class FlatAdam(torch.optim.Optimizer):
             if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 ops.param_view(self.flat_g, off, p).copy_(p.grad)
                 p.grad = ops.param_view(self.flat_g, off, p)
+                p._da_gz = False                    # the slice is no longer all zeros
+
+    def grads_written(self, params=None):
+        """Tell the optimiser that gradient slices were written from OUTSIDE this package after zero_grad() (a hook that adds into
+        `p.grad`, manual gradient accumulation across micro-batches through `p.grad.add_`): the next weight gradient of those
+        parameters is then accumulated instead of written straight over the (assumed all-zero) slice.  Every writer inside the package
+        (ops.WgradTarget, ops.grad_for_autograd, _gather_stray_grads) keeps the `_da_gz` marks itself."""
+        for p, _, _ in self._slices:
+            if params is None or any(p is q for q in params):
+                p._da_gz = False
 
     def _frozen_mask(self):
         """1.0 for elements whose parameter takes part in the update, 0.0 for frozen ones (requires_grad=False or no gradient this

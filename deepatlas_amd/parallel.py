@@ -4,8 +4,9 @@ The reference is single-process.  Volumes shard on the bat
 per-replica (= the reference's batch-1 statistics); the only exchange is the mean of the gradients, which
 FlatAdam keeps in ONE contiguous fp32 buffer (seg 3.5 MB / reg 1.0 MB): a single torch.distributed all-reduce
 (backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests).  allreduce_gradients(average=True) (the default, what
-every caller in this package uses) divides the reduced bucket by world_size in place; callers that prefer to fold the scale into
-the Adam kernel call allreduce_gradients(average=False) and optimizer.step(grad_scale=1/world_size) -- never both.
+every caller in this package uses) leaves the MEAN in the bucket: on RCCL the collective itself averages (ReduceOp.AVG), elsewhere the
+reduced bucket is divided in place; callers that prefer to fold the scale into the Adam kernel call allreduce_gradients(average=False)
+and optimizer.step(grad_scale=1/world_size) -- never both.
 """
 import torch
 import torch.distributed as dist
@@ -23,10 +24,25 @@ def rank():
     return dist.get_rank() if is_dist() else 0
 
 
+_avg_in_collective = None          # None: not tried yet; True / False: the backend does / does not take ReduceOp.AVG
+
+
 def allreduce_flat_(flat, average=True):
-    """Sum (and average) a flat gradient bucket across ranks, in place.  No-op for a single process."""
+    """Sum (and average) a flat gradient bucket across ranks, in place.  No-op for a single process.  On RCCL the average is part of
+    the collective (ReduceOp.AVG: no second pass over the bucket, one launch less per optimiser step); gloo (the CPU tests) and any
+    backend that refuses AVG -- every rank gets the same refusal from the argument check, before any communication -- sum and divide."""
+    global _avg_in_collective
     if not is_dist() or dist.get_world_size() == 1:
         return flat
+    if average and _avg_in_collective is not False and dist.get_backend() == 'nccl':
+        try:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            _avg_in_collective = True
+            return flat
+        except (RuntimeError, ValueError):
+            if _avg_in_collective:          # it worked before: a real failure, not a refusal
+                raise
+            _avg_in_collective = False
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.div_(dist.get_world_size())
