@@ -1325,11 +1325,11 @@ struct WgP {
     S2dSrc s2in;                        // MASKED: in1 is the original tensor of a stride-2 layer, read as its space-to-depth view (cin > 0)
 };
 
-__global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
+__global__ void wgrad_tiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz, int tzv) {      // tzv: z planes per tile (2 | 4)
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < ntiles; pos += gridDim.x * blockDim.x) {
         int n, tx, ty, tz;
-        brick_tile<2, 4, 16>(pos, ntx, nty, ntz, n, tx, ty, tz);                                // brick = 32^3 voxels
-        tiles[pos] = make_int4(n, tz * 2, ty * TY, tx * TX);
+        if (tzv == 2) brick_tile<2, 4, 16>(pos, ntx, nty, ntz, n, tx, ty, tz); else brick_tile<2, 4, 8>(pos, ntx, nty, ntz, n, tx, ty, tz);      // brick = 32^3 voxels
+        tiles[pos] = make_int4(n, tz * tzv, ty * TY, tx * TX);
     }
 }
 
@@ -1579,6 +1579,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 #ifndef DA_WG_ZPAD
 #define DA_WG_ZPAD 4
 #endif
+#ifndef DA_WG_TZ
+#define DA_WG_TZ 2      // z planes per tile of the split weight gradient (4: two z-plane pairs per staged tile -- measured 48 -> 16 2.01 -> 1.85 ms but 16 -> 16 0.64 -> 0.70: spills at 256 VGPRs; kept for A/B builds)
+#endif
 template <bool PRO, int NPL = 2, bool HB = false>
 __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     static_assert(!HB || NPL == 1, "bf16 activation storage goes with the bf16 matrix mode");
@@ -1588,7 +1591,8 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     constexpr bool RAWA = HB && !SPL && !PRO, RAWY = HB && !SPL;       // bf16 tensors copied straight into the bf16 LDS image (da_buf_loadq)
     constexpr unsigned ES = HbEl<HB>::ES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CK = 8, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX;
+    constexpr int CK = 8, CG = 16, TZ = DA_WG_TZ, HZ = TZ + 2, TVOX = TZ * TY * TX;      // tile 4 x 8 x 16: two z-plane pairs per staged tile (half the barriers and tile-table reads per MFMA, halo 2.1x instead of 2.8x)
+    static_assert(TZ == 2 || TZ == 4, "one or two z-plane pairs per tile");
     constexpr int ZPQ = DA_WG_ZPAD, ZPE = 4 * ZPQ;                         // padding after every z plane of the x tile: quads / elements
     constexpr int PLA = HZ * (HY * HX * CK + ZPE), PLY = TVOX * CG;        // elements per plane
     float* ldsA = lds;
@@ -1630,8 +1634,9 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     };
     struct F3 { WFrag p[NPL]; };
+    int zpA = 0, zpY = 0;                                                  // element offsets of the z-plane pair being accumulated
     auto loadF = [&](int c, int h) -> F3 {                                  // x fragment of class c, halo row 2 wave + h
-        F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * CK);
+        F3 f; const short* a = ldsAh + laneA + zpA + offC[c] + h * (HX * CK);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
         return f;
@@ -1640,13 +1645,13 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     // halo rows (2 wave + h | 2 wave + h + 1).  Its three dy then need two accumulators instead of three: 14 instead of 15 MFMA groups per
     // row pair (27 taps in 28 slots instead of 30).
     auto loadG = [&](int h) -> F3 {
-        F3 f; const short* a = ldsAh + laneA + offC[4] + (h + (q >> 1)) * (HX * CK);
+        F3 f; const short* a = ldsAh + laneA + zpA + offC[4] + (h + (q >> 1)) * (HX * CK);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * CK);
         return f;
     };
     auto loadY = [&](int r) -> F3 {                                         // dY fragment of output row 2 wave + r
-        F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
+        F3 f; const short* a = ldsYh + laneY + zpY + r * (TX * CG);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLY, 4 * CG);
         return f;
@@ -1766,6 +1771,9 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                 for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * f;
             Eacc = Enext;
         }
+#pragma unroll
+        for (int zp = 0; zp < TZ / 2; ++zp) {                   // the tile's z-plane pairs (K = 16 voxels x the two planes of a pair)
+        zpA = zp * 2 * (HY * HX * CK + ZPE); zpY = zp * 2 * (TY * TX * CG);
         F3 Y0 = loadY(0), Y1 = loadY(1);
         F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
 #pragma unroll
@@ -1803,6 +1811,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                 acc[4][1] = mma(acc[4][1], Fd.p[PA[pr]], Y1.p[PB[pr]]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if (has_next) {
             if (p.prio_ranks == -1) __builtin_amdgcn_s_setprio(0);
@@ -2049,7 +2058,7 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
     if (split && q.CK) { q.CK = 8; q.NREP = 1; }             // split mode: two fp16 planes of x and dY in LDS -> 8-channel chunks, one cout tile
     q.ngroups = (NT + q.NREP - 1) / q.NREP;
     q.nchunks = q.CK ? (C1 + C2) / q.CK : 1;
-    q.ntz = (D + 1) / 2; q.nty = (H + TY - 1) / TY; q.ntx = (W + TX - 1) / TX;
+    q.ntz = (split && q.CK) ? (D + DA_WG_TZ - 1) / DA_WG_TZ : (D + 1) / 2; q.nty = (H + TY - 1) / TY; q.ntx = (W + TX - 1) / TX;      // (the row-owner kernel: DA_WG_TZ planes per tile)
     q.ntiles = N * q.ntz * q.nty * q.ntx;
     const size_t O = (size_t)27 * (C1 + C2) * Cout;
     long long slabs = 512 / (q.nchunks * q.ngroups); if (slabs < 1) slabs = 1;      // one resident round: 2 workgroups / CU
@@ -2452,7 +2461,7 @@ static int launch_wgrad_mfma(const WgP& p, const WgPlan& q, hipStream_t st) {
 
 template <bool PRO, int NPL = 2, bool HB = false>
 static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
-    size_t shm = (size_t)(4 * (HY * HX * 8 + 4 * DA_WG_ZPAD) + 2 * TY * TX * 16) * 2 * NPL + 32;      // + the waves' tile maxima (split mode)
+    size_t shm = (size_t)((DA_WG_TZ + 2) * (HY * HX * 8 + 4 * DA_WG_ZPAD) + DA_WG_TZ * TY * TX * 16) * 2 * NPL + 32;      // + the waves' tile maxima (split mode)
     if (shm < (size_t)2 * 15 * 64 * sizeof(float4)) shm = (size_t)2 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tiles' LDS
     auto kern = conv3_split_wgrad_kernel<PRO, NPL, HB>;
     static bool attr_set = false;
@@ -2547,7 +2556,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
       static int phase = -1; if (phase < 0) { const char* e = getenv("DA_PHASE_PRIO"); phase = (e && atoi(e)) ? 1 : 0; } if (phase) p.prio_ranks = -1; }
     if (split || rows1) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
-        hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
+        hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz, DA_WG_TZ);
         DA_LAUNCH_CHECK();
         p.tiles = tiles;
     }

@@ -227,8 +227,8 @@ def _reruns():
         ('seg_light_first_step_vs_golden_fused_head_dice', lambda g: tn.test_seg_light_first_step_vs_golden(g, True, perturbed_trials=5)),
         ('reg_three_steps_vs_golden_odd', lambda g: tn.test_reg_three_steps_vs_golden(g, 'reg_odd', (20, 24, 20))),
         ('reg_three_steps_vs_golden_even', lambda g: tn.test_reg_three_steps_vs_golden(g, 'reg_even', (16, 24, 32))),
-        ('joint_step_vs_oracle_c32', lambda g: tn.test_joint_step_vs_oracle(32, True)),
-        ('joint_step_vs_oracle_c8_unlabelled', lambda g: tn.test_joint_step_vs_oracle(8, False)),
+        ('joint_step_vs_oracle_c32', lambda g: tn.test_joint_step_vs_oracle(32, True, True)),
+        ('joint_step_vs_oracle_c8_unlabelled', lambda g: tn.test_joint_step_vs_oracle(8, False, False)),
         ('unet_full_blockwise_backward_bn', lambda g: tn.test_unet_full_blockwise_backward(True)),
         ('eval_dice_vs_cpu_reference_after_training', lambda g: tn.test_eval_dice_vs_cpu_reference_after_training()),
         ('lazy_batchnorm_matches_materialised_unet_light', lambda g: tn.test_lazy_batchnorm_matches_materialised_activations('UNET_LIGHT', 32)),

@@ -10,6 +10,7 @@ f=$(ls $O/prof_$tag/*/*.db 2>/dev/null | head -1)
 if [ -n "$f" ]; then
   python tools/rocpd_summary.py "$f" --top 60 > $O/${tag}_kernel_stats.txt 2>&1 < /dev/null
   python tools/rocpd_timeline.py "$f" > $O/${tag}_timeline.txt 2>&1 < /dev/null
+  python tools/rocpd_timeline.py "$f" --dump --dump-all > $O/${tag}_step_dump.txt 2>&1 < /dev/null
 fi
 rm -rf $O/prof_$tag
 timeout 600 python tools/step_calls.py $w 2>&1 | grep -v amdgpu.ids > $O/${tag}_calls.txt

@@ -2,7 +2,7 @@
 """Timeline view of a rocprofv3 (rocpd sqlite) kernel trace of a two-stream training step: how much of the wall time has a
 matrix (MFMA conv) kernel in flight, how much only HBM-bound kernels, how much nothing, and which kernels account for the time
 that no matrix kernel covers ("exposed" time).
-Usage: python tools/rocpd_timeline.py x_results.db [--skip-frac 0.3] [--top 25]"""
+Usage: python tools/rocpd_timeline.py x_results.db [--skip-frac 0.3] [--top 25] [--dump]"""
 import re
 import sqlite3
 import sys
@@ -75,7 +75,7 @@ def main():
         print('  %8.3f ms  %4d x  %-44s -> %s' % (v / 1e6, c, a[:44], b[:60]))
 
 
-def dump_last_step(path, min_us=150.0):
+def dump_last_step(path, min_us=150.0):      # (--dump-all: every kernel)
     """--dump: start / end / queue / duration of every kernel longer than min_us in the last optimiser step of the trace."""
     db = sqlite3.connect(path)
     rows = db.execute("select name, start, end, queue_id from kernels order by start").fetchall()
@@ -90,6 +90,6 @@ def dump_last_step(path, min_us=150.0):
 
 if __name__ == '__main__':
     if '--dump' in sys.argv:
-        dump_last_step(sys.argv[1])
+        dump_last_step(sys.argv[1], 0.0 if '--dump-all' in sys.argv else 150.0)
         sys.exit(0)
     main()
