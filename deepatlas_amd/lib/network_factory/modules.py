@@ -57,7 +57,7 @@ class SegBlock(nn.Sequential):
         if self.batchnorm and self.stride == 1:
             bn = self.BN
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
+                ops.bump_batches_tracked(bn)
             # conv + BN + act as one autograd node (BN backward also yields the conv bias gradient); LazyAct inputs are consumed raw,
             # their BatchNorm + activation is applied by the convolution's input staging
             pro1 = (x.scale, x.shift, x.slope) if isinstance(x, ops.LazyAct) else None
@@ -74,7 +74,7 @@ class SegBlock(nn.Sequential):
         if self.batchnorm:
             bn = self.BN
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
+                ops.bump_batches_tracked(bn)
             y = ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, self.stride, -1.0)
             return ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      self.training, bn.momentum, bn.eps, self.slope)
@@ -106,7 +106,7 @@ class SegUpBlock(nn.Sequential):
         if self.batchnorm:
             bn = self.BN
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
+                ops.bump_batches_tracked(bn)
             if lazy_out:
                 out = ops.DeconvBNActFn.apply(x, self.deconv.weight, self.deconv.bias, bn.weight, bn.bias, bn.running_mean,
                                               bn.running_var, self.training, bn.momentum, bn.eps, self.slope, True)
@@ -136,7 +136,7 @@ class UNetEncBlock(nn.Sequential):
         if self.batchnorm:
             bn = self[1]
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
+                ops.bump_batches_tracked(bn)
             return ops.ConvBNActFn.apply(x, skip, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                          self.training, bn.momentum, bn.eps, 0.0)
         return ops.Conv3dK3Fn.apply(x, skip, conv.weight, conv.bias, 1, 0.0)
@@ -166,7 +166,7 @@ class UNetDecBlock(nn.Sequential):
         dc = self[0]
         bn = self[1] if self.batchnorm else None
         if bn is not None and self.training and bn.track_running_stats:
-            bn.num_batches_tracked += 1
+            ops.bump_batches_tracked(bn)
         if self.kind == 'up':
             if skip is not None:
                 raise ValueError('the k2/s2 up-sampler takes a single input')
@@ -258,7 +258,7 @@ class convBlock(nn.Module):
             y = ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, -1.0)
             bn = self.bn
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
+                ops.bump_batches_tracked(bn)
             y = ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, slope)
         else:
             y = ops.Conv3dK3Fn.apply(x, skip, self.conv.weight, self.conv.bias, self.stride, slope)
@@ -287,7 +287,7 @@ class deconvBlock(nn.Module):
         if self.bn is not None:
             bn = self.bn
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
+                ops.bump_batches_tracked(bn)
             y = ops.BNActFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, slope)
         else:
             y = ops.ActFn.apply(y, slope)

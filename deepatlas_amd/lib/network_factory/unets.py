@@ -31,6 +31,7 @@ def UNet_generator(encoders, decoders, act='ReLU', upsample=False, maxpool=True,
     class UNetTemplate(nn.Module):
         def __init__(self, in_channel, n_classes, bias=False, BN=False):
             super(UNetTemplate, self).__init__()
+            self.register_forward_hook(ops.flush_batches_tracked)      # the deferred num_batches_tracked increments of this pass: one launch
             self.in_channel = in_channel
             self.n_classes = n_classes
             self.levels = len(encoders)
@@ -137,6 +138,7 @@ class UNet(nn.Module):
         self.in_channel = in_channel
         self.n_classes = n_classes
         super(UNet, self).__init__()
+        self.register_forward_hook(ops.flush_batches_tracked)      # the deferred num_batches_tracked increments of this pass: one launch
         self.ec0 = self.encoder(self.in_channel, 32, bias=bias, batchnorm=BN)
         self.ec1 = self.encoder(32, 64, bias=bias, batchnorm=BN)
         self.ec2 = self.encoder(64, 64, bias=bias, batchnorm=BN)

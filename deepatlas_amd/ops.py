@@ -195,6 +195,22 @@ DETERMINISTIC = os.environ.get('DA_DETERMINISTIC') == '1'
 CHECK_LABELS = os.environ.get('DA_CHECK_LABELS') == '1'      # validate index targets of the cross-entropy family like torch does (host sync per call)
 
 
+_nbt_pending = []
+
+
+def bump_batches_tracked(bn):
+    """`bn.num_batches_tracked += 1` (nn.BatchNorm3d in training mode), deferred: one 4-us launch per BatchNorm layer in the dependent chain
+    of a forward pass (17 per UNet_light step) becomes ONE multi-tensor launch when the network's forward returns (a forward hook the
+    network classes register) -- or, for blocks used on their own, at the next optimiser step / flush_batches_tracked()."""
+    _nbt_pending.append(bn.num_batches_tracked)
+
+
+def flush_batches_tracked(*_):
+    if _nbt_pending:
+        torch._foreach_add_(_nbt_pending, 1)
+        _nbt_pending.clear()
+
+
 def init_into(param, init_fn):
     """Fill a parameter with `init_fn` (an nn.init.*_ function) in the element order of a CONTIGUOUS tensor of its shape.  Tagged convolution
     weights are strided views of FlatAdam's tap-major buckets once an optimiser exists; a random fill of the view itself would walk

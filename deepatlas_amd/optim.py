@@ -126,6 +126,7 @@ class FlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        ops.flush_batches_tracked()
         self._gather_stray_grads()
         g = self.param_groups[0]
         for p, off, k in self._slices:
