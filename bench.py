@@ -668,6 +668,12 @@ def main():
                 pm2 = pmc_traffic_for(slow['call'], args.precision)
                 roofline['traffic'] = pm2['traffic'] if pm2 else None
                 roofline['traffic_source'] = pm2['traffic_source'] if pm2 else None
+                roofline['mfma_busy_vs_peak_clock'] = pm2.get('mfma_busy_vs_peak_clock') if pm2 else None
+                if args.precision == 'fp32_split':
+                    # what the chip sustains of this arithmetic on random operands (tools/ubench/split_f16_kloop.hip, profiles/r04_ubench_f16_kloop.txt):
+                    # matrix pipe alone 659 TFLOP/s at the power-limited 1.90 GHz; the K loop with its LDS fragment reads 525 (row pairs) - 580
+                    roofline['measured_ceilings_tflops'] = dict(mfma_only=659.1, kloop_with_lds_reads=524.6, kloop_halo_row_reuse=579.6)
+                    roofline['frac_of_measured_kloop_ceiling'] = round(slow['tflops'] / 524.6, 4)
                 roofline['post_run_pass'] = dict(
                     note='3 extra steps after the timed region, weight gradients on the main stream, every conv call timed with HIP events',
                     roofline_layer=[strip(r) for r in same],
