@@ -349,6 +349,10 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
                                          N, D, H, W, Cout, stride, act_slope, ws, ws_bytes, st);
         if (rc != DA_ERR_UNSUPPORTED) return rc;           // e.g. a per-sample tensor beyond 32-bit byte offsets: direct kernels below
     }
+    if (!force_direct() && stride == 1 && da_conv3_flowmm_supported(C1, C2, Cout, N, D, H, W)) {      // <= 3 outputs, split mode: (dy, cout) columns on the matrix cores
+        const int rc = da_conv3_flowmm_fwd(in1, C1, in2, C2, w_tio, bias, out, N, D, H, W, Cout, act_slope, ws, ws_bytes, st);
+        if (rc != DA_ERR_UNSUPPORTED) return rc;
+    }
     if (!force_direct() && da_conv3_thin_supported(C1, C2, Cout, stride) && !getenv("DA_NO_THIN")) {
         const int rc = da_conv3_thin_fwd(in1, C1, in2, C2, w_tio, 0, bias, out, Cout, nullptr, 0, N, D, H, W, Cout, act_slope, ws, ws_bytes, st);
         if (rc != DA_ERR_UNSUPPORTED) return rc;
@@ -431,6 +435,10 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
         if (!force_direct() && da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) {
             const int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, /*w_is_flipped_tr=*/1, nullptr, dx1, C1, dx2, C2,
                                              N, D, H, W, Cin, 1, -1.f, ws, ws_bytes, st);
+            if (rc != DA_ERR_UNSUPPORTED) return rc;
+        }
+        if (!force_direct() && da_conv3_flowmm_supported(C1, C2, Cout, N, D, H, W)) {
+            const int rc = da_conv3_flowmm_dgrad(dy, w_tio, dx1, C1, dx2, C2, N, D, H, W, Cout, ws, ws_bytes, st);
             if (rc != DA_ERR_UNSUPPORTED) return rc;
         }
         if (!force_direct() && da_conv3_thin_supported(Cout, 0, Cin, 1)) {

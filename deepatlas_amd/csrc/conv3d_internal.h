@@ -55,6 +55,14 @@ int da_conv3_s2n_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, 
 int da_conv3_s2n_wgrad(const float* in, int Cin, const float* dy, float* dw_tio, int N, int D, int H, int W, int Cout,
                        void* ws, size_t ws_bytes, hipStream_t st);
 
+// the flow convolution (<= 3 output channels) and its data gradient on the matrix cores, split matrix mode (conv3d_flowmm.hip)
+bool da_conv3_flowmm_supported(int C1, int C2, int Cout, int N, int D, int H, int W);
+size_t da_conv3_flowmm_ws_bytes();
+int da_conv3_flowmm_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, const float* bias, float* out,
+                        int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st);
+int da_conv3_flowmm_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
+                          int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+
 // thin convs (Cout <= 4 or Cin <= 4) on the VALU from an LDS halo tile; flip_tr: `w` is the original layer's [27][Cout][Cin]
 // tensor and the data-gradient convolution is computed
 bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride);

@@ -58,6 +58,9 @@ CASES = [
     (64, 0, 64, (1, 4, 6, 20)),        # two cout groups
     (64, 0, 8, (1, 4, 8, 16)),         # reg dec3 64 -> 8
     (32, 0, 48, (1, 4, 8, 16)),        # three N-tiles
+    (8, 16, 3, (1, 5, 9, 18)),         # the flow conv 24 -> 3 (conv3d_flowmm.hip: (dy, cout) columns), ragged tiles in every axis
+    (16, 0, 3, (2, 4, 8, 16)),         # one source tensor, two samples, exact tiles
+    (8, 8, 2, (1, 3, 7, 20)),          # two output channels
 ]
 
 
@@ -87,8 +90,11 @@ def test_split_mode_is_fp32_accurate(case, kind):
         m_nat, m_sp = max_abs_rel(a.numpy().astype(np.float64), r), max_abs_rel(s.numpy().astype(np.float64), r)
         # not worse than the fmaf chain beyond half an fp32 ulp (2^-24 = 6e-8: where the chain's own error is below one rounding -- sums
         # dominated by a single product -- the split's three partial sums each round once and a single product carries up to 2^-21), and far inside the 1e-5 of the exact-kernel tests
-        assert e_sp <= 1.25 * e_nat + 6e-8, '%s: split rel-l2 %.3e vs fp32 chain %.3e' % (nm, e_sp, e_nat)
-        assert m_sp <= 1.5 * m_nat + 1.2e-7, '%s: split max-abs %.3e vs fp32 chain %.3e' % (nm, m_sp, m_nat)
+        # Log-normal magnitudes (ten decades): a sum is dominated by ONE product, the chain's error is then a single rounding (2e-8) while the
+        # two-term split shows its per-product error -- bound 2^-21 + 2^-22 = 7e-7, typically 2^-22 -- so the additive slack there is 2^-22.
+        s2, sm = (2.4e-7, 4.8e-7) if kind == 'lognormal' else (6e-8, 1.2e-7)
+        assert e_sp <= 1.25 * e_nat + s2, '%s: split rel-l2 %.3e vs fp32 chain %.3e' % (nm, e_sp, e_nat)
+        assert m_sp <= 1.5 * m_nat + sm, '%s: split max-abs %.3e vs fp32 chain %.3e' % (nm, m_sp, m_nat)
         assert e_sp < 1e-5 and m_sp < 1e-5, (nm, e_sp, m_sp)
         record.append((nm, e_nat, e_sp, m_nat, m_sp))
     print('\n'.join('%-7s rel-l2 chain %.2e split %.2e | max-abs chain %.2e split %.2e' % r for r in record))
