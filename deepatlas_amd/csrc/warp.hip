@@ -522,30 +522,48 @@ __global__ void label_warp_dice_bwd_kernel(const void* __restrict__ lab_m, int b
 // rows: one line per lane; 1.94 -> 0.54 ms at 160x192x160, profiles/r03_gather_kernels.txt).  A = W^T 1 needs no scatter of its own:
 // every weight lands in exactly one class plane, so A[u] = sum_c B[c][u] (formed by the consumer from the values it reads anyway); voxels
 // whose target label is outside [0, C) put their weights into the separate array A_extra (NULL when the caller knows there are none).
+// Wave-level pre-aggregation along x: lane L (voxel x) and lane L + 1 (voxel x + 1) of a smooth field usually sample cells that are one voxel
+// apart, so lane L's four cx = 1 corners ARE lane L + 1's four cx = 0 corners.  Where that holds (same label, same (y0, z0), x0 one apart, both
+// finite: checked per lane pair) lane L hands its cx = 1 weights to lane L + 1 through a DPP-free shuffle and issues no atomics for them:
+// four to six instead of eight atomics per voxel on a smooth field (0.54 -> 0.49 ms at 160x192x160; a random field has nothing to merge: 1.68 ms).
 __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int bt, const float* __restrict__ disp,
                                            float* __restrict__ A_extra, float* __restrict__ B, int N, int D, int H, int W, int C) {
     const long long V = (long long)D * H * W, nvox = V * N;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
-        int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
-        const float gx = disp[v * 3 + 0] + id_coord(w, W);
-        const float gy = disp[v * 3 + 1] + id_coord(h, H);
-        const float gz = disp[v * 3 + 2] + id_coord(d, D);
-        if (!is_finite_coord(gx, gy, gz)) continue;
-        const Taps t = make_taps(gx, gy, gz, D, H, W);
-        const int lab = warp_label_at(lab_t, bt, v);
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v0 = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); v0 < nvox; v0 += stride) {      // whole waves iterate together (shuffles inside)
+        const long long v = v0 + lane;
+        const bool inr = v < nvox;
+        int n = 0, d = 0, h = 0, w = 0;
+        if (inr) da_vox4(v, D, H, W, n, d, h, w);
+        const float gx = inr ? disp[v * 3 + 0] + id_coord(w, W) : 0.f;
+        const float gy = inr ? disp[v * 3 + 1] + id_coord(h, H) : 0.f;
+        const float gz = inr ? disp[v * 3 + 2] + id_coord(d, D) : 0.f;
+        const bool live = inr && is_finite_coord(gx, gy, gz);
+        const Taps t = make_taps(live ? gx : 0.f, live ? gy : 0.f, live ? gz : 0.f, D, H, W);
+        const int lab = inr ? warp_label_at(lab_t, bt, v) : -1;
         const bool lok = lab >= 0 && lab < C;
+        // this lane's cell, as one comparable key per (n, label, z0, y0) and the x0 beside it
+        const bool inbox = live && t.z0 >= -1 && t.z0 < D && t.y0 >= -1 && t.y0 < H;      // (cells with no corner row inside the volume never merge)
+        const long long key = inbox ? ((((long long)n * (C + 2) + (lok ? lab : C)) * (D + 2) + (t.z0 + 1)) * (H + 2) + (t.y0 + 1)) : -1 - (long long)lane;
+        const long long pkey = __shfl_up(key, 1);
+        const int px0 = __shfl_up(t.x0, 1);
+        const bool take = inbox && lane > 0 && pkey == key && px0 + 1 == t.x0;      // lane - 1's cx = 1 corners are this lane's cx = 0 corners
+        const bool given = __shfl_down((int)take, 1) != 0 && lane < 63;            // ... and lane + 1 took ours
         const long long sbase = (long long)n * V;
+        float* plane = lok ? B + ((long long)n * C + lab) * V : (A_extra ? A_extra + sbase : nullptr);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
-            const int x = t.x0 + cx, y = t.y0 + cy, z = t.z0 + cz;
-            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
-                const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
-                const long long uu = sbase + ((long long)z * H + y) * W + x;
-                if (wgt == 0.f) continue;                                    // (an integer coordinate: four of the eight weights are exact zeros)
-                if (lok) atomicAdd(B + ((long long)n * C + lab) * V + (uu - sbase), wgt);
-                else if (A_extra) atomicAdd(A_extra + uu, wgt);
-            }
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const int cz = k2 >> 1, cy = k2 & 1;
+            const float wyz = (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+            const float w0 = t.fx1 * wyz, w1 = t.fx0 * wyz;                       // cx = 0 | 1
+            const float got = __shfl_up(w1, 1);
+            const int y = t.y0 + cy, z = t.z0 + cz;
+            const bool yz = live && plane && y >= 0 && y < H && z >= 0 && z < D;
+            const long long row = ((long long)z * H + y) * W;
+            const float a0 = w0 + (take ? got : 0.f);
+            if (yz && t.x0 >= 0 && t.x0 < W && a0 != 0.f) atomicAdd(plane + row + t.x0, a0);
+            if (yz && !given && t.x0 + 1 >= 0 && t.x0 + 1 < W && w1 != 0.f) atomicAdd(plane + row + t.x0 + 1, w1);
         }
     }
 }
