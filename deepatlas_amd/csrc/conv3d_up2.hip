@@ -323,22 +323,30 @@ __global__ void __launch_bounds__(256) up_pack_dgrad_kernel(const float* __restr
     if (blockIdx.y == 0 && threadIdx.x == 0) wexp[ch] = ew;
     const float sc = da_pow2(ew);
     const int units = 16 * NTN * 64;                             // (step, N-tile, lane)
+    const bool vec = (Cout & 3) == 0 && ch * 8 + 8 <= Cout && (reinterpret_cast<size_t>(w) & 15) == 0;
     for (int u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
         const int lane = u & 63, nt = (u >> 6) % NTN, st = (u >> 6) / NTN;
         const int g = lane >> 4, n = lane & 15;
         const int ft = 4 * st + g, ci = nt * 16 + n;
         int tz[2], ty[2], tx[2];
         const int nz = up_taps_of_f((ft >> 4) & 3, tz), ny = up_taps_of_f((ft >> 2) & 3, ty), nx = up_taps_of_f(ft & 3, tx);
+        // the 8 couts of the chunk are contiguous in w: two quad loads per folded tap when the layout allows it (same summation order either way)
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ci < Cin)
+            for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c) {
+                const float* src = w + ((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + ch * 8;
+                if (vec) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(src), p1 = *reinterpret_cast<const float4*>(src + 4);
+                    acc[0] += (double)p0.x; acc[1] += (double)p0.y; acc[2] += (double)p0.z; acc[3] += (double)p0.w;
+                    acc[4] += (double)p1.x; acc[5] += (double)p1.y; acc[6] += (double)p1.z; acc[7] += (double)p1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (ch * 8 + e < Cout) acc[e] += (double)src[e];
+                }
+            }
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int co = ch * 8 + e;
-            double acc = 0.0;
-            if (ci < Cin && co < Cout)
-                for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
-                    acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
-            v[e] = (float)acc;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = (float)acc[e];
         uint2 h0, l0, h1, l1;
         da_split2(make_float4(v[0], v[1], v[2], v[3]), sc, h0, l0);
         da_split2(make_float4(v[4], v[5], v[6], v[7]), sc, h1, l1);
@@ -725,7 +733,7 @@ extern "C" int da_upconv3d_k3_fwd(const float* s1, int C1, const float* s2, int 
     p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.bias = bias; p.out = out;
     p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
     p.nchunks = Cin / 8; p.NTall = (Cout + 15) / 16; p.slope = act_slope;
-    hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(p.nchunks, 8), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.NTall);
+    hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(p.nchunks, 4 * p.NTall), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.NTall);
     DA_LAUNCH_CHECK();
     const size_t shm = NPLN * SPLANE_B + 16;
     static bool a1 = false, a2 = false;
@@ -754,7 +762,7 @@ extern "C" int da_upconv3d_k3_dgrad(const float* dy, const float* w_tio, float* 
     p.nchunks = Cout / 8;
     int NTN = (Cin + 15) / 16; if (NTN == 3) NTN = 4;            // (48 input channels: a fourth, empty tile)
     p.NTN = NTN;
-    hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(p.nchunks, 8), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, NTN);
+    hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(p.nchunks, 4 * NTN), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, NTN);
     DA_LAUNCH_CHECK();
     const size_t shm = NPLN * FPLANE_B + 16;
     static bool a[5] = {false, false, false, false, false};

@@ -14,15 +14,22 @@
 // (tests/test_gpu_split.py: 0.4 - 0.6 x the chain's error on uniform data, equal on log-normal data where single products dominate).
 // Four values at a time, packed pairwise (element 0 in the low half).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));    // eight fp16 (the A / B fragment of v_mfma_f32_16x16x32_f16)
+// h: two packed multiplies + two v_cvt_pk_f16_f32.  l: v_fma_mix{lo,hi}_f16 computes fma(x, s, -h) in fp32 straight from the packed fp16 h and
+// rounds it into one half of the destination -- four instructions per quad where the compiler's form (widen h, packed fma, convert) takes
+// eight; the same bits (tools/ubench/split_mix_check.hip: 4M quads, l underflow and zeros included).
 __device__ __forceinline__ void da_split2(const float4 v, const float s, uint2& h, uint2& l) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t a = {v.x * s, v.y * s}, b = {v.z * s, v.w * s};
     const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);      // v_cvt_pk_f16_f32 (RNE)
-    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
-    const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
-    h = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-    l = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+    const unsigned uha = __builtin_bit_cast(unsigned, ha), uhb = __builtin_bit_cast(unsigned, hb);
+    unsigned la, lb;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(la) : "v"(v.x), "v"(s), "v"(uha));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(la) : "v"(v.y), "v"(s), "v"(uha));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v.z), "v"(s), "v"(uhb));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v.w), "v"(s), "v"(uhb));
+    h = make_uint2(uha, uhb);
+    l = make_uint2(la, lb);
 }
 // largest magnitude of a quad, folded into a running maximum (NaN operands are ignored by v_max: they still propagate through the split)
 // (two v_max3_f32 with |.| source modifiers; fmaxf(fabsf()) compiles to seven instructions per quad: a canonicalising v_max per operand)

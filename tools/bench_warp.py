@@ -41,6 +41,7 @@ def main():
     prob = torch.softmax(torch.randn((1, V, C), generator=g), -1).to(dev)
     dlog = torch.empty_like(prob)
     coef_a = torch.rand((2, 1, C), generator=g).to(dev)
+    flush = torch.empty(1 << 28, device=dev)
 
     def timed(name, fn, nbytes):
         for _ in range(3):
@@ -53,10 +54,22 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        print('%-44s %7.3f ms  %8.1f GB/s  %.3f of HBM peak' % (name, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 8000.0))
+        # cold: a 1 GiB fill between calls evicts L2 and the 256 MB Infinity Cache, the state the call sees inside a training step
+        cold = []
+        for _ in range(min(a.iters, 8)):
+            flush.fill_(1.0)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(); fn(); c1.record()
+            torch.cuda.synchronize()
+            cold.append(c0.elapsed_time(c1))
+        cms = sorted(cold)[len(cold) // 2]
+        print('%-40s hot %7.3f ms %7.1f GB/s %.3f of peak | cold %7.3f ms %7.1f GB/s %.3f of peak' % (
+            name, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 8000.0, cms, nbytes / cms / 1e6, nbytes / cms / 1e6 / 8000.0))
 
-    for dn, u in (('smooth', smooth), ('random', rnd)):
+    tiny = (torch.randn((1, D, H, W, 3), generator=g) * 1e-6).to(dev)       # an untrained flow head: sample points within 1e-4 voxel of the grid
+    for dn, u in (('smooth', smooth), ('random', rnd), ('tiny', tiny)):
         timed('da_warp_fwd[1] %s' % dn, lambda: call('da_warp_fwd', ptr(img), ptr(u), ptr(deform), ptr(out1), 1, D, H, W, 1, st), 5 * 4 * V)
+        timed('da_warp_bwd[1] d_disp only %s' % dn, lambda: call('da_warp_bwd', ptr(out1), ptr(img), ptr(u), ptr(d_disp), None, 1, D, H, W, 1, st), 8 * 4 * V)
         timed('da_warp_fwd[32] %s' % dn, lambda: call('da_warp_fwd', ptr(src32), ptr(u), ptr(deform), ptr(out32), 1, D, H, W, C, st), 67 * 4 * V)
         timed('da_label_warp_dice_fwd %s' % dn, lambda: call('da_label_warp_dice_fwd', ptr(lab_m), 1, ptr(lab_t), 1, ptr(u), 1, D, H, W, C, 0, 0, 1e-6,
                                                             ptr(loss), ptr(coef), wp, wn, st), 14 * V)
