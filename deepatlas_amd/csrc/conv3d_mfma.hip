@@ -352,8 +352,7 @@ __device__ __forceinline__ float da_quad_xor2(float v) { return __builtin_bit_ca
 // ---------------------------------------------------------------------------------------------------
 struct TileWalk { int lo, J, cnt; };
 
-__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
-    const int G = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ TileWalk tile_walk(int ntiles, int G = gridDim.x, int b = blockIdx.x) {
     const int X = (G % 8 == 0) ? 8 : 1;
     const int J = G / X, xcd = b % X, j = b / X;
     const int lo = (int)((long long)ntiles * xcd / X), hi = (int)((long long)ntiles * (xcd + 1) / X);
@@ -591,7 +590,7 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
         if (chn != 0) E = min(E, Emin + 40);
         // keep the accumulators' unit (Ecur: the item being accumulated) while the next chunk fits it -- staged up to 8x smaller than its own
         // maximum allows; see conv3_split_wgrad_kernel -- so that the per-item accumulator multiplies run only when the magnitude moves
-        if (chn != 0 && E >= Ecur && E <= Ecur + 3) E = Ecur;
+        if (chn != 0 && E >= Ecur && E <= Ecur + 3 && !(p.ablate & 8)) E = Ecur;
         Emin = (chn == 0) ? E : min(Emin, E);
         Enext = E;
         return da_pow2(E - ew);
@@ -1590,6 +1589,9 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
 #ifndef DA_WG_TZ
 #define DA_WG_TZ 2      // z planes per tile of the split weight gradient (4: two z-plane pairs per staged tile -- measured 48 -> 16 2.01 -> 1.85 ms but 16 -> 16 0.64 -> 0.70: spills at 256 VGPRs; kept for A/B builds)
 #endif
+// (Tried: a 1-D launch that gives the two workgroups of a CU -- blocks L and L + 256, tools/ubench/wg_placement.hip -- neighbouring chunks of
+// one slab so that the one behind finds the other's lines in L1.  No effect, 2.008 vs 2.017 ms on 48 -> 16 on one box: a tile's lines, 92 KB,
+// pass through the 32 KB L1 long before the partner asks for them.)
 template <bool PRO, int NPL = 2, bool HB = false>
 __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     static_assert(!HB || NPL == 1, "bf16 activation storage goes with the bf16 matrix mode");
@@ -1611,7 +1613,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4, q = i & 3, vq = i >> 2;
-    const int ch = blockIdx.y, cg = blockIdx.z;
+    const int slab = blockIdx.x, nsl = gridDim.x, ch = blockIdx.y, cg = blockIdx.z;
     const int cbase = ch * CK;
     const float* src; int Cs, choff;
     if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
@@ -1670,7 +1672,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const TileWalk tw = tile_walk(p.ntiles);
+    const TileWalk tw = tile_walk(p.ntiles, nsl, slab);
     constexpr int NITA = StageGeom<CK, HZ>::NIT, QY = CG / 4, NITY = (TVOX * QY + 255) / 256;
     float4 preA[NITA], preY[NITY];
     // Per-thread constants of the two staging patterns (the tile coordinates come from the table the launcher's tile kernel wrote):
@@ -1743,7 +1745,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
             // (its largest value then lies in [2^11, 2^15) instead of [2^14, 2^15): the per-product bound is unchanged, only the floor below
             // which l underflows rises from 2^-40 to 2^-37 of the tile maximum), so the 60 accumulator multiplies run only when the data's
             // magnitude really moves -- they cost 0.19 of 1.98 ms on the 48 -> 16 layer when done every tile
-            if (!first_tile && E >= Eacc && E <= Eacc + 3) E = Eacc;
+            if (!first_tile && E >= Eacc && E <= Eacc + 3 && !(p.ablate & 32)) E = Eacc;
             Emin = first_tile ? E : min(Emin, E);
             first_tile = false;
             Enext = E;
@@ -1869,7 +1871,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
     __syncthreads();
     if (wave == 0) {
         add(0);
-        float* part = p.partial + (size_t)blockIdx.x * p.O;
+        float* part = p.partial + (size_t)slab * p.O;
         const int Cin = p.C1 + p.C2;
         const int co = cg * CG + i;
 #pragma unroll
@@ -1883,6 +1885,306 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
                     const int combo = c < 4 ? 2 * c + (row >> 3) : 8;
                     const int dyt = c < 4 ? d : 2 * d + (row >> 3);
                     const int tap = (combo / 3) * 9 + dyt * 3 + combo % 3, ci = row & 7;
+                    if (dyt < 3 && (c < 4 || d < 2) && co < p.Cout) part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[c][d][reg];
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient in split mode, third form: 16-channel chunks, eight waves.
+// The staging loads of the row-owner kernel above fetch 32 bytes (8 channels) of every voxel while the L1 asks the L2 for 64-byte
+// sectors, and the kernel is bound by exactly that stream: with everything but the loads removed it runs 1.91 of 1.98 ms (48 -> 16,
+// DA_WG_ABLATE=6); the counters show 167 M sector requests per launch at 387 cycles of latency and the L1 stalled on its outstanding
+// requests 35 % of the time -- ~64 sectors in flight x 64 B / 387 cycles = the observed ~10 B / clk / CU (profiles/r04_wgrad_memory_path.txt).
+// Here a workgroup stages 16 channels = one whole sector per voxel (half the requests for the same data, and half as many passes over
+// the dY tile), as EIGHT waves: waves 0 - 3 own the chunk's first 8 channels, waves 4 - 7 the second 8, each exactly the row-owner
+// kernel's per-wave program (two output rows, all 27 taps, 14 accumulators) on the shared dY tile -- so the register budget per wave is
+// unchanged, and per thread the staging shrinks (6 x quads as before, 2 dY quads instead of 4).  One workgroup per CU (62 KB of LDS,
+// 2 waves per SIMD as before); chosen when C1 and C2 are multiples of 16 and slabs x chunks x cout groups fills >= 224 of the 256 CUs.
+// ---------------------------------------------------------------------------------------------------
+#ifndef DA_WG16_ZPAD
+#define DA_WG16_ZPAD 4
+#endif
+template <bool PRO>
+__global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CK = 16, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX, NT = 512;
+    constexpr int ZPQ = DA_WG16_ZPAD, ZPE = 4 * ZPQ;
+    constexpr int QA = CK / 4, HV = HZ * HY * HX, TOTA = HV * QA, NITA = (TOTA + NT - 1) / NT;
+    constexpr int PLA = HZ * (HY * HX * CK + ZPE), PLY = TVOX * CG;        // elements per plane
+    constexpr int QY = CG / 4, NITY = (TVOX * QY + NT - 1) / NT;
+    float* ldsA = lds;
+    float* ldsY = lds + PLA;                                               // two fp16 planes of PLA elements = PLA floats
+    float* smax = ldsY + PLY;                                              // [2][8]
+    typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+    const short* ldsAh = reinterpret_cast<const short*>(ldsA);
+    const short* ldsYh = reinterpret_cast<const short*>(ldsY);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave & 3, wh = wave >> 2;                               // row pair, channel half
+    const int i = lane & 15, g = lane >> 4, q = i & 3, vq = i >> 2;
+    const int slab = blockIdx.x, nsl = gridDim.x, ch = blockIdx.y, cg = blockIdx.z;
+    const int cbase = ch * CK;
+    const float* src; int Cs, choff;
+    if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
+    const int c4 = (int)threadIdx.x % QA;
+    unsigned vmA = 0;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
+    if constexpr (PRO) {
+        const int cofs = choff + c4 * 4;
+        psc = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.ps1 : p.ps2) + cofs);
+        psf = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.pt1 : p.pt2) + cofs);
+        pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
+    }
+    // fragment sources as in conv3_split_wgrad_kernel, on 32-byte voxel records: this wave's channel half sits at + 8 wh
+    const int laneA = ((((g >> 1) * HY) + 2 * wr) * HX + 8 * (g & 1) + vq) * CK + wh * 8 + (q & 1) * 4 + (g >> 1) * ZPE;
+    int offC[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int combo = (c < 4) ? 2 * c + (q >> 1) : 8;
+        offC[c] = ((combo / 3) * HY * HX + combo % 3) * CK + (combo / 3) * ZPE;
+    }
+    const int laneY = ((((g >> 1) * TY) + 2 * wr) * TX + 8 * (g & 1) + vq) * CG + q * 4;
+    auto tr8 = [&](const short* a, int step) -> f16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto mma = [&](f32x4 c, const f16x8& a, const f16x8& b) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); };
+    struct F3 { f16x8 p[2]; };
+    auto loadF = [&](int c, int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * CK);
+        f.p[0] = tr8(a, 4 * CK); f.p[1] = tr8(a + PLA, 4 * CK);
+        return f;
+    };
+    auto loadG = [&](int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA + offC[4] + (h + (q >> 1)) * (HX * CK);
+        f.p[0] = tr8(a, 4 * CK); f.p[1] = tr8(a + PLA, 4 * CK);
+        return f;
+    };
+    auto loadY = [&](int r) -> F3 {
+        F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
+        f.p[0] = tr8(a, 4 * CG); f.p[1] = tr8(a + PLY, 4 * CG);
+        return f;
+    };
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const TileWalk tw = tile_walk(p.ntiles, nsl, slab);
+    float4 preA[NITA], preY[NITY];
+    // staging maps (launch constants): x halo quad idx = threadIdx.x + 512 it -> halo voxel idx / 4; dY quad idx -> voxel idx / 4
+    int voA[NITA]; unsigned pkA[NITA];
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+        const int hv = ((int)threadIdx.x + it * NT) / QA;
+        const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
+        pkA[it] = (hv < HV) ? ((unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx) : 0xFFFF0000u;
+        voA[it] = (hv < HV) ? (hz * p.H + hy) * p.W + hx : 0;
+    }
+    const bool smallA = (long long)HZ * p.H * p.W < (1ll << 24) && (long long)Cs * 4 < (1ll << 24);
+    const int yq4 = cg * CG + ((int)threadIdx.x % QY) * 4;
+    const int yv0 = (int)threadIdx.x / QY;
+    int voY[NITY];
+    const bool smallY = (long long)TZ * p.H * p.W < (1ll << 24) && (long long)p.Cout * 4 < (1ll << 24);
+#pragma unroll
+    for (int it = 0; it < NITY; ++it) { const int v = yv0 + it * (NT / QY); voY[it] = ((v >> 7) * p.H + ((v >> 4) & 7)) * p.W + (v & 15); }
+    auto fetch_tile = [&](int tile) -> int4 {
+        int pos = tw.lo + tile * tw.J; pos = pos < p.ntiles ? pos : p.ntiles - 1;
+        return p.tiles[__builtin_amdgcn_readfirstlane(pos)];
+    };
+    auto issue_loads = [&](const int4 tv) {
+        const int n = __builtin_amdgcn_readfirstlane(tv.x), z0 = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
+        {
+            const long long sample = (long long)p.D * p.H * p.W * Cs;
+            const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<false>(src, n, sample);
+            const bool interior = smallA && z0 >= 1 && z0 + HZ - 2 < p.D && y0 >= 1 && y0 + HY - 2 < p.H && x0 >= 1 && x0 + HX - 2 < p.W;
+            const unsigned Cs4 = (unsigned)Cs * 4u, cofs4 = (unsigned)(choff + c4 * 4) * 4u;
+            const unsigned base = (unsigned)(((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * Cs4 + cofs4;
+            if constexpr (PRO) vmA = 0;
+#pragma unroll
+            for (int it = 0; it < NITA; ++it) {
+                const int hz = (int)(pkA[it] >> 16), hy = (int)((pkA[it] >> 8) & 255u), hx = (int)(pkA[it] & 255u);
+                unsigned so;
+                if (interior) so = ((it + 1) * NT <= TOTA || hz != 0xFFFF) ? __umul24((unsigned)voA[it], Cs4) + base : 0xFFFFFFFFu;
+                else {
+                    const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+                    const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    so = inb ? (unsigned)(((z * p.H + y) * p.W + x)) * Cs4 + cofs4 : 0xFFFFFFFFu;
+                }
+                preA[it] = da_buf_loadq<false, false>(rs, so);
+                if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
+            }
+        }
+        const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<false>(p.dy, n, sampleY);
+        const bool inside = smallY && z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;
+        const int basev = (z0 * p.H + y0) * p.W + x0;
+        const unsigned baseY = ((unsigned)basev * (unsigned)p.Cout + (unsigned)yq4) * 4u;
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int v = yv0 + it * (NT / QY);
+            const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+            unsigned off;
+            if (inside) off = __umul24((unsigned)voY[it], (unsigned)p.Cout * 4u) + baseY;
+            else {
+                const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+                const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
+                off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * 4) : 0xFFFFFFFFu;
+            }
+            preY[it] = da_buf_loadq<false, false>(ry, off);
+        }
+    };
+    int Eacc = 0, Emin = 0, Enext = 0; bool first_tile = true;
+    auto publish_max = [&]() {
+        if constexpr (PRO) stage_pro_apply<0, NITA>(preA, vmA, psc, psf, pslope);
+        const float ma = da_wave_max_nonneg(stage_absmax<NITA>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+        if (lane == 0) { smax[wave] = ma; smax[8 + wave] = my; }
+    };
+    auto write_lds = [&]() {
+        const float4 ma0 = *reinterpret_cast<const float4*>(smax), ma1 = *reinterpret_cast<const float4*>(smax + 4);
+        const float4 my0 = *reinterpret_cast<const float4*>(smax + 8), my1 = *reinterpret_cast<const float4*>(smax + 12);
+        const float mA = fmaxf(fmaxf(fmaxf(ma0.x, ma0.y), fmaxf(ma0.z, ma0.w)), fmaxf(fmaxf(ma1.x, ma1.y), fmaxf(ma1.z, ma1.w)));
+        const float mY = fmaxf(fmaxf(fmaxf(my0.x, my0.y), fmaxf(my0.z, my0.w)), fmaxf(fmaxf(my1.x, my1.y), fmaxf(my1.z, my1.w)));
+        const int ea = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mA))));
+        const int ey = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mY))));
+        int E = ea + ey;
+        if (!first_tile) E = min(E, Emin + 40);
+        if (!first_tile && E >= Eacc && E <= Eacc + 3) E = Eacc;           // (keep the accumulators' unit: see conv3_split_wgrad_kernel)
+        Emin = first_tile ? E : min(Emin, E);
+        first_tile = false;
+        Enext = E;
+        const float sy = da_pow2(ey), sa = da_pow2(E - ey);
+#pragma unroll
+        for (int it = 0; it < NITA; ++it) {
+            const int idx0 = threadIdx.x + it * NT;
+            if (idx0 < TOTA) {
+                const int idx = idx0 + ZPQ * (idx0 / (HY * HX * QA));
+                uint2 h, l; da_split2(preA[it], sa, h, l);
+                reinterpret_cast<uint2*>(ldsA)[idx] = h; reinterpret_cast<uint2*>(ldsA)[idx + PLA / 4] = l;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int idx = threadIdx.x + it * NT;
+            if (idx < TVOX * QY) {
+                uint2 h, l; da_split2(preY[it], sy, h, l);
+                reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + PLY / 4] = l;
+            }
+        }
+    };
+    int4 tnext = fetch_tile(1);
+    if (tw.cnt > 0) { issue_loads(fetch_tile(0)); publish_max(); __syncthreads(); write_lds(); }
+    __syncthreads();
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll 1
+    for (int tile = 0; tile < tw.cnt; ++tile) {
+        const bool has_next = tile + 1 < tw.cnt;
+        if (has_next && !(p.ablate & 1)) issue_loads(tnext);
+        tnext = fetch_tile(tile + 2);
+        if (Enext != Eacc) {
+            const float f = da_pow2(Enext - Eacc);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * f;
+            Eacc = Enext;
+        }
+        if (!(p.ablate & 2)) {
+        F3 Y0 = loadY(0), Y1 = loadY(1);
+        F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Fd = loadF(c, 3);
+            Na = (c < 3) ? loadF(c + 1, 0) : loadG(0);
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+                acc[c][0] = mma(acc[c][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
+                acc[c][1] = mma(acc[c][1], Fb.p[PA[pr]], Y0.p[PB[pr]]);
+                acc[c][2] = mma(acc[c][2], Fc.p[PA[pr]], Y0.p[PB[pr]]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 3) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); } else { Nb = loadG(1); Nc = loadF(4, 2); }
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+                acc[c][0] = mma(acc[c][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
+                acc[c][1] = mma(acc[c][1], Fc.p[PA[pr]], Y1.p[PB[pr]]);
+                acc[c][2] = mma(acc[c][2], Fd.p[PA[pr]], Y1.p[PB[pr]]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Fa = Na; Fb = Nb; Fc = Nc;
+        }
+        {
+            Fd = loadF(4, 3);
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+                acc[4][0] = mma(acc[4][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
+                acc[4][1] = mma(acc[4][1], Fc.p[PA[pr]], Y0.p[PB[pr]]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+                acc[4][0] = mma(acc[4][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
+                acc[4][1] = mma(acc[4][1], Fd.p[PA[pr]], Y1.p[PB[pr]]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        if (has_next && !(p.ablate & 4)) {
+            publish_max();
+            __syncthreads();
+            write_lds();
+            __syncthreads();
+        }
+    }
+    {
+        const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * inv1 * inv2;
+    }
+    // reduce the four row-pair waves of each channel half through LDS (two rounds; 4 x 15 KB), then waves 0 and 4 write the slab's partial dW
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds);
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) red[((slot * 15) + c * 3 + d) * 64 + lane] = make_float4(acc[c][d][0], acc[c][d][1], acc[c][d][2], acc[c][d][3]);
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float4 v = red[((slot * 15) + c * 3 + d) * 64 + lane];
+                acc[c][d][0] += v.x; acc[c][d][1] += v.y; acc[c][d][2] += v.z; acc[c][d][3] += v.w;
+            }
+    };
+    if (wr >= 2) put(2 * wh + wr - 2);
+    __syncthreads();
+    if (wr < 2) add(2 * wh + wr);
+    __syncthreads();
+    if (wr == 1) put(wh);
+    __syncthreads();
+    if (wr == 0) {
+        add(wh);
+        float* part = p.partial + (size_t)slab * p.O;
+        const int Cin = p.C1 + p.C2;
+        const int co = cg * CG + i;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 4 * g + reg;
+                    const int combo = c < 4 ? 2 * c + (row >> 3) : 8;
+                    const int dyt = c < 4 ? d : 2 * d + (row >> 3);
+                    const int tap = (combo / 3) * 9 + dyt * 3 + combo % 3, ci = wh * 8 + (row & 7);
                     if (dyt < 3 && (c < 4 || d < 2) && co < p.Cout) part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[c][d][reg];
                 }
     }
@@ -2063,8 +2365,8 @@ static size_t packed_bytes(int Cin, int Cout, int CK) {
     return da_align(b) + da_align(kDynCtrInts * sizeof(int));
 }
 
-struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; };
-static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, bool split = false) {
+struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; int w16; };      // w16: conv3_split_wgrad16_kernel (16-channel chunks, one 8-wave workgroup per CU)
+static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, bool split = false, bool allow16 = false) {
     WgPlan q;
     q.CK = pick_ck(C1, C2);
     const int NT = (Cout + 15) / 16;
@@ -2077,6 +2379,13 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
     const size_t O = (size_t)27 * (C1 + C2) * Cout;
     long long slabs = 512 / (q.nchunks * q.ngroups); if (slabs < 1) slabs = 1;      // one resident round: 2 workgroups / CU
     const long long cap = (long long)((96ull << 20) / (O * 4)); if (slabs > cap) slabs = cap < 1 ? 1 : cap;
+    q.w16 = 0;
+    if (allow16 && split && q.CK && C1 % 16 == 0 && C2 % 16 == 0 && DA_WG_TZ == 2) {
+        static int on = -1; if (on < 0) { const char* e = getenv("DA_WG16"); on = (e && !atoi(e)) ? 0 : 1; }
+        const int combos = ((C1 + C2) / 16) * q.ngroups;
+        long long s16 = (256 / combos) & ~7ll;               // one workgroup per CU, a multiple of 8 slabs (XCD grouping)
+        if (on && s16 >= 8 && s16 * combos >= 224 && s16 <= cap && s16 <= q.ntiles) { q.w16 = 1; q.nchunks = (C1 + C2) / 16; slabs = s16; }
+    }
     if (slabs > q.ntiles) slabs = q.ntiles;
     if (slabs >= 8) slabs &= ~7ll;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
     q.tps = (int)da_cdiv(q.ntiles, slabs);
@@ -2489,6 +2798,22 @@ static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
     return 0;
 }
 
+template <bool PRO>
+static int launch_split_wgrad16(const WgP& p, const WgPlan& q, hipStream_t st) {
+    size_t shm = (size_t)(4 * (HY * HX * 16 + 4 * DA_WG16_ZPAD) + 2 * TY * TX * 16 + 16) * sizeof(float);
+    if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tiles' LDS
+    auto kern = conv3_split_wgrad16_kernel<PRO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(q.nslabs, q.nchunks, q.ngroups), dim3(512), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f, int act_bf16) {
     const bool hb = act_bf16 != 0;
@@ -2557,7 +2882,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     // (measured, 2 x 160 x 192 x 160: bf16 storage 48 -> 16 1.23 -> 1.09 ms, 16 -> 16 0.42 -> 0.38; NOT for more than one cout tile -- 96 -> 32: 0.44 ->
     // 0.70 ms, the kernel re-stages x per 16-cout group -- and not with fp32 tensors, 1.21 -> 1.94 ms: there the staging conversions dominate)
     const bool rows1 = !bfv1 && hb && da_matrix_mode() == 1 && s2d_cin == 0 && Cout % 4 == 0 && Cout <= 16 && pick_ck(C1, C2) != 0;
-    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1);
+    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
@@ -2592,7 +2917,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
-        if (split) rcp = launch_split_wgrad<true>(p, q, st);
+        if (split) rcp = q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
         else if (rows1) rcp = launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
@@ -2602,7 +2927,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (split) rc = launch_split_wgrad<false>(p, q, st);
+    if (split) rc = q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
     else if (rows1) rc = launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
