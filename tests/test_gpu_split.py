@@ -61,6 +61,10 @@ CASES = [
     (8, 16, 3, (1, 5, 9, 18)),         # the flow conv 24 -> 3 (conv3d_flowmm.hip: (dy, cout) columns), ragged tiles in every axis
     (16, 0, 3, (2, 4, 8, 16)),         # one source tensor, two samples, exact tiles
     (8, 8, 2, (1, 3, 7, 20)),          # two output channels
+    # enough tiles for the weight gradient's 16-channel / eight-wave form (conv3_split_wgrad16_kernel: slabs x chunks x groups >= 224)
+    (32, 16, 16, (1, 15, 41, 50)),     # 48 -> 16: three 16-channel chunks over two tensors, ragged tiles in every axis, odd tile count per slab
+    (16, 0, 16, (2, 16, 40, 64)),      # one chunk, 256 slabs, two samples
+    (32, 0, 32, (1, 12, 36, 40)),      # two chunks x two cout groups
 ]
 
 
@@ -111,6 +115,21 @@ S2_CASES = [
     (32, 64, (1, 8, 8, 40)),           # two 32-wide output groups
     (16, 64, (1, 2, 2, 2)),            # a single output voxel
 ]
+
+
+@pytest.mark.parametrize('C1,C2,Cout,dims,lazy', [(32, 16, 16, (1, 15, 41, 50), (True, False)), (16, 0, 16, (2, 16, 40, 64), (True, False)),
+                                                  (16, 16, 32, (1, 13, 24, 48), (True, True))])
+def test_split_mode_input_prologue_is_bit_identical_at_sizes_of_the_eight_wave_weight_gradient(C1, C2, Cout, dims, lazy):
+    """The deferred BatchNorm + LeakyReLU prologue (fwd_pro / wgrad_pro) against the plain entries on the materialised activation, in split
+    mode and at sizes where the weight gradient runs its 16-channel eight-wave form: the tile maxima are taken after the prologue, so
+    scales, splits and sums are the same -> bit-identical."""
+    from deepatlas_amd import ops
+    from test_gpu_ops import _prologue_case
+    prev = ops.set_matrix_precision('fp32_split')
+    try:
+        _prologue_case(C1, C2, Cout, dims, lazy)
+    finally:
+        ops.set_matrix_precision(prev)
 
 
 @pytest.mark.parametrize('kind', ['uniform', 'lognormal'])

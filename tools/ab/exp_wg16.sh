@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_split.py -q -x 2>&1 | tail -3
+python -m pytest tests/test_gpu_split.py -q -x 2>&1 | tail -8
 for on in 0 1 0 1; do
 for L in 32,16,16,2,160,192,160 16,0,16,2,160,192,160 32,0,32,2,80,96,80 64,64,64,2,40,48,40; do
   echo "DA_WG16=$on"
