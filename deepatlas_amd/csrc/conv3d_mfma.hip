@@ -1905,23 +1905,25 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
 #ifndef DA_WG16_ZPAD
 #define DA_WG16_ZPAD 4
 #endif
+// Phases as in the row-owner kernel (MFMAs | barrier | convert + write | barrier), ~205 registers and 62 KB of LDS.  A two-buffer form (one
+// barrier per tile, the next tile converted between the MFMAs, loads two tiles ahead: 254 registers, 125 KB) is faster alone (48 -> 16:
+// 1.72 vs 1.85 ms) but slower in the training step (seg 22.8 vs 21.65 ms): it fills the register file, and the BatchNorm-backward kernels
+// of the main stream -- HBM-bound, the natural partners of a matrix-bound weight gradient on the side stream -- then wait for it to end
+// instead of running beside it in the 2 x 48 registers per SIMD and 98 KB of LDS this form leaves free.
 template <bool PRO>
 __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CK = 16, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX, NT = 512;
     constexpr int ZPQ = DA_WG16_ZPAD, ZPE = 4 * ZPQ;
     constexpr int QA = CK / 4, HV = HZ * HY * HX, TOTA = HV * QA, NITA = (TOTA + NT - 1) / NT;
-    // LDS image of the x tile: the chunk's two 8-channel halves as two images of 16-byte voxel records -- the row-owner kernel's layout, whose
-    // fragment reads are nearly conflict-free (1.2 LDS cycles per half-wave read with 4 quads of padding per z plane; 32-byte records with the
-    // halves side by side: 2.8, SQ_LDS_BANK_CONFLICT 8x higher -- lanes 8 voxels apart are then exactly 64 banks apart)
-    constexpr int PLH = HZ * (HY * HX * 8 + ZPE), PLA = 2 * PLH, PLY = TVOX * CG;      // elements per half image / per plane
+    constexpr int PLH = HZ * (HY * HX * 8 + ZPE), PLA = 2 * PLH, PLY = TVOX * CG;      // elements per half image / per plane (x tile: the chunk's two 8-channel halves as two images of 16-byte voxel records -- the row-owner kernel's layout, 1.2 LDS cycles per half-wave fragment read; 32-byte records with the halves side by side: 2.8, lanes 8 voxels apart are then exactly 64 banks apart)
     constexpr int QY = CG / 4, NITY = (TVOX * QY + NT - 1) / NT;
-    constexpr int BUF = PLA + PLY;                                         // floats per buffer: two fp16 planes of the x tile, two of the dY tile
-    // Two buffers: tile t is read from buffer t & 1 while tile t + 1 is converted into the other one, between the MFMAs -- one barrier per
-    // tile, and the staging arithmetic runs in the matrix pipe's shadow instead of in a phase of its own (with one workgroup per CU there
-    // is no second workgroup to fill that phase).  The loads run two tiles ahead (two register sets), the waves' maxima one barrier ahead.
-    float* smax = lds + 2 * BUF;                                           // [2 parities][2][8]
+    float* ldsA = lds;
+    float* ldsY = lds + PLA;                                               // two fp16 planes of PLA elements = PLA floats
+    float* smax = ldsY + PLY;                                              // [2][8]
     typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+    const short* ldsAh = reinterpret_cast<const short*>(ldsA);
+    const short* ldsYh = reinterpret_cast<const short*>(ldsY);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave & 3, wh = wave >> 2;                               // row pair, channel half
@@ -1931,6 +1933,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
     const float* src; int Cs, choff;
     if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
     const int c4 = (int)threadIdx.x % QA;
+    unsigned vmA = 0;
     float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
     if constexpr (PRO) {
         const int cofs = choff + c4 * 4;
@@ -1954,6 +1957,21 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
     };
     auto mma = [&](f32x4 c, const f16x8& a, const f16x8& b) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); };
     struct F3 { f16x8 p[2]; };
+    auto loadF = [&](int c, int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * 8);
+        f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
+        return f;
+    };
+    auto loadG = [&](int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA + offC[4] + (h + (q >> 1)) * (HX * 8);
+        f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
+        return f;
+    };
+    auto loadY = [&](int r) -> F3 {
+        F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
+        f.p[0] = tr8(a, 4 * CG); f.p[1] = tr8(a + PLY, 4 * CG);
+        return f;
+    };
     f32x4 acc[5][3];
 #pragma unroll
     for (int c = 0; c < 5; ++c)
@@ -1961,8 +1979,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         for (int d = 0; d < 3; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const TileWalk tw = tile_walk(p.ntiles, nsl, slab);
-    float4 preA[2][NITA], preY[2][NITY];
-    unsigned vmA[2] = {0u, 0u};
+    float4 preA[NITA], preY[NITY];
     // staging maps (launch constants): x halo quad idx = threadIdx.x + 512 it -> halo voxel idx / 4; dY quad idx -> voxel idx / 4
     int voA[NITA]; unsigned pkA[NITA];
 #pragma unroll
@@ -1983,7 +2000,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         int pos = tw.lo + tile * tw.J; pos = pos < p.ntiles ? pos : p.ntiles - 1;
         return p.tiles[__builtin_amdgcn_readfirstlane(pos)];
     };
-    auto issue_loads = [&](const int4 tv, float4* pa, float4* py, unsigned& vm) __attribute__((always_inline)) {
+    auto issue_loads = [&](const int4 tv) {
         const int n = __builtin_amdgcn_readfirstlane(tv.x), z0 = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
         {
             const long long sample = (long long)p.D * p.H * p.W * Cs;
@@ -1991,7 +2008,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
             const bool interior = smallA && z0 >= 1 && z0 + HZ - 2 < p.D && y0 >= 1 && y0 + HY - 2 < p.H && x0 >= 1 && x0 + HX - 2 < p.W;
             const unsigned Cs4 = (unsigned)Cs * 4u, cofs4 = (unsigned)(choff + c4 * 4) * 4u;
             const unsigned base = (unsigned)(((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * Cs4 + cofs4;
-            if constexpr (PRO) vm = 0;
+            if constexpr (PRO) vmA = 0;
 #pragma unroll
             for (int it = 0; it < NITA; ++it) {
                 const int hz = (int)(pkA[it] >> 16), hy = (int)((pkA[it] >> 8) & 255u), hx = (int)(pkA[it] & 255u);
@@ -2002,8 +2019,8 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
                     const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
                     so = inb ? (unsigned)(((z * p.H + y) * p.W + x)) * Cs4 + cofs4 : 0xFFFFFFFFu;
                 }
-                pa[it] = da_buf_loadq<false, false>(rs, so);
-                if constexpr (PRO) vm |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
+                preA[it] = da_buf_loadq<false, false>(rs, so);
+                if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
             }
         }
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
@@ -2022,69 +2039,66 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
                 const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
                 off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * 4) : 0xFFFFFFFFu;
             }
-            py[it] = da_buf_loadq<false, false>(ry, off);
+            preY[it] = da_buf_loadq<false, false>(ry, off);
         }
     };
-    // the waves' largest |x| and |dY| of a parked tile -> smax[parity]; read after the next barrier
-    auto publish_max = [&](float4* pa, float4* py, unsigned vm, int par) __attribute__((always_inline)) {
-        if constexpr (PRO) stage_pro_apply<0, NITA>(pa, vm, psc, psf, pslope);
-        const float ma = da_wave_max_nonneg(stage_absmax<NITA>(pa)), my = da_wave_max_nonneg(stage_absmax<NITY>(py));
-        if (lane == 0) { smax[par * 16 + wave] = ma; smax[par * 16 + 8 + wave] = my; }
+    int Eacc = 0, Emin = 0, Enext = 0; bool first_tile = true;
+    auto publish_max = [&]() {
+        if constexpr (PRO) stage_pro_apply<0, NITA>(preA, vmA, psc, psf, pslope);
+        const float ma = da_wave_max_nonneg(stage_absmax<NITA>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+        if (lane == 0) { smax[wave] = ma; smax[8 + wave] = my; }
     };
-    int Eacc = 0, Emin = 0, Ecur = 0; bool first_tile = true;
-    float sa = 1.f, sy = 1.f; int Enew = 0;
-    auto next_scales = [&](int par) __attribute__((always_inline)) {                                      // scales of the parked tile (unit Enew), from the published maxima
-        const float* sm = smax + par * 16;
-        const float4 ma0 = *reinterpret_cast<const float4*>(sm), ma1 = *reinterpret_cast<const float4*>(sm + 4);
-        const float4 my0 = *reinterpret_cast<const float4*>(sm + 8), my1 = *reinterpret_cast<const float4*>(sm + 12);
+    auto write_lds = [&]() {
+        const float4 ma0 = *reinterpret_cast<const float4*>(smax), ma1 = *reinterpret_cast<const float4*>(smax + 4);
+        const float4 my0 = *reinterpret_cast<const float4*>(smax + 8), my1 = *reinterpret_cast<const float4*>(smax + 12);
         const float mA = fmaxf(fmaxf(fmaxf(ma0.x, ma0.y), fmaxf(ma0.z, ma0.w)), fmaxf(fmaxf(ma1.x, ma1.y), fmaxf(ma1.z, ma1.w)));
         const float mY = fmaxf(fmaxf(fmaxf(my0.x, my0.y), fmaxf(my0.z, my0.w)), fmaxf(fmaxf(my1.x, my1.y), fmaxf(my1.z, my1.w)));
         const int ea = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mA))));
         const int ey = da_scale_exp(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mY))));
         int E = ea + ey;
         if (!first_tile) E = min(E, Emin + 40);
-        if (!first_tile && E >= Ecur && E <= Ecur + 3) E = Ecur;           // (keep the accumulators' unit: see conv3_split_wgrad_kernel)
+        if (!first_tile && E >= Eacc && E <= Eacc + 3) E = Eacc;           // (keep the accumulators' unit: see conv3_split_wgrad_kernel)
         Emin = first_tile ? E : min(Emin, E);
         first_tile = false;
-        Enew = E;
-        sy = da_pow2(ey); sa = da_pow2(E - ey);
-    };
-    auto conv_x = [&](const float4* pa, float* buf, int it) __attribute__((always_inline)) {              // one parked x quad -> the two planes of `buf`
-        const int idx0 = threadIdx.x + it * NT;
-        if (idx0 < TOTA) {
-            const int hv = idx0 >> 2;                                      // halo voxel; this thread's quad c4 = idx0 & 3 -> half c4 >> 1, quad c4 & 1 of the half
-            const int idx = (c4 >> 1) * (PLH / 4) + hv * 2 + (c4 & 1) + ZPQ * (hv / (HY * HX));
-            uint2 h, l; da_split2(pa[it], sa, h, l);
-            reinterpret_cast<uint2*>(buf)[idx] = h; reinterpret_cast<uint2*>(buf)[idx + PLA / 4] = l;
+        Enext = E;
+        const float sy = da_pow2(ey), sa = da_pow2(E - ey);
+#pragma unroll
+        for (int it = 0; it < NITA; ++it) {
+            const int idx0 = threadIdx.x + it * NT;
+            if (idx0 < TOTA) {
+                const int hv = idx0 >> 2;
+                const int idx = (c4 >> 1) * (PLH / 4) + hv * 2 + (c4 & 1) + ZPQ * (hv / (HY * HX));
+                uint2 h, l; da_split2(preA[it], sa, h, l);
+                reinterpret_cast<uint2*>(ldsA)[idx] = h; reinterpret_cast<uint2*>(ldsA)[idx + PLA / 4] = l;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int idx = threadIdx.x + it * NT;
+            if (idx < TVOX * QY) {
+                uint2 h, l; da_split2(preY[it], sy, h, l);
+                reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + PLY / 4] = l;
+            }
         }
     };
-    auto conv_y = [&](const float4* py, float* buf, int it) __attribute__((always_inline)) {
-        const int idx = threadIdx.x + it * NT;
-        if (idx < TVOX * QY) {
-            uint2 h, l; da_split2(py[it], sy, h, l);
-            reinterpret_cast<uint2*>(buf + PLA)[idx] = h; reinterpret_cast<uint2*>(buf + PLA)[idx + PLY / 4] = l;
+    int4 tnext = fetch_tile(1);
+    if (tw.cnt > 0) { issue_loads(fetch_tile(0)); publish_max(); __syncthreads(); write_lds(); }
+    __syncthreads();
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll 1
+    for (int tile = 0; tile < tw.cnt; ++tile) {
+        const bool has_next = tile + 1 < tw.cnt;
+        if (has_next && !(p.ablate & 1)) issue_loads(tnext);
+        tnext = fetch_tile(tile + 2);
+        if (Enext != Eacc) {
+            const float f = da_pow2(Enext - Eacc);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * f;
+            Eacc = Enext;
         }
-    };
-    // One tile: MFMAs on buffer `cur`, the parked tile converted into buffer `nxt` between them (STG quads: 6 x + 2 dY over the 10 groups).
-    auto run_tile = [&](const float* cur, float* nxt, const float4* pa, const float4* py, bool stage) __attribute__((always_inline)) {
-        const short* ldsAh = reinterpret_cast<const short*>(cur);
-        const short* ldsYh = reinterpret_cast<const short*>(cur + PLA);
-        auto loadF = [&](int c, int h) __attribute__((always_inline)) -> F3 {
-            F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * 8);
-            f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
-            return f;
-        };
-        auto loadG = [&](int h) __attribute__((always_inline)) -> F3 {
-            F3 f; const short* a = ldsAh + laneA + offC[4] + (h + (q >> 1)) * (HX * 8);
-            f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
-            return f;
-        };
-        auto loadY = [&](int r) __attribute__((always_inline)) -> F3 {
-            F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
-            f.p[0] = tr8(a, 4 * CG); f.p[1] = tr8(a + PLY, 4 * CG);
-            return f;
-        };
-        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+        if (!(p.ablate & 2)) {
         F3 Y0 = loadY(0), Y1 = loadY(1);
         F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
 #pragma unroll
@@ -2097,7 +2111,6 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
                 acc[c][1] = mma(acc[c][1], Fb.p[PA[pr]], Y0.p[PB[pr]]);
                 acc[c][2] = mma(acc[c][2], Fc.p[PA[pr]], Y0.p[PB[pr]]);
             }
-            if (stage) { if (2 * c < NITA) conv_x(pa, nxt, 2 * c); }
             __builtin_amdgcn_sched_barrier(0);
             if (c < 3) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); } else { Nb = loadG(1); Nc = loadF(4, 2); }
 #pragma unroll
@@ -2106,7 +2119,6 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
                 acc[c][1] = mma(acc[c][1], Fc.p[PA[pr]], Y1.p[PB[pr]]);
                 acc[c][2] = mma(acc[c][2], Fd.p[PA[pr]], Y1.p[PB[pr]]);
             }
-            if (stage) { if (2 * c + 1 < NITA) conv_x(pa, nxt, 2 * c + 1); }
             __builtin_amdgcn_sched_barrier(0);
             Fa = Na; Fb = Nb; Fc = Nc;
         }
@@ -2117,60 +2129,21 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
                 acc[4][0] = mma(acc[4][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
                 acc[4][1] = mma(acc[4][1], Fc.p[PA[pr]], Y0.p[PB[pr]]);
             }
-            if (stage) conv_y(py, nxt, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {
                 acc[4][0] = mma(acc[4][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
                 acc[4][1] = mma(acc[4][1], Fd.p[PA[pr]], Y1.p[PB[pr]]);
             }
-            if (stage) {
-#pragma unroll
-                for (int it = 1; it < NITY; ++it) conv_y(py, nxt, it);
-#pragma unroll
-                for (int it = 8; it < NITA; ++it) conv_x(pa, nxt, it);
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    static_assert(NITA <= 8 && NITY >= 1, "staging slots of run_tile");
-    if (tw.cnt <= 0) return;                                               // (every thread of the workgroup: no barrier has been reached)
-    // prologue: tile 0 into buffer 0 (register set 0), tile 1 parked in set 1 with its maxima published
-    issue_loads(fetch_tile(0), preA[0], preY[0], vmA[0]);
-    if (tw.cnt > 1) issue_loads(fetch_tile(1), preA[1], preY[1], vmA[1]);
-    publish_max(preA[0], preY[0], vmA[0], 0);
-    __syncthreads();
-    next_scales(0); Ecur = Enew; Eacc = Enew;
-#pragma unroll
-    for (int it = 0; it < NITA; ++it) conv_x(preA[0], lds, it);
-#pragma unroll
-    for (int it = 0; it < NITY; ++it) conv_y(preY[0], lds, it);
-    if (tw.cnt > 1) publish_max(preA[1], preY[1], vmA[1], 1);
-    __syncthreads();
-    int4 tnext = fetch_tile(2);
-    // iteration t (parity b): buffer b holds tile t; register set b ^ 1 holds tile t + 1 (maxima in smax[b ^ 1]); set b is free for tile t + 2
-    auto body = [&](auto BC, int t) __attribute__((always_inline)) {
-        constexpr int b = decltype(BC)::value;
-        const bool has1 = t + 1 < tw.cnt, has2 = t + 2 < tw.cnt;
-        if (has1) next_scales(b ^ 1);
-        if (has2 && !(p.ablate & 1)) issue_loads(tnext, preA[b], preY[b], vmA[b]);
-        tnext = fetch_tile(t + 3);
-        if (Ecur != Eacc) {
-            const float f = da_pow2(Ecur - Eacc);
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * f;
-            Eacc = Ecur;
         }
-        run_tile(lds + b * BUF, lds + (b ^ 1) * BUF, preA[b ^ 1], preY[b ^ 1], has1);
-        if (has2) publish_max(preA[b], preY[b], vmA[b], b);
-        if (has1) { __syncthreads(); Ecur = Enew; }
-    };
-#pragma unroll 1
-    for (int t = 0; t < tw.cnt; t += 2) {
-        body(IntC<0>{}, t);
-        if (t + 1 < tw.cnt) body(IntC<1>{}, t + 1);
+        if (has_next && !(p.ablate & 4)) {
+            publish_max();
+            __syncthreads();
+            write_lds();
+            __syncthreads();
+        }
     }
     {
         const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));
@@ -2833,8 +2806,8 @@ static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
 
 template <bool PRO>
 static int launch_split_wgrad16(const WgP& p, const WgPlan& q, hipStream_t st) {
-    size_t shm = (size_t)(2 * (2 * 4 * (HY * HX * 8 + 4 * DA_WG16_ZPAD) + 2 * TY * TX * 16) + 32) * sizeof(float);      // two tile buffers + the waves' maxima
-    if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tiles' LDS
+    size_t shm = (size_t)(2 * 4 * (HY * HX * 8 + 4 * DA_WG16_ZPAD) + 2 * TY * TX * 16 + 32) * sizeof(float);      // the tile + the waves' maxima
+    if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tile's LDS
     auto kern = conv3_split_wgrad16_kernel<PRO>;
     static bool attr_set = false;
     if (!attr_set) {
