@@ -2389,8 +2389,10 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
     if (allow16 && split && q.CK && C1 % 16 == 0 && C2 % 16 == 0 && DA_WG_TZ == 2) {
         static int on = -1; if (on < 0) { const char* e = getenv("DA_WG16"); on = (e && !atoi(e)) ? 0 : 1; }
         const int combos = ((C1 + C2) / 16) * q.ngroups;
-        long long s16 = (256 / combos) & ~7ll;               // one workgroup per CU, a multiple of 8 slabs (XCD grouping)
-        if (on && s16 >= 8 && s16 * combos >= 224 && s16 <= cap && s16 <= q.ntiles) { q.w16 = 1; q.nchunks = (C1 + C2) / 16; slabs = s16; }
+        long long s16 = (256 / combos) & ~7ll;               // one workgroup per CU, a multiple of 8 slabs (XCD grouping) ...
+        { static int any = -1; if (any < 0) { const char* e = getenv("DA_WG16_ANY"); any = (e && !atoi(e)) ? 0 : 1; }
+          if (any && s16 * combos < 224) s16 = 256 / combos; }  // ... or any slab count that fills the chip (tile_walk then walks one list): 192 -> 64 0.65 -> 0.60 ms, 96 -> 32 unchanged
+        if (on && s16 >= 1 && s16 * combos >= 224 && s16 <= cap && s16 <= q.ntiles) { q.w16 = 1; q.nchunks = (C1 + C2) / 16; slabs = s16; }
     }
     if (slabs > q.ntiles) slabs = q.ntiles;
     if (slabs >= 8) slabs &= ~7ll;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
