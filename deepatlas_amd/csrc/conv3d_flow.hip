@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
 
     constexpr int NX2 = TVOX * 4 / 256;            // float4 loads per thread for a 16-channel tile (8)
     constexpr int NDY = (HVOX * 3 + 255) / 256;    // dword loads per thread for the dy halo tile, Cout <= 3 (13)
-    float4 pa[NX2], pb[NX2];
+    constexpr int NX1 = TWO ? TVOX * (S1 / 4) / 256 : 1;   // float4 loads per thread for the in1 tile (S1 = 8: at most 8 channels, 4 loads)
+    float4 pa[NX2], pb[NX1];
     float pd[NDY];
     auto issue = [&](int tile) {
         int t = tile;
@@ -95,14 +96,15 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
         const __amdgpu_buffer_rsrc_t ry2 = flow_rsrc(Cd2 > 0 ? p.dyb + (size_t)n * vol * Cd2 : p.dy, Cd2 > 0 ? (unsigned)(vol * Cd2 * 4ull) : 0u);
 #pragma unroll
         for (int it = 0; it < NX2; ++it) {
-            const int idx = threadIdx.x + it * 256;
+            int idx = threadIdx.x + it * 256;
+            asm volatile("" : "+v"(idx));                 // keep the decomposition out of the persistent loop's invariants (registers)
             {   // in2: Q2 quads per voxel
                 const int c4 = Q2 > 0 ? idx % Q2 : 0, v = Q2 > 0 ? idx / Q2 : TVOX;
                 const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
                 const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
                 pa[it] = ldx(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * EX) : 0xFFFFFFFFu);
             }
-            if (TWO) {   // in1: Q1 quads per voxel
+            if (TWO && it < NX1) {   // in1: Q1 quads per voxel (<= S1 / 4: the tile is covered by the first NX1 iterations)
                 const int c4 = Q1 > 0 ? idx % Q1 : 0, v = Q1 > 0 ? idx / Q1 : TVOX;
                 const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
                 const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
         for (int it = 0; it < NX2; ++it) {
             const int idx = threadIdx.x + it * 256;
             if (Q2 > 0 && idx < TVOX * Q2) *reinterpret_cast<float4*>(xa + (idx / Q2) * 16 + (idx % Q2) * 4) = pa[it];
-            if (TWO && Q1 > 0 && idx < TVOX * Q1) *reinterpret_cast<float4*>(xb + (idx / Q1) * S1 + (idx % Q1) * 4) = pb[it];
+            if (TWO && it < NX1 && Q1 > 0 && idx < TVOX * Q1) *reinterpret_cast<float4*>(xb + (idx / Q1) * S1 + (idx % Q1) * 4) = pb[it < NX1 ? it : 0];
         }
 #pragma unroll
         for (int it = 0; it < NDY; ++it) {
