@@ -45,7 +45,8 @@ def main():
         sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false, 2>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true, 0, true, false, 2>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false, 2>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_split_wgrad_kernel<false, 2, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+               'conv3_split_wgrad_kernel<false, 2, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+               'conv3_split_wgrad16_kernel<false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}      # (16-channel chunks: whole 64-B sectors per voxel)
     else:
         sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
                'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
@@ -117,7 +118,7 @@ def main():
         # same + dy = 1 contiguous; data gradient: dy = 1 contiguous.  raw = sum_s actual_s / factor_s with equal over-fetch ratios, so
         # actual = raw * sum_s B_s / sum_s (B_s / factor_s)
         b_half, b_contig = (0.0, 1.0) if 'dgrad' in name else ((2.0, 2.0) if 'wgrad' in name else (2.0, 1.0))
-        if mode == 2:
+        if mode == 2 and 'wgrad16' not in k:      # (the 16-channel weight gradient stages the fp32 matrix mode's shapes: 64-B runs at a 128-B stride, contiguous rows)
             # split mode stages 8-channel chunks: in1 (32 channels) as 32-B runs at a 128-B stride, in2 / dy-as-input (16 channels) as 32-B runs at a
             # 64-B stride; the weight gradient's dY tile is staged in whole 64-B voxel rows (contiguous).  "half" below = the 128-B-stride
             # shape, "contig" = the 64-B-stride shape (+ the contiguous dY of the weight gradient, whose factor is folded in by weight)
