@@ -273,6 +273,118 @@ __global__ void fewcin_place_kernel(const float* __restrict__ tmp, float* __rest
     }
 }
 
+// ---- the same first-layer weight gradients on the vector ALUs (fp32 tensors).  27 Cin Cout <= 864 sums over 10^7 voxels are 2 - 4 GFMA: 0.03 -
+// 0.06 ms of v_fma, while the matrix form above spends 0.30 ms on seg's 1 -> 8 layer reading four-byte LDS operands for exact fp32 MFMAs of which
+// half the columns are padding -- and the seg step ends on that kernel (it needs the gradient that is computed last).  Here: 0.16 ms, seg step
+// 21.54 -> 21.38 ms.  One input channel only (see the dispatch below).
+// A lane owns (x, ci, cout quad); a wave walks a strip of XW = 64 / (Cin Cout / 4) voxels along x down YR rows.  Per row a lane loads its
+// dy quad (one 16-byte load, coalesced along x) and the 9 new values of its 3 x 3 x 3 input window (the window slides along y in registers,
+// the row index rotating through three unrolled copies of the body) and issues 108 FMAs into 27 x 4 accumulators that stay in registers for
+// every strip of the (persistent) wave; one shuffle tree per wave and one LDS pass per workgroup at the end.  Partials in dw_tio order.
+template <int CIN, int CQ>
+__global__ void __launch_bounds__(256) fewcin_wgrad_valu_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int cstride,
+                                                                const float* __restrict__ dy, float* __restrict__ partial,
+                                                                int N, int D, int H, int W, int YR, int nxs, int nys, int nstrips) {
+    constexpr int LPV = CIN * CQ, XW = 64 / LPV, COUT = 4 * CQ, O = 27 * CIN * COUT;
+    __shared__ float sh[4 * LPV * 108];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xl = lane / LPV, sub = lane % LPV, ci = sub / CQ, cq = sub % CQ;
+    const long long vol = (long long)D * H * W;
+    // ci -> (tensor, channel): one tensor with CIN channels (cstride = CIN) or two one-channel tensors (cstride = 1)
+    const float* xt = (CIN == 2 && cstride == 1 && ci == 1) ? xb : xa;
+    const int coff = (cstride == 1) ? 0 : ci;
+    const __amdgpu_buffer_rsrc_t rx = flow_rsrc(xt, (unsigned)((unsigned long long)N * vol * cstride * 4ull));
+    const __amdgpu_buffer_rsrc_t rg = flow_rsrc(dy, (unsigned)((unsigned long long)N * vol * COUT * 4ull));
+    float acc[27][4];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+#pragma unroll 1
+    for (int s = wid; s < nstrips; s += nw) {
+        int r = s;
+        const int xs = r % nxs; r /= nxs;
+        const int ys = r % nys; r /= nys;
+        const int z = r % D; const int n = r / D;
+        const int x = xs * XW + xl, y0 = ys * YR, y1 = min(H, y0 + YR);
+        // input value at (z + dz - 1, yy, x + dx - 1), zero outside the volume (out-of-range offsets read as zero)
+        auto ldx = [&](int dz, int yy, int dx) -> float {
+            const int zz = z + dz - 1, xx = x + dx - 1;
+            const bool ok = (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((((long long)n * D + zz) * H + yy) * W + xx) * cstride + coff) * 4u : 0xFFFFFFFFu;
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+        };
+        float xw[3][3][3];      // [dz][row slot][dx]; slot of input row yy: (yy - y0 + 1) % 3
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) { xw[dz][0][dx] = ldx(dz, y0 - 1, dx); xw[dz][1][dx] = ldx(dz, y0, dx); xw[dz][2][dx] = 0.f; }
+        const unsigned gbase = (unsigned)((((long long)n * D + z) * H) * W + x) * (unsigned)(COUT * 4) + (unsigned)cq * 16u;
+        const unsigned grow = (unsigned)W * (unsigned)(COUT * 4);
+        const bool xin = x < W;
+#pragma unroll 1
+        for (int yb = y0; yb < y1; yb += 3) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int y = yb + rr;
+                if (y < y1) {                                                   // wave-uniform
+                    // slots: row y - 1 -> rr, row y -> (rr + 1) % 3, row y + 1 -> (rr + 2) % 3 (loaded now)
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) xw[dz][(rr + 2) % 3][dx] = ldx(dz, y + 1, dx);
+                    const float4 g = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, xin ? gbase + (unsigned)y * grow : 0xFFFFFFFFu, 0, 0));
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                        for (int dyt = 0; dyt < 3; ++dyt)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const float a = xw[dz][(rr + dyt) % 3][dx];
+                                float* c = acc[(dz * 3 + dyt) * 3 + dx];
+                                c[0] = fmaf(a, g.x, c[0]); c[1] = fmaf(a, g.y, c[1]); c[2] = fmaf(a, g.z, c[2]); c[3] = fmaf(a, g.w, c[3]);
+                            }
+                }
+            }
+        }
+    }
+    // lanes with the same (ci, cout quad) of a wave, fixed order; then the four waves through LDS
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[t][j];
+#pragma unroll
+            for (int m = LPV; m < 64; m <<= 1) v += __shfl_xor(v, m);
+            acc[t][j] = v;
+        }
+    if (lane < LPV) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[(wave * LPV + sub) * 108 + t * 4 + j] = acc[t][j];
+    }
+    __syncthreads();
+    float* part = partial + (size_t)blockIdx.x * O;
+    for (int e = threadIdx.x; e < LPV * 108; e += 256) {
+        const int sb = e / 108, k = e % 108, t = k >> 2, j = k & 3;
+        const float v = (sh[e] + sh[LPV * 108 + e]) + (sh[2 * LPV * 108 + e] + sh[3 * LPV * 108 + e]);
+        part[(t * CIN + sb / CQ) * COUT + (sb % CQ) * 4 + j] = v;
+    }
+}
+
+template <int CIN, int CQ>
+static int fewcin_valu_launch(const float* in1, int C1, const float* in2, const float* dy, float* dw_tio, int N, int D, int H, int W, void* ws, hipStream_t st) {
+    constexpr int LPV = CIN * CQ, XW = 64 / LPV, O = 27 * CIN * 4 * CQ;
+    const int YR = 33;                                    // rows per strip (a multiple of 3: whole turns of the slot rotation)
+    const int nxs = (W + XW - 1) / XW, nys = (H + YR - 1) / YR;
+    const long long nstrips = (long long)N * D * nxs * nys;
+    if (nstrips > 0x7FFFFFFFll) return DA_ERR_UNSUPPORTED;
+    int nb = (int)((nstrips + 3) / 4); if (nb > kFlowBlocks) nb = kFlowBlocks;
+    hipLaunchKernelGGL((fewcin_wgrad_valu_kernel<CIN, CQ>), dim3(nb), dim3(256), 0, st, in1, in2, C1 == CIN ? CIN : 1, dy, (float*)ws, N, D, H, W, YR, nxs, nys, (int)nstrips);
+    DA_LAUNCH_CHECK();
+    return da_reduce_partials((float*)ws, nb, O, dw_tio, st);
+}
+
 bool da_conv3_fewcin_wgrad_supported(int C1, int C2, int Cout, int stride) {
     return stride == 1 && C1 >= 1 && C2 >= 0 && C1 + C2 <= 2 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16;
 }
@@ -283,6 +395,18 @@ int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, co
     const int Cin = C1 + C2, O = 27 * Cin * Cout;
     if (ws_bytes < da_align((size_t)kFlowBlocks * O * sizeof(float)) + da_align((size_t)O * sizeof(float))) return DA_ERR_WS_SMALL;
     if ((unsigned long long)D * H * W * 16ull * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
+    if (!dy_bf16 && (unsigned long long)N * D * H * W * (unsigned long long)Cout * 4ull < 0xFFFFFFF0ull && (Cout == 8 || Cout == 16) && (C2 == 0 || (C1 == 1 && C2 == 1))) {
+        static int off = -1; if (off < 0) { const char* e = getenv("DA_NO_FEWCIN_VALU"); off = (e && atoi(e)) ? 1 : 0; }
+        if (!off) {
+            if (Cin == 1 && Cout == 8) return fewcin_valu_launch<1, 2>(in1, C1, in2, dy, dw_tio, N, D, H, W, ws, st);
+            if (Cin == 1 && Cout == 16) return fewcin_valu_launch<1, 4>(in1, C1, in2, dy, dw_tio, N, D, H, W, ws, st);
+            // (two input channels: 8 lanes per voxel leave 8 voxels per wave-wide load -- reg 1 + 1 -> 16: 0.22 ms on the matrix form, slower here;
+            //  the instantiations stay for A/B builds)
+            static int two = -1; if (two < 0) { const char* e = getenv("DA_FEWCIN_VALU2"); two = (e && atoi(e)) ? 1 : 0; }
+            if (two && Cin == 2 && Cout == 8) return fewcin_valu_launch<2, 2>(in1, C1, in2, dy, dw_tio, N, D, H, W, ws, st);
+            if (two && Cin == 2 && Cout == 16) return fewcin_valu_launch<2, 4>(in1, C1, in2, dy, dw_tio, N, D, H, W, ws, st);
+        }
+    }
     FlowWgP p;
     p.in1 = nullptr; p.C1 = 0; p.in2 = dy; p.C2 = Cout;                   // "X" = dy
     p.dy = in1; p.dyb = in2; p.Cd1 = C1; p.Cout = Cin;                    // "DY" = x (one or two tensors)
