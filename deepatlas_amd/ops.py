@@ -237,13 +237,22 @@ def enable_async_wgrad(flag=True):
     ASYNC_WGRAD = bool(flag)
 
 
+_N_SIDE = max(1, int(os.environ.get('DA_SIDE_STREAMS', '1')))      # > 1: weight gradients alternate between that many side streams (experiment)
+_side_streams = []
+_side_rr = 0
+
+
 def side_stream():
-    """The second HIP stream; every caller is about to queue work on it."""
-    global _side_stream, _side_dirty
+    """The second HIP stream (round-robin over DA_SIDE_STREAMS of them); every caller is about to queue work on it."""
+    global _side_stream, _side_dirty, _side_rr
     if _side_stream is None:
         _side_stream = torch.cuda.Stream()
+        _side_streams.append(_side_stream)
+        for _ in range(_N_SIDE - 1):
+            _side_streams.append(torch.cuda.Stream())
     _side_dirty = True
-    return _side_stream
+    _side_rr = (_side_rr + 1) % len(_side_streams)
+    return _side_streams[_side_rr]
 
 
 _side_dirty = False      # work has been queued on the side stream since the last join
@@ -254,7 +263,8 @@ def join_side_stream():
     dependency at all (inside a HIP-graph capture a wait on work from before the capture would be illegal)."""
     global _side_dirty
     if _side_stream is not None and (_side_dirty or _side_keep):
-        torch.cuda.current_stream().wait_stream(_side_stream)
+        for s_ in _side_streams:
+            torch.cuda.current_stream().wait_stream(s_)
     _side_keep.clear()
     _side_dirty = False
 
@@ -274,7 +284,8 @@ def _serialize_matrix_kernels(flops, voxels):
     tails and waiting costs 10 % (268 vs 300 ms per step), and equally long kernels are left to overlap too."""
     if (ASYNC_WGRAD and _side_stream is not None and _side_dirty and flops >= _SERIALIZE_MIN_FLOPS and voxels >= _SERIALIZE_MIN_VOXELS
             and _last_side_flops <= _SERIALIZE_MAX_RATIO * flops):
-        torch.cuda.current_stream().wait_stream(_side_stream)
+        for s_ in _side_streams:
+            torch.cuda.current_stream().wait_stream(s_)
 
 
 _SERIALIZE_MIN_FLOPS = float(os.environ.get('DA_MFMA_SERIALIZE_MIN_FLOPS', '3e11'))      # 'inf' disables the rule
