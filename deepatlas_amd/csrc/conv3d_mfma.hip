@@ -1910,8 +1910,15 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
 // 1.72 vs 1.85 ms) but slower in the training step (seg 22.8 vs 21.65 ms): it fills the register file, and the BatchNorm-backward kernels
 // of the main stream -- HBM-bound, the natural partners of a matrix-bound weight gradient on the side stream -- then wait for it to end
 // instead of running beside it in the 2 x 48 registers per SIMD and 98 KB of LDS this form leaves free.
-template <bool PRO>
+// NPL = 2: split mode (fp32 tensors, two fp16 planes, three products).  NPL = 1 with HB: bf16 activation storage in the bf16 matrix mode -- one
+// bf16 plane, one product, no scales; a 16-channel chunk is then 32 bytes of a voxel (the row-owner form stages 16: a quarter of a sector).
+template <bool PRO, int NPL = 2, bool HB = false>
 __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
+    static_assert(NPL == 2 || (NPL == 1 && HB), "two fp16 planes of fp32 tensors, or one bf16 plane of bf16 tensors");
+    constexpr bool SPL = NPL == 2;
+    using WFrag = std::conditional_t<SPL, f16x8, bf16x8>;
+    constexpr bool RAWA = HB && !SPL && !PRO, RAWY = HB && !SPL;       // bf16 tensors copied straight into the bf16 LDS image
+    constexpr unsigned ES = HbEl<HB>::ES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CK = 16, CG = 16, TZ = 2, HZ = TZ + 2, TVOX = TZ * TY * TX, NT = 512;
     constexpr int ZPQ = DA_WG16_ZPAD, ZPE = 4 * ZPQ;
@@ -1919,8 +1926,8 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
     constexpr int PLH = HZ * (HY * HX * 8 + ZPE), PLA = 2 * PLH, PLY = TVOX * CG;      // elements per half image / per plane (x tile: the chunk's two 8-channel halves as two images of 16-byte voxel records -- the row-owner kernel's layout, 1.2 LDS cycles per half-wave fragment read; 32-byte records with the halves side by side: 2.8, lanes 8 voxels apart are then exactly 64 banks apart)
     constexpr int QY = CG / 4, NITY = (TVOX * QY + NT - 1) / NT;
     float* ldsA = lds;
-    float* ldsY = lds + PLA;                                               // two fp16 planes of PLA elements = PLA floats
-    float* smax = ldsY + PLY;                                              // [2][8]
+    float* ldsY = lds + PLA / 2 * NPL;                                     // NPL planes of PLA two-byte elements
+    float* smax = ldsY + PLY / 2 * NPL;                                    // [2][8]
     typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
     const short* ldsAh = reinterpret_cast<const short*>(ldsA);
     const short* ldsYh = reinterpret_cast<const short*>(ldsY);
@@ -1950,26 +1957,32 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         offC[c] = ((combo / 3) * HY * HX + combo % 3) * 8 + (combo / 3) * ZPE;
     }
     const int laneY = ((((g >> 1) * TY) + 2 * wr) * TX + 8 * (g & 1) + vq) * CG + q * 4;
-    auto tr8 = [&](const short* a, int step) -> f16x8 {
+    auto tr8 = [&](const short* a, int step) -> WFrag {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step));
-        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(WFrag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    auto mma = [&](f32x4 c, const f16x8& a, const f16x8& b) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); };
-    struct F3 { f16x8 p[2]; };
+    auto mma = [&](f32x4 c, const WFrag& a, const WFrag& b) -> f32x4 {
+        if constexpr (SPL) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
+    struct F3 { WFrag p[NPL]; };
     auto loadF = [&](int c, int h) -> F3 {
         F3 f; const short* a = ldsAh + laneA + offC[c] + h * (HX * 8);
-        f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * 8);
         return f;
     };
     auto loadG = [&](int h) -> F3 {
         F3 f; const short* a = ldsAh + laneA + offC[4] + (h + (q >> 1)) * (HX * 8);
-        f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLA, 4 * 8);
         return f;
     };
     auto loadY = [&](int r) -> F3 {
         F3 f; const short* a = ldsYh + laneY + r * (TX * CG);
-        f.p[0] = tr8(a, 4 * CG); f.p[1] = tr8(a + PLY, 4 * CG);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.p[pl] = tr8(a + pl * PLY, 4 * CG);
         return f;
     };
     f32x4 acc[5][3];
@@ -1989,11 +2002,11 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         pkA[it] = (hv < HV) ? ((unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx) : 0xFFFF0000u;
         voA[it] = (hv < HV) ? (hz * p.H + hy) * p.W + hx : 0;
     }
-    const bool smallA = (long long)HZ * p.H * p.W < (1ll << 24) && (long long)Cs * 4 < (1ll << 24);
+    const bool smallA = (long long)HZ * p.H * p.W < (1ll << 24) && (long long)Cs * ES < (1ll << 24);
     const int yq4 = cg * CG + ((int)threadIdx.x % QY) * 4;
     const int yv0 = (int)threadIdx.x / QY;
     int voY[NITY];
-    const bool smallY = (long long)TZ * p.H * p.W < (1ll << 24) && (long long)p.Cout * 4 < (1ll << 24);
+    const bool smallY = (long long)TZ * p.H * p.W < (1ll << 24) && (long long)p.Cout * ES < (1ll << 24);
 #pragma unroll
     for (int it = 0; it < NITY; ++it) { const int v = yv0 + it * (NT / QY); voY[it] = ((v >> 7) * p.H + ((v >> 4) & 7)) * p.W + (v & 15); }
     auto fetch_tile = [&](int tile) -> int4 {
@@ -2004,9 +2017,9 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         const int n = __builtin_amdgcn_readfirstlane(tv.x), z0 = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
         {
             const long long sample = (long long)p.D * p.H * p.W * Cs;
-            const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<false>(src, n, sample);
+            const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<HB>(src, n, sample);
             const bool interior = smallA && z0 >= 1 && z0 + HZ - 2 < p.D && y0 >= 1 && y0 + HY - 2 < p.H && x0 >= 1 && x0 + HX - 2 < p.W;
-            const unsigned Cs4 = (unsigned)Cs * 4u, cofs4 = (unsigned)(choff + c4 * 4) * 4u;
+            const unsigned Cs4 = (unsigned)Cs * ES, cofs4 = (unsigned)(choff + c4 * 4) * ES;      // (bytes per voxel record / of this thread's quad)
             const unsigned base = (unsigned)(((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * Cs4 + cofs4;
             if constexpr (PRO) vmA = 0;
 #pragma unroll
@@ -2019,36 +2032,57 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
                     const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
                     so = inb ? (unsigned)(((z * p.H + y) * p.W + x)) * Cs4 + cofs4 : 0xFFFFFFFFu;
                 }
-                preA[it] = da_buf_loadq<false, false>(rs, so);
+                preA[it] = da_buf_loadq<HB, RAWA>(rs, so);
                 if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
             }
         }
         const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
-        const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<false>(p.dy, n, sampleY);
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<HB>(p.dy, n, sampleY);
         const bool inside = smallY && z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;
         const int basev = (z0 * p.H + y0) * p.W + x0;
-        const unsigned baseY = ((unsigned)basev * (unsigned)p.Cout + (unsigned)yq4) * 4u;
+        const unsigned baseY = ((unsigned)basev * (unsigned)p.Cout + (unsigned)yq4) * ES;
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
             const int v = yv0 + it * (NT / QY);
             const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
             unsigned off;
-            if (inside) off = __umul24((unsigned)voY[it], (unsigned)p.Cout * 4u) + baseY;
+            if (inside) off = __umul24((unsigned)voY[it], (unsigned)p.Cout * ES) + baseY;
             else {
                 const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
                 const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
-                off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * 4) : 0xFFFFFFFFu;
+                off = vin ? (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + yq4) * ES) : 0xFFFFFFFFu;
             }
-            preY[it] = da_buf_loadq<false, false>(ry, off);
+            preY[it] = da_buf_loadq<HB, RAWY>(ry, off);
         }
     };
     int Eacc = 0, Emin = 0, Enext = 0; bool first_tile = true;
     auto publish_max = [&]() {
         if constexpr (PRO) stage_pro_apply<0, NITA>(preA, vmA, psc, psf, pslope);
-        const float ma = da_wave_max_nonneg(stage_absmax<NITA>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
-        if (lane == 0) { smax[wave] = ma; smax[8 + wave] = my; }
+        if constexpr (SPL) {
+            const float ma = da_wave_max_nonneg(stage_absmax<NITA>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+            if (lane == 0) { smax[wave] = ma; smax[8 + wave] = my; }
+        }
+    };
+    auto pack_bf16 = [&](const float4 v, bool raw) -> uint2 {             // one parked quad as four bf16 (raw: it already is, in .x / .y)
+        return raw ? make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)) : make_uint2(da_bf16x2(v.x, v.y), da_bf16x2(v.z, v.w));
     };
     auto write_lds = [&]() {
+        if constexpr (!SPL) {
+#pragma unroll
+            for (int it = 0; it < NITA; ++it) {
+                const int idx0 = threadIdx.x + it * NT;
+                if (idx0 < TOTA) {
+                    const int hv = idx0 >> 2;
+                    reinterpret_cast<uint2*>(ldsA)[(c4 >> 1) * (PLH / 4) + hv * 2 + (c4 & 1) + ZPQ * (hv / (HY * HX))] = pack_bf16(preA[it], RAWA);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NITY; ++it) {
+                const int idx = threadIdx.x + it * NT;
+                if (idx < TVOX * QY) reinterpret_cast<uint2*>(ldsY)[idx] = pack_bf16(preY[it], RAWY);
+            }
+            return;
+        }
         const float4 ma0 = *reinterpret_cast<const float4*>(smax), ma1 = *reinterpret_cast<const float4*>(smax + 4);
         const float4 my0 = *reinterpret_cast<const float4*>(smax + 8), my1 = *reinterpret_cast<const float4*>(smax + 12);
         const float mA = fmaxf(fmaxf(fmaxf(ma0.x, ma0.y), fmaxf(ma0.z, ma0.w)), fmaxf(fmaxf(ma1.x, ma1.y), fmaxf(ma1.z, ma1.w)));
@@ -2084,13 +2118,14 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
     int4 tnext = fetch_tile(1);
     if (tw.cnt > 0) { issue_loads(fetch_tile(0)); publish_max(); __syncthreads(); write_lds(); }
     __syncthreads();
-    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+    constexpr int NPR = SPL ? 3 : 1;
+    constexpr int PA[3] = {0, SPL ? 1 : 0, 0}, PB[3] = {SPL ? 1 : 0, 0, 0};      // (x, dY) plane pairs, small terms first (one plane: the single product)
 #pragma unroll 1
     for (int tile = 0; tile < tw.cnt; ++tile) {
         const bool has_next = tile + 1 < tw.cnt;
         if (has_next && !(p.ablate & 1)) issue_loads(tnext);
         tnext = fetch_tile(tile + 2);
-        if (Enext != Eacc) {
+        if (SPL && Enext != Eacc) {
             const float f = da_pow2(Enext - Eacc);
 #pragma unroll
             for (int c = 0; c < 5; ++c)
@@ -2106,7 +2141,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
             Fd = loadF(c, 3);
             Na = (c < 3) ? loadF(c + 1, 0) : loadG(0);
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
+            for (int pr = 0; pr < NPR; ++pr) {
                 acc[c][0] = mma(acc[c][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
                 acc[c][1] = mma(acc[c][1], Fb.p[PA[pr]], Y0.p[PB[pr]]);
                 acc[c][2] = mma(acc[c][2], Fc.p[PA[pr]], Y0.p[PB[pr]]);
@@ -2114,7 +2149,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
             __builtin_amdgcn_sched_barrier(0);
             if (c < 3) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); } else { Nb = loadG(1); Nc = loadF(4, 2); }
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
+            for (int pr = 0; pr < NPR; ++pr) {
                 acc[c][0] = mma(acc[c][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
                 acc[c][1] = mma(acc[c][1], Fc.p[PA[pr]], Y1.p[PB[pr]]);
                 acc[c][2] = mma(acc[c][2], Fd.p[PA[pr]], Y1.p[PB[pr]]);
@@ -2125,13 +2160,13 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         {
             Fd = loadF(4, 3);
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
+            for (int pr = 0; pr < NPR; ++pr) {
                 acc[4][0] = mma(acc[4][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
                 acc[4][1] = mma(acc[4][1], Fc.p[PA[pr]], Y0.p[PB[pr]]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
+            for (int pr = 0; pr < NPR; ++pr) {
                 acc[4][0] = mma(acc[4][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
                 acc[4][1] = mma(acc[4][1], Fd.p[PA[pr]], Y1.p[PB[pr]]);
             }
@@ -2145,7 +2180,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
             __syncthreads();
         }
     }
-    {
+    if constexpr (SPL) {
         const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));
 #pragma unroll
         for (int c = 0; c < 5; ++c)
@@ -2806,11 +2841,11 @@ static int launch_split_wgrad(const WgP& p, const WgPlan& q, hipStream_t st) {
     return 0;
 }
 
-template <bool PRO>
+template <bool PRO, int NPL = 2, bool HB = false>
 static int launch_split_wgrad16(const WgP& p, const WgPlan& q, hipStream_t st) {
-    size_t shm = (size_t)(2 * 4 * (HY * HX * 8 + 4 * DA_WG16_ZPAD) + 2 * TY * TX * 16 + 32) * sizeof(float);      // the tile + the waves' maxima
+    size_t shm = (size_t)(2 * 4 * (HY * HX * 8 + 4 * DA_WG16_ZPAD) + 2 * TY * TX * 16) * 2 * NPL + 128;      // the tile's planes + the waves' maxima
     if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);      // the cross-wave reduction at the end reuses the tile's LDS
-    auto kern = conv3_split_wgrad16_kernel<PRO>;
+    auto kern = conv3_split_wgrad16_kernel<PRO, NPL, HB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -2890,7 +2925,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     // (measured, 2 x 160 x 192 x 160: bf16 storage 48 -> 16 1.23 -> 1.09 ms, 16 -> 16 0.42 -> 0.38; NOT for more than one cout tile -- 96 -> 32: 0.44 ->
     // 0.70 ms, the kernel re-stages x per 16-cout group -- and not with fp32 tensors, 1.21 -> 1.94 ms: there the staging conversions dominate)
     const bool rows1 = !bfv1 && hb && da_matrix_mode() == 1 && s2d_cin == 0 && Cout % 4 == 0 && Cout <= 16 && pick_ck(C1, C2) != 0;
-    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split);
+    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split || rows1);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
@@ -2926,7 +2961,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
         if (split) rcp = q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
-        else if (rows1) rcp = launch_split_wgrad<true, 1, true>(p, q, st);
+        else if (rows1) rcp = q.w16 ? launch_split_wgrad16<true, 1, true>(p, q, st) : launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
         { DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2); }
@@ -2936,7 +2971,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     }
     int rc = DA_ERR_UNSUPPORTED;
     if (split) rc = q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
-    else if (rows1) rc = launch_split_wgrad<false, 1, true>(p, q, st);
+    else if (rows1) rc = q.w16 ? launch_split_wgrad16<false, 1, true>(p, q, st) : launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
         if (hb) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true, false, false, true>(p, q, st);

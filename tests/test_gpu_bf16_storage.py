@@ -375,3 +375,41 @@ def test_joint_step_bf16_storage(bf16_storage):
         nets.ACT_STORE_ROUND = None
     for k in keys:
         assert abs(got[k] - float(ref[k].item())) < 2e-2 * max(1.0, abs(float(ref[k].item()))), (k, got[k], float(ref[k].item()))
+
+
+@pytest.mark.parametrize('C1,C2,Cout,dims,lazy', [(32, 16, 16, (1, 15, 41, 50), False), (32, 16, 16, (1, 15, 41, 50), True), (16, 0, 16, (2, 16, 40, 64), True)])
+def test_bf16_storage_weight_gradient_eight_wave_form(bf16_storage, C1, C2, Cout, dims, lazy):
+    """da_conv3d_k3_wgrad_bf16 / _wgrad_pro_bf16 at sizes where the weight gradient runs its 16-channel eight-wave form (enough tiles to fill the
+    chip) against a double-precision evaluation on the same bf16 values: bf16 operands multiply exactly in fp32, so only the summation order
+    differs (ragged tiles in every axis, two source tensors, deferred BatchNorm + LeakyReLU on the first one)."""
+    import torch.nn.functional as F
+    from deepatlas_amd import _native as nat
+    from deepatlas_amd._native import call, ptr, stream, workspace
+    N, D, H, W = dims
+    d = dev()
+    g = torch.Generator().manual_seed(17)
+    raw1 = (torch.rand((N, D, H, W, C1), generator=g) * 2 - 1).to(torch.bfloat16)
+    raw2 = (torch.rand((N, D, H, W, C2), generator=g) * 2 - 1).to(torch.bfloat16) if C2 else None
+    dy = (torch.rand((N, D, H, W, Cout), generator=g) * 2 - 1).to(torch.bfloat16)
+    sc, sh, slope = torch.rand((C1,), generator=g) * 0.5 + 0.75, (torch.rand((C1,), generator=g) - 0.5) * 0.4, 0.01
+    if lazy:      # the kernel applies scale / shift / LeakyReLU in fp32 and rounds to bf16 on the way into LDS
+        z = raw1.float() * sc + sh
+        a1 = torch.maximum(z, z * slope).to(torch.bfloat16)
+    else:
+        a1 = raw1
+    x = torch.cat((a1, raw2), -1) if C2 else a1
+    xr = x.double().permute(0, 4, 1, 2, 3).requires_grad_(False)
+    wr = torch.zeros((Cout, C1 + C2, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv3d(xr, wr, None, padding=1).backward(dy.double().permute(0, 4, 1, 2, 3))
+    ref = wr.grad.permute(2, 3, 4, 1, 0).reshape(27, C1 + C2, Cout)
+    dw = torch.empty((27, C1 + C2, Cout), device=d)
+    wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)
+    wp, wn = workspace.get(wsb, d)
+    r1, r2, dyd = raw1.to(d), (raw2.to(d) if C2 else None), dy.to(d)
+    mask = 7 if C2 else 5                                      # in1 | in2 | dy stored as bf16
+    if lazy:
+        scd, shd = sc.to(d), sh.to(d)
+        call('da_conv3d_k3_wgrad_pro_bf16', ptr(r1), C1, ptr(scd), ptr(shd), slope, ptr(r2) if C2 else None, C2, None, None, -1.0, ptr(dyd), ptr(dw), N, D, H, W, Cout, wp, wn, stream(), mask)
+    else:
+        call('da_conv3d_k3_wgrad_bf16', ptr(r1), C1, ptr(r2) if C2 else None, C2, ptr(dyd), ptr(dw), None, N, D, H, W, Cout, 1, wp, wn, stream(), mask)
+    assert rel_l2(dw.cpu().numpy().astype(np.float64), ref.numpy()) < 2e-6

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_bf16_storage.py -q -x 2>&1 | tail -3
+DA_WG16=0 python -m pytest tests/test_gpu_bf16_storage.py -q -x -k eight_wave 2>&1 | tail -2
+for rep in 1 2; do
+for v in 0 1; do
+  echo "DA_WG16=$v"
+  DA_WG16=$v python bench.py --workload seg --precision bf16_storage --no-cpu-baseline --no-extra 2>&1 | grep '"metric"' > /tmp/b.json; python tools/bench_brief.py /tmp/b.json | head -1
+done
+done
