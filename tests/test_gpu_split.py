@@ -132,6 +132,27 @@ def test_split_mode_input_prologue_is_bit_identical_at_sizes_of_the_eight_wave_w
         ops.set_matrix_precision(prev)
 
 
+def test_eight_wave_weight_gradient_against_the_row_owner_kernel(tmp_path):
+    """The two forms of the split weight gradient (DA_WG16=1: 16-channel chunks / eight waves; DA_WG16=0: 8-channel chunks / four waves) on eight
+    layer shapes the unit cases do not reach -- 8 / 12 / 24 / 64 output channels, three samples, odd plane counts, input prologue -- in two
+    processes (the switch is read once per process): same tiles, same per-wave program, so they agree to the last bits of an fp32 sum."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ('1', '0'):
+        f = str(tmp_path / ('wg16_%s.npz' % v))
+        env = dict(os.environ, DA_WG16=v)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ab', 'w16_compare.py'), f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 8
+    for k in a.files:
+        x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+        assert np.isfinite(x).all()
+        assert np.linalg.norm(x - y) <= 2e-7 * np.linalg.norm(y), (k, np.linalg.norm(x - y) / np.linalg.norm(y))
+
+
 @pytest.mark.parametrize('kind', ['uniform', 'lognormal'])
 @pytest.mark.parametrize('case', S2_CASES, ids=lambda c: 's2_c%d_o%d_%s' % (c[0], c[1], 'x'.join(str(v) for v in c[2])))
 def test_native_stride2_split_kernels_are_fp32_accurate(case, kind):
