@@ -463,9 +463,9 @@ def main():
     ap.add_argument('--no-extra', action='store_true', help="skip the reg / joint legs and the post-run backward-kernel timing pass")
     ap.add_argument('--precision', default='fp32_split', choices=['fp32_split', 'fp32', 'bf16', 'bf16_storage'],
                     help="matrix arithmetic of the 3x3x3 convolutions.  'fp32_split' (headline): fp32 operands scaled per tile and split into two fp16 "
-                         "terms, three partial products per multiply on the fp16 pipe, fp32 accumulate -- fp32-accurate; 'fp32': the fp32 matrix "
+                         "terms, three partial products per multiply on the fp16 pipe, fp32 accumulate -- 22-bit products (per product narrower than fp32); 'fp32': the fp32 matrix "
                          "instructions (one fmaf per product; also timed by the default run, under extra.native_fp32_mfma); 'bf16': operands "
-                         "ROUNDED to bf16 (BASELINE configs[4]'s mixed precision; not fp32-accurate, never the headline)")
+                         "ROUNDED to bf16 (BASELINE configs[4]'s mixed precision; never the headline)")
     ap.add_argument('--graph', action='store_true', help='capture each step once as HIP graph(s) and replay it (one host call per step; per-call '
                     'HIP-event timing is then taken in the eager post-run pass only)')
     ap.add_argument('--no-fused-head', action='store_true', help='run the 1x1x1 head, softmax and Dice as separate kernels (logits materialised)')

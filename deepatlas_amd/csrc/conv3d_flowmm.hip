@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) fm_fwd_kernel(FwdP p) {
             const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
             const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bool inb = hv < HV && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            pre[it] = fm_load4(second ? r2 : r1, inb ? (unsigned)((((z * p.H + y) * p.W + x) * Ck + q * 4) * 4) : 0xFFFFFFFFu);
+            pre[it] = fm_load4(second ? r2 : r1, inb ? ((unsigned)((z * p.H + y) * p.W + x) * (unsigned)Ck + (unsigned)q * 4u) * 4u : 0xFFFFFFFFu);
         }
     };
     int Ecur = 0;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) fm_fwd_kernel(FwdP p) {
                 }
                 const int y = y0 + 4 * half + yl;
                 const bool ok = g == 0 && z < p.D && y < p.H && x < p.W;
-                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout) * 4);
+                const unsigned off = (unsigned)((z * p.H + y) * p.W + x) * (unsigned)p.Cout * 4u;      // (voxel index < 2^31 by da_conv3_flowmm_supported; the byte offset needs all 32 bits: unsigned arithmetic)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[c]), ro, (ok && c < p.Cout) ? off + 4 * c : 0xFFFFFFFFu, 0, 0);
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) fm_dgrad_kernel(DgP p) {
             const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
             const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bool inb = hv < HV && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout) * 4);
+            const unsigned off = (unsigned)((z * p.H + y) * p.W + x) * (unsigned)p.Cout * 4u;      // (voxel index < 2^31 by da_conv3_flowmm_supported; the byte offset needs all 32 bits: unsigned arithmetic)
             float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c] = fm_load1(ry, (inb && c < p.Cout) ? off + 4 * c : 0xFFFFFFFFu);
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) fm_dgrad_kernel(DgP p) {
                     const int y = y0 + 4 * half + r;
                     const bool ok = c0 < Cin && z < p.D && y < p.H && x < p.W;
                     const int v = (z * p.H + y) * p.W + x;
-                    const unsigned off = to1 ? (unsigned)((v * C1 + c0) * 4) : (unsigned)((v * C2 + c0 - C1) * 4);
+                    const unsigned off = to1 ? ((unsigned)v * (unsigned)C1 + (unsigned)c0) * 4u : ((unsigned)v * (unsigned)C2 + (unsigned)(c0 - C1)) * 4u;
                     fm_store4(to1 ? r1 : r2, ok ? off : 0xFFFFFFFFu, acc[r][nt] * inv1 * inv2);
                 }
             }

@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
         if constexpr (SP) {          // bring the running sums into this item's unit (exact: a power of two; zero sums on a tile's first chunk)
             if (Ecur != Eacc) {
                 if (ch != 0) {                                   // (a tile's first chunk starts from zero sums)
-                    const float f = da_pow2(Ecur - Eacc);
+                    const float f = da_acc_factor(Ecur - Eacc);
 #pragma unroll
                     for (int r = 0; r < TY; ++r)
 #pragma unroll
@@ -1779,7 +1779,7 @@ __global__ void __launch_bounds__(256, 2) conv3_split_wgrad_kernel(WgP p) {
         if (has_next && !(p.ablate & 1)) issue_loads(tnext);    // next tile's global loads fly during this tile's MFMAs
         tnext = fetch_tile(tile + 2);
         if (SPL && Enext != Eacc && !(p.ablate & 16)) {         // bring the running sums into this tile's unit (exact: a power of two)
-            const float f = da_pow2(Enext - Eacc);
+            const float f = da_acc_factor(Enext - Eacc);
 #pragma unroll
             for (int c = 0; c < 5; ++c)
 #pragma unroll
@@ -2126,7 +2126,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
         if (has_next && !(p.ablate & 1)) issue_loads(tnext);
         tnext = fetch_tile(tile + 2);
         if (SPL && Enext != Eacc) {
-            const float f = da_pow2(Enext - Eacc);
+            const float f = da_acc_factor(Enext - Eacc);
 #pragma unroll
             for (int c = 0; c < 5; ++c)
 #pragma unroll

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) s2n_fwd_kernel(FwdP p) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue(ch + 1);                                 // next chunk's loads fly under this chunk's MFMAs
         {
-            const float f = da_pow2(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
+            const float f = da_acc_factor(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
 #pragma unroll
             for (int r = 0; r < TY; ++r) acc[r] = acc[r] * f;
             Eacc = Ecur;
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256, 1) s2n_wgrad_kernel(WgP p) {
         const bool more = k + 1 < cnt;
         if (more) issue(slab + (k + 1) * p.nslabs);              // next tile's global loads fly during this tile's MFMAs
         {
-            const float f = da_pow2(Enext - Eacc);               // the running sums into this tile's unit (exact)
+            const float f = da_acc_factor(Enext - Eacc);               // the running sums into this tile's unit (exact)
 #pragma unroll
             for (int s = 0; s < WG_SLOTS; ++s) { acc[s][0] = acc[s][0] * f; acc[s][1] = acc[s][1] * f; }
             Eacc = Enext;

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) up_fwd_kernel(FwdP p) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue(ch + 1);
         {
-            const float f = da_pow2(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
+            const float f = da_acc_factor(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256, 1) up_dgrad_kernel(DgP p) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue(ch + 1);
         {
-            const float f = da_pow2(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
+            const float f = da_acc_factor(Ecur - Eacc);                // the running sums into this chunk's unit (exact)
 #pragma unroll
             for (int m = 0; m < MPW; ++m) acc[m] = acc[m] * f;
             Eacc = Ecur;
@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
         const bool more = k + 1 < cnt;
         if (more) issue(slab + (k + 1) * p.nslabs);
         {
-            const float f = da_pow2(Enext - Eacc);               // the running sums into this tile's unit (exact)
+            const float f = da_acc_factor(Enext - Eacc);               // the running sums into this tile's unit (exact)
 #pragma unroll
             for (int s = 0; s < 4; ++s) { acc[s][0] = acc[s][0] * f; acc[s][1] = acc[s][1] * f; }
             Eacc = Enext;

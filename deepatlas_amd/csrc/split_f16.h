@@ -52,7 +52,10 @@ __device__ __forceinline__ float da_wave_max_nonneg(float m) {
 }
 // Power-of-two scale exponent of a tile whose largest magnitude is m: m 2^e in [2^14, 2^15) (fp16 overflows at 65504), clamped to +-100;
 // an all-zero (or denormal) tile gets +100, i.e. it counts as "very small" and never constrains the exponents of its neighbours.
-// da_pow2(e) = 2^e for e in [-126, 127].
+// da_pow2(e) = 2^e for e in [-126, 127] (clamped outside: callers pass either a tile's own exponent, |e| <= 100, or go through da_acc_factor).
+// Non-finite operands: an Inf makes h = Inf and l = Inf - Inf = NaN, so the outputs that touch the tile are NaN where the fp32 matrix instructions give
+// +-Inf or NaN (an fp32 convolution over a tile with an Inf is NaN as soon as two taps disagree in sign); |x| > 2^114 saturates the +-100 clamp the same way.
+// Non-finite in, non-finite out -- not the same non-finite.
 constexpr int kSplitEmax = 100;
 __device__ __forceinline__ int da_scale_exp(float m) {
     const int ef = (__float_as_int(m) >> 23) & 255;
@@ -60,6 +63,12 @@ __device__ __forceinline__ int da_scale_exp(float m) {
     return ef == 0 ? kSplitEmax : (e > kSplitEmax ? kSplitEmax : (e < -kSplitEmax ? -kSplitEmax : e));
 }
 __device__ __forceinline__ float da_pow2(int e) { e = e < -126 ? -126 : (e > 127 ? 127 : e); return __int_as_float((e + 127) << 23); }
+// Factor that brings running sums from the unit 2^-Eacc into the unit 2^-Enew, d = Enew - Eacc.  d <= 40 by construction (every caller caps a later
+// item's E at 40 above the smallest E so far); a NEGATIVE d is unbounded (|E| <= 200) and one fp32 factor only reaches 2^-126.  Below that the old
+// sums (|sum| < 2^42 in their unit: K <= 2^12 products of two fp16 magnitudes < 2^15) are < 2^-84 in the new unit, whose own products are staged
+// with their largest magnitudes at 2^11..2^15 each: 2^-100 of what one fp32 rounding of the new sum discards.  The factor is then 0, not a clamped 2^-126
+// (which would leave the old sums wrong by a power of two).
+__device__ __forceinline__ float da_acc_factor(int d) { return d < -126 ? 0.f : da_pow2(d); }
 // A workgroup's (4 waves) largest magnitude of a staged tile: every wave publishes its maximum (one float per wave at `slot`, 16 bytes of LDS),
 // a barrier, everyone reads the four.  The barrier doubles as "all waves are done with the tile in LDS" wherever the caller needs that.
 __device__ __forceinline__ float da_block_max4(float m, float* slot, int wave, int lane) {

@@ -18,6 +18,7 @@ class VoxelMorphCVPR2018(nn.Module):
 
     def __init__(self, input_channel=2, output_channel=3, enc_filters=(16, 32, 32, 32, 32), dec_filters=(32, 32, 32, 8, 8)):
         super(VoxelMorphCVPR2018, self).__init__()
+        self.register_forward_hook(ops.flush_batches_tracked)      # (convBlocks built with batchnorm=True defer their num_batches_tracked increments)
         self.input_channel = input_channel
         self.output_channel = output_channel
         self.enc_filters = enc_filters

@@ -111,9 +111,9 @@ class SegmentationExperiment(BaseExperiment):
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.config['learning_rate'])
         # conv weight gradients on a second stream, accumulated into the optimiser's flat bucket (joined in zero_grad / step)
         ops.enable_async_wgrad(bool(self.config.get('async_wgrad', True)))
-        # matrix mode of the 3x3x3 convolutions: 'fp32_split' (default, and what bench.py measures: fp32-accurate products from an exact
-        # two-term fp16 split on the fp16 matrix pipe), 'fp32' (the fp32 matrix instructions, the A/B) or 'bf16' (operands rounded,
-        # BASELINE config 5)
+        # matrix mode of the 3x3x3 convolutions: 'fp32_split' (default, and what bench.py measures: two-term fp16 split per staged tile, 22-bit
+        # products on the fp16 matrix pipe -- per product narrower than fp32, bounds in csrc/split_f16.h), 'fp32' (the fp32 matrix instructions:
+        # the reference's arithmetic; pass matrix_precision='fp32' for that) or 'bf16' (operands rounded, BASELINE config 5)
         ops.set_matrix_precision(self.config.get('matrix_precision') or ops.DEFAULT_MATRIX_PRECISION)
         self.scheduler = self.make_scheduler(self.optimizer, self.config)
 

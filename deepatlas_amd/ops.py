@@ -178,8 +178,10 @@ def set_matrix_precision(mode):
     """Arithmetic of the 3x3x3 convolutions on the matrix cores (process-wide; returns the previous mode):
     'fp32'        fp32 operands on the fp32 matrix instructions (one fmaf per product, like the reference's CPU convolution);
     'fp32_split'  fp32 operands scaled by a per-tile power of two and split into two fp16 terms (22 significand bits), three partial products
-                  per multiply on the fp16 matrix pipe with fp32 accumulation: fp32-accurate (error against double not larger than 'fp32',
-                  tests/test_gpu_split.py; csrc/split_f16.h states the bounds) at 3/16 of the matrix time;
+                  per multiply on the fp16 matrix pipe with fp32 accumulation.  Per product NARROWER than fp32 (bound 2^-21 + 2^-22 = 7e-7 against
+                  fp32's 6e-8; an element more than 2^15..2^18 below its staged tile's maximum keeps an absolute 2^-40 of that maximum);
+                  over the K >= 216 sums of these layers the error against double is not larger than 'fp32's (tests/test_gpu_split.py,
+                  incl. the structured-outlier cases; csrc/split_f16.h states the bounds).  3/16 of the matrix time;
     'bf16'        operands ROUNDED to bf16 (BASELINE config 5); everything else stays fp32."""
     if mode not in MATRIX_MODES:
         raise ValueError("matrix precision must be one of %r, got %r" % (MATRIX_MODES, mode))
@@ -195,19 +197,36 @@ DETERMINISTIC = os.environ.get('DA_DETERMINISTIC') == '1'
 CHECK_LABELS = os.environ.get('DA_CHECK_LABELS') == '1'      # validate index targets of the cross-entropy family like torch does (host sync per call)
 
 
-_nbt_pending = []
+_nbt_pending = {}          # id(tensor) -> [tensor, count]: an alias bumped twice is ONE entry (a multi-tensor add over duplicates could race)
+_NBT_FLUSH_AT = 256        # blocks used on their own, with another optimiser, never reach a flush hook: bound the list
 
 
 def bump_batches_tracked(bn):
     """`bn.num_batches_tracked += 1` (nn.BatchNorm3d in training mode), deferred: one 4-us launch per BatchNorm layer in the dependent chain
     of a forward pass (17 per UNet_light step) becomes ONE multi-tensor launch when the network's forward returns (a forward hook the
-    network classes register) -- or, for blocks used on their own, at the next optimiser step / flush_batches_tracked()."""
-    _nbt_pending.append(bn.num_batches_tracked)
+    network classes register), at the next FlatAdam.step(), before any state_dict() of a module that owns a bumped counter (a state_dict
+    pre-hook registered here), or when 256 distinct counters are pending."""
+    t = bn.num_batches_tracked
+    e = _nbt_pending.get(id(t))
+    if e is None:
+        _nbt_pending[id(t)] = [t, 1]
+        if not getattr(bn, '_da_nbt_hooked', False):
+            bn._da_nbt_hooked = True
+            bn.register_state_dict_pre_hook(lambda module, prefix, keep_vars: flush_batches_tracked())
+        if len(_nbt_pending) >= _NBT_FLUSH_AT:
+            flush_batches_tracked()
+    else:
+        e[1] += 1
 
 
 def flush_batches_tracked(*_):
     if _nbt_pending:
-        torch._foreach_add_(_nbt_pending, 1)
+        ones = [e[0] for e in _nbt_pending.values() if e[1] == 1]
+        if ones:
+            torch._foreach_add_(ones, 1)
+        for t, n in _nbt_pending.values():
+            if n != 1:
+                t.add_(n)
         _nbt_pending.clear()
 
 

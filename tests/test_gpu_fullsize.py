@@ -252,8 +252,8 @@ def test_whole_network_step_and_eval_dice_vs_cpu_oracle_at_metric_size():
         # max norm of the train-mode logits: north_star's 1e-4, or -- where the reference arithmetic itself is further than that from the
         # exact result -- twice the fp32 oracle's own measured distance from the fp64 evaluation of the same network on the same batch
         floor = r['oracle_fp32_max_abs_vs_fp64']
-        assert r['logits_max_abs_vs_fp64'] <= max(1e-4, 2.0 * floor), (r['logits_max_abs_vs_fp64'], floor)
-        assert r['logits_max_abs_over_max'] <= max(1e-4, 3.0 * floor), (r['logits_max_abs_over_max'], floor)
+        assert r['logits_max_abs_vs_fp64'] <= max(1e-4, 1.25 * floor), (r['logits_max_abs_vs_fp64'], floor)
+        assert r['logits_max_abs_over_max'] <= max(1e-4, 1.5 * floor)      # (measured 1.08e-4 against a floor of 9.1e-5: two evaluations that are each ~1 floor from fp64), (r['logits_max_abs_over_max'], floor)
         print('%s: logits max-abs vs oracle fp32 %.3e, vs fp64 %.3e; oracle fp32 vs fp64 (the floor) %.3e' % (r['matrix_precision'], r['logits_max_abs_over_max'], r['logits_max_abs_vs_fp64'], floor))
         assert r['flips_away_from_ties'] == 0 and r['nan_pattern_equal'], r
         assert r['eval_dice_abs_diff'] <= 1e-4 and r['eval_dice_mean_abs_diff'] <= 1e-4, r

@@ -104,6 +104,144 @@ def test_split_mode_is_fp32_accurate(case, kind):
     print('\n'.join('%-7s rel-l2 chain %.2e split %.2e | max-abs chain %.2e split %.2e' % r for r in record))
 
 
+# ---- structured dynamic range: where split_f16.h says the mode is weaker than fp32 -------------------------------------------------------
+# The scale of the split is per STAGED TILE (a halo box of a few thousand voxels x 8 / 16 channels).  An element more than 2^15..2^18 below the box's
+# largest magnitude M leaves fp16's normal range in its l term and keeps an ABSOLUTE error: <= 2^-39 M at the ideal scale (M s in [2^14, 2^15), fp16
+# subnormal quantum 2^-24), <= 2^-36 M where a kernel keeps the previous item's accumulator unit (scale up to 2^3 below the ideal).  i.i.d.
+# log-normal operands cannot show this (every output is dominated by its own largest product); ONE outlier among O(1) values does: the outputs
+# that never touch the outlier but share its box are the ones to look at.
+OUTLIER_CASES = [
+    # C1, C2, Cout, (N, D, H, W), outlier voxel (z, y, x), outlier channel
+    (16, 0, 16, (1, 12, 24, 48), (5, 11, 21), 3),       # row-owner weight gradient (few tiles), two 8-channel chunks
+    (32, 16, 16, (1, 15, 41, 50), (7, 20, 30), 37),      # eight-wave weight gradient; the outlier sits in the second tensor of the concat
+]
+BOX = (6, 10, 18)       # the largest staged halo box of the stride-1 kernels (forward / data gradient: 6 x 10 x 18 voxels)
+
+
+def _dist_masks(dims, pos):
+    """touch: voxels whose 3x3x3 neighbourhood contains `pos`; near: not touching, but possibly staged in a box with it; far: beyond every such box."""
+    D, H, W = dims
+    z, y, x = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing='ij')
+    dz, dy, dx = np.abs(z - pos[0]), np.abs(y - pos[1]), np.abs(x - pos[2])
+    touch = (dz <= 1) & (dy <= 1) & (dx <= 1)
+    far = (dz > BOX[0] + 1) | (dy > BOX[1] + 1) | (dx > BOX[2] + 1)
+    return touch, ~touch & ~far, far
+
+
+@pytest.mark.parametrize('k', [20, 30])
+@pytest.mark.parametrize('where', ['x', 'dy'])
+@pytest.mark.parametrize('case', OUTLIER_CASES, ids=lambda c: 'c%d+%d_o%d' % (c[0], c[1], c[2]))
+def test_split_mode_one_outlier_in_a_staged_box(case, where, k):
+    """One element at 2^k among uniform(-1, 1) values, in the activations (forward + weight gradient) or in the output gradient (data gradient +
+    weight gradient).  Against DOUBLE, on the outputs that do not touch the outlier:
+      * inside the reach of a staged box: |error| <= sum|w| 2^-36 M + 2^-20 sum|w||x|  (the bound split_f16.h states; M = 2^k), relative error recorded;
+      * beyond every box that can contain the outlier: the ordinary level, 2^-20 sum|w||x| -- the damage is local to the box;
+      * weight gradient: channels in the outlier's 16-channel chunk <= 2048 terms x 2^-36 M max|other operand|, channels of other chunks ordinary."""
+    C1, C2, Cout, (N, D, H, W), pos, oc = case
+    M = float(2.0 ** k)
+    x = rnd((N, C1 + C2, D, H, W), 11)
+    w = rnd((Cout, C1 + C2, 3, 3, 3), 12, 0.2)
+    b = rnd((Cout,), 13, 0.1)
+    go = rnd((N, Cout, D, H, W), 14)
+    if where == 'x':
+        x[0, oc, pos[0], pos[1], pos[2]] = M
+    else:
+        oc = oc % Cout
+        go[0, oc, pos[0], pos[1], pos[2]] = M
+    x1, x2 = (x[:, :C1].contiguous(), x[:, C1:].contiguous()) if C2 else (x, None)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br, padding=1)
+    yr.backward(go.double())
+    out = _run('fp32_split', x1, x2, w, b, go)
+    y, dx, dw = out[0].double(), (torch.cat((out[1], out[2]), 1) if C2 else out[1]).double(), out[-2].double()
+    touch, near, far = _dist_masks((D, H, W), pos)
+    aw = w.double().abs()
+    small = x.double().abs()
+    gsmall = go.double().abs()
+    if where == 'x':
+        small[0, oc, pos[0], pos[1], pos[2]] = 0.0
+    else:
+        gsmall[0, oc, pos[0], pos[1], pos[2]] = 0.0
+    rec = []
+    if where == 'x':          # forward: outputs that never see the outlier
+        A = F.conv3d(small, aw, None, padding=1)[0].numpy()                        # sum |w| |x| per output
+        Sw = aw.sum(dim=(1, 2, 3, 4)).numpy()[:, None, None, None]                   # sum |w| per cout
+        err = (y - yr.detach())[0].abs().numpy()
+        bound_near = Sw * 2.0 ** -36 * M + 2.0 ** -20 * A
+        assert (err[:, near] <= bound_near[:, near]).all(), float((err[:, near] / bound_near[:, near]).max())
+        assert (err[:, far] <= 2.0 ** -20 * A[:, far]).all(), float((err[:, far] / A[:, far]).max())
+        ref = yr.detach()[0].abs().numpy()
+        big = ref > 0.1
+        rec.append(('fwd near', float(err[:, near].max()), float((err / np.maximum(ref, 1e-30))[:, near][big[:, near]].max()), float((err[:, near] / (Sw * 2.0 ** -39 * M)).max())))
+        rec.append(('fwd far ', float(err[:, far].max()), float((err / np.maximum(ref, 1e-30))[:, far][big[:, far]].max()), 0.0))
+    else:                     # data gradient: inputs whose 27 taps never see the outlier
+        A = F.conv_transpose3d(gsmall, aw, None, padding=1)[0].numpy()
+        Sw = aw.sum(dim=(0, 2, 3, 4)).numpy()[:, None, None, None]
+        err = (dx - xr.grad)[0].abs().numpy()
+        bound_near = Sw * 2.0 ** -36 * M + 2.0 ** -20 * A
+        assert (err[:, near] <= bound_near[:, near]).all(), float((err[:, near] / bound_near[:, near]).max())
+        assert (err[:, far] <= 2.0 ** -20 * A[:, far]).all(), float((err[:, far] / A[:, far]).max())
+        ref = xr.grad[0].abs().numpy()
+        big = ref > 0.1
+        rec.append(('dgrad near', float(err[:, near].max()), float((err / np.maximum(ref, 1e-30))[:, near][big[:, near]].max()), float((err[:, near] / (Sw * 2.0 ** -39 * M)).max())))
+        rec.append(('dgrad far ', float(err[:, far].max()), float((err / np.maximum(ref, 1e-30))[:, far][big[:, far]].max()), 0.0))
+    # weight gradient: dW[co, ci, t] = sum_v x[v + t - 1, ci] dY[v, co]; the entries of the outlier's own channel are dominated by it (relative criterion),
+    # the other channels of its chunk sum only small elements of the degraded box (<= 8 tiles x 256 terms), other chunks are untouched
+    e_dw = (dw - wr.grad).abs().numpy()
+    T = F.conv3d(small.transpose(0, 1), gsmall.transpose(0, 1), padding=1).transpose(0, 1).numpy()       # sum |x| |dY| per (co, ci, tap), outlier removed
+    other = float(gsmall.max()) if where == 'x' else float(small.max())
+    if where == 'x':
+        same = np.zeros(C1 + C2, bool); same[(oc // 16) * 16:(oc // 16) * 16 + 16] = True; same[oc] = False
+        assert (e_dw[:, same] <= 2048 * 2.0 ** -36 * M * other + 2.0 ** -20 * T[:, same]).all()
+        rest = ~same; rest[oc] = False
+        assert (e_dw[:, rest] <= 2.0 ** -20 * T[:, rest]).all(), float((e_dw[:, rest] / T[:, rest]).max())
+        own = np.abs(wr.grad.numpy()[:, oc])
+        # (an fp32 accumulator that holds the outlier's product rounds every later addition at ITS ulp: any fp32 weight gradient, the reference's too)
+        assert (e_dw[:, oc] <= 2.0 ** -12 * own + 2.0 ** -20 * T[:, oc] + 2048 * 2.0 ** -36 * M * other).all()
+        rec.append(('wgrad same-chunk', float(e_dw[:, same].max()), float((e_dw[:, same] / np.maximum(np.abs(wr.grad.numpy()[:, same]), 1e-30)).max()), 0.0))
+    else:                     # the outlier is one dY element: it multiplies 27 x Cin activations; every cout shares the dY tile
+        co_other = np.ones(Cout, bool); co_other[oc] = False
+        assert (e_dw[co_other] <= 2048 * 2.0 ** -36 * M * other + 2.0 ** -20 * T[co_other]).all()
+        own = np.abs(wr.grad.numpy()[oc])
+        assert (e_dw[oc] <= 2.0 ** -12 * own + 2.0 ** -20 * T[oc] + 2048 * 2.0 ** -36 * M * other).all()
+        rec.append(('wgrad other-cout', float(e_dw[co_other].max()), float((e_dw[co_other] / np.maximum(np.abs(wr.grad.numpy()[co_other]), 1e-30)).max()), 0.0))
+    print('\noutlier 2^%d in %s:' % (k, where))
+    print('\n'.join('  %-18s max |error| %.3e   max relative error (|ref| > 0.1) %.3e   error / (sum|w| 2^-39 M) %.3f' % r for r in rec))
+
+
+@pytest.mark.parametrize('fill', ['zero', 'denormal', 'below_fp16_limit'])
+def test_split_mode_degenerate_boxes(fill):
+    """Whole staged boxes of zeros, of fp32 denormals, and of +-m with m one ulp below a power of two (scaled: one ulp below 2^15; fp16 rounds it UP
+    to 32768 -- representable, the format overflows at 65504): finite results at the ordinary accuracy, zeros exactly."""
+    C, Cout, (N, D, H, W) = 16, 16, (1, 12, 24, 48)
+    g = torch.Generator().manual_seed(21)
+    w = rnd((Cout, C, 3, 3, 3), 22, 0.2)
+    b = torch.zeros(Cout)
+    go = rnd((N, Cout, D, H, W), 23)
+    x = rnd((N, C, D, H, W), 24)
+    if fill == 'zero':
+        x[:, :, :, :, :40] = 0.0
+    elif fill == 'denormal':
+        x[:, :, :, :, :40] = torch.where(torch.rand((N, C, D, H, 40), generator=g) < 0.5, 1.0, -1.0) * 1e-40
+    else:
+        m = float(np.nextafter(np.float32(4.0), np.float32(0.0)))
+        x = torch.where(torch.rand((N, C, D, H, W), generator=g) < 0.5, 1.0, -1.0) * m
+    yr = F.conv3d(x.double(), w.double(), None, padding=1)
+    A = F.conv3d(x.double().abs(), w.double().abs(), None, padding=1)
+    y = _run('fp32_split', x, None, w, b, go)[0].double()
+    assert torch.isfinite(y).all()
+    err = (y - yr).abs()
+    if fill == 'zero':
+        assert (y[..., :38] == 0).all()                 # outputs whose taps are all zeros: exactly zero (bias is zero here)
+        assert (err <= 2.0 ** -20 * A).all()
+    elif fill == 'denormal':
+        assert (err[..., :38] <= 1e-37).all()           # denormal operands may be flushed by the vector ALU: an absolute criterion
+        assert (err[..., 42:] <= 2.0 ** -20 * A[..., 42:]).all()
+    else:
+        assert (err <= 2.0 ** -20 * A).all(), float((err / A).max())
+
+
 S2_CASES = [
     # Cin, Cout, (N, D, H, W): the registration encoder's stride-2 layers (voxel_morph.py:43-47) on the native kernels of conv3d_s2n.hip
     (16, 32, (1, 20, 24, 20)),         # enc1 of the odd pyramid (10 x 12 x 10 out: ragged y / x tiles)

@@ -1,77 +1,98 @@
 #!/usr/bin/env python
-"""Fold the two rocprofv3 --pmc passes of tools/pmc_conv.sh (FETCH_SIZE, WRITE_SIZE; one counter per pass as
-MI355X_MICROARCH.md prescribes) into profiles/rNN_pmc_traffic.json: HBM-side bytes per launch of each conv kernel of the
-dominant layer, keyed by the C-ABI call signature bench.py reports as `roofline.kernel`.
+"""Fold the rocprofv3 --pmc passes of tools/pmc_conv.sh into profiles/rNN_pmc_traffic.json: HBM-side bytes per CALL of the dominant layer's
+fwd + statistics / data gradient / weight gradient, keyed by the C-ABI call signature bench.py reports as `roofline.kernel`.
 
-Units / corrections: rocprofv3 reports both counters in KiB.  WRITE_SIZE of the forward kernel equals the algorithmic output
-(N*V*Cout*4 B = 614400 KiB) exactly, so no write correction.  FETCH_SIZE is CALIBRATED (MI355X_MICROARCH.md: gfx950 reports half the
-bytes of a wide coalesced streaming read; other widths uncalibrated): tools/ubench/fetch_calib.hip streams 1 GiB once in the two request
-shapes of the halo staging (contiguous 16 B / lane; 64-byte runs at a 128-byte stride) under the same counter, and the measured
-requested-bytes / FETCH_SIZE factors are applied to the conv kernels' raw FETCH_SIZE in proportion to the bytes each shape stages.
-Usage: python tools/pmc_summary.py gpurun_out/pmc profiles r02"""
+How a call's rows are found: tools/pmc_conv.sh runs ONE op per process, so every kernel row that is not a torch / runtime kernel belongs to that op
+(conv kernels, their weight packs, tile tables, partial reductions), whatever the kernels are called at HEAD; per call = sum / calls of the process.
+An op without rows is an ERROR (exit 2) -- round 4 lost the dominant kernel's record to a renamed template instantiation.
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE on gfx950 tallies every L2 -> fabric read
+request at 64 B although 128-B requests exist (a wide coalesced stream reads exactly half), other widths "uncalibrated: calibrate on a known byte
+count in your own access pattern".  Done here in two steps:
+  1. tools/ubench/fetch_calib.hip streams 1 GiB once in four request shapes under the same passes.  On those KNOWN byte counts the script checks
+     which of   raw FETCH_SIZE  |  request-size mix 32 n32 + 64 n64 + 128 n128  |  size-weighted 32 (DRAM_32B + GMI_32B + IO_32B)
+     reproduces the sector bytes touched (method accepted when every shape is within 3 %);
+  2. the accepted method is read on the conv kernels themselves: fetch_bytes = that counter, fetch_correction = fetch_bytes / raw FETCH_SIZE --
+     i.e. FETCH_SIZE corrected with THIS kernel's own request mix, not with an assumed mix of shapes.
+If no method passes step 1 the script falls back to raw FETCH_SIZE x the calibration factor of the contiguous shape and says so.
+WRITE_SIZE of the forward equals the algorithmic output exactly (checked below), so writes are not corrected.
+Usage: python tools/pmc_summary.py gpurun_out/pmc profiles r05
+       python tools/pmc_summary.py --averages counter_collection.csv KERNEL_SUBSTR [label]      (per-launch averages, for tools/ab/ab.sh pmc)"""
 import collections
 import csv
 import json
 import os
 import shutil
+import subprocess
 import sys
+
+CALLS_PER_PROCESS = 6.0          # tools/bench_conv.py --iters 3: max(3, iters) warm-up + iters timed calls
+LAYER = 'conv3d_48to16'
+OPS = {'fwdstats': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
+       'dgrad': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+       'wgrad': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
+SKIP = ('at::', 'void at::', '__amd_rocclr', 'hipcub', 'rocprim', 'void rocprim', 'void hipcub')
+
+
+def kname(r):
+    return r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+
+
+def is_ours(name):
+    return not any(name.startswith(s.replace('void ', '')) for s in SKIP)
+
+
+def per_call(path):
+    """{counter: bytes-or-count per call}, {kernel: launches per call} over our kernels of one one-op process."""
+    tot, launches = collections.defaultdict(float), collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = kname(r)
+        if not is_ours(k):
+            continue
+        tot[r['Counter_Name']] += float(r['Counter_Value'])
+        launches[k].add(r['Dispatch_Id'])
+    return {c: v / CALLS_PER_PROCESS for c, v in tot.items()}, {k: len(v) / CALLS_PER_PROCESS for k, v in launches.items()}
+
+
+def calib_rows(path):
+    """{kernel: {counter: mean per launch}} of the calibration microbenchmark (first launch of each kernel dropped: cold)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        acc[kname(r)][r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: {c: (sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0]) for c, v in d.items()} for k, d in acc.items()}
+
+
+def fetch_methods(cnt):
+    """bytes by each method from a {counter: value} dict (missing counters -> method absent)."""
+    m = {}
+    if 'FETCH_SIZE' in cnt:
+        m['fetch_size_raw'] = cnt['FETCH_SIZE'] * 1024.0
+    if all(k in cnt for k in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_EA0_RDREQ_128B_sum')):
+        n, n32, n128 = cnt['TCC_EA0_RDREQ_sum'], cnt['TCC_EA0_RDREQ_32B_sum'], cnt['TCC_EA0_RDREQ_128B_sum']
+        m['request_mix'] = 32.0 * n32 + 128.0 * n128 + 64.0 * (n - n32 - n128)
+    if 'TCC_EA0_RDREQ_DRAM_32B_sum' in cnt:
+        m['size_weighted'] = 32.0 * (cnt['TCC_EA0_RDREQ_DRAM_32B_sum'] + cnt.get('TCC_EA0_RDREQ_GMI_32B_sum', 0.0) + cnt.get('TCC_EA0_RDREQ_IO_32B_sum', 0.0))
+    return m
+
+
+def averages(path, substr, label=''):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if substr in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    print(label, {k: '%.4g' % (sum(v) / len(v)) for k, v in acc.items()}, 'launches', max((len(v) for v in acc.values()), default=0))
 
 
 def main():
+    if sys.argv[1] == '--averages':
+        return averages(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else '')
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    layer = 'conv3d_48to16'
-    per = {}
-    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        f = os.path.join(src, '%s_%s.csv' % (layer, c))
-        out = os.path.join(dst, '%s_%s_pmc_%s.csv' % (tag, layer, c.lower()))
-        shutil.copyfile(f, out)
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            agg[k].append(float(r['Counter_Value']) * 1024.0)
-            agg[k + '@' + r['Grid_Size']].append(float(r['Counter_Value']) * 1024.0)          # same kernel, different launch shape (split mode: forward vs data gradient)
-        for k, v in agg.items():
-            v = v[1:] if len(v) > 1 else v          # first launch includes cold allocation effects
-            per.setdefault(k, {})[c] = sum(v) / len(v)
-    # kernel template instantiations at HEAD: fwd <CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR, HB>, wgrad <CK, NREP, YS, MASKED, BF, PRO, SP, HB>,
-    # split weight gradient conv3_split_wgrad_kernel<PRO, NPL, HB>
+    passes = ('FETCH_SIZE', 'WRITE_SIZE', 'RDMIX', 'RDW32', 'L1L2', 'SQ')
     mode = 0
     try:
         mode = int(open(os.path.join(src, 'matrix_mode.txt')).read().strip())
     except (OSError, ValueError):
         pass
-    if mode == 2:
-        # (the data gradient 16 -> 48 runs the forward kernel with one N-tile per workgroup and three cout groups: 168 x 3 workgroups)
-        sig = {'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false, 2>@131072': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<8, 1, false, true, true, false, false, true, 0, true, false, 2>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<8, 1, false, false, true, false, false, true, 0, true, false, 2>@129024': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_split_wgrad_kernel<false, 2, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_split_wgrad16_kernel<false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}      # (16-channel chunks: whole 64-B sectors per voxel)
-    else:
-        sig = {'conv3_mfma_fwd_kernel<16, 1, false, false, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_fwd[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<16, 1, false, true, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_fwd_kernel<16, 3, false, false, false, false, false, false, 0, false, false, 2>': 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
-               'conv3_mfma_wgrad_kernel<16, 1, false, false, false, false, false, false>': 'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]'}
-    # data gradient: collected in its own process (tools/pmc_conv.sh); per call = the sum over its conv kernels (split mode: two launches)
-    dg_calls = 6.0                                   # bench_conv.py --iters 3: 3 warm-up + 3 timed calls
-    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        f = os.path.join(src, '%s_dgrad_%s.csv' % (layer, c))
-        if not os.path.isfile(f):
-            continue
-        shutil.copyfile(f, os.path.join(dst, '%s_%s_dgrad_pmc_%s.csv' % (tag, layer, c.lower())))
-        tot, names = 0.0, set()
-        for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            if k.startswith('conv3_mfma_fwd_kernel'):
-                tot += float(r['Counter_Value']) * 1024.0
-                names.add(k)
-        per.setdefault('__dgrad__', {})[c] = tot / dg_calls
-        per['__dgrad__']['names'] = ' + '.join(sorted(names))
-    vox = 2 * 160 * 192 * 160
-    alg = {'fwd': vox * (48 + 16) * 4, 'dgrad': vox * (16 + 48) * 4, 'wgrad': vox * (48 + 16) * 4 + 27 * 48 * 16 * 4}
-    res = {'unit': 'bytes per launch', 'counters': 'FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, KiB -> bytes)',
-           'layer': '3x3x3 conv 48(=32+16 concat) -> 16, batch 2, 160x192x160 fp32', 'calls': {},
-           'matrix_precision': {0: 'fp32', 1: 'bf16', 2: 'fp32_split'}.get(mode, 'fp32')}
     commit = '?'
     try:
         commit = open(os.path.join(src, 'commit.txt')).read().strip() or '?'
@@ -79,87 +100,93 @@ def main():
         pass
     if commit == '?':          # the GPU box gets a snapshot without .git: the summary is folded where the history is
         try:
-            import subprocess
-            commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=os.path.dirname(os.path.abspath(__file__)), text=True).strip() + ' (summary folded at this commit; the CSVs were collected on the working-tree snapshot gpurun pushed at or shortly before it)'
+            commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=os.path.dirname(os.path.abspath(__file__)), text=True).strip() \
+                + ' (summary folded at this commit; the CSVs were collected on the working-tree snapshot gpurun pushed at or shortly before it)'
         except Exception:
             pass
-    res['commit'] = commit
-    # calibration (tools/ubench/fetch_calib.hip): requested bytes / FETCH_SIZE for the two request shapes of the halo staging
-    calib = {}
-    fc = os.path.join(src, 'fetch_calib_FETCH_SIZE.csv')
-    if os.path.isfile(fc):
-        shutil.copyfile(fc, os.path.join(dst, '%s_fetch_calib_pmc_fetch_size.csv' % tag))
-        # bytes of the 64-B sectors each kernel touches (= what has to cross the L2 - fabric interface): the 32-B-run shapes touch twice /
-        # as many sector bytes as they request
-        want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 29), 'stream_b128_run32<64>': float(1 << 30), 'stream_b128_run32<128>': float(1 << 29)}
-        got = collections.defaultdict(list)
-        for r in csv.DictReader(open(fc)):
-            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-            if k in want:
-                got[k].append(float(r['Counter_Value']) * 1024.0)
-        for k, v in got.items():
-            v = v[1:] if len(v) > 1 else v
-            m = sum(v) / len(v)
-            calib[k] = {'sector_bytes_touched': want[k], 'fetch_size_bytes': m, 'requested_over_fetch_size': want[k] / m if m else None}
-    res['fetch_size_calibration'] = calib
-    if '__dgrad__' in per:
-        sig = {k: v for k, v in sig.items() if 'dgrad' not in v}
-        sig['__dgrad__'] = 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]'
-    for k, name in sig.items():
-        if k not in per:
-            continue
-        f, w = per[k].get('FETCH_SIZE', 0.0), per[k].get('WRITE_SIZE', 0.0)
-        a = alg[name.split('_')[3].split('[')[0]]            # 'fwd' also for da_conv3d_k3_fwd_bnstats
-        # corrected fetch: the forward / weight-gradient kernels stage in1 (32-channel tensor: 64-B runs at a 128-B stride, "half" shape)
-        # and in2 (16-channel tensor: contiguous, "contig" shape); the data gradient stages dy (16 channels: contiguous)
-        fc_contig = (calib.get('stream_b128_contig') or {}).get('requested_over_fetch_size') or 1.0
-        fc_half = (calib.get('stream_b128_half') or {}).get('requested_over_fetch_size') or 1.0
-        # bytes staged per shape (in units of one 16-channel tensor): forward: in1 = 2 half-shape, in2 = 1 contiguous; weight gradient: the
-        # same + dy = 1 contiguous; data gradient: dy = 1 contiguous.  raw = sum_s actual_s / factor_s with equal over-fetch ratios, so
-        # actual = raw * sum_s B_s / sum_s (B_s / factor_s)
-        b_half, b_contig = (0.0, 1.0) if 'dgrad' in name else ((2.0, 2.0) if 'wgrad' in name else (2.0, 1.0))
-        if mode == 2 and 'wgrad16' not in k:      # (the 16-channel weight gradient stages the fp32 matrix mode's shapes: 64-B runs at a 128-B stride, contiguous rows)
-            # split mode stages 8-channel chunks: in1 (32 channels) as 32-B runs at a 128-B stride, in2 / dy-as-input (16 channels) as 32-B runs at a
-            # 64-B stride; the weight gradient's dY tile is staged in whole 64-B voxel rows (contiguous).  "half" below = the 128-B-stride
-            # shape, "contig" = the 64-B-stride shape (+ the contiguous dY of the weight gradient, whose factor is folded in by weight)
-            fcc = fc_contig
-            fc_half = (calib.get('stream_b128_run32<128>') or {}).get('requested_over_fetch_size') or 1.0
-            f64 = (calib.get('stream_b128_run32<64>') or {}).get('requested_over_fetch_size') or 2.0
-            fc_contig = f64 if 'wgrad' not in name else 2.0 / (1.0 / f64 + 1.0 / fcc)
-        share_half = b_half / (b_half + b_contig)
-        fcorr = f * (b_half + b_contig) / (b_half / fc_half + b_contig / fc_contig)
-        res['calls'][name] = {'kernel': per[k].get('names', k), 'fetch_bytes_raw': f, 'fetch_bytes': fcorr, 'write_bytes': w, 'traffic_bytes': fcorr + w,
-                              'algorithmic_bytes': a, 'traffic_over_algorithmic': (fcorr + w) / a,
-                              'fetch_correction': 'raw FETCH_SIZE x %.4f: %.0f %% of the staged bytes come from the 32-channel tensor (one 64-B sector per request, calibration '
-                                                  'factor %.3f) and %.0f %% from 16-channel tensors (adjacent sectors merge into 128-B requests tallied as 64 B, factor %.3f); '
-                                                  'raw = sum of actual / factor.  FETCH_SIZE counts L2 misses, Infinity-Cache hits included'
-                                                  % (fcorr / f if f else 0.0, 100 * share_half, fc_half, 100 * (1 - share_half), fc_contig)}
-    # third pass (SQ block): matrix-pipe occupancy.  SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x (wave-level v_mfma_f32_16x16x4_f32 count),
-    # summed over the 1024 SIMDs; divided by SIMDs and kernel duration it is the rate at which a SIMD's matrix pipe is busy, to be
-    # read against the shader clock (2.4 GHz peak; ~1.95-2.0 GHz sustained under this load, DA_CLK probe in DESIGN.md 4.1).
-    fsq = os.path.join(src, '%s_SQ.csv' % layer)
-    if os.path.isfile(fsq):
-        shutil.copyfile(fsq, os.path.join(dst, '%s_%s_pmc_sq_counters.csv' % (tag, layer)))
-        sq = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(fsq)):
-            k0 = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            for k in (k0, k0 + '@' + r['Grid_Size']):
-                sq[k][r['Counter_Name']].append(float(r['Counter_Value']))
-                if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
-                    sq[k]['duration_ns'].append(float(int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
-        for k, name in sig.items():
-            v = sq.get(k)
-            if not v or name not in res['calls']:
+    # ---- step 1: which counter reproduces known byte counts
+    want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 29), 'stream_b128_run32<64>': float(1 << 30), 'stream_b128_run32<128>': float(1 << 29)}
+    cal_cnt = collections.defaultdict(dict)
+    for p in ('FETCH_SIZE', 'RDMIX', 'RDW32'):
+        f = os.path.join(src, 'fetch_calib_%s.csv' % p)
+        if os.path.isfile(f):
+            shutil.copyfile(f, os.path.join(dst, '%s_fetch_calib_pmc_%s.csv' % (tag, p.lower())))
+            for k, d in calib_rows(f).items():
+                if k in want:
+                    cal_cnt[k].update(d)
+    calib, ok = {}, collections.defaultdict(list)
+    for k, cnt in cal_cnt.items():
+        ms = fetch_methods(cnt)
+        calib[k] = {'sector_bytes_touched': want[k], 'by_method': {m: {'bytes': v, 'known_over_measured': want[k] / v if v else None} for m, v in ms.items()}}
+        for m, v in ms.items():
+            ok[m].append(bool(v) and abs(want[k] / v - 1.0) <= 0.03)
+    accepted = [m for m in ('size_weighted', 'request_mix', 'fetch_size_raw') if ok.get(m) and len(ok[m]) == len(want) and all(ok[m])]
+    method = accepted[0] if accepted else None
+    contig = (calib.get('stream_b128_contig', {}).get('by_method', {}).get('fetch_size_raw') or {}).get('known_over_measured')
+    vox = 2 * 160 * 192 * 160
+    alg = {'fwdstats': vox * (48 + 16) * 4, 'dgrad': vox * (16 + 48) * 4, 'wgrad': vox * (48 + 16) * 4 + 27 * 48 * 16 * 4}
+    res = {'unit': 'bytes per call', 'layer': '3x3x3 conv 48(=32+16 concat) -> 16, batch 2, 160x192x160 fp32', 'commit': commit,
+           'matrix_precision': {0: 'fp32', 1: 'bf16', 2: 'fp32_split'}.get(mode, 'fp32'),
+           'counters': 'rocprofv3 --pmc, one counter block per pass, one op per process (tools/pmc_conv.sh); KiB -> bytes',
+           'fetch_method': method or 'fetch_size_raw x contiguous-stream factor (no counter reproduced the known byte counts within 3 %)',
+           'fetch_size_calibration': calib, 'calls': {}}
+    missing = []
+    for op, name in OPS.items():
+        cnt, launches = {}, {}
+        for p in passes:
+            f = os.path.join(src, '%s_%s_%s.csv' % (LAYER, op, p))
+            if not os.path.isfile(f):
                 continue
-            m = {c: (sum(x[1:]) / len(x[1:]) if len(x) > 1 else x[0]) for c, x in v.items()}
-            busy_per_simd_ghz = m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / m['duration_ns']
-            res['calls'][name]['sq'] = {'mfma_busy_cycles': m['SQ_VALU_MFMA_BUSY_CYCLES'], 'duration_ms_under_pmc': m['duration_ns'] / 1e6,
-                                        'mfma_busy_ghz_per_simd': busy_per_simd_ghz, 'mfma_util_vs_2p4ghz_peak': busy_per_simd_ghz / 2.4,
-                                        'lds_bank_conflict_cycles': m.get('SQ_LDS_BANK_CONFLICT'), 'lds_active_cycles': m.get('SQ_LDS_IDX_ACTIVE'),
-                                        'wave_cycles': m.get('SQ_WAVE_CYCLES'), 'wait_inst_any': m.get('SQ_WAIT_INST_ANY'), 'wait_any': m.get('SQ_WAIT_ANY')}
+            shutil.copyfile(f, os.path.join(dst, '%s_%s_%s_pmc_%s.csv' % (tag, LAYER, op, p.lower())))
+            c, l = per_call(f)
+            cnt.update(c)
+            launches = launches or l
+            if p == 'SQ':          # kernel duration under the SQ pass, per call, conv kernels only
+                dur = 0.0
+                seen = set()
+                for r in csv.DictReader(open(f)):
+                    if is_ours(kname(r)) and r['Dispatch_Id'] not in seen:
+                        seen.add(r['Dispatch_Id'])
+                        dur += float(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+                cnt['duration_ns'] = dur / CALLS_PER_PROCESS
+        if 'FETCH_SIZE' not in cnt or 'WRITE_SIZE' not in cnt:
+            missing.append(op)
+            continue
+        ms = fetch_methods(cnt)
+        raw = ms['fetch_size_raw']
+        if method and method in ms:
+            fetch, how = ms[method], "%s counter read on this call's own kernels (accepted on the calibration shapes)" % method
+        else:
+            fetch, how = raw * (contig or 2.0), 'raw FETCH_SIZE x %.3f (contiguous-stream calibration; the call mixes request sizes, so this is an upper estimate)' % (contig or 2.0)
+        w = cnt['WRITE_SIZE'] * 1024.0
+        rec = {'kernels_per_call': {k: round(v, 2) for k, v in sorted(launches.items())}, 'fetch_bytes_raw': raw, 'fetch_bytes': fetch, 'write_bytes': w,
+               'traffic_bytes': fetch + w, 'algorithmic_bytes': alg[op], 'traffic_over_algorithmic': (fetch + w) / alg[op],
+               'fetch_correction': fetch / raw if raw else None, 'fetch_correction_how': how,
+               'fetch_bytes_by_method': ms,
+               'note': 'FETCH_SIZE-class counters count L2 misses at the L2 - fabric interface, Infinity-Cache hits included'}
+        if 'TCC_EA0_RDREQ_sum' in cnt:
+            rec['read_requests'] = {k: cnt.get(k) for k in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_EA0_RDREQ_64B_sum', 'TCC_EA0_RDREQ_128B_sum')}
+        if 'TCC_EA0_WRREQ_WRITE_DRAM_32B_sum' in cnt:
+            rec['write_bytes_size_weighted'] = 32.0 * cnt['TCC_EA0_WRREQ_WRITE_DRAM_32B_sum']
+        if 'TCP_TCC_READ_REQ_sum' in cnt:
+            rq, acc_ = cnt['TCP_TCC_READ_REQ_sum'], cnt.get('TCP_TOTAL_CACHE_ACCESSES_sum', 0.0)
+            hit, miss = cnt.get('TCC_HIT_sum', 0.0), cnt.get('TCC_MISS_sum', 0.0)
+            rec['memory_path'] = {'l1_to_l2_read_requests': rq, 'l1_to_l2_request_bytes_at_64B': 64.0 * rq,
+                                  'l1_to_l2_mean_latency_cycles': cnt.get('TCP_TCC_READ_REQ_LATENCY_sum', 0.0) / rq if rq else None,
+                                  'l1_hit_rate': 1.0 - rq / acc_ if acc_ else None, 'l2_hit_rate': hit / (hit + miss) if hit + miss else None,
+                                  'l1_pending_stall_cycles_per_cu': cnt.get('TCP_PENDING_STALL_CYCLES_sum', 0.0) / 256.0}
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in cnt and cnt.get('duration_ns'):
+            ghz = cnt['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cnt['duration_ns']
+            rec['sq'] = {'mfma_busy_cycles': cnt['SQ_VALU_MFMA_BUSY_CYCLES'], 'duration_ms_under_pmc': cnt['duration_ns'] / 1e6, 'mfma_busy_ghz_per_simd': ghz,
+                         'mfma_util_vs_2p4ghz_peak': ghz / 2.4, 'lds_bank_conflict_cycles': cnt.get('SQ_LDS_BANK_CONFLICT'), 'lds_active_cycles': cnt.get('SQ_LDS_IDX_ACTIVE'),
+                         'wave_cycles': cnt.get('SQ_WAVE_CYCLES'), 'active_inst_any': cnt.get('SQ_ACTIVE_INST_ANY'), 'wait_inst_any': cnt.get('SQ_WAIT_INST_ANY'), 'wait_any': cnt.get('SQ_WAIT_ANY')}
+        res['calls'][name] = rec
     with open(os.path.join(dst, '%s_pmc_traffic.json' % tag), 'w') as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
+    if missing:
+        print('ERROR: no FETCH_SIZE / WRITE_SIZE rows for: %s' % ', '.join(missing), file=sys.stderr)
+        sys.exit(2)
 
 
 if __name__ == '__main__':

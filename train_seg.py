@@ -59,9 +59,11 @@ def main(argv=None):
     parser.add_argument('--log-root', '-log', default='./logs', type=str, help='root of the log folders')
     parser.add_argument('--shape', nargs=3, type=int, default=[64, 64, 64], help='synthetic volume size D H W (multiples of 8)')
     parser.add_argument('--matrix-precision', default=None, choices=['fp32', 'fp32_split', 'bf16'],
-                        help="arithmetic of the 3x3x3 convolutions: 'fp32_split' (default; what bench.py measures) fp32-accurate products from an exact "
-                             "two-term fp16 split on the fp16 matrix pipe; 'fp32' the fp32 matrix instructions (A/B, ~1.35x slower); 'bf16' operands "
-                             "rounded to bf16 (not fp32-accurate)")
+                        help="arithmetic of the 3x3x3 convolutions: 'fp32_split' (default; what bench.py measures) every fp32 operand scaled per staged "
+                             "tile and split into two fp16 terms, three products per multiply on the fp16 matrix pipe: 22-bit products (per-product bound "
+                             "7e-7, NARROWER than an fp32 multiply; sums of >= ~100 terms are as close to double as fp32's; elements > 2^15..2^18 below "
+                             "their tile's maximum keep only an absolute 2^-40 of it -- csrc/split_f16.h); 'fp32' the fp32 matrix instructions = the "
+                             "reference's arithmetic (~1.7x slower steps); 'bf16' operands rounded to bf16")
     args = parser.parse_args(argv)
     exp = SegmentationExperiment(build_config(args))
     if not args.test_only:
