@@ -38,7 +38,8 @@ PRECISION_NOTE = {
     'fp32': 'fp32 operands on v_mfma_f32_16x16x4_f32 (one fmaf per product)',
     'fp32_split': 'fp32 tensors; in the 3x3x3 convolutions every operand is scaled by a per-tile power of two and split into two fp16 terms '
                   '(h + l, 22 significand bits) and a product is the sum of three fp16 x fp16 partial products on v_mfma_f32_16x16x32_f16, fp32 '
-                  'accumulate -- error against double not larger than the fmaf chain (tests/test_gpu_split.py); everything else is plain fp32',
+                  'accumulate -- per product NARROWER than fp32 (bound 7e-7; small elements of a staged tile keep an absolute 2^-36..2^-39 of its maximum), over these '
+                  'layers\' K >= 216 sums not further from double than the fmaf chain (tests/test_gpu_split.py); everything else is plain fp32',
     'bf16': 'operands of the 3x3x3 convolutions ROUNDED to bf16, fp32 accumulate; every tensor in HBM fp32 (the A/B of bf16_storage)',
     'bf16_storage': 'BASELINE configs[4] mixed precision: activations and their gradients between the layers STORED as bf16, bf16 x bf16 -> fp32 '
                     'matrix products, fp32 statistics / reductions / master weights / weight gradients / losses',
@@ -420,19 +421,19 @@ def call_table(summ, peak=FP32_MFMA_PEAK_TFLOPS):
 
 
 def pmc_traffic_for(kname, precision):
-    """HBM bytes per launch of a call from the newest committed PMC passes at this round (tools/pmc_conv.sh -> tools/pmc_summary.py):
-    FETCH_SIZE + WRITE_SIZE, one counter per rocprofv3 pass, of the same C-ABI call on the same shape.  A separate rocprofv3 run, not
-    a measurement of this process -- `traffic_source` says so."""
+    """HBM bytes per call from the newest committed PMC passes (tools/pmc_conv.sh -> tools/pmc_summary.py): separate rocprofv3 --pmc passes
+    (one counter block each) of the same C-ABI call on the same shape, the fetch counter corrected with the call's own request-size mix.  A
+    separate rocprofv3 run, not a measurement of this process -- `traffic_source` says so.  Returns (record | None, reason)."""
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
     if not files:
-        return None
+        return None, 'no profiles/rNN_pmc_traffic.json'
     try:
         doc = json.load(open(files[-1]))
         calls = doc['calls']
-        if doc.get('matrix_precision', 'fp32') != precision:
-            return None
-    except (OSError, ValueError, KeyError):
-        return None
+    except (OSError, ValueError, KeyError) as e:
+        return None, '%s unreadable: %s' % (files[-1], e)
+    if doc.get('matrix_precision', 'fp32') != precision:
+        return None, '%s was collected in matrix mode %s, this run is %s' % (os.path.relpath(files[-1], ROOT), doc.get('matrix_precision'), precision)
     cands = [kname]
     if kname.startswith('da_conv3d_k3_fwd_pro['):
         body = kname[len('da_conv3d_k3_fwd_pro['):]
@@ -443,12 +444,17 @@ def pmc_traffic_for(kname, precision):
         rec = calls.get(c)
         if rec:
             out = dict(traffic=rec['traffic_bytes'],
-                       traffic_source='%s (separate rocprofv3 --pmc passes of this call at commit %s; algorithmic %d B)'
-                                      % (os.path.relpath(files[-1], ROOT), doc.get('commit', '?'), rec['algorithmic_bytes']))
+                       traffic_source='%s (separate rocprofv3 --pmc passes of this call at commit %s; algorithmic %d B; fetch counter: %s)'
+                                      % (os.path.relpath(files[-1], ROOT), doc.get('commit', '?'), rec['algorithmic_bytes'], doc.get('fetch_method', 'FETCH_SIZE calibrated')),
+                       traffic_over_algorithmic=round(rec['traffic_bytes'] / rec['algorithmic_bytes'], 3))
             if 'sq' in rec:
                 out['mfma_busy_vs_peak_clock'] = round(rec['sq']['mfma_util_vs_2p4ghz_peak'], 4)
-            return out
-    return None
+            return out, None
+    return None, '%s has no record of %s (has: %s) -- re-run tools/pmc_conv.sh + tools/pmc_summary.py' % (os.path.relpath(files[-1], ROOT), kname, ', '.join(sorted(calls)))
+
+
+ROOFLINE_LAYER_CALLS = ('da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]', 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
+                        'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]')
 
 
 def main():
@@ -476,6 +482,15 @@ def main():
                     help="headline leg: 'seg' = BASELINE configs[1] (the metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
     args = ap.parse_args()
 
+    headline_default = (args.workload == 'seg' and args.net == 'UNet_light' and args.precision == 'fp32_split' and tuple(args.shape) == (160, 192, 160)
+                        and args.batch == 2 and not args.no_extra and not args.no_profile and not args.graph)
+    if headline_default and int(os.environ.get('RANK', '0')) == 0 and os.environ.get('DA_BENCH_ALLOW_NO_TRAFFIC') != '1':
+        # `roofline.traffic` comes from committed PMC passes; a missing record must stop the run BEFORE anything is timed, not become `traffic: null`
+        for c in ROOFLINE_LAYER_CALLS:
+            rec, why = pmc_traffic_for(c, args.precision)
+            if rec is None:
+                sys.stderr.write('bench.py: roofline.traffic has no source: %s\n(set DA_BENCH_ALLOW_NO_TRAFFIC=1 to run anyway and report traffic: null)\n' % why)
+                sys.exit(4)
     want = max(args.gpus, 1)
     if 'WORLD_SIZE' not in os.environ and want > 1:
         self_spawn(want)                                   # never returns
@@ -639,7 +654,7 @@ def main():
                             all_profiled=dict(tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), ms_per_step=round(tot_ms / args.steps, 3),
                                               frac_of_step=round(tot_ms / args.steps / head_res['ms_per_step'], 3)))
             if not args.precision.startswith('bf16'):
-                pm = pmc_traffic_for(top['call'], args.precision)
+                pm, _why = pmc_traffic_for(top['call'], args.precision)
                 if pm:
                     roofline.update(pm)
             if head.flops_per_step and not args.precision.startswith('bf16'):
@@ -665,10 +680,13 @@ def main():
                                          'most time over forward + backward')
                 if args.precision == 'fp32_split':
                     roofline['frac_of_fp32_mfma_peak'] = round(slow['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4)
-                pm2 = pmc_traffic_for(slow['call'], args.precision)
+                pm2, why2 = pmc_traffic_for(slow['call'], args.precision)
                 roofline['traffic'] = pm2['traffic'] if pm2 else None
-                roofline['traffic_source'] = pm2['traffic_source'] if pm2 else None
+                roofline['traffic_source'] = pm2['traffic_source'] if pm2 else ('MISSING: ' + why2)
+                roofline['traffic_over_algorithmic'] = pm2.get('traffic_over_algorithmic') if pm2 else None
                 roofline['mfma_busy_vs_peak_clock'] = pm2.get('mfma_busy_vs_peak_clock') if pm2 else None
+                if pm2 is None:
+                    sys.stderr.write('bench.py: roofline.traffic is null: %s\n' % why2)
                 if args.precision == 'fp32_split':
                     # what the chip sustains of this arithmetic on random operands (tools/ubench/split_f16_kloop.hip, profiles/r04_ubench_f16_kloop.txt):
                     # matrix pipe alone 659 TFLOP/s at the power-limited 1.90 GHz; the K loop with its LDS fragment reads 525 (row pairs) - 580
@@ -728,6 +746,17 @@ def main():
                         parity_eval_dice_abs_diff=pf['eval_dice_abs_diff'], argmax_flips_away_from_ties=pf['flips_away_from_ties'])
         if roofline:
             line.update(roofline_kernel=roofline['kernel'], roofline_frac=roofline['frac'], roofline_avg_ms=roofline['avg_ms'])
+        # the driver's record keeps `config` and `roofline` but drops unknown top-level keys: the same scalars once more where they survive
+        cfg = line['config']
+        cfg['matrix_arithmetic_bits'] = {'fp32_split': 22, 'fp32': 24, 'bf16': 8, 'bf16_storage': 8}[args.precision]
+        for k in ('ms_per_step_with_loss_item', 'reg_ms_per_step', 'joint_ms_per_step', 'native_fp32_mfma_ms_per_step', 'parity_logits_max_abs_vs_fp64',
+                  'parity_oracle_fp32_max_abs_vs_fp64', 'parity_loss_abs_diff', 'parity_logits_rel_l2', 'parity_logits_max_abs', 'parity_eval_dice_abs_diff',
+                  'argmax_flips_away_from_ties'):
+            if k in line:
+                cfg[k] = line[k]
+        if roofline and 'native_fp32_mfma_ms_per_step' in line:
+            roofline['native_fp32_mfma_ms_per_step'] = line['native_fp32_mfma_ms_per_step']
+            roofline['native_fp32_mfma_volumes_per_s'] = extra['native_fp32_mfma']['value']
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

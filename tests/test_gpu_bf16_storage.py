@@ -377,6 +377,59 @@ def test_joint_step_bf16_storage(bf16_storage):
         assert abs(got[k] - float(ref[k].item())) < 2e-2 * max(1.0, abs(float(ref[k].item()))), (k, got[k], float(ref[k].item()))
 
 
+def test_joint_step_bf16_storage_at_configs4_shape():
+    """BASELINE configs[4] as the repo defines it -- joint DeepAtlas step, bf16 ACTIVATION STORAGE + bf16 matrix operands, 192 x 224 x 192, the 32-class
+    UNet_light + VoxelMorph, one pair per GPU -- next to the fp32 step (fp32 matrix instructions) on the same seeds.  The reference has no such mode; what
+    a run at this size can assert is size-independent: every loss term finite and in its range, the parameters finite and moved by at most lr,
+    every term within the op-level bf16 bound of the fp32 step (3e-2, as test_joint_step_bf16_matrix_mode_small_and_configs4_shape holds the
+    operand-rounding mode to), no conversion bridge taken, and the stored activations really bf16 (the displacement field and the losses stay fp32)."""
+    from deepatlas_amd import ops
+    from deepatlas_amd.optim import FlatAdam
+    from deepatlas_amd.models.joint import DeepAtlasJointStep
+    from deepatlas_amd.lib.network_factory import get_network
+    from deepatlas_amd.lib.datasets import synthetic_batch_on_device
+    keys = ('sim', 'bend', 'anat_reg', 'sup', 'anat_seg', 'loss_reg', 'loss_seg')
+    shape, C, d = (192, 224, 192), 32, dev()
+    res = {}
+    pm, ps = ops.set_matrix_precision('fp32'), ops.set_activation_storage('fp32')
+    try:
+        for mode in ('fp32', 'bf16_storage'):
+            ops.set_matrix_precision('bf16' if mode == 'bf16_storage' else 'fp32')
+            ops.set_activation_storage('bf16' if mode == 'bf16_storage' else 'fp32')
+            ops.bridged_calls.clear()
+            torch.manual_seed(230)
+            seg = get_network('UNet_light')(in_channel=1, n_classes=C, bias=True, BN=True); seg.weights_init(); seg.to(d).train()
+            reg = get_network('voxel_morph_cvpr')(); reg.weights_init(); reg.to(d).train()
+            so, ro = FlatAdam(seg.parameters(), lr=1e-3), FlatAdam(reg.parameters(), lr=1e-3)
+            p0 = torch.cat([so.flat_p, ro.flat_p]).clone()
+            x, y = synthetic_batch_on_device(2, shape, C, seed=230, device=d, structured=True)
+            out = DeepAtlasJointStep(seg, so, reg, ro, C)(x[:1], x[1:], y[:1], y[1:])
+            torch.cuda.synchronize()
+            p1 = torch.cat([so.flat_p, ro.flat_p])
+            assert bool(torch.isfinite(p1).all()) and 1e-4 < float((p1 - p0).abs().max()) <= 1e-3 * 1.001
+            res[mode] = {k: float(v.item()) for k, v in out.items()}
+            if mode == 'bf16_storage':
+                assert not ops.bridged_calls, dict(ops.bridged_calls)
+                # one stored activation of each net, taken from a fresh forward: bf16 in HBM
+                with torch.no_grad():
+                    h = seg.encoders[0][0](x[:1])
+                    assert (h.raw if isinstance(h, ops.LazyAct) else h).dtype == torch.bfloat16, type(h)
+                    disp, warped, _ = reg(x[:1], x[1:])
+                    assert disp.dtype == torch.float32 and warped.dtype == torch.float32
+                del h, disp, warped
+            del seg, reg, so, ro, x, y, out, p0, p1
+            torch.cuda.empty_cache()
+    finally:
+        ops.set_activation_storage(ps)
+        ops.set_matrix_precision(pm)
+    print('configs[4] joint step:', res)
+    for mode, r in res.items():
+        assert all(np.isfinite(v) for v in r.values()), (mode, r)
+        assert 0.0 <= r['anat_reg'] <= 1.0 and 0.0 <= r['sup'] <= 1.0 and 0.0 <= r['anat_seg'] <= 1.0 and 0.0 <= r['sim'] <= 2.0 and r['bend'] >= 0.0, (mode, r)
+    for k in keys:
+        assert abs(res['bf16_storage'][k] - res['fp32'][k]) < 3e-2 * max(1.0, abs(res['fp32'][k])), (k, res)
+
+
 @pytest.mark.parametrize('C1,C2,Cout,dims,lazy', [(32, 16, 16, (1, 15, 41, 50), False), (32, 16, 16, (1, 15, 41, 50), True), (16, 0, 16, (2, 16, 40, 64), True)])
 def test_bf16_storage_weight_gradient_eight_wave_form(bf16_storage, C1, C2, Cout, dims, lazy):
     """da_conv3d_k3_wgrad_bf16 / _wgrad_pro_bf16 at sizes where the weight gradient runs its 16-channel eight-wave form (enough tiles to fill the

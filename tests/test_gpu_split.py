@@ -199,13 +199,13 @@ def test_split_mode_one_outlier_in_a_staged_box(case, where, k):
         own = np.abs(wr.grad.numpy()[:, oc])
         # (an fp32 accumulator that holds the outlier's product rounds every later addition at ITS ulp: any fp32 weight gradient, the reference's too)
         assert (e_dw[:, oc] <= 2.0 ** -12 * own + 2.0 ** -20 * T[:, oc] + 2048 * 2.0 ** -36 * M * other).all()
-        rec.append(('wgrad same-chunk', float(e_dw[:, same].max()), float((e_dw[:, same] / np.maximum(np.abs(wr.grad.numpy()[:, same]), 1e-30)).max()), 0.0))
+        rec.append(('wgrad same-chunk', float(e_dw[:, same].max()), float((e_dw[:, same] / np.maximum(np.abs(wr.grad.numpy()[:, same]), 0.1)).max()), 0.0))
     else:                     # the outlier is one dY element: it multiplies 27 x Cin activations; every cout shares the dY tile
         co_other = np.ones(Cout, bool); co_other[oc] = False
         assert (e_dw[co_other] <= 2048 * 2.0 ** -36 * M * other + 2.0 ** -20 * T[co_other]).all()
         own = np.abs(wr.grad.numpy()[oc])
         assert (e_dw[oc] <= 2.0 ** -12 * own + 2.0 ** -20 * T[oc] + 2048 * 2.0 ** -36 * M * other).all()
-        rec.append(('wgrad other-cout', float(e_dw[co_other].max()), float((e_dw[co_other] / np.maximum(np.abs(wr.grad.numpy()[co_other]), 1e-30)).max()), 0.0))
+        rec.append(('wgrad other-cout', float(e_dw[co_other].max()), float((e_dw[co_other] / np.maximum(np.abs(wr.grad.numpy()[co_other]), 0.1)).max()), 0.0))
     print('\noutlier 2^%d in %s:' % (k, where))
     print('\n'.join('  %-18s max |error| %.3e   max relative error (|ref| > 0.1) %.3e   error / (sum|w| 2^-39 M) %.3f' % r for r in rec))
 

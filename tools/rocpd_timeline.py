@@ -2,7 +2,8 @@
 """Timeline view of a rocprofv3 (rocpd sqlite) kernel trace of a two-stream training step: how much of the wall time has a
 matrix (MFMA conv) kernel in flight, how much only HBM-bound kernels, how much nothing, and which kernels account for the time
 that no matrix kernel covers ("exposed" time).
-Usage: python tools/rocpd_timeline.py x_results.db [--skip-frac 0.3] [--top 25] [--dump]"""
+Usage: python tools/rocpd_timeline.py x_results.db [--skip-frac 0.3] [--top 25] [--dump] [--adam-per-step 2]
+(--adam-per-step: optimiser launches per training step -- 1 for seg / reg, 2 for the joint step's two phases; the window is cut at optimiser launches.)"""
 import re
 import sqlite3
 import sys
@@ -27,11 +28,12 @@ def main():
     rows = db.execute("select name, start, end, queue_id from kernels order by start").fetchall()
     t0, t1 = rows[0][1], max(r[2] for r in rows)
     lo = t0 + (t1 - t0) * skip                      # drop warm-up at the head of the trace
+    aps = int(sys.argv[sys.argv.index('--adam-per-step') + 1]) if '--adam-per-step' in sys.argv else 1
     adam = [e for n, s, e, q in rows if 'adam_kernel' in n]
     nsteps = 0
-    if len(adam) >= 3:                               # steady state: from the end of an optimiser launch to the end of the last one
-        k = max(1, len(adam) // 2)
-        lo, t1, nsteps = adam[-k - 1], adam[-1], k
+    if len(adam) >= 3 * aps:                         # steady state: from the end of an optimiser launch to the end of the last one, whole steps only
+        k = max(1, len(adam) // (2 * aps)) * aps
+        lo, t1, nsteps = adam[-k - 1], adam[-1], k // aps
     rows = [(short(n), max(s, lo), min(e, t1), q) for n, s, e, q in rows if e > lo and s < t1]
     ev = []                                          # sweep line over [start, end) of every kernel
     for i, (n, s, e, q) in enumerate(rows):
