@@ -482,15 +482,6 @@ def main():
                     help="headline leg: 'seg' = BASELINE configs[1] (the metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
     args = ap.parse_args()
 
-    headline_default = (args.workload == 'seg' and args.net == 'UNet_light' and args.precision == 'fp32_split' and tuple(args.shape) == (160, 192, 160)
-                        and args.batch == 2 and not args.no_extra and not args.no_profile and not args.graph)
-    if headline_default and int(os.environ.get('RANK', '0')) == 0 and os.environ.get('DA_BENCH_ALLOW_NO_TRAFFIC') != '1':
-        # `roofline.traffic` comes from committed PMC passes; a missing record must stop the run BEFORE anything is timed, not become `traffic: null`
-        for c in ROOFLINE_LAYER_CALLS:
-            rec, why = pmc_traffic_for(c, args.precision)
-            if rec is None:
-                sys.stderr.write('bench.py: roofline.traffic has no source: %s\n(set DA_BENCH_ALLOW_NO_TRAFFIC=1 to run anyway and report traffic: null)\n' % why)
-                sys.exit(4)
     want = max(args.gpus, 1)
     if 'WORLD_SIZE' not in os.environ and want > 1:
         self_spawn(want)                                   # never returns
@@ -506,6 +497,15 @@ def main():
     if torch.cuda.device_count() <= local_rank and not share:
         sys.stderr.write('bench.py: rank %d needs device %d but only %d GPU(s) are visible\n' % (rank, local_rank, torch.cuda.device_count()))
         sys.exit(2)
+    headline_default = (args.workload == 'seg' and args.net == 'UNet_light' and args.precision == 'fp32_split' and tuple(args.shape) == (160, 192, 160)
+                        and args.batch == 2 and not args.no_extra and not args.no_profile and not args.graph)
+    if headline_default and world == 1 and os.environ.get('DA_BENCH_ALLOW_NO_TRAFFIC') != '1':      # (one rank: a lone exit cannot strand peers in a rendezvous)
+        # `roofline.traffic` comes from committed PMC passes; a missing record must stop the run BEFORE anything is timed, not become `traffic: null`
+        for c in ROOFLINE_LAYER_CALLS:
+            rec, why = pmc_traffic_for(c, args.precision)
+            if rec is None:
+                sys.stderr.write('bench.py: roofline.traffic has no source: %s\n(set DA_BENCH_ALLOW_NO_TRAFFIC=1 to run anyway and report traffic: null)\n' % why)
+                sys.exit(4)
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)

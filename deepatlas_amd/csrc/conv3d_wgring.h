@@ -1,0 +1,387 @@
+// Split-mode weight gradient, fourth form: the eight-wave 16-channel kernel of conv3d_mfma.hip (conv3_split_wgrad16_kernel) walking z COLUMNS
+// with the x halo planes in an LDS RING.  Included by conv3d_mfma.hip inside its anonymous namespace (WgP, the staging helpers, split_f16.h).
+//
+// Why.  conv3_split_wgrad16_kernel stages a 4 x 10 x 18 halo box for every 2 x 8 x 16 output tile: 2.81 x the tile's voxels, every tile, through the
+// L1 -- 7.1 GB per launch of the 48 -> 16 layer against 2.5 GB of tensors, at the ~10 B / clk / CU an L1 sustains on 64-byte sector requests
+// (profiles/r04_wgrad_memory_path.txt: the staging loads ALONE take the row-owner kernel's whole time).  A weight gradient keeps its sums per
+// (tap, cin, cout) and only walks voxels, so a workgroup can walk a z column: consecutive tiles (z0, z0 + 2, ...) share two of their four halo
+// planes.  Here the x planes live in a ring of six plane slots (three slabs of two planes): a tile reads the slabs (lower, upper), the next
+// tile's new slab (planes z0 + 3, z0 + 4) is converted into the third slot WHILE the current tile's slabs are being read -- one barrier per tile
+// instead of two, 3 + 2 parked quads per thread instead of 6 + 2 -- and only 1.41 x the tile's voxels are loaded per tile: 4.5 GB per launch.
+//
+// Scales (split_f16.h).  The planes of a ring are shared by consecutive tiles, so they carry ONE power-of-two scale 2^ea for the whole run of
+// tiles; a run ends at the end of a column, at the end of the workgroup's range, or when the incoming slab does not fit the scale: it would
+// overflow fp16 (its ideal exponent e_new < ea) or the tile's own window {upper slab, new slab} would sit more than 2^3 below the ideal scale
+// (ea < min(e_up, e_new) - 3).  The next run starts with a whole-tile load and a fresh scale.  What a tile's x operands get is therefore the
+// same as in the row-owner / eight-wave kernels, whose accumulator-unit hysteresis also stages x up to 2^3 below its box's ideal scale.  dY has
+// no halo: its scale is per tile, 2^(E - ea) with E the accumulators' unit (kept while the ideal unit lies within [E, E + 3]).
+template <bool PRO>
+__global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
+    using WFrag = f16x8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CK = 16, CG = 16, TVOX = 2 * TY * TX, NT = 512;
+    constexpr int ZPQ = DA_WG16_ZPAD, ZPE = 4 * ZPQ;
+    constexpr int PV = HY * HX;                               // voxels of a halo plane
+    constexpr int PS = PV * 8 + ZPE;                          // two-byte elements of one plane slot of one half image
+    constexpr int NSLOT = 6;                                  // plane slots: three slabs of two planes
+    constexpr int PLH = NSLOT * PS, PLA = 2 * PLH;            // elements per half image / per fp16 plane (h | l)
+    constexpr int PLY = TVOX * CG;                            // elements per fp16 plane of a dY tile (two buffers of two planes)
+    constexpr int QA = CK / 4, QY = CG / 4;
+    constexpr int NIT2 = (2 * PV * QA + NT - 1) / NT;         // parked quads of a slab (3)
+    constexpr int NIT4 = (4 * PV * QA + NT - 1) / NT;         // ... of a whole tile, at the start of a run (6)
+    constexpr int NITY = (TVOX * QY + NT - 1) / NT;           // ... of a dY tile (2)
+    float* ldsA = lds;
+    float* ldsY = lds + PLA;                                  // (two planes of PLA two-byte elements = PLA floats)
+    float* smax = ldsY + 2 * PLY;                             // [2 parities][3: x lower | x upper (or the slab) | dY][8 waves]
+    typedef s16x4 __attribute__((address_space(3))) * lds_frag_ptr;
+    const short* ldsAh = reinterpret_cast<const short*>(ldsA);
+    const short* ldsYh = reinterpret_cast<const short*>(ldsY);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave & 3, wh = wave >> 2;                  // row pair, channel half
+    const int i = lane & 15, g = lane >> 4, q = i & 3, vq = i >> 2;
+    const int slab = blockIdx.x, nsl = gridDim.x, ch = blockIdx.y, cg = blockIdx.z;
+    const int cbase = ch * CK;
+    const float* src; int Cs, choff;
+    if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
+    const int c4 = (int)threadIdx.x % QA;
+    unsigned vmA = 0;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
+    if constexpr (PRO) {
+        const int cofs = choff + c4 * 4;
+        psc = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.ps1 : p.ps2) + cofs);
+        psf = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.pt1 : p.pt2) + cofs);
+        pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
+    }
+    // fragment sources: the eight-wave kernel's, with the z plane of a read resolved through the ring (offC, per tile)
+    const int laneA0 = ((2 * wr) * HX + 8 * (g & 1) + vq) * 8 + (q & 1) * 4 + wh * PLH;
+    const int laneY = ((((g >> 1) * TY) + 2 * wr) * TX + 8 * (g & 1) + vq) * CG + q * 4;
+    int offC[5];
+    auto set_ring = [&](int L, int U) {                        // a tile's planes 0, 1 = slab slot L, planes 2, 3 = slab slot U
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int combo = (c < 4) ? 2 * c + (q >> 1) : 8;
+            const int rel = (g >> 1) + combo / 3;              // plane of the tile's halo box this lane reads for tap column `combo`
+            const int ps = rel < 2 ? 2 * L + rel : 2 * U + rel - 2;
+            offC[c] = ps * PS + (combo % 3) * 8;
+        }
+    };
+    auto tr8 = [&](const short* a, int step) -> WFrag {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_frag_ptr)(a + step));
+        return __builtin_bit_cast(WFrag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto mma = [&](f32x4 c, const WFrag& a, const WFrag& b) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); };
+    struct F3 { WFrag p[2]; };
+    auto loadF = [&](int c, int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA0 + offC[c] + h * (HX * 8);
+        f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
+        return f;
+    };
+    auto loadG = [&](int h) -> F3 {
+        F3 f; const short* a = ldsAh + laneA0 + offC[4] + (h + (q >> 1)) * (HX * 8);
+        f.p[0] = tr8(a, 4 * 8); f.p[1] = tr8(a + PLA, 4 * 8);
+        return f;
+    };
+    int ybo = 0;                                               // element offset of the dY buffer the current tile reads
+    auto loadY = [&](int r) -> F3 {
+        F3 f; const short* a = ldsYh + ybo + laneY + r * (TX * CG);
+        f.p[0] = tr8(a, 4 * CG); f.p[1] = tr8(a + PLY, 4 * CG);
+        return f;
+    };
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 preA[NIT4], preY[NITY];
+    // staging maps (launch constants): x quad idx = threadIdx.x + 512 it -> (plane, hy, hx) of a box of up to four planes
+    int voA[NIT4]; unsigned pkA[NIT4];
+#pragma unroll
+    for (int it = 0; it < NIT4; ++it) {
+        const int hv = ((int)threadIdx.x + it * NT) / QA;
+        const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
+        pkA[it] = (unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx;
+        voA[it] = (hz * p.H + hy) * p.W + hx;
+    }
+    const bool smallA = (long long)4 * p.H * p.W < (1ll << 24) && (long long)Cs * 4 < (1ll << 24);
+    const int yq4 = cg * CG + ((int)threadIdx.x % QY) * 4;
+    const int yv0 = (int)threadIdx.x / QY;
+    int voY[NITY];
+    const bool smallY = (long long)2 * p.H * p.W < (1ll << 24) && (long long)p.Cout * 4 < (1ll << 24);
+#pragma unroll
+    for (int it = 0; it < NITY; ++it) { const int v = yv0 + it * (NT / QY); voY[it] = ((v >> 7) * p.H + ((v >> 4) & 7)) * p.W + (v & 15); }
+    // NPL planes of x starting at plane zf of sample n (zf may be -1 or reach past D: zeros), halo box origin (y0 - 1, x0 - 1)
+    auto issue_x = [&](auto NPLC, int n, int zf, int y0, int x0) {
+        constexpr int NPL = decltype(NPLC)::value, NITS = NPL == 2 ? NIT2 : NIT4;
+        const long long sample = (long long)p.D * p.H * p.W * Cs;
+        const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<false>(src, n, sample);
+        const bool interior = smallA && zf >= 0 && zf + NPL <= p.D && y0 >= 1 && y0 + HY - 2 < p.H && x0 >= 1 && x0 + HX - 2 < p.W;
+        const unsigned Cs4 = (unsigned)Cs * 4u, cofs4 = (unsigned)(choff + c4 * 4) * 4u;
+        const unsigned base = (unsigned)((zf * p.H + (y0 - 1)) * p.W + (x0 - 1)) * Cs4 + cofs4;
+        if constexpr (PRO) vmA = 0;
+#pragma unroll
+        for (int it = 0; it < NITS; ++it) {
+            const int hz = (int)(pkA[it] >> 16), hy = (int)((pkA[it] >> 8) & 255u), hx = (int)(pkA[it] & 255u);
+            unsigned so;
+            if (interior) so = ((it + 1) * NT <= NPL * PV * QA || hz < NPL) ? __umul24((unsigned)voA[it], Cs4) + base : 0xFFFFFFFFu;
+            else {
+                const int z = zf + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool inb = hz < NPL && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                so = inb ? (unsigned)((z * p.H + y) * p.W + x) * Cs4 + cofs4 : 0xFFFFFFFFu;
+            }
+            preA[it] = da_buf_load4(rs, so);
+            if constexpr (PRO) vmA |= (so != 0xFFFFFFFFu ? 1u : 0u) << it;
+        }
+    };
+    auto issue_y = [&](int n, int z0, int y0, int x0) {
+        const long long sampleY = (long long)p.D * p.H * p.W * p.Cout;
+        const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<false>(p.dy, n, sampleY);
+        const bool inside = smallY && z0 + 2 <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && cg * CG + CG <= p.Cout;
+        const unsigned baseY = ((unsigned)((z0 * p.H + y0) * p.W + x0) * (unsigned)p.Cout + (unsigned)yq4) * 4u;
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int v = yv0 + it * (NT / QY);
+            const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+            unsigned off;
+            if (inside) off = __umul24((unsigned)voY[it], (unsigned)p.Cout * 4u) + baseY;
+            else {
+                const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+                const bool vin = z < p.D && y < p.H && x < p.W && yq4 < p.Cout;
+                off = vin ? ((unsigned)((z * p.H + y) * p.W + x) * (unsigned)p.Cout + (unsigned)yq4) * 4u : 0xFFFFFFFFu;
+            }
+            preY[it] = da_buf_load4(ry, off);
+        }
+    };
+    // parked quads -> the two fp16 planes of the ring, planes of the box going to plane slots ps0, ps0 + 1 (, ps0 + 2, ps0 + 3)
+    auto write_x = [&](auto NPLC, int ps0, float sa) {
+        constexpr int NPL = decltype(NPLC)::value, NITS = NPL == 2 ? NIT2 : NIT4;
+#pragma unroll
+        for (int it = 0; it < NITS; ++it) {
+            const int hz = (int)(pkA[it] >> 16);
+            if ((it + 1) * NT <= NPL * PV * QA || hz < NPL) {
+                const int hv = ((int)threadIdx.x + it * NT) >> 2;
+                const int idx = (c4 >> 1) * (PLH / 4) + (ps0 + hz) * (PS / 4) + (hv - hz * PV) * 2 + (c4 & 1);
+                uint2 h, l; da_split2(preA[it], sa, h, l);
+                reinterpret_cast<uint2*>(ldsA)[idx] = h; reinterpret_cast<uint2*>(ldsA)[idx + PLA / 4] = l;
+            }
+        }
+    };
+    auto write_y = [&](int yb, float sy) {
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int idx = yb * (2 * PLY / 4) + (int)threadIdx.x + it * NT;
+            uint2 h, l; da_split2(preY[it], sy, h, l);
+            reinterpret_cast<uint2*>(ldsY)[idx] = h; reinterpret_cast<uint2*>(ldsY)[idx + PLY / 4] = l;
+        }
+    };
+    auto wave_read_max = [&](const float* s) -> float {       // the eight waves' maxima of one quantity -> a wave-uniform float
+        const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+        const float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m)));
+    };
+    // the unit 2^-E of a tile's products given the ring's x exponent and the tile's ideal dY exponent (hysteresis and cap as in the other forms)
+    int Eacc = 0, Emin = 0; bool first_tile = true;
+    auto pick_E = [&](int ea, int ey_ideal, int Eref) -> int {
+        int E = ea + ey_ideal;
+        if (!first_tile) E = min(E, Emin + 40);
+        if (!first_tile && E >= Eref && E <= Eref + 3) E = Eref;
+        Emin = first_tile ? E : min(Emin, E);
+        first_tile = false;
+        return E;
+    };
+
+    const int lo = slab * p.tiles_per_slab, hi = min(lo + p.tiles_per_slab, p.ntiles);
+    auto tile_at = [&](int pos) -> int4 { pos = pos < p.ntiles ? pos : p.ntiles - 1; return p.tiles[__builtin_amdgcn_readfirstlane(pos)]; };
+    int pos = lo;
+    int par = 0;
+#pragma unroll 1
+    while (pos < hi) {
+        // ---- start of a run: the whole tile `pos` (four planes + dY), a fresh ring scale
+        const int4 tv = tile_at(pos);
+        const int n = __builtin_amdgcn_readfirstlane(tv.x), zc = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
+        int4 tn = tile_at(pos + 1);
+        issue_x(IntC<4>(), n, zc - 1, y0, x0);
+        issue_y(n, zc, y0, x0);
+        if constexpr (PRO) stage_pro_apply<0, NIT4>(preA, vmA, psc, psf, pslope);
+        {
+            float mlo = 0.f, mup = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT4; ++it) {
+                const bool low = (int)(pkA[it] >> 16) < 2;
+                if ((it + 1) * NT <= 2 * PV * QA) mlo = da_absmax4(mlo, preA[it]);
+                else if (it * NT >= 2 * PV * QA) mup = da_absmax4(mup, preA[it]);
+                else { const float m1 = da_absmax4(0.f, preA[it]); mlo = low ? fmaxf(mlo, m1) : mlo; mup = low ? mup : fmaxf(mup, m1); }
+            }
+            const float a0 = da_wave_max_nonneg(mlo), a1 = da_wave_max_nonneg(mup), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+            if (lane == 0) { smax[par * 24 + wave] = a0; smax[par * 24 + 8 + wave] = a1; smax[par * 24 + 16 + wave] = my; }
+        }
+        __syncthreads();
+        int e_up, ea, Ecur;
+        {
+            const int e_lo = da_scale_exp(wave_read_max(smax + par * 24));
+            e_up = da_scale_exp(wave_read_max(smax + par * 24 + 8));
+            ea = min(e_lo, e_up);
+            const int ey = da_scale_exp(wave_read_max(smax + par * 24 + 16));
+            Ecur = pick_E(ea, ey, Eacc);
+            write_x(IntC<4>(), 0, da_pow2(ea));
+            write_y(0, da_pow2(Ecur - ea));
+        }
+        par ^= 1;
+        int L = 0, U = 1, yb = 0, t = pos;
+        // the next tile of the column, if it is ours: its new slab (planes z + 3, z + 4 of the current tile) and its dY
+        bool have_next = pos + 1 < hi && __builtin_amdgcn_readfirstlane(tn.y) != 0;
+        if (have_next) {
+            issue_x(IntC<2>(), n, zc + 3, y0, x0);
+            issue_y(n, zc + 2, y0, x0);
+            if constexpr (PRO) stage_pro_apply<0, NIT2>(preA, vmA, psc, psf, pslope);
+            const float a1 = da_wave_max_nonneg(stage_absmax<NIT2>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+            if (lane == 0) { smax[par * 24 + 8 + wave] = a1; smax[par * 24 + 16 + wave] = my; }
+        }
+        __syncthreads();
+        // ---- the run: one barrier per tile
+#pragma unroll 1
+        for (;;) {
+            int Enext = Ecur; bool conv = false, have_next2 = false;
+            if (have_next) {
+                const int e_new = da_scale_exp(wave_read_max(smax + par * 24 + 8));
+                const int ey = da_scale_exp(wave_read_max(smax + par * 24 + 16));
+                conv = ea <= e_new && ea >= min(e_up, e_new) - 3;
+                if (conv) {
+                    const int N = U == 2 ? 0 : U + 1;
+                    Enext = pick_E(ea, ey, Ecur);
+                    write_x(IntC<2>(), 2 * N, da_pow2(ea));
+                    write_y(yb ^ 1, da_pow2(Enext - ea));
+                    e_up = e_new;
+                    tn = tile_at(t + 2);
+                    have_next2 = t + 2 < hi && __builtin_amdgcn_readfirstlane(tn.y) != 0;
+                    if (have_next2 && !(p.ablate & 1)) {
+                        const int z2 = zc + 2 * (t - pos);                       // z0 of tile t
+                        issue_x(IntC<2>(), n, z2 + 5, y0, x0);
+                        issue_y(n, z2 + 4, y0, x0);
+                    }
+                }
+            }
+            if (Ecur != Eacc) {
+                const float f = da_acc_factor(Ecur - Eacc);
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * f;
+                Eacc = Ecur;
+            }
+            set_ring(L, U);
+            ybo = yb * (2 * PLY);
+            if (!(p.ablate & 2)) {
+                F3 Y0 = loadY(0), Y1 = loadY(1);
+                F3 Fa = loadF(0, 0), Fb = loadF(0, 1), Fc = loadF(0, 2), Fd, Na, Nb, Nc;
+                constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};             // (x, dY) plane pairs, small terms first
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    Fd = loadF(c, 3);
+                    Na = (c < 3) ? loadF(c + 1, 0) : loadG(0);
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        acc[c][0] = mma(acc[c][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
+                        acc[c][1] = mma(acc[c][1], Fb.p[PA[pr]], Y0.p[PB[pr]]);
+                        acc[c][2] = mma(acc[c][2], Fc.p[PA[pr]], Y0.p[PB[pr]]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c < 3) { Nb = loadF(c + 1, 1); Nc = loadF(c + 1, 2); } else { Nb = loadG(1); Nc = loadF(4, 2); }
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        acc[c][0] = mma(acc[c][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
+                        acc[c][1] = mma(acc[c][1], Fc.p[PA[pr]], Y1.p[PB[pr]]);
+                        acc[c][2] = mma(acc[c][2], Fd.p[PA[pr]], Y1.p[PB[pr]]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    Fa = Na; Fb = Nb; Fc = Nc;
+                }
+                {
+                    Fd = loadF(4, 3);
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        acc[4][0] = mma(acc[4][0], Fa.p[PA[pr]], Y0.p[PB[pr]]);
+                        acc[4][1] = mma(acc[4][1], Fc.p[PA[pr]], Y0.p[PB[pr]]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        acc[4][0] = mma(acc[4][0], Fb.p[PA[pr]], Y1.p[PB[pr]]);
+                        acc[4][1] = mma(acc[4][1], Fd.p[PA[pr]], Y1.p[PB[pr]]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (conv && have_next2) {                                           // the slab after next has landed: its maxima, for the decision at the top of the next tile
+                if constexpr (PRO) stage_pro_apply<0, NIT2>(preA, vmA, psc, psf, pslope);
+                const float a1 = da_wave_max_nonneg(stage_absmax<NIT2>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+                if (lane == 0) { smax[(par ^ 1) * 24 + 8 + wave] = a1; smax[(par ^ 1) * 24 + 16 + wave] = my; }
+            }
+            __syncthreads();
+            if (!conv) break;
+            L = U; U = (U == 2 ? 0 : U + 1); yb ^= 1; t += 1; have_next = have_next2; par ^= 1; Ecur = Enext;
+        }
+        pos = t + 1;
+    }
+    {
+        const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc[c][d] = acc[c][d] * inv1 * inv2;
+    }
+    // reduce the four row-pair waves of each channel half through LDS (two rounds; 4 x 15 KB), then waves 0 and 4 write the slab's partial dW
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds);
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) red[((slot * 15) + c * 3 + d) * 64 + lane] = make_float4(acc[c][d][0], acc[c][d][1], acc[c][d][2], acc[c][d][3]);
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float4 v = red[((slot * 15) + c * 3 + d) * 64 + lane];
+                acc[c][d][0] += v.x; acc[c][d][1] += v.y; acc[c][d][2] += v.z; acc[c][d][3] += v.w;
+            }
+    };
+    if (wr >= 2) put(2 * wh + wr - 2);
+    __syncthreads();
+    if (wr < 2) add(2 * wh + wr);
+    __syncthreads();
+    if (wr == 1) put(wh);
+    __syncthreads();
+    if (wr == 0) {
+        add(wh);
+        float* part = p.partial + (size_t)slab * p.O;
+        const int Cin = p.C1 + p.C2;
+        const int co = cg * CG + i;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 4 * g + reg;
+                    const int combo = c < 4 ? 2 * c + (row >> 3) : 8;
+                    const int dyt = c < 4 ? d : 2 * d + (row >> 3);
+                    const int tap = (combo / 3) * 9 + dyt * 3 + combo % 3, ci = wh * 8 + (row & 7);
+                    if (dyt < 3 && (c < 4 || d < 2) && co < p.Cout) part[((size_t)tap * Cin + cbase + ci) * p.Cout + co] = acc[c][d][reg];
+                }
+    }
+    (void)nsl;
+}
+
+// tile table of the ring kernel: z fastest, so that a workgroup's contiguous range of positions walks whole columns
+__global__ void wgrad_ztiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < ntiles; pos += gridDim.x * blockDim.x) {
+        const int tz = pos % ntz, col = pos / ntz;
+        const int tx = col % ntx, r = col / ntx;
+        tiles[pos] = make_int4(r / nty, tz * 2, (r % nty) * TY, tx * TX);
+    }
+}

@@ -9,9 +9,11 @@ An op without rows is an ERROR (exit 2) -- round 4 lost the dominant kernel's re
 Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE on gfx950 tallies every L2 -> fabric read
 request at 64 B although 128-B requests exist (a wide coalesced stream reads exactly half), other widths "uncalibrated: calibrate on a known byte
 count in your own access pattern".  Done here in two steps:
-  1. tools/ubench/fetch_calib.hip streams 1 GiB once in four request shapes under the same passes.  On those KNOWN byte counts the script checks
-     which of   raw FETCH_SIZE  |  request-size mix 32 n32 + 64 n64 + 128 n128  |  size-weighted 32 (DRAM_32B + GMI_32B + IO_32B)
-     reproduces the sector bytes touched (method accepted when every shape is within 3 %);
+  1. tools/ubench/fetch_calib.hip sweeps a 1 GiB buffer once in four request shapes under the same passes.  On that KNOWN byte count (the 128-byte
+     lines touched: the L2 fetches whole lines, see `want` below) the script checks which of
+         raw FETCH_SIZE  |  request-size mix 32 n32 + 64 n64 + 128 n128  |  size-weighted 32 (DRAM_32B + GMI_32B + IO_32B)
+     reproduces it (method accepted when every shape is within 3 %).  Round 5: both request-aware counters reproduce 1 GiB to four digits on all
+     four shapes; raw FETCH_SIZE reads exactly half on all four (every request is 128 bytes, tallied as 64);
   2. the accepted method is read on the conv kernels themselves: fetch_bytes = that counter, fetch_correction = fetch_bytes / raw FETCH_SIZE --
      i.e. FETCH_SIZE corrected with THIS kernel's own request mix, not with an assumed mix of shapes.
 If no method passes step 1 the script falls back to raw FETCH_SIZE x the calibration factor of the contiguous shape and says so.
@@ -105,7 +107,10 @@ def main():
         except Exception:
             pass
     # ---- step 1: which counter reproduces known byte counts
-    want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 29), 'stream_b128_run32<64>': float(1 << 30), 'stream_b128_run32<128>': float(1 << 29)}
+    # Known byte count of each calibration stream = the 128-BYTE LINES it touches: on gfx950 every L2 -> fabric read is a 128-byte request (RDMIX pass:
+    # RDREQ_128B == RDREQ, no 32- / 64-byte requests at all), so a stream that uses only 32 or 64 bytes of every line (the `half` / `run32<128>` shapes:
+    # one chunk of a 32-channel voxel) still moves the whole line.  All four streams sweep every line of the 1 GiB buffer exactly once.
+    want = {'stream_b128_contig': float(1 << 30), 'stream_b128_half': float(1 << 30), 'stream_b128_run32<64>': float(1 << 30), 'stream_b128_run32<128>': float(1 << 30)}
     cal_cnt = collections.defaultdict(dict)
     for p in ('FETCH_SIZE', 'RDMIX', 'RDW32'):
         f = os.path.join(src, 'fetch_calib_%s.csv' % p)
