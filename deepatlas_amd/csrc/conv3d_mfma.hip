@@ -2231,6 +2231,8 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16_kernel(WgP p) {
     }
 }
 
+#include "conv3d_wgring.h"      // conv3_split_wgrad16r_kernel: the eight-wave form walking z columns with the x planes in an LDS ring
+
 __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nparts, int O, float* __restrict__ out) {
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
         double s = 0.0;
@@ -2406,8 +2408,8 @@ static size_t packed_bytes(int Cin, int Cout, int CK) {
     return da_align(b) + da_align(kDynCtrInts * sizeof(int));
 }
 
-struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; int w16; };      // w16: conv3_split_wgrad16_kernel (16-channel chunks, one 8-wave workgroup per CU)
-static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, bool split = false, bool allow16 = false) {
+struct WgPlan { int CK, NREP, ngroups, nchunks, ntz, nty, ntx, ntiles, nslabs, tps; size_t partial_bytes; int w16; };      // w16: 1 conv3_split_wgrad16_kernel (16-channel chunks, one 8-wave workgroup per CU), 2 its ring form conv3_split_wgrad16r_kernel
+static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, bool split = false, bool allow16 = false, bool allow_ring = false) {
     WgPlan q;
     q.CK = pick_ck(C1, C2);
     const int NT = (Cout + 15) / 16;
@@ -2428,6 +2430,16 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
         { static int any = -1; if (any < 0) { const char* e = getenv("DA_WG16_ANY"); any = (e && !atoi(e)) ? 0 : 1; }
           if (any && s16 * combos < 224) s16 = 256 / combos; }  // ... or any slab count that fills the chip (tile_walk then walks one list): 192 -> 64 0.65 -> 0.60 ms, 96 -> 32 unchanged
         if (on && s16 >= 1 && s16 * combos >= 224 && s16 <= cap && s16 <= q.ntiles) { q.w16 = 1; q.nchunks = (C1 + C2) / 16; slabs = s16; }
+        // the ring form (conv3d_wgring.h): fp32 tensors in split mode only; contiguous tile ranges per slab, so no multiple-of-8 rounding below
+        static int ring = -1; if (ring < 0) { const char* e = getenv("DA_WG16R"); ring = (e && !atoi(e)) ? 0 : 1; }
+        if (q.w16 && ring && allow_ring) {
+            q.w16 = 2;
+            if (slabs > q.ntiles) slabs = q.ntiles;
+            q.tps = (int)da_cdiv(q.ntiles, slabs);
+            q.nslabs = (int)da_cdiv(q.ntiles, q.tps);           // (every slab non-empty)
+            q.partial_bytes = da_align((size_t)q.nslabs * O * sizeof(float));
+            return q;
+        }
     }
     if (slabs > q.ntiles) slabs = q.ntiles;
     if (slabs >= 8) slabs &= ~7ll;                           // multiple of 8: blockIdx.x % 8 is then the XCD (tile_walk)
@@ -2857,6 +2869,23 @@ static int launch_split_wgrad16(const WgP& p, const WgPlan& q, hipStream_t st) {
     return 0;
 }
 
+template <bool PRO>
+static int launch_split_wgrad16r(const WgP& p, const WgPlan& q, hipStream_t st) {
+    // six plane slots x two half images x two fp16 planes + two dY buffers of two planes + the waves' maxima (2 parities x 3 x 8 floats)
+    size_t shm = (size_t)(2 * 2 * 6 * (HY * HX * 8 + 4 * DA_WG16_ZPAD)) * 2 + (size_t)(2 * 2 * 2 * TY * TX * 16) * 2 + 2 * 24 * sizeof(float);
+    if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);
+    auto kern = conv3_split_wgrad16r_kernel<PRO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(q.nslabs, q.nchunks, q.ngroups), dim3(512), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f, int act_bf16) {
     const bool hb = act_bf16 != 0;
@@ -2925,7 +2954,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     // (measured, 2 x 160 x 192 x 160: bf16 storage 48 -> 16 1.23 -> 1.09 ms, 16 -> 16 0.42 -> 0.38; NOT for more than one cout tile -- 96 -> 32: 0.44 ->
     // 0.70 ms, the kernel re-stages x per 16-cout group -- and not with fp32 tensors, 1.21 -> 1.94 ms: there the staging conversions dominate)
     const bool rows1 = !bfv1 && hb && da_matrix_mode() == 1 && s2d_cin == 0 && Cout % 4 == 0 && Cout <= 16 && pick_ck(C1, C2) != 0;
-    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split || rows1);
+    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split || rows1, split && !hb);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
@@ -2939,7 +2968,8 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     { static int abl = -1; if (abl < 0) { const char* e = getenv("DA_WG_ABLATE"); abl = e ? atoi(e) : 0; } p.ablate = abl; }
     if (split || rows1) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
-        hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz, DA_WG_TZ);
+        if (q.w16 == 2) hipLaunchKernelGGL(wgrad_ztiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
+        else hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz, DA_WG_TZ);
         DA_LAUNCH_CHECK();
         p.tiles = tiles;
     }
@@ -2960,7 +2990,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
-        if (split) rcp = q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
+        if (split) rcp = q.w16 == 2 ? launch_split_wgrad16r<true>(p, q, st) : q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
         else if (rows1) rcp = q.w16 ? launch_split_wgrad16<true, 1, true>(p, q, st) : launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
@@ -2970,7 +3000,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (split) rc = q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
+    if (split) rc = q.w16 == 2 ? launch_split_wgrad16r<false>(p, q, st) : q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
     else if (rows1) rc = q.w16 ? launch_split_wgrad16<false, 1, true>(p, q, st) : launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;

@@ -273,7 +273,7 @@ def test_split_mode_input_prologue_is_bit_identical_at_sizes_of_the_eight_wave_w
 def test_eight_wave_weight_gradient_against_the_row_owner_kernel(tmp_path):
     """The two forms of the split weight gradient (DA_WG16=1: 16-channel chunks / eight waves; DA_WG16=0: 8-channel chunks / four waves) on eight
     layer shapes the unit cases do not reach -- 8 / 12 / 24 / 64 output channels, three samples, odd plane counts, input prologue -- in two
-    processes (the switch is read once per process): same tiles, same per-wave program, so they agree to the last bits of an fp32 sum."""
+    processes (the switch is read once per process): same arithmetic per tile, different order of the fp32 partial sums."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
@@ -288,7 +288,9 @@ def test_eight_wave_weight_gradient_against_the_row_owner_kernel(tmp_path):
     for k in a.files:
         x, y = a[k].astype(np.float64), b[k].astype(np.float64)
         assert np.isfinite(x).all()
-        assert np.linalg.norm(x - y) <= 2e-7 * np.linalg.norm(y), (k, np.linalg.norm(x - y) / np.linalg.norm(y))
+        # (the ring form of the eight-wave kernel gives every slab a contiguous range of z columns instead of an interleaved brick walk: other partial
+        # sums per slab, so the two forms differ by a few fp32 roundings of sums of ~1e5 terms -- measured 2.4e-7 on the largest case)
+        assert np.linalg.norm(x - y) <= 5e-7 * np.linalg.norm(y), (k, np.linalg.norm(x - y) / np.linalg.norm(y))
 
 
 @pytest.mark.parametrize('kind', ['uniform', 'lognormal'])
