@@ -509,6 +509,8 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
+    if os.environ.get('DA_MAIN_PRIO'):      # experiment: the whole run on a stream of this HIP priority (-1 = high; the side stream stays at 0)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ['DA_MAIN_PRIO'])))
     rccl = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

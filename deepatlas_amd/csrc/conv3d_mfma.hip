@@ -2434,6 +2434,10 @@ static WgPlan wgrad_plan(int N, int D, int H, int W, int C1, int C2, int Cout, b
         static int ring = -1; if (ring < 0) { const char* e = getenv("DA_WG16R"); ring = (e && !atoi(e)) ? 0 : 1; }
         if (q.w16 && ring && allow_ring) {
             q.w16 = 2;
+            // DA_WG16R_SLABMUL=k: k times as many (k times shorter) workgroups than CUs can hold at once, so that workgroups of a kernel queued later
+            // on a higher-priority stream get CUs as these retire (experiment: the persistent form holds every CU until its slab is done)
+            static int mul = -1; if (mul < 0) { const char* e = getenv("DA_WG16R_SLABMUL"); mul = e ? atoi(e) : 1; if (mul < 1) mul = 1; }
+            slabs *= mul; if (slabs > cap) slabs = cap;
             if (slabs > q.ntiles) slabs = q.ntiles;
             q.tps = (int)da_cdiv(q.ntiles, slabs);
             q.nslabs = (int)da_cdiv(q.ntiles, q.tps);           // (every slab non-empty)
@@ -2465,7 +2469,7 @@ size_t da_conv3_mfma_ws_bytes(int N, int D, int H, int W, int Cin, int Cout, int
     if (Cin % 8 == 0) { const size_t a = packed_bytes(Cin, Cout, Cin % 16 == 0 ? 16 : 8); if (a > pk) pk = a; const size_t b = packed_bytes(Cin, Cout, 8); if (b > pk) pk = b; }
     if (Cout % 8 == 0) { const size_t a = packed_bytes(Cout, Cin, Cout % 16 == 0 ? 16 : 8); if (a > pk) pk = a; }
     size_t part = 0;
-    if (Cin % 8 == 0) part = wgrad_plan(N, D, H, W, Cin, 0, Cout).partial_bytes;
+    if (Cin % 8 == 0) { part = wgrad_plan(N, D, H, W, Cin, 0, Cout).partial_bytes; const size_t pr = wgrad_plan(N, D, H, W, Cin, 0, Cout, true, true, true).partial_bytes; if (pr > part) part = pr; }
     if (Cin <= 4 && Cout <= 32) part = da_align((size_t)kScBlocksFwd * 27 * Cin * Cout * sizeof(float));
     if (Cout <= 4 && Cin <= 32) { const size_t sw = da_align((size_t)(kScBlocksFwd + 1) * 27 * Cin * Cout * sizeof(float)); if (sw > part) part = sw; }   // swapped-operand weight gradient
     return pk + tile_table_bytes(N, D, H, W) + part + wg_tile_table_bytes(N, D, H, W);
@@ -2872,14 +2876,14 @@ static int launch_split_wgrad16(const WgP& p, const WgPlan& q, hipStream_t st) {
 template <bool PRO>
 static int launch_split_wgrad16r(const WgP& p, const WgPlan& q, hipStream_t st) {
     // six plane slots x two half images x two fp16 planes + two dY buffers of two planes + the waves' maxima (2 parities x 3 x 8 floats)
-    size_t shm = (size_t)(2 * 2 * 6 * (HY * HX * 8 + 4 * DA_WG16_ZPAD)) * 2 + (size_t)(2 * 2 * 2 * TY * TX * 16) * 2 + 2 * 24 * sizeof(float);
+    size_t shm = (size_t)(2 * 2 * 6 * (HY * HX * 8 + 4 * DA_WG16_ZPAD)) * 2 + (size_t)(2 * 2 * 2 * TY * TX * 16) * 2 + 2 * 24 * sizeof(float) + 8 * sizeof(float4);      // (+ the prologue's scale / shift quads)
     if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);
     auto kern = conv3_split_wgrad16r_kernel<PRO>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_done = false;
+    if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(q.nslabs, q.nchunks, q.ngroups), dim3(512), shm, st, p);
     DA_LAUNCH_CHECK();
@@ -2968,7 +2972,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     { static int abl = -1; if (abl < 0) { const char* e = getenv("DA_WG_ABLATE"); abl = e ? atoi(e) : 0; } p.ablate = abl; }
     if (split || rows1) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
-        if (q.w16 == 2) hipLaunchKernelGGL(wgrad_ztiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
+        if (q.w16 >= 2) hipLaunchKernelGGL(wgrad_ztiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
         else hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz, DA_WG_TZ);
         DA_LAUNCH_CHECK();
         p.tiles = tiles;
@@ -2990,7 +2994,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps1 = pro->s1 ? pro->s1 : ones; p.pt1 = pro->s1 ? pro->t1 : zeros;
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
-        if (split) rcp = q.w16 == 2 ? launch_split_wgrad16r<true>(p, q, st) : q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
+        if (split) rcp = q.w16 >= 2 ? launch_split_wgrad16r<true>(p, q, st) : q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
         else if (rows1) rcp = q.w16 ? launch_split_wgrad16<true, 1, true>(p, q, st) : launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
@@ -3000,7 +3004,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         return da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st);
     }
     int rc = DA_ERR_UNSUPPORTED;
-    if (split) rc = q.w16 == 2 ? launch_split_wgrad16r<false>(p, q, st) : q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
+    if (split) rc = q.w16 >= 2 ? launch_split_wgrad16r<false>(p, q, st) : q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
     else if (rows1) rc = q.w16 ? launch_split_wgrad16<false, 1, true>(p, q, st) : launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;

@@ -6,8 +6,13 @@
 // (profiles/r04_wgrad_memory_path.txt: the staging loads ALONE take the row-owner kernel's whole time).  A weight gradient keeps its sums per
 // (tap, cin, cout) and only walks voxels, so a workgroup can walk a z column: consecutive tiles (z0, z0 + 2, ...) share two of their four halo
 // planes.  Here the x planes live in a ring of six plane slots (three slabs of two planes): a tile reads the slabs (lower, upper), the next
-// tile's new slab (planes z0 + 3, z0 + 4) is converted into the third slot WHILE the current tile's slabs are being read -- one barrier per tile
+// tile's new slab (planes z0 + 3, z0 + 4) is converted into the third slot while the current tile's slabs are still in use -- one barrier per tile
 // instead of two, 3 + 2 parked quads per thread instead of 6 + 2 -- and only 1.41 x the tile's voxels are loaded per tile: 4.5 GB per launch.
+// A run starts with a PRIME: the tile's lower slab alone (its maximum fixes the ring's scale), then the upper slab + dY as an ordinary unit of the
+// pipeline with nothing to multiply beside it.  Register budget: <= 200, so that two 56-register waves of the HBM-bound BatchNorm-backward kernels
+// fit per SIMD beside the two resident waves of this kernel (in the training step this kernel runs on the side stream beside them; a form with
+// specialised producer / consumer waves -- 1.51 instead of 1.61 ms alone on the 48 -> 16 layer, 241 registers -- lost 0.3 ms of step time to exactly
+// that and was removed: git history of this file).
 //
 // Scales (split_f16.h).  The planes of a ring are shared by consecutive tiles, so they carry ONE power-of-two scale 2^ea for the whole run of
 // tiles; a run ends at the end of a column, at the end of the workgroup's range, or when the incoming slab does not fit the scale: it would
@@ -28,7 +33,6 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
     constexpr int PLY = TVOX * CG;                            // elements per fp16 plane of a dY tile (two buffers of two planes)
     constexpr int QA = CK / 4, QY = CG / 4;
     constexpr int NIT2 = (2 * PV * QA + NT - 1) / NT;         // parked quads of a slab (3)
-    constexpr int NIT4 = (4 * PV * QA + NT - 1) / NT;         // ... of a whole tile, at the start of a run (6)
     constexpr int NITY = (TVOX * QY + NT - 1) / NT;           // ... of a dY tile (2)
     float* ldsA = lds;
     float* ldsY = lds + PLA;                                  // (two planes of PLA two-byte elements = PLA floats)
@@ -46,12 +50,17 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
     if (cbase < p.C1) { src = p.in1; Cs = p.C1; choff = cbase; } else { src = p.in2; Cs = p.C2; choff = cbase - p.C1; }
     const int c4 = (int)threadIdx.x % QA;
     unsigned vmA = 0;
-    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f); float pslope = -1.f;
+    // PRO: the per-channel scale / shift quads of the input prologue live in LDS (eight registers less: the budget above), re-read where they are applied
+    float* spro = smax + 2 * 24;                                // [scale | shift][4 channel quads]
+    float pslope = -1.f;
     if constexpr (PRO) {
-        const int cofs = choff + c4 * 4;
-        psc = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.ps1 : p.ps2) + cofs);
-        psf = *reinterpret_cast<const float4*>((cbase < p.C1 ? p.pt1 : p.pt2) + cofs);
+        if (threadIdx.x < 8) {
+            const int cofs = choff + ((int)threadIdx.x & 3) * 4;
+            const float* sp = threadIdx.x < 4 ? (cbase < p.C1 ? p.ps1 : p.ps2) : (cbase < p.C1 ? p.pt1 : p.pt2);
+            reinterpret_cast<float4*>(spro)[threadIdx.x] = *reinterpret_cast<const float4*>(sp + cofs);
+        }
         pslope = cbase < p.C1 ? p.pslope1 : p.pslope2;
+        __syncthreads();
     }
     // fragment sources: the eight-wave kernel's, with the z plane of a read resolved through the ring (offC, per tile)
     const int laneA0 = ((2 * wr) * HX + 8 * (g & 1) + vq) * 8 + (q & 1) * 4 + wh * PLH;
@@ -95,16 +104,22 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 preA[NIT4], preY[NITY];
-    // staging maps (launch constants): x quad idx = threadIdx.x + 512 it -> (plane, hy, hx) of a box of up to four planes
-    int voA[NIT4]; unsigned pkA[NIT4];
+    float4 preA[NIT2], preY[NITY];
+    // staging maps (launch constants): x quad idx = threadIdx.x + 512 it -> (plane, hy, hx) of a slab (two planes)
+    int voA[NIT2]; unsigned pkA[NIT2];
 #pragma unroll
-    for (int it = 0; it < NIT4; ++it) {
+    for (int it = 0; it < NIT2; ++it) {
         const int hv = ((int)threadIdx.x + it * NT) / QA;
         const int hx = hv % HX, t = hv / HX, hy = t % HY, hz = t / HY;
         pkA[it] = (unsigned)hz << 16 | (unsigned)hy << 8 | (unsigned)hx;
         voA[it] = (hz * p.H + hy) * p.W + hx;
     }
+    auto pro_apply = [&]() {
+        if constexpr (PRO) {
+            const float4 psc = reinterpret_cast<const float4*>(spro)[c4], psf = reinterpret_cast<const float4*>(spro)[4 + c4];
+            stage_pro_apply<0, NIT2>(preA, vmA, psc, psf, pslope);
+        }
+    };
     const bool smallA = (long long)4 * p.H * p.W < (1ll << 24) && (long long)Cs * 4 < (1ll << 24);
     const int yq4 = cg * CG + ((int)threadIdx.x % QY) * 4;
     const int yv0 = (int)threadIdx.x / QY;
@@ -112,9 +127,9 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
     const bool smallY = (long long)2 * p.H * p.W < (1ll << 24) && (long long)p.Cout * 4 < (1ll << 24);
 #pragma unroll
     for (int it = 0; it < NITY; ++it) { const int v = yv0 + it * (NT / QY); voY[it] = ((v >> 7) * p.H + ((v >> 4) & 7)) * p.W + (v & 15); }
-    // NPL planes of x starting at plane zf of sample n (zf may be -1 or reach past D: zeros), halo box origin (y0 - 1, x0 - 1)
-    auto issue_x = [&](auto NPLC, int n, int zf, int y0, int x0) {
-        constexpr int NPL = decltype(NPLC)::value, NITS = NPL == 2 ? NIT2 : NIT4;
+    // the slab of planes zf, zf + 1 of sample n (zf may be -1, zf + 1 may reach D: zeros), halo box origin (y0 - 1, x0 - 1)
+    auto issue_x = [&](int n, int zf, int y0, int x0) {
+        constexpr int NPL = 2;
         const long long sample = (long long)p.D * p.H * p.W * Cs;
         const __amdgpu_buffer_rsrc_t rs = da_rsrc_n<false>(src, n, sample);
         const bool interior = smallA && zf >= 0 && zf + NPL <= p.D && y0 >= 1 && y0 + HY - 2 < p.H && x0 >= 1 && x0 + HX - 2 < p.W;
@@ -122,7 +137,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
         const unsigned base = (unsigned)((zf * p.H + (y0 - 1)) * p.W + (x0 - 1)) * Cs4 + cofs4;
         if constexpr (PRO) vmA = 0;
 #pragma unroll
-        for (int it = 0; it < NITS; ++it) {
+        for (int it = 0; it < NIT2; ++it) {
             const int hz = (int)(pkA[it] >> 16), hy = (int)((pkA[it] >> 8) & 255u), hx = (int)(pkA[it] & 255u);
             unsigned so;
             if (interior) so = ((it + 1) * NT <= NPL * PV * QA || hz < NPL) ? __umul24((unsigned)voA[it], Cs4) + base : 0xFFFFFFFFu;
@@ -154,13 +169,12 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
             preY[it] = da_buf_load4(ry, off);
         }
     };
-    // parked quads -> the two fp16 planes of the ring, planes of the box going to plane slots ps0, ps0 + 1 (, ps0 + 2, ps0 + 3)
-    auto write_x = [&](auto NPLC, int ps0, float sa) {
-        constexpr int NPL = decltype(NPLC)::value, NITS = NPL == 2 ? NIT2 : NIT4;
+    // parked quads -> the two fp16 planes of the ring, the slab's planes going to plane slots ps0, ps0 + 1
+    auto write_x = [&](int ps0, float sa) {
 #pragma unroll
-        for (int it = 0; it < NITS; ++it) {
+        for (int it = 0; it < NIT2; ++it) {
             const int hz = (int)(pkA[it] >> 16);
-            if ((it + 1) * NT <= NPL * PV * QA || hz < NPL) {
+            if ((it + 1) * NT <= 2 * PV * QA || hz < 2) {
                 const int hv = ((int)threadIdx.x + it * NT) >> 2;
                 const int idx = (c4 >> 1) * (PLH / 4) + (ps0 + hz) * (PS / 4) + (hv - hz * PV) * 2 + (c4 & 1);
                 uint2 h, l; da_split2(preA[it], sa, h, l);
@@ -196,46 +210,51 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
     auto tile_at = [&](int pos) -> int4 { pos = pos < p.ntiles ? pos : p.ntiles - 1; return p.tiles[__builtin_amdgcn_readfirstlane(pos)]; };
     int pos = lo;
     int par = 0;
+    int hint = kSplitEmax;                                     // upper bound for the next run's ring exponent: the ideal exponent of the slab that ended the previous run
 #pragma unroll 1
     while (pos < hi) {
-        // ---- start of a run: the whole tile `pos` (four planes + dY), a fresh ring scale
+        // ---- start of a run at tile `pos`.  Prime: its lower slab (planes z0 - 1, z0) alone; the ring's scale is that slab's ideal one, capped by `hint`
         const int4 tv = tile_at(pos);
         const int n = __builtin_amdgcn_readfirstlane(tv.x), zc = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
         int4 tn = tile_at(pos + 1);
-        issue_x(IntC<4>(), n, zc - 1, y0, x0);
-        issue_y(n, zc, y0, x0);
-        if constexpr (PRO) stage_pro_apply<0, NIT4>(preA, vmA, psc, psf, pslope);
+        issue_x(n, zc - 1, y0, x0);
+        pro_apply();
         {
-            float mlo = 0.f, mup = 0.f;
-#pragma unroll
-            for (int it = 0; it < NIT4; ++it) {
-                const bool low = (int)(pkA[it] >> 16) < 2;
-                if ((it + 1) * NT <= 2 * PV * QA) mlo = da_absmax4(mlo, preA[it]);
-                else if (it * NT >= 2 * PV * QA) mup = da_absmax4(mup, preA[it]);
-                else { const float m1 = da_absmax4(0.f, preA[it]); mlo = low ? fmaxf(mlo, m1) : mlo; mup = low ? mup : fmaxf(mup, m1); }
-            }
-            const float a0 = da_wave_max_nonneg(mlo), a1 = da_wave_max_nonneg(mup), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
-            if (lane == 0) { smax[par * 24 + wave] = a0; smax[par * 24 + 8 + wave] = a1; smax[par * 24 + 16 + wave] = my; }
+            const float a0 = da_wave_max_nonneg(stage_absmax<NIT2>(preA));
+            if (lane == 0) smax[par * 24 + wave] = a0;
         }
         __syncthreads();
-        int e_up, ea, Ecur;
+        int e_up = da_scale_exp(wave_read_max(smax + par * 24));
+        const int ea = min(e_up, hint);
+        hint = kSplitEmax;
+        write_x(0, da_pow2(ea));
+        par ^= 1;
+        // its upper slab (planes z0 + 1, z0 + 2) and dY tile: an ordinary unit of the pipeline, with no tile to multiply beside it yet
+        issue_x(n, zc + 1, y0, x0);
+        issue_y(n, zc, y0, x0);
+        pro_apply();
         {
-            const int e_lo = da_scale_exp(wave_read_max(smax + par * 24));
-            e_up = da_scale_exp(wave_read_max(smax + par * 24 + 8));
-            ea = min(e_lo, e_up);
-            const int ey = da_scale_exp(wave_read_max(smax + par * 24 + 16));
-            Ecur = pick_E(ea, ey, Eacc);
-            write_x(IntC<4>(), 0, da_pow2(ea));
+            const float a1 = da_wave_max_nonneg(stage_absmax<NIT2>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
+            if (lane == 0) { smax[par * 24 + 8 + wave] = a1; smax[par * 24 + 16 + wave] = my; }
+        }
+        __syncthreads();
+        int Ecur;
+        {
+            const int e_new = da_scale_exp(wave_read_max(smax + par * 24 + 8));
+            if (!(ea <= e_new && ea >= min(e_up, e_new) - 3)) { hint = e_new; par ^= 1; continue; }      // (the retry's scale min(e_lo, e_new) fits both slabs)
+            Ecur = pick_E(ea, da_scale_exp(wave_read_max(smax + par * 24 + 16)), Eacc);
+            write_x(2, da_pow2(ea));
             write_y(0, da_pow2(Ecur - ea));
+            e_up = e_new;
         }
         par ^= 1;
         int L = 0, U = 1, yb = 0, t = pos;
         // the next tile of the column, if it is ours: its new slab (planes z + 3, z + 4 of the current tile) and its dY
         bool have_next = pos + 1 < hi && __builtin_amdgcn_readfirstlane(tn.y) != 0;
         if (have_next) {
-            issue_x(IntC<2>(), n, zc + 3, y0, x0);
+            issue_x(n, zc + 3, y0, x0);
             issue_y(n, zc + 2, y0, x0);
-            if constexpr (PRO) stage_pro_apply<0, NIT2>(preA, vmA, psc, psf, pslope);
+            pro_apply();
             const float a1 = da_wave_max_nonneg(stage_absmax<NIT2>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
             if (lane == 0) { smax[par * 24 + 8 + wave] = a1; smax[par * 24 + 16 + wave] = my; }
         }
@@ -248,17 +267,18 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
                 const int e_new = da_scale_exp(wave_read_max(smax + par * 24 + 8));
                 const int ey = da_scale_exp(wave_read_max(smax + par * 24 + 16));
                 conv = ea <= e_new && ea >= min(e_up, e_new) - 3;
+                if (!conv) hint = e_new;                                        // (the next run starts at tile t + 1: its lower slab is the current upper one)
                 if (conv) {
                     const int N = U == 2 ? 0 : U + 1;
                     Enext = pick_E(ea, ey, Ecur);
-                    write_x(IntC<2>(), 2 * N, da_pow2(ea));
+                    write_x(2 * N, da_pow2(ea));
                     write_y(yb ^ 1, da_pow2(Enext - ea));
                     e_up = e_new;
                     tn = tile_at(t + 2);
                     have_next2 = t + 2 < hi && __builtin_amdgcn_readfirstlane(tn.y) != 0;
                     if (have_next2 && !(p.ablate & 1)) {
                         const int z2 = zc + 2 * (t - pos);                       // z0 of tile t
-                        issue_x(IntC<2>(), n, z2 + 5, y0, x0);
+                        issue_x(n, z2 + 5, y0, x0);
                         issue_y(n, z2 + 4, y0, x0);
                     }
                 }
@@ -315,7 +335,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
                 }
             }
             if (conv && have_next2) {                                           // the slab after next has landed: its maxima, for the decision at the top of the next tile
-                if constexpr (PRO) stage_pro_apply<0, NIT2>(preA, vmA, psc, psf, pslope);
+                pro_apply();
                 const float a1 = da_wave_max_nonneg(stage_absmax<NIT2>(preA)), my = da_wave_max_nonneg(stage_absmax<NITY>(preY));
                 if (lane == 0) { smax[(par ^ 1) * 24 + 8 + wave] = a1; smax[(par ^ 1) * 24 + 16 + wave] = my; }
             }

@@ -158,6 +158,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
     cm[C + c] = (float)(s2 / (double)M);
 }
 
+// <= 56 registers: two waves of this HBM-bound pass then fit per SIMD beside the two resident 200-register waves of the split weight gradient that
+// the training step runs next to it on the side stream (conv3d_wgring.h); at 60 only one did
 template <int VEC, typename T = float>
 __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -170,12 +172,12 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __res
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i00 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool fixed_q = (stride % cq == 0);
-    float k_sc[VEC], k_sf[VEC], k_mu[VEC], k_rs[VEC], k_c1[VEC], k_c2[VEC];
+    float k_sc[VEC], k_sf[VEC], k_mu[VEC], k_c1[VEC], k_c2[VEC];      // (k_c1 = scale mean(dz), k_c2 = scale rstd mean(dz xhat): five quads, not six -- the register budget above)
     auto load_consts = [&](int q) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const int c = q * VEC + j;
-            k_sc[j] = scale[c]; k_sf[j] = shift[c]; k_mu[j] = mean[c]; k_rs[j] = rstd[c]; k_c1[j] = cm[c]; k_c2[j] = cm[C + c];
+            k_sc[j] = scale[c]; k_sf[j] = shift[c]; k_mu[j] = mean[c]; k_c1[j] = scale[c] * cm[c]; k_c2[j] = scale[c] * rstd[c] * cm[C + c];
         }
     };
     if (fixed_q) load_consts((int)(i00 % cq));
@@ -207,8 +209,7 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __res
                 const float z = xv[u][j] * k_sc[j] + k_sf[j];
                 const float dz = gv[u][j] * da_act_grad(z, slope);
                 if (train) {
-                    const float xh = (xv[u][j] - k_mu[j]) * k_rs[j];
-                    o[j] = k_sc[j] * (dz - k_c1[j] - xh * k_c2[j]);
+                    o[j] = k_sc[j] * dz - k_c1[j] - (xv[u][j] - k_mu[j]) * k_c2[j];      // = scale (dz - mean(dz) - xhat mean(dz xhat))
                 } else {
                     o[j] = k_sc[j] * dz;
                 }

@@ -257,6 +257,7 @@ def enable_async_wgrad(flag=True):
 
 
 _N_SIDE = max(1, int(os.environ.get('DA_SIDE_STREAMS', '1')))      # > 1: weight gradients alternate between that many side streams (experiment)
+_SIDE_PRIO = int(os.environ.get('DA_SIDE_PRIO', '0'))      # HIP stream priority of the side stream (lower number = higher priority; out-of-range values clamp)
 _side_streams = []
 _side_rr = 0
 
@@ -265,10 +266,10 @@ def side_stream():
     """The second HIP stream (round-robin over DA_SIDE_STREAMS of them); every caller is about to queue work on it."""
     global _side_stream, _side_dirty, _side_rr
     if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
+        _side_stream = torch.cuda.Stream(priority=_SIDE_PRIO)
         _side_streams.append(_side_stream)
         for _ in range(_N_SIDE - 1):
-            _side_streams.append(torch.cuda.Stream())
+            _side_streams.append(torch.cuda.Stream(priority=_SIDE_PRIO))
     _side_dirty = True
     _side_rr = (_side_rr + 1) % len(_side_streams)
     return _side_streams[_side_rr]
