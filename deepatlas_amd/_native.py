@@ -66,6 +66,7 @@ SIGNATURES = {
     'da_bn_act_fwd': (I, [P, P, P, F, P, LL, I, P]),
     'da_bn_act_bwd': (I, [P, P, P, P, P, P, P, F, I, P, P, P, LL, I, P, SZ, P]),
     'da_bn_act_bwd_dbias': (I, [P, P, P, P, P, P, F, I, P, P, P, P, LL, I, P, SZ, P]),
+    'da_bn_act_bwd_dbias_pre': (I, [P, P, P, P, P, P, F, I, P, P, P, P, LL, I, P, I, P, SZ, P]),
     'da_act_bwd': (I, [P, P, F, P, LL, P]),
     'da_act_bwd_add_dbias': (I, [P, P, P, F, P, P, LL, I, P, SZ, P]),
     'da_colsum': (I, [P, LL, I, P, P, SZ, P]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     'da_head_dice_ws_bytes': (SZ, [I, LL, I, I]),
     'da_head_dice_fwd': (I, [P, P, P, F, P, P, P, I, I, LL, I, I, I, I, F, P, P, P, SZ, P]),
     'da_head_dice_bwd': (I, [P, P, P, F, P, P, P, I, P, P, P, P, P, I, LL, I, I, P, SZ, P]),
+    'da_head_dice_bwd_bst': (I, [P, P, P, F, P, P, P, P, I, P, P, P, P, P, I, LL, I, I, P, I, P, P, SZ, P]),
     'da_ncc_ws_bytes': (SZ, [I, LL]),
     'da_ncc_fwd': (I, [P, P, I, LL, P, P, P, SZ, P]),
     'da_ncc_bwd': (I, [P, P, P, P, P, P, I, LL, P]),

@@ -27,6 +27,8 @@ struct HdP {
     double* partial;                         // fwd: [N][gridDim.x][3][C]
     const float* coef; const float* dloss;   // bwd
     float* dx; float* wpartial;              // bwd: dx [N][V][K]; per-workgroup [K*C + C] partial (dW, dbias)
+    const float* pmean; double* bst;         // bwd, K = 16 with a prologue: BatchNorm-backward sums of the PRODUCER of x (its statistics pass folded in here):
+                                             // bst[workgroup][2][K] = (sum dz, sum dz (x - mean)), dz = dx act'(x scale + shift)
 };
 
 __device__ __forceinline__ float hd_act01(float z, float s) { return fmaxf(z, z * s); }
@@ -214,6 +216,11 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) db[n][reg] = 0.f;
+    // BatchNorm-backward sums of x's producer (p.bst; KC == 1): this lane's four input channels 4g .. 4g + 3 over its voxels
+    const bool bst = KC == 1 && p.bst != nullptr;
+    float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsf = bsc, bmu = bsc;
+    float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bst) { bsc = *reinterpret_cast<const float4*>(p.ps + 4 * g); bsf = *reinterpret_cast<const float4*>(p.pt + 4 * g); bmu = *reinterpret_cast<const float4*>(p.pmean + 4 * g); }
     const long long chunks_per_sample = (p.V + 255) / 256, nchunks = chunks_per_sample * p.N;
     for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
         const int n_s = (int)(cb / chunks_per_sample);
@@ -274,6 +281,15 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
 #pragma unroll
                 for (int c = 0; c < KC; ++c)          // lane (voxel i, group g) holds input channels 16c + 4g .. + 3
                     da_stq(dxs, (vox * p.K + 16 * c + 4 * g) >> 2, make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]));
+                if (bst) {                            // the raw x of this voxel again (an L1 / L2 hit: this wave loaded it for the logits a moment ago)
+                    const float4 xr = da_ldq(xs, (vox * p.K + 4 * g) >> 2);
+                    const float xv[4] = {xr.x, xr.y, xr.z, xr.w}, scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, sfv[4] = {bsf.x, bsf.y, bsf.z, bsf.w}, muv[4] = {bmu.x, bmu.y, bmu.z, bmu.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dz = dacc[0][j] * da_act_grad(xv[j] * scv[j] + sfv[j], p.pslope >= 1.f ? -1.f : p.pslope);
+                        bs1[j] += dz; bs2[j] += dz * (xv[j] - muv[j]);
+                    }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();       // xl / dl are this wave's own tiles and a wave's LDS accesses execute in order: no workgroup barrier
@@ -321,6 +337,22 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
     }
     float* part = p.wpartial + (size_t)blockIdx.x * (K * C + C);
     for (int idx = threadIdx.x; idx < K * C + C; idx += blockDim.x) part[idx] = red[idx];
+    if (bst) {                                                // per-lane fp32 sums (<= a few hundred voxels) -> doubles over the 16 voxel lanes -> the four waves
+        __syncthreads();
+        double* dred = reinterpret_cast<double*>(lds);        // [wave][2][16]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a0 = (double)bs1[j], a1 = (double)bs2[j];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+            if (i == 0) { dred[(wave * 2 + 0) * 16 + 4 * g + j] = a0; dred[(wave * 2 + 1) * 16 + 4 * g + j] = a1; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+            p.bst[((size_t)blockIdx.x * 2 + k) * 16 + c] = (dred[(0 * 2 + k) * 16 + c] + dred[(1 * 2 + k) * 16 + c]) + (dred[(2 * 2 + k) * 16 + c] + dred[(3 * 2 + k) * 16 + c]);
+        }
+    }
 }
 
 static bool hd_shape_ok(int K, int C) { return (K == 16 || K == 64) && (C == 16 || C == 32); }
@@ -376,7 +408,7 @@ static int head_dice_fwd_t(const float* x, const float* pro_scale, const float* 
     HdP p;
     p.x = x; p.ps = pro_scale; p.pt = pro_shift; p.pslope = pro_scale ? (pro_slope < 0.f ? 1.f : pro_slope) : 1.f;
     p.wp_fwd = wp; p.wp_bwd = nullptr; p.bias = bias; p.labels = labels; p.label_bytes = label_bytes;
-    p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = partial; p.coef = nullptr; p.dloss = nullptr; p.dx = nullptr; p.wpartial = nullptr;
+    p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = partial; p.coef = nullptr; p.dloss = nullptr; p.dx = nullptr; p.wpartial = nullptr; p.pmean = nullptr; p.bst = nullptr;
     int rc;
     if (Cin == 16 && C == 32) rc = hd_launch_fwd<1, 2, T>(p, nblocks, st);
     else if (Cin == 16 && C == 16) rc = hd_launch_fwd<1, 1, T>(p, nblocks, st);
@@ -402,7 +434,9 @@ template <typename T>
 static int head_dice_bwd_t(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                            const float* w_io, const float* bias, const void* labels, int label_bytes,
                            const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
-                           int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
+                           int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream,
+                           const float* pro_mean = nullptr, double* bst = nullptr, int bst_cap = 0, int* bst_n = nullptr) {
+    if (bst_n) *bst_n = 0;
     if (!x || !w_io || !labels || !coef || !dloss || !dx || !dw_io || N <= 0 || V <= 0 || (label_bytes != 1 && label_bytes != 8) ||
         ((pro_scale == nullptr) != (pro_shift == nullptr))) return DA_ERR_BADARG;
     if (!hd_shape_ok(Cin, C) || (pro_scale && pro_slope >= 1.f)) return DA_ERR_UNSUPPORTED;
@@ -422,6 +456,10 @@ static int head_dice_bwd_t(const float* x, const float* pro_scale, const float* 
     p.x = x; p.ps = pro_scale; p.pt = pro_shift; p.pslope = pro_scale ? (pro_slope < 0.f ? 1.f : pro_slope) : 1.f;
     p.wp_fwd = wpf; p.wp_bwd = wpb; p.bias = bias; p.labels = labels; p.label_bytes = label_bytes;
     p.V = V; p.N = N; p.K = Cin; p.C = C; p.partial = nullptr; p.coef = coef; p.dloss = dloss; p.dx = dx; p.wpartial = wpartial;
+    // the producer's BatchNorm-backward sums ride along when x carries a deferred BatchNorm (16 input channels: one channel quad per lane group)
+    const bool want_bst = bst && pro_scale && pro_mean && Cin == 16 && bst_cap >= nblocks && !DaEl<T>::bf;
+    p.pmean = want_bst ? pro_mean : nullptr; p.bst = want_bst ? bst : nullptr;
+    if (want_bst && bst_n) *bst_n = nblocks;
     int rc;
     if (Cin == 16 && C == 32) rc = hd_launch_bwd<1, 2, T>(p, nblocks, st);
     else if (Cin == 16 && C == 16) rc = hd_launch_bwd<1, 1, T>(p, nblocks, st);
@@ -440,6 +478,17 @@ extern "C" int da_head_dice_bwd(const float* x, const float* pro_scale, const fl
                                 const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
                                 int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream) {
     return head_dice_bwd_t<float>(x, pro_scale, pro_shift, pro_slope, w_io, bias, labels, label_bytes, coef, dloss, dx, dw_io, dbias, N, V, Cin, C, ws, ws_bytes, stream);
+}
+// The same, plus the BatchNorm-backward sums of the layer that produced x (x = its raw convolution output, (pro_scale, pro_shift, pro_mean) its
+// batch statistics): bst[bst_n][2][Cin] doubles = (sum dz, sum dz (x - mean)) per workgroup, dz = dx act'(x scale + shift) -- what
+// da_bn_act_bwd_dbias_pre takes instead of its own reduction pass over (dx, x).  *bst_n = 0 when the shape has no such epilogue (Cin != 16, bf16 storage,
+// bst_cap < 1024): the caller then runs the stand-alone pass.  autograd of unets.py:31-32 on the last decoder block.
+extern "C" int da_head_dice_bwd_bst(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope, const float* pro_mean,
+                                    const float* w_io, const float* bias, const void* labels, int label_bytes,
+                                    const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
+                                    int N, long long V, int Cin, int C, double* bst, int bst_cap, int* bst_n, void* ws, size_t ws_bytes, void* stream) {
+    return head_dice_bwd_t<float>(x, pro_scale, pro_shift, pro_slope, w_io, bias, labels, label_bytes, coef, dloss, dx, dw_io, dbias, N, V, Cin, C, ws, ws_bytes, stream,
+                                  pro_mean, bst, bst_cap, bst_n);
 }
 extern "C" int da_head_dice_bwd_bf16(const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                                      const float* w_io, const float* bias, const void* labels, int label_bytes,

@@ -145,13 +145,15 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restri
 }
 
 // finalize BN-backward sums: dgamma = s2, dbeta = s1, cm[0][c] = s1/M, cm[1][c] = s2/M
+// `rstd_scale`: the partials hold sum dz (x - mean) instead of sum dz xhat (sums accumulated by the PRODUCER of dy, which has no rstd at hand)
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long long M, int C,
-                                       float* dgamma, float* dbeta, float* cm) {
+                                       float* dgamma, float* dbeta, float* cm, const float* __restrict__ rstd_scale = nullptr) {
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 64) { s1 += partial[((size_t)b * 2) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
     s1 = da_wave_sum(s1); s2 = da_wave_sum(s2);
     if (threadIdx.x != 0) return;
+    if (rstd_scale) s2 *= (double)rstd_scale[c];
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     cm[c] = (float)(s1 / (double)M);
@@ -413,16 +415,21 @@ template <typename T>
 static int bn_act_bwd_impl(const T* dy, const T* x, const float* mean, const float* rstd,
                            const float* scale, const float* shift, float act_slope, int train,
                            T* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
-                           void* ws, size_t ws_bytes, void* stream) {
+                           void* ws, size_t ws_bytes, void* stream, const double* pre = nullptr, int pre_n = 0) {
     if (!dy || !x || !dx || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
     if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
     const RowPlan p = plan_rows(M, C);
     double* partial = (double*)ws;
     float* cm = (float*)((char*)ws + da_align((size_t)kMaxBlocks * 2 * C * sizeof(double)));
     hipStream_t st = da_stream(stream);
-    int rc = launch_partial<2, T>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm);
+    if (pre && pre_n > 0) {
+        // the two sums arrive from the kernel that produced dy (sum dz, sum dz (x - mean) per workgroup): no reduction pass over (dy, x)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, pre, pre_n, M, C, dgamma, dbeta, cm, rstd);
+    } else {
+        int rc = launch_partial<2, T>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm, (const float*)nullptr);
+    }
     DA_LAUNCH_CHECK();
     if (C % 4 == 0) {
         const long long nvec = M * C / 4;
@@ -459,6 +466,15 @@ extern "C" int da_bn_act_bwd_dbias(const float* dy, const float* x, const float*
                                    float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
                                    void* ws, size_t ws_bytes, void* stream) {
     return bn_act_bwd_impl<float>(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, dxsum, M, C, ws, ws_bytes, stream);
+}
+// da_bn_act_bwd_dbias with the reduction pass replaced by sums the producer of dy accumulated in its epilogue: pre[pre_n][2][C] doubles =
+// (sum dz, sum dz (x - mean)) with dz = dy act'(x scale + shift) (da_head_dice_bwd_bst; autograd of unets.py:31-32)
+extern "C" int da_bn_act_bwd_dbias_pre(const float* dy, const float* x, const float* mean, const float* rstd,
+                                       const float* scale, const float* shift, float act_slope, int train,
+                                       float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                                       const double* pre, int pre_n, void* ws, size_t ws_bytes, void* stream) {
+    if (!pre || pre_n <= 0 || !train) return DA_ERR_BADARG;
+    return bn_act_bwd_impl<float>(dy, x, mean, rstd, scale, shift, act_slope, train, dx, dgamma, dbeta, dxsum, M, C, ws, ws_bytes, stream, pre, pre_n);
 }
 extern "C" int da_bn_act_bwd_dbias_bf16(const void* dy, const void* x, const float* mean, const float* rstd,
                                         const float* scale, const float* shift, float act_slope, int train,

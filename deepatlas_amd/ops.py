@@ -997,6 +997,17 @@ def _bn_forward(a, gamma, beta, running_mean, running_var, training, momentum, e
     return out, stats, g, (M, C, float(slope), train, wsb)
 
 
+# BatchNorm-backward sums that the PRODUCER of a gradient tensor accumulated in its own epilogue (da_head_dice_bwd_bst): gradient data pointer ->
+# (the gradient tensor itself -- kept alive so that the pointer cannot be reused while the entry exists --, partials, count, M, C).  The consumer
+# (_bn_backward of the layer whose output that gradient belongs to) pops its entry; FlatAdam.zero_grad / step drop whatever was never consumed.
+_bwd_stats = {}
+FUSE_BN_BWD_STATS = os.environ.get('DA_NO_BN_BWD_FUSE') != '1'
+
+
+def drop_bwd_stats(*_):
+    _bwd_stats.clear()
+
+
 def _bn_backward(go, y, stats, cfg, want_dbias, st):
     """BN+activation backward; returns (dy, dgamma, dbeta, dbias_of_producer or None) -- the producer's bias gradient is the
     column sum of dy and is accumulated inside the apply pass."""
@@ -1004,6 +1015,11 @@ def _bn_backward(go, y, stats, cfg, want_dbias, st):
     dy = torch.empty_like(y)
     dgb = _empty((3, C), y)                   # rows: producer bias, gamma, beta -- the order the parameters have in a block
     wp, wn = _ws(wsb, y)
+    pre = _bwd_stats.pop(go.data_ptr(), None) if _bwd_stats else None
+    if pre is not None and train and pre[3] == M and pre[4] == C and go.dtype == torch.float32 and y.dtype == torch.float32 and go.is_contiguous():
+        call('da_bn_act_bwd_dbias_pre', ptr(go), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             slope, 1, ptr(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, ptr(pre[1]), pre[2], wp, wn, st)
+        return dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None)
     call_act('da_bn_act_bwd_dbias', A(go), A(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              slope, 1 if train else 0, O(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, wp, wn, st)
     return dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None)
@@ -1488,8 +1504,20 @@ class HeadDiceFn(Function):
         dw_io = torch.empty_like(w_io)
         db = _empty((C,), a) if has_bias else None
         wp, wn = _ws(wsb, a)
-        call_act('da_head_dice_bwd', A(a), ptr(ps), ptr(pt), float(sl), ptr(w_io), ptr(b), ptr(lab), lb, ptr(coef), ptr(gl),
-                 O(dx), ptr(dw_io), ptr(db), N, V, Cin, C, wp, wn, st)
+        if (FUSE_BN_BWD_STATS and ps is not None and Cin == 16 and a.dtype == torch.float32 and ps.data_ptr() - 8 * Cin == pt.data_ptr() - 12 * Cin
+                and ps.untyped_storage().data_ptr() <= ps.data_ptr() - 8 * Cin):
+            # x is the raw output of a conv + BatchNorm block whose statistics are the rows (mean, rstd, scale, shift) of one [4][C] buffer
+            # (_bn_forward): that block's BatchNorm-backward sums are accumulated here, where x and its gradient are in registers anyway
+            import ctypes
+            bst = torch.empty((1024, 2, Cin), dtype=torch.float64, device=a.device)
+            nb = ctypes.c_int(0)
+            call('da_head_dice_bwd_bst', ptr(a), ptr(ps), ptr(pt), float(sl), ctypes.c_void_p(ps.data_ptr() - 8 * Cin), ptr(w_io), ptr(b), ptr(lab), lb,
+                 ptr(coef), ptr(gl), ptr(dx), ptr(dw_io), ptr(db), N, V, Cin, C, ptr(bst), 1024, ctypes.byref(nb), wp, wn, st)
+            if nb.value > 0:
+                _bwd_stats[dx.data_ptr()] = (dx, bst, nb.value, N * V, Cin)
+        else:
+            call_act('da_head_dice_bwd', A(a), ptr(ps), ptr(pt), float(sl), ptr(w_io), ptr(b), ptr(lab), lb, ptr(coef), ptr(gl),
+                     O(dx), ptr(dw_io), ptr(db), N, V, Cin, C, wp, wn, st)
         dw = grad_for_autograd(dw_io.view(1, Cin, C), 'oik', ctx.wparam)
         return (ncdhw(dx), dw, db, None, None, None, None) + (None,) * ctx.n_extra
 

@@ -88,6 +88,7 @@ class FlatAdam(torch.optim.Optimizer):
         """Gradients live in the flat bucket: zero it in one memset and keep the views attached (`set_to_none` would detach them
         from the bucket the all-reduce and the Adam kernel work on, so it is ignored)."""
         ops.join_side_stream()                      # asynchronous weight gradients of the previous step have landed
+        ops.drop_bwd_stats()                        # (producer-side BatchNorm-backward sums nobody consumed: release the gradient tensors they pin)
         self.flat_g.zero_()
         for p, off, k in self._slices:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
@@ -127,6 +128,7 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
         ops.flush_batches_tracked()
+        ops.drop_bwd_stats()
         self._gather_stray_grads()
         g = self.param_groups[0]
         for p, off, k in self._slices:

@@ -209,6 +209,13 @@ int da_bn_act_bwd_dbias(const float* dy, const float* x, const float* mean, cons
                         const float* scale, const float* shift, float act_slope, int train,
                         float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
                         void* ws, size_t ws_bytes, void* stream);
+/* da_bn_act_bwd_dbias without its reduction pass over (dy, x): the two sums come from the kernel that PRODUCED dy, which accumulated them in its
+ * epilogue -- pre[pre_n][2][C] doubles = (sum dz, sum dz (x - mean)) per workgroup, dz = dy act'(x scale + shift) (da_head_dice_bwd_bst).
+ * train only.  autograd of nn.BatchNorm3d + nn.LeakyReLU (unets.py:31-32). */
+int da_bn_act_bwd_dbias_pre(const float* dy, const float* x, const float* mean, const float* rstd,
+                            const float* scale, const float* shift, float act_slope, int train,
+                            float* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C,
+                            const double* pre, int pre_n, void* ws, size_t ws_bytes, void* stream);
 /* Backward of a bare activation from its OUTPUT y (ReLU / LeakyReLU): dx = dy * (y > 0 ? 1 : slope). */
 int da_act_bwd(const float* dy, const float* y, float act_slope, float* dx, long long numel, void* stream);
 /* Per-channel column sum of x[M][C] -> out[C] (bias gradients). */
@@ -333,6 +340,13 @@ int da_head_dice_bwd(const float* x, const float* pro_scale, const float* pro_sh
                      const float* w_io, const float* bias, const void* labels, int label_bytes,
                      const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
                      int N, long long V, int Cin, int C, void* ws, size_t ws_bytes, void* stream);
+/* da_head_dice_bwd that also accumulates the BatchNorm-backward sums of the layer that produced x (x = its raw conv output; pro_scale / pro_shift /
+ * pro_mean = rows of its batch statistics): bst[*bst_n][2][Cin] doubles for da_bn_act_bwd_dbias_pre.  *bst_n = 0: shape without that epilogue
+ * (Cin != 16, bst_cap < 1024) -- run da_bn_act_bwd_dbias as usual. */
+int da_head_dice_bwd_bst(const float* x, const float* pro_scale, const float* pro_shift, float pro_slope, const float* pro_mean,
+                         const float* w_io, const float* bias, const void* labels, int label_bytes,
+                         const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
+                         int N, long long V, int Cin, int C, double* bst, int bst_cap, int* bst_n, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- NCC loss (row a12; lib/loss.py:493-501) -------------------------------------------------- */
 size_t da_ncc_ws_bytes(int N, long long V);
