@@ -33,6 +33,10 @@ SIGNATURES = {
     'da_w_tio_to_iok_acc': (I, [P, P, I, I, I, P]),
     'da_w_tio_to_iok_flip_acc': (I, [P, P, I, I, I, P]),
     'da_conv3d_k3_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
+    'da_conv3d_k3_pack_bytes': (SZ, [I, I, I, I, I, I]),
+    'da_conv3d_k3_prepack': (I, [P, I, I, I, I, I, I, I, I, P, SZ, P, SZ, P, P]),
+    'da_conv3d_k3_use_prepacked': (None, [P, P, SZ, P, SZ]),
+    'da_conv3d_k3_prepack_many': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'da_conv3d_k3_fwd': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     'da_conv3d_k3_fwd_bnstats': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),
     'da_conv3d_k3_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, I, I, P, SZ, P]),

@@ -1263,8 +1263,12 @@ __global__ void pack_fwd_weights_kernel(const float* __restrict__ w, float* __re
 // power-of-two scale (largest |w| of the chunk in [2^14, 2^15); the exponent goes to wexp[chunk] for the kernel's accumulator bookkeeping).
 // Grid (chunks, PY): every workgroup of a chunk finds the chunk's maximum (27 x 8 x Cout values, L2-resident) and packs its share of the
 // (step, N-tile, lane) units with one 16-byte store per plane.  Also writes the tile table of the launch that follows (pack_fwd_weights_kernel).
-__global__ void __launch_bounds__(256) pack_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout,
-                                                                 int NTpad, int flipped, int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz, int cout0, int CoutW) {
+struct PackJob { const float* w; unsigned short* wp; int* wexp; int4* tiles; int Cin, Cout, NTpad, flipped, ntiles, ntx, nty, ntz, cout0, CoutW; };
+constexpr int kPackJobsMax = 48;
+struct PackJobs { PackJob j[kPackJobsMax]; };
+
+__device__ __forceinline__ void pack_split_weights_body(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout,
+                                                        int NTpad, int flipped, int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz, int cout0, int CoutW) {
     __shared__ float wmax[4];
     const int nb = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
     for (int pos = bid * 256 + threadIdx.x; pos < ntiles; pos += nb * 256) {
@@ -1315,6 +1319,16 @@ __global__ void __launch_bounds__(256) pack_split_weights_kernel(const float* __
         uint4* o = reinterpret_cast<uint4*>(wp + ((size_t)((ch * 7 + st) * NTpad + nt) * 2) * 512) + lane;
         o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
+}
+__global__ void __launch_bounds__(256) pack_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int* __restrict__ wexp, int Cin, int Cout,
+                                                                 int NTpad, int flipped, int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz, int cout0, int CoutW) {
+    pack_split_weights_body(w, wp, wexp, Cin, Cout, NTpad, flipped, tiles, ntiles, ntx, nty, ntz, cout0, CoutW);
+}
+// the same for many layers at once (blockIdx.z = job; grid.x = the largest chunk count): the kept packs of a whole network after an optimiser step
+__global__ void __launch_bounds__(256) pack_split_weights_many_kernel(const PackJobs jobs) {
+    const PackJob& j = jobs.j[blockIdx.z];
+    if ((int)blockIdx.x >= j.Cin / 8) return;
+    pack_split_weights_body(j.w, j.wp, j.wexp, j.Cin, j.Cout, j.NTpad, j.flipped, j.tiles, j.ntiles, j.ntx, j.nty, j.ntz, j.cout0, j.CoutW);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2549,6 +2563,17 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
                                void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, double* stats_partial, int* stats_nparts, const DaPro* pro, const DaS2dFuse* s2f,
                                int cout0, int CoutW, bool hb);
 
+// ---- packed operands kept across calls (split mode) -----------------------------------------------------------------------------------------
+// A convolution call packs its weights (fragment order, two fp16 planes, per-chunk exponents) and writes its tile table before the matrix kernel can
+// start: a 10-us launch in the dependent chain of every layer, forward and data gradient, every step, for data that only changes when the optimiser
+// steps.  The caller may keep the packed operand itself: da_conv3d_k3_prepack fills a caller-owned buffer (the host side does so for every layer right
+// after the optimiser step, on the side stream), da_conv3d_k3_use_prepacked hands it to the NEXT convolution call of this thread on the same weights.
+// mode 1: use, 2: fill (the matrix kernel is not launched).  Up to two regions: the 48 <- 16 data gradient runs two launches with their own packs.
+struct PrepackState { int mode; const float* w; char* buf[2]; size_t bytes[2]; int next, used; };
+static thread_local PrepackState g_pp = {0, nullptr, {nullptr, nullptr}, {0, 0}, 0, 0};
+static thread_local PackJobs* g_pp_collect = nullptr;       // fill mode: record the pack launches here instead of issuing them (da_conv3d_k3_prepack_many)
+static thread_local int g_pp_ncollect = 0;
+
 int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const float* w_tio, int w_is_flipped_tr,
                       const float* bias, float* out1, int Cs1, float* out2, int Cs2,
                       int N, int D, int H, int W, int Cout, int stride, float slope,
@@ -2557,6 +2582,8 @@ int da_conv3_mfma_fwd(const float* in1, int C1, const float* in2, int C2, const 
     // Split mode, data gradient of a concat layer whose outputs are 32 + 16 channels (the 48 -> 16 decoder convolution: three N-tiles).  One
     // launch with one N-tile per workgroup stages dY three times; two launches -- two N-tiles sharing every dY fragment for the first output
     // tensor, one N-tile (paired staging) for the second -- stage it twice and write each output tensor from its own launch.
+    struct PpReset { ~PpReset() { if (g_pp.mode == 1) g_pp.mode = 0; } } pp_reset;      // a handed-over pack serves exactly one call
+    if (g_pp.mode && g_pp.w != w_tio) g_pp.mode = 0;                                      // (it belongs to other weights: a call in between went elsewhere)
     static int no2 = -1; if (no2 < 0) { const char* e = getenv("DA_NO_DGRAD_SPLIT_LAUNCH"); no2 = (e && atoi(e)) ? 1 : 0; }
     if (!no2 && da_matrix_mode() == 2 && w_is_flipped_tr && s2d_cin == 0 && !stats_partial && !pro && Cs2 > 0 && Cs1 == 32 && Cs2 == 16 && Cout == 48 &&
         pick_ck(C1, C2) != 0) {
@@ -2609,11 +2636,18 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     const int pkmode = split ? 3 : bf ? (s2d_cin > 0 ? 1 : 2) : 0;       // 0 fp32 | 1 bf16, one tap per K-step (sparse taps) | 2 bf16, K = 32 per step | 3 split: three bf16 planes, K = 32
     const int NSTEPS = pkmode >= 2 ? (CK == 16 ? 14 : 7) : (27 * CK + 15) / 16;
     const size_t pk = packed_bytes(Cin, Cout, CK);
-    if (ws_bytes < pk + tile_table_bytes(N, D, H, W)) return DA_ERR_WS_SMALL;
-    float* wp = (float*)ws;
-    int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + pk);
+    char* opbase = reinterpret_cast<char*>(ws);                 // [packed weights | exponents / tile counters][tile table]: the workspace, or the caller's kept copy
+    int pp_mode = 0;
+    if (g_pp.mode && split) {
+        const int idx = g_pp.next++;
+        if (idx < 2 && g_pp.buf[idx] && g_pp.bytes[idx] >= pk + tile_table_bytes(N, D, H, W)) { opbase = g_pp.buf[idx]; pp_mode = g_pp.mode; }
+        else if (g_pp.mode == 2) return DA_ERR_WS_SMALL;
+    } else if (g_pp.mode == 2) return DA_ERR_UNSUPPORTED;       // (nothing to keep outside the split mode)
+    if (!pp_mode && ws_bytes < pk + tile_table_bytes(N, D, H, W)) return DA_ERR_WS_SMALL;
+    float* wp = reinterpret_cast<float*>(opbase);
+    int4* tiles = reinterpret_cast<int4*>(opbase + pk);
     const long long total = (long long)(Cin / CK) * NSTEPS * NTpad * 256;
-    int* dyn_ctr = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pk - da_align(kDynCtrInts * sizeof(int)));
+    int* dyn_ctr = reinterpret_cast<int*>(opbase + pk - da_align(kDynCtrInts * sizeof(int)));
     static int dyn_env = -1; if (dyn_env < 0) { const char* e = getenv("DA_DYN_TILES"); dyn_env = (e && atoi(e)) ? 1 : 0; }
     const bool dyn = dyn_env && !bf && !split && !pro && s2d_cin == 0 && !stats_partial && gy * 8 <= kDynCtrInts;
     FwdP p;
@@ -2621,8 +2655,13 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     p.ntiles = N * p.ntz * p.nty * p.ntx;
     if (split) {
         if (Cin / 8 > kDynCtrInts) return DA_ERR_UNSUPPORTED;
+        if (pp_mode == 2 && g_pp_collect) {
+            if (g_pp_ncollect >= kPackJobsMax) return DA_ERR_WS_SMALL;
+            g_pp_collect->j[g_pp_ncollect++] = PackJob{w_tio, reinterpret_cast<unsigned short*>(wp), dyn_ctr, tiles, Cin, Cout, NTpad, w_is_flipped_tr, p.ntiles, p.ntx, p.nty, p.ntz, cout0, CoutW};
+        } else if (pp_mode != 1)
         hipLaunchKernelGGL(pack_split_weights_kernel, dim3(Cin / 8, 8), dim3(256), 0, st, w_tio, reinterpret_cast<unsigned short*>(wp), dyn_ctr, Cin, Cout, NTpad, w_is_flipped_tr,
                            tiles, p.ntiles, p.ntx, p.nty, p.ntz, cout0, CoutW);
+        if (pp_mode == 2) { DA_LAUNCH_CHECK(); g_pp.used++; return 0; }
     } else
     hipLaunchKernelGGL(pack_fwd_weights_kernel, dim3(da_grid(total > p.ntiles ? total : p.ntiles, 256, 1024)), dim3(256), 0, st, w_tio, wp, Cin, Cout, CK, NSTEPS, NTpad, w_is_flipped_tr, total, pkmode,
                        dyn ? dyn_ctr : nullptr, gy * 8, tiles, p.ntiles, p.ntx, p.nty, p.ntz, cout0, CoutW);
@@ -2972,7 +3011,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     { static int abl = -1; if (abl < 0) { const char* e = getenv("DA_WG_ABLATE"); abl = e ? atoi(e) : 0; } p.ablate = abl; }
     if (split || rows1) {
         int4* tiles = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + q.partial_bytes);
-        if (q.w16 >= 2) hipLaunchKernelGGL(wgrad_ztiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz);
+        if (q.w16 >= 2) tiles = nullptr;           // (the ring form derives its tiles from the position: no table, no launch)
         else hipLaunchKernelGGL(wgrad_tiles_kernel, dim3(da_grid(q.ntiles, 256, 256)), dim3(256), 0, st, tiles, q.ntiles, q.ntx, q.nty, q.ntz, DA_WG_TZ);
         DA_LAUNCH_CHECK();
         p.tiles = tiles;
@@ -3021,4 +3060,68 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     if (rc) return rc;
     { const int rc2 = da_reduce_partials(p.partial, q.nslabs, p.O, dw_tio, st); if (rc2) return rc2; }
     return 0;
+}
+
+// ---- C ABI of the kept packs (see PrepackState) --------------------------------------------------------------------------------------------
+extern "C" size_t da_conv3d_k3_pack_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    if (Cin % 8 != 0 && Cout % 8 != 0) return 0;
+    size_t a = Cin % 8 == 0 ? packed_bytes(Cin, Cout, 8) : 0;
+    if (Cout % 8 == 0) { const size_t b = packed_bytes(Cout, Cin, 8); if (b > a) a = b; }      // (the data gradient: channels exchanged)
+    return a + tile_table_bytes(N, D, H, W);
+}
+// Fill caller-owned buffer(s) with the packed operand of the stride-1 3x3x3 convolution C1 + C2 -> Cout on an N x D x H x W grid: the forward's
+// (dgrad = 0) or the data gradient's (dgrad = 1; two regions when that call runs as two launches).  *used = regions filled; 0 = this shape / matrix
+// mode does not run the split matrix-core kernels, keep nothing.  Only enqueues (one small kernel per region) on `stream`.
+extern "C" int da_conv3d_k3_prepack(const float* w_tio, int C1, int C2, int Cout, int dgrad, int N, int D, int H, int W,
+                                    void* b0, size_t n0, void* b1, size_t n1, int* used, void* stream) {
+    if (used) *used = 0;
+    if (!w_tio || !b0 || C1 <= 0 || C2 < 0 || Cout <= 0 || N <= 0) return DA_ERR_BADARG;
+    if (da_matrix_mode() != 2) return 0;
+    const int Cin = C1 + C2;
+    if (!dgrad ? !da_conv3_mfma_fwd_supported(C1, C2, Cout, 1) : !da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) return 0;
+    g_pp = PrepackState{2, w_tio, {(char*)b0, (char*)b1}, {n0, b1 ? n1 : 0}, 0, 0};
+    float* dummy = const_cast<float*>(w_tio);                   // (never dereferenced: in fill mode the call returns before its matrix kernel)
+    const int rc = !dgrad ? da_conv3_mfma_fwd(dummy, C1, C2 > 0 ? dummy : nullptr, C2, w_tio, 0, nullptr, dummy, Cout, nullptr, 0, N, D, H, W, Cout, 1, -1.f,
+                                              b0, 0, (hipStream_t)stream, 0, nullptr, nullptr, nullptr, nullptr, 0)
+                          : da_conv3_mfma_fwd(dummy, Cout, nullptr, 0, w_tio, 1, nullptr, dummy, C1, C2 > 0 ? dummy : nullptr, C2, N, D, H, W, Cin, 1, -1.f,
+                                              b0, 0, (hipStream_t)stream, 0, nullptr, nullptr, nullptr, nullptr, 0);
+    const int n = g_pp.used;
+    g_pp.mode = 0;
+    if (rc == DA_ERR_UNSUPPORTED) return 0;
+    if (rc) return rc;
+    if (used) *used = n;
+    return 0;
+}
+// The next stride-1 3x3x3 forward / data-gradient call of this thread on `w_tio` reads its packed operand(s) from here instead of packing (one call only;
+// a call on other weights, or one that takes another kernel family, drops the hand-over).
+extern "C" void da_conv3d_k3_use_prepacked(const float* w_tio, const void* b0, size_t n0, const void* b1, size_t n1) {
+    g_pp = PrepackState{(w_tio && b0) ? 1 : 0, w_tio, {(char*)const_cast<void*>(b0), (char*)const_cast<void*>(b1)}, {n0, b1 ? n1 : 0}, 0, 0};
+}
+
+// da_conv3d_k3_prepack for `n` layers with as few launches as the kernel-argument size allows (48 regions per launch): what the host side runs after an
+// optimiser step.  Arrays of length n; used[i] as in da_conv3d_k3_prepack.
+extern "C" int da_conv3d_k3_prepack_many(int n, const float* const* w_tio, const int* C1, const int* C2, const int* Cout, const int* dgrad,
+                                         const int* N, const int* D, const int* H, const int* W,
+                                         void* const* b0, const size_t* n0, void* const* b1, const size_t* n1, int* used, void* stream) {
+    if (n <= 0) return 0;
+    if (!w_tio || !C1 || !C2 || !Cout || !dgrad || !N || !D || !H || !W || !b0 || !n0 || !b1 || !n1 || !used) return DA_ERR_BADARG;
+    static thread_local PackJobs jobs;
+    auto flush = [&]() -> int {
+        if (g_pp_ncollect == 0) return 0;
+        int gx = 1;
+        for (int k = 0; k < g_pp_ncollect; ++k) if (jobs.j[k].Cin / 8 > gx) gx = jobs.j[k].Cin / 8;
+        hipLaunchKernelGGL(pack_split_weights_many_kernel, dim3(gx, 8, g_pp_ncollect), dim3(256), 0, (hipStream_t)stream, jobs);
+        g_pp_ncollect = 0;
+        DA_LAUNCH_CHECK();
+        return 0;
+    };
+    g_pp_collect = &jobs; g_pp_ncollect = 0;
+    int rc = 0;
+    for (int i = 0; i < n && !rc; ++i) {
+        if (g_pp_ncollect + 2 > kPackJobsMax) rc = flush();
+        if (!rc) rc = da_conv3d_k3_prepack(w_tio[i], C1[i], C2[i], Cout[i], dgrad[i], N[i], D[i], H[i], W[i], b0[i], n0[i], b1[i], n1[i], &used[i], stream);
+    }
+    if (!rc) rc = flush();
+    g_pp_collect = nullptr; g_pp_ncollect = 0;
+    return rc;
 }

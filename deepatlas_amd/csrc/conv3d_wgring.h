@@ -207,16 +207,15 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
     };
 
     const int lo = slab * p.tiles_per_slab, hi = min(lo + p.tiles_per_slab, p.ntiles);
-    auto tile_at = [&](int pos) -> int4 { pos = pos < p.ntiles ? pos : p.ntiles - 1; return p.tiles[__builtin_amdgcn_readfirstlane(pos)]; };
     int pos = lo;
     int par = 0;
     int hint = kSplitEmax;                                     // upper bound for the next run's ring exponent: the ideal exponent of the slab that ended the previous run
 #pragma unroll 1
     while (pos < hi) {
         // ---- start of a run at tile `pos`.  Prime: its lower slab (planes z0 - 1, z0) alone; the ring's scale is that slab's ideal one, capped by `hint`
-        const int4 tv = tile_at(pos);
-        const int n = __builtin_amdgcn_readfirstlane(tv.x), zc = __builtin_amdgcn_readfirstlane(tv.y), y0 = __builtin_amdgcn_readfirstlane(tv.z), x0 = __builtin_amdgcn_readfirstlane(tv.w);
-        int4 tn = tile_at(pos + 1);
+        // position -> tile, z fastest (a workgroup's contiguous range walks whole columns): three scalar divisions per RUN, none per tile, no tile table
+        const int tz0 = pos % p.ntz, col = pos / p.ntz, tx0 = col % p.ntx, rr = col / p.ntx;
+        const int n = rr / p.nty, zc = 2 * tz0, y0 = (rr % p.nty) * TY, x0 = tx0 * TX;
         issue_x(n, zc - 1, y0, x0);
         pro_apply();
         {
@@ -250,7 +249,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
         par ^= 1;
         int L = 0, U = 1, yb = 0, t = pos;
         // the next tile of the column, if it is ours: its new slab (planes z + 3, z + 4 of the current tile) and its dY
-        bool have_next = pos + 1 < hi && __builtin_amdgcn_readfirstlane(tn.y) != 0;
+        bool have_next = pos + 1 < hi && tz0 + 1 < p.ntz;
         if (have_next) {
             issue_x(n, zc + 3, y0, x0);
             issue_y(n, zc + 2, y0, x0);
@@ -274,8 +273,7 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
                     write_x(2 * N, da_pow2(ea));
                     write_y(yb ^ 1, da_pow2(Enext - ea));
                     e_up = e_new;
-                    tn = tile_at(t + 2);
-                    have_next2 = t + 2 < hi && __builtin_amdgcn_readfirstlane(tn.y) != 0;
+                    have_next2 = t + 2 < hi && tz0 + (t + 2 - pos) < p.ntz;
                     if (have_next2 && !(p.ablate & 1)) {
                         const int z2 = zc + 2 * (t - pos);                       // z0 of tile t
                         issue_x(n, z2 + 5, y0, x0);
@@ -397,11 +395,3 @@ __global__ void __launch_bounds__(512, 1) conv3_split_wgrad16r_kernel(WgP p) {
     (void)nsl;
 }
 
-// tile table of the ring kernel: z fastest, so that a workgroup's contiguous range of positions walks whole columns
-__global__ void wgrad_ztiles_kernel(int4* __restrict__ tiles, int ntiles, int ntx, int nty, int ntz) {
-    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < ntiles; pos += gridDim.x * blockDim.x) {
-        const int tz = pos % ntz, col = pos / ntz;
-        const int tx = col % ntx, r = col / ntx;
-        tiles[pos] = make_int4(r / nty, tz * 2, (r % nty) * TY, tx * TX);
-    }
-}

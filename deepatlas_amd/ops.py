@@ -186,8 +186,14 @@ def set_matrix_precision(mode):
     if mode not in MATRIX_MODES:
         raise ValueError("matrix precision must be one of %r, got %r" % (MATRIX_MODES, mode))
     from ._native import lib
+    global _matrix_mode
     prev = lib().da_set_matrix_mode(MATRIX_MODES.index(mode))
+    _matrix_mode = mode
     return MATRIX_MODES[prev]
+
+
+# what the library was last told (it starts in 'fp32' unless DA_MATRIX_MODE says otherwise); only the kept-pack logic below reads it
+_matrix_mode = {'1': 'bf16', '2': 'fp32_split'}.get(os.environ.get('DA_MATRIX_MODE', '0'), 'fp32')
 
 
 # Every kernel of the package reduces in a fixed order (per-block partials + a second launch) except ONE: the scatter of the trilinear
@@ -370,15 +376,141 @@ _weights_epoch = 0
 _flat_param_buckets = []          # weak references to every FlatAdam parameter bucket
 
 
-def bump_weights_epoch():
-    global _weights_epoch
+_other_bumps = 0                  # bumps that are not one optimiser's step (parameters moved into a bucket, broadcast, graph replay): everything is stale
+_bucket_epoch = {}                # storage pointer of a FlatAdam parameter bucket -> number of its optimiser's steps
+
+
+def bump_weights_epoch(flat_p=None):
+    """Weights changed behind torch's version counters.  flat_p: only the parameters of that FlatAdam bucket (its step); None: anything."""
+    global _weights_epoch, _other_bumps
     _weights_epoch += 1
+    if flat_p is None:
+        _other_bumps += 1
+    else:
+        k = flat_p.untyped_storage().data_ptr()
+        _bucket_epoch[k] = _bucket_epoch.get(k, 0) + 1
 
 
 def register_flat_params(flat_p):
     import weakref
     _flat_param_buckets[:] = [r for r in _flat_param_buckets if r() is not None]
     _flat_param_buckets.append(weakref.ref(flat_p))
+
+
+# ------------------------------------------------------------------------------------------------
+# packed convolution operands, kept across calls (include/deepatlas_hip.h: da_conv3d_k3_prepack / _use_prepacked)
+# ------------------------------------------------------------------------------------------------
+# In the split matrix mode every stride-1 3x3x3 forward / data-gradient call used to launch a 10-us pack kernel (weights into fragment order + tile
+# table) in front of its matrix kernel: 27 launches in the dependent chain of a seg step.  The packs only change when the weights do, so they are
+# kept per (weights, direction, shape): filled in-chain the first time, and from then on re-filled for ALL layers of an optimiser right after its
+# step -- on the side stream, beside the start of the next forward pass -- with one event per entry that the consuming call waits for.
+# An entry is valid while its stamp (weights epoch, version counters: the one of weight_tio) matches and the weights' base tensor is alive; it holds
+# a weak reference to that base only.  Not inside a HIP-graph capture.  DA_NO_PACK_CACHE=1 switches it off.
+PACK_CACHE = os.environ.get('DA_NO_PACK_CACHE') != '1'
+_pack_entries = {}
+
+
+class _Pack(object):
+    __slots__ = ('bufs', 'stamp', 'event', 'base', 'view', 'args', 'disabled', 'storage', 'pversion')
+
+
+def _pack_stamp(e):
+    # pversion: the version counter of the PARAMETER the weights belong to (a Parameter whose .data is a view of the flat bucket keeps its own
+    # counter), as seen at the last use; FlatAdam's kernel moves neither counter, hence the epochs -- the one of the entry's OWN bucket, so that the
+    # other network's optimiser step (joint training) leaves it valid
+    b = e.base()
+    return (_other_bumps, _bucket_epoch.get(e.storage, 0), e.pversion, b._version if b is not None else -1)
+
+
+def _pack_fill(e, w_tio, st):
+    import ctypes
+    C1, C2, Cout, dgrad, N, D, H, W = e.args
+    used = ctypes.c_int(0)
+    b1 = e.bufs[1]
+    call('da_conv3d_k3_prepack', ptr(w_tio), C1, C2, Cout, dgrad, N, D, H, W, ptr(e.bufs[0]), e.bufs[0].numel(),
+         ptr(b1), b1.numel() if b1 is not None else 0, ctypes.byref(used), st)
+    return used.value
+
+
+def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
+    """Right before a stride-1 da_conv3d_k3_{fwd,fwd_bnstats,fwd_pro,dgrad} call: hand it the kept packed operand of these weights (filling it now
+    if it is new or stale).  No-op outside the split matrix mode, for weights that are not views of a live base tensor, and inside graph capture."""
+    if not PACK_CACHE or _matrix_mode != 'fp32_split' or w_tio.dtype != torch.float32 or torch.cuda.is_current_stream_capturing():
+        return
+    key = (w_tio.data_ptr(), dgrad, C1, C2, Cout, N, D, H, W)
+    e = _pack_entries.get(key)
+    sp = w_tio.untyped_storage().data_ptr()
+    if e is not None and (e.base() is None or e.storage != sp):
+        e = None                                        # (the address was reused by other weights)
+    if e is None:
+        # only weights that live in a registered FlatAdam parameter bucket (tap-major views of it, weight_tio): the bucket is the live base object
+        base = next((r for r in _flat_param_buckets if r() is not None and r().untyped_storage().data_ptr() == sp), None)
+        if base is None:
+            return
+        nbytes = nat.lib().da_conv3d_k3_pack_bytes(N, D, H, W, C1 + C2, Cout)
+        e = _Pack()
+        e.args, e.event, e.stamp, e.disabled = (C1, C2, Cout, dgrad, N, D, H, W), None, None, nbytes == 0
+        e.base = base
+        e.storage = sp
+        e.view = (tuple(w_tio.shape), tuple(w_tio.stride()), w_tio.storage_offset())
+        e.bufs = [None, None]
+        if not e.disabled:
+            e.bufs[0] = torch.empty((nbytes,), dtype=torch.uint8, device=w_tio.device)
+            if dgrad and C2 > 0:
+                e.bufs[1] = torch.empty((nbytes,), dtype=torch.uint8, device=w_tio.device)
+        _pack_entries[key] = e
+    if e.disabled:
+        return
+    e.pversion = w_tio._version
+    stamp = _pack_stamp(e)
+    if e.stamp != stamp:
+        if _pack_fill(e, w_tio, stream()) == 0:
+            e.disabled = True
+            e.bufs = [None, None]
+            return
+        e.stamp, e.event = stamp, None
+    elif e.event is not None:
+        torch.cuda.current_stream().wait_event(e.event)
+    b1 = e.bufs[1]
+    nat.lib().da_conv3d_k3_use_prepacked(ptr(w_tio), ptr(e.bufs[0]), e.bufs[0].numel(), ptr(b1), b1.numel() if b1 is not None else 0)
+
+
+def repack_after_step(flat_p):
+    """FlatAdam.step() calls this behind its update kernel: every kept pack of weights that live in `flat_p` is re-filled on the side stream."""
+    if not PACK_CACHE or not _pack_entries or _matrix_mode != 'fp32_split' or torch.cuda.is_current_stream_capturing():
+        return
+    sp = flat_p.untyped_storage().data_ptr()
+    mine = [e for e in _pack_entries.values() if not e.disabled and e.storage == sp and e.base() is not None]
+    dead = [k for k, e in _pack_entries.items() if e.base() is None]
+    for k in dead:
+        del _pack_entries[k]
+    if not mine:
+        return
+    import ctypes
+    n = len(mine)
+    views = [torch.as_strided(e.base(), e.view[0], e.view[1], e.view[2]) for e in mine]
+    PA, IA, SA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_size_t * n
+    cols = list(zip(*[e.args for e in mine]))                   # C1, C2, Cout, dgrad, N, D, H, W
+    used = IA()
+    side = side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call('da_conv3d_k3_prepack_many', n, PA(*[v.data_ptr() for v in views]), IA(*cols[0]), IA(*cols[1]), IA(*cols[2]), IA(*cols[3]),
+             IA(*cols[4]), IA(*cols[5]), IA(*cols[6]), IA(*cols[7]),
+             PA(*[e.bufs[0].data_ptr() for e in mine]), SA(*[e.bufs[0].numel() for e in mine]),
+             PA(*[(e.bufs[1].data_ptr() if e.bufs[1] is not None else None) for e in mine]), SA(*[(e.bufs[1].numel() if e.bufs[1] is not None else 0) for e in mine]),
+             used, stream())
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for e, v, u in zip(mine, views, used):
+        if u == 0:
+            e.disabled = True
+            continue
+        e.stamp, e.event = _pack_stamp(e), ev
+
+
+def clear_pack_cache():
+    _pack_entries.clear()
 
 
 _TIO_ENTRY = {'oik': 'da_w_oik_to_tio', 'iok': 'da_w_iok_to_tio', 'iok_flip': 'da_w_iok_flip_to_tio'}
@@ -640,6 +772,8 @@ class Conv3dK3Fn(Function):
             out = _empty((N, Do, Ho, Wo, Cout), a1, _act_dtype(Cout))
             wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
             wp, wn = _ws(wsb, a1)
+            if stride == 1:
+                use_pack(w_tio, 0, C1, C2, Cout, N, D, H, W)
             call_act('da_conv3d_k3_fwd', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(out),
                      N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
         ctx.dims = (N, D, H, W, C1, C2, Cout, stride, float(act_slope), wsb)
@@ -662,6 +796,8 @@ class Conv3dK3Fn(Function):
             if up2:
                 call_act('da_upconv3d_k3_dgrad', A(g_), ptr(w_tio), O(dx1_), C1, O(dx2_), C2, N, D, H, W, Cout, wp_, wn_, st_)
             else:
+                if stride == 1:
+                    use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W)
                 call_act('da_conv3d_k3_dgrad', A(g_), ptr(w_tio), O(dx1_), C1, O(dx2_), C2, N, D, H, W, Cout, stride, wp_, wn_, st_)
 
         def k_wgrad(g_, dw_tio_, db_, wp_, wn_, st_):
@@ -1095,11 +1231,13 @@ class ConvBNActFn(Function):
         if pro1 is not None or pro2 is not None:
             s1, t1, sl1 = _pro_args(pro1)
             s2, t2, sl2 = _pro_args(pro2)
+            use_pack(w_tio, 0, C1, C2, Cout, N, D, H, W)
             done = call_act('da_conv3d_k3_fwd_pro', A(a1), C1, s1, t1, sl1, A(a2), C2, s2, t2, sl2, ptr(w_tio), ptr(b), O(y),
                             N, D, H, W, Cout, -1.0, ptr(pbuf), cap, ctypes.byref(npar), wp, wn, st, may_decline=True)
             if not done:           # shape not taken by the prologue kernels: apply the deferred activation as its own pass
                 a1, a2, pro1, pro2 = _apply_pro(a1, pro1, st), (_apply_pro(a2, pro2, st) if a2 is not None else None), None, None
         if not done:
+            use_pack(w_tio, 0, C1, C2, Cout, N, D, H, W)
             if train_stats:
                 # the MFMA epilogue accumulates the BatchNorm partial sums, so the statistics need no pass over y
                 call_act('da_conv3d_k3_fwd_bnstats', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(y), N, D, H, W, Cout, 1,
@@ -1139,6 +1277,7 @@ class ConvBNActFn(Function):
             dx1 = torch.empty_like(a1)
             dx2 = torch.empty_like(a2) if a2 is not None else None
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
+            use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W)
             call_act('da_conv3d_k3_dgrad', A(dy), ptr(w_tio), O(dx1), C1, O(dx2), C2, N, D, H, W, Cout, 1, wp, wn, st)
         kind_w = 'iok_flip' if ctx.transposed else 'oik'
         wt = WgradTarget(ctx.wparam, kind_w, w_tio) if ctx.needs_input_grad[2] else _NO_WGRAD_TARGET

@@ -136,7 +136,7 @@ class FlatAdam(torch.optim.Optimizer):
                 raise RuntimeError('FlatAdam: a parameter no longer lives in the flat bucket (model.to()/.half() after constructing the '
                                    'optimiser?); build the optimiser after moving the model')
         mask = self._frozen_mask()
-        ops.bump_weights_epoch()                   # cached weight layouts (ops.weight_tio) are stale from here on
+        ops.bump_weights_epoch(self.flat_p)        # cached weight layouts (ops.weight_tio) and kept packs of THIS bucket are stale from here on
         if self.device_step:
             # being captured into a HIP graph (graphs.GraphedStep): step count and hyper-parameters come from device memory; the
             # host-side book-keeping happens per REPLAY in note_replayed_step()
@@ -157,6 +157,7 @@ class FlatAdam(torch.optim.Optimizer):
         for p, _, _ in self._slices:
             if p.requires_grad and p.grad is not None:
                 self.state[p]['step'] += 1
+        ops.repack_after_step(self.flat_p)          # the kept packed operands of these weights, re-filled beside the next forward pass (side stream)
         return loss
 
     def load_state_dict(self, state_dict):

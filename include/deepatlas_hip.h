@@ -348,6 +348,23 @@ int da_head_dice_bwd_bst(const float* x, const float* pro_scale, const float* pr
                          const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
                          int N, long long V, int Cin, int C, double* bst, int bst_cap, int* bst_n, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- packed convolution operands kept across calls (split matrix mode; conv3d_mfma.hip) ----------------------------------------------
+ * A 3x3x3 convolution call first packs its weights for the matrix cores and writes its tile table (a 10-us launch in front of every matrix kernel).  Both
+ * only change when the weights do (torch.optim.Adam.step in the reference's loop, models/segmentation.py:157): the caller may keep them.
+ *   da_conv3d_k3_pack_bytes      bytes of one region for a C1 + C2 = Cin -> Cout layer on an N x D x H x W grid (0: no such kernel for the shape)
+ *   da_conv3d_k3_prepack         fill b0 (and b1: the data gradient of a 32 + 16 concat layer runs two launches) for the forward (dgrad = 0) or the data
+ *                                gradient (dgrad = 1); *used = regions filled, 0 = this shape / matrix mode keeps nothing.  Only enqueues on `stream`.
+ *   da_conv3d_k3_use_prepacked   the NEXT da_conv3d_k3_{fwd,fwd_bnstats,fwd_pro,dgrad} call of this thread on `w_tio` skips its pack launch and reads b0 / b1
+ *                                (one call; dropped when the next call is on other weights).  The caller orders the fill before the use (stream / event). */
+size_t da_conv3d_k3_pack_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int da_conv3d_k3_prepack(const float* w_tio, int C1, int C2, int Cout, int dgrad, int N, int D, int H, int W,
+                         void* b0, size_t n0, void* b1, size_t n1, int* used, void* stream);
+void da_conv3d_k3_use_prepacked(const float* w_tio, const void* b0, size_t n0, const void* b1, size_t n1);
+/* da_conv3d_k3_prepack for n layers (arrays of length n) in ceil(regions / 48) launches: the whole network behind one optimiser step. */
+int da_conv3d_k3_prepack_many(int n, const float* const* w_tio, const int* C1, const int* C2, const int* Cout, const int* dgrad,
+                              const int* N, const int* D, const int* H, const int* W,
+                              void* const* b0, const size_t* n0, void* const* b1, const size_t* n1, int* used, void* stream);
+
 /* ---- NCC loss (row a12; lib/loss.py:493-501) -------------------------------------------------- */
 size_t da_ncc_ws_bytes(int N, long long V);
 int da_ncc_fwd(const float* x, const float* y, int N, long long V, float* loss, double* stats /*[N][8]*/,
