@@ -395,6 +395,9 @@ struct FwdP {
     const int* wexp; // SP: power-of-two exponent of every channel chunk of the packed weights (pack_split_weights_kernel)
     S2dSrc s2out;    // MASKED data gradient: the 8 * cin output channels are scattered to the original-resolution gradient (cin > 0)
     int ablate;      // diagnostic only (env DA_ABLATE): 1 no staging loads (offsets forced out of range), 2 no epilogue, 4 no LDS writes + barriers
+    // STATS == 2 (a data gradient whose output dx is the gradient with respect to act(BN(y))): y = that layer's raw conv output (same shape as out1),
+    // bst_par = its statistics rows [mean | rstd | scale | shift][Cs1]; stats_partial then receives (sum dz, sum dz (y - mean)), dz = dx act'(y scale + shift)
+    const float* bst_y; const float* bst_par; float bst_slope;
 };
 
 // BF: bf16 matrix mode (da_set_matrix_bf16): tensors stay fp32 in HBM, the staged tile and the packed weights are bf16 and one
@@ -412,9 +415,10 @@ struct FwdP {
 // 2^(E - E_previous) (exact), in the epilogue by 2^-E.  E of a later chunk is capped at 40 above the smallest E the tile has seen, so the
 // rescaled sums cannot overflow (a chunk 2^40 below its neighbours does not reach the fp32 sum anyway).  LDS holds the two planes (CK = 8:
 // 2 x 17 KB); fragments of the next two rows are read while the current two rows' 6 MFMAs issue.
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false, int WPE = 2>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: BN partial sums; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores; HB: bf16 activation storage; WPE: waves per SIMD the register allocation must leave room for
+template <int CK, int NREP, bool MASKED = false, int STATS = 0, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false, int WPE = 2>   // MASKED: sparse tap sets (stride-2 via space-to-depth); STATS: 1 BN partial sums of the output, 2 (data gradient) BatchNorm-BACKWARD sums of the layer that produced the input this gradient belongs to; PRO: input prologue; S2F: 1 virtual space-to-depth input, 2 depth-to-space stores; HB: bf16 activation storage; WPE: waves per SIMD the register allocation must leave room for
 __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
     static_assert(!HB || (BF && !SP && !DYN), "bf16 activation storage: bf16 matrix mode only");
+    static_assert(STATS != 2 || (SP && NREP == 1 && !PRO), "BatchNorm-backward sums: the split mode's one-N-tile data gradient");
     static_assert(S2F == 0 || MASKED, "fused space-to-depth addressing belongs to the tap-masked (stride-2) variants");
     // PAIR (split mode, one N-tile): two consecutive 8-channel chunks share every 64-byte sector of their input.  Staged one work item apart
     // the second one misses L2 (the launch turns its L2 over in about one item time): FETCH_SIZE 1.8x the algorithmic bytes.  With PAIR the
@@ -929,6 +933,24 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
             const int x = x0 + i;
             const bool do_ep = last && !(p.ablate & 2);
             const float inv1 = SP ? da_pow2(-(Ecur / 2)) : 1.f, inv2 = SP ? da_pow2(-(Ecur - Ecur / 2)) : 1.f;
+            // STATS == 2: the producer layer's raw output at this lane's voxels and channel quad (issued on every item, out of range -- no traffic --
+            // unless this is a tile's last chunk: no vector-memory instruction in a branch), and its per-channel constants
+            float4 yq[STATS == 2 ? TY : 1], bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsf = bsc, bmu = bsc;
+            if constexpr (STATS == 2) {
+                const int cq = nt0 * 16 + 4 * a4;
+                const bool cokq = do_ep && (cq + 3 < p.Cout) && z < p.D && x < p.W;
+                const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<false>(p.bst_y, n, (long long)p.D * p.H * p.W * p.Cs1);
+#pragma unroll
+                for (int r = 0; r < TY; ++r) {
+                    const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * p.Cs1 + cq) * 4);
+                    yq[r] = da_buf_load4(ry, (cokq && y0 + r < p.H) ? off : 0xFFFFFFFFu);
+                }
+                const __amdgpu_buffer_rsrc_t rp = da_rsrc(p.bst_par, (unsigned)(4 * p.Cs1 * 4));
+                const unsigned po = (do_ep && cq + 3 < p.Cout) ? (unsigned)(cq * 4) : 0xFFFFFFFFu;
+                bmu = da_buf_load4(rp, po);
+                bsc = da_buf_load4(rp, po == 0xFFFFFFFFu ? po : po + (unsigned)(2 * p.Cs1 * 4));
+                bsf = da_buf_load4(rp, po == 0xFFFFFFFFu ? po : po + (unsigned)(3 * p.Cs1 * 4));
+            }
             if (do_ep) {
 #pragma unroll
                 for (int nn = 0; nn < NREP; ++nn) {
@@ -937,7 +959,14 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
                         float t0 = acc[r][nn][0], t1 = acc[r][nn][1], t2 = acc[r][nn][2], t3 = acc[r][nn][3];      // couts co0..co0+3 of voxel (z, y0 + r, x)
                         if constexpr (SP) { t0 = t0 * inv1 * inv2; t1 = t1 * inv1 * inv2; t2 = t2 * inv1 * inv2; t3 = t3 * inv1 * inv2; }      // back to the true unit (two exact factors: |E| may exceed 127)
                         const float v0 = t0 + bvv[nn][0], v1 = t1 + bvv[nn][1], v2 = t2 + bvv[nn][2], v3 = t3 + bvv[nn][3];
-                        if (STATS) {
+                        if constexpr (STATS == 2) {
+                            const float m = (z < p.D && y0 + r < p.H && x < p.W) ? 1.f : 0.f;
+                            const float4 yv = yq[r];
+                            const float d0 = m * v0 * da_act_grad(yv.x * bsc.x + bsf.x, p.bst_slope), d1 = m * v1 * da_act_grad(yv.y * bsc.y + bsf.y, p.bst_slope);
+                            const float d2 = m * v2 * da_act_grad(yv.z * bsc.z + bsf.z, p.bst_slope), d3 = m * v3 * da_act_grad(yv.w * bsc.w + bsf.w, p.bst_slope);
+                            st1[nn][0] += d0; st1[nn][1] += d1; st1[nn][2] += d2; st1[nn][3] += d3;
+                            st2[nn][0] += d0 * (yv.x - bmu.x); st2[nn][1] += d1 * (yv.y - bmu.y); st2[nn][2] += d2 * (yv.z - bmu.z); st2[nn][3] += d3 * (yv.w - bmu.w);
+                        } else if (STATS) {
                             const float m = (z < p.D && y0 + r < p.H && x < p.W) ? 1.f : 0.f;
                             st1[nn][0] += m * v0; st1[nn][1] += m * v1; st1[nn][2] += m * v2; st1[nn][3] += m * v3;
                             st2[nn][0] += m * v0 * v0; st2[nn][1] += m * v1 * v1; st2[nn][2] += m * v2 * v2; st2[nn][3] += m * v3 * v3;
@@ -2501,7 +2530,7 @@ bool da_conv3_mfma_fwd_supported(int C1, int C2, int Cout, int stride, int Cs1, 
     return true;
 }
 
-template <int CK, int NREP, bool MASKED = false, bool STATS = false, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false, int WPE = 2>
+template <int CK, int NREP, bool MASKED = false, int STATS = 0, bool BF = false, bool PRO = false, bool DYN = false, bool SP = false, int S2F = 0, bool PAIR = false, bool HB = false, int WPE = 2>
 static int launch_fwd_mfma(const FwdP& p, int gy, hipStream_t st) {
     const size_t shm = (size_t)6 * HY * HX * CK * (BF ? 2 : 4) * (SP ? 2 : 1) + (STATS ? (size_t)4 * 2 * NREP * 16 * sizeof(double) : 0) + ((DYN || SP) ? 16 : 0);
     auto kern = conv3_mfma_fwd_kernel<CK, NREP, MASKED, STATS, BF, PRO, DYN, SP, S2F, PAIR, HB, WPE>;
@@ -2569,6 +2598,10 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
 // steps.  The caller may keep the packed operand itself: da_conv3d_k3_prepack fills a caller-owned buffer (the host side does so for every layer right
 // after the optimiser step, on the side stream), da_conv3d_k3_use_prepacked hands it to the NEXT convolution call of this thread on the same weights.
 // mode 1: use, 2: fill (the matrix kernel is not launched).  Up to two regions: the 48 <- 16 data gradient runs two launches with their own packs.
+// BatchNorm-backward sums in the data gradient's epilogue (STATS == 2): set by da_conv3d_k3_dgrad_bst for the one call it makes
+struct BstState { const float* y; const float* par; float slope; };
+static thread_local BstState g_bst = {nullptr, nullptr, -1.f};
+
 struct PrepackState { int mode; const float* w; char* buf[2]; size_t bytes[2]; int next, used; };
 static thread_local PrepackState g_pp = {0, nullptr, {nullptr, nullptr}, {0, 0}, 0, 0};
 static thread_local PackJobs* g_pp_collect = nullptr;       // fill mode: record the pack launches here instead of issuing them (da_conv3d_k3_prepack_many)
@@ -2651,6 +2684,7 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     static int dyn_env = -1; if (dyn_env < 0) { const char* e = getenv("DA_DYN_TILES"); dyn_env = (e && atoi(e)) ? 1 : 0; }
     const bool dyn = dyn_env && !bf && !split && !pro && s2d_cin == 0 && !stats_partial && gy * 8 <= kDynCtrInts;
     FwdP p;
+    p.bst_y = nullptr; p.bst_par = nullptr; p.bst_slope = -1.f;
     p.ntz = (D + 3) / 4; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx;
     if (split) {
@@ -2715,6 +2749,12 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
         if (wg3s && NREP == 1)      // experiment: three workgroups per CU (<= 168 VGPRs), no paired staging
             return stats_partial ? (pro ? launch_fwd_mfma<8, 1, false, true, true, true, false, true, 0, false, false, 3>(p, gy, st) : launch_fwd_mfma<8, 1, false, true, true, false, false, true, 0, false, false, 3>(p, gy, st))
                                  : (pro ? launch_fwd_mfma<8, 1, false, false, true, true, false, true, 0, false, false, 3>(p, gy, st) : launch_fwd_mfma<8, 1, false, false, true, false, false, true, 0, false, false, 3>(p, gy, st));
+        p.bst_y = nullptr; p.bst_par = nullptr; p.bst_slope = -1.f;
+        if (g_bst.y) {                                       // (da_conv3d_k3_dgrad_bst checked the shape: one N-tile, one output tensor, no prologue)
+            if (!(stats_partial && NREP == 1 && !pro && Cs2 == 0 && gy == 1)) return DA_ERR_UNSUPPORTED;
+            p.bst_y = g_bst.y; p.bst_par = g_bst.par; p.bst_slope = g_bst.slope;
+            return launch_fwd_mfma<8, 1, false, 2, true, false, false, true>(p, gy, st);      // (unpaired staging: with the pair's second parked chunk the eight y quads of the epilogue spill)
+        }
         if (!nopair && NREP == 1 && !pro && C1 % 16 == 0 && C2 % 16 == 0)
             return stats_partial ? launch_fwd_mfma<8, 1, false, true, true, false, false, true, 0, true>(p, gy, st)
                                  : launch_fwd_mfma<8, 1, false, false, true, false, false, true, 0, true>(p, gy, st);
@@ -3123,5 +3163,23 @@ extern "C" int da_conv3d_k3_prepack_many(int n, const float* const* w_tio, const
     }
     if (!rc) rc = flush();
     g_pp_collect = nullptr; g_pp_ncollect = 0;
+    return rc;
+}
+
+// da_conv3d_k3_dgrad of a one-input layer whose input was act(BN(y)) applied on the fly (y = the producer's raw conv output, `stats4` = its statistics
+// rows [mean | rstd | scale | shift][C1], `slope` its activation): besides dx -- the gradient with respect to the ACTIVATED tensor, as always -- the
+// epilogue accumulates the producer's BatchNorm-backward sums, bst[*bst_n][2][C1] doubles = (sum dz, sum dz (y - mean)), dz = dx act'(y scale + shift),
+// for da_bn_act_bwd_dbias_pre: the stand-alone reduction pass over (dx, y) is not needed.  Split matrix mode, <= 16 input channels of the layer
+// (one N-tile); anything else returns DA_ERR_UNSUPPORTED and the caller runs da_conv3d_k3_dgrad + the usual BatchNorm backward.  autograd of unets.py:30-32.
+extern "C" int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float* dx1, int C1, int N, int D, int H, int W, int Cout,
+                                      const float* y, const float* stats4, float slope, double* bst, int bst_cap, int* bst_n,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (bst_n) *bst_n = 0;
+    if (!dy || !w_tio || !dx1 || !y || !stats4 || !bst || !bst_n || C1 <= 0 || N <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (da_matrix_mode() != 2 || C1 > 16 || C1 % 4 != 0 || bst_cap < 512 || !da_conv3_mfma_fwd_supported(Cout, 0, C1, 1, C1, 0)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3_mfma_ws_bytes(N, D, H, W, C1, Cout, 1)) return DA_ERR_WS_SMALL;
+    g_bst = BstState{y, stats4, slope};
+    const int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, nullptr, 0, N, D, H, W, C1, 1, -1.f, ws, ws_bytes, (hipStream_t)stream, 0, bst, bst_n);
+    g_bst = BstState{nullptr, nullptr, -1.f};
     return rc;
 }

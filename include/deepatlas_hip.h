@@ -348,6 +348,15 @@ int da_head_dice_bwd_bst(const float* x, const float* pro_scale, const float* pr
                          const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
                          int N, long long V, int Cin, int C, double* bst, int bst_cap, int* bst_n, void* ws, size_t ws_bytes, void* stream);
 
+/* da_conv3d_k3_dgrad of a ONE-input layer (C1 <= 16 channels) whose input was act(BN(y)) applied on the fly: y = the producer's raw conv output,
+ * stats4 = its statistics rows [mean | rstd | scale | shift][C1], slope its activation.  dx1 as always (gradient with respect to the ACTIVATED tensor); the
+ * epilogue also accumulates the PRODUCER's BatchNorm-backward sums, bst[*bst_n][2][C1] doubles = (sum dz, sum dz (y - mean)), dz = dx act'(y scale + shift),
+ * for da_bn_act_bwd_dbias_pre -- no reduction pass over (dx, y).  Split matrix mode only; DA_ERR_UNSUPPORTED: run da_conv3d_k3_dgrad and the usual backward.
+ * autograd of nn.Conv3d -> nn.BatchNorm3d -> nn.LeakyReLU chains (unets.py:30-37). */
+int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float* dx1, int C1, int N, int D, int H, int W, int Cout,
+                           const float* y, const float* stats4, float slope, double* bst, int bst_cap, int* bst_n,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* ---- packed convolution operands kept across calls (split matrix mode; conv3d_mfma.hip) ----------------------------------------------
  * A 3x3x3 convolution call first packs its weights for the matrix cores and writes its tile table (a 10-us launch in front of every matrix kernel).  Both
  * only change when the weights do (torch.optim.Adam.step in the reference's loop, models/segmentation.py:157): the caller may keep them.
