@@ -2969,6 +2969,22 @@ static int launch_split_wgrad16r(const WgP& p, const WgPlan& q, hipStream_t st) 
     return 0;
 }
 
+template <bool PRO>
+static int launch_bf16_wgrad16r(const WgP& p, const WgPlan& q, hipStream_t st) {
+    size_t shm = (size_t)(2 * 6 * (HY * HX * 8 + 4 * DA_WG16_ZPAD)) * 2 + (size_t)(2 * 2 * TY * TX * 16) * 2 + 8 * sizeof(float4);
+    if (shm < (size_t)4 * 15 * 64 * sizeof(float4)) shm = (size_t)4 * 15 * 64 * sizeof(float4);
+    auto kern = conv3_bf16_wgrad16r_kernel<PRO>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(q.nslabs, q.nchunks, q.ngroups), dim3(512), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                         int N, int D, int H, int W, int Cout, int stride, void* ws, size_t ws_bytes, hipStream_t st, int s2d_cin, const DaPro* pro, const DaS2dFuse* s2f, int act_bf16) {
     const bool hb = act_bf16 != 0;
@@ -3037,7 +3053,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     // (measured, 2 x 160 x 192 x 160: bf16 storage 48 -> 16 1.23 -> 1.09 ms, 16 -> 16 0.42 -> 0.38; NOT for more than one cout tile -- 96 -> 32: 0.44 ->
     // 0.70 ms, the kernel re-stages x per 16-cout group -- and not with fp32 tensors, 1.21 -> 1.94 ms: there the staging conversions dominate)
     const bool rows1 = !bfv1 && hb && da_matrix_mode() == 1 && s2d_cin == 0 && Cout % 4 == 0 && Cout <= 16 && pick_ck(C1, C2) != 0;
-    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split || rows1, split && !hb);
+    const WgPlan q = wgrad_plan(N, D, H, W, C1, C2, Cout, split || rows1, split || rows1, (split && !hb) || rows1);
     if (!q.CK) return DA_ERR_UNSUPPORTED;
     const bool bf = da_matrix_bf16();      // (Cout % 4 != 0 keeps the exact kernel: its dY staging is scalar)
     if ((unsigned long long)D * H * W * 4ull * (unsigned long long)((C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout) >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
@@ -3074,7 +3090,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
         p.ps2 = (C2 > 0 && pro->s2) ? pro->s2 : ones; p.pt2 = (C2 > 0 && pro->s2) ? pro->t2 : zeros;
         int rcp = DA_ERR_UNSUPPORTED;
         if (split) rcp = q.w16 >= 2 ? launch_split_wgrad16r<true>(p, q, st) : q.w16 ? launch_split_wgrad16<true>(p, q, st) : launch_split_wgrad<true>(p, q, st);
-        else if (rows1) rcp = q.w16 ? launch_split_wgrad16<true, 1, true>(p, q, st) : launch_split_wgrad<true, 1, true>(p, q, st);
+        else if (rows1) rcp = q.w16 >= 2 ? launch_bf16_wgrad16r<true>(p, q, st) : q.w16 ? launch_split_wgrad16<true, 1, true>(p, q, st) : launch_split_wgrad<true, 1, true>(p, q, st);
         else
 #define DA_WP_CASE(ck, nr) if (q.CK == ck && q.NREP == nr) rcp = hb ? launch_wgrad_mfma<ck, nr, false, false, true, true, false, true>(p, q, st) : bf ? launch_wgrad_mfma<ck, nr, false, false, true, true>(p, q, st) : launch_wgrad_mfma<ck, nr, false, false, false, true>(p, q, st)
         { DA_WP_CASE(16, 1); DA_WP_CASE(16, 2); DA_WP_CASE(8, 1); DA_WP_CASE(8, 2); }
@@ -3084,7 +3100,7 @@ int da_conv3_mfma_wgrad(const float* in1, int C1, const float* in2, int C2, cons
     }
     int rc = DA_ERR_UNSUPPORTED;
     if (split) rc = q.w16 >= 2 ? launch_split_wgrad16r<false>(p, q, st) : q.w16 ? launch_split_wgrad16<false>(p, q, st) : launch_split_wgrad<false>(p, q, st);
-    else if (rows1) rc = q.w16 ? launch_split_wgrad16<false, 1, true>(p, q, st) : launch_split_wgrad<false, 1, true>(p, q, st);
+    else if (rows1) rc = q.w16 >= 2 ? launch_bf16_wgrad16r<false>(p, q, st) : q.w16 ? launch_split_wgrad16<false, 1, true>(p, q, st) : launch_split_wgrad<false, 1, true>(p, q, st);
     else if (p.maskmode != 0) {
         if (Cout % 4 != 0) return DA_ERR_UNSUPPORTED;
         if (hb) rc = (q.NREP == 1) ? launch_wgrad_mfma<16, 1, false, true, true, false, false, true>(p, q, st) : launch_wgrad_mfma<16, 2, false, true, true, false, false, true>(p, q, st);

@@ -548,43 +548,33 @@ __device__ __forceinline__ float bend_grad_elem(const float* __restrict__ u, int
 template <bool L1>
 __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ dloss,
                                    float* __restrict__ d_disp, int D, int H, int W, BendK K) {
-    // One thread per VOXEL, all three components (round 5; was one thread per element): the 25 points of the composed stencils are 12-byte voxel
-    // reads -- a third of the load instructions of the per-element form -- and the three results go out as one 12-byte store.
     const int n = blockIdx.y;
     const float* u = disp + (long long)n * D * H * W * 3;
     float* du = d_disp + (long long)n * D * H * W * 3;
-    const long long total = (long long)D * H * W;
+    const long long total = (long long)D * H * W * 3;
     const float gl = (L1 ? 1.f : 2.f) * dloss[0];
-    const long long sH = W, sD = (long long)H * W;
+    const long long sW = 3, sH = (long long)W * 3, sD = (long long)H * W * 3;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long r = i;
+        const int c = (int)(i % 3); long long r = i / 3;
         const int w = (int)(r % W); r /= W;
         const int h = (int)(r % H); const int d = (int)(r / H);
-        float g[3];
+        float g;
         const bool deep = !L1 && d >= 2 && d < D - 2 && h >= 2 && h < H - 2 && w >= 2 && w < W - 2;
         if (deep) {
-            const F3 c0 = ld3(u, i);
-            const F3 dP2 = ld3(u, i + 2 * sD), dM2 = ld3(u, i - 2 * sD), dP1 = ld3(u, i + sD), dM1 = ld3(u, i - sD);
-            const F3 hP2 = ld3(u, i + 2 * sH), hM2 = ld3(u, i - 2 * sH), hP1 = ld3(u, i + sH), hM1 = ld3(u, i - sH);
-            const F3 wP2 = ld3(u, i + 2), wM2 = ld3(u, i - 2), wP1 = ld3(u, i + 1), wM1 = ld3(u, i - 1);
-            const F3 dh0 = ld3(u, i + 2 * sD + 2 * sH), dh1 = ld3(u, i + 2 * sD - 2 * sH), dh2 = ld3(u, i - 2 * sD + 2 * sH), dh3 = ld3(u, i - 2 * sD - 2 * sH);
-            const F3 hw0 = ld3(u, i + 2 * sH + 2), hw1 = ld3(u, i + 2 * sH - 2), hw2 = ld3(u, i - 2 * sH + 2), hw3 = ld3(u, i - 2 * sH - 2);
-            const F3 dw0 = ld3(u, i + 2 * sD + 2), dw1 = ld3(u, i + 2 * sD - 2), dw2 = ld3(u, i - 2 * sD + 2), dw3 = ld3(u, i - 2 * sD - 2);
-#define BEND_G(f, c)                                                                                                         \
-            {                                                                                                                \
-                const float d2 = dP2.f + dM2.f, d1 = dP1.f + dM1.f, h2 = hP2.f + hM2.f, h1 = hP1.f + hM1.f, w2 = wP2.f + wM2.f, w1 = wP1.f + wM1.f;   \
-                const float dh = dh0.f + dh1.f + dh2.f + dh3.f, hw = hw0.f + hw1.f + hw2.f + hw3.f, dw = dw0.f + dw1.f + dw2.f + dw3.f;            \
-                g[c] = K.k[c][0] * (d2 - 4.f * d1 + 6.f * c0.f) + K.k[c][1] * (h2 - 4.f * h1 + 6.f * c0.f) + K.k[c][2] * (w2 - 4.f * w1 + 6.f * c0.f) +       \
-                       K.k[c][3] * (4.f * c0.f - 2.f * (d2 + h2) + dh) + K.k[c][4] * (4.f * c0.f - 2.f * (h2 + w2) + hw) + K.k[c][5] * (4.f * c0.f - 2.f * (d2 + w2) + dw); \
-            }
-            BEND_G(x, 0) BEND_G(y, 1) BEND_G(z, 2)
-#undef BEND_G
+            const float* q = u + i;
+            const float c0 = q[0];
+            const float d2 = q[2 * sD] + q[-2 * sD], d1 = q[sD] + q[-sD];
+            const float h2 = q[2 * sH] + q[-2 * sH], h1 = q[sH] + q[-sH];
+            const float w2 = q[2 * sW] + q[-2 * sW], w1 = q[sW] + q[-sW];
+            const float dh = q[2 * sD + 2 * sH] + q[2 * sD - 2 * sH] + q[-2 * sD + 2 * sH] + q[-2 * sD - 2 * sH];
+            const float hw = q[2 * sH + 2 * sW] + q[2 * sH - 2 * sW] + q[-2 * sH + 2 * sW] + q[-2 * sH - 2 * sW];
+            const float dw = q[2 * sD + 2 * sW] + q[2 * sD - 2 * sW] + q[-2 * sD + 2 * sW] + q[-2 * sD - 2 * sW];
+            g = K.k[c][0] * (d2 - 4.f * d1 + 6.f * c0) + K.k[c][1] * (h2 - 4.f * h1 + 6.f * c0) + K.k[c][2] * (w2 - 4.f * w1 + 6.f * c0) +
+                K.k[c][3] * (4.f * c0 - 2.f * (d2 + h2) + dh) + K.k[c][4] * (4.f * c0 - 2.f * (h2 + w2) + hw) + K.k[c][5] * (4.f * c0 - 2.f * (d2 + w2) + dw);
         } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = bend_grad_elem<L1>(u, d, h, w, c, D, H, W, K);
+            g = bend_grad_elem<L1>(u, d, h, w, c, D, H, W, K);
         }
-        float* o = du + i * 3;
-        o[0] = gl * g[0]; o[1] = gl * g[1]; o[2] = gl * g[2];
+        du[i] = gl * g;
     }
 }
 #undef BU
@@ -835,8 +825,8 @@ extern "C" int da_bending_bwd(const float* disp, const float* dloss, float* d_di
     if (!disp || !dloss || !d_disp || N <= 0 || D < 3 || H < 3 || W < 3 || (norm != 1 && norm != 2)) return DA_ERR_BADARG;
     const BendK K = bending_coeffs(N, D, H, W, spacing3, normalize, norm);
     const long long total = (long long)D * H * W * 3;
-    if (norm == 2) hipLaunchKernelGGL((bending_bwd_kernel<false>), dim3(da_grid(total / 3, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
-    else hipLaunchKernelGGL((bending_bwd_kernel<true>), dim3(da_grid(total / 3, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
+    if (norm == 2) hipLaunchKernelGGL((bending_bwd_kernel<false>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
+    else hipLaunchKernelGGL((bending_bwd_kernel<true>), dim3(da_grid(total, 256, 4096), N), dim3(256), 0, da_stream(stream), disp, dloss, d_disp, D, H, W, K);
     DA_LAUNCH_CHECK();
     return 0;
 }
