@@ -2,6 +2,8 @@
 // (lib/loss.py:625-671, 'gradient').  Both are HBM-bound stencil + reduction passes; reductions go through per-block double
 // partials and a one-block finalize (deterministic, no float atomics).
 #include "common.h"
+#include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -136,6 +138,302 @@ __global__ void lncc_bwd_boxw_combine_kernel(const float* __restrict__ t, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// LNCC, marching form (round 5; dilation 1, stride 1, F = 5 or 9 -- VoxelMorphLNCC as the registry builds it).  The separable passes
+// above move the five (seven) intermediate fields through HBM three times; here a workgroup owns a TW x TH tile of windows and walks
+// z.  Per plane: every thread loads its share of the (TH+F-1) x (TW+F-1) halo tile, forms the five fields and puts them into LDS; the
+// x pass reads 8+F-1 consecutive values per (field, row, segment) task and writes eight sums back; the y pass gives each thread two
+// windows of one column; the last F plane sums of those stay in registers (the z loop is unrolled F times so that the ring slot is a
+// compile-time index) and are re-added every plane -- no running subtraction, so nothing drifts along z.  HBM sees I and J once
+// (halo re-reads are L2 hits) plus, in the forward pass, the five window sums the backward pass starts from.
+// The backward pass is the same walk over the zero-padded WINDOW fields (the adjoint of a valid box sum is a full one):
+//   dL/dI_p = J_p [A] + 2 I_p [B] - [A Jbar + 2 B Ibar] ,  dL/dJ_p = I_p [A] + 2 J_p [C] - [A Ibar + 2 C Jbar]
+// -- five fields again, formed from the five window sums when a plane is staged.
+// ------------------------------------------------------------------------------------------------
+template <int... Is, class Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn&& fn) { (fn(std::integral_constant<int, Is>{}), ...); }
+template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& fn) { static_for_impl(std::make_integer_sequence<int, N>{}, fn); }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+// N eight-byte LDS reads at byte address a + k * STEP, each a plain ds_read_b64; the caller waits for lgkmcnt
+template <int K, int N, int STEP> __device__ __forceinline__ void lds_col_b64(f2* c, unsigned a) {
+    if constexpr (K < N) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c[K]) : "v"(a), "n"(K * STEP));
+        lds_col_b64<K + 1, N, STEP>(c, a);
+    }
+}
+
+struct MarchP {
+    const float* I; const float* J; const float* sums_in; float* sums_out; float* dI; float* dJ; double* partial; const float* dloss;
+    int N, Liz, Liy, Lix, Loz, Loy, Lox, pad, ZC, ntx, nty, nch, nwg;
+    long long P;                       // windows per field (N * Do * Ho * Wo)
+    float n, eps, inv_m;
+};
+
+// What the forward pass leaves per window for the backward pass (the marching form's `sums`; the separable form keeps the five raw sums):
+//   A' = 2 cross / den,  B' = -cross^2 Jvar / den^2,  C' = -cross^2 Ivar / den^2,  E1' = A' Jbar + 2 B' Ibar,  E2' = A' Ibar + 2 C' Jbar
+// -- the backward fields up to the factor -dloss / M, which is applied to the box sums at the end (they are linear): the backward staging does no
+// arithmetic at all.
+// The five fields travel as three PAIRS -- forward (I, J), (I^2, J^2), (I J, -); backward (A', B'), (C', E1'), (E2', -) -- one v_pk_add_f32 per
+// add of two fields.  LDS rows are padded so that the lanes of one 16-byte access group touch different bank groups.  All global accesses are
+// buffer instructions with per-thread offsets fixed before the walk (an out-of-tile or out-of-volume position is offset 0xFFFFFFFF: loads
+// return 0, stores are dropped) and per-plane descriptors built on the SALU.
+// The kernel is bound by latency, not by a pipe (ablations: profiles/r05_lncc_marching.txt), so the three stages of three consecutive planes
+// share ONE barrier interval: y pass + z ring + epilogue of plane i, x pass of plane i + 1 (xs double-buffered), staging of plane i + 2 (the
+// forward pass double-buffers its 8 KB (I, J) tile too; the backward pass, whose tile is three pairs, stages after a second barrier).
+template <int F, bool BWD>
+__global__ void __launch_bounds__(256, 2) lncc_march_kernel(MarchP p) {
+    static_assert(F == 9 || F == 5, "x-pass reads whole 16-byte pieces; operand lists of the LDS waits");
+    constexpr int G = 3, TW = 32, TH = 16, IW = TW + F - 1, IH = TH + F - 1, NPOS = IH * IW, NSL = (NPOS + 255) / 256, NIN = BWD ? 5 : 2;
+    constexpr int SEG = 16, NSEG = TW / SEG, NTASK = G * IH * NSEG, RD = SEG + F - 1;
+    static_assert(IH * NSEG <= 64, "one wave per field pair in the x pass");
+    constexpr int RS = IW + 2, XS = TW + 2;                     // row strides in pairs: (stride * 8 bytes / 16) odd
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    constexpr int GR = BWD ? G : 1;                             // forward: only (I, J) is staged, the x pass forms the products of its group
+    constexpr int RB = BWD ? 1 : 2;                             // staging buffers
+    constexpr int RROWS = (NSL * 256 + IW - 1) / IW;            // staging rows incl. the spare ones the last (partly out-of-tile) slot writes zeros to
+    constexpr int RAWN = GR * RROWS * RS, XSN = G * IH * XS;
+    __shared__ __attribute__((aligned(16))) f2 raw[RB * RAWN];
+    __shared__ __attribute__((aligned(16))) f2 xs[2 * XSN];
+    __shared__ double red[4];
+    const int t = threadIdx.x;
+    // workgroup -> tile: x fastest, then y, then z chunk, then sample; consecutive ids go round the eight XCDs (giving each XCD a contiguous run
+    // of tiles, for the shared halos, measured slower: 87 vs 75 us backward)
+    const int wid = blockIdx.x;
+    const int tile = wid % (p.ntx * p.nty), chunk = (wid / (p.ntx * p.nty)) % p.nch, n = wid / (p.ntx * p.nty * p.nch);
+    const int x0 = (tile % p.ntx) * TW, y0 = (tile / p.ntx) * TH;
+    const int zo0 = chunk * p.ZC, zo1 = min(zo0 + p.ZC, p.Loz);
+    const int nplanes = zo1 - zo0 + F - 1;
+    const long long plane_in = (long long)p.Liy * p.Lix, plane_out = (long long)p.Loy * p.Lox;
+    const unsigned in_bytes = (unsigned)(plane_in * 4), out_bytes = (unsigned)(plane_out * 4);
+    auto rsrc = [](const float* ptr, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, bytes, 0x00020000); };
+    auto ld = [](__amdgpu_buffer_rsrc_t r, unsigned o) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0)); };
+    auto st = [](__amdgpu_buffer_rsrc_t r, unsigned o, float x) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, o, 0, 0); };
+    unsigned voff[NSL]; int lofs[NSL];
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        const int idx = t + 256 * j, iy = idx / IW, ix = idx % IW;
+        const int gy = y0 - p.pad + iy, gx = x0 - p.pad + ix;
+        const bool ok = idx < NPOS && gy >= 0 && gy < p.Liy && gx >= 0 && gx < p.Lix;
+        voff[j] = ok ? (unsigned)(gy * p.Lix + gx) * 4u : OOB;
+        lofs[j] = iy * RS + ix;
+    }
+    const int lx = t % TW, ys = t / TW;
+    unsigned ooff[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int yy = y0 + 2 * ys + o, xx = x0 + lx;
+        ooff[o] = (yy < p.Loy && xx < p.Lox) ? (unsigned)(yy * p.Lox + xx) * 4u : OOB;
+    }
+    // descriptors span one sample of one field and are built once; a plane is a scalar byte offset (the launcher keeps a sample below 2 GiB); a
+    // plane outside the volume / the chunk keeps its offset inside the sample and loads (stores) through the EMPTY descriptor instead
+    const unsigned in_sample = in_bytes * (unsigned)p.Liz, out_sample = out_bytes * (unsigned)p.Loz;
+    const __amdgpu_buffer_rsrc_t r_null = rsrc(p.I, 0u);
+    const float* in0 = BWD ? p.sums_in : p.I;
+    const float* in1 = BWD ? p.sums_in + p.P : p.J;
+    const __amdgpu_buffer_rsrc_t r_in0 = rsrc(in0 + (long long)n * p.Liz * plane_in, in_sample), r_in1 = rsrc(in1 + (long long)n * p.Liz * plane_in, in_sample);
+    const __amdgpu_buffer_rsrc_t r_in2 = rsrc(BWD ? p.sums_in + 2 * p.P + (long long)n * p.Liz * plane_in : p.I, BWD ? in_sample : 0u);
+    const __amdgpu_buffer_rsrc_t r_in3 = rsrc(BWD ? p.sums_in + 3 * p.P + (long long)n * p.Liz * plane_in : p.I, BWD ? in_sample : 0u);
+    const __amdgpu_buffer_rsrc_t r_in4 = rsrc(BWD ? p.sums_in + 4 * p.P + (long long)n * p.Liz * plane_in : p.I, BWD ? in_sample : 0u);
+    auto ldo = [](__amdgpu_buffer_rsrc_t r, unsigned o, unsigned so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, so, 0)); };
+    auto sto = [](__amdgpu_buffer_rsrc_t r, unsigned o, unsigned so, float x) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, o, so, 0); };
+    float v[NIN][NSL];
+    auto issue = [&](int i) {                                   // input plane i of the chunk (zeros outside the volume / past the chunk)
+        const int zin = zo0 - p.pad + i;
+        const bool zok = i < nplanes && zin >= 0 && zin < p.Liz;
+        const unsigned so = zok ? (unsigned)zin * in_bytes : 0u;
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            v[0][j] = ldo(zok ? r_in0 : r_null, voff[j], so); v[1][j] = ldo(zok ? r_in1 : r_null, voff[j], so);
+            if constexpr (BWD) { v[2][j] = ldo(zok ? r_in2 : r_null, voff[j], so); v[3][j] = ldo(zok ? r_in3 : r_null, voff[j], so); v[4][j] = ldo(zok ? r_in4 : r_null, voff[j], so); }
+        }
+    };
+    const __amdgpu_buffer_rsrc_t r_pi = rsrc(p.I + (long long)n * p.Loz * plane_out, BWD ? out_sample : 0u), r_pj = rsrc(p.J + (long long)n * p.Loz * plane_out, BWD ? out_sample : 0u);
+    float pi[2] = {0.f, 0.f}, pj[2] = {0.f, 0.f};               // backward: I, J at this thread's two voxels of the output plane of walk step i
+    auto issue_post = [&](int i) {
+        if constexpr (BWD) {
+            const int zo = zo0 + i - (F - 1);
+            const bool zok = zo >= zo0 && zo < zo1;
+            const unsigned so = zok ? (unsigned)zo * out_bytes : 0u;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) { pi[o] = ldo(zok ? r_pi : r_null, ooff[o], so); pj[o] = ldo(zok ? r_pj : r_null, ooff[o], so); }
+        }
+    };
+    // outputs: backward dI, dJ; forward the five window terms
+    const float* o0 = BWD ? p.dI : p.sums_out;
+    const float* o1 = BWD ? p.dJ : p.sums_out + p.P;
+    const long long osmp = (long long)n * p.Loz * plane_out;
+    const __amdgpu_buffer_rsrc_t r_o0 = rsrc(o0 ? o0 + osmp : nullptr, o0 ? out_sample : 0u), r_o1 = rsrc(o1 ? o1 + osmp : nullptr, o1 ? out_sample : 0u);
+    const __amdgpu_buffer_rsrc_t r_o2 = rsrc(BWD ? nullptr : p.sums_out + 2 * p.P + osmp, BWD ? 0u : out_sample);
+    const __amdgpu_buffer_rsrc_t r_o3 = rsrc(BWD ? nullptr : p.sums_out + 3 * p.P + osmp, BWD ? 0u : out_sample);
+    const __amdgpu_buffer_rsrc_t r_o4 = rsrc(BWD ? nullptr : p.sums_out + 4 * p.P + osmp, BWD ? 0u : out_sample);
+    float gs = 0.f;
+    if constexpr (BWD) gs = -p.dloss[0] * p.inv_m;
+    const float inv_n = 1.f / p.n;
+    auto stage = [&](int rb) {
+        f2* dst = raw + rb * RAWN;
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            dst[lofs[j]] = (f2){v[0][j], v[1][j]};
+            if constexpr (BWD) { dst[RROWS * RS + lofs[j]] = (f2){v[2][j], v[3][j]}; dst[2 * RROWS * RS + lofs[j]] = (f2){v[4][j], v[4][j]}; }
+        }
+    };
+    // x pass, one task per thread (the first NTASK threads): lanes run over rows first (conflict-free 16-byte LDS accesses with the padded
+    // strides).  Two sums of a segment are added up (outputs 0 and 8); the others slide from them (+ entering - leaving value), two independent
+    // chains of seven.
+    const int xg = __builtin_amdgcn_readfirstlane(t >> 6), xl = t & 63;      // wave g does group g: the product branch is wave-uniform
+    const bool xact = xg < G && xl < IH * NSEG;
+    const int xrow = xl % IH, xseg = xl / IH;
+    const int xsrc = (BWD ? xg * (RROWS * RS) : 0) + xrow * RS + xseg * SEG, xdst = xg * (IH * XS) + xrow * XS + xseg * SEG;
+    auto xtask = [&](auto gc, int rb, int xb) {                 // one instantiation per pair: no values merge between the product forms
+        constexpr int g = decltype(gc)::value;
+        const f2* src = raw + rb * RAWN + xsrc;
+        f2 pv[RD];
+#pragma unroll
+        for (int k = 0; k < RD; ++k) pv[k] = src[k];
+        if constexpr (!BWD && g == 1) {
+#pragma unroll
+            for (int k = 0; k < RD; ++k) pv[k] = pv[k] * pv[k];
+        }
+        if constexpr (!BWD && g == 2) {
+#pragma unroll
+            for (int k = 0; k < RD; ++k) pv[k].x = pv[k].x * pv[k].y;                  // .y of the third pair is never read
+        }
+        f2 so[SEG];
+        auto anchor = [&](int o) {
+            if constexpr (F == 9) return ((pv[o] + pv[o + 1]) + pv[o + 2]) + ((pv[o + 3] + pv[o + 4]) + pv[o + 5]) + ((pv[o + 6] + pv[o + 7]) + pv[o + 8]);
+            else return ((pv[o] + pv[o + 1]) + (pv[o + 2] + pv[o + 3])) + pv[o + 4];
+        };
+        so[0] = anchor(0); so[SEG / 2] = anchor(SEG / 2);
+#pragma unroll
+        for (int o = 1; o < SEG / 2; ++o) {
+            so[o] = so[o - 1] + (pv[o + F - 1] - pv[o - 1]);
+            so[SEG / 2 + o] = so[SEG / 2 + o - 1] + (pv[SEG / 2 + o + F - 1] - pv[SEG / 2 + o - 1]);
+        }
+        f2* dst = xs + xb * XSN + xdst;
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) dst[o] = so[o];
+    };
+    auto xpass = [&](int rb, int xb) {
+        if (xact) {
+            if (xg == 0) xtask(std::integral_constant<int, 0>{}, rb, xb);
+            else if (xg == 1) xtask(std::integral_constant<int, 1>{}, rb, xb);
+            else xtask(std::integral_constant<int, 2>{}, rb, xb);
+        }
+    };
+    // y pass column reads as plain ds_read_b64 (256 B/clk): left to itself the compiler pairs them into ds_read2_b64, which runs at half that
+    const unsigned ybase = (unsigned)(((2 * ys) * XS + lx) * 8) + (unsigned)(size_t)(&xs[0]);
+    auto wait_cols = [&](f2* c) {                               // the wait carries the read registers as operands: nothing may use them before it
+        if constexpr (F == 9) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]) :: "memory");
+    };
+    f2 P[G][2][F], T3[G][2][F];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int k = 0; k < F; ++k) { P[g][o][k] = (f2){0.f, 0.f}; T3[g][o][k] = (f2){0.f, 0.f}; }
+    double acc = 0.0;
+    // prologue: plane 0 through the x pass, plane 1 staged, plane 2 on its way
+    issue(0);
+    stage(0);
+    issue(1);
+    __syncthreads();
+    xpass(0, 0);
+    if constexpr (RB == 1) __syncthreads();
+    stage(RB == 2 ? 1 : 0);
+    issue(2);
+    issue_post(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int ib = 0; ib < nplanes; ib += F) {
+        static_for<F>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;                   // the ring slot, a compile-time index
+            const int i = ib + r;                                    // walk steps past the chunk (the walk is padded to whole rings: a conditional slot would
+            const int par = i & 1;                                   // keep all 2 x F ring registers of every field alive) load zeros and store nothing
+            float ci[2], cj[2];
+            if constexpr (BWD) { ci[0] = pi[0]; ci[1] = pi[1]; cj[0] = pj[0]; cj[1] = pj[1]; }
+            issue_post(i + 1);
+            xpass(RB == 2 ? par ^ 1 : 0, par ^ 1);
+            if constexpr (RB == 2) { stage(par); issue(i + 3); }
+            f2 c[G][F + 1];
+#pragma unroll
+            for (int g = 0; g < G; ++g) lds_col_b64<0, F + 1, XS * 8>(c[g], ybase + (unsigned)((par * XSN + g * IH * XS) * 8));
+#pragma unroll
+            for (int g = 0; g < G; ++g) wait_cols(c[g]);
+            f2 s[G][2];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f2 m;
+                if constexpr (F == 9) m = ((c[g][1] + c[g][2]) + (c[g][3] + c[g][4])) + ((c[g][5] + c[g][6]) + (c[g][7] + c[g][8]));
+                else m = (c[g][1] + c[g][2]) + (c[g][3] + c[g][4]);
+                P[g][0][r] = m + c[g][0]; P[g][1][r] = m + c[g][F];
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    if constexpr (F == 9) {
+                        T3[g][o][r] = P[g][o][r] + P[g][o][(r + F - 1) % F] + P[g][o][(r + F - 2) % F];
+                        s[g][o] = T3[g][o][r] + T3[g][o][(r + F - 3) % F] + T3[g][o][(r + F - 6) % F];
+                    } else {
+                        s[g][o] = ((P[g][o][0] + P[g][o][1]) + (P[g][o][2] + P[g][o][3])) + P[g][o][4];
+                    }
+                }
+            }
+            if (i >= F - 1) {
+                const int zo = zo0 + i - (F - 1);
+                const bool zin = zo < zo1;
+                const unsigned so = zin ? (unsigned)zo * out_bytes : 0u;
+                if constexpr (BWD) {
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        sto(zin ? r_o0 : r_null, ooff[o], so, gs * (cj[o] * s[0][o].x + 2.f * ci[o] * s[0][o].y - s[1][o].y));
+                        sto(zin ? r_o1 : r_null, ooff[o], so, gs * (ci[o] * s[0][o].x + 2.f * cj[o] * s[1][o].x - s[2][o].x));
+                    }
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const float sI = s[0][o].x, sJ = s[0][o].y, sII = s[1][o].x, sJJ = s[1][o].y, sIJ = s[2][o].x;
+                        const float im = sI * inv_n, jm = sJ * inv_n;
+                        const float cross = sIJ - im * sJ - jm * sI + im * jm * p.n;
+                        const float ivar = sII - 2.f * im * sI + im * im * p.n, jvar = sJJ - 2.f * jm * sJ + jm * jm * p.n;
+                        const float rd = __builtin_amdgcn_rcpf(ivar * jvar + p.eps), cr = cross * rd, q = -(cr * cr);
+                        if (zin && ooff[o] != OOB) acc += (double)(cross * cr);
+                        const float A = 2.f * cr, B = q * jvar, C = q * ivar;
+                        sto(zin ? r_o0 : r_null, ooff[o], so, A); sto(zin ? r_o1 : r_null, ooff[o], so, B); sto(zin ? r_o2 : r_null, ooff[o], so, C);
+                        sto(zin ? r_o3 : r_null, ooff[o], so, A * jm + 2.f * B * im); sto(zin ? r_o4 : r_null, ooff[o], so, A * im + 2.f * C * jm);
+                    }
+                }
+            }
+            __syncthreads();
+            if constexpr (RB == 1) { stage(0); issue(i + 3); __syncthreads(); }
+        });
+    }
+    if constexpr (!BWD) {
+        const double tot = da_block_sum(acc, red);
+        if (t == 0) p.partial[wid] = tot;
+    }
+}
+
+struct MarchGeom { int ntx, nty, nch, ZC; bool ok; };
+static MarchGeom lncc_march_geom(int N, int Lz, int Ly, int Lx, int F, int dil, int stride) {
+    MarchGeom g{};
+    static const int off = [] { const char* e = getenv("DA_LNCC_MARCH"); return (e && e[0] == '0') ? 1 : 0; }();
+    g.ok = !off && dil == 1 && stride == 1 && (F == 9 || F == 5) && (long long)(Lz + F) * (Ly + F) * (Lx + F) * 4 < (1ll << 31);
+    if (!g.ok) return g;
+    g.ntx = (Lx + 31) / 32; g.nty = (Ly + 15) / 16;
+    const long long tiles = (long long)g.ntx * g.nty * N;
+    // z chunks: two workgroups per CU are resident (registers), so the time is (rounds of 512 workgroups) x (planes a workgroup walks: its chunk
+    // + F - 1 re-read planes, padded to whole rings of F); among equal times the fewest total planes
+    long long best_t = -1, best_w = -1;
+    for (int nch = 1; nch <= (Lz + F - 1) / F; ++nch) {
+        int ZC = (Lz + nch - 1) / nch;
+        ZC = ((ZC - 1 + F - 1) / F) * F + 1;                    // ZC + F - 1 a multiple of F wastes no ring slot
+        const int n2 = (Lz + ZC - 1) / ZC;
+        const long long walk = ZC + F - 1, nwg = tiles * n2, t = ((nwg + 511) / 512) * walk, w = nwg * walk;
+        if (best_t < 0 || t < best_t || (t == best_t && w < best_w)) { best_t = t; best_w = w; g.ZC = ZC; g.nch = n2; }
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
 // gradientLoss (lib/loss.py:625-671) on disp [N][D][H][W][3] (NDHWC).  Central differences WITHOUT the 1/2h and with the
 // reference's sign quirk: along D it is u(+1) - u(-1), along H and W it is u(+1) + u(-1) (lib/loss.py:659-663).
 // L2: mean over the axis-interior voxels of d^2, times (spatial_dims[c] spacing[c] / spacing[k])^2 where the 3-vector is
@@ -217,6 +515,8 @@ extern "C" size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F, int dil, i
     if (F < 1 || dil < 1 || stride < 1) return 0;
     const size_t Wo = lncc_out(W, F, dil, stride), Ho = lncc_out(H, F, dil, stride), Do = lncc_out(D, F, dil, stride);
     if (!Wo || !Ho || !Do) return 0;
+    const MarchGeom mg = lncc_march_geom(N, (int)Do, (int)Ho, (int)Wo, F, dil, stride);
+    if (mg.ok) return da_align((size_t)mg.ntx * mg.nty * mg.nch * N * sizeof(double));     // marching form: the loss partials only
     // forward: t1 [5][N][D][H][Wo], t2 [5][N][D][Ho][Wo], partials; backward: G [7][N][Do][Ho][Wo], [7][N][D][Ho][Wo], [7][N][D][H][Wo]
     const size_t fwd = da_align((size_t)5 * N * D * H * Wo * 4) + da_align((size_t)5 * N * D * Ho * Wo * 4) + da_align((size_t)kBlocks * 8);
     const size_t bwd = da_align((size_t)7 * N * Do * Ho * Wo * 4) + da_align((size_t)7 * N * D * Ho * Wo * 4) + da_align((size_t)7 * N * D * H * Wo * 4);
@@ -230,6 +530,20 @@ extern "C" int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, 
     if (!Wo || !Ho || !Do) return DA_ERR_BADARG;
     if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F, dil, stride)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
+    const MarchGeom mg = lncc_march_geom(N, Do, Ho, Wo, F, dil, stride);
+    if (mg.ok) {
+        MarchP p{};
+        p.I = I; p.J = J; p.sums_out = sums; p.partial = (double*)ws;
+        p.N = N; p.Liz = D; p.Liy = H; p.Lix = W; p.Loz = Do; p.Loy = Ho; p.Lox = Wo; p.pad = 0; p.ZC = mg.ZC; p.ntx = mg.ntx; p.nty = mg.nty; p.nch = mg.nch; p.nwg = mg.ntx * mg.nty * mg.nch * N;
+        p.P = (long long)N * Do * Ho * Wo; p.n = (float)((double)F * F * F); p.eps = eps;
+        const dim3 grid((unsigned)p.nwg);
+        if (F == 9) hipLaunchKernelGGL((lncc_march_kernel<9, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((lncc_march_kernel<5, false>), grid, dim3(256), 0, st, p);
+        DA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, p.nwg, -1.0 / (double)p.P, 1.0, loss);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     float* t1 = (float*)ws;
     float* t2 = (float*)((char*)ws + da_align((size_t)5 * N * D * H * Wo * 4));
     double* partial = (double*)((char*)t2 + da_align((size_t)5 * N * D * Ho * Wo * 4));
@@ -255,6 +569,18 @@ extern "C" int da_lncc_bwd(const float* I, const float* J, const float* sums, co
     if (!Wo || !Ho || !Do) return DA_ERR_BADARG;
     if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F, dil, stride)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
+    const MarchGeom mg = lncc_march_geom(N, D, H, W, F, dil, stride);
+    if (mg.ok) {
+        MarchP p{};
+        p.I = I; p.J = J; p.sums_in = sums; p.dI = dI; p.dJ = dJ; p.dloss = dloss;
+        p.N = N; p.Liz = Do; p.Liy = Ho; p.Lix = Wo; p.Loz = D; p.Loy = H; p.Lox = W; p.pad = F - 1; p.ZC = mg.ZC; p.ntx = mg.ntx; p.nty = mg.nty; p.nch = mg.nch; p.nwg = mg.ntx * mg.nty * mg.nch * N;
+        p.P = (long long)N * Do * Ho * Wo; p.n = (float)((double)F * F * F); p.eps = eps; p.inv_m = (float)(1.0 / (double)p.P);
+        const dim3 grid((unsigned)p.nwg);
+        if (F == 9) hipLaunchKernelGGL((lncc_march_kernel<9, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((lncc_march_kernel<5, true>), grid, dim3(256), 0, st, p);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     float* G = (float*)ws;
     float* g1 = (float*)((char*)ws + da_align((size_t)7 * N * Do * Ho * Wo * 4));
     float* g2 = (float*)((char*)g1 + da_align((size_t)7 * N * D * Ho * Wo * 4));

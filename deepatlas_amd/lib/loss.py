@@ -121,8 +121,11 @@ class VoxelMorphLNCC(nn.Module):
         self.eps = eps
 
     def forward(self, I, J):
-        if not bool((self.filter == 1).all()):
-            raise NotImplementedError('VoxelMorphLNCC.filter must stay all ones on the accelerated path')
+        key = (self.filter._version, self.filter.data_ptr())        # the check reads the device: once per state of the parameter, not per call
+        if getattr(self, '_ones_checked', None) != key:
+            if not bool((self.filter == 1).all()):
+                raise NotImplementedError('VoxelMorphLNCC.filter must stay all ones on the accelerated path')
+            self._ones_checked = key
         return ops.LNCCFn.apply(I, J, self.filter_size, self.eps)
 
 

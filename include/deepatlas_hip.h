@@ -438,7 +438,9 @@ int da_synth_volume(float* img, unsigned char* labels, int N, int D, int H, int 
 /* ---- LNCC similarity (lib/loss.py:589-617 VoxelMorphLNCC = registry 'lncc', and :512-586 LNCCLoss) -----
  * I, J: [N][D][H][W] fp32 (single channel); all-ones F^3 window with dilation `dil` and stride `stride` (1, 1 for VoxelMorphLNCC),
  * valid padding; loss = 1 - mean(cross^2 / (Ivar Jvar + eps)).  Output extent per axis: (L - dil (F-1) - 1) / stride + 1.
- * sums: [5][N][Do][Ho][Wo] window sums (I, J, I^2, J^2, IJ), written by fwd and consumed by bwd. */
+ * sums: [5][N][Do][Ho][Wo] floats written by fwd and consumed by bwd of the SAME geometry, opaque to the caller: the five window
+ * sums (I, J, I^2, J^2, IJ) in the separable form; in the z-marching form (dil = stride = 1, F = 5 or 9: one fused kernel per
+ * direction, reglosses.hip) the five per-window backward terms A', B', C', E1', E2'.  DA_LNCC_MARCH=0 keeps the separable form. */
 size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F, int dil, int stride);
 int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, int W, int F, int dil, int stride, float eps,
                 float* loss, float* sums, void* ws, size_t ws_bytes, void* stream);

@@ -797,6 +797,24 @@ def test_lncc_vs_oracle_ragged_and_errors():
         VoxelMorphLNCC()(rnd((1, 2, 12, 16, 16), 3).to(dev()), rnd((1, 2, 12, 16, 16), 4).to(dev()))
 
 
+def test_lncc_marching_form_chunks_and_partial_tiles():
+    """The z-marching LNCC kernels (dilation 1, stride 1, F = 9 / 5) on a volume that needs several z chunks, partial x / y tiles, two samples
+    and one-sided gradients: loss and gradients against the oracle's conv3d restatement of lib/loss.py:599-617."""
+    from deepatlas_amd.lib.loss import VoxelMorphLNCC
+    from oracle import losses
+    for fs, shape in ((9, (2, 1, 61, 45, 70)), (5, (1, 1, 23, 37, 33))):
+        I, J = rnd(shape, 5) * 0.5 + 0.5, rnd(shape, 6) * 0.5 + 0.5
+        Ir, Jr = I.clone().requires_grad_(True), J.clone().requires_grad_(True)
+        lr = losses.lncc_loss(Ir, Jr, fs); lr.backward()
+        Ig, Jg = I.to(dev()).requires_grad_(True), J.to(dev()).requires_grad_(True)
+        lg = VoxelMorphLNCC(filter_size=fs)(Ig, Jg); lg.backward()
+        assert abs(lg.item() - lr.item()) < 1e-4
+        check(Ig.grad, Ir.grad, tol=2e-4, what='grad_I f%d' % fs); check(Jg.grad, Jr.grad, tol=2e-4, what='grad_J f%d' % fs)
+        Ig2 = I.to(dev()).requires_grad_(True)
+        VoxelMorphLNCC(filter_size=fs)(Ig2, J.to(dev())).backward()            # only dI asked for
+        assert torch.equal(Ig2.grad, Ig.grad)
+
+
 def test_gradient_loss_golden(golden):
     from deepatlas_amd.lib.loss import get_loss_function
     g = golden('reglosses')
