@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kHdBlocks = 1024;           // workgroups per sample (forward partial sums) / in total (backward partials)
 constexpr int MT = 4;                     // M-tiles (16 voxels) per wave and chunk: a workgroup covers 256 voxels per iteration
+constexpr float kLog2e = 1.44269504088896341f;
 
 struct HdP {
     const float* x; const float* ps; const float* pt; float pslope;      // input [N][V][K] (+ optional deferred BatchNorm + activation)
@@ -54,22 +55,56 @@ __global__ void hd_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // The softmax of a voxel is then a reduction over this lane's registers and the three other lane groups (two DPP-free xor steps),
 // the voxel's label is one load per tile, and in the backward pass the gradient with respect to the logits is already in the B-operand
 // layout of the data-gradient GEMM (no transpose through LDS), whose result comes out as 4 consecutive input channels per lane
-// (16-byte stores).  Returns probabilities in acc (0 for voxels past the end).
-template <int KC, int NT, typename T = float>
-__device__ __forceinline__ void hd_probs(const HdP& p, const T* __restrict__ xs, long long vbase, int i, int g,
-                                         const float4 (&wf)[NT][KC], const float (&bv)[NT][4], float4 (&a)[MT][KC], f32x4 (&acc)[MT][NT]) {
+// (16-byte stores).
+// Round 5: both kernels were bound by their VALU instruction count and by load latency (SQ counters: 22 % issuing, 38 % parked on s_waitcnt,
+// 39 % issue-stalled; profiles/r05_head_dice_counters.txt), so (1) the next chunk's input quads and labels are loaded before the current
+// chunk is worked on (hd_load / hd_labels), (2) the weights and the bias carry a factor log2(e) so that the softmax is v_exp_f32 (= 2^x) on
+// the logits as they stand, 1 / sum is v_rcp_f32, and (3) everything per class -- one-hot masks, Dice sums, the softmax Jacobian -- works on
+// register PAIRS (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 hd_lo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f2 hd_hi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f2 hd_bc(float x) { return (f2){x, x}; }
+
+template <int KC, typename T>
+__device__ __forceinline__ void hd_load(const HdP& p, const T* __restrict__ xs, long long vbase, int i, int g, float4 (&a)[MT][KC]) {
+    // unconditional loads (a voxel past the end reads the last voxel's quads: finite values whose probabilities are zeroed in hd_probs): a load
+    // under a branch is waited for at the end of the branch, which would undo the prefetch
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const long long vox = vbase + t * 16 + i;
-        const bool ok = vox < p.V;
+        const long long vox = min(vbase + t * 16 + i, p.V - 1);
 #pragma unroll
-        for (int c = 0; c < KC; ++c)
-            a[t][c] = ok ? da_ldq(xs, (vox * p.K + 16 * c + 4 * g) >> 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < KC; ++c) a[t][c] = da_ldq(xs, (vox * p.K + 16 * c + 4 * g) >> 2);
     }
+}
+// the labels of this lane's voxels (t, i), as loaded; hd_rel turns one into `rel` = label minus this lane group's first class 4g (a hit is
+// rel == 16n + reg), -1000 past the end
+__device__ __forceinline__ void hd_labels(const HdP& p, long long lbase, long long vbase, int i, int g, int (&rel)[MT]) {
+    // one byte per label whatever its width (the low byte of a little-endian int64 label < 256), again without a branch around the load
+    // -- and nothing computed from the loaded byte here: the first use of a loaded register is where the wait for ALL earlier loads goes
+#pragma unroll
+    for (int t = 0; t < MT; ++t) rel[t] = (int)((const unsigned char*)p.labels)[(lbase + min(vbase + t * 16 + i, p.V - 1)) * p.label_bytes];
+}
+// raw label byte -> rel (see hd_labels), at the time the chunk is worked on
+__device__ __forceinline__ int hd_rel(const HdP& p, int lab, long long vox, int g) { return (vox < p.V ? lab : -1000) - 4 * g; }
+// one-hot of the label over this lane's classes, as 0 / 1 floats in the accumulator layout
+template <int NT>
+__device__ __forceinline__ void hd_mask(int rel, f2 (&mk)[NT][2]) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        mk[n][0] = (f2){rel == 16 * n ? 1.f : 0.f, rel == 16 * n + 1 ? 1.f : 0.f};
+        mk[n][1] = (f2){rel == 16 * n + 2 ? 1.f : 0.f, rel == 16 * n + 3 ? 1.f : 0.f};
+    }
+}
+
+// a: the raw input quads of the chunk (hd_load) -> activated in place; acc: probabilities (0 for voxels past the end).  wf / bv carry log2(e).
+template <int KC, int NT, typename T = float>
+__device__ __forceinline__ void hd_probs(const HdP& p, long long vbase, int i, int g, const float4 (&psc)[KC], const float4 (&psf)[KC],
+                                         const float4 (&wf)[NT][KC], const float (&bv)[NT][4], float4 (&a)[MT][KC], f32x4 (&acc)[MT][NT]) {
     if (p.ps) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-            const float4 sc = *reinterpret_cast<const float4*>(p.ps + 16 * c + 4 * g), sf = *reinterpret_cast<const float4*>(p.pt + 16 * c + 4 * g);
+            const float4 sc = psc[c], sf = psf[c];
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 a[t][c].x = hd_act01(a[t][c].x * sc.x + sf.x, p.pslope); a[t][c].y = hd_act01(a[t][c].y * sc.y + sf.y, p.pslope);
@@ -82,19 +117,29 @@ __device__ __forceinline__ void hd_probs(const HdP& p, const T* __restrict__ xs,
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
-    // A = W^T fragment (lane: class 16n + i, input channel 16c + 4g + m), B = x^T fragment (lane: voxel i, input channel 16c + 4g + m)
+    // A = W^T fragment (lane: class 16n + i, input channel 16c + 4g + m), B = x^T fragment (lane: voxel i, input channel 16c + 4g + m);
+    // the MT * NT accumulators take turns (an MFMA on the accumulator of the one before it waits for its result)
 #pragma unroll
-    for (int c = 0; c < KC; ++c)
+    for (int c = 0; c < KC; ++c) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].x, a[t][c].x, acc[t][n], 0, 0, 0);
-                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].y, a[t][c].y, acc[t][n], 0, 0, 0);
-                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].z, a[t][c].z, acc[t][n], 0, 0, 0);
-                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].w, a[t][c].w, acc[t][n], 0, 0, 0);
-            }
-    // softmax over the classes of voxel (t, i): NT * 4 values in this lane x the four lane groups (F.softmax(source, dim=1), loss.py:426-427)
+            for (int t = 0; t < MT; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].x, a[t][c].x, acc[t][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].y, a[t][c].y, acc[t][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].z, a[t][c].z, acc[t][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][c].w, a[t][c].w, acc[t][n], 0, 0, 0);
+    }
+    // softmax over the classes of voxel (t, i): NT * 4 values in this lane x the four lane groups (F.softmax(source, dim=1), loss.py:426-427);
+    // the logits are in units of log 2: 2^(l - max) = e^(logit - max logit)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const bool valid = vbase + t * 16 + i < p.V;
@@ -104,17 +149,20 @@ __device__ __forceinline__ void hd_probs(const HdP& p, const T* __restrict__ xs,
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) m = fmaxf(m, acc[t][n][reg]);
         m = da_rows_max(m);
-        float s = 0.f;
+        f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) { acc[t][n][reg] = __expf(acc[t][n][reg] - m); s += acc[t][n][reg]; }      // v_exp_f32: arguments <= 0, relative error ~1e-6
-        s = da_rows_sum(s);
-        const float inv = valid ? 1.f / s : 0.f;
+            for (int reg = 0; reg < 4; ++reg) acc[t][n][reg] = __builtin_amdgcn_exp2f(acc[t][n][reg] - m);      // arguments <= 0, relative error ~1e-6
+            s2 += hd_lo(acc[t][n]) + hd_hi(acc[t][n]);
+        }
+        const float s = da_rows_sum(s2.x + s2.y);
+        const f2 inv = hd_bc(valid ? __builtin_amdgcn_rcpf(s) : 0.f);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) acc[t][n][reg] *= inv;
+        for (int n = 0; n < NT; ++n) {
+            const f2 lo = hd_lo(acc[t][n]) * inv, hi = hd_hi(acc[t][n]) * inv;
+            acc[t][n] = (f32x4){lo.x, lo.y, hi.x, hi.y};
+        }
     }
 }
 
@@ -125,7 +173,25 @@ __device__ __forceinline__ void hd_bias(const HdP& p, int g, float (&bv)[NT][4])
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) bv[n][reg] = p.bias ? p.bias[16 * n + 4 * g + reg] : 0.f;
+        for (int reg = 0; reg < 4; ++reg) bv[n][reg] = p.bias ? p.bias[16 * n + 4 * g + reg] * kLog2e : 0.f;
+}
+template <int KC, int NT>
+__device__ __forceinline__ void hd_weights(const HdP& p, int lane, float4 (&wf)[NT][KC]) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const float4 w = reinterpret_cast<const float4*>(p.wp_fwd)[(n * KC + c) * 64 + lane];
+            wf[n][c] = make_float4(w.x * kLog2e, w.y * kLog2e, w.z * kLog2e, w.w * kLog2e);
+        }
+}
+template <int KC>
+__device__ __forceinline__ void hd_prologue(const HdP& p, int g, float4 (&psc)[KC], float4 (&psf)[KC]) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        psc[c] = p.ps ? *reinterpret_cast<const float4*>(p.ps + 16 * c + 4 * g) : make_float4(1.f, 1.f, 1.f, 1.f);
+        psf[c] = p.ps ? *reinterpret_cast<const float4*>(p.pt + 16 * c + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 template <int KC, int NT, typename T = float>     // T: storage type of x / dx (da_bf16 = bf16 activation storage, common.h)
@@ -136,34 +202,40 @@ __global__ void __launch_bounds__(256) head_dice_fwd_kernel(HdP p) {
     const int n_s = blockIdx.y;
     const T* xs = reinterpret_cast<const T*>(p.x) + (long long)n_s * p.V * p.K;
     const long long lbase = (long long)n_s * p.V;
-    float4 wf[NT][KC]; float bv[NT][4];
+    float4 wf[NT][KC]; float bv[NT][4]; float4 psc[KC], psf[KC];
     hd_bias<NT>(p, g, bv);
+    hd_weights<KC, NT>(p, lane, wf);
+    hd_prologue<KC>(p, g, psc, psf);
+    f2 sI[NT][2], sS[NT][2], sT[NT][2];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int c = 0; c < KC; ++c) wf[n][c] = reinterpret_cast<const float4*>(p.wp_fwd)[(n * KC + c) * 64 + lane];
-    float sI[NT][4], sS[NT][4], sT[NT][4];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) sI[n][reg] = sS[n][reg] = sT[n][reg] = 0.f;
+        for (int h = 0; h < 2; ++h) sI[n][h] = sS[n][h] = sT[n][h] = (f2){0.f, 0.f};
     const long long nchunks = (p.V + 255) / 256;
+    float4 an[MT][KC]; int reln[MT];
+    if ((long long)blockIdx.x < nchunks) { hd_load<KC, T>(p, xs, (long long)blockIdx.x * 256 + wave * 64, i, g, an); hd_labels(p, lbase, (long long)blockIdx.x * 256 + wave * 64, i, g, reln); }
     for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
         const long long vbase = cb * 256 + wave * 64;
-        float4 a[MT][KC]; f32x4 acc[MT][NT];
-        hd_probs<KC, NT, T>(p, xs, vbase, i, g, wf, bv, a, acc);
+        float4 a[MT][KC]; f32x4 acc[MT][NT]; int rel[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const long long vox = vbase + t * 16 + i;
-            const int rel = (vox < p.V ? (int)hd_label(p.labels, p.label_bytes, lbase + vox) : -1) - 4 * g;     // hit: rel == 16n + reg
+            rel[t] = hd_rel(p, reln[t], vbase + t * 16 + i, g);
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int c = 0; c < KC; ++c) a[t][c] = an[t][c];
+        }
+        { const long long vn = min(cb + (long long)gridDim.x, nchunks - 1) * 256 + wave * 64; hd_load<KC, T>(p, xs, vn, i, g, an); hd_labels(p, lbase, vn, i, g, reln); }      // (the last iteration re-reads a chunk)
+        hd_probs<KC, NT, T>(p, vbase, i, g, psc, psf, wf, bv, a, acc);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float pr = acc[t][n][reg];
-                    const bool hit = rel == 16 * n + reg;
-                    sS[n][reg] += pr; sI[n][reg] += hit ? pr : 0.f; sT[n][reg] += hit ? 1.f : 0.f;
-                }
+        for (int t = 0; t < MT; ++t) {
+            f2 mk[NT][2];
+            hd_mask<NT>(rel[t], mk);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f2 lo = hd_lo(acc[t][n]), hi = hd_hi(acc[t][n]);
+                sS[n][0] += lo; sS[n][1] += hi;
+                sI[n][0] += lo * mk[n][0]; sI[n][1] += hi * mk[n][1];
+                sT[n][0] += mk[n][0]; sT[n][1] += mk[n][1];
+            }
         }
     }
     // per-lane fp32 sums cover at most a few hundred voxels; everything past them is double: the 16 voxel lanes, then the four waves
@@ -171,7 +243,7 @@ __global__ void __launch_bounds__(256) head_dice_fwd_kernel(HdP p) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            double a0 = (double)sI[n][reg], a1 = (double)sS[n][reg], a2 = (double)sT[n][reg];
+            double a0 = (double)sI[n][reg >> 1][reg & 1], a1 = (double)sS[n][reg >> 1][reg & 1], a2 = (double)sT[n][reg >> 1][reg & 1];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
             if (i == 0) { const int c = 16 * n + 4 * g + reg; sred[wave][0][c] = a0; sred[wave][1][c] = a1; sred[wave][2][c] = a2; }
@@ -191,12 +263,10 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
     const int i = lane & 15, g = lane >> 4;
     float* xl = lds + wave * (64 * LDX + 64 * LDD);          // this wave's activated-input tile [64 voxels][LDX]
     float* dl = xl + 64 * LDX;                               // this wave's d loss / d logits tile [64 voxels][LDD]
-    float4 wf[NT][KC]; float bv[NT][4];
+    float4 wf[NT][KC]; float bv[NT][4]; float4 psc[KC], psf[KC];
     hd_bias<NT>(p, g, bv);
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int c = 0; c < KC; ++c) wf[n][c] = reinterpret_cast<const float4*>(p.wp_fwd)[(n * KC + c) * 64 + lane];
+    hd_weights<KC, NT>(p, lane, wf);
+    hd_prologue<KC>(p, g, psc, psf);
     // data gradient, A operand: wd[c][n][reg] (lane (i, g)) = W[input channel 16c + i][class 16n + 4g + reg]
     float wd[KC][NT][4];
 #pragma unroll
@@ -211,57 +281,70 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
     for (int c = 0; c < KC; ++c)
 #pragma unroll
         for (int n = 0; n < NT; ++n) wacc[c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float db[NT][4];
+    f2 db[NT][2];
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) db[n][reg] = 0.f;
+    for (int n = 0; n < NT; ++n) db[n][0] = db[n][1] = (f2){0.f, 0.f};
     // BatchNorm-backward sums of x's producer (p.bst; KC == 1): this lane's four input channels 4g .. 4g + 3 over its voxels
     const bool bst = KC == 1 && p.bst != nullptr;
     float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsf = bsc, bmu = bsc;
     float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs2[4] = {0.f, 0.f, 0.f, 0.f};
     if (bst) { bsc = *reinterpret_cast<const float4*>(p.ps + 4 * g); bsf = *reinterpret_cast<const float4*>(p.pt + 4 * g); bmu = *reinterpret_cast<const float4*>(p.pmean + 4 * g); }
     const long long chunks_per_sample = (p.V + 255) / 256, nchunks = chunks_per_sample * p.N;
+    float4 an[MT][KC]; int reln[MT];
+    auto fetch = [&](long long cb) {                           // the input quads and labels of chunk cb, one iteration ahead of their use
+        const int n_s = (int)(cb / chunks_per_sample);
+        const long long vbase = (cb - (long long)n_s * chunks_per_sample) * 256 + wave * 64;
+        hd_load<KC, T>(p, reinterpret_cast<const T*>(p.x) + (long long)n_s * p.V * p.K, vbase, i, g, an);
+        hd_labels(p, (long long)n_s * p.V, vbase, i, g, reln);
+    };
+    if ((long long)blockIdx.x < nchunks) fetch(blockIdx.x);
     for (long long cb = blockIdx.x; cb < nchunks; cb += gridDim.x) {
         const int n_s = (int)(cb / chunks_per_sample);
         const long long vbase = (cb - (long long)n_s * chunks_per_sample) * 256 + wave * 64;
         const T* xs = reinterpret_cast<const T*>(p.x) + (long long)n_s * p.V * p.K;
         T* dxs = reinterpret_cast<T*>(p.dx) + (long long)n_s * p.V * p.K;
-        const long long lbase = (long long)n_s * p.V;
         const float* c0 = p.coef + (size_t)n_s * p.C;                  // coef[0][n][c]
         const float* c1 = p.coef + (size_t)(p.N + n_s) * p.C;          // coef[1][n][c]
-        float4 a[MT][KC]; f32x4 acc[MT][NT];
-        hd_probs<KC, NT, T>(p, xs, vbase, i, g, wf, bv, a, acc);
+        float4 a[MT][KC]; f32x4 acc[MT][NT]; int rel[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            rel[t] = hd_rel(p, reln[t], vbase + t * 16 + i, g);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) a[t][c] = an[t][c];
+        }
+        fetch(min(cb + (long long)gridDim.x, nchunks - 1));      // (the last iteration re-reads a chunk)
+        hd_probs<KC, NT, T>(p, vbase, i, g, psc, psf, wf, bv, a, acc);
         // activated input tile -> LDS [voxel][cin] (A operand of the weight-gradient GEMM, read transposed)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int c = 0; c < KC; ++c) *reinterpret_cast<float4*>(xl + (t * 16 + i) * LDX + 16 * c + 4 * g) = a[t][c];
-        float k0[NT][4], k1[NT][4];
+        f2 k0[NT][2], k1[NT][2];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) { k0[n][reg] = c0[16 * n + 4 * g + reg]; k1[n][reg] = c1[16 * n + 4 * g + reg]; }
+            for (int h = 0; h < 2; ++h) {
+                k0[n][h] = (f2){c0[16 * n + 4 * g + 2 * h], c0[16 * n + 4 * g + 2 * h + 1]};
+                k1[n][h] = (f2){c1[16 * n + 4 * g + 2 * h], c1[16 * n + 4 * g + 2 * h + 1]};
+            }
         // d loss / d logits = gl * p * (g - sum_c g p),  g = coef0 [label == c] + coef1   (Dice backward through the softmax Jacobian)
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const long long vox = vbase + t * 16 + i;
-            const int rel = (vox < p.V ? (int)hd_label(p.labels, p.label_bytes, lbase + vox) : -1) - 4 * g;
-            float gg[NT][4], dot = 0.f;
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { gg[n][reg] = k0[n][reg] * (rel == 16 * n + reg ? 1.f : 0.f) + k1[n][reg]; dot += gg[n][reg] * acc[t][n][reg]; }
-            dot = da_rows_sum(dot);
+            f2 mk[NT][2], gg[NT][2], pr[NT][2], dot2 = (f2){0.f, 0.f};
+            hd_mask<NT>(rel[t], mk);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                pr[n][0] = hd_lo(acc[t][n]); pr[n][1] = hd_hi(acc[t][n]);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float d = gl * acc[t][n][reg] * (gg[n][reg] - dot);       // voxels past the end: p = 0 -> 0
-                    db[n][reg] += d;
-                    acc[t][n][reg] = d;
-                }
-                *reinterpret_cast<float4*>(dl + (t * 16 + i) * LDD + 16 * n + 4 * g) = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
+                for (int h = 0; h < 2; ++h) { gg[n][h] = k0[n][h] * mk[n][h] + k1[n][h]; dot2 += gg[n][h] * pr[n][h]; }
+            }
+            const f2 dot = hd_bc(da_rows_sum(dot2.x + dot2.y)), gl2 = hd_bc(gl);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f2 d0 = (gl2 * pr[n][0]) * (gg[n][0] - dot), d1 = (gl2 * pr[n][1]) * (gg[n][1] - dot);       // voxels past the end: p = 0 -> 0
+                db[n][0] += d0; db[n][1] += d1;
+                acc[t][n] = (f32x4){d0.x, d0.y, d1.x, d1.y};
+                *reinterpret_cast<float4*>(dl + (t * 16 + i) * LDD + 16 * n + 4 * g) = make_float4(d0.x, d0.y, d1.x, d1.y);
             }
         }
         // data gradient: dx^T[k][voxel] = sum_c W[k][c] dl[c][voxel]; the dl registers are the B operand as they stand
@@ -326,7 +409,7 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    float d = db[n][reg];
+                    float d = db[n][reg >> 1][reg & 1];
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) d += __shfl_xor(d, o);
                     const int cidx = K * C + 16 * n + 4 * g + reg;
