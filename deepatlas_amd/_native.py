@@ -34,7 +34,7 @@ SIGNATURES = {
     'da_w_tio_to_iok_flip_acc': (I, [P, P, I, I, I, P]),
     'da_conv3d_k3_ws_bytes': (SZ, [I, I, I, I, I, I, I]),
     'da_conv3d_k3_pack_bytes': (SZ, [I, I, I, I, I, I]),
-    'da_conv3d_k3_dgrad_bst': (I, [P, P, P, I, I, I, I, I, I, P, P, F, P, I, P, P, SZ, P]),
+    'da_conv3d_k3_dgrad_bst': (I, [P, P, P, I, P, I, I, I, I, I, I, P, P, F, P, I, P, P, SZ, P]),
     'da_conv3d_k3_prepack': (I, [P, I, I, I, I, I, I, I, I, P, SZ, P, SZ, P, P]),
     'da_conv3d_k3_use_prepacked': (None, [P, P, SZ, P, SZ]),
     'da_conv3d_k3_prepack_many': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -2651,12 +2651,14 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
     const int NT = (Cout + 15) / 16;
     int NREP = pick_nrep(NT);
     if ((bf || split || pro) && NREP > 2) NREP = 2;        // bf16 mode is not matrix-bound, three N-tiles would spill; the prologue variant parks the whole next tile in registers
+    const bool want_bst = g_bst.y != nullptr && split && stats_partial != nullptr;
+    if (want_bst) NREP = 1;                                // the BatchNorm-backward epilogue holds TY quads of the producer's output: one N-tile per workgroup
     {   // Coarse levels have few tiles (30 per volume at 20x24x20, 180 at 40x48x40): the persistent grid then runs one or two
         // uneven rounds.  Makespan model: a workgroup walks ceil(tiles / nblk) tiles, each costing ~NREP (one N-tile per
         // workgroup is ~8 % less efficient per FLOP but quadruples / doubles the number of work items); take the cheaper.
         static int adapt = -1; if (adapt < 0) { const char* e = getenv("DA_NREP_ADAPT"); adapt = e ? atoi(e) : 1; }
         const long long tiles = (long long)N * ((D + 3) / 4) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
-        if (adapt && s2d_cin == 0 && NREP > 1) {
+        if (adapt && s2d_cin == 0 && NREP > 1 && !want_bst) {
             auto cost = [&](int nrep) {
                 const int g = (NT + nrep - 1) / nrep;
                 long long nb = 512 / g; if (nb < 1) nb = 1; if (nb > tiles) nb = tiles;
@@ -2750,8 +2752,8 @@ static int conv3_mfma_fwd_impl(const float* in1, int C1, const float* in2, int C
             return stats_partial ? (pro ? launch_fwd_mfma<8, 1, false, true, true, true, false, true, 0, false, false, 3>(p, gy, st) : launch_fwd_mfma<8, 1, false, true, true, false, false, true, 0, false, false, 3>(p, gy, st))
                                  : (pro ? launch_fwd_mfma<8, 1, false, false, true, true, false, true, 0, false, false, 3>(p, gy, st) : launch_fwd_mfma<8, 1, false, false, true, false, false, true, 0, false, false, 3>(p, gy, st));
         p.bst_y = nullptr; p.bst_par = nullptr; p.bst_slope = -1.f;
-        if (g_bst.y) {                                       // (da_conv3d_k3_dgrad_bst checked the shape: one N-tile, one output tensor, no prologue)
-            if (!(stats_partial && NREP == 1 && !pro && Cs2 == 0 && gy == 1)) return DA_ERR_UNSUPPORTED;
+        if (want_bst) {                                      // (da_conv3d_k3_dgrad_bst checked the shape: one output tensor of <= 32 channels, no prologue)
+            if (!(NREP == 1 && !pro && Cs2 == 0 && gy <= 2)) return DA_ERR_UNSUPPORTED;
             p.bst_y = g_bst.y; p.bst_par = g_bst.par; p.bst_slope = g_bst.slope;
             return launch_fwd_mfma<8, 1, false, 2, true, false, false, true>(p, gy, st);      // (unpaired staging: with the pair's second parked chunk the eight y quads of the epilogue spill)
         }
@@ -3182,20 +3184,38 @@ extern "C" int da_conv3d_k3_prepack_many(int n, const float* const* w_tio, const
     return rc;
 }
 
-// da_conv3d_k3_dgrad of a one-input layer whose input was act(BN(y)) applied on the fly (y = the producer's raw conv output, `stats4` = its statistics
-// rows [mean | rstd | scale | shift][C1], `slope` its activation): besides dx -- the gradient with respect to the ACTIVATED tensor, as always -- the
+// da_conv3d_k3_dgrad of a layer whose FIRST input was act(BN(y)) applied on the fly (y = the producer's raw conv output, `stats4` = its statistics
+// rows [mean | rstd | scale | shift][C1], `slope` its activation): besides dx1 -- the gradient with respect to the ACTIVATED tensor, as always -- the
 // epilogue accumulates the producer's BatchNorm-backward sums, bst[*bst_n][2][C1] doubles = (sum dz, sum dz (y - mean)), dz = dx act'(y scale + shift),
-// for da_bn_act_bwd_dbias_pre: the stand-alone reduction pass over (dx, y) is not needed.  Split matrix mode, <= 16 input channels of the layer
-// (one N-tile); anything else returns DA_ERR_UNSUPPORTED and the caller runs da_conv3d_k3_dgrad + the usual BatchNorm backward.  autograd of unets.py:30-32.
-extern "C" int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float* dx1, int C1, int N, int D, int H, int W, int Cout,
+// for da_bn_act_bwd_dbias_pre: the stand-alone reduction pass over (dx1, y) is not needed.  Split matrix mode; one-input layers of <= 16 channels, and
+// concat layers (dx2 / C2: the decoder's 48 <- 16 data gradient, C1 = 32 up-sampled channels first, unets.py:275) as two launches -- dx1 with one
+// N-tile per workgroup and the epilogue, dx2 as da_conv3d_k3_dgrad does it.  Anything else returns DA_ERR_UNSUPPORTED and the caller runs
+// da_conv3d_k3_dgrad + the usual BatchNorm backward.  autograd of unets.py:30-32.
+extern "C" int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2, int N, int D, int H, int W, int Cout,
                                       const float* y, const float* stats4, float slope, double* bst, int bst_cap, int* bst_n,
                                       void* ws, size_t ws_bytes, void* stream) {
     if (bst_n) *bst_n = 0;
-    if (!dy || !w_tio || !dx1 || !y || !stats4 || !bst || !bst_n || C1 <= 0 || N <= 0 || Cout <= 0) return DA_ERR_BADARG;
-    if (da_matrix_mode() != 2 || C1 > 16 || C1 % 4 != 0 || bst_cap < 512 || !da_conv3_mfma_fwd_supported(Cout, 0, C1, 1, C1, 0)) return DA_ERR_UNSUPPORTED;
-    if (ws_bytes < da_conv3_mfma_ws_bytes(N, D, H, W, C1, Cout, 1)) return DA_ERR_WS_SMALL;
+    if (!dy || !w_tio || !dx1 || !y || !stats4 || !bst || !bst_n || C1 <= 0 || C2 < 0 || (C2 > 0 && !dx2) || N <= 0 || Cout <= 0) return DA_ERR_BADARG;
+    if (da_matrix_mode() != 2 || bst_cap < 512) return DA_ERR_UNSUPPORTED;
+    if (C2 == 0) {
+        if (C1 > 16 || C1 % 4 != 0 || !da_conv3_mfma_fwd_supported(Cout, 0, C1, 1, C1, 0)) return DA_ERR_UNSUPPORTED;
+        if (ws_bytes < da_conv3_mfma_ws_bytes(N, D, H, W, C1, Cout, 1)) return DA_ERR_WS_SMALL;
+        g_bst = BstState{y, stats4, slope};
+        const int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, nullptr, 0, N, D, H, W, C1, 1, -1.f, ws, ws_bytes, (hipStream_t)stream, 0, bst, bst_n);
+        g_bst = BstState{nullptr, nullptr, -1.f};
+        return rc;
+    }
+    if (C1 != 32 || C2 % 16 != 0 || C2 > 16 || !da_conv3_mfma_fwd_supported(Cout, 0, C1 + C2, 1, C1, C2) || pick_ck(Cout, 0) == 0) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_conv3_mfma_ws_bytes(N, D, H, W, C1 + C2, Cout, 1)) return DA_ERR_WS_SMALL;
+    struct PpReset { ~PpReset() { if (g_pp.mode == 1) g_pp.mode = 0; } } pp_reset;
+    if (g_pp.mode && g_pp.w != w_tio) g_pp.mode = 0;
     g_bst = BstState{y, stats4, slope};
-    const int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, nullptr, 0, N, D, H, W, C1, 1, -1.f, ws, ws_bytes, (hipStream_t)stream, 0, bst, bst_n);
+    int rc = conv3_mfma_fwd_impl(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, nullptr, 0, N, D, H, W, C1, 1, -1.f, ws, ws_bytes, (hipStream_t)stream, 0, bst, bst_n,
+                                 nullptr, nullptr, 0, C1 + C2, false);
     g_bst = BstState{nullptr, nullptr, -1.f};
+    if (rc) { *bst_n = 0; return rc; }
+    rc = conv3_mfma_fwd_impl(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx2, C2, nullptr, 0, N, D, H, W, C2, 1, -1.f, ws, ws_bytes, (hipStream_t)stream, 0, nullptr, nullptr,
+                             nullptr, nullptr, C1, C1 + C2, false);
+    if (rc) *bst_n = 0;
     return rc;
 }

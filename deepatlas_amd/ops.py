@@ -1279,7 +1279,8 @@ class ConvBNActFn(Function):
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
             use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W)
             done = False
-            if (FUSE_BN_BWD_STATS and pro1 is not None and a2 is None and C1 <= 16 and _matrix_mode == 'fp32_split' and dy.dtype == torch.float32
+            if (FUSE_BN_BWD_STATS and pro1 is not None and ((a2 is None and C1 <= 16) or (a2 is not None and C1 == 32 and C2 == 16 and a2.dtype == torch.float32))
+                    and _matrix_mode == 'fp32_split' and dy.dtype == torch.float32
                     and a1.dtype == torch.float32 and p1s.data_ptr() - 8 * C1 == p1t.data_ptr() - 12 * C1 and p1s.untyped_storage().data_ptr() <= p1s.data_ptr() - 8 * C1
                     and not torch.cuda.is_current_stream_capturing()):
                 # the input was the raw output of a conv + BatchNorm block (a1) with its statistics rows (mean, rstd, scale, shift): that block's
@@ -1287,7 +1288,7 @@ class ConvBNActFn(Function):
                 import ctypes
                 bst = torch.empty((512, 2, C1), dtype=torch.float64, device=a1.device)
                 nb = ctypes.c_int(0)
-                done = nat.call_supported('da_conv3d_k3_dgrad_bst', ptr(dy), ptr(w_tio), ptr(dx1), C1, N, D, H, W, Cout, ptr(a1), ctypes.c_void_p(p1s.data_ptr() - 8 * C1),
+                done = nat.call_supported('da_conv3d_k3_dgrad_bst', ptr(dy), ptr(w_tio), ptr(dx1), C1, ptr(dx2), C2, N, D, H, W, Cout, ptr(a1), ctypes.c_void_p(p1s.data_ptr() - 8 * C1),
                                           float(ctx.pro_slopes[0]), ptr(bst), 512, ctypes.byref(nb), wp, wn, st) and nb.value > 0
                 if done:
                     _bwd_stats[dx1.data_ptr()] = (dx1, bst, nb.value, N * D * H * W, C1)

@@ -348,12 +348,13 @@ int da_head_dice_bwd_bst(const float* x, const float* pro_scale, const float* pr
                          const float* coef, const float* dloss, float* dx, float* dw_io, float* dbias,
                          int N, long long V, int Cin, int C, double* bst, int bst_cap, int* bst_n, void* ws, size_t ws_bytes, void* stream);
 
-/* da_conv3d_k3_dgrad of a ONE-input layer (C1 <= 16 channels) whose input was act(BN(y)) applied on the fly: y = the producer's raw conv output,
- * stats4 = its statistics rows [mean | rstd | scale | shift][C1], slope its activation.  dx1 as always (gradient with respect to the ACTIVATED tensor); the
- * epilogue also accumulates the PRODUCER's BatchNorm-backward sums, bst[*bst_n][2][C1] doubles = (sum dz, sum dz (y - mean)), dz = dx act'(y scale + shift),
- * for da_bn_act_bwd_dbias_pre -- no reduction pass over (dx, y).  Split matrix mode only; DA_ERR_UNSUPPORTED: run da_conv3d_k3_dgrad and the usual backward.
- * autograd of nn.Conv3d -> nn.BatchNorm3d -> nn.LeakyReLU chains (unets.py:30-37). */
-int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float* dx1, int C1, int N, int D, int H, int W, int Cout,
+/* da_conv3d_k3_dgrad of a layer whose FIRST input was act(BN(y)) applied on the fly: y = the producer's raw conv output, stats4 = its statistics rows
+ * [mean | rstd | scale | shift][C1], slope its activation.  dx1 / dx2 as always (gradients with respect to the ACTIVATED tensors); the epilogue also accumulates
+ * the PRODUCER's BatchNorm-backward sums, bst[*bst_n][2][C1] doubles = (sum dz, sum dz (y - mean)), dz = dx1 act'(y scale + shift), for
+ * da_bn_act_bwd_dbias_pre -- no reduction pass over (dx1, y).  Shapes: one input of <= 16 channels (dx2 NULL, C2 0), or the decoder's concat layer (C1 = 32
+ * up-sampled channels, C2 = 16 skip channels; unets.py:275).  Split matrix mode only; DA_ERR_UNSUPPORTED: run da_conv3d_k3_dgrad and the usual backward.
+ * autograd of nn.Conv3d / nn.ConvTranspose3d -> nn.BatchNorm3d -> nn.LeakyReLU chains (unets.py:30-37, 50-53). */
+int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2, int N, int D, int H, int W, int Cout,
                            const float* y, const float* stats4, float slope, double* bst, int bst_cap, int* bst_n,
                            void* ws, size_t ws_bytes, void* stream);
 
