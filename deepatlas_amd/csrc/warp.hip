@@ -4,6 +4,7 @@
 // NDHWC: src[N][D][H][W][C], disp[N][D][H][W][3] with channel order (x, y, z) = (W, H, D) axis.
 // HBM-bound gather: 12-byte disp read + 8 corner taps of C contiguous floats (16-byte lanes when C % 4 == 0).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -568,6 +569,77 @@ __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int b
     }
 }
 
+// The same scatter through an LDS box (round 5).  A workgroup takes a BX x BY x BZ box of TARGET voxels; a registration field moves a voxel by a
+// voxel or two, so nearly all of its 8 * BX * BY * BZ weights land in the box grown by M cells on every side -- they are added there with LDS
+// atomics, one copy of the grown box per label present (piecewise-constant label maps: up to K labels per box get a copy, found / claimed through a
+// K-entry table), and the box is then flushed with ONE global atomic per non-zero cell, rows of consecutive floats.  A weight that falls outside the
+// grown box, or whose label found no copy, goes to global memory directly as before: any field is handled, a wild one just gains nothing.
+// 8 scattered global atomics per voxel become ~2 coalesced ones (boxes overlap in their margins, so the flush still has to add).
+template <int BX, int BY, int BZ, int M, int K>
+__global__ void __launch_bounds__(256) warp_adjoint_labels_box_kernel(const void* __restrict__ lab_t, int bt, const float* __restrict__ disp,
+                                                                      float* __restrict__ A_extra, float* __restrict__ B, int N, int D, int H, int W, int C,
+                                                                      int nbx, int nby, int nbz) {
+    constexpr int LX = BX + 2 * M + 1, LY = BY + 2 * M + 1, LZ = BZ + 2 * M + 1, CELLS = LX * LY * LZ, NV = BX * BY * BZ;
+    extern __shared__ float box[];                            // [K][CELLS]
+    __shared__ int slot_label[K];
+    const long long V = (long long)D * H * W;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby; b /= nby;
+    const int bz = b % nbz; const int n = b / nbz;
+    const int ox = bx * BX - M, oy = by * BY - M, oz = bz * BZ - M;      // volume coordinates of box cell (0, 0, 0)
+    for (int i = threadIdx.x; i < K * CELLS; i += 256) box[i] = 0.f;
+    if (threadIdx.x < K) slot_label[threadIdx.x] = -1;
+    __syncthreads();
+    const long long sbase = (long long)n * V;
+#pragma unroll 1
+    for (int l = threadIdx.x; l < NV; l += 256) {
+        const int x = bx * BX + l % BX, y = by * BY + (l / BX) % BY, z = bz * BZ + l / (BX * BY);
+        if (x >= W || y >= H || z >= D) continue;
+        const long long v = sbase + ((long long)z * H + y) * W + x;
+        const float gx = disp[v * 3 + 0] + id_coord(x, W), gy = disp[v * 3 + 1] + id_coord(y, H), gz = disp[v * 3 + 2] + id_coord(z, D);
+        if (!is_finite_coord(gx, gy, gz)) continue;
+        const Taps t = make_taps(gx, gy, gz, D, H, W);
+        const int lab = warp_label_at(lab_t, bt, v);
+        const bool lok = lab >= 0 && lab < C;
+        float* plane = lok ? B + ((long long)n * C + lab) * V : (A_extra ? A_extra + sbase : nullptr);
+        if (!plane) continue;
+        int slot = -1;
+        if (lok) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (slot < 0) {
+                    int cur = slot_label[k];
+                    if (cur == -1) cur = atomicCAS(&slot_label[k], -1, lab), cur = cur == -1 ? lab : cur;
+                    if (cur == lab) slot = k;
+                }
+            }
+        }
+        const int cx0 = t.x0 - ox, cy0 = t.y0 - oy, cz0 = t.z0 - oz;
+        const bool inbox = slot >= 0 && cx0 >= 0 && cx0 + 1 < LX && cy0 >= 0 && cy0 + 1 < LY && cz0 >= 0 && cz0 + 1 < LZ;
+        float* lb = box + slot * CELLS + (cz0 * LY + cy0) * LX + cx0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cz = k >> 2, cy = (k >> 1) & 1, cx = k & 1;
+            const int xx = t.x0 + cx, yy = t.y0 + cy, zz = t.z0 + cz;
+            const float wgt = (cx ? t.fx0 : t.fx1) * (cy ? t.fy0 : t.fy1) * (cz ? t.fz0 : t.fz1);
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D && wgt != 0.f) {
+                if (inbox) atomicAdd(lb + (cz * LY + cy) * LX + cx, wgt);
+                else atomicAdd(plane + ((long long)zz * H + yy) * W + xx, wgt);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * CELLS; i += 256) {
+        const float val = box[i];
+        if (val != 0.f) {
+            const int k = i / CELLS, c = i - k * CELLS;
+            const int cx = c % LX, cy = (c / LX) % LY, cz = c / (LX * LY);
+            atomicAdd(B + ((long long)n * C + slot_label[k]) * V + ((long long)(oz + cz) * H + (oy + cy)) * W + (ox + cx), val);      // (only in-volume cells were added to)
+        }
+    }
+}
+
 // dlogits[u][j] = p[u][j] (g[u][j] - sum_c g[u][c] p[u][c]),  g = gl_a (b_a[c] A[u] + a_a[c] B[c][u]) + gl_s (a_s[c] [Sm[u] == c] + b_s[c]),
 // p = softmax(logits) given as `prob` ([N][V][C]); B class-major ([N][C][V], see above); dlogits [N][V][C].  A workgroup takes `tv`
 // consecutive voxels: the C planes' segments are read coalesced into an LDS tile [C][tv + 1], then lpv = C / 4 lanes per voxel form the
@@ -819,6 +891,25 @@ extern "C" int da_warp_adjoint_labels(const void* lab_t, int lab_t_bytes, const 
     hipError_t e = hipMemsetAsync(B, 0, (size_t)nvox * C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     if (A) { e = hipMemsetAsync(A, 0, (size_t)nvox * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+    static const int use_box = [] { const char* e = getenv("DA_ADJ_BOX"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (use_box) {
+        constexpr int BX = 32, BY = 8, BZ = 4, M = 2, K = 3;
+        constexpr size_t shm = (size_t)K * (BX + 2 * M + 1) * (BY + 2 * M + 1) * (BZ + 2 * M + 1) * sizeof(float);
+        auto kern = warp_adjoint_labels_box_kernel<BX, BY, BZ, M, K>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const int nbx = (W + BX - 1) / BX, nby = (H + BY - 1) / BY, nbz = (D + BZ - 1) / BZ;
+        const long long nb = (long long)nbx * nby * nbz * N;
+        if (nb < (1ll << 31)) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), shm, st, lab_t, lab_t_bytes, disp, A, B, N, D, H, W, C, nbx, nby, nbz);
+            DA_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(warp_adjoint_labels_kernel, dim3(da_grid(nvox, 256)), dim3(256), 0, st, lab_t, lab_t_bytes, disp, A, B, N, D, H, W, C);
     DA_LAUNCH_CHECK();
     return 0;

@@ -1281,8 +1281,9 @@ class ConvBNActFn(Function):
             done = False
             if (FUSE_BN_BWD_STATS and pro1 is not None and ((a2 is None and C1 <= 16) or (a2 is not None and C1 == 32 and C2 == 16 and a2.dtype == torch.float32))
                     and _matrix_mode == 'fp32_split' and dy.dtype == torch.float32
-                    and a1.dtype == torch.float32 and p1s.data_ptr() - 8 * C1 == p1t.data_ptr() - 12 * C1 and p1s.untyped_storage().data_ptr() <= p1s.data_ptr() - 8 * C1
-                    and not torch.cuda.is_current_stream_capturing()):
+                    and a1.dtype == torch.float32 and p1s.data_ptr() - 8 * C1 == p1t.data_ptr() - 12 * C1 and p1s.untyped_storage().data_ptr() <= p1s.data_ptr() - 8 * C1):
+                # (also while a HIP graph is being captured: whether the route exists is decided on the host, and a graphed step must run the same kernels --
+                # the same summation order -- as an eager one: tests/test_gpu_dp.py compares them bit for bit)
                 # the input was the raw output of a conv + BatchNorm block (a1) with its statistics rows (mean, rstd, scale, shift): that block's
                 # BatchNorm-backward sums are accumulated in this data gradient's epilogue instead of a pass over (dx1, a1)
                 import ctypes
