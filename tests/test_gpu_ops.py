@@ -297,6 +297,52 @@ def test_ncc_bending_golden(golden):
     assert abs(l2.item() - g['ops/bending/loss_spacing']) < 1e-4 * abs(g['ops/bending/loss_spacing'])
 
 
+def test_adjoint_label_scatter_box_and_direct_paths():
+    """da_warp_adjoint_labels, B[n][c][u] = sum over target voxels v with label c of the trilinear weight v puts on source voxel u (the adjoint of
+    voxel_morph.py:90-91's warp applied to one-hot labels): the LDS-box kernel against a float64 scatter built from the same taps.  Fields: small and
+    smooth (everything lands in the grown box), eight voxels of noise (everything takes the direct global atomics), and a mix; labels: piecewise constant
+    (<= 3 per box) and per-voxel random (more labels than a box has copies); ragged sizes; coordinates outside the volume and a NaN."""
+    from deepatlas_amd import _native as nat
+    call, ptr = nat.call, nat.ptr
+    g = torch.Generator().manual_seed(5)
+    N, D, H, W, C = 2, 11, 21, 45, 5
+    V = D * H * W
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing='ij')
+    blocky = ((zz // 6 + yy // 9 + xx // 14) % C).to(torch.uint8)
+    labs = {'blocky': torch.stack([blocky, (blocky + 1) % C]), 'random': torch.randint(0, C, (N, D, H, W), generator=g, dtype=torch.uint8)}
+    scale = torch.tensor([2.0 / (W - 1), 2.0 / (H - 1), 2.0 / (D - 1)])
+    fields = {'smooth': torch.randn((N, 1, 1, 1, 3), generator=g).expand(N, D, H, W, 3) * 0.7 * scale + torch.randn((N, D, H, W, 3), generator=g) * 0.2 * scale,
+              'noise8': torch.randn((N, D, H, W, 3), generator=g) * 8.0 * scale}
+    mix = fields['smooth'].clone(); mix[:, ::2] = fields['noise8'][:, ::2]; mix[0, 3, 4, 5, 0] = float('nan'); mix[1, 2, 3, 4] = 7.0
+    fields['mix'] = mix
+    ident = torch.stack([xx * scale[0] - 1, yy * scale[1] - 1, zz * scale[2] - 1], -1).double()
+    for ln, lab in labs.items():
+        for fn, u in fields.items():
+            u = u.contiguous()
+            ref = torch.zeros((N, C, V), dtype=torch.float64)
+            grid = u.double() + ident
+            fin = (grid.abs() < 1e9).all(-1) & ~torch.isnan(grid).any(-1)
+            pos = [((torch.nan_to_num(grid[..., a]) + 1) / 2) * (s - 1) for a, s in ((0, W), (1, H), (2, D))]
+            p0 = [torch.floor(q) for q in pos]
+            for cz in (0, 1):
+                for cy in (0, 1):
+                    for cx in (0, 1):
+                        ix, iy, iz = p0[0] + cx, p0[1] + cy, p0[2] + cz
+                        wgt = ((pos[0] - p0[0]) if cx else (p0[0] + 1 - pos[0])) * ((pos[1] - p0[1]) if cy else (p0[1] + 1 - pos[1])) * ((pos[2] - p0[2]) if cz else (p0[2] + 1 - pos[2]))
+                        ok = fin & (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H) & (iz >= 0) & (iz < D)
+                        for n in range(N):
+                            sel = ok[n]
+                            dst = lab[n][sel].long() * V + ((iz[n][sel] * H + iy[n][sel]) * W + ix[n][sel]).long()
+                            ref[n].view(-1).index_add_(0, dst, wgt[n][sel])
+            B = torch.full((N, C, V), 7.0, device=dev())                 # (the launcher zero-fills)
+            ud, ld = u.float().to(dev()).contiguous(), lab.to(dev()).contiguous()
+            call('da_warp_adjoint_labels', ptr(ld), 1, ptr(ud), None, ptr(B), N, D, H, W, C, nat.stream())
+            torch.cuda.synchronize()
+            err = (B.cpu().double() - ref).abs().max().item()
+            assert err < 2e-5, (ln, fn, err)
+            assert abs(B.sum().item() - ref.sum().item()) < 1e-2 * max(1.0, ref.sum().item() * 1e-3), (ln, fn)
+
+
 def test_softmax():
     from deepatlas_amd import ops
     for C in (32, 5):
