@@ -81,6 +81,7 @@ SIGNATURES = {
     'da_maxpool2_fwd_pro': (I, [P, P, P, F, P, P, I, I, I, I, I, P]),
     'da_maxpool2_bwd': (I, [P, P, P, I, I, I, I, I, P]),
     'da_maxpool2_bwd_add': (I, [P, P, P, P, I, I, I, I, I, P]),
+    'da_maxpool2_bwd_bst': (I, [P, P, P, P, I, I, I, I, I, P, F, P, I, P, P]),
     'da_upsample_nearest_fwd': (I, [P, P, I, I, I, I, I, I, I, I, P]),
     'da_upsample_nearest_bwd': (I, [P, P, I, I, I, I, I, I, I, I, P]),
     'da_warp_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -111,6 +111,77 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ dy, const T* __restric
     }
 }
 
+// The same with the pooled tensor given as the RAW producer output it was computed from (deferred BatchNorm + activation, maxpool2_fwd_pro_kernel):
+// the activated values are formed again with that kernel's own expression (so the arg-max is the one the stored skip tensor has), and -- dx and the
+// raw value being in registers -- the kernel also accumulates the PRODUCER's BatchNorm-backward sums, bst[workgroup][2][C] doubles =
+// (sum dz, sum dz (x - mean)), dz = dx act'(x scale + shift): the reduction pass over (dx, x) that BatchNorm's backward would start with is not
+// needed (da_bn_act_bwd_dbias_pre).  fp32 tensors, C / 4 a power of two <= 64 (a lane keeps its channel quad for the whole launch), even D, H, W.
+__global__ void __launch_bounds__(256) maxpool2_bwd_bst_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                                               int N, int D, int H, int W, int C, const float* __restrict__ add,
+                                                               const float* __restrict__ par, float slope, double* __restrict__ bst) {
+    __shared__ double sred[4][2][64 * 4];
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, cq = C / 4;
+    const long long total = (long long)N * Do * Ho * Wo * cq;
+    const int q = (int)(threadIdx.x & (unsigned)(cq - 1));           // gridDim.x * 256 is a multiple of cq: the same quad in every iteration
+    const float4 mu = reinterpret_cast<const float4*>(par)[q], sc = reinterpret_cast<const float4*>(par + 2 * C)[q], sf = reinterpret_cast<const float4*>(par + 3 * C)[q];
+    const float s = slope < 0.f ? 1.f : slope;                    // the forward's max(z, z s)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
+    int cnt = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long v = i / cq;
+        int n, od, oh, ow; da_vox4(v, Do, Ho, Wo, n, od, oh, ow);
+        const float4 g4 = da_ldq(dy, (((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + q * 4) >> 2);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float4 a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            a[t] = da_ldq(x, (((((long long)n * D + d) * H + h) * W + w) * C + q * 4) >> 2);
+        }
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int am[4] = {0, 0, 0, 0};
+        float4 zz[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float4 z;
+            z.x = a[t].x * sc.x + sf.x; z.y = a[t].y * sc.y + sf.y; z.z = a[t].z * sc.z + sf.z; z.w = a[t].w * sc.w + sf.w;
+            zz[t] = z;
+            z.x = fmaxf(z.x, z.x * s); z.y = fmaxf(z.y, z.y * s); z.z = fmaxf(z.z, z.z * s); z.w = fmaxf(z.w, z.w * s);
+            const float e[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (e[j] > m[j] || e[j] != e[j]) { m[j] = e[j]; am[j] = t; }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int d = od * 2 + (t >> 2), h = oh * 2 + ((t >> 1) & 1), w = ow * 2 + (t & 1);
+            const long long off = ((((long long)n * D + d) * H + h) * W + w) * C + q * 4;
+            float4 o = make_float4(am[0] == t ? g[0] : 0.f, am[1] == t ? g[1] : 0.f, am[2] == t ? g[2] : 0.f, am[3] == t ? g[3] : 0.f);
+            if (add) { const float4 e = da_ldq(add, off >> 2); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+            da_stq(dx, off >> 2, o);
+            const float dz0 = o.x * da_act_grad(zz[t].x, slope), dz1 = o.y * da_act_grad(zz[t].y, slope), dz2 = o.z * da_act_grad(zz[t].z, slope), dz3 = o.w * da_act_grad(zz[t].w, slope);
+            s1[0] += dz0; s1[1] += dz1; s1[2] += dz2; s1[3] += dz3;
+            s2[0] += dz0 * (a[t].x - mu.x); s2[1] += dz1 * (a[t].y - mu.y); s2[2] += dz2 * (a[t].z - mu.z); s2[3] += dz3 * (a[t].w - mu.w);
+        }
+        if (++cnt == 8) {                                         // fp32 over 64 voxels, double beyond
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { d1[j] += (double)s1[j]; d2[j] += (double)s2[j]; s1[j] = 0.f; s2[j] = 0.f; }
+            cnt = 0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double u = d1[j] + (double)s1[j], w2 = d2[j] + (double)s2[j];
+        for (int o = cq; o < 64; o <<= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }      // lanes with the same quad
+        if (lane < cq) { sred[wave][0][lane * 4 + j] = u; sred[wave][1][lane * 4 + j] = w2; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C) {
+        const int k = (int)threadIdx.x / C, c = (int)threadIdx.x % C;
+        bst[((size_t)blockIdx.x * 2 + k) * C + c] = (sred[0][k][c] + sred[1][k][c]) + (sred[2][k][c] + sred[3][k][c]);
+    }
+}
+
 // PyTorch nearest (legacy "nearest", not "nearest-exact"): src = min(floor(dst * (float)in/out), in-1)
 __device__ __forceinline__ int nearest_src(int dst, int in, int out, float scale) {
     if (in == out) return dst;
@@ -303,6 +374,22 @@ extern "C" int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N
 extern "C" int da_maxpool2_bwd_add(const float* dy, const float* x, const float* gskip, float* dx, int N, int D, int H, int W, int C, void* stream) {
     if (!gskip) return DA_ERR_BADARG;
     return maxpool2_bwd_t<float>(dy, x, gskip, dx, N, D, H, W, C, stream);
+}
+// da_maxpool2_bwd[_add] on the RAW tensor the pool's forward (da_maxpool2_fwd_pro) was given, + the BatchNorm-backward sums of that tensor's producer
+// (stats4 = its statistics rows [mean | rstd | scale | shift][C], slope its activation): bst[*bst_n][2][C] doubles for da_bn_act_bwd_dbias_pre.
+// DA_ERR_UNSUPPORTED (odd sizes, channel counts, bst_cap < 1024): the caller runs da_maxpool2_bwd[_add] on the activated tensor and the usual backward.
+extern "C" int da_maxpool2_bwd_bst(const float* dy, const float* x_raw, const float* gskip, float* dx, int N, int D, int H, int W, int C,
+                                   const float* stats4, float slope, double* bst, int bst_cap, int* bst_n, void* stream) {
+    if (bst_n) *bst_n = 0;
+    if (!dy || !x_raw || !dx || !stats4 || !bst || !bst_n || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
+    const int cq = C / 4;
+    if (((D | H | W) & 1) || C % 4 != 0 || cq > 64 || (cq & (cq - 1)) != 0 || 2 * C > 256 || bst_cap < 1024 || slope >= 1.f) return DA_ERR_UNSUPPORTED;
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * cq;
+    int nb = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(maxpool2_bwd_bst_kernel, dim3(nb), dim3(256), 0, da_stream(stream), dy, x_raw, dx, N, D, H, W, C, gskip, stats4, slope, bst);
+    DA_LAUNCH_CHECK();
+    *bst_n = nb;
+    return 0;
 }
 extern "C" int da_maxpool2_bwd_bf16(const void* dy, const void* x, void* dx, int N, int D, int H, int W, int C, void* stream) {
     return maxpool2_bwd_t<da_bf16>((const da_bf16*)dy, (const da_bf16*)x, nullptr, (da_bf16*)dx, N, D, H, W, C, stream);

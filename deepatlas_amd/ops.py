@@ -1458,25 +1458,46 @@ class MaxPool2SkipFn(Function):
         N, D, H, W, C = a.shape
         out = _empty((N, D // 2, H // 2, W // 2, C), a, a.dtype)
         st = stream()
+        raw = None
+        ctx.pro_slope = None
         if extra:
             act = torch.empty_like(a)
             if not call_act('da_maxpool2_fwd_pro', A(a), ptr(extra[0]), ptr(extra[1]), float(extra[2]), O(act), O(out), N, D, H, W, C, st, may_decline=True):
                 act = _apply_pro(a, extra, st)
                 call_act('da_maxpool2_fwd', A(act), O(out), N, D, H, W, C, st)
+            ps, pt = extra[0], extra[1]
+            if (FUSE_BN_BWD_STATS and os.environ.get('DA_NO_POOL_BST') != '1' and a.dtype == torch.float32 and ps.data_ptr() - 8 * C == pt.data_ptr() - 12 * C
+                    and ps.untyped_storage().data_ptr() <= ps.data_ptr() - 8 * C):
+                # (scale, shift) are rows of the producer's [mean | rstd | scale | shift] buffer: its BatchNorm-backward sums can ride on this node's backward
+                raw, ctx.pro_slope = a, float(extra[2])
             a = act
         else:
             call_act('da_maxpool2_fwd', A(a), O(out), N, D, H, W, C, st)
-        ctx.save_for_backward(a)
+        if raw is not None:
+            ctx.save_for_backward(a, raw, extra[0])
+        else:
+            ctx.save_for_backward(a)
         return ncdhw(a), ncdhw(out)
 
     @staticmethod
     def backward(ctx, gskip, gpool):
-        a, = ctx.saved_tensors
+        a = ctx.saved_tensors[0]
         N, D, H, W, C = a.shape
         if gpool is None:
             return (gskip,) + (None,) * ctx.n_extra
         g = ndhwc(gpool)
         dx = torch.empty_like(a)
+        if len(ctx.saved_tensors) == 3 and FUSE_BN_BWD_STATS and g.dtype == torch.float32:
+            # the pooled tensor was the raw output of a conv + BatchNorm block: dx and that block's BatchNorm-backward sums from one kernel
+            import ctypes
+            raw, ps = ctx.saved_tensors[1], ctx.saved_tensors[2]
+            bst = torch.empty((1024, 2, C), dtype=torch.float64, device=a.device)
+            nb = ctypes.c_int(0)
+            gs = ndhwc(gskip) if gskip is not None else None
+            if nat.call_supported('da_maxpool2_bwd_bst', ptr(g), ptr(raw), ptr(gs), ptr(dx), N, D, H, W, C, ctypes.c_void_p(ps.data_ptr() - 8 * C),
+                                  ctx.pro_slope, ptr(bst), 1024, ctypes.byref(nb), stream()) and nb.value > 0:
+                _bwd_stats[dx.data_ptr()] = (dx, bst, nb.value, N * D * H * W, C)
+                return (ncdhw(dx),) + (None,) * ctx.n_extra
         if gskip is None:
             call_act('da_maxpool2_bwd', A(g), A(a), O(dx), N, D, H, W, C, stream())
         else:

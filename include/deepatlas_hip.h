@@ -243,6 +243,13 @@ int da_maxpool2_fwd_pro(const float* x, const float* pro_scale, const float* pro
 int da_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int D, int H, int W, int C, void* stream);
 /* dx = gskip + maxpool_bwd(dy): the pooled tensor also feeds a skip connection (unets.py:266-267,275) */
 int da_maxpool2_bwd_add(const float* dy, const float* x, const float* gskip, float* dx, int N, int D, int H, int W, int C, void* stream);
+/* The same (gskip may be NULL) on the RAW tensor da_maxpool2_fwd_pro pooled, whose BatchNorm + activation was applied on the fly: x_raw = the producer's raw
+ * conv output, stats4 = its statistics rows [mean | rstd | scale | shift][C], slope its activation.  The arg-max is that of the activated values (formed again
+ * with the forward's expression); besides dx the kernel accumulates the PRODUCER's BatchNorm-backward sums, bst[*bst_n][2][C] doubles =
+ * (sum dz, sum dz (x - mean)), dz = dx act'(x scale + shift), for da_bn_act_bwd_dbias_pre.  Even D, H, W, C / 4 a power of two, bst_cap >= 1024; else
+ * DA_ERR_UNSUPPORTED.  autograd of nn.MaxPool3d(2) + the skip connection behind conv -> BatchNorm -> LeakyReLU (unets.py:30-37, 266-267). */
+int da_maxpool2_bwd_bst(const float* dy, const float* x_raw, const float* gskip, float* dx, int N, int D, int H, int W, int C,
+                        const float* stats4, float slope, double* bst, int bst_cap, int* bst_n, void* stream);
 
 /* ---- nearest-neighbour up-sampling to a given size (row a8; voxel_morph.py:72,74,76,80) ------ */
 int da_upsample_nearest_fwd(const float* x, float* y, int N, int D, int H, int W, int C,
