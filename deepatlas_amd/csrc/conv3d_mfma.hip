@@ -3198,7 +3198,7 @@ extern "C" int da_conv3d_k3_dgrad_bst(const float* dy, const float* w_tio, float
     if (!dy || !w_tio || !dx1 || !y || !stats4 || !bst || !bst_n || C1 <= 0 || C2 < 0 || (C2 > 0 && !dx2) || N <= 0 || Cout <= 0) return DA_ERR_BADARG;
     if (da_matrix_mode() != 2 || bst_cap < 512) return DA_ERR_UNSUPPORTED;
     if (C2 == 0) {
-        if (C1 > 16 || C1 % 4 != 0 || !da_conv3_mfma_fwd_supported(Cout, 0, C1, 1, C1, 0)) return DA_ERR_UNSUPPORTED;
+        if (C1 > 32 || C1 % 4 != 0 || (C1 > 16 && C1 % 16 != 0) || !da_conv3_mfma_fwd_supported(Cout, 0, C1, 1, C1, 0)) return DA_ERR_UNSUPPORTED;      // (one or two N-tiles)
         if (ws_bytes < da_conv3_mfma_ws_bytes(N, D, H, W, C1, Cout, 1)) return DA_ERR_WS_SMALL;
         g_bst = BstState{y, stats4, slope};
         const int rc = da_conv3_mfma_fwd(dy, Cout, nullptr, 0, w_tio, 1, nullptr, dx1, C1, nullptr, 0, N, D, H, W, C1, 1, -1.f, ws, ws_bytes, (hipStream_t)stream, 0, bst, bst_n);
