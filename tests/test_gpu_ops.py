@@ -175,6 +175,48 @@ def test_maxpool_golden_and_random(golden):
     assert torch.equal(yg.detach().cpu(), yr.detach()) and torch.equal(xg.grad.cpu(), xr.grad)
 
 
+def test_maxpool_backward_with_producer_sums():
+    """da_maxpool2_bwd_bst: the max-pool (+ skip) backward on the RAW tensor the pool's forward normalised on the fly.  dx must be bit-equal to
+    da_maxpool2_bwd_add on the activated tensor da_maxpool2_fwd_pro wrote (same arg-max, also for channels with a NEGATIVE BatchNorm scale, where the
+    order of the raw values is the reverse of the activated ones), and the partials must add up to sum dz, sum dz (x - mean) with dz = dx act'(x scale + shift)."""
+    import ctypes
+    from deepatlas_amd import _native as nat
+    call, ptr = nat.call, nat.ptr
+    N, D, H, W = 2, 6, 8, 10
+    for C, slope in ((16, 0.01), (32, 0.0), (8, 0.2)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn((N, D, H, W, C), generator=g).to(dev())
+        stats = torch.empty((4, C), device=dev())
+        stats[0] = torch.randn(C, generator=g).to(dev()) * 0.1                      # mean
+        stats[1] = 1.0                                                            # rstd (not read)
+        stats[2] = (torch.randn(C, generator=g) * 0.8 + 0.3).to(dev())            # scale: both signs
+        stats[3] = torch.randn(C, generator=g).to(dev()) * 0.2                      # shift
+        act, pooled = torch.empty_like(x), torch.empty((N, D // 2, H // 2, W // 2, C), device=dev())
+        st = nat.stream()
+        call('da_maxpool2_fwd_pro', ptr(x), ptr(stats[2]), ptr(stats[3]), slope, ptr(act), ptr(pooled), N, D, H, W, C, st)
+        dy = torch.randn(pooled.shape, generator=g).to(dev())
+        gskip = torch.randn(x.shape, generator=g).to(dev())
+        for skip in (gskip, None):
+            ref, dx = torch.empty_like(x), torch.empty_like(x)
+            if skip is None:
+                call('da_maxpool2_bwd', ptr(dy), ptr(act), ptr(ref), N, D, H, W, C, st)
+            else:
+                call('da_maxpool2_bwd_add', ptr(dy), ptr(act), ptr(skip), ptr(ref), N, D, H, W, C, st)
+            bst = torch.zeros((1024, 2, C), dtype=torch.float64, device=dev())
+            nb = ctypes.c_int(0)
+            call('da_maxpool2_bwd_bst', ptr(dy), ptr(x), ptr(skip), ptr(dx), N, D, H, W, C, ptr(stats), slope, ptr(bst), 1024, ctypes.byref(nb), st)
+            torch.cuda.synchronize()
+            assert nb.value > 0 and torch.equal(dx, ref), (C, slope, skip is None)
+            z = x.double() * stats[2].double() + stats[3].double()
+            dz = dx.double() * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+            s1 = dz.sum((0, 1, 2, 3)); s2 = (dz * (x.double() - stats[0].double())).sum((0, 1, 2, 3))
+            got = bst[:nb.value].sum(0)
+            assert float((got[0] - s1).abs().max()) < 1e-4 * (1 + float(s1.abs().max())), (C, slope)
+            assert float((got[1] - s2).abs().max()) < 1e-4 * (1 + float(s2.abs().max())), (C, slope)
+    with pytest.raises(nat.NativeError):                                           # odd size: declined (the caller takes the plain kernels)
+        call('da_maxpool2_bwd_bst', ptr(dy), ptr(x), None, ptr(dx), N, 5, H, W, 8, ptr(stats), 0.2, ptr(bst), 1024, ctypes.byref(nb), st)
+
+
 def test_upsample_nearest_golden_odd_sizes(golden):
     from deepatlas_amd import ops
     g = golden('ops')
