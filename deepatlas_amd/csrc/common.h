@@ -100,6 +100,12 @@ __device__ __forceinline__ float4 da_ldq(const float* p, long long q) { return r
 __device__ __forceinline__ float4 da_ldq(const da_bf16* p, long long q) { return da_unpack_bf16x4(reinterpret_cast<const uint2*>(p)[q]); }
 __device__ __forceinline__ void da_stq(float* p, long long q, float4 v) { reinterpret_cast<float4*>(p)[q] = v; }
 __device__ __forceinline__ void da_stq(da_bf16* p, long long q, float4 v) { reinterpret_cast<uint2*>(p)[q] = da_pack_bf16x4(v); }
+// streaming forms (non-temporal: the line is not kept for this kernel's sake) for passes that touch every byte once
+typedef float da_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 da_ldq_nt(const float* p, long long q) { const da_f4v v = __builtin_nontemporal_load(reinterpret_cast<const da_f4v*>(p) + q); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void da_stq_nt(float* p, long long q, float4 v) { __builtin_nontemporal_store((da_f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<da_f4v*>(p) + q); }
+__device__ __forceinline__ float4 da_ldq_nt(const da_bf16* p, long long q) { return da_ldq(p, q); }
+__device__ __forceinline__ void da_stq_nt(da_bf16* p, long long q, float4 v) { da_stq(p, q, v); }
 // single elements
 __device__ __forceinline__ float da_ld1(const float* p, long long i) { return p[i]; }
 __device__ __forceinline__ float da_ld1(const da_bf16* p, long long i) { return __uint_as_float((unsigned)p[i].v << 16); }

@@ -129,6 +129,33 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restri
     const bool fixed_q = (VEC == 4) && (stride % cq == 0);
     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sf = sc;
     if (fixed_q) { const int q = (int)(i0 % cq); sc = reinterpret_cast<const float4*>(scale)[q]; sf = reinterpret_cast<const float4*>(shift)[q]; }
+    if (VEC == 4 && fixed_q && sizeof(T) == 4) {
+        // four 16-byte loads in flight per lane before the first store; streaming (non-temporal) accesses: nothing here is read twice
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const float4* xi = reinterpret_cast<const float4*>(x); float4* yo = reinterpret_cast<float4*>(y);
+        const f4v* xv = reinterpret_cast<const f4v*>(x); f4v* yv = reinterpret_cast<f4v*>(y);
+        long long i = i0;
+        for (; i + 3 * stride < nvec; i += 4 * stride) {
+            f4v t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_nontemporal_load(xv + i + k * stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f4v o;
+                o.x = da_act(t[k].x * sc.x + sf.x, slope); o.y = da_act(t[k].y * sc.y + sf.y, slope);
+                o.z = da_act(t[k].z * sc.z + sf.z, slope); o.w = da_act(t[k].w * sc.w + sf.w, slope);
+                __builtin_nontemporal_store(o, yv + i + k * stride);
+            }
+        }
+        for (; i < nvec; i += stride) {
+            const float4 t = xi[i];
+            float4 o;
+            o.x = da_act(t.x * sc.x + sf.x, slope); o.y = da_act(t.y * sc.y + sf.y, slope);
+            o.z = da_act(t.z * sc.z + sf.z, slope); o.w = da_act(t.w * sc.w + sf.w, slope);
+            yo[i] = o;
+        }
+        return;
+    }
     for (long long i = i0; i < nvec; i += stride) {
         if (VEC == 4) {
             if (!fixed_q) { const int q = (int)(i % cq); sc = reinterpret_cast<const float4*>(scale)[q]; sf = reinterpret_cast<const float4*>(shift)[q]; }
@@ -193,8 +220,8 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __res
             const long long i = i0 + u * stride;
             if (i < nvec) {
                 if (VEC == 4) {
-                    const float4 t = da_ldq(x, i);
-                    const float4 g = da_ldq(dy, i);
+                    const float4 t = da_ldq_nt(x, i);
+                    const float4 g = da_ldq_nt(dy, i);
                     xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
                     gv[u][0] = g.x; gv[u][1] = g.y; gv[u][2] = g.z; gv[u][3] = g.w;
                 } else { xv[u][0] = da_ld1(x, i); gv[u][0] = da_ld1(dy, i); }
@@ -216,7 +243,7 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __res
                     o[j] = k_sc[j] * dz;
                 }
             }
-            if (VEC == 4) da_stq(dx, i, make_float4(o[0], o[1], o[2], o[3]));
+            if (VEC == 4) da_stq_nt(dx, i, make_float4(o[0], o[1], o[2], o[3]));
             else da_st1(dx, i, o[0]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) colacc[j] += o[j];
