@@ -303,10 +303,10 @@ __global__ void act_bwd_add_dbias_kernel(const T* __restrict__ g1, const T* __re
     for (long long row = r0 + r; row < r1; row += rpi) {
         float gv[VEC], yv[VEC];
         if (VEC == 4) {
-            float4 t = da_ldq(g1, row * cq + q);
-            if (g2) { const float4 u = da_ldq(g2, row * cq + q); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            float4 t = da_ldq_nt(g1, row * cq + q);
+            if (g2) { const float4 u = da_ldq_nt(g2, row * cq + q); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
             gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
-            if (y) { const float4 v = da_ldq(y, row * cq + q); yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w; }
+            if (y) { const float4 v = da_ldq_nt(y, row * cq + q); yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w; }
         } else {
             gv[0] = da_ld1(g1, row * C + q) + (g2 ? da_ld1(g2, row * C + q) : 0.f);
             if (y) yv[0] = da_ld1(y, row * C + q);
@@ -314,7 +314,7 @@ __global__ void act_bwd_add_dbias_kernel(const T* __restrict__ g1, const T* __re
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { o[j] = y ? gv[j] * (yv[j] > 0.f ? 1.f : slope) : gv[j]; a0[j] += o[j]; }
-        if (VEC == 4) da_stq(dx, row * cq + q, make_float4(o[0], o[1], o[2], o[3]));
+        if (VEC == 4) da_stq_nt(dx, row * cq + q, make_float4(o[0], o[1], o[2], o[3]));
         else da_st1(dx, row * C + q, o[0]);
     }
     if (!partial) return;
