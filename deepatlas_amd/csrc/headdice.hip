@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(256) head_dice_bwd_kernel(HdP p) {
             if (vox < p.V) {
 #pragma unroll
                 for (int c = 0; c < KC; ++c)          // lane (voxel i, group g) holds input channels 16c + 4g .. + 3
-                    da_stq(dxs, (vox * p.K + 16 * c + 4 * g) >> 2, make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]));
+                    da_stq_nt(dxs, (vox * p.K + 16 * c + 4 * g) >> 2, make_float4(dacc[c][0], dacc[c][1], dacc[c][2], dacc[c][3]));
                 if (bst) {                            // the raw x of this voxel again (an L1 / L2 hit: this wave loaded it for the logits a moment ago)
                     const float4 xr = da_ldq(xs, (vox * p.K + 4 * g) >> 2);
                     const float xv[4] = {xr.x, xr.y, xr.z, xr.w}, scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, sfv[4] = {bsf.x, bsf.y, bsf.z, bsf.w}, muv[4] = {bmu.x, bmu.y, bmu.z, bmu.w};
