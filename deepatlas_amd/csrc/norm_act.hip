@@ -217,15 +217,15 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __res
         float xv[UNR][VEC], gv[UNR][VEC];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const long long i = i0 + u * stride;
-            if (i < nvec) {
-                if (VEC == 4) {
-                    const float4 t = da_ldq_nt(x, i);
-                    const float4 g = da_ldq_nt(dy, i);
-                    xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
-                    gv[u][0] = g.x; gv[u][1] = g.y; gv[u][2] = g.z; gv[u][3] = g.w;
-                } else { xv[u][0] = da_ld1(x, i); gv[u][0] = da_ld1(dy, i); }
-            }
+            // unconditional loads (a slot past the end re-reads the last one and stores nothing): a load under a branch is waited for where the branch
+            // ends, and the pairs would not be in flight together
+            const long long i = (i0 + u * stride < nvec) ? i0 + u * stride : nvec - 1;
+            if (VEC == 4) {
+                const float4 t = da_ldq_nt(x, i);
+                const float4 g = da_ldq_nt(dy, i);
+                xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                gv[u][0] = g.x; gv[u][1] = g.y; gv[u][2] = g.z; gv[u][3] = g.w;
+            } else { xv[u][0] = da_ld1(x, i); gv[u][0] = da_ld1(dy, i); }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
