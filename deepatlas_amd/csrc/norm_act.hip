@@ -45,7 +45,25 @@ __global__ void col_partial_kernel(const T* __restrict__ x, const T* __restrict_
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { mu[j] = mean[q * VEC + j]; rs[j] = rstd[q * VEC + j]; sc[j] = scale[q * VEC + j]; sf[j] = shift[q * VEC + j]; }
     }
-    for (long long row = r0 + r; row < r1; row += rpi) {
+    long long row = r0 + r;
+    if (VEC == 4 && MODE == 2) {
+        // BatchNorm-backward sums: two rows in flight per lane (unconditional loads, the second row clamped and masked)
+        for (; row < r1; row += 2 * rpi) {
+            const long long rb = row + rpi < r1 ? row + rpi : row;
+            const float live = row + rpi < r1 ? 1.f : 0.f;
+            const float4 t0 = da_ldq(x, row * cq + q), g0 = da_ldq(dy, row * cq + q), t1 = da_ldq(x, rb * cq + q), g1 = da_ldq(dy, rb * cq + q);
+            const float xa[2][4] = {{t0.x, t0.y, t0.z, t0.w}, {t1.x, t1.y, t1.z, t1.w}}, ga[2][4] = {{g0.x, g0.y, g0.z, g0.w}, {g1.x * live, g1.y * live, g1.z * live, g1.w * live}};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float z = xa[u][j] * sc[j] + sf[j];
+                    const float dz = ga[u][j] * da_act_grad(z, slope);
+                    a0[j] += dz; a1[j] += dz * ((xa[u][j] - mu[j]) * rs[j]);
+                }
+        }
+    }
+    for (; row < r1; row += rpi) {
         float xv[VEC], gv[VEC];
         if (VEC == 4) {
             const float4 t = da_ldq(x, row * cq + q);
