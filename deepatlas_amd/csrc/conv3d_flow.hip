@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
 
     // static share of the tile list (contiguous range per workgroup: neighbouring tiles share dy halo rows in L2)
     const int per = (p.ntiles + gridDim.x - 1) / gridDim.x;
-    const int t_begin = blockIdx.x * per, t_end = min(p.ntiles, t_begin + per);
+    const int vb = (gridDim.x % 8 == 0) ? da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;      // neighbouring ranges on the same XCD
+    const int t_begin = vb * per, t_end = min(p.ntiles, t_begin + per);
 
     constexpr int NX2 = TVOX * 4 / 256;            // float4 loads per thread for a 16-channel tile (8)
     constexpr int NDY = (HVOX * 3 + 255) / 256;    // dword loads per thread for the dy halo tile, Cout <= 3 (13)
@@ -298,9 +299,9 @@ __global__ void __launch_bounds__(256) fewcin_wgrad_valu_kernel(const float* __r
     float acc[27][4];
 #pragma unroll
     for (int t = 0; t < 27; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
-    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const DaXcdItems SL = da_xcd_items(nstrips, wave, 4);
 #pragma unroll 1
-    for (int s = wid; s < nstrips; s += nw) {
+    for (int s = (int)SL.i; s < (int)SL.end; s += (int)SL.step) {
         int r = s;
         const int xs = r % nxs; r /= nxs;
         const int ys = r % nys; r /= nys;

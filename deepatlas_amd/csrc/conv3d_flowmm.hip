@@ -162,12 +162,13 @@ __global__ void __launch_bounds__(256, 2) fm_fwd_kernel(FwdP p) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) bv[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
     auto ld = [&](int off) -> f16x8 { return *reinterpret_cast<const f16x8*>(lds + off); };
-    const int first = blockIdx.x, stride = gridDim.x;
-    if (first < p.ntiles) { issue(first); stage(); }
+    const DaXcdItems TL = da_xcd_items(p.ntiles);            // an XCD's workgroups walk one contiguous eighth of the tile list together: neighbouring tiles' halo lines meet in ONE L2
+    const int first = (int)TL.i, stride = (int)TL.step, tend = (int)TL.end;
+    if (first < tend) { issue(first); stage(); }
     __syncthreads();
 #pragma unroll 1
-    for (int tile = first; tile < p.ntiles; tile += stride) {
-        const bool more = tile + stride < p.ntiles;
+    for (int tile = first; tile < tend; tile += stride) {
+        const bool more = tile + stride < tend;
         const int Eused = Ecur;
         if (more) issue(tile + stride);                      // next tile's loads fly under this tile's MFMAs
         f32x4 acc[6];
@@ -341,12 +342,13 @@ __global__ void __launch_bounds__(256, 2) fm_dgrad_kernel(DgP p) {
         const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
         return __builtin_bit_cast(f16x8, v);
     };
-    const int first = blockIdx.x, stride = gridDim.x;
-    if (first < p.ntiles) { issue(first); stage(); }
+    const DaXcdItems TL = da_xcd_items(p.ntiles);            // an XCD's workgroups walk one contiguous eighth of the tile list together: neighbouring tiles' halo lines meet in ONE L2
+    const int first = (int)TL.i, stride = (int)TL.step, tend = (int)TL.end;
+    if (first < tend) { issue(first); stage(); }
     __syncthreads();
 #pragma unroll 1
-    for (int tile = first; tile < p.ntiles; tile += stride) {
-        const bool more = tile + stride < p.ntiles;
+    for (int tile = first; tile < tend; tile += stride) {
+        const bool more = tile + stride < tend;
         const int Eused = Ecur;
         if (more) issue(tile + stride);
         f32x4 acc[4][NTN];

@@ -865,12 +865,12 @@ int launch_fwdsp(const FwdP& p, int gy, hipStream_t st) {
 
 bool da_conv3_fwdsp_enabled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("DA_FWDSP"); on = (e && !atoi(e)) ? 0 : 1; }
+    if (on < 0) { const char* e = getenv("DA_FWDSP"); on = (e && atoi(e)) ? 1 : 0; }      // off by default: measured equal alone and 0.1 - 0.3 ms SLOWER in the seg step
     return on != 0;
 }
 
 int da_conv3_fwdsp_launch(const DaC3FwdP& p, int gy, int nrep, int stats, int pro, int pair, hipStream_t st) {
-    static int w8 = -1; if (w8 < 0) { const char* e = getenv("DA_FWDSP8"); w8 = (e && !atoi(e)) ? 0 : 1; }
+    static int w8 = -1; if (w8 < 0) { const char* e = getenv("DA_FWDSP8"); w8 = (e && atoi(e)) ? 1 : 0; }
     if (w8 && nrep == 1 && p.nblocks >= 16 && p.nblocks % 16 == 0) {      // eight-wave pipelined form: half as many, twice as large workgroups (multiple of 8: tile_walk's XCD split)
 #define DA_FSP8(s, pr, pa) if (stats == s && (pro != 0) == pr && (pair != 0) == pa) return launch_fwdsp8<s, pr, pa>(p, gy, st)
         DA_FSP8(0, false, false); DA_FSP8(0, false, true); DA_FSP8(0, true, false);

@@ -762,7 +762,8 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
     constexpr bool WSCAL = CT <= 16;      // weights through the scalar cache (few outputs per thread) or staged in LDS (CT >= 24: too many SGPR loads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TZ = 2 * VPT, HZ = TZ + 2, HVOX = HZ * HY * HX;
-    int t = blockIdx.x;
+    int t = da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x);      // consecutive tiles on the same XCD: their shared halo lines are fetched into ONE L2 (x-fastest order on
+                                                                        // round-robin XCDs: the first encoder's 39 MB input cost 163 MB of fabric reads, profiles/r06_step_traffic_seg.txt)
     const int tx = t % p.ntx; t /= p.ntx;
     const int ty = t % p.nty; t /= p.nty;
     const int tz = t % p.ntz; const int n = t / p.ntz;
@@ -1973,8 +1974,8 @@ __global__ void __launch_bounds__(256) conv3_smallcin_wgrad_kernel(ScP p) {
     bool from2[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) from2[mt] = (src[mt] == p.in2) && p.C2 > 0;
-    const long long wave_id = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
-    for (long long row = wave_id; row < p.nrows; row += nwaves) {
+    for (DaXcdItems RL = da_xcd_items(p.nrows, wave, 4); RL.i < RL.end; RL.i += RL.step) {      // (rows of one XCD are neighbours: the 9 (dz, dy) uses of an input row meet in its L2)
+        const long long row = RL.i;
         const int y = (int)(row % p.H); const int z = (int)((row / p.H) % p.D);
         const int n = __builtin_amdgcn_readfirstlane((int)(row / ((long long)p.H * p.D)));
         const __amdgpu_buffer_rsrc_t r1 = da_rsrc(p.in1 + (size_t)n * vol * p.C1, (unsigned)(vol * p.C1 * 4ull));

@@ -461,7 +461,8 @@ __global__ void bending_partial_kernel(const float* __restrict__ disp, int D, in
     const long long total = (long long)Di * Hi * Wi;
     const long long sH = W, sD = (long long)H * W;
     float acc = 0.f; double dacc = 0.0; int cnt = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (DaXcdLoop L = da_xcd_loop(total); L.i < L.end; L.i += L.step) {      // (z-neighbour planes stay inside one XCD's L2)
+        const long long i = L.i;
         long long r = i;
         const int w = (int)(r % Wi) + 1; r /= Wi;
         const int h = (int)(r % Hi) + 1; const int d = (int)(r / Hi) + 1;
@@ -554,7 +555,8 @@ __global__ void bending_bwd_kernel(const float* __restrict__ disp, const float* 
     const long long total = (long long)D * H * W * 3;
     const float gl = (L1 ? 1.f : 2.f) * dloss[0];
     const long long sW = 3, sH = (long long)W * 3, sD = (long long)H * W * 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (DaXcdLoop L = da_xcd_loop(total, 768); L.i < L.end; L.i += L.step) {
+        const long long i = L.i;
         const int c = (int)(i % 3); long long r = i / 3;
         const int w = (int)(r % W); r /= W;
         const int h = (int)(r % H); const int d = (int)(r / H);

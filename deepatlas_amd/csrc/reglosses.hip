@@ -413,10 +413,16 @@ __global__ void __launch_bounds__(256, 2) lncc_march_kernel(MarchP p) {
 }
 
 struct MarchGeom { int ntx, nty, nch, ZC; bool ok; };
-static MarchGeom lncc_march_geom(int N, int Lz, int Ly, int Lx, int F, int dil, int stride) {
-    MarchGeom g{};
+// Which form a call takes is decided ONCE, from the INPUT extents (D, H, W) -- da_lncc_ws_bytes, da_lncc_fwd and da_lncc_bwd must agree: the forward
+// writes the marching form's five backward terms into `sums` where the separable form keeps raw window sums, and the workspace is sized per form.
+// (Both walks address at most (D + F)(H + F)(W + F) elements per sample with 32-bit byte offsets.)  The tiling below is per walk direction.
+static bool lncc_march_ok(int D, int H, int W, int F, int dil, int stride) {
     static const int off = [] { const char* e = getenv("DA_LNCC_MARCH"); return (e && e[0] == '0') ? 1 : 0; }();
-    g.ok = !off && dil == 1 && stride == 1 && (F == 9 || F == 5) && (long long)(Lz + F) * (Ly + F) * (Lx + F) * 4 < (1ll << 31);
+    return !off && dil == 1 && stride == 1 && (F == 9 || F == 5) && (long long)(D + F) * (H + F) * (W + F) * 4 < (1ll << 31);
+}
+static MarchGeom lncc_march_geom(int N, int Lz, int Ly, int Lx, int F, bool ok) {
+    MarchGeom g{};
+    g.ok = ok;
     if (!g.ok) return g;
     g.ntx = (Lx + 31) / 32; g.nty = (Ly + 15) / 16;
     const long long tiles = (long long)g.ntx * g.nty * N;
@@ -515,7 +521,7 @@ extern "C" size_t da_lncc_ws_bytes(int N, int D, int H, int W, int F, int dil, i
     if (F < 1 || dil < 1 || stride < 1) return 0;
     const size_t Wo = lncc_out(W, F, dil, stride), Ho = lncc_out(H, F, dil, stride), Do = lncc_out(D, F, dil, stride);
     if (!Wo || !Ho || !Do) return 0;
-    const MarchGeom mg = lncc_march_geom(N, (int)Do, (int)Ho, (int)Wo, F, dil, stride);
+    const MarchGeom mg = lncc_march_geom(N, (int)Do, (int)Ho, (int)Wo, F, lncc_march_ok(D, H, W, F, dil, stride));
     if (mg.ok) return da_align((size_t)mg.ntx * mg.nty * mg.nch * N * sizeof(double));     // marching form: the loss partials only
     // forward: t1 [5][N][D][H][Wo], t2 [5][N][D][Ho][Wo], partials; backward: G [7][N][Do][Ho][Wo], [7][N][D][Ho][Wo], [7][N][D][H][Wo]
     const size_t fwd = da_align((size_t)5 * N * D * H * Wo * 4) + da_align((size_t)5 * N * D * Ho * Wo * 4) + da_align((size_t)kBlocks * 8);
@@ -530,7 +536,7 @@ extern "C" int da_lncc_fwd(const float* I, const float* J, int N, int D, int H, 
     if (!Wo || !Ho || !Do) return DA_ERR_BADARG;
     if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F, dil, stride)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
-    const MarchGeom mg = lncc_march_geom(N, Do, Ho, Wo, F, dil, stride);
+    const MarchGeom mg = lncc_march_geom(N, Do, Ho, Wo, F, lncc_march_ok(D, H, W, F, dil, stride));
     if (mg.ok) {
         MarchP p{};
         p.I = I; p.J = J; p.sums_out = sums; p.partial = (double*)ws;
@@ -569,7 +575,7 @@ extern "C" int da_lncc_bwd(const float* I, const float* J, const float* sums, co
     if (!Wo || !Ho || !Do) return DA_ERR_BADARG;
     if (ws_bytes < da_lncc_ws_bytes(N, D, H, W, F, dil, stride)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
-    const MarchGeom mg = lncc_march_geom(N, D, H, W, F, dil, stride);
+    const MarchGeom mg = lncc_march_geom(N, D, H, W, F, lncc_march_ok(D, H, W, F, dil, stride));
     if (mg.ok) {
         MarchP p{};
         p.I = I; p.J = J; p.sums_in = sums; p.dI = dI; p.dJ = dJ; p.dloss = dloss;

@@ -44,7 +44,8 @@ __global__ void warp_fwd_kernel(const float* __restrict__ src, const float* __re
                                 int N, int D, int H, int W, int C, int lpv) {
     const long long nvox = (long long)N * D * H * W;
     const long long total = nvox * lpv;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (DaXcdLoop L = da_xcd_loop(total, 256 * (long long)lpv); L.i < L.end; L.i += L.step) {      // (a target neighbourhood gathers from one XCD's L2)
+        const long long i = L.i;
         int q; long long v; da_divmod(i, lpv, v, q);
         int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
@@ -92,7 +93,8 @@ __global__ void warp_bwd_kernel(const float* __restrict__ dout, const float* __r
     const long long nvox = (long long)N * D * H * W;
     const long long total = nvox * lpv;
     // total is padded by the launcher to a multiple of lpv*...; every lane of a voxel group runs the same trip count
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (DaXcdLoop L = da_xcd_loop(total, 256 * (long long)lpv); L.i < L.end; L.i += L.step) {      // (a target neighbourhood gathers from one XCD's L2)
+        const long long i = L.i;
         int q; long long v; da_divmod(i, lpv, v, q);
         int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
@@ -280,7 +282,8 @@ __global__ void warp_labels_fwd_kernel(const void* __restrict__ labels, int labe
 __global__ void warp_labels_bwd_kernel(const float* __restrict__ dout, const void* __restrict__ labels, int label_bytes,
                                        const float* __restrict__ disp, float* __restrict__ d_disp, int N, int D, int H, int W, int C) {
     const long long nvox = (long long)N * D * H * W;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+    for (DaXcdLoop XL = da_xcd_loop(nvox); XL.i < XL.end; XL.i += XL.step) {
+        const long long v = XL.i;
         int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(256) warp_dice_partial_kernel(const float* __r
     const int q = threadIdx.x % lpv, s = threadIdx.x / lpv;
     const long long V = (long long)D * H * W;
     const long long vpb = da_cdiv(V, (long long)gridDim.x);
-    const long long v0 = (long long)blockIdx.x * vpb;
+    const long long v0 = (long long)((gridDim.x % 8 == 0) ? da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * vpb;      // neighbouring ranges gather from ONE XCD's L2
     long long v1 = v0 + vpb; if (v1 > V) v1 = V;
     const float* sb = src + (long long)n * V * C;
     float aI[4] = {0, 0, 0, 0}, aS[4] = {0, 0, 0, 0}, aT[4] = {0, 0, 0, 0};
@@ -423,7 +426,8 @@ __global__ void __launch_bounds__(256) label_warp_dice_partial_kernel(const void
             todo &= ~__ballot(m);
         }
     };
-    for (long long base = (long long)blockIdx.x * 256 + wave * 64; base < V; base += stride) {      // wave-uniform trip count
+    const DaXcdLoop XL = da_xcd_loop(V, 256);              // (an XCD's workgroups walk one contiguous eighth of the volume)
+    for (long long base = XL.i - lane; base < XL.end; base += XL.step) {      // wave-uniform trip count
         const long long v = base + lane;
         const bool live = v < V;
         const long long vv = live ? v : V - 1;
@@ -487,7 +491,8 @@ __global__ void label_warp_dice_bwd_kernel(const void* __restrict__ lab_m, int b
     const long long V = (long long)D * H * W, nvox = V * N;
     const float gl = dloss[0];
     const int NC = N * C;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+    for (DaXcdLoop XL = da_xcd_loop(nvox); XL.i < XL.end; XL.i += XL.step) {
+        const long long v = XL.i;
         int n, d, h, w; da_vox4(v, D, H, W, n, d, h, w);
         const float gx = disp[v * 3 + 0] + id_coord(w, W);
         const float gy = disp[v * 3 + 1] + id_coord(h, H);
@@ -532,7 +537,8 @@ __global__ void warp_adjoint_labels_kernel(const void* __restrict__ lab_t, int b
     const long long V = (long long)D * H * W, nvox = V * N;
     const int lane = threadIdx.x & 63;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long v0 = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); v0 < nvox; v0 += stride) {      // whole waves iterate together (shuffles inside)
+    const DaXcdLoop XL = da_xcd_loop(nvox, 256);
+    for (long long v0 = XL.i - lane; v0 < XL.end; v0 += XL.step) {      // whole waves iterate together (shuffles inside)
         const long long v = v0 + lane;
         const bool inr = v < nvox;
         int n = 0, d = 0, h = 0, w = 0;
@@ -583,7 +589,7 @@ __global__ void __launch_bounds__(256) warp_adjoint_labels_box_kernel(const void
     extern __shared__ float box[];                            // [K][CELLS]
     __shared__ int slot_label[K];
     const long long V = (long long)D * H * W;
-    int b = blockIdx.x;
+    int b = da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x);      // neighbouring boxes on one XCD
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby; b /= nby;
     const int bz = b % nbz; const int n = b / nbz;
@@ -654,7 +660,8 @@ __global__ void __launch_bounds__(256) seg_anat_dlogits_kernel(const float* __re
     const int ltv = __ffs(tv) - 1, llp = __ffs(lpv) - 1;                   // tv, lpv: powers of two
     const float gs = (coef_s && gl_s) ? gl_s[0] : 0.f, ga = gl_a ? gl_a[0] : 0.f;
     const long long tps = (V + tv - 1) / tv, ntiles = tps * N;
-    for (long long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    for (DaXcdItems TL = da_xcd_items(ntiles); TL.i < TL.end; TL.i += TL.step) {
+        const long long tix = TL.i;
         const int n = (int)(tix / tps);
         const long long u0 = (tix - (long long)n * tps) * tv;
         __syncthreads();                                                   // the previous tile has been consumed
@@ -702,7 +709,8 @@ __global__ void __launch_bounds__(256) seg_anat_dlogits_lane_kernel(const float*
     const int NC = N * CC;
     const float gs = (coef_s && gl_s) ? gl_s[0] : 0.f, ga = gl_a ? gl_a[0] : 0.f;
     const long long bps = (V + 255) / 256, nb = bps * N;                   // a workgroup never straddles two samples: n is uniform
-    for (long long bix = blockIdx.x; bix < nb; bix += gridDim.x) {
+    for (DaXcdItems BL = da_xcd_items(nb); BL.i < BL.end; BL.i += BL.step) {
+        const long long bix = BL.i;
         const int n = (int)(bix / bps);
         const long long u = (bix - (long long)n * bps) * 256 + threadIdx.x;
         if (u >= V) continue;

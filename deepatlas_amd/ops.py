@@ -218,11 +218,15 @@ def bump_batches_tracked(bn):
         _nbt_pending[id(t)] = [t, 1]
         if not getattr(bn, '_da_nbt_hooked', False):
             bn._da_nbt_hooked = True
-            bn.register_state_dict_pre_hook(lambda module, prefix, keep_vars: flush_batches_tracked())
+            bn.register_state_dict_pre_hook(_nbt_state_dict_pre_hook)
         if len(_nbt_pending) >= _NBT_FLUSH_AT:
             flush_batches_tracked()
     else:
         e[1] += 1
+
+
+def _nbt_state_dict_pre_hook(module, prefix, keep_vars):      # (a module-level function: a lambda here made every trained BatchNorm module unpicklable)
+    flush_batches_tracked()
 
 
 def flush_batches_tracked(*_):
@@ -411,7 +415,7 @@ _pack_entries = {}
 
 
 class _Pack(object):
-    __slots__ = ('bufs', 'stamp', 'event', 'base', 'view', 'args', 'disabled', 'storage', 'pversion')
+    __slots__ = ('bufs', 'stamp', 'event', 'base', 'view', 'args', 'disabled', 'storage', 'pversion', 'used')
 
 
 def _pack_stamp(e):
@@ -449,7 +453,7 @@ def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
             return
         nbytes = nat.lib().da_conv3d_k3_pack_bytes(N, D, H, W, C1 + C2, Cout)
         e = _Pack()
-        e.args, e.event, e.stamp, e.disabled = (C1, C2, Cout, dgrad, N, D, H, W), None, None, nbytes == 0
+        e.args, e.event, e.stamp, e.disabled, e.used = (C1, C2, Cout, dgrad, N, D, H, W), None, None, nbytes == 0, True
         e.base = base
         e.storage = sp
         e.view = (tuple(w_tio.shape), tuple(w_tio.stride()), w_tio.storage_offset())
@@ -462,8 +466,11 @@ def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
     if e.disabled:
         return
     e.pversion = w_tio._version
+    e.used = True
     stamp = _pack_stamp(e)
     if e.stamp != stamp:
+        if e.event is not None:                         # a side-stream re-fill of these buffers may still be in flight (weights changed again right after the step)
+            torch.cuda.current_stream().wait_event(e.event)
         if _pack_fill(e, w_tio, stream()) == 0:
             e.disabled = True
             e.bufs = [None, None]
@@ -480,10 +487,21 @@ def repack_after_step(flat_p):
     if not PACK_CACHE or not _pack_entries or _matrix_mode != 'fp32_split' or torch.cuda.is_current_stream_capturing():
         return
     sp = flat_p.untyped_storage().data_ptr()
-    mine = [e for e in _pack_entries.values() if not e.disabled and e.storage == sp and e.base() is not None]
-    dead = [k for k, e in _pack_entries.items() if e.base() is None]
+    # only the packs a call asked for since the previous step of this bucket are re-filled (a validation size, random crops or sliding windows would
+    # otherwise grow the per-step work with every shape ever seen); the others go stale (re-filled in their next call) and, past _PACK_KEEP shapes
+    # idle for a step, are dropped
+    all_mine = [(k, e) for k, e in _pack_entries.items() if not e.disabled and e.storage == sp and e.base() is not None]
+    mine, idle = [], []
+    for k, e in all_mine:
+        if e.used:
+            mine.append(e)
+            e.used = False
+        else:
+            idle.append(k)
+            e.stamp = None                              # stale: its next call re-fills it in the call's own chain
+    dead = [k for k, e in _pack_entries.items() if e.base() is None] + (idle[:len(idle) - _PACK_KEEP] if len(idle) > _PACK_KEEP else [])
     for k in dead:
-        del _pack_entries[k]
+        _pack_entries.pop(k, None)
     if not mine:
         return
     import ctypes
@@ -507,6 +525,9 @@ def repack_after_step(flat_p):
             e.disabled = True
             continue
         e.stamp, e.event = _pack_stamp(e), ev
+
+
+_PACK_KEEP = 64          # kept packs idle for a whole optimiser step beyond this many are dropped (oldest first: dicts keep insertion order)
 
 
 def clear_pack_cache():
@@ -1147,21 +1168,47 @@ def drop_bwd_stats(*_):
     _bwd_stats.clear()
 
 
-def _bn_backward(go, y, stats, cfg, want_dbias, st):
+DIRECT_SMALL_GRADS = os.environ.get('DA_NO_DIRECT_SMALL_GRADS') != '1'
+
+
+def _direct_small_target(small_params, C, want_dbias):
+    """The (3, C) slice of a FlatAdam gradient bucket that holds (bias, gamma, beta) of one block, if the BatchNorm-backward kernels may WRITE their three
+    results straight into it: all three gradients are views of a registered bucket, consecutive there (conv.bias, BN.weight, BN.bias are consecutive
+    parameters), and still all zeros since zero_grad (`_da_gz`, the mark the direct weight gradients use).  Saves the (3, C) scratch tensor and one
+    torch add per block (19 launches on the dependent chain of a seg step).  None: take the scratch tensor + _accumulate_small_grads."""
+    if not DIRECT_SMALL_GRADS or small_params is None or not want_dbias or False:
+        return None
+    bias, gamma, beta = small_params
+    if bias is None or gamma is None or beta is None:
+        return None
+    if not (getattr(bias, '_da_gz', False) and getattr(gamma, '_da_gz', False) and getattr(beta, '_da_gz', False)):
+        return None
+    gb, gg, gbt = _async_target(bias), _async_target(gamma), _async_target(beta)
+    if gb is None or gg is None or gbt is None:
+        return None
+    if not (gb.numel() == gg.numel() == gbt.numel() == C and gb.is_contiguous() and gg.data_ptr() == gb.data_ptr() + 4 * C and gbt.data_ptr() == gg.data_ptr() + 4 * C):
+        return None
+    bias._da_gz = gamma._da_gz = beta._da_gz = False
+    return torch.as_strided(gb, (3, C), (C, 1))
+
+
+def _bn_backward(go, y, stats, cfg, want_dbias, st, small_params=None):
     """BN+activation backward; returns (dy, dgamma, dbeta, dbias_of_producer or None) -- the producer's bias gradient is the
-    column sum of dy and is accumulated inside the apply pass."""
+    column sum of dy and is accumulated inside the apply pass.  With `small_params` = the block's (bias, gamma, beta) parameters the three
+    gradients may be written straight into the optimiser's bucket (_direct_small_target); the returned gradients are then all None."""
     M, C, slope, train, wsb = cfg
     dy = torch.empty_like(y)
-    dgb = _empty((3, C), y)                   # rows: producer bias, gamma, beta -- the order the parameters have in a block
+    direct = _direct_small_target(small_params, C, want_dbias) if train else None
+    dgb = direct if direct is not None else _empty((3, C), y)                   # rows: producer bias, gamma, beta -- the order the parameters have in a block
     wp, wn = _ws(wsb, y)
     pre = _bwd_stats.pop(go.data_ptr(), None) if _bwd_stats else None
     if pre is not None and train and pre[3] == M and pre[4] == C and go.dtype == torch.float32 and y.dtype == torch.float32 and go.is_contiguous():
         call('da_bn_act_bwd_dbias_pre', ptr(go), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              slope, 1, ptr(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, ptr(pre[1]), pre[2], wp, wn, st)
-        return dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None)
+        return (dy, None, None, None) if direct is not None else (dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None))
     call_act('da_bn_act_bwd_dbias', A(go), A(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              slope, 1 if train else 0, O(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]) if want_dbias else None, M, C, wp, wn, st)
-    return dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None)
+    return (dy, None, None, None) if direct is not None else (dy, dgb[1], dgb[2], (dgb[0] if want_dbias else None))
 
 
 def _accumulate_small_grads(bias, gamma, beta, db, dgamma, dbeta):
@@ -1273,7 +1320,7 @@ class ConvBNActFn(Function):
         pro2 = (p2s, p2t, ctx.pro_slopes[1]) if p2s is not None else None
         N, D, H, W, C1, C2, Cout, wsb = ctx.dims
         st = stream()
-        dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st)
+        dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st, ctx.small_params)
         wp, wn = _ws(wsb, a1)
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[1]):
@@ -1373,7 +1420,7 @@ class DeconvBNActFn(Function):
         N, D, H, W, Cin = a.shape
         Cout = w_tio.shape[2]
         st = stream()
-        dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st)
+        dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st, ctx.small_params)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a)
