@@ -323,12 +323,24 @@ def make_workloads(args, dev, rank, which):
                 args.batch, shape[0], shape[1], shape[2], prec)
             fl = None
         out['seg'] = Workload(nm, seg_step, args.batch, 'volumes/s', fl, lambda r: r, [opt])
+    if 'joint_smooth' in which:
+        which = list(which) + ['joint']
     if 'reg' in which or 'joint' in which:
         from deepatlas_amd.models.joint import RegistrationStep, DeepAtlasJointStep
         reg = get_network('voxel_morph_cvpr')()
         reg.weights_init()
+        smooth = 'joint_smooth' in which
+        if smooth:
+            # A registration-like displacement field for the joint leg's gather / scatter kernels: the untrained net's Xavier-initialised flow head
+            # turns noise volumes into 12 - 19 voxels of noise that differ by 8 voxels between neighbours (tools/debug/joint_field_stats.py) -- a worst case
+            # no registration run sees.  Here the flow weights are scaled by 2^-8 and the bias is a shift of (1.7, -1.3, 0.9) voxels: smooth, a few voxels,
+            # +- 0.05 voxels of texture; the registration optimiser's step size is 1e-7 so that the field stays like that over the timed steps (Adam moves
+            # every weight by ~lr per step whatever the gradient).  Same kernels, same launches; only the field differs.
+            with torch.no_grad():
+                reg.flow.weight.mul_(1.0 / 256.0)
+                reg.flow.bias.copy_(torch.tensor([1.7 * 2.0 / (shape[2] - 1), -1.3 * 2.0 / (shape[1] - 1), 0.9 * 2.0 / (shape[0] - 1)]))
         reg.to(dev).train()
-        ropt = FlatAdam(reg.parameters(), lr=1e-3)
+        ropt = FlatAdam(reg.parameters(), lr=1e-7 if smooth else 1e-3)
         parallel.broadcast_parameters(ropt)
         x2, y2 = synthetic_batch_on_device(1, shape, n_classes, seed=1230 + rank, device=dev)
         im_m, im_t, sm, st_ = x[:1], x2, y[:1], y2
@@ -344,6 +356,9 @@ def make_workloads(args, dev, rank, which):
                                     '(BASELINE configs[3] per-GPU shape)' % (shape + (prec,)),
                                     joint_fn, 1, 'pairs/s',
                                     (SEG_TRAIN_FLOP_PER_VOXEL + REG_TRAIN_FLOP_PER_VOXEL) * V if args.net == 'UNet_light' else None, lambda r: r, [ropt, opt])
+            if smooth:
+                out['joint_smooth'] = out.pop('joint')
+                out['joint_smooth'].name += ' -- on a registration-like field (smooth shift of 1 - 2 voxels + 0.05 voxels of texture) instead of the untrained net\'s 8-voxel noise'
     return out, n_classes
 
 
@@ -453,6 +468,27 @@ def pmc_traffic_for(kname, precision):
     return None, '%s has no record of %s (has: %s) -- re-run tools/pmc_conv.sh + tools/pmc_summary.py' % (os.path.relpath(files[-1], ROOT), kname, ', '.join(sorted(calls)))
 
 
+def step_traffic_for(workload, ms_per_step):
+    """Fabric-side bytes of one WHOLE step from the newest committed profiles/rNN_step_traffic_<workload>.json (tools/pmc_step.sh: two rocprofv3 --pmc
+    passes over this same bench workload, reads from the size-weighted request counters, writes from WRITE_SIZE; kernels serialised by the counter
+    collection -- a separate run, `source` says so) against SURVEY section 8(d)'s algorithmic bytes, and what both mean at this run's step time."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_step_traffic_%s.json' % workload)))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        tot, alg = float(doc['total']), float(doc['algorithmic'])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+    top = sorted(doc.get('per_kernel', {}).items(), key=lambda kv: -(kv[1]['read'] + kv[1]['write']))[:5]
+    return dict(step_traffic=tot, step_traffic_read=doc.get('read'), step_traffic_write=doc.get('write'), step_algorithmic_bytes=alg,
+                step_traffic_over_algorithmic=round(tot / alg, 3),
+                step_fabric_gbs=round(tot / (ms_per_step * 1e-3) / 1e9, 1), step_frac_of_hbm_peak_on_traffic=round(tot / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                step_frac_of_hbm_peak_on_algorithmic_bytes=round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                step_traffic_top_kernels=[dict(kernel=k[:80], bytes=round(v['read'] + v['write'])) for k, v in top],
+                step_traffic_source='%s (tools/pmc_step.sh: separate rocprofv3 --pmc passes over `bench.py --workload %s`)' % (os.path.relpath(files[-1], ROOT), workload))
+
+
 ROOFLINE_LAYER_CALLS = ('da_conv3d_k3_fwd_bnstats[32, 16, 2, 160, 192, 160, 16, 1]', 'da_conv3d_k3_dgrad[32, 16, 2, 160, 192, 160, 16, 1]',
                         'da_conv3d_k3_wgrad[32, 16, 2, 160, 192, 160, 16, 1]')
 
@@ -478,7 +514,7 @@ def main():
     ap.add_argument('--sync-wgrad', action='store_true', help='weight gradients on the main stream (default: side stream, overlapped with the HBM-bound backward kernels)')
     ap.add_argument('--net', default='UNet_light', choices=['UNet_light', 'UNet'],
                     help="segmentation network of the 'seg' workload; 'UNet' = the fixed 19 M-parameter net (SURVEY.md row f3), not the headline config")
-    ap.add_argument('--workload', default='seg', choices=['seg', 'reg', 'joint'],
+    ap.add_argument('--workload', default='seg', choices=['seg', 'reg', 'joint', 'joint_smooth'],
                     help="headline leg: 'seg' = BASELINE configs[1] (the metric); 'reg' / 'joint' = configs[2] / [3] per-GPU shapes (1 pair / GPU)")
     args = ap.parse_args()
 
@@ -529,7 +565,7 @@ def main():
     ops.enable_async_wgrad(not args.sync_wgrad)
     set_precision(ops, args.precision)
     shape = tuple(args.shape)
-    extra_legs = [] if (args.no_extra or args.workload != 'seg' or args.net != 'UNet_light') else ['reg', 'joint']
+    extra_legs = [] if (args.no_extra or args.workload != 'seg' or args.net != 'UNet_light') else ['reg', 'joint', 'joint_smooth']
     # Only the headline workload exists while it is timed; the other legs are built right before their own timed region and dropped after it.
     # (Where a workload's tensors land in HBM depends on what was allocated before them, and that is worth 1 - 4 % of a step: with all
     # three workloads built up front the joint leg ran at 24.13 ms against 23.19 ms for `bench.py --workload joint` on the same box, and the
@@ -735,7 +771,7 @@ def main():
             line['ms_per_step_with_loss_item'] = sync_ms
         if head_res.get('host_issue_ms_per_step') is not None:
             line['host_issue_ms_per_step'] = head_res['host_issue_ms_per_step']
-        for leg in ('reg', 'joint'):
+        for leg in ('reg', 'joint', 'joint_smooth'):
             if leg in extra:
                 line['%s_ms_per_step' % leg] = extra[leg]['ms_per_step']
         if 'native_fp32_mfma' in extra:
@@ -747,11 +783,20 @@ def main():
             line.update(parity_loss_abs_diff=pf['loss_abs_diff'], parity_logits_rel_l2=pf['logits_rel_l2'], parity_logits_max_abs=pf['logits_max_abs_over_max'],
                         parity_eval_dice_abs_diff=pf['eval_dice_abs_diff'], argmax_flips_away_from_ties=pf['flips_away_from_ties'])
         if roofline:
+            stt = step_traffic_for(args.workload, head_res['ms_per_step']) if (args.precision == 'fp32_split' and tuple(shape) == (160, 192, 160)) else None
+            if stt:
+                roofline.update(stt)
+                line.update(step_traffic_over_algorithmic=stt['step_traffic_over_algorithmic'], step_frac_of_hbm_peak_on_traffic=stt['step_frac_of_hbm_peak_on_traffic'])
+            for leg in ('reg', 'joint'):
+                if leg in extra and args.precision == 'fp32_split' and tuple(shape) == (160, 192, 160):
+                    st2 = step_traffic_for(leg, extra[leg]['ms_per_step'])
+                    if st2:
+                        extra[leg]['traffic'] = st2
             line.update(roofline_kernel=roofline['kernel'], roofline_frac=roofline['frac'], roofline_avg_ms=roofline['avg_ms'])
         # the driver's record keeps `config` and `roofline` but drops unknown top-level keys: the same scalars once more where they survive
         cfg = line['config']
         cfg['matrix_arithmetic_bits'] = {'fp32_split': 22, 'fp32': 24, 'bf16': 8, 'bf16_storage': 8}[args.precision]
-        for k in ('ms_per_step_with_loss_item', 'reg_ms_per_step', 'joint_ms_per_step', 'native_fp32_mfma_ms_per_step', 'parity_logits_max_abs_vs_fp64',
+        for k in ('ms_per_step_with_loss_item', 'reg_ms_per_step', 'joint_ms_per_step', 'joint_smooth_ms_per_step', 'native_fp32_mfma_ms_per_step', 'parity_logits_max_abs_vs_fp64',
                   'parity_oracle_fp32_max_abs_vs_fp64', 'parity_loss_abs_diff', 'parity_logits_rel_l2', 'parity_logits_max_abs', 'parity_eval_dice_abs_diff',
                   'argmax_flips_away_from_ties'):
             if k in line:
