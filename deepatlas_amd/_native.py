@@ -62,6 +62,8 @@ SIGNATURES = {
     'da_deconv_k2s2_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_deconv_k2s2_fwd_bnstats': (I, [P, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),
     'da_deconv_k2s2_dgrad': (I, [P, P, P, I, I, I, I, I, I, P, SZ, P]),
+    'da_deconv_k2s2_bn_bwd_ws_bytes': (SZ, [I, I, I, I, I, I]),
+    'da_deconv_k2s2_bn_bwd': (I, [P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, I, P, I, P, SZ, P]),
     'da_deconv_k2s2_wgrad_ws_bytes': (SZ, [I, I, I, I, I, I]),
     'da_deconv_k2s2_wgrad': (I, [P, P, P, P, I, I, I, I, I, I, P, SZ, P]),
     'da_bn_ws_bytes': (SZ, [LL, I]),

@@ -242,6 +242,31 @@ extern "C" int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* 
     return 0;
 }
 
+// Fused backward of ConvTranspose3d(k2, s2) + BatchNorm3d(train) + LeakyReLU/ReLU (autograd of unets.py:49-52): from the gradient with respect to the
+// ACTIVATED output (gout) and the raw transposed-conv output y, in one pass over the two tensors -- dx (gradient of the block's input), dW, the transposed
+// conv's bias gradient, dgamma, dbeta.  The BatchNorm-backward sums come from one reduction pass over (gout, y) or from `pre` (sums the producer of gout
+// accumulated: da_bn_act_bwd_dbias_pre's argument); the apply pass, the tensor dy and the data / weight gradients' second and third read of it do not exist.
+// DA_ERR_UNSUPPORTED for channel counts without the fused kernel (callers then run da_bn_act_bwd_dbias + da_deconv_k2s2_dgrad + da_deconv_k2s2_wgrad).
+extern "C" size_t da_deconv_k2s2_bn_bwd_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    const long long M = (long long)N * D * H * W;
+    return da_align(da_bn_ws_bytes(M * 8, Cout)) + da_deconv_bn_bwd_ws_bytes(M, Cin, Cout);
+}
+extern "C" int da_deconv_k2s2_bn_bwd(const float* gout, const float* y, const float* mean, const float* rstd, const float* scale, const float* shift, float act_slope,
+                                     const float* in, const float* w_tio, float* dx, float* dw_tio, float* dbias, float* dgamma, float* dbeta,
+                                     int N, int D, int H, int W, int Cin, int Cout, const double* pre, int pre_n,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    if (!gout || !y || !mean || !rstd || !scale || !shift || !in || !w_tio || !dx || !dw_tio || N <= 0 || D <= 0 || H <= 0 || W <= 0) return DA_ERR_BADARG;
+    if (!da_deconv_bn_bwd_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_deconv_k2s2_bn_bwd_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
+    const long long M = (long long)N * D * H * W;
+    hipStream_t st = da_stream(stream);
+    const size_t bnb = da_align(da_bn_ws_bytes(M * 8, Cout));
+    const float* cm = nullptr;
+    int rc = da_bn_bwd_sums(gout, y, mean, rstd, scale, shift, act_slope, M * 8, Cout, dgamma, dbeta, &cm, ws, bnb, st, pre, pre_n);
+    if (rc) return rc;
+    return da_deconv_bn_bwd(gout, y, mean, rstd, scale, shift, cm, act_slope, in, w_tio, dx, dw_tio, dbias, M, D, H, W, Cin, Cout, (char*)ws + bnb, ws_bytes - bnb, st);
+}
+
 extern "C" size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
     long long per;
     const int O = 8 * Cin * Cout;

@@ -499,6 +499,28 @@ static int bn_act_bwd_impl(const T* dy, const T* x, const float* mean, const flo
     return 0;
 }
 
+// Internal (pointwise_internal.h): only the SUMS of a training-mode BatchNorm + activation backward -- dgamma, dbeta and cm[2][C] = (mean dz, mean dz xhat),
+// the constants bn_act_bwd_apply_kernel takes -- for a consumer that applies them itself (the fused transposed-conv backward, pointwise_mfma.hip).
+// pre / pre_n: sums a producer of dy accumulated (da_bn_act_bwd_dbias_pre); otherwise one reduction pass over (dy, x).  cm lies inside ws (returned).
+int da_bn_bwd_sums(const float* dy, const float* x, const float* mean, const float* rstd, const float* scale, const float* shift, float act_slope,
+                   long long M, int C, float* dgamma, float* dbeta, const float** cm_out, void* ws, size_t ws_bytes, hipStream_t st, const double* pre, int pre_n) {
+    if (!dy || !x || M <= 0 || C <= 0 || C > 1024) return DA_ERR_BADARG;
+    if (ws_bytes < da_bn_ws_bytes(M, C)) return DA_ERR_WS_SMALL;
+    const RowPlan p = plan_rows(M, C);
+    double* partial = (double*)ws;
+    float* cm = (float*)((char*)ws + da_align((size_t)kMaxBlocks * 2 * C * sizeof(double)));
+    if (pre && pre_n > 0) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, pre, pre_n, M, C, dgamma, dbeta, cm, rstd);
+    } else {
+        int rc = launch_partial<2, float>(p, x, dy, mean, rstd, scale, shift, act_slope, M, C, partial, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, p.grid, M, C, dgamma, dbeta, cm, (const float*)nullptr);
+    }
+    DA_LAUNCH_CHECK();
+    *cm_out = cm;
+    return 0;
+}
+
 extern "C" int da_bn_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                              const float* scale, const float* shift, float act_slope, int train,
                              float* dx, float* dgamma, float* dbeta, long long M, int C,

@@ -15,3 +15,13 @@ size_t da_pw_wgrad_ws_bytes(long long M, int ntaps, int Cin, int Cout);
 int da_pw_wgrad(const float* in, const float* dy, float* dw, long long M, int D, int H, int W, int Cin, int Cout,
                 int ntaps, int up, void* ws, size_t ws_bytes, hipStream_t st,
                 const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = -1.f, int in_bf16 = 0, int dy_bf16 = 0);
+
+// norm_act.hip: the sums of a training-mode BatchNorm + activation backward (dgamma, dbeta, cm = (mean dz, mean dz xhat)); cm lies inside ws
+int da_bn_bwd_sums(const float* dy, const float* x, const float* mean, const float* rstd, const float* scale, const float* shift, float act_slope,
+                   long long M, int C, float* dgamma, float* dbeta, const float** cm_out, void* ws, size_t ws_bytes, hipStream_t st, const double* pre, int pre_n);
+// pointwise_mfma.hip: fused BatchNorm-backward apply + transposed-conv (k2 s2) data gradient + weight gradient (da_deconv_k2s2_bn_bwd, deconv.hip)
+bool da_deconv_bn_bwd_supported(int Cin, int Cout);
+size_t da_deconv_bn_bwd_ws_bytes(long long M, int Cin, int Cout);
+int da_deconv_bn_bwd(const float* gout, const float* y, const float* mean, const float* rstd, const float* scale, const float* shift, const float* cm, float slope,
+                     const float* in, const float* w_tio, float* dx, float* dw_tio, float* dbias,
+                     long long M, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st);

@@ -446,6 +446,231 @@ __global__ void pw_reduce_kernel(const float* __restrict__ partial, int nparts, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused backward of an up-sampler block: BatchNorm + activation backward APPLIED ON THE FLY + transposed-conv (k2 s2) data gradient + weight gradient
+// (autograd of unets.py:49-52).  Op by op the 32-channel full-resolution link moves the tensor five times beyond the reduction pass: the apply pass reads
+// the incoming gradient and the raw output y and writes dy (13.5 GB per seg step in bn_act_bwd_apply alone, profiles/r06_step_traffic_seg.txt), then the
+// data gradient and the weight gradient each read dy again.  Here ONE kernel reads (gout, y) once: dy = scale (dz - mean dz - xhat mean(dz xhat)),
+// dz = gout act'(y scale + shift), lives in registers only,
+//   dx[v][ci]     = sum_t sum_co dy[map(v, t)][co] W_t[ci][co]      M = coarse voxels, K = (tap, cout)     (GATHER form of pw_mfma_kernel)
+//   dW_t[ci][co]  = sum_v in[v][ci] dy[map(v, t)][co]               K = coarse voxels                      (pw_mfma_wgrad_kernel)
+//   dbias[co]     = sum dy[.][co]                                   (the transposed conv's bias: analytically zero behind a BatchNorm, computed all the same)
+// A workgroup walks chunks of 32 coarse voxels; its four waves SHARE a chunk and take two taps each (the weight gradient keeps one accumulator set per
+// tap: 8 taps would be 128 registers per wave).  dy is formed in the data gradient's A layout (lane = voxel, four consecutive couts), multiplied, then
+// turned into the weight gradient's B layout (lane = cout, K = voxel) through a padded per-wave LDS tile (144-byte rows: conflict-free 16-byte stores and
+// 4-byte column reads).  The four waves' partial dx tiles meet in LDS (two barriers per chunk), every wave owns its taps' dW outright.
+// fp32 matrix instructions (exact, as the kernels it replaces); the next (chunk, tap)'s loads fly under the current one's MFMAs.
+// ---------------------------------------------------------------------------------------------------
+struct DbP {
+    const float* gout; const float* y; const float* in; const float* wp; float* dx;
+    float* dw_partial; double* col_partial;
+    const float* mean; const float* rstd; const float* scale; const float* shift; const float* cm; float slope;
+    long long M, nchunks; int D, H, W;
+};
+
+template <int CTRL> __device__ __forceinline__ double pw_dpp_add_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+template <int KC, int NT>
+__global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
+    constexpr int MT = 2;                                   // M-tiles (16 coarse voxels) per chunk
+    static_assert(MT * NT == 4, "one dx tile per wave in the cross-wave reduction");
+    constexpr int COUT = 16 * KC, CIN = 16 * NT, TRS = COUT + 4;
+    __shared__ __attribute__((aligned(16))) float tr[4][MT * 16 * TRS];
+    __shared__ __attribute__((aligned(16))) float red[4][MT * NT][64 * 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4;
+    const int t0 = 2 * wave;
+    float k_sc[KC][4], k_sf[KC][4], k_mu[KC][4], k_c1[KC][4], k_c2[KC][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ch = 16 * c + 4 * g + m;
+            k_sc[c][m] = p.scale[ch]; k_sf[c][m] = p.shift[ch]; k_mu[c][m] = p.mean[ch];
+            k_c1[c][m] = p.scale[ch] * p.cm[ch]; k_c2[c][m] = p.scale[ch] * p.rstd[ch] * p.cm[COUT + ch];
+        }
+    f32x4 acc_dw[2][NT][KC];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) acc_dw[tt][a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float colacc[KC][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) colacc[c][m] = 0.f;
+    const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + lane;
+    const long long toffA = tapoff(t0, p.H, p.W), toffB = tapoff(t0 + 1, p.H, p.W);
+    float* trw = tr[wave];
+
+    // unconditional loads (a row past the end reads coarse voxel 0 and is masked when dy is formed): nothing that touches memory sits in a branch
+    auto rows = [&](long long chunk, long long (&frow)[MT], bool (&aval)[MT]) {
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+            const long long v = chunk * (MT * 16) + r * 16 + i;
+            aval[r] = v < p.M;
+            frow[r] = fine0(aval[r] ? v : 0, p.D, p.H, p.W);
+        }
+    };
+    auto load_raw = [&](const long long (&frow)[MT], long long tf, float4 (&gq)[MT][KC], float4 (&yq)[MT][KC]) {
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const long long q = ((frow[r] + tf) * COUT + 16 * c + 4 * g) >> 2;
+                gq[r][c] = da_ldq_nt(p.gout, q); yq[r][c] = da_ldq_nt(p.y, q);
+            }
+    };
+    auto load_in = [&](long long chunk, float (&ain)[MT][4][NT]) {     // A operand of the weight gradient: lane (i, g) holds in[voxel 16 r + 4 g + m][16 a + i]
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const long long v = chunk * (MT * 16) + r * 16 + 4 * g + m;
+                const bool ok = v < p.M;
+                const long long vv = ok ? v : 0;
+#pragma unroll
+                for (int a = 0; a < NT; ++a) { const float t = p.in[vv * CIN + 16 * a + i]; ain[r][m][a] = ok ? t : 0.f; }
+            }
+    };
+    auto compute = [&](int tt, const float4 (&gq)[MT][KC], const float4 (&yq)[MT][KC], const bool (&aval)[MT], const float (&ain)[MT][4][NT], f32x4 (&acc_dx)[MT][NT]) {
+        float4 dq[MT][KC];
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const float gv[4] = {gq[r][c].x, gq[r][c].y, gq[r][c].z, gq[r][c].w}, xv[4] = {yq[r][c].x, yq[r][c].y, yq[r][c].z, yq[r][c].w};
+                float o[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float z = xv[m] * k_sc[c][m] + k_sf[c][m];
+                    const float dz = gv[m] * da_act_grad(z, p.slope);
+                    const float t = k_sc[c][m] * dz - k_c1[c][m] - (xv[m] - k_mu[c][m]) * k_c2[c][m];      // bn_act_bwd_apply_kernel's expression (norm_act.hip)
+                    o[m] = aval[r] ? t : 0.f;
+                    colacc[c][m] += o[m];
+                }
+                dq[r][c] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        // data gradient: A = dy (row = coarse voxel i, K = cout 16 c + 4 g + m), B = packed W_t (K = cout, column = cin 16 n + i)
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 b = wp4[(((size_t)(t0 + tt) * NT + n) * KC + c) * 64];
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].x, b.x, acc_dx[r][n], 0, 0, 0);
+                    acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].y, b.y, acc_dx[r][n], 0, 0, 0);
+                    acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].z, b.z, acc_dx[r][n], 0, 0, 0);
+                    acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].w, b.w, acc_dx[r][n], 0, 0, 0);
+                }
+            }
+        // dy into the weight gradient's B layout through this wave's LDS tile
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) *reinterpret_cast<float4*>(trw + (16 * r + i) * TRS + 16 * c + 4 * g) = dq[r][c];
+        // weight gradient: A = in (row = cin 16 a + i, K = voxel 16 r + 4 g + m), B = dy (K = voxel, column = cout 16 c + i)
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float bd[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) bd[c] = trw[(16 * r + 4 * g + m) * TRS + 16 * c + i];
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int c = 0; c < KC; ++c)
+                        acc_dw[tt][a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ain[r][m][a], bd[c], acc_dw[tt][a][c], 0, 0, 0);
+            }
+    };
+
+    long long chunk = blockIdx.x;
+    long long frow[MT]; bool aval[MT];
+    float4 g0[MT][KC], y0[MT][KC], g1[MT][KC], y1[MT][KC];
+    float ain[MT][4][NT];
+    if (chunk < p.nchunks) { rows(chunk, frow, aval); load_raw(frow, toffA, g0, y0); load_in(chunk, ain); }
+#pragma unroll 1
+    while (chunk < p.nchunks) {
+        f32x4 acc_dx[MT][NT];
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc_dx[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        load_raw(frow, toffB, g1, y1);                        // this chunk's second tap
+        compute(0, g0, y0, aval, ain, acc_dx);
+        const long long next = chunk + gridDim.x;
+        const bool has = next < p.nchunks;
+        long long frow2[MT]; bool aval2[MT];
+        rows(has ? next : chunk, frow2, aval2);
+        load_raw(frow2, toffA, g0, y0);                       // the next chunk's first tap (the last iteration re-reads its own chunk: harmless)
+        float ain2[MT][4][NT];
+        load_in(has ? next : chunk, ain2);
+        compute(1, g1, y1, aval, ain, acc_dx);
+        // the four waves' partial dx tiles (two taps each) -> LDS -> wave q sums tile q and stores it
+#pragma unroll
+        for (int r = 0; r < MT; ++r)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                *reinterpret_cast<float4*>(&red[wave][r * NT + n][lane * 4]) = make_float4(acc_dx[r][n][0], acc_dx[r][n][1], acc_dx[r][n][2], acc_dx[r][n][3]);
+        __syncthreads();
+        {
+            const int r = wave / NT, n = wave % NT;
+            float4 s = *reinterpret_cast<const float4*>(&red[0][wave][lane * 4]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const float4 t = *reinterpret_cast<const float4*>(&red[w][wave][lane * 4]); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+            const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long long v = chunk * (MT * 16) + r * 16 + 4 * g + reg;
+                if (v < p.M) p.dx[v * CIN + 16 * n + i] = sv[reg];
+            }
+        }
+        __syncthreads();
+        chunk = next;
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+            frow[r] = frow2[r]; aval[r] = aval2[r];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int a = 0; a < NT; ++a) ain[r][m][a] = ain2[r][m][a];
+        }
+    }
+    // this workgroup's dW partial: every wave writes its two taps (rows = cin 4 g + reg, columns = cout i)
+    float* part = p.dw_partial + (size_t)blockIdx.x * 8 * CIN * COUT;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    part[((size_t)(t0 + tt) * CIN + 16 * a + 4 * g + reg) * COUT + 16 * c + i] = acc_dw[tt][a][c][reg];
+    // column sums of dy: over the 16 voxel lanes of a row (DPP, double), then the four waves through LDS
+    double* cred = reinterpret_cast<double*>(&red[0][0][0]);      // [4 waves][COUT]
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double v = (double)colacc[c][m];
+            v = pw_dpp_add_f64<0xB1>(v); v = pw_dpp_add_f64<0x4E>(v); v = pw_dpp_add_f64<0x141>(v); v = pw_dpp_add_f64<0x140>(v);
+            if (i == 0) cred[wave * COUT + 16 * c + 4 * g + m] = v;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < COUT) p.col_partial[((size_t)blockIdx.x * 2) * COUT + threadIdx.x] = (cred[threadIdx.x] + cred[COUT + threadIdx.x]) + (cred[2 * COUT + threadIdx.x] + cred[3 * COUT + threadIdx.x]);
+}
+
 template <int KC, int NT, typename TA, typename TO>
 int launch_pw_t(const PwP& p, bool gather, hipStream_t st) {
     const unsigned grid = (unsigned)da_cdiv(p.M, 256);
@@ -633,5 +858,39 @@ static int pw_wgrad_slice(const float* in, const float* dy, float* dw, long long
 #undef DA_WG_CASE
     if (rc) return rc;
     { const int rc2 = da_reduce_partials(p.partial, nb, (int)O, dw, st); if (rc2) return rc2; }
+    return 0;
+}
+
+
+// ---- fused BatchNorm-backward + transposed-conv backward (deconv_bn_bwd_kernel) ----
+bool da_deconv_bn_bwd_supported(int Cin, int Cout) { return Cin == 32 && Cout == 32; }      // one (cout, cin) tile pair per wave pair: the full-resolution up-sampler of UNet_light
+static int db_blocks(long long nchunks) { return (int)(nchunks < 512 ? nchunks : 512); }    // two workgroups per CU
+size_t da_deconv_bn_bwd_ws_bytes(long long M, int Cin, int Cout) {
+    const long long nchunks = da_cdiv(M, 32);
+    const int nb = db_blocks(nchunks);
+    return da_pw_packed_bytes(8, Cout, Cin) + da_align((size_t)nb * 8 * Cin * Cout * sizeof(float)) + da_align((size_t)nb * 2 * Cout * sizeof(double));
+}
+int da_deconv_bn_bwd(const float* gout, const float* y, const float* mean, const float* rstd, const float* scale, const float* shift, const float* cm, float slope,
+                     const float* in, const float* w_tio, float* dx, float* dw_tio, float* dbias,
+                     long long M, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!da_deconv_bn_bwd_supported(Cin, Cout)) return DA_ERR_UNSUPPORTED;
+    if (ws_bytes < da_deconv_bn_bwd_ws_bytes(M, Cin, Cout)) return DA_ERR_WS_SMALL;
+    if ((unsigned long long)M * 8ull * (unsigned long long)Cout >= (1ull << 62)) return DA_ERR_UNSUPPORTED;
+    const long long nchunks = da_cdiv(M, 32);
+    const int nb = db_blocks(nchunks);
+    float* wp = (float*)ws;
+    float* dwp = (float*)((char*)ws + da_pw_packed_bytes(8, Cout, Cin));
+    double* colp = (double*)((char*)dwp + da_align((size_t)nb * 8 * Cin * Cout * sizeof(float)));
+    // B_t[k = cout][j = cin] = w_tio[(t * Cin + cin) * Cout + cout]: the data gradient's packing (da_deconv_k2s2_dgrad)
+    hipLaunchKernelGGL(pw_pack_kernel, dim3(da_grid((long long)8 * Cin * Cout, 256, 512)), dim3(256), 0, st, w_tio, wp, 8, Cout, Cin, 1, Cout, Cin, 0, 0);
+    DA_LAUNCH_CHECK();
+    DbP p;
+    p.gout = gout; p.y = y; p.in = in; p.wp = wp; p.dx = dx; p.dw_partial = dwp; p.col_partial = colp;
+    p.mean = mean; p.rstd = rstd; p.scale = scale; p.shift = shift; p.cm = cm; p.slope = slope;
+    p.M = M; p.nchunks = nchunks; p.D = D; p.H = H; p.W = W;
+    hipLaunchKernelGGL((deconv_bn_bwd_kernel<2, 2>), dim3(nb), dim3(256), 0, st, p);
+    DA_LAUNCH_CHECK();
+    { const int rc = da_reduce_partials(dwp, nb, 8 * Cin * Cout, dw_tio, st); if (rc) return rc; }
+    if (dbias) return da_colsum_finish((const void*)colp, nb, Cout, dbias, 0, (void*)st);
     return 0;
 }

@@ -1373,6 +1373,49 @@ class ConvBNActFn(Function):
                 None, None, None, None, None, None) + (None,) * ctx.n_extra
 
 
+FUSE_DECONV_BN_BWD = os.environ.get('DA_NO_DECONV_BN_BWD_FUSE') != '1'
+
+
+def _deconv_bn_bwd_fused(ctx, go, a, w_tio, y, stats, N, D, H, W, Cin, Cout, st):
+    """The up-sampler block's whole backward as ONE pass over (gout, y) (da_deconv_k2s2_bn_bwd: BatchNorm-backward apply on the fly + transposed-conv data
+    and weight gradient; the tensor dy is never written).  Taken in training mode, fp32 tensors, Cin = Cout = 32 (the full-resolution link of UNet_light),
+    when input and weight both want their gradients and the weight gradient goes straight into the optimiser's bucket or to a fresh tensor.  Runs on the
+    MAIN stream (it replaces the apply pass and the data gradient as well; the side stream keeps the 3x3x3 weight gradients).  None: not taken."""
+    M, C, slope, train, wsb = ctx.cfg
+    if not (FUSE_DECONV_BN_BWD and train and Cin == 32 and Cout == 32 and go.dtype == torch.float32 and y.dtype == torch.float32 and a.dtype == torch.float32
+            and go.is_contiguous() and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.has_bias):
+        return None
+    import ctypes
+    pre = _bwd_stats.pop(go.data_ptr(), None) if _bwd_stats else None
+    if pre is not None and not (pre[3] == M and pre[4] == C):
+        pre = None
+    dx = torch.empty_like(a)
+    direct = _direct_small_target(ctx.small_params, C, True)
+    dgb = direct if direct is not None else _empty((3, C), y)         # rows: transposed-conv bias, gamma, beta
+    wt = WgradTarget(ctx.wparam, 'iok', w_tio)
+    wp, wn = _ws(nat.lib().da_deconv_k2s2_bn_bwd_ws_bytes(N, D, H, W, Cin, Cout), a)
+    # (the weight-gradient target: the optimiser's bucket slice / a scratch tensor added into it by wt.finish(), or a fresh tensor handed to autograd)
+    if wt.gw is not None:
+        dw_out = wt.out()
+    else:
+        dw_out = torch.empty_like(w_tio)
+    ok = nat.call_supported('da_deconv_k2s2_bn_bwd', ptr(go), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), float(slope),
+                            ptr(a), ptr(w_tio), ptr(dx), ptr(dw_out), ptr(dgb[0]), ptr(dgb[1]), ptr(dgb[2]),
+                            N, D, H, W, Cin, Cout, ptr(pre[1]) if pre is not None else None, pre[2] if pre is not None else 0, wp, wn, st)
+    if not ok:
+        raise nat.NativeError('da_deconv_k2s2_bn_bwd declined a shape da_deconv_bn_bwd_supported accepts')
+    if wt.gw is not None:
+        wt.finish()
+        dw = None
+    else:
+        dw = grad_for_autograd(dw_out, 'iok', ctx.wparam)
+    if direct is not None:
+        db = dgamma = dbeta = None
+    else:
+        db, dgamma, dbeta = _accumulate_small_grads(*ctx.small_params, dgb[0], dgb[1], dgb[2])
+    return (ncdhw(dx), dw, db, dgamma, dbeta, None, None, None, None, None, None) + (None,) * ctx.n_extra
+
+
 class DeconvBNActFn(Function):
     """unets.deconvBlock with batchnorm=True as one autograd node: ConvTranspose3d(k2,s2) -> BatchNorm3d -> LeakyReLU (unets.py:42-52)."""
 
@@ -1420,6 +1463,9 @@ class DeconvBNActFn(Function):
         N, D, H, W, Cin = a.shape
         Cout = w_tio.shape[2]
         st = stream()
+        fused = _deconv_bn_bwd_fused(ctx, ndhwc(gout), a, w_tio, y, stats, N, D, H, W, Cin, Cout, st)
+        if fused is not None:
+            return fused
         dy, dgamma, dbeta, db = _bn_backward(ndhwc(gout), y, stats, ctx.cfg, ctx.has_bias, st, ctx.small_params)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -172,6 +172,17 @@ int da_deconv_k2s2_fwd_bnstats(const float* in, const float* w_tio, const float*
                                void* ws, size_t ws_bytes, void* stream);
 int da_deconv_k2s2_dgrad(const float* dy, const float* w_tio, float* dx,
                          int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* Fused backward of the up-sampler block ConvTranspose3d(k2, s2) -> BatchNorm3d(train) -> LeakyReLU/ReLU (autograd of unets.py:49-52).  gout = gradient
+ * with respect to the ACTIVATED output, y = the raw transposed-conv output, both [N][2D][2H][2W][Cout]; mean / rstd / scale / shift = the block's statistics
+ * rows; in = the block's input [N][D][H][W][Cin].  One pass over (gout, y) after the sums (one reduction pass, or `pre`[pre_n][2][Cout] = sums accumulated by
+ * the producer of gout as for da_bn_act_bwd_dbias_pre): dx [N][D][H][W][Cin], dw_tio [8][Cin][Cout], dbias[Cout] (may be NULL), dgamma[Cout], dbeta[Cout].
+ * The tensor dy = d loss / d y is never written.  DA_ERR_UNSUPPORTED unless Cin = Cout = 32 (callers fall back to da_bn_act_bwd_dbias +
+ * da_deconv_k2s2_dgrad + da_deconv_k2s2_wgrad). */
+size_t da_deconv_k2s2_bn_bwd_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int da_deconv_k2s2_bn_bwd(const float* gout, const float* y, const float* mean, const float* rstd, const float* scale, const float* shift, float act_slope,
+                          const float* in, const float* w_tio, float* dx, float* dw_tio, float* dbias, float* dgamma, float* dbeta,
+                          int N, int D, int H, int W, int Cin, int Cout, const double* pre, int pre_n,
+                          void* ws, size_t ws_bytes, void* stream);
 size_t da_deconv_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
 int da_deconv_k2s2_wgrad(const float* in, const float* dy, float* dw_tio, float* dbias,
                          int N, int D, int H, int W, int Cin, int Cout,

@@ -437,6 +437,20 @@ def test_parity_suite_holds_in_split_mode(name, fn, golden):
         ops.set_matrix_precision(prev)
 
 
+@pytest.mark.parametrize('env', [{'DA_FWDSP': '1'}, {'DA_FWDSP': '1', 'DA_FWDSP8': '1'}], ids=['four_wave_lds_weights', 'eight_wave_pipelined'])
+def test_opt_in_forward_kernels_hold_this_file(env):
+    """conv3d_fwdsp.hip (packed weights in LDS; four-wave form and the eight-wave pipelined form) is opt-in -- measured equal alone and slower in the step,
+    DESIGN.md section 4.11 -- and switched by environment variables read once per process: this file's cases (operand distributions against double,
+    outliers, degenerate boxes, the golden / oracle / full-size crop re-runs, which reach the eight-wave grid sizes) re-run in a child process."""
+    import os, subprocess, sys
+    if os.environ.get('DA_FWDSP') == '1':
+        pytest.skip('already inside the opt-in run')
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-k', 'not opt_in_forward_kernels'],
+                       env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_seg_light_golden_single_run_in_split_mode(golden):
     """ONE unperturbed split-mode run of the UNet_light golden step (no median over draws).  What a single run can be held to was measured with
     tools/debug/split_single_run.py (24 draws: the closed-form input + 23 inputs with 1e-7 relative noise, worst parameter's error over the bound
