@@ -344,6 +344,13 @@ def make_workloads(args, dev, rank, which):
         parallel.broadcast_parameters(ropt)
         x2, y2 = synthetic_batch_on_device(1, shape, n_classes, seed=1230 + rank, device=dev)
         im_m, im_t, sm, st_ = x[:1], x2, y[:1], y2
+        if smooth:
+            # ... and label maps with anatomy-like structure (blocky regions, lib/datasets.structured_labels) instead of iid labels: with 32 different labels
+            # inside every 32 x 8 x 4 box / every wave the label-keyed kernels (adjoint scatter through its LDS box: three label slots per box; label-warp Dice:
+            # one histogram pass per distinct label of a wave) run their overflow paths whatever the field
+            xs, ys = synthetic_batch_on_device(1, shape, n_classes, seed=230 + rank, device=dev, structured=True, sample0=0)
+            xt, yt = synthetic_batch_on_device(1, shape, n_classes, seed=230 + rank, device=dev, structured=True, sample0=1)
+            im_m, im_t, sm, st_ = xs, xt, ys, yt
         if 'reg' in which:
             rstep = RegistrationStep(reg, ropt)
             reg_fn = (lambda: rstep(im_m, im_t)[0]) if not args.graph else graphed(*rstep.segments(im_m, im_t), 'loss')
@@ -358,7 +365,7 @@ def make_workloads(args, dev, rank, which):
                                     (SEG_TRAIN_FLOP_PER_VOXEL + REG_TRAIN_FLOP_PER_VOXEL) * V if args.net == 'UNet_light' else None, lambda r: r, [ropt, opt])
             if smooth:
                 out['joint_smooth'] = out.pop('joint')
-                out['joint_smooth'].name += ' -- on a registration-like field (smooth shift of 1 - 2 voxels + 0.05 voxels of texture) instead of the untrained net\'s 8-voxel noise'
+                out['joint_smooth'].name += ' -- on registration-like inputs: blocky label maps and a smooth field (shift of 1 - 2 voxels + 0.05 voxels of texture) instead of iid labels and the untrained net\'s 8-voxel noise'
     return out, n_classes
 
 
