@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
                 const __amdgpu_buffer_rsrc_t ry = da_rsrc_n<false>(p.bst_y, n, (long long)p.D * p.H * p.W * p.Cs1);
 #pragma unroll
                 for (int r = 0; r < TY; ++r) {
-                    const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * p.Cs1 + cq) * 4);
+                    const unsigned off = ((unsigned)((z * p.H + (y0 + r)) * p.W + x) * (unsigned)p.Cs1 + (unsigned)cq) * 4u;      // (unsigned: the guard bounds the byte offset below 2^32, not 2^31)
                     yq[r] = da_buf_load4(ry, (cokq && y0 + r < p.H) ? off : 0xFFFFFFFFu);
                 }
                 const __amdgpu_buffer_rsrc_t rp = da_rsrc(p.bst_par, (unsigned)(4 * p.Cs1 * 4));
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
 #pragma unroll
                         for (int r = 0; r < TY; ++r) {
                             const int ys = 2 * (y0 + r) + ry;
-                            const unsigned off = (unsigned)((((zs * p.s2out.H0 + ys) * p.s2out.W0 + xs) * p.s2out.cin + c0) * HbEl<HB>::ES);
+                            const unsigned off = ((unsigned)((zs * p.s2out.H0 + ys) * p.s2out.W0 + xs) * (unsigned)(p.s2out.cin) + (unsigned)(c0)) * (unsigned)(HbEl<HB>::ES);
                             da_buf_storeq<HB>(r0, (ok0 && y0 + r < p.H && ys < p.s2out.H0) ? off : 0xFFFFFFFFu, acc[r][nn]);
                         }
                     }
@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(256, WPE) conv3_mfma_fwd_kernel(FwdP p) {
                     const __amdgpu_buffer_rsrc_t ro = da_rsrc_n<HB>(dbase, n, sample);
 #pragma unroll
                     for (int r = 0; r < TY; ++r) {
-                        const unsigned off = (unsigned)((((z * p.H + (y0 + r)) * p.W + x) * Cd + cd) * HbEl<HB>::ES);
+                        const unsigned off = ((unsigned)((z * p.H + (y0 + r)) * p.W + x) * (unsigned)Cd + (unsigned)cd) * HbEl<HB>::ES;
                         da_buf_storeq<HB>(ro, (cok && y0 + r < p.H) ? off : 0xFFFFFFFFu, acc[r][nn]);
                     }
                 }
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
                 const int hy = tt % HY; const int hz = tt / HY;
                 const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
                 const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + q * 4) * ES);
+                const unsigned off = ((unsigned)((z * p.H + y) * p.W + x) * (unsigned)(Cs) + (unsigned)(choff + q * 4)) * (unsigned)(ES);
                 *reinterpret_cast<float4*>(lds + idx * 4) = p.in_bf ? da_buf_loadq<true>(rs, inb ? off : 0xFFFFFFFFu) : da_buf_loadq<false>(rs, inb ? off : 0xFFFFFFFFu);
             }
         } else {
@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(256) conv3_thin_kernel(ThinP p) {
                 const int hy = tt % HY; const int hz = tt / HY;
                 const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
                 const bool inb = c < cvalid && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * Cs + choff + c) * ES);
+                const unsigned off = ((unsigned)((z * p.H + y) * p.W + x) * (unsigned)(Cs) + (unsigned)(choff + c)) * (unsigned)(ES);
                 lds[idx] = p.in_bf ? __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, inb ? off : 0xFFFFFFFFu, 0, 0) << 16)
                                    : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, inb ? off : 0xFFFFFFFFu, 0, 0));
             }
@@ -1127,7 +1127,7 @@ __global__ void __launch_bounds__(256, 2) conv3_mfma_wgrad_kernel(WgP p) {
             const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
             const int co = cg * CG + c4 * 4;
             const bool vin = idx < TVOX * QY && z < p.D && y < p.H && x < p.W;
-            const unsigned off = (unsigned)((((z * p.H + y) * p.W + x) * p.Cout + co) * HbEl<HB>::ES);
+            const unsigned off = ((unsigned)((z * p.H + y) * p.W + x) * (unsigned)(p.Cout) + (unsigned)(co)) * (unsigned)(HbEl<HB>::ES);
             if constexpr (!YS) {
                 preY[it] = da_buf_loadq<HB>(ry, (vin && co < p.Cout) ? off : 0xFFFFFFFFu);
             } else {

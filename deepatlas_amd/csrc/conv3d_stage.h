@@ -112,7 +112,7 @@ __device__ __forceinline__ void stage_load(float4* pre, const float* __restrict_
     for (int it = IT0; it < IT1; ++it) {
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
-        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * HbEl<HB>::ES);
+        const unsigned off = ((unsigned)((z * H + y) * W + x) * (unsigned)(Cs) + (unsigned)(cofs)) * (unsigned)(HbEl<HB>::ES);
         pre[it - IT0] = da_buf_loadq<HB, RAW>(rs, inb ? off : 0xFFFFFFFFu);
         if (vmask) *vmask |= (inb ? 1u : 0u) << (it - IT0);
         hv += STEP;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void stage_load_s2d(float4* pre, const float* __restr
         const int zs = 2 * z + rz, ys = 2 * y + ry, xs = 2 * x + rx;
         const bool inb = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q)
                          && zs < s2.D0 && ys < s2.H0 && xs < s2.W0;
-        const unsigned off = (unsigned)((((zs * s2.H0 + ys) * s2.W0 + xs) * s2.cin + cofs) * HbEl<HB>::ES);
+        const unsigned off = ((unsigned)((zs * s2.H0 + ys) * s2.W0 + xs) * (unsigned)(s2.cin) + (unsigned)(cofs)) * (unsigned)(HbEl<HB>::ES);
         pre[it - IT0] = da_buf_loadq<HB>(rs, inb ? off : 0xFFFFFFFFu);
         hv += STEP;
         hx += SX; const int cx = hx >= HX ? 1 : 0; hx -= cx * HX;
@@ -253,7 +253,7 @@ template <int CK, int HZ, bool HB = false, bool RAW = false> struct StageCursor 
         constexpr int SX = STEP % HX, SY = (STEP / HX) % HY, SZ = STEP / (HX * HY);
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inb = valid && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (hv < TOTAL / Q);
-        const unsigned off = (unsigned)((((z * H + y) * W + x) * Cs + cofs) * HbEl<HB>::ES);
+        const unsigned off = ((unsigned)((z * H + y) * W + x) * (unsigned)(Cs) + (unsigned)(cofs)) * (unsigned)(HbEl<HB>::ES);
         const float4 v = da_buf_loadq<HB, RAW>(rs, inb ? off : 0xFFFFFFFFu);
         last_inb = inb;
         hv += STEP;
