@@ -18,7 +18,7 @@ def short(name):
 
 
 def is_matrix(name):
-    return name.startswith('conv3_mfma_') or name.startswith('conv3_split_wgrad') or name.startswith('s2n_') or name.startswith('up_fwd') or name.startswith('up_dgrad') or name.startswith('up_wgrad_kernel')
+    return name.startswith('conv3_mfma_') or name.startswith('conv3_fwdsp') or name.startswith('conv3_split_wgrad') or name.startswith('s2n_') or name.startswith('up_fwd') or name.startswith('up_dgrad') or name.startswith('up_wgrad_kernel')
 
 
 def main():
