@@ -237,7 +237,8 @@ static void flow_geom(FlowWgP& p, int N, int D, int H, int W, int* nb) {
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.ntz = (D + TZ - 1) / TZ; p.nty = (H + TY - 1) / TY; p.ntx = (W + TX - 1) / TX;
     p.ntiles = N * p.ntz * p.nty * p.ntx;
-    *nb = p.ntiles < kFlowBlocks ? p.ntiles : kFlowBlocks;
+    static const int cap = [] { const char* e = getenv("DA_FLOW_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v < kFlowBlocks ? v : kFlowBlocks; }();   // A/B: 256 = one workgroup per CU
+    *nb = p.ntiles < cap ? p.ntiles : cap;
 }
 
 int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,

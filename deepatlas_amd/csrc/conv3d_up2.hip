@@ -150,14 +150,20 @@ __global__ void __launch_bounds__(256) up_pack_fwd_kernel(const float* __restric
         int tz[2], ty[2], tx[2];
         const int nz = up_taps_of((cls >> 2) & 1, (jt >> 2) & 1, tz), ny = up_taps_of((cls >> 1) & 1, (jt >> 1) & 1, ty), nx = up_taps_of(cls & 1, jt & 1, tx);
         float v[8];
+        int toff[8];                                             // the (up to) eight folded taps; an absent one re-reads a present tap and adds nothing
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int a = j >> 2, b = (j >> 1) & 1, c = j & 1; toff[j] = tz[a < nz ? a : 0] * 9 + ty[b < ny ? b : 0] * 3 + tx[c < nx ? c : 0]; }
+        const int coc = co < Cout ? co : Cout - 1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ci = ch * 8 + e;
+            const int ci = ch * 8 + e, cic = ci < Cin ? ci : Cin - 1;
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = w[((size_t)toff[j] * Cin + cic) * Cout + coc];
             double acc = 0.0;
-            if (ci < Cin && co < Cout)
-                for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c)
-                    acc += (double)w[((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + co];
-            v[e] = (float)acc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int a = j >> 2, b = (j >> 1) & 1, c = j & 1; if (a < nz && b < ny && c < nx) acc += (double)t[j]; }
+            v[e] = (ci < Cin && co < Cout) ? (float)acc : 0.f;
         }
         uint2 h0, l0, h1, l1;
         da_split2(make_float4(v[0], v[1], v[2], v[3]), sc, h0, l0);
@@ -318,12 +324,27 @@ __global__ void __launch_bounds__(256) up_pack_dgrad_kernel(const float* __restr
     __shared__ float red[4];
     const int ch = blockIdx.x;
     float m = 0.f;
-    for (int idx = threadIdx.x; idx < 27 * Cin * 8; idx += 256) { const int e = idx & 7, r = idx >> 3; const int co = ch * 8 + e; if (co < Cout) m = fmaxf(m, fabsf(w[(size_t)r * Cout + co])); }
+    const bool vec = (Cout & 3) == 0 && ch * 8 + 8 <= Cout && (reinterpret_cast<size_t>(w) & 15) == 0;
+    if (vec) {                                                   // quad loads, four in flight per lane (the largest |w| does not depend on the order)
+        const int nq = 27 * Cin * 2;
+        float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+        int idx = threadIdx.x;
+        for (; idx + 768 < nq; idx += 1024) {
+            const float4 a = *reinterpret_cast<const float4*>(w + (size_t)(idx >> 1) * Cout + ch * 8 + (idx & 1) * 4);
+            const float4 b = *reinterpret_cast<const float4*>(w + (size_t)((idx + 256) >> 1) * Cout + ch * 8 + (idx & 1) * 4);
+            const float4 c = *reinterpret_cast<const float4*>(w + (size_t)((idx + 512) >> 1) * Cout + ch * 8 + (idx & 1) * 4);
+            const float4 d = *reinterpret_cast<const float4*>(w + (size_t)((idx + 768) >> 1) * Cout + ch * 8 + (idx & 1) * 4);
+            m = da_absmax4(m, a); m1 = da_absmax4(m1, b); m2 = da_absmax4(m2, c); m3 = da_absmax4(m3, d);
+        }
+        for (; idx < nq; idx += 256) m = da_absmax4(m, *reinterpret_cast<const float4*>(w + (size_t)(idx >> 1) * Cout + ch * 8 + (idx & 1) * 4));
+        m = fmaxf(fmaxf(m, m1), fmaxf(m2, m3));
+    } else {
+        for (int idx = threadIdx.x; idx < 27 * Cin * 8; idx += 256) { const int e = idx & 7, r = idx >> 3; const int co = ch * 8 + e; if (co < Cout) m = fmaxf(m, fabsf(w[(size_t)r * Cout + co])); }
+    }
     const int ew = up_sum_exp(da_block_max4(m, red, (int)threadIdx.x >> 6, (int)threadIdx.x & 63));
     if (blockIdx.y == 0 && threadIdx.x == 0) wexp[ch] = ew;
     const float sc = da_pow2(ew);
     const int units = 16 * NTN * 64;                             // (step, N-tile, lane)
-    const bool vec = (Cout & 3) == 0 && ch * 8 + 8 <= Cout && (reinterpret_cast<size_t>(w) & 15) == 0;
     for (int u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
         const int lane = u & 63, nt = (u >> 6) % NTN, st = (u >> 6) / NTN;
         const int g = lane >> 4, n = lane & 15;
@@ -332,17 +353,28 @@ __global__ void __launch_bounds__(256) up_pack_dgrad_kernel(const float* __restr
         const int nz = up_taps_of_f((ft >> 4) & 3, tz), ny = up_taps_of_f((ft >> 2) & 3, ty), nx = up_taps_of_f(ft & 3, tx);
         // the 8 couts of the chunk are contiguous in w: two quad loads per folded tap when the layout allows it (same summation order either way)
         double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (ci < Cin)
+        if (vec) {                                               // all sixteen quad loads issued before the first sum (absent taps re-read a present one and add 0)
+            const int cic = ci < Cin ? ci : Cin - 1;
+            float4 p0[8], p1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int a = j >> 2, b = (j >> 1) & 1, c = j & 1;
+                const float* src = w + ((size_t)(tz[a < nz ? a : 0] * 9 + ty[b < ny ? b : 0] * 3 + tx[c < nx ? c : 0]) * Cin + cic) * Cout + ch * 8;
+                p0[j] = *reinterpret_cast<const float4*>(src); p1[j] = *reinterpret_cast<const float4*>(src + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int a = j >> 2, b = (j >> 1) & 1, c = j & 1;
+                if (ci < Cin && a < nz && b < ny && c < nx) {
+                    acc[0] += (double)p0[j].x; acc[1] += (double)p0[j].y; acc[2] += (double)p0[j].z; acc[3] += (double)p0[j].w;
+                    acc[4] += (double)p1[j].x; acc[5] += (double)p1[j].y; acc[6] += (double)p1[j].z; acc[7] += (double)p1[j].w;
+                }
+            }
+        } else if (ci < Cin)
             for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c) {
                 const float* src = w + ((size_t)(tz[a] * 9 + ty[b] * 3 + tx[c]) * Cin + ci) * Cout + ch * 8;
-                if (vec) {
-                    const float4 p0 = *reinterpret_cast<const float4*>(src), p1 = *reinterpret_cast<const float4*>(src + 4);
-                    acc[0] += (double)p0.x; acc[1] += (double)p0.y; acc[2] += (double)p0.z; acc[3] += (double)p0.w;
-                    acc[4] += (double)p1.x; acc[5] += (double)p1.y; acc[6] += (double)p1.z; acc[7] += (double)p1.w;
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (ch * 8 + e < Cout) acc[e] += (double)src[e];
-                }
+                for (int e = 0; e < 8; ++e) if (ch * 8 + e < Cout) acc[e] += (double)src[e];
             }
         float v[8];
 #pragma unroll
