@@ -526,7 +526,11 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 const long long q = ((frow[r] + tf) * COUT + 16 * c + 4 * g) >> 2;
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 4)
+                gq[r][c] = make_float4((float)q, 1.f, 2.f, 3.f); yq[r][c] = make_float4(1.f, (float)q, 2.f, 3.f);      // timing only
+#else
                 gq[r][c] = da_ldq_nt(p.gout, q); yq[r][c] = da_ldq_nt(p.y, q);
+#endif
             }
     };
     auto load_in = [&](long long chunk, float (&ain)[MT][4][NT]) {     // A operand of the weight gradient: lane (i, g) holds in[voxel 16 r + 4 g + m][16 a + i]
@@ -567,18 +571,28 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
                 const float4 b = wp4[(((size_t)(t0 + tt) * NT + n) * KC + c) * 64];
 #pragma unroll
                 for (int r = 0; r < MT; ++r) {
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 1)
+                    acc_dx[r][n][0] += dq[r][c].x * b.x + dq[r][c].y * b.y + dq[r][c].z * b.z + dq[r][c].w * b.w;      // timing only
+#else
                     acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].x, b.x, acc_dx[r][n], 0, 0, 0);
                     acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].y, b.y, acc_dx[r][n], 0, 0, 0);
                     acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].z, b.z, acc_dx[r][n], 0, 0, 0);
                     acc_dx[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r][c].w, b.w, acc_dx[r][n], 0, 0, 0);
+#endif
                 }
             }
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 2)
+        if (p.slope == 12345.f)      // timing only: no weight-gradient half
+#endif
         // dy into the weight gradient's B layout through this wave's LDS tile
 #pragma unroll
         for (int r = 0; r < MT; ++r)
 #pragma unroll
             for (int c = 0; c < KC; ++c) *reinterpret_cast<float4*>(trw + (16 * r + i) * TRS + 16 * c + 4 * g) = dq[r][c];
         // weight gradient: A = in (row = cin 16 a + i, K = voxel 16 r + 4 g + m), B = dy (K = voxel, column = cout 16 c + i)
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 2)
+        if (p.slope == 12345.f)
+#endif
 #pragma unroll
         for (int r = 0; r < MT; ++r)
 #pragma unroll
@@ -590,7 +604,11 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
                 for (int a = 0; a < NT; ++a)
 #pragma unroll
                     for (int c = 0; c < KC; ++c)
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 1)
+                        acc_dw[tt][a][c][0] += ain[r][m][a] * bd[c];      // timing only
+#else
                         acc_dw[tt][a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ain[r][m][a], bd[c], acc_dw[tt][a][c], 0, 0, 0);
+#endif
             }
     };
 
@@ -617,6 +635,10 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
         load_in(has ? next : chunk, ain2);
         compute(1, g1, y1, aval, ain, acc_dx);
         // the four waves' partial dx tiles (two taps each) -> LDS -> wave q sums tile q and stores it
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 8)
+        if (acc_dx[0][0][0] == 12345.678f)      // timing only: no cross-wave sum, no dx store, no barriers
+        {
+#endif
 #pragma unroll
         for (int r = 0; r < MT; ++r)
 #pragma unroll
@@ -636,6 +658,9 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
             }
         }
         __syncthreads();
+#if defined(DA_DB_ABL) && (DA_DB_ABL & 8)
+        }
+#endif
         chunk = next;
 #pragma unroll
         for (int r = 0; r < MT; ++r) {

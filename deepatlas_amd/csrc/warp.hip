@@ -86,6 +86,141 @@ __global__ void warp_fwd_kernel(const float* __restrict__ src, const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The many-channel gather, grouped (round 6).  In the kernels above the C / 4 lanes of a voxel each derive the voxel's taps themselves (index
+// division, three float divisions, floor, bounds): at C = 32 that arithmetic ran eight times per voxel and, with each corner's load and its
+// use inside one bounds branch, the eight loads of a voxel went out one round trip after the other -- the 32-channel warp sat at a quarter
+// of what the L1 path delivers, VALU- and latency-bound.  Here a wave first derives ONE plan per lane (64 voxels: base offset of the
+// (x0, y0, z0) corner, six weights, an 8-bit in-range mask), then walks the 64 voxels in `lpv` groups of 64 / lpv: the group's lanes fetch
+// their voxel's plan by cross-lane reads (ds_bpermute, no memory) and issue all eight 16-byte corner loads back to back (an out-of-range
+// corner re-reads element q of the sample and is not added).  Same taps, same weights, same order of the eight additions per channel.
+// ------------------------------------------------------------------------------------------------
+struct GatherPlan { int base, mask; float fx0, fx1, fy0, fy1, fz0, fz1; };
+
+__device__ __forceinline__ GatherPlan gather_plan(float gx, float gy, float gz, bool live, int D, int H, int W, int C) {
+    const bool fin = live && is_finite_coord(gx, gy, gz);
+    const Taps t = make_taps(fin ? gx : -4.f, fin ? gy : -4.f, fin ? gz : -4.f, D, H, W);
+    GatherPlan p;
+    p.fx0 = t.fx0; p.fx1 = t.fx1; p.fy0 = t.fy0; p.fy1 = t.fy1; p.fz0 = t.fz0; p.fz1 = t.fz1;
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = t.x0 + (k & 1), y = t.y0 + ((k >> 1) & 1), z = t.z0 + (k >> 2);
+        if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) m |= 1 << k;
+    }
+    p.mask = fin ? m : 0;
+    p.base = m ? ((t.z0 * H + t.y0) * W + t.x0) * C : 0;      // (only read where a mask bit is set: the cell then touches the volume and the product fits)
+    return p;
+}
+__device__ __forceinline__ GatherPlan gather_plan_from(const GatherPlan& p, int sl) {
+    GatherPlan r;
+    r.base = __shfl(p.base, sl); r.mask = __shfl(p.mask, sl);
+    r.fx0 = __shfl(p.fx0, sl); r.fx1 = __shfl(p.fx1, sl); r.fy0 = __shfl(p.fy0, sl); r.fy1 = __shfl(p.fy1, sl); r.fz0 = __shfl(p.fz0, sl); r.fz1 = __shfl(p.fz1, sl);
+    return r;
+}
+// the 8-corner gather of one voxel's channel quad q (sb: the sample's first element), as two halves so that the next group's loads can be
+// issued before this group's sums wait for theirs
+__device__ __forceinline__ void gather_issue(const float* __restrict__ sb, const GatherPlan& g, int q, int H, int W, int C, float4* a) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int koff = (((k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1)) * C;
+#if defined(DA_WARP_ABL) && (DA_WARP_ABL & 1)
+        const int off = ((g.mask >> k) & 1) ? ((g.base + koff) & 0xFFF) + q * 4 : q * 4;      // timing only: every gather hits the first 16 KB
+#else
+        const int off = ((g.mask >> k) & 1) ? g.base + koff + q * 4 : q * 4;
+#endif
+        a[k] = *reinterpret_cast<const float4*>(sb + off);
+    }
+}
+__device__ __forceinline__ float4 gather_reduce(const GatherPlan& g, const float4* a) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float wgt = ((k & 1) ? g.fx0 : g.fx1) * (((k >> 1) & 1) ? g.fy0 : g.fy1) * ((k >> 2) ? g.fz0 : g.fz1);
+        if ((g.mask >> k) & 1) { acc.x += a[k].x * wgt; acc.y += a[k].y * wgt; acc.z += a[k].z * wgt; acc.w += a[k].w * wgt; }
+    }
+    return acc;
+}
+// The walk over a wave's 64 plans, two groups in flight: `use(sl, acc)` receives the gathered quad of the voxel planned by lane sl.
+template <class Use>
+__device__ __forceinline__ void gather_walk(const float* __restrict__ sb, const GatherPlan& p, int lpv, int vpw, int gl, int q, int H, int W, int C, Use use) {
+#if defined(DA_WARP_NOPIPE)
+    for (int j = 0; j < lpv; ++j) {
+        float4 a[8];
+        const GatherPlan g = gather_plan_from(p, j * vpw + gl);
+        gather_issue(sb, g, q, H, W, C, a);
+        use(j * vpw + gl, gather_reduce(g, a));
+    }
+    return;
+#endif
+    float4 aA[8], aB[8];
+    GatherPlan gA = gather_plan_from(p, gl), gB;
+    gather_issue(sb, gA, q, H, W, C, aA);
+    int j = 0;
+    for (; j + 2 < lpv; j += 2) {
+        gB = gather_plan_from(p, (j + 1) * vpw + gl);
+        gather_issue(sb, gB, q, H, W, C, aB);
+        use(j * vpw + gl, gather_reduce(gA, aA));
+        gA = gather_plan_from(p, (j + 2) * vpw + gl);
+        gather_issue(sb, gA, q, H, W, C, aA);
+        use((j + 1) * vpw + gl, gather_reduce(gB, aB));
+    }
+    if (j + 1 < lpv) {
+        gB = gather_plan_from(p, (j + 1) * vpw + gl);
+        gather_issue(sb, gB, q, H, W, C, aB);
+        use(j * vpw + gl, gather_reduce(gA, aA));
+        use((j + 1) * vpw + gl, gather_reduce(gB, aB));
+    } else use(j * vpw + gl, gather_reduce(gA, aA));
+}
+// V * C < 2^31 (element offsets in 32 bits), C / 4 a power of two <= 64
+static bool gather_grouped_ok(int D, int H, int W, int C, int lpv) {
+    const long long V = (long long)D * H * W;
+    return lpv >= 2 && lpv <= 16 && (V + (long long)H * W + W + 1) * C < 0x7FFFFFF0LL;
+}
+
+// grid (blocks, N): a workgroup walks a contiguous range of one sample's voxels, 256 per iteration (64 per wave)
+__global__ void __launch_bounds__(256) warp_fwd_grouped_kernel(const float* __restrict__ src, const float* __restrict__ disp,
+                                                               float* __restrict__ deform, float* __restrict__ out, int D, int H, int W, int C, int lpv) {
+    const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int V = D * H * W, vpw = 64 / lpv, q = lane % lpv, gl = lane / lpv;
+    const int per = (int)(((long long)V + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int b = (gridDim.x % 8 == 0) ? da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const long long r0 = (long long)b * per;
+    const int v0 = r0 < V ? (int)r0 : V, v1 = r0 + per < V ? (int)(r0 + per) : V;
+    const float* sb = src + (long long)n * V * C;
+    float* ob = out + (long long)n * V * C;
+    extern __shared__ float4 gtile[];                          // [4 waves][64 voxels][lpv quads]
+    float4* tile = gtile + wave * 64 * lpv;
+    for (int vb = v0 + wave * 64; vb < v1; vb += 256) {
+        const int v = vb + lane;
+        const bool live = v < v1;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (live) {
+            int d, h, w; da_vox3(v, H, W, d, h, w);
+            const float* u = disp + ((long long)n * V + v) * 3;
+            gx = u[0] + id_coord(w, W); gy = u[1] + id_coord(h, H); gz = u[2] + id_coord(d, D);
+            if (deform) { float* o = deform + ((long long)n * V + v) * 3; o[0] = gx; o[1] = gy; o[2] = gz; }
+        }
+        const GatherPlan p = gather_plan(gx, gy, gz, live, D, H, W, C);
+        // the wave's 64 x C results pass through its LDS tile (the layout of 64 consecutive voxels in `out`) and leave as whole 1 KB rows: the
+        // gather loop itself holds no store that the next group's loads would have to wait behind (stores and loads share one counter)
+        gather_walk(sb, p, lpv, vpw, gl, q, H, W, C, [&](int sl, const float4 acc) { tile[sl * lpv + q] = acc; });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4* og = reinterpret_cast<float4*>(ob + (long long)vb * C);
+        for (int i = 0; i < lpv; ++i) {
+            const int idx = i * 64 + lane;
+#if defined(DA_WARP_ABL) && (DA_WARP_ABL & 2)
+            if (vb + idx / lpv < v1 && tile[idx].x == 12345.678f) og[idx] = tile[idx];      // timing only: no output stores
+#else
+            if (vb + idx / lpv < v1) og[idx] = tile[idx];
+#endif
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int VEC>
 __global__ void warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ src,
                                 const float* __restrict__ disp, float* __restrict__ d_disp, float* __restrict__ d_src,
@@ -369,6 +504,53 @@ __global__ void __launch_bounds__(256) warp_dice_partial_kernel(const float* __r
         const float pv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float tt = (rel == j) ? 1.f : 0.f; aI[j] += pv[j] * tt; aS[j] += pv[j]; aT[j] += tt; }
+    }
+    float* sI = shf; float* sS = shf + (size_t)slots * C; float* sT = shf + (size_t)2 * slots * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sI[s * C + q * 4 + j] = aI[j]; sS[s * C + q * 4 + j] = aS[j]; sT[s * C + q * 4 + j] = aT[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double tI = 0, tS = 0, tT = 0;
+        for (int k = 0; k < slots; ++k) { tI += sI[k * C + c]; tS += sS[k * C + c]; tT += sT[k * C + c]; }
+        double* o = partial + (((size_t)n * gridDim.x + blockIdx.x) * 3) * C;
+        o[c] = tI; o[C + c] = tS; o[2 * C + c] = tT;
+    }
+}
+
+// The same sums with the grouped gather (warp_fwd_grouped_kernel): one plan per voxel, eight loads in flight per lane.
+__global__ void __launch_bounds__(256) warp_dice_grouped_kernel(const float* __restrict__ src, const float* __restrict__ disp,
+                                                                const void* __restrict__ lab_t, int bt,
+                                                                int D, int H, int W, int C, int lpv, double* __restrict__ partial) {
+    extern __shared__ float shf[];   // [3][slots][C]
+    const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slots = 256 / lpv;
+    const int V = D * H * W, vpw = 64 / lpv, q = lane % lpv, gl = lane / lpv, s = threadIdx.x / lpv;
+    const int per = (int)(((long long)V + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int b = (gridDim.x % 8 == 0) ? da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const long long r0 = (long long)b * per;
+    const int v0 = r0 < V ? (int)r0 : V, v1 = r0 + per < V ? (int)(r0 + per) : V;
+    const float* sb = src + (long long)n * V * C;
+    float aI[4] = {0, 0, 0, 0}, aS[4] = {0, 0, 0, 0}, aT[4] = {0, 0, 0, 0};
+    for (int vb = v0 + wave * 64; vb < v1; vb += 256) {
+        const int v = vb + lane;
+        const bool live = v < v1;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        int lab = -1;
+        if (live) {
+            int d, h, w; da_vox3(v, H, W, d, h, w);
+            const float* u = disp + ((long long)n * V + v) * 3;
+            gx = u[0] + id_coord(w, W); gy = u[1] + id_coord(h, H); gz = u[2] + id_coord(d, D);
+            lab = warp_label_at(lab_t, bt, (long long)n * V + v);
+        }
+        const GatherPlan p = gather_plan(gx, gy, gz, live, D, H, W, C);
+        gather_walk(sb, p, lpv, vpw, gl, q, H, W, C, [&](int sl, const float4 acc) {
+            const int rel = __shfl(lab, sl) - q * 4;
+            if (vb + sl < v1) {
+                const float pv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { const float tt = (rel == jj) ? 1.f : 0.f; aI[jj] += pv[jj] * tt; aS[jj] += pv[jj]; aT[jj] += tt; }
+            }
+        });
     }
     float* sI = shf; float* sS = shf + (size_t)slots * C; float* sT = shf + (size_t)2 * slots * C;
 #pragma unroll
@@ -757,7 +939,11 @@ extern "C" int da_warp_fwd(const float* src, const float* disp, float* deform, f
     if (!src || !disp || !out || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return DA_ERR_BADARG;
     int lpv; const bool v4 = vec_ok(C, &lpv);
     const long long total = (long long)N * D * H * W * lpv;
-    if (v4) hipLaunchKernelGGL((warp_fwd_kernel<4>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), src, disp, deform, out, N, D, H, W, C, lpv);
+    static const bool grouped = [] { const char* e = getenv("DA_WARP_GROUPED"); return !(e && atoi(e) == 0); }();      // A/B: 0 = the per-lane-group kernels
+    if (v4 && grouped && lpv >= 2 && gather_grouped_ok(D, H, W, C, lpv) && N <= 65535) {
+        int nb = (int)da_cdiv((long long)D * H * W, 512); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(warp_fwd_grouped_kernel, dim3(nb, N), dim3(256), (size_t)4 * 64 * lpv * sizeof(float4), da_stream(stream), src, disp, deform, out, D, H, W, C, lpv);
+    } else if (v4) hipLaunchKernelGGL((warp_fwd_kernel<4>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), src, disp, deform, out, N, D, H, W, C, lpv);
     else hipLaunchKernelGGL((warp_fwd_kernel<1>), dim3(da_grid(total, 256)), dim3(256), 0, da_stream(stream), src, disp, deform, out, N, D, H, W, C, lpv);
     DA_LAUNCH_CHECK();
     return 0;
@@ -874,8 +1060,13 @@ extern "C" int da_warp_dice_fwd(const float* src, const float* disp, const void*
     const long long V = (long long)D * H * W;
     const int slots = 256 / lpv;
     int nblocks = (int)da_cdiv(V, (long long)slots * 4); if (nblocks > kLwdBlocks) nblocks = kLwdBlocks; if (nblocks < 1) nblocks = 1;
-    hipLaunchKernelGGL(warp_dice_partial_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
-                       src, disp, lab_t, lab_t_bytes, D, H, W, C, lpv, partial);
+    static const bool grouped = [] { const char* e = getenv("DA_WARP_GROUPED"); return !(e && atoi(e) == 0); }();
+    if (grouped && lpv >= 2 && gather_grouped_ok(D, H, W, C, lpv))
+        hipLaunchKernelGGL(warp_dice_grouped_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
+                           src, disp, lab_t, lab_t_bytes, D, H, W, C, lpv, partial);
+    else
+        hipLaunchKernelGGL(warp_dice_partial_kernel, dim3(nblocks, N), dim3(256), (size_t)3 * slots * C * sizeof(float), st,
+                           src, disp, lab_t, lab_t_bytes, D, H, W, C, lpv, partial);
     DA_LAUNCH_CHECK();
     return da_dice_finish(partial, nblocks, N, C, weight_type, no_bg, eps, loss, coef, isc, st);
 }

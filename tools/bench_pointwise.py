@@ -28,6 +28,7 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--only', default='', help='run only the cases whose name contains this')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     st = stream()
@@ -50,6 +51,15 @@ def main():
         ('deconv dgrad', lambda: call('da_deconv_k2s2_dgrad', ptr(dy), ptr(w), ptr(dx), N, D, H, W, Ci, Co, wp, wn, st), fine + coarse),
         ('deconv wgrad', lambda: call('da_deconv_k2s2_wgrad', ptr(x), ptr(dy), ptr(dw), None, N, D, H, W, Ci, Co, wp, wn, st), fine + coarse),
     ]
+    # the up-sampler block's fused backward (BatchNorm-backward sums pass + apply-on-the-fly + data / weight / bias gradients)
+    mean, rstd = torch.rand(Co, device=dev) - 0.5, torch.rand(Co, device=dev) + 0.5
+    gam, bet = torch.rand(Co, device=dev) + 0.5, torch.rand(Co, device=dev) - 0.5
+    dbias, dgam, dbet = torch.empty(Co, device=dev), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+    fb = nat.lib().da_deconv_k2s2_bn_bwd_ws_bytes(N, D, H, W, Ci, Co)
+    wpf, wnf = workspace.get(fb, dev)
+    yraw = torch.rand_like(y) - 0.5
+    cases.append(('deconv bn bwd (fused)', lambda: call('da_deconv_k2s2_bn_bwd', ptr(dy), ptr(yraw), ptr(mean), ptr(rstd), ptr(gam), ptr(bet), 0.01, ptr(x), ptr(w), ptr(dx), ptr(dw),
+                                                       ptr(dbias), ptr(dgam), ptr(dbet), N, D, H, W, Ci, Co, None, 0, wpf, wnf, st), 2 * fine + 2 * coarse))
     # head 16 -> 32 at full resolution
     M, Hi, Ho = 2 * 160 * 192 * 160, 16, 32
     hx = torch.rand((M, Hi), device=dev) - 0.5
@@ -69,6 +79,8 @@ def main():
         ('head wgrad (prologue)', lambda: call('da_conv1x1_wgrad_pro', ptr(hx), ptr(sc), ptr(sh), 0.01, ptr(hdy), ptr(hdw), None, M, Hi, Ho, wp2, wn2, st), bi + bo),
     ]
     for name, fn, nbytes in cases:
+        if a.only and a.only not in name:
+            continue
         ms = timeit(fn, a.iters)
         print('%-24s %7.3f ms  %7.1f MB  %7.1f GB/s  %.3f of HBM peak' % (name, ms, nbytes / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 8000.0))
 
