@@ -22,12 +22,12 @@ if want bench; then
   rm -f $O/bench_*.log
 fi
 if want prof; then
-  for w in seg reg joint; do
+  for w in seg reg joint joint_smooth; do
     timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$w -- python bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/prof_$w.log 2>&1 < /dev/null
     f=$(ls $O/prof_$w/*/*.db 2>/dev/null | head -1)
     if [ -n "$f" ]; then
       python tools/rocpd_summary.py "$f" --top 60 > $O/${w}_kernel_stats.txt 2>&1 < /dev/null
-      python tools/rocpd_timeline.py "$f" $([ $w = joint ] && echo --adam-per-step 2) > $O/${w}_timeline.txt 2>&1 < /dev/null
+      python tools/rocpd_timeline.py "$f" $([ ${w%%_*} = joint ] && echo --adam-per-step 2) > $O/${w}_timeline.txt 2>&1 < /dev/null
     fi
     rm -rf $O/prof_$w $O/prof_$w.log
     timeout 600 python tools/step_calls.py $w 2>&1 | grep -v amdgpu.ids > $O/${w}_calls.txt
@@ -43,6 +43,11 @@ if want kernels; then
   timeout 600 python tools/bench_losses.py 2>&1 | grep -v amdgpu.ids | grep -v '^\[' > $O/hbm_bound_calls.txt
   timeout 300 python tools/bench_warp.py 2>&1 | grep -v amdgpu.ids > $O/gather_kernels.txt
   LAYERS="32,16,16,2,160,192,160 16,0,16,2,160,192,160 8,0,16,2,160,192,160 64,32,32,2,80,96,80 32,0,32,2,80,96,80 64,64,64,2,40,48,40"
+  DA_MATRIX_MODE=2 timeout 300 python tools/bench_pointwise.py 2>&1 | grep -v amdgpu.ids > $O/pointwise_calls.txt
+  { echo "# a tiny kernel on the main stream beside a whole-GPU kernel on a side stream (tools/debug/concurrency_probe.py): probe ms / big-kernel ms / probe start after the big kernel's start";
+    for a in "--layer 8,16,3,1,160,192,160 --what wgrad" "--layer 32,16,16,1,160,192,160 --what wgrad" "--layer 32,16,16,1,160,192,160 --what fwd"; do DA_MATRIX_MODE=2 timeout 300 python tools/debug/concurrency_probe.py $a 2>&1 | grep -v amdgpu.ids; done; } > $O/concurrency_probe.txt
+  { echo "# the fused up-sampler backward (deconv_bn_bwd_kernel) with pieces removed (tools/ab/deconv_bwd_ablate.sh; timing only): DA_DB_ABL bits 1 no MFMAs, 2 no weight-gradient half, 4 no gout / y loads, 8 no cross-wave sum + dx store";
+    if ls deepatlas_amd/csrc/libda_D1.so > /dev/null 2>&1; then bash tools/ab/deconv_bwd_ablate.sh 2>&1 | grep -v "simple_timer\|amdgpu.ids"; fi; } > $O/deconv_bwd_ablate.txt
   echo "# DA_MATRIX_MODE=2 (fp32_split: two-term fp16 split), tools/bench_conv.py --layer C1,C2,Cout,N,D,H,W; one process per layer and variant, same box" > $O/conv_layers_isolated.txt
   for e in "" "DA_FWDSP=1" "DA_FWDSP=1 DA_FWDSP8=1"; do
     echo "== ${e:-shipped kernels (conv3d_mfma.hip)}" >> $O/conv_layers_isolated.txt
