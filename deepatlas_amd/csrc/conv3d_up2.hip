@@ -686,26 +686,37 @@ __global__ void __launch_bounds__(256, 2) up_wgrad_kernel(WgP p) {
 }
 
 // dW[t][ci][co] = sum over the 8 (class, coarse tap) pairs that contain original tap t and over the slabs, in double, fixed order
-__global__ void up_wgrad_reduce_kernel(const float* __restrict__ partial, int nslabs, int Cin, int Cout, float* __restrict__ dw) {
+// eight lanes per output (one per (class, coarse tap) pair holding the tap), the slabs four loads at a time; fixed order: per pair over the slabs, then the pairs
+__global__ void __launch_bounds__(256) up_wgrad_reduce_kernel(const float* __restrict__ partial, int nslabs, int Cin, int Cout, float* __restrict__ dw) {
     const int IO = Cin * Cout;
     const int total = 27 * IO;
-    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
-        const int tap = o / IO, r = o - tap * IO;
+    const int k = threadIdx.x & 7;
+    for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {      // (block-uniform trip count: the shuffles below need whole waves)
+        const int o = base + ((int)threadIdx.x >> 3);
+        const bool live = o < total;
+        const int oo = live ? o : 0;
+        const int tap = oo / IO, r = oo - tap * IO;
         const int t3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
         // per axis the two (p, j) pairs holding tap t: t 0: (0,0) (1,0); t 1: (0,1) (1,0); t 2: (0,1) (1,1)
-        int pa[3][2], ja[3][2];
+        int cls = 0, jt = 0;
+#pragma unroll
         for (int a = 0; a < 3; ++a) {
-            pa[a][0] = 0; ja[a][0] = t3[a] == 0 ? 0 : 1;
-            pa[a][1] = 1; ja[a][1] = t3[a] == 2 ? 1 : 0;
+            const int sel = (k >> (2 - a)) & 1;
+            const int pa = sel, ja = sel ? (t3[a] == 2 ? 1 : 0) : (t3[a] == 0 ? 0 : 1);
+            cls = cls * 2 + pa; jt = jt * 2 + ja;
         }
-        double s = 0.0;
-        for (int k = 0; k < 8; ++k) {
-            const int kz = (k >> 2) & 1, ky = (k >> 1) & 1, kx = k & 1;
-            const int cls = pa[0][kz] * 4 + pa[1][ky] * 2 + pa[2][kx], jt = ja[0][kz] * 4 + ja[1][ky] * 2 + ja[2][kx];
-            const size_t off = (size_t)(cls * 8 + jt) * IO + r;
-            for (int b = 0; b < nslabs; ++b) s += (double)partial[(size_t)b * 64 * IO + off];
+        const float* src = partial + (size_t)(cls * 8 + jt) * IO + r;
+        const size_t bs = (size_t)64 * IO;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = 0;
+        for (; b + 4 <= nslabs; b += 4) {
+            const float v0 = src[(size_t)b * bs], v1 = src[(size_t)(b + 1) * bs], v2 = src[(size_t)(b + 2) * bs], v3 = src[(size_t)(b + 3) * bs];
+            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
         }
-        dw[o] = (float)s;
+        for (; b < nslabs; ++b) s0 += (double)src[(size_t)b * bs];
+        double s = (s0 + s1) + (s2 + s3);
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (live && k == 0) dw[o] = (float)s;
     }
 }
 
@@ -830,7 +841,7 @@ extern "C" int da_upconv3d_k3_wgrad(const float* s1, int C1, const float* s2, in
     if (!attr) { const int e = up_set_lds(up_wgrad_kernel, shm); if (e) return e; attr = true; }
     hipLaunchKernelGGL(up_wgrad_kernel, dim3(p.nslabs, nchunks, 8), dim3(256), shm, st, p);
     DA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(up_wgrad_reduce_kernel, dim3(da_grid(27 * Cin * Cout, 256, 1024)), dim3(256), 0, st, p.partial, p.nslabs, Cin, Cout, dw_tio);
+    hipLaunchKernelGGL(up_wgrad_reduce_kernel, dim3(da_grid((long long)27 * Cin * Cout * 8, 256, 2048)), dim3(256), 0, st, p.partial, p.nslabs, Cin, Cout, dw_tio);
     DA_LAUNCH_CHECK();
     return 0;
 }
