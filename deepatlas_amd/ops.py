@@ -266,6 +266,7 @@ def enable_async_wgrad(flag=True):
     ASYNC_WGRAD = bool(flag)
 
 
+LAST_WGRAD_ON_MAIN = os.environ.get('DA_LAST_WGRAD_ON_MAIN', '1') == '1'      # see Conv3dFn.backward
 _N_SIDE = max(1, int(os.environ.get('DA_SIDE_STREAMS', '1')))      # > 1: weight gradients alternate between that many side streams (experiment)
 _SIDE_PRIO = int(os.environ.get('DA_SIDE_PRIO', '0'))      # HIP stream priority of the side stream (lower number = higher priority; out-of-range values clamp)
 _side_streams = []
@@ -885,8 +886,12 @@ class Conv3dK3Fn(Function):
             if db is not None:
                 gbt.add_(db)                         # the fused pass above already produced the bias gradient (main stream)
                 db = None
-            side = side_stream()
-            side.wait_stream(torch.cuda.current_stream())
+            # a layer whose inputs want no gradient is the net's first: nothing follows it on the main chain, while the side stream still has the weight
+            # gradients of the layers before it queued up -- its own weight gradient runs on the main stream (reg step: the side stream's backlog was the step's tail)
+            on_main = LAST_WGRAD_ON_MAIN and dx1 is None and dx2 is None
+            side = torch.cuda.current_stream() if on_main else side_stream()
+            if not on_main:
+                side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 sst = stream()
                 if db_partial is not None:
