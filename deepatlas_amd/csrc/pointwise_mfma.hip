@@ -481,11 +481,12 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
     static_assert(MT * NT == 4, "one dx tile per wave in the cross-wave reduction");
     constexpr int COUT = 16 * KC, CIN = 16 * NT, TRS = COUT + 4;
     __shared__ __attribute__((aligned(16))) float tr[4][MT * 16 * TRS];
-    __shared__ __attribute__((aligned(16))) float red[4][MT * NT][64 * 4];
+    __shared__ __attribute__((aligned(16))) float red2[2][4][MT * NT][64 * 4];      // two copies, alternating by chunk: ONE barrier per chunk (a copy is rewritten two barriers after it was read)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
     const int t0 = 2 * wave;
+    int par = 0;
     float k_sc[KC][4], k_sf[KC][4], k_mu[KC][4], k_c1[KC][4], k_c2[KC][4];
 #pragma unroll
     for (int c = 0; c < KC; ++c)
@@ -643,13 +644,13 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
         for (int r = 0; r < MT; ++r)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                *reinterpret_cast<float4*>(&red[wave][r * NT + n][lane * 4]) = make_float4(acc_dx[r][n][0], acc_dx[r][n][1], acc_dx[r][n][2], acc_dx[r][n][3]);
+                *reinterpret_cast<float4*>(&red2[par][wave][r * NT + n][lane * 4]) = make_float4(acc_dx[r][n][0], acc_dx[r][n][1], acc_dx[r][n][2], acc_dx[r][n][3]);
         __syncthreads();
         {
             const int r = wave / NT, n = wave % NT;
-            float4 s = *reinterpret_cast<const float4*>(&red[0][wave][lane * 4]);
+            float4 s = *reinterpret_cast<const float4*>(&red2[par][0][wave][lane * 4]);
 #pragma unroll
-            for (int w = 1; w < 4; ++w) { const float4 t = *reinterpret_cast<const float4*>(&red[w][wave][lane * 4]); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+            for (int w = 1; w < 4; ++w) { const float4 t = *reinterpret_cast<const float4*>(&red2[par][w][wave][lane * 4]); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
             const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
                 if (v < p.M) p.dx[v * CIN + 16 * n + i] = sv[reg];
             }
         }
-        __syncthreads();
+        par ^= 1;
 #if defined(DA_DB_ABL) && (DA_DB_ABL & 8)
         }
 #endif
@@ -683,7 +684,8 @@ __global__ void __launch_bounds__(256, 2) deconv_bn_bwd_kernel(DbP p) {
                 for (int reg = 0; reg < 4; ++reg)
                     part[((size_t)(t0 + tt) * CIN + 16 * a + 4 * g + reg) * COUT + 16 * c + i] = acc_dw[tt][a][c][reg];
     // column sums of dy: over the 16 voxel lanes of a row (DPP, double), then the four waves through LDS
-    double* cred = reinterpret_cast<double*>(&red[0][0][0]);      // [4 waves][COUT]
+    __syncthreads();                                               // (the last chunk's tiles are still being read)
+    double* cred = reinterpret_cast<double*>(&red2[0][0][0][0]);      // [4 waves][COUT]
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
