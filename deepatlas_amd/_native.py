@@ -37,6 +37,8 @@ SIGNATURES = {
     'da_conv3d_k3_dgrad_bst': (I, [P, P, P, I, P, I, I, I, I, I, I, P, P, F, P, I, P, P, SZ, P]),
     'da_conv3d_k3_prepack': (I, [P, I, I, I, I, I, I, I, I, P, SZ, P, SZ, P, P]),
     'da_conv3d_k3_use_prepacked': (None, [P, P, SZ, P, SZ]),
+    'da_conv3d_k3_prepack_any': (I, [P, I, I, I, I, I, I, I, I, I, I, P, SZ, P, P, P, P, SZ, P]),
+    'da_conv3d_k3_use_prepacked_any': (None, [P, P, SZ, I]),
     'da_conv3d_k3_prepack_many': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'da_conv3d_k3_fwd': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     'da_conv3d_k3_fwd_bnstats': (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, P, I, POINTER(c_int), P, SZ, P]),

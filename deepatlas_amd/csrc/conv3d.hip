@@ -279,6 +279,27 @@ static int launch_fwd(long long nvox, int Cout, hipStream_t st, Args... args) {
 
 }  // namespace
 
+// ---- kept packed operands of the families outside the split matrix kernels (conv3d_internal.h: da_pp_lookup) --------------------------------------
+namespace {
+struct KeptAny { int mode; const float* w; unsigned char* buf; size_t cap; int tag; size_t need; int filled; };      // mode 0 none, 1 hand-over (use), 2 fill
+thread_local KeptAny g_kp = {0, nullptr, nullptr, 0, 0, 0, 0};
+}
+DaKeptPack da_pp_lookup(const float* w_tio, size_t need, int tag) {
+    if (g_kp.mode == 2) {                                       // da_conv3d_k3_prepack_any in progress: size query (no buffer) or fill
+        g_kp.need = need; g_kp.tag = tag;
+        if (g_kp.w == w_tio && g_kp.buf && g_kp.cap >= need) { g_kp.filled = 1; return DaKeptPack{g_kp.buf, 1, 1}; }
+        return DaKeptPack{nullptr, 0, 1};
+    }
+    if (g_kp.mode == 1) {
+        const bool ok = g_kp.w == w_tio && g_kp.tag == tag && g_kp.buf && g_kp.cap >= need;
+        unsigned char* b = ok ? g_kp.buf : nullptr;
+        g_kp.mode = 0;
+        return DaKeptPack{b, 0, 0};
+    }
+    return DaKeptPack{nullptr, 0, 0};
+}
+void da_pp_drop_handover() { if (g_kp.mode == 1) g_kp.mode = 0; }
+
 // ---------------------------------------------------------------------------------------------------
 // internal entry points (also used by the MFMA dispatcher and the tests' A/B switch)
 // ---------------------------------------------------------------------------------------------------
@@ -339,6 +360,7 @@ extern "C" int da_conv3d_k3_fwd(const float* in1, int C1, const float* in2, int 
     if (!in1 || !w_tio || !out || C1 <= 0 || C2 < 0 || (C2 > 0 && !in2) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
         return DA_ERR_BADARG;
     hipStream_t st = da_stream(stream);
+    DaPpScope pp_scope;
     if (!force_direct() && stride == 2 && da_conv3_s2_supported(C1, C2, Cout) && !s2_prefers_direct(N, D, H, W)) {
         if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)) return DA_ERR_WS_SMALL;
         return da_conv3_s2_fwd(in1, C1, w_tio, bias, out, N, D, H, W, Cout, act_slope, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
@@ -428,6 +450,7 @@ extern "C" int da_conv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx
                                   void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w_tio || !dx1 || C1 <= 0 || C2 < 0 || (C2 > 0 && !dx2) || N <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
     hipStream_t st = da_stream(stream);
+    DaPpScope pp_scope;
     const int Cin = C1 + C2;
     if (ws_bytes < da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)) return DA_ERR_WS_SMALL;
     if (stride == 1) {
@@ -632,4 +655,55 @@ extern "C" int da_conv3d_k3_wgrad_bf16(const void* in1, int C1, const void* in2,
     }
     if (!da_conv3_mfma_wgrad_supported(C1, C2, Cout, stride)) return DA_ERR_UNSUPPORTED;
     return da_conv3_mfma_wgrad((const float*)in1, C1, (const float*)in2, C2, (const float*)dy, dw_tio, N, D, H, W, Cout, stride, ws, ws_bytes, da_stream(stream), 0, nullptr, nullptr, 1);
+}
+
+// ---- C ABI: kept packs of the folded up-sampling / native stride-2 / flow / thin kernels (conv3d_internal.h) ----------------------------------------
+// The family that da_conv3d_k3_fwd / da_conv3d_k3_dgrad (up2 = 0) or da_upconv3d_k3_fwd / _dgrad (up2 = 1; D, H, W = the COARSE extents) would run for this
+// shape packs its operand into `buf` (capacity `cap` bytes) and launches nothing else.  *need = bytes such a pack takes (0: the shape runs a kernel that keeps
+// nothing here -- the split matrix kernels have da_conv3d_k3_prepack, the direct kernels pack nothing); buf == NULL: size query only.  *tag identifies
+// (family, direction) for da_conv3d_k3_use_prepacked_any; *filled = 1 when buf was written.  KEEP IN STEP with the dispatch order of the two entries above.
+extern "C" int da_conv3d_k3_prepack_any(const float* w_tio, int C1, int C2, int Cout, int dgrad, int stride, int up2, int N, int D, int H, int W,
+                                        void* buf, size_t cap, size_t* need, int* tag, int* filled, void* ws, size_t ws_bytes, void* stream) {
+    if (need) *need = 0;
+    if (tag) *tag = 0;
+    if (filled) *filled = 0;
+    if (!w_tio || !need || !tag || C1 <= 0 || C2 < 0 || Cout <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return DA_ERR_BADARG;
+    if (da_matrix_mode() != 2 || force_direct()) return 0;
+    hipStream_t st = da_stream(stream);
+    const int Cin = C1 + C2;
+    float* dummy = const_cast<float*>(w_tio);                   // (never dereferenced: a fill call returns right after its pack stage)
+    g_kp = KeptAny{2, w_tio, (unsigned char*)buf, buf ? cap : 0, 0, 0, 0};
+    int rc = DA_ERR_UNSUPPORTED;
+    if (up2) {
+        if (stride == 1 && da_upconv3d_k3_supported(C1, C2, Cout))
+            rc = dgrad ? da_upconv3d_k3_dgrad(dummy, w_tio, dummy, C1, C2 > 0 ? dummy : nullptr, C2, N, D, H, W, Cout, ws, ws_bytes, stream)
+                       : da_upconv3d_k3_fwd(dummy, C1, C2 > 0 ? dummy : nullptr, C2, w_tio, nullptr, dummy, N, D, H, W, Cout, -1.f, ws, ws_bytes, stream);
+    } else if (stride == 2) {
+        if (C2 == 0 && da_conv3_s2_supported(C1, C2, Cout) && !s2_prefers_direct(N, D, H, W) && da_conv3_s2_is_native(Cin, Cout, N, D, H, W) &&
+            ws_bytes >= da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, 2))
+            rc = dgrad ? da_conv3_s2n_dgrad(dummy, w_tio, dummy, Cin, N, D, H, W, Cout, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st)
+                       : da_conv3_s2n_fwd(dummy, Cin, w_tio, nullptr, dummy, N, D, H, W, Cout, -1.f, ws, ws_bytes - da_bn_ws_bytes(0, Cout) - 4096, st);
+    } else if (!dgrad) {
+        if (da_conv3_mfma_fwd_supported(C1, C2, Cout, 1)) rc = DA_ERR_UNSUPPORTED;
+        else if (da_conv3_flowmm_supported(C1, C2, Cout, N, D, H, W)) rc = da_conv3_flowmm_fwd(dummy, C1, C2 > 0 ? dummy : nullptr, C2, w_tio, nullptr, dummy, N, D, H, W, Cout, -1.f, ws, ws_bytes, st);
+        else if (da_conv3_thin_supported(C1, C2, Cout, 1) && !getenv("DA_NO_THIN"))
+            rc = da_conv3_thin_fwd(dummy, C1, C2 > 0 ? dummy : nullptr, C2, w_tio, 0, nullptr, dummy, Cout, nullptr, 0, N, D, H, W, Cout, -1.f, ws, ws_bytes, st);
+    } else {
+        if (da_conv3_mfma_fwd_supported(Cout, 0, Cin, 1, C1, C2)) rc = DA_ERR_UNSUPPORTED;
+        else if (da_conv3_flowmm_supported(C1, C2, Cout, N, D, H, W)) rc = da_conv3_flowmm_dgrad(dummy, w_tio, dummy, C1, C2 > 0 ? dummy : nullptr, C2, N, D, H, W, Cout, ws, ws_bytes, st);
+        else if (da_conv3_thin_supported(Cout, 0, Cin, 1))
+            rc = da_conv3_thin_fwd(dummy, Cout, nullptr, 0, w_tio, 1, nullptr, dummy, C1, C2 > 0 ? dummy : nullptr, C2, N, D, H, W, Cin, -1.f, ws, ws_bytes, st);
+    }
+    const KeptAny got = g_kp;
+    g_kp.mode = 0;
+    if (rc == DA_ERR_UNSUPPORTED || rc == DA_ERR_WS_SMALL) return 0;
+    if (rc) return rc;
+    *need = got.need; *tag = got.tag;
+    if (filled) *filled = got.filled;
+    return 0;
+}
+// The NEXT da_conv3d_k3_fwd / _dgrad / da_upconv3d_k3_fwd / _dgrad call of this thread on `w_tio` whose kernel family and direction carry `tag` reads its
+// packed operand from buf (one call only; any other call drops the hand-over).
+extern "C" void da_conv3d_k3_use_prepacked_any(const float* w_tio, const void* buf, size_t cap, int tag) {
+    g_kp = KeptAny{(w_tio && buf && tag) ? 1 : 0, w_tio, (unsigned char*)const_cast<void*>(buf), cap, tag, 0, 0};
 }

@@ -429,10 +429,17 @@ int da_conv3_flowmm_fwd(const float* in1, int C1, const float* in2, int C2, cons
     const Plan q = fm_plan(N, D, H, W);
     const int Cin = C1 + C2, NSTEP = (9 * (Cin / 8) + 3) / 4;
     FwdP p;
-    p.in1 = in1; p.in2 = in2; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.bias = bias; p.out = out;
+    // the packed operand: in the workspace, or in the caller's kept buffer (conv3d_internal.h: da_pp_lookup)
+    const DaKeptPack kp = da_pp_lookup(w_tio, da_conv3_flowmm_ws_bytes(), DA_PP_FM_FWD);
+    if (kp.only && !kp.buf) return 0;
+    unsigned char* pk = kp.buf ? kp.buf : (unsigned char*)ws;
+    p.in1 = in1; p.in2 = in2; p.wexp = (const int*)pk; p.wp = pk + 256; p.bias = bias; p.out = out;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles; p.slope = slope;
-    hipLaunchKernelGGL(fm_pack_fwd_kernel, dim3(1), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, NSTEP);
-    DA_LAUNCH_CHECK();
+    if (!kp.buf || kp.fill) {
+        hipLaunchKernelGGL(fm_pack_fwd_kernel, dim3(1), dim3(256), 0, st, w_tio, (unsigned short*)(pk + 256), (int*)pk, Cin, Cout, NSTEP);
+        DA_LAUNCH_CHECK();
+    }
+    if (kp.only) return 0;
     const int grid = q.ntiles < 512 ? q.ntiles : 512;
     const size_t shm = (size_t)2 * HV * Cin * 2 + 16;
 #define X(a, b) if (C1 == a && C2 == b) { static bool set = false; if (!set) { const int e = fm_set_lds(fm_fwd_kernel<a, b>, shm); if (e) return e; set = true; } \
@@ -450,10 +457,16 @@ int da_conv3_flowmm_dgrad(const float* dy, const float* w_tio, float* dx1, int C
     const Plan q = fm_plan(N, D, H, W);
     const int Cin = C1 + C2, NTN = (Cin + 15) / 16;
     DgP p;
-    p.dy = dy; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.dx1 = dx1; p.dx2 = dx2;
+    const DaKeptPack kp = da_pp_lookup(w_tio, da_conv3_flowmm_ws_bytes(), DA_PP_FM_DGRAD);
+    if (kp.only && !kp.buf) return 0;
+    unsigned char* pk = kp.buf ? kp.buf : (unsigned char*)ws;
+    p.dy = dy; p.wexp = (const int*)pk; p.wp = pk + 256; p.dx1 = dx1; p.dx2 = dx2;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.Cin = Cin; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.ntiles = q.ntiles;
-    hipLaunchKernelGGL(fm_pack_dgrad_kernel, dim3(1), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, NTN);
-    DA_LAUNCH_CHECK();
+    if (!kp.buf || kp.fill) {
+        hipLaunchKernelGGL(fm_pack_dgrad_kernel, dim3(1), dim3(256), 0, st, w_tio, (unsigned short*)(pk + 256), (int*)pk, Cin, Cout, NTN);
+        DA_LAUNCH_CHECK();
+    }
+    if (kp.only) return 0;
     const int grid = q.ntiles < 512 ? q.ntiles : 512;
     const size_t shm = (size_t)2 * HV * 8 + 16;
 #define X(a, b) if (C1 == a && C2 == b) hipLaunchKernelGGL((fm_dgrad_kernel<a, b>), dim3(grid), dim3(256), shm, st, p);

@@ -80,3 +80,17 @@ int da_conv3_flow_wgrad(const float* in1, int C1, const float* in2, int C2, cons
 bool da_conv3_fewcin_wgrad_supported(int C1, int C2, int Cout, int stride);
 int da_conv3_fewcin_wgrad(const float* in1, int C1, const float* in2, int C2, const float* dy, float* dw_tio,
                           int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, hipStream_t st, int dy_bf16 = 0);     // dy_bf16: dy is a bf16 tensor (in1 / in2 fp32)
+
+// ---- kept packed operands of the kernel families OUTSIDE the split matrix kernels (folded up-sampling, native stride-2, flow, thin) -----------------
+// Each of them packs its weights into the call's workspace before its main kernel: a 5 - 20 us launch in the dependent chain of a layer, every call, for
+// data that only changes when the optimiser steps (a registration step: 22 of them, 0.2 ms of 4.3).  da_conv3d_k3_prepack_any (conv3d.hip) fills a
+// caller-owned buffer, da_conv3d_k3_use_prepacked_any hands it to the NEXT call on the same weights.  A family calls da_pp_lookup where it would pack:
+//   .buf != nullptr: the packed operand lives there -- pack into it first when .fill, it is ready otherwise;  .buf == nullptr: pack into the workspace as always;
+//   .only: return right after the pack stage (a fill call: dummy tensor pointers, nothing else may be launched).
+// tag: the family's own id for (kernel, direction), so that a hand-over meant for the forward is never taken by the data gradient of the same weights.
+struct DaKeptPack { unsigned char* buf; int fill; int only; };
+DaKeptPack da_pp_lookup(const float* w_tio, size_t need, int tag);
+void da_pp_drop_handover();      // at the end of every public entry that may have been handed a pack: an unconsumed hand-over serves no later call
+struct DaPpScope { ~DaPpScope() { da_pp_drop_handover(); } };
+enum { DA_PP_UP_FWD = 1, DA_PP_UP_DGRAD, DA_PP_S2N_FWD, DA_PP_S2N_DGRAD, DA_PP_FM_FWD, DA_PP_FM_DGRAD, DA_PP_THIN, DA_PP_THIN_FLIP };
+bool da_conv3_s2_is_native(int Cin, int Cout, int N, int D, int H, int W);      // conv3d_s2.hip: the stride-2 layer runs conv3d_s2n.hip

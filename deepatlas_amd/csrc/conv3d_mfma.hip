@@ -2482,6 +2482,7 @@ bool da_conv3_thin_supported(int C1, int C2, int Cout, int stride) {
     return false;
 }
 
+static thread_local int g_thin_pack = 1, g_thin_only = 0;      // kept packed weights (da_pp_lookup in da_conv3_thin_fwd): pack at all / stop after the pack
 static const size_t kThinPackBytes = 65536;        // padded weights [27][CinP][CT]: <= 27.6 KB (Cin <= 64, CT = 4) / 13.8 KB (Cin <= 4, CT <= 32)
 
 template <int CL, int CT, int VPT, int JR = CT, int CR = CL>
@@ -2489,7 +2490,8 @@ static int thin_launch(ThinP& p, const float* w_src, float* wq, hipStream_t st, 
     const int Cin = p.C1 + p.C2;
     const int CinP = (Cin + CL - 1) / CL * CL;
     if ((size_t)27 * CinP * CT * sizeof(float) > kThinPackBytes / 2) return DA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(thin_pack_kernel, dim3(da_grid(27 * CinP * CT, 256, 64)), dim3(256), 0, st, w_src, wq, Cin, CinP, p.Cout, CT, p.flip_tr, j0, Cw < 0 ? p.Cout : Cw);
+    if (g_thin_pack) hipLaunchKernelGGL(thin_pack_kernel, dim3(da_grid(27 * CinP * CT, 256, 64)), dim3(256), 0, st, w_src, wq, Cin, CinP, p.Cout, CT, p.flip_tr, j0, Cw < 0 ? p.Cout : Cw);
+    if (g_thin_only) return 0;
     p.w = wq;
     const size_t ldsb = ((size_t)(2 * VPT + 2) * HY * HX * CL + (CT <= 16 ? 0 : (size_t)27 * CinP * CT)) * sizeof(float);
     p.ntz = (p.D + 2 * VPT - 1) / (2 * VPT);
@@ -2524,7 +2526,13 @@ int da_conv3_thin_fwd(const float* in1, int C1, const float* in2, int C2, const 
                       void* ws, size_t ws_bytes, hipStream_t st, int in_bf16, int out_bf16) {
     if ((unsigned long long)D * H * W * (C1 > C2 ? C1 : C2) * 4ull >= 0xFFFFFFF0ull) return DA_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < kThinPackBytes) return DA_ERR_WS_SMALL;
-    float* wq = (float*)ws;
+    const int Cin_ = C1 + C2;
+    if (!(Cout <= 4 || Cin_ == 1 || (Cin_ <= 4 && C2 > 0) || (Cin_ <= 4 && C2 == 0))) return DA_ERR_UNSUPPORTED;      // (the cases below; decided before the kept-pack lookup)
+    // the padded weights: in the workspace, or in the caller's kept buffer (conv3d_internal.h: da_pp_lookup; fp32 tensors only -- the bf16 twins pack per call)
+    const DaKeptPack kp = (in_bf16 || out_bf16) ? DaKeptPack{nullptr, 0, 0} : da_pp_lookup(w, kThinPackBytes, flip_tr ? DA_PP_THIN_FLIP : DA_PP_THIN);
+    if (kp.only && !kp.buf) return 0;
+    float* wq = kp.buf ? (float*)kp.buf : (float*)ws;
+    struct ThinFlags { ThinFlags(int pack, int only) { g_thin_pack = pack; g_thin_only = only; } ~ThinFlags() { g_thin_pack = 1; g_thin_only = 0; } } thin_flags((!kp.buf || kp.fill) ? 1 : 0, kp.only);
     ThinP p;
     p.in1 = in1; p.in2 = in2; p.C1 = C1; p.C2 = C2; p.w = w; p.bias = bias; p.out1 = out1; p.out2 = out2; p.Cs1 = Cs1; p.Cs2 = Cs2;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.flip_tr = flip_tr; p.slope = slope;

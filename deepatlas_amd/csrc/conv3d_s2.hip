@@ -103,6 +103,8 @@ size_t da_conv3_s2_ws_bytes(int N, int D, int H, int W, int Cin, int Cout) {
 }
 
 // ws layout: [S (space-to-depth tensor or its gradient)] [W' expanded] [dW' expanded] [inner conv scratch]
+bool da_conv3_s2_is_native(int Cin, int Cout, int N, int D, int H, int W) { return s2_native(Cin, Cout, N, D, H, W); }
+
 int da_conv3_s2_fwd(const float* in, int Cin, const float* w_tio, const float* bias, float* out,
                     int N, int D, int H, int W, int Cout, float slope, void* ws, size_t ws_bytes, hipStream_t st, int act_bf16) {
     if (act_bf16 && (da_matrix_mode() != 1 || !s2_fused())) return DA_ERR_UNSUPPORTED;      // bf16 activation storage: fused addressing, bf16 matrix mode

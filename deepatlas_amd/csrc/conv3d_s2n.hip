@@ -699,11 +699,18 @@ int da_conv3_s2n_fwd(const float* in, int Cin, const float* w_tio, const float* 
     if (ws_bytes < da_conv3_s2n_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     const Plan q = s2n_plan(N, D, H, W);
     FwdP p;
-    p.in = in; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.bias = bias; p.out = out;
+    // the packed operand: in the workspace, or in the caller's kept buffer (conv3d_internal.h: da_pp_lookup)
+    const DaKeptPack kp = da_pp_lookup(w_tio, da_align((size_t)(Cin / 8) * NSTEPS * (Cout / 16) * NPLN * 1024) + 256, DA_PP_S2N_FWD);
+    if (kp.only && !kp.buf) return 0;
+    unsigned char* pk = kp.buf ? kp.buf : (unsigned char*)ws;
+    p.in = in; p.wexp = (const int*)pk; p.wp = pk + 256; p.bias = bias; p.out = out;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Do = q.Do; p.Ho = q.Ho; p.Wo = q.Wo;
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.nchunks = Cin / 8; p.NT = Cout / 16; p.slope = slope;
-    hipLaunchKernelGGL(s2n_pack_fwd_kernel, dim3(p.nchunks, 4), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.NT);
-    DA_LAUNCH_CHECK();
+    if (!kp.buf || kp.fill) {
+        hipLaunchKernelGGL(s2n_pack_fwd_kernel, dim3(p.nchunks, 4), dim3(256), 0, st, w_tio, (unsigned short*)(pk + 256), (int*)pk, Cin, Cout, p.NT);
+        DA_LAUNCH_CHECK();
+    }
+    if (kp.only) return 0;
     static bool attr = false;
     if (!attr) { const int e = s2n_set_lds(s2n_fwd_kernel, NPLN * PLANE_B + 16); if (e) return e; attr = true; }
     hipLaunchKernelGGL(s2n_fwd_kernel, dim3(q.ntiles, Cout / 32), dim3(256), NPLN * PLANE_B + 16, st, p);
@@ -716,11 +723,17 @@ int da_conv3_s2n_dgrad(const float* dy, const float* w_tio, float* dx, int Cin, 
     if (ws_bytes < da_conv3_s2n_ws_bytes(N, D, H, W, Cin, Cout)) return DA_ERR_WS_SMALL;
     const Plan q = s2n_plan(N, D, H, W);
     DgP p;
-    p.dy = dy; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.dx = dx;
+    const DaKeptPack kp = da_pp_lookup(w_tio, da_align((size_t)27 * (Cout / 32) * (Cin / 16) * NPLN * 1024) + 256, DA_PP_S2N_DGRAD);
+    if (kp.only && !kp.buf) return 0;
+    unsigned char* pk = kp.buf ? kp.buf : (unsigned char*)ws;
+    p.dy = dy; p.wexp = (const int*)pk; p.wp = pk + 256; p.dx = dx;
     p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Do = q.Do; p.Ho = q.Ho; p.Wo = q.Wo;
     p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx; p.KS = Cout / 32; p.NTN = Cin / 16;
-    hipLaunchKernelGGL(s2n_pack_dgrad_kernel, dim3(da_grid((long long)27 * p.KS * p.NTN * 64, 256, 32)), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.KS, p.NTN);
-    DA_LAUNCH_CHECK();
+    if (!kp.buf || kp.fill) {
+        hipLaunchKernelGGL(s2n_pack_dgrad_kernel, dim3(da_grid((long long)27 * p.KS * p.NTN * 64, 256, 32)), dim3(256), 0, st, w_tio, (unsigned short*)(pk + 256), (int*)pk, Cin, Cout, p.KS, p.NTN);
+        DA_LAUNCH_CHECK();
+    }
+    if (kp.only) return 0;
     const size_t shm = (size_t)NPLN * (Cout / 8) * GV * 16 + 16;
     static bool attr[3] = {false, false, false};
     int e = 0;

@@ -767,17 +767,25 @@ static bool up_sizes_ok(int N, int Dc, int Hc, int Wc, int Cin, int Cout) {
 extern "C" int da_upconv3d_k3_fwd(const float* s1, int C1, const float* s2, int C2, const float* w_tio, const float* bias, float* out,
                                   int N, int Dc, int Hc, int Wc, int Cout, float act_slope, void* ws, size_t ws_bytes, void* stream) {
     if (!s1 || !w_tio || !out || (C2 > 0 && !s2) || N <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0) return DA_ERR_BADARG;
+    DaPpScope pp_scope;
     const int Cin = C1 + C2;
     if (!da_upconv3d_k3_supported(C1, C2, Cout) || !up_sizes_ok(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_upconv3d_k3_ws_bytes(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
     const Plan q = up_plan(N, Dc, Hc, Wc);
     FwdP p;
-    p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.bias = bias; p.out = out;
-    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
     p.nchunks = Cin / 8; p.NTall = (Cout + 15) / 16; p.slope = act_slope;
-    hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(p.nchunks, 4 * p.NTall), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, p.NTall);
-    DA_LAUNCH_CHECK();
+    // the packed operand: in the workspace, or in the caller's kept buffer (conv3d_internal.h: da_pp_lookup)
+    const DaKeptPack kp = da_pp_lookup(w_tio, da_align((size_t)p.nchunks * 16 * p.NTall * NPLN * 1024) + 256, DA_PP_UP_FWD);
+    if (kp.only && !kp.buf) return 0;
+    unsigned char* pk = kp.buf ? kp.buf : (unsigned char*)ws;
+    p.s1 = s1; p.s2 = s2; p.C1 = C1; p.C2 = C2; p.wexp = (const int*)pk; p.wp = pk + 256; p.bias = bias; p.out = out;
+    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
+    if (!kp.buf || kp.fill) {
+        hipLaunchKernelGGL(up_pack_fwd_kernel, dim3(p.nchunks, 4 * p.NTall), dim3(256), 0, st, w_tio, (unsigned short*)(pk + 256), (int*)pk, Cin, Cout, p.NTall);
+        DA_LAUNCH_CHECK();
+    }
+    if (kp.only) return 0;
     const size_t shm = NPLN * SPLANE_B + 16;
     static bool a1 = false, a2 = false;
     if (p.NTall == 1) {
@@ -794,19 +802,26 @@ extern "C" int da_upconv3d_k3_fwd(const float* s1, int C1, const float* s2, int 
 extern "C" int da_upconv3d_k3_dgrad(const float* dy, const float* w_tio, float* dx1, int C1, float* dx2, int C2,
                                     int N, int Dc, int Hc, int Wc, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w_tio || !dx1 || (C2 > 0 && !dx2) || N <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0) return DA_ERR_BADARG;
+    DaPpScope pp_scope;
     const int Cin = C1 + C2;
     if (!da_upconv3d_k3_supported(C1, C2, Cout) || !up_sizes_ok(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_UNSUPPORTED;
     if (ws_bytes < da_upconv3d_k3_ws_bytes(N, Dc, Hc, Wc, Cin, Cout)) return DA_ERR_WS_SMALL;
     hipStream_t st = da_stream(stream);
     const Plan q = up_plan(N, Dc, Hc, Wc);
     DgP p;
-    p.dy = dy; p.wexp = (const int*)ws; p.wp = (const unsigned char*)ws + 256; p.dx1 = dx1; p.dx2 = dx2; p.C1 = C1; p.C2 = C2;
-    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
     p.nchunks = Cout / 8;
     int NTN = (Cin + 15) / 16; if (NTN == 3) NTN = 4;            // (48 input channels: a fourth, empty tile)
     p.NTN = NTN;
-    hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(p.nchunks, 4 * NTN), dim3(256), 0, st, w_tio, (unsigned short*)((unsigned char*)ws + 256), (int*)ws, Cin, Cout, NTN);
-    DA_LAUNCH_CHECK();
+    const DaKeptPack kp = da_pp_lookup(w_tio, da_align((size_t)p.nchunks * 16 * NTN * NPLN * 1024) + 256, DA_PP_UP_DGRAD);
+    if (kp.only && !kp.buf) return 0;
+    unsigned char* pk = kp.buf ? kp.buf : (unsigned char*)ws;
+    p.dy = dy; p.wexp = (const int*)pk; p.wp = pk + 256; p.dx1 = dx1; p.dx2 = dx2; p.C1 = C1; p.C2 = C2;
+    p.N = N; p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.Cout = Cout; p.ntz = q.ntz; p.nty = q.nty; p.ntx = q.ntx;
+    if (!kp.buf || kp.fill) {
+        hipLaunchKernelGGL(up_pack_dgrad_kernel, dim3(p.nchunks, 4 * NTN), dim3(256), 0, st, w_tio, (unsigned short*)(pk + 256), (int*)pk, Cin, Cout, NTN);
+        DA_LAUNCH_CHECK();
+    }
+    if (kp.only) return 0;
     const size_t shm = NPLN * FPLANE_B + 16;
     static bool a[5] = {false, false, false, false, false};
     int e = 0;

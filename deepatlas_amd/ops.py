@@ -416,7 +416,7 @@ _pack_entries = {}
 
 
 class _Pack(object):
-    __slots__ = ('bufs', 'stamp', 'event', 'base', 'view', 'args', 'disabled', 'storage', 'pversion', 'used')
+    __slots__ = ('bufs', 'stamp', 'event', 'base', 'view', 'args', 'disabled', 'storage', 'pversion', 'used', 'any', 'tag')
 
 
 def _pack_stamp(e):
@@ -427,8 +427,23 @@ def _pack_stamp(e):
     return (_other_bumps, _bucket_epoch.get(e.storage, 0), e.pversion, b._version if b is not None else -1)
 
 
+def _pack_any(w_tio, C1, C2, Cout, dgrad, stride, up2, N, D, H, W, buf, st):
+    """da_conv3d_k3_prepack_any: (bytes such a pack needs, tag, filled).  buf None: size query."""
+    import ctypes
+    need, tag, filled = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0)
+    wsb = nat.lib().da_upconv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout) if up2 else nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, C1 + C2, Cout, stride)
+    wp, wn = _ws(wsb, w_tio)
+    call('da_conv3d_k3_prepack_any', ptr(w_tio), C1, C2, Cout, dgrad, stride, 1 if up2 else 0, N, D, H, W, ptr(buf), buf.numel() if buf is not None else 0,
+         ctypes.byref(need), ctypes.byref(tag), ctypes.byref(filled), wp, wn, st)
+    return need.value, tag.value, filled.value
+
+
 def _pack_fill(e, w_tio, st):
     import ctypes
+    if e.any is not None:                                # the families outside the split matrix kernels: one region, filled by the family's own pack kernel
+        C1, C2, Cout, dgrad, N, D, H, W = e.args
+        stride, up2 = e.any
+        return _pack_any(w_tio, C1, C2, Cout, dgrad, stride, up2, N, D, H, W, e.bufs[0], st)[2]
     C1, C2, Cout, dgrad, N, D, H, W = e.args
     used = ctypes.c_int(0)
     b1 = e.bufs[1]
@@ -437,12 +452,21 @@ def _pack_fill(e, w_tio, st):
     return used.value
 
 
-def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
-    """Right before a stride-1 da_conv3d_k3_{fwd,fwd_bnstats,fwd_pro,dgrad} call: hand it the kept packed operand of these weights (filling it now
-    if it is new or stale).  No-op outside the split matrix mode, for weights that are not views of a live base tensor, and inside graph capture."""
+# Kept packs ALSO for the folded up-sampling / native stride-2 / flow / thin kernels (da_conv3d_k3_prepack_any).  OFF by default: measured on the registration step
+# (22 such packs of 5 - 20 us) it is 0.07 - 0.09 ms SLOWER than packing per call (4.25 vs 4.33 ms; backward packs only: 4.32) -- a kept pack costs the host a dictionary
+# lookup, a stamp, an event wait and a hand-over call per layer plus a re-fill call per layer behind the optimiser step, more than the 3-us launch it removes, and the
+# reg step's forward runs 10 - 20 us kernels that leave the host no slack.  DA_PACK_CACHE_ANY=1 switches it on (tests/test_gpu_nets.py exercises it).
+_PACK_ANY_BWD_ONLY = os.environ.get('DA_PACK_CACHE_ANY_BWD_ONLY') == '1'
+PACK_CACHE_ANY = os.environ.get('DA_PACK_CACHE_ANY') == '1'
+
+
+def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W, stride=1, up2=False):
+    """Right before a da_conv3d_k3_{fwd,fwd_bnstats,fwd_pro,dgrad} or da_upconv3d_k3_{fwd,dgrad} call (up2: D, H, W = the coarse extents): hand it the kept
+    packed operand of these weights (filling it now if it is new or stale).  No-op outside the split matrix mode, for weights that are not views of a live base
+    tensor, and inside graph capture."""
     if not PACK_CACHE or _matrix_mode != 'fp32_split' or w_tio.dtype != torch.float32 or torch.cuda.is_current_stream_capturing():
         return
-    key = (w_tio.data_ptr(), dgrad, C1, C2, Cout, N, D, H, W)
+    key = (w_tio.data_ptr(), dgrad, C1, C2, Cout, N, D, H, W, stride, bool(up2))
     e = _pack_entries.get(key)
     sp = w_tio.untyped_storage().data_ptr()
     if e is not None and (e.base() is None or e.storage != sp):
@@ -452,8 +476,13 @@ def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
         base = next((r for r in _flat_param_buckets if r() is not None and r().untyped_storage().data_ptr() == sp), None)
         if base is None:
             return
-        nbytes = nat.lib().da_conv3d_k3_pack_bytes(N, D, H, W, C1 + C2, Cout)
+        nbytes = nat.lib().da_conv3d_k3_pack_bytes(N, D, H, W, C1 + C2, Cout) if (stride == 1 and not up2) else 0
         e = _Pack()
+        e.any, e.tag = None, 0
+        if nbytes == 0 and PACK_CACHE_ANY and (dgrad or not _PACK_ANY_BWD_ONLY):                # not a split matrix-kernel layer: one of the other families may keep its pack
+            nbytes, e.tag, _ = _pack_any(w_tio, C1, C2, Cout, dgrad, stride, up2, N, D, H, W, None, stream())
+            if nbytes:
+                e.any = (stride, bool(up2))
         e.args, e.event, e.stamp, e.disabled, e.used = (C1, C2, Cout, dgrad, N, D, H, W), None, None, nbytes == 0, True
         e.base = base
         e.storage = sp
@@ -461,7 +490,7 @@ def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
         e.bufs = [None, None]
         if not e.disabled:
             e.bufs[0] = torch.empty((nbytes,), dtype=torch.uint8, device=w_tio.device)
-            if dgrad and C2 > 0:
+            if dgrad and C2 > 0 and e.any is None:
                 e.bufs[1] = torch.empty((nbytes,), dtype=torch.uint8, device=w_tio.device)
         _pack_entries[key] = e
     if e.disabled:
@@ -479,6 +508,9 @@ def use_pack(w_tio, dgrad, C1, C2, Cout, N, D, H, W):
         e.stamp, e.event = stamp, None
     elif e.event is not None:
         torch.cuda.current_stream().wait_event(e.event)
+    if e.any is not None:
+        nat.lib().da_conv3d_k3_use_prepacked_any(ptr(w_tio), ptr(e.bufs[0]), e.bufs[0].numel(), e.tag)
+        return
     b1 = e.bufs[1]
     nat.lib().da_conv3d_k3_use_prepacked(ptr(w_tio), ptr(e.bufs[0]), e.bufs[0].numel(), ptr(b1), b1.numel() if b1 is not None else 0)
 
@@ -506,6 +538,24 @@ def repack_after_step(flat_p):
     if not mine:
         return
     import ctypes
+    others = [e for e in mine if e.any is not None]
+    mine = [e for e in mine if e.any is None]
+    if others:                                          # the other families: one small pack launch each, on the side stream like the batched ones
+        side = side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sst = stream()
+            for e in others:
+                v = torch.as_strided(e.base(), e.view[0], e.view[1], e.view[2])
+                if _pack_fill(e, v, sst) == 0:
+                    e.disabled = True
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for e in others:
+            if not e.disabled:
+                e.stamp, e.event = _pack_stamp(e), ev
+    if not mine:
+        return
     n = len(mine)
     views = [torch.as_strided(e.base(), e.view[0], e.view[1], e.view[2]) for e in mine]
     PA, IA, SA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_size_t * n
@@ -788,14 +838,14 @@ class Conv3dK3Fn(Function):
             out = _empty((N, 2 * D, 2 * H, 2 * W, Cout), a1, _act_dtype(Cout))
             wsb = nat.lib().da_upconv3d_k3_ws_bytes(N, D, H, W, Cin, Cout)
             wp, wn = _ws(wsb, a1)
+            use_pack(w_tio, 0, C1, C2, Cout, N, D, H, W, 1, True)
             call_act('da_upconv3d_k3_fwd', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(out), N, D, H, W, Cout, float(act_slope), wp, wn, st)
         else:
             Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
             out = _empty((N, Do, Ho, Wo, Cout), a1, _act_dtype(Cout))
             wsb = nat.lib().da_conv3d_k3_ws_bytes(N, D, H, W, Cin, Cout, stride)
             wp, wn = _ws(wsb, a1)
-            if stride == 1:
-                use_pack(w_tio, 0, C1, C2, Cout, N, D, H, W)
+            use_pack(w_tio, 0, C1, C2, Cout, N, D, H, W, stride)
             call_act('da_conv3d_k3_fwd', A(a1), C1, A(a2), C2, ptr(w_tio), ptr(b), O(out),
                      N, D, H, W, Cout, stride, float(act_slope), wp, wn, st)
         ctx.dims = (N, D, H, W, C1, C2, Cout, stride, float(act_slope), wsb)
@@ -816,10 +866,10 @@ class Conv3dK3Fn(Function):
 
         def k_dgrad(g_, dx1_, dx2_, wp_, wn_, st_):
             if up2:
+                use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W, 1, True)
                 call_act('da_upconv3d_k3_dgrad', A(g_), ptr(w_tio), O(dx1_), C1, O(dx2_), C2, N, D, H, W, Cout, wp_, wn_, st_)
             else:
-                if stride == 1:
-                    use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W)
+                use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W, stride)
                 call_act('da_conv3d_k3_dgrad', A(g_), ptr(w_tio), O(dx1_), C1, O(dx2_), C2, N, D, H, W, Cout, stride, wp_, wn_, st_)
 
         def k_wgrad(g_, dw_tio_, db_, wp_, wn_, st_):

@@ -393,6 +393,18 @@ int da_conv3d_k3_prepack_many(int n, const float* const* w_tio, const int* C1, c
                               const int* N, const int* D, const int* H, const int* W,
                               void* const* b0, const size_t* n0, void* const* b1, const size_t* n1, int* used, void* stream);
 
+/* The same for the kernel families OUTSIDE the split matrix kernels -- the folded up-sampling convolution (da_upconv3d_k3_fwd / _dgrad; voxel_morph.py:72-80 + the conv
+ * behind it), the native stride-2 convolution (modules.py:48, stride 2), the flow convolution (voxel_morph.py:57) and the first layers' thin kernels -- whose per-call
+ * packs were 22 launches of 5 - 20 us in the dependent chain of a registration step.
+ *   da_conv3d_k3_prepack_any        the family that da_conv3d_k3_fwd / _dgrad (up2 = 0; stride 1 | 2) or da_upconv3d_k3_fwd / _dgrad (up2 = 1; D, H, W = the coarse
+ *                                   extents) runs for this shape packs into buf (cap bytes) and launches nothing else.  *need: bytes of such a pack (0: the shape keeps
+ *                                   nothing here -- split matrix kernels: da_conv3d_k3_prepack; direct kernels: no pack); buf NULL: size query.  *tag: (family,
+ *                                   direction), to be passed back; *filled: buf was written.  ws: the call's usual workspace.
+ *   da_conv3d_k3_use_prepacked_any  the NEXT of those calls on `w_tio` whose family / direction carries `tag` reads its packed operand from buf (one call only). */
+int da_conv3d_k3_prepack_any(const float* w_tio, int C1, int C2, int Cout, int dgrad, int stride, int up2, int N, int D, int H, int W,
+                             void* buf, size_t cap, size_t* need, int* tag, int* filled, void* ws, size_t ws_bytes, void* stream);
+void da_conv3d_k3_use_prepacked_any(const float* w_tio, const void* buf, size_t cap, int tag);
+
 /* ---- NCC loss (row a12; lib/loss.py:493-501) -------------------------------------------------- */
 size_t da_ncc_ws_bytes(int N, long long V);
 int da_ncc_fwd(const float* x, const float* y, int N, long long V, float* loss, double* stats /*[N][8]*/,
