@@ -172,10 +172,10 @@ __device__ __forceinline__ void gather_walk(const float* __restrict__ sb, const 
         use((j + 1) * vpw + gl, gather_reduce(gB, aB));
     } else use(j * vpw + gl, gather_reduce(gA, aA));
 }
-// V * C < 2^31 (element offsets in 32 bits), C / 4 a power of two <= 64
+// V * C < 2^31 (element offsets in 32 bits), 8 <= C <= 32 (C / 4 = 2, 4 or 8 lanes per voxel: the forward tile of a wave is 64 x C x 4 bytes of LDS)
 static bool gather_grouped_ok(int D, int H, int W, int C, int lpv) {
     const long long V = (long long)D * H * W;
-    return lpv >= 2 && lpv <= 16 && (V + (long long)H * W + W + 1) * C < 0x7FFFFFF0LL;
+    return lpv >= 2 && lpv <= 8 && (V + (long long)H * W + W + 1) * C < 0x7FFFFFF0LL;
 }
 
 // grid (blocks, N): a workgroup walks a contiguous range of one sample's voxels, 256 per iteration (64 per wave)

@@ -57,12 +57,13 @@ def test_pool_and_upsample_random_shapes(c, d, h, w, n):
 
 
 @settings(**SET)
-@given(c=st.sampled_from([1, 2, 8, 32]), d=st.integers(2, 9), h=st.integers(2, 11), w=st.integers(2, 13), amp=st.sampled_from([0.05, 0.5, 3.0]))
-def test_warp_random_shapes(c, d, h, w, amp):
-    """incl. displacements that push most taps out of the volume (zeros padding)"""
+@given(c=st.sampled_from([1, 2, 8, 16, 32]), d=st.integers(2, 9), h=st.integers(2, 11), w=st.integers(2, 13), amp=st.sampled_from([0.05, 0.5, 3.0]), n=st.integers(1, 2))
+def test_warp_random_shapes(c, d, h, w, amp, n):
+    """incl. displacements that push most taps out of the volume (zeros padding); c = 8 / 16 / 32 take the grouped gather (warp.hip: 2 / 4 / 8 lanes per voxel),
+    two samples its grid.y"""
     from deepatlas_amd import ops
     from oracle import nets
-    src, disp = rnd((1, c, d, h, w), 10), rnd((1, 3, d, h, w), 11, amp)
+    src, disp = rnd((n, c, d, h, w), 10), rnd((n, 3, d, h, w), 11, amp)
     sr, dr = src.clone().requires_grad_(True), disp.clone().requires_grad_(True)
     wr = nets.warp_trilinear(sr, dr + nets.identity_transform((d, h, w))); go = rnd(tuple(wr.shape), 12); wr.backward(go)
     sg, dg = cl(src).requires_grad_(True), cl(disp).requires_grad_(True)
