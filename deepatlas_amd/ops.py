@@ -267,6 +267,7 @@ def enable_async_wgrad(flag=True):
 
 
 LAST_WGRAD_ON_MAIN = os.environ.get('DA_LAST_WGRAD_ON_MAIN', '1') == '1'      # see Conv3dFn.backward
+LAST_WGRAD_ON_MAIN_BN = os.environ.get('DA_LAST_WGRAD_ON_MAIN_BN', '0') == '1'
 _N_SIDE = max(1, int(os.environ.get('DA_SIDE_STREAMS', '1')))      # > 1: weight gradients alternate between that many side streams (experiment)
 _SIDE_PRIO = int(os.environ.get('DA_SIDE_PRIO', '0'))      # HIP stream priority of the side stream (lower number = higher priority; out-of-range values clamp)
 _side_streams = []
@@ -1410,8 +1411,10 @@ class ConvBNActFn(Function):
         elif gw is not None:
             global _last_side_flops
             _last_side_flops = 54.0 * (C1 + C2) * Cout * N * D * H * W
-            side = side_stream()
-            side.wait_stream(torch.cuda.current_stream())
+            on_main = LAST_WGRAD_ON_MAIN_BN and dx1 is None and dx2 is None      # the net's first layer: see Conv3dFn.backward (A/B switch; off: no gain measured on the seg step)
+            side = torch.cuda.current_stream() if on_main else side_stream()
+            if not on_main:
+                side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 sst = stream()
                 swp, swn = _ws(wsb, a1)
