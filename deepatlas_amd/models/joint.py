@@ -11,6 +11,8 @@ compare against:
   Sm = None (moving image without a manual segmentation): the reg phase warps softmax(S(Im)).detach() (segmentation net in eval
   mode under no_grad: no state change) instead of onehot(Sm), and the seg phase drops its supervised term.
 """
+import os
+
 import torch
 
 from .. import ops, parallel, trace
@@ -65,11 +67,35 @@ class DeepAtlasJointStep:
         self.dice_logits = DiceLossMultiClass(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=True, eps=1e-6)
         self.dice_prob = DiceLossMultiClass(n_class=n_classes, weight_type='Uniform', no_bg=False, softmax=False, eps=1e-6)
 
+    # The segmentation net's FORWARD pass does not depend on the registration phase (with a manual segmentation of the moving image: the registration phase warps
+    # one-hot(seg_m), and the deformation is only needed by the segmentation phase's LOSS).  It is issued first, on its own stream, and runs beside the registration
+    # phase -- a chain of small latency-bound kernels that leaves most of the GPU idle -- instead of after it.  Same kernels, same order inside either network:
+    # results are those of the sequential step.  DA_JOINT_OVERLAP=0 (or overlap_phases=False) runs the phases one after the other.
+    overlap_phases = os.environ.get('DA_JOINT_OVERLAP', '1') == '1'
+    _phase_stream = None
+    _ev_disp = None
+
+    def _seg_forward_ahead(self, im_m):
+        main = torch.cuda.current_stream()
+        if self._phase_stream is None:
+            self._phase_stream = torch.cuda.Stream()
+        ps = self._phase_stream
+        ps.wait_stream(main)                       # (the previous step's segmentation update, the input)
+        with torch.cuda.stream(ps):
+            self.seg.train()
+            self.seg_opt.zero_grad()
+            with trace.range('joint/seg_phase/forward'):
+                logits = ops.materialize_logits(self.seg(im_m))
+        return logits
+
     def __call__(self, im_m, im_t, seg_m, seg_t):
+        ahead = None
+        if (self.overlap_phases and seg_m is not None and im_m.is_cuda and not torch.cuda.is_current_stream_capturing()):
+            ahead = self._seg_forward_ahead(im_m)
         r = self.reg_gradients(im_m, im_t, seg_m, seg_t)
         parallel.allreduce_gradients(self.reg_opt)
         self.reg_opt.step()
-        s = self.seg_gradients(im_m, seg_m, seg_t, r['disp'])
+        s = self.seg_gradients(im_m, seg_m, seg_t, r['disp'], ahead)
         parallel.allreduce_gradients(self.seg_opt)
         self.seg_opt.step()
         r.pop('disp')
@@ -106,6 +132,9 @@ class DeepAtlasJointStep:
                 prob_m = ops.SoftmaxFn.apply(ops.materialize_logits(self.seg(im_m)))
         with trace.range('joint/reg_phase/forward'):
             disp, warped, deform = self.reg(im_m, im_t)
+        if disp.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self._ev_disp = torch.cuda.Event()
+            self._ev_disp.record()                 # the segmentation phase's losses (phase stream) wait for this, not for the rest of the registration phase
         fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
         trace.mark('joint/reg_phase/losses')
         l_sim = self.ncc(warped, im_t)
@@ -124,14 +153,30 @@ class DeepAtlasJointStep:
             loss_r.backward()
         return dict(loss_reg=loss_r.detach(), sim=l_sim.detach(), bend=l_reg.detach(), anat_reg=l_anat.detach(), disp=disp.detach())
 
-    def seg_gradients(self, im_m, seg_m, seg_t, disp):
-        """segmentation phase up to its gradients (deformation fixed)."""
+    def seg_gradients(self, im_m, seg_m, seg_t, disp, logits_ahead=None):
+        """segmentation phase up to its gradients (deformation fixed).  logits_ahead: the forward pass was already issued on the phase stream (_seg_forward_ahead)."""
         lam = self.lam
         fused = self.fused and ops.fused_anatomy_supported(self.n_classes)
+        if logits_ahead is not None:
+            # the whole phase stays on the phase stream: its losses wait for the deformation (an event behind the registration forward), not for the registration
+            # phase's backward pass and update, and run beside them
+            main, ps = torch.cuda.current_stream(), self._phase_stream
+            ps.wait_event(self._ev_disp)
+            disp.record_stream(ps)                 # (allocated on the main stream, read on the phase stream)
+            with torch.cuda.stream(ps):
+                out = self._seg_losses_backward(logits_ahead, seg_m, seg_t, disp, fused)
+            main.wait_stream(ps)                   # the update (this stream) comes after the backward pass; weight gradients: FlatAdam.step() joins the side stream
+            for v in out.values():
+                v.record_stream(main)
+            return out
         self.seg.train()
         self.seg_opt.zero_grad()
         with trace.range('joint/seg_phase/forward'):
             logits = ops.materialize_logits(self.seg(im_m))
+        return self._seg_losses_backward(logits, seg_m, seg_t, disp, fused)
+
+    def _seg_losses_backward(self, logits, seg_m, seg_t, disp, fused):
+        lam = self.lam
         trace.mark('joint/seg_phase/losses')
         if fused and not ops.DETERMINISTIC:
             # both Dice terms as one node: structured adjoint warp + one pass to the logit gradient (ops.SegPhaseLossFn); its scatter
