@@ -1218,6 +1218,7 @@ _bwd_stats = {}
 # slower in the step: 20.46 - 20.56 -> 20.59 - 20.67 ms (DA_DGRAD_BST_MAXC=32)
 _DGRAD_BST_MAXC = int(os.environ.get('DA_DGRAD_BST_MAXC', '16'))
 FUSE_BN_BWD_STATS = os.environ.get('DA_NO_BN_BWD_FUSE') != '1'
+_DGRAD_BST_CONCAT = os.environ.get('DA_NO_DGRAD_BST_CONCAT') != '1'      # the 32 + 16 concat layer's data gradient with the producer's sums (only reached with DA_LAZY_BN_UPSAMPLER=1)
 
 
 def drop_bwd_stats(*_):
@@ -1385,7 +1386,7 @@ class ConvBNActFn(Function):
             _serialize_matrix_kernels(54.0 * (C1 + C2) * Cout * N * D * H * W, N * D * H * W)
             use_pack(w_tio, 1, C1, C2, Cout, N, D, H, W)
             done = False
-            if (FUSE_BN_BWD_STATS and pro1 is not None and ((a2 is None and C1 <= _DGRAD_BST_MAXC) or (a2 is not None and C1 == 32 and C2 == 16 and a2.dtype == torch.float32))
+            if (FUSE_BN_BWD_STATS and pro1 is not None and ((a2 is None and C1 <= _DGRAD_BST_MAXC) or (a2 is not None and C1 == 32 and C2 == 16 and a2.dtype == torch.float32 and _DGRAD_BST_CONCAT))
                     and _matrix_mode == 'fp32_split' and dy.dtype == torch.float32
                     and a1.dtype == torch.float32 and p1s.data_ptr() - 8 * C1 == p1t.data_ptr() - 12 * C1 and p1s.untyped_storage().data_ptr() <= p1s.data_ptr() - 8 * C1):
                 # (also while a HIP graph is being captured: whether the route exists is decided on the host, and a graphed step must run the same kernels --
