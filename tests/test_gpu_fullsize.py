@@ -318,3 +318,77 @@ def test_reg_and_joint_steps_vs_cpu_oracle_at_metric_size():
             assert abs(out[k].item() - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, out[k].item(), ref[k].item())
     finally:
         ops.set_matrix_precision(prev)
+
+
+def test_full_size_grouped_gather_and_fused_upsampler_backward_properties():
+    """Round-6 kernels at BASELINE's full size through size-independent properties: (a) the 32-channel warp (warp.hip: grouped gather) of a tensor by the zero
+    displacement reproduces it, and a one-voxel shift along x reproduces the shifted tensor away from the border (the taps' weights are then 0 / 1 up to the
+    rounding of the normalised coordinates); (b) the fused warp + Dice (da_warp_dice_fwd) of the zero displacement equals da_dice_fwd on the same probabilities;
+    (c) da_deconv_k2s2_bn_bwd on the full-resolution up-sampler link (2 x 80 x 96 x 80 -> 160 x 192 x 160, 32 -> 32) equals the three calls it replaces."""
+    import ctypes
+    from deepatlas_amd import ops, _native as nat
+    from deepatlas_amd._native import call, ptr, stream, workspace
+    D, H, W = FULL
+    C = 32
+    st = stream()
+    g = torch.Generator(device=dev()).manual_seed(5)
+    src = torch.empty((1, D, H, W, C), device=dev()).uniform_(0.0, 1.0, generator=g)
+    src = src / src.sum(dim=-1, keepdim=True)                      # rows like probabilities
+    disp = torch.zeros((1, D, H, W, 3), device=dev())
+    out = torch.empty_like(src)
+    call('da_warp_fwd', ptr(src), ptr(disp), None, ptr(out), 1, D, H, W, C, st)
+    torch.cuda.synchronize()
+    assert float((out - src).abs().max()) < 3e-5 * float(src.abs().max())          # (the taps' fractions are ~1e-5 voxel: fp32 coordinate arithmetic, SURVEY a10)
+    # one voxel along x: disp_x = 2 / (W - 1) in normalised units
+    disp[..., 0] = 2.0 / (W - 1)
+    call('da_warp_fwd', ptr(src), ptr(disp), None, ptr(out), 1, D, H, W, C, st)
+    torch.cuda.synchronize()
+    err = float((out[:, :, :, 1:W - 2] - src[:, :, :, 2:W - 1]).abs().max())
+    assert err < 1e-3 * float(src.abs().max()), err                # (fractional parts of ~1e-5 voxel from the fp32 coordinate arithmetic)
+    # (b) fused warp + Dice at the identity == Dice on the same tensor
+    disp.zero_()
+    lab = torch.randint(0, C, (1, D, H, W), device=dev(), dtype=torch.uint8, generator=g)
+    V = D * H * W
+    loss_a, loss_b = torch.empty(1, device=dev()), torch.empty(1, device=dev())
+    coef_a, coef_b = torch.empty((2, 1, C), device=dev()), torch.empty((2, 1, C), device=dev())
+    wp, wn = workspace.get(max(nat.lib().da_warp_dice_ws_bytes(1, C), nat.lib().da_dice_ws_bytes(1, V, C)), dev())
+    call('da_warp_dice_fwd', ptr(src), ptr(disp), ptr(lab), 1, 1, D, H, W, C, 0, 0, 1e-6, ptr(loss_a), ptr(coef_a), wp, wn, st)
+    call('da_dice_fwd', ptr(src), ptr(lab), 1, None, 1, V, C, 0, 0, 0, 1e-6, ptr(loss_b), ptr(coef_b), wp, wn, st)
+    torch.cuda.synchronize()
+    assert abs(loss_a.item() - loss_b.item()) < 2e-6, (loss_a.item(), loss_b.item())
+    assert rel_l2(coef_a.cpu().numpy(), coef_b.cpu().numpy()) < 1e-5
+    del out, src, disp
+    # (c) the fused up-sampler backward against its three calls at the full-resolution link
+    N, Dc, Hc, Wc = 2, D // 2, H // 2, W // 2
+    x = torch.empty((N, Dc, Hc, Wc, C), device=dev()).uniform_(-1, 1, generator=g)
+    w = torch.empty((8, C, C), device=dev()).uniform_(-0.2, 0.2, generator=g)
+    y = torch.empty((N, D, H, W, C), device=dev()).normal_(0.3, 1.5, generator=g)
+    go = torch.empty((N, D, H, W, C), device=dev()).uniform_(-1, 1, generator=g)
+    gamma = torch.empty(C, device=dev()).uniform_(-0.5, 1.0, generator=g)
+    beta = torch.empty(C, device=dev()).uniform_(-0.5, 0.5, generator=g)
+    M = N * D * H * W
+    mean = y.double().mean(dim=(0, 1, 2, 3))
+    var = y.double().var(dim=(0, 1, 2, 3), unbiased=False)
+    rstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    mean = mean.float()
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    # three calls
+    dy = torch.empty_like(y)
+    dgb = torch.empty((3, C), device=dev())
+    wsb = max(nat.lib().da_bn_ws_bytes(M, C), nat.lib().da_pointwise_ws_bytes(8, C, C), nat.lib().da_deconv_k2s2_wgrad_ws_bytes(N, Dc, Hc, Wc, C, C),
+              nat.lib().da_deconv_k2s2_bn_bwd_ws_bytes(N, Dc, Hc, Wc, C, C))
+    wp, wn = workspace.get(wsb, dev())
+    call('da_bn_act_bwd_dbias', ptr(go), ptr(y), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), 0.01, 1, ptr(dy), ptr(dgb[1]), ptr(dgb[2]), ptr(dgb[0]), M, C, wp, wn, st)
+    dx0, dw0 = torch.empty_like(x), torch.empty_like(w)
+    call('da_deconv_k2s2_dgrad', ptr(dy), ptr(w), ptr(dx0), N, Dc, Hc, Wc, C, C, wp, wn, st)
+    call('da_deconv_k2s2_wgrad', ptr(x), ptr(dy), ptr(dw0), None, N, Dc, Hc, Wc, C, C, wp, wn, st)
+    torch.cuda.synchronize()
+    del dy
+    dx1, dw1, dgb1 = torch.empty_like(x), torch.empty_like(w), torch.empty((3, C), device=dev())
+    call('da_deconv_k2s2_bn_bwd', ptr(go), ptr(y), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), 0.01, ptr(x), ptr(w), ptr(dx1), ptr(dw1),
+         ptr(dgb1[0]), ptr(dgb1[1]), ptr(dgb1[2]), N, Dc, Hc, Wc, C, C, None, 0, wp, wn, st)
+    torch.cuda.synchronize()
+    assert rel_l2(dx1.cpu().numpy(), dx0.cpu().numpy()) < 2e-6
+    assert rel_l2(dw1.cpu().numpy(), dw0.cpu().numpy()) < 2e-6
+    assert torch.equal(dgb1[1], dgb[1]) and torch.equal(dgb1[2], dgb[2])
