@@ -12,6 +12,7 @@
 // da_reduce_partials sums them in double, in a fixed order.  Algorithmic bytes: (Cin + Cout) * 4 per voxel, read once.
 #include "common.h"
 #include "conv3d_internal.h"
+#include "split_f16.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -207,6 +208,286 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_kernel(FlowWgP p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient in the SPLIT matrix mode (round 6): two-term fp16 operands, v_mfma_f32_16x16x32_f16 with K = 32 VOXELS per instruction
+// instead of the exact-fp32 16x16x4 (96 matrix-pipe cycles per voxel -> 18).  K runs along x, so both operands are staged TRANSPOSED: the x tile as
+// per-channel planes [channel][2 x 8 x 16 voxels] (a lane's fragment = 8 consecutive x of one channel: one ds_read_b128), the dy halo tile as per-(shift,
+// cout) planes [dx shift 0..2][cout][4 x 10 rows][16 x] -- three copies shifted by one voxel each, because a tap's window along x would otherwise start on
+// an odd 2-byte element.  Scales as in conv3d_mfma.hip "SP": every staged tile at its own power of two (x and dy separately, one workgroup-wide maximum
+// each), the accumulators carried from tile to tile in the unit of the current one (exact power-of-two factors), 2^-E applied once at the end.
+// Tile 2 x 8 x 16 voxels; wave w: z = w / 2, rows 4 (w % 2) .. + 3 = two K-steps of two rows.  LDS 47 KB, fixed-order reductions as above.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+namespace sp {
+constexpr int TZ = 2, TY = 8, TX = 16, TVOX = TZ * TY * TX;              // 256
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;   // 4 x 10 x 18 = 720
+constexpr int CHS = TVOX * 2 + 16;                                       // bytes per channel plane of the x tile (+ 16: the 16 channel lanes of a fragment read hit different banks)
+constexpr int YROW = TX * 2;                                             // bytes per (shift, cout, hz, hy) row of the dy copies
+constexpr int NDY = (HVOX * 3 + 255) / 256;                              // dword loads per thread for the dy halo tile, Cout <= 3 (9)
+}
+
+template <int MT, bool TWO, int S1>
+__global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
+    constexpr int TZ = sp::TZ, TY = sp::TY, TX = sp::TX, TVOX = sp::TVOX, HZ = sp::HZ, HY = sp::HY, HX = sp::HX, HVOX = sp::HVOX, CHS = sp::CHS, YROW = sp::YROW, NDY = sp::NDY;
+    (void)TZ;
+    constexpr int NTT = TWO ? 2 : 1;
+    constexpr int NCH = 16 + (TWO ? S1 : 0);                     // x planes: in2's 16 channels, then in1's S1
+    constexpr int XPL = NCH * CHS;                               // bytes of one x plane set (h or l)
+    constexpr int YPL = 3 * 3 * HZ * HY * YROW;                  // bytes of one dy plane set: [shift][cout <= 3][hz][hy][16 x]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    unsigned char* xh = lds8;                                    // x planes: h | l
+    unsigned char* yh = lds8 + 2 * XPL;                          // dy planes: h | l
+    float* smax = reinterpret_cast<float*>(lds8 + 2 * XPL + 2 * YPL);      // [8]: the waves' maxima of the x tile, of the dy tile
+    unsigned char* zrow = lds8 + 2 * XPL + 2 * YPL + 32;         // 16 zero bytes: the A fragment of padding rows
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, g = lane >> 4;
+    const int Cout = p.Cout, Cin = p.C1 + p.C2;
+    const int Q2 = p.C2 / 4, Q1 = p.C1 / 4;
+    if (threadIdx.x < 4) reinterpret_cast<unsigned*>(zrow)[threadIdx.x] = 0u;
+    // x planes of channels a tensor does not have stay zero for the whole launch
+    for (int t = threadIdx.x; t < 2 * XPL / 16; t += 256) reinterpret_cast<uint4*>(xh)[t] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // A rows of this lane: m = 16 mt + i -> (tap, co); byte offset of the row's window in the dy copies for K-step row pair (z, y): + (z * HY + y) * YROW
+    int offA[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + i;
+        const bool ok = m < 27 * Cout;
+        const int tap = ok ? m / Cout : 13, co = ok ? m % Cout : 0;
+        const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+        // dy[p - (tap - 1)]: halo row (z + 2 - tz, y + 2 - ty), x window starting at x + 2 - tx -> copy (2 - tx)
+        offA[mt] = ok ? ((((2 - tx) * 3 + co) * HZ + (2 - tz)) * HY + (2 - ty)) * YROW + (g & 1) * 16 + (g >> 1) * YROW : -1;
+    }
+    f32x4 acc[MT][NTT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+    const int vb = (gridDim.x % 8 == 0) ? da_xcd_item_of_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int t_begin = vb * per, t_end = min(p.ntiles, t_begin + per);
+
+    // staging: a thread takes PAIRS of x-adjacent voxels of one channel quad (two 16-byte loads -> four packed fp16 pairs per plane, 4-byte LDS stores)
+    constexpr int NP2 = TVOX / 2 * 4 / 256;                      // pairs per thread, in2 with 4 quads (2)
+    constexpr int NP1 = TWO ? (TVOX / 2 * (S1 / 4) + 255) / 256 : 0;      // in1 (S1 = 8: 1, S1 = 16: 2)
+    float4 pa[NP2][2], pb[NP1 > 0 ? NP1 : 1][2];
+    float pd[NDY];
+    // this thread's dy halo elements (fixed for the launch): cout | hx << 8 | hy << 16 | hz << 24, -1 past the tile
+    int pk[NDY];
+#pragma unroll
+    for (int it = 0; it < NDY; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int co = idx % Cout, hv = idx / Cout;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        pk[it] = hv < HVOX ? (co | hx << 8 | hy << 16 | hz << 24) : -1;
+    }
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.ntx; t /= p.ntx;
+        const int ty = t % p.nty; t /= p.nty;
+        const int tz = t % p.ntz; const int n = t / p.ntz;
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        const unsigned long long vol = (unsigned long long)p.D * p.H * p.W;
+        const __amdgpu_buffer_rsrc_t r2 = flow_rsrc(p.C2 > 0 ? p.in2 + (size_t)n * vol * p.C2 : p.dy, p.C2 > 0 ? (unsigned)(vol * p.C2 * 4ull) : 0u);
+        const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p.C1 > 0 ? p.in1 + (size_t)n * vol * p.C1 : p.dy, p.C1 > 0 ? (unsigned)(vol * p.C1 * 4ull) : 0u);
+        auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float4 { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
+        const int Cd2 = Cout - p.Cd1;
+        const __amdgpu_buffer_rsrc_t ry = flow_rsrc(p.dy + (size_t)n * vol * p.Cd1, (unsigned)(vol * p.Cd1 * 4ull));
+        const __amdgpu_buffer_rsrc_t ry2 = flow_rsrc(Cd2 > 0 ? p.dyb + (size_t)n * vol * Cd2 : p.dy, Cd2 > 0 ? (unsigned)(vol * Cd2 * 4ull) : 0u);
+#pragma unroll
+        for (int it = 0; it < NP2; ++it) {
+            int idx = threadIdx.x + it * 256;
+            asm volatile("" : "+v"(idx));
+            const int c4 = Q2 > 0 ? idx % Q2 : 0, vp = Q2 > 0 ? idx / Q2 : TVOX;      // voxel pair vp: voxels 2 vp, 2 vp + 1 (same row)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int v = 2 * vp + h2;
+                const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
+                const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
+                pa[it][h2] = ld4(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * 4) : 0xFFFFFFFFu);
+            }
+        }
+        if (TWO) {
+#pragma unroll
+            for (int it = 0; it < NP1; ++it) {
+                int idx = threadIdx.x + it * 256;
+                asm volatile("" : "+v"(idx));
+                const int c4 = Q1 > 0 ? idx % Q1 : 0, vp = Q1 > 0 ? idx / Q1 : TVOX;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int v = 2 * vp + h2;
+                    const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
+                    const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
+                    pb[it][h2] = ld4(r1, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C1 + c4 * 4) * 4) : 0xFFFFFFFFu);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int co = pk[it] & 255, hx = (pk[it] >> 8) & 255, hy = (pk[it] >> 16) & 255, hz = pk[it] >> 24;
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = pk[it] >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const unsigned vo = (unsigned)((z * p.H + y) * p.W + x);
+            // (one load per tensor with the other tensor's lanes out of range -> 0: a per-lane choice of the DESCRIPTOR makes the compiler loop over the lanes)
+            float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (ok && co < p.Cd1) ? (vo * p.Cd1 + co) * 4u : 0xFFFFFFFFu, 0, 0));
+            if (Cd2 > 0) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry2, (ok && co >= p.Cd1) ? (vo * Cd2 + (co - p.Cd1)) * 4u : 0xFFFFFFFFu, 0, 0));
+            pd[it] = v;
+        }
+    };
+    int Eacc = 0, Emin = 0;
+    bool first_tile = true;
+    // largest magnitudes of the parked tile (two workgroup-wide maxima through one barrier), its exponents, split + transposed stores.  Returns the tile's E.
+    auto stage = [&]() -> int {
+        float mx = 0.f, my = 0.f;
+#pragma unroll
+        for (int it = 0; it < NP2; ++it) { mx = da_absmax4(mx, pa[it][0]); mx = da_absmax4(mx, pa[it][1]); }
+        if (TWO) {
+#pragma unroll
+            for (int it = 0; it < NP1; ++it) { mx = da_absmax4(mx, pb[it][0]); mx = da_absmax4(mx, pb[it][1]); }
+        }
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) my = fmaxf(my, fabsf(pd[it]));
+        mx = da_wave_max_nonneg(mx); my = da_wave_max_nonneg(my);
+        if (lane == 0) { smax[wave] = mx; smax[4 + wave] = my; }
+        __syncthreads();                                         // (also: every wave is done reading the previous tile)
+        const float4 m4 = *reinterpret_cast<const float4*>(smax), n4 = *reinterpret_cast<const float4*>(smax + 4);
+        mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)))));
+        my = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(n4.x, n4.y), fmaxf(n4.z, n4.w)))));
+        const int ex = da_scale_exp(mx);
+        int E = ex + da_scale_exp(my);
+        if (!first_tile) E = min(E, Emin + 40);
+        Emin = first_tile ? E : min(Emin, E);
+        first_tile = false;
+        const float sx = da_pow2(ex), sy = da_pow2(E - ex);
+        // x planes: per channel of the quad the two voxels' halves side by side (one 4-byte store per plane)
+        auto put_pair = [&](int idx, int Q, int chan0, const float4& v0, const float4& v1) {
+            if (Q <= 0 || idx >= TVOX / 2 * Q) return;
+            const int c4 = idx % Q, vp = idx / Q;
+            uint2 h0, l0, h1, l1;
+            da_split2(v0, sx, h0, l0); da_split2(v1, sx, h1, l1);
+            const unsigned hw[4] = {__builtin_amdgcn_perm(h1.x, h0.x, 0x05040100u), __builtin_amdgcn_perm(h1.x, h0.x, 0x07060302u),
+                                    __builtin_amdgcn_perm(h1.y, h0.y, 0x05040100u), __builtin_amdgcn_perm(h1.y, h0.y, 0x07060302u)};
+            const unsigned lw[4] = {__builtin_amdgcn_perm(l1.x, l0.x, 0x05040100u), __builtin_amdgcn_perm(l1.x, l0.x, 0x07060302u),
+                                    __builtin_amdgcn_perm(l1.y, l0.y, 0x05040100u), __builtin_amdgcn_perm(l1.y, l0.y, 0x07060302u)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned char* o = xh + (chan0 + c4 * 4 + j) * CHS + vp * 4;
+                *reinterpret_cast<unsigned*>(o) = hw[j];
+                *reinterpret_cast<unsigned*>(o + XPL) = lw[j];
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < NP2; ++it) put_pair((int)threadIdx.x + it * 256, Q2, 0, pa[it][0], pa[it][1]);
+        if (TWO) {
+#pragma unroll
+            for (int it = 0; it < NP1; ++it) put_pair((int)threadIdx.x + it * 256, Q1, 16, pb[it][0], pb[it][1]);
+        }
+        // dy copies: halo element (hz, hy, hx) of cout co lands at x = hx - s of copy s
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            if (pk[it] >= 0) {
+                const int co = pk[it] & 255, hx = (pk[it] >> 8) & 255, hy = (pk[it] >> 16) & 255, hz = pk[it] >> 24;
+                const float a = pd[it] * sy;
+                const _Float16 h = (_Float16)a;
+                const _Float16 l = (_Float16)__builtin_fmaf(pd[it], sy, -(float)h);
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft) {
+                    const int x = hx - sft;
+                    if (x >= 0 && x < TX) {
+                        unsigned char* o = yh + (((sft * 3 + co) * HZ + hz) * HY + hy) * YROW + x * 2;
+                        *reinterpret_cast<_Float16*>(o) = h;
+                        *reinterpret_cast<_Float16*>(o + YPL) = l;
+                    }
+                }
+            }
+        }
+        return E;
+    };
+
+    int Ecur = 0;
+    if (t_begin < t_end) { issue(t_begin); Ecur = stage(); }
+    __syncthreads();
+    const int zw = wave >> 1, yw = (wave & 1) * 4;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool has_next = tile + 1 < t_end;
+        if (has_next) issue(tile + 1);
+        {
+            const float f = da_acc_factor(Ecur - Eacc);          // the running sums into this tile's unit (exact)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTT; ++nt) acc[mt][nt] = acc[mt][nt] * f;
+            Eacc = Ecur;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int y = yw + 2 * ks;                           // rows y, y + 1: K index (g, e) = row y + g / 2, x = 8 (g % 2) + e
+            const int rowoff = (zw * HY + y) * YROW;
+            const int vrow = ((zw * TY + y + (g >> 1)) * TX + (g & 1) * 8) * 2;      // byte offset of the lane's 8 voxels inside a channel plane
+            f16x8 B[NTT][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                B[0][pl] = *reinterpret_cast<const f16x8*>(xh + pl * XPL + i * CHS + vrow);
+                if (TWO) B[NTT - 1][pl] = *reinterpret_cast<const f16x8*>(xh + pl * XPL + (16 + (i & (S1 - 1))) * CHS + vrow);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned char* ap = offA[mt] >= 0 ? yh + offA[mt] + rowoff : zrow;
+                const f16x8 Ah = *reinterpret_cast<const f16x8*>(ap);
+                const f16x8 Al = *reinterpret_cast<const f16x8*>(offA[mt] >= 0 ? ap + YPL : zrow);
+#pragma unroll
+                for (int nt = 0; nt < NTT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, B[nt][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, B[nt][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, B[nt][0], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (has_next) {
+            Ecur = stage();                                      // (its barrier: every wave is done reading this tile)
+            __syncthreads();
+        }
+    }
+    // the sums back to the true unit (two exact factors), then as in flow_wgrad_kernel: cross-wave reduction through LDS, this workgroup's partial dW[tap][ci][co]
+    const float inv1 = da_pow2(-(Eacc / 2)), inv2 = da_pow2(-(Eacc - Eacc / 2));
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds8);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTT; ++nt) {
+                    float4* slot = red + (mt * NTT + nt) * 64 + lane;
+                    float4 cur = (w == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
+                    cur.x += acc[mt][nt][0] * inv1 * inv2; cur.y += acc[mt][nt][1] * inv1 * inv2; cur.z += acc[mt][nt][2] * inv1 * inv2; cur.w += acc[mt][nt][3] * inv1 * inv2;
+                    *slot = cur;
+                }
+        }
+        __syncthreads();
+    }
+    const int O = 27 * Cin * Cout;
+    float* part = p.partial + (size_t)blockIdx.x * O;
+    for (int idx = threadIdx.x; idx < MT * NTT * 64; idx += 256) {
+        const int ln = idx & 63, q = idx >> 6;
+        const int nt = q % NTT, mt = q / NTT;
+        const float4 v = red[idx];
+        const float vals[4] = {v.x, v.y, v.z, v.w};
+        const int col = ln & 15;
+        const int ci = nt == 0 ? p.C1 + col : col;
+        const bool cok = nt == 0 ? col < p.C2 : col < p.C1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * mt + 4 * (ln >> 4) + reg;
+            if (cok && m < 27 * Cout) part[((size_t)(m / Cout) * Cin + ci) * Cout + (m % Cout)] = vals[reg];
+        }
+    }
+}
+
 }  // namespace
 
 bool da_conv3_flow_wgrad_supported(int C1, int C2, int Cout, int stride) {
@@ -229,8 +510,36 @@ static int flow_launch_t(const FlowWgP& p, int nb, hipStream_t st) {
 }
 
 template <int MTT, bool TWO, int S1>
-static int flow_launch(const FlowWgP& p, int nb, hipStream_t st, int x_bf16) {
-    return x_bf16 ? flow_launch_t<MTT, TWO, S1, true>(p, nb, st) : flow_launch_t<MTT, TWO, S1, false>(p, nb, st);
+static int flow_launch_split(const FlowWgP& p, int nb, hipStream_t st) {
+    const size_t shm = (size_t)2 * (16 + (TWO ? S1 : 0)) * sp::CHS + (size_t)2 * 3 * 3 * sp::HZ * sp::HY * sp::YROW + 48;
+    auto kern = flow_wgrad_split_kernel<MTT, TWO, S1>;
+    static bool attr_set = false;
+    if (!attr_set) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); if (e != hipSuccess) return (int)e; attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), shm, st, p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// split matrix mode, fp32 tensors: the two-term fp16 kernel (its tile is 2 x 8 x 16: the geometry is re-derived); DA_NO_FLOW_WGRAD_SPLIT=1: the exact-fp32 kernel
+static bool flow_use_split(int x_bf16) {
+    static const bool off = [] { const char* e = getenv("DA_NO_FLOW_WGRAD_SPLIT"); return e && atoi(e) != 0; }();
+    return !off && !x_bf16 && da_matrix_mode() == 2;
+}
+static void flow_geom_split(FlowWgP& p, int* nb) {
+    p.ntz = (p.D + sp::TZ - 1) / sp::TZ; p.nty = (p.H + sp::TY - 1) / sp::TY; p.ntx = (p.W + sp::TX - 1) / sp::TX;
+    p.ntiles = p.N * p.ntz * p.nty * p.ntx;
+    *nb = p.ntiles < kFlowBlocks ? p.ntiles : kFlowBlocks;
+}
+
+template <int MTT, bool TWO, int S1>
+static int flow_launch(const FlowWgP& p0, int& nb, hipStream_t st, int x_bf16) {      // nb: in = the fp32 kernel's workgroups, out = the number of partial rows written
+    // (two window tensors -- the registration net's first layer, 1 + 1 -> 16, roles exchanged -- stay on the fp32 kernel: 0.225 ms there, 0.246 here with two loads per element)
+    if (flow_use_split(x_bf16) && p0.Cd1 == p0.Cout) {
+        FlowWgP p = p0;
+        flow_geom_split(p, &nb);
+        return flow_launch_split<MTT, TWO, S1>(p, nb, st);
+    }
+    return x_bf16 ? flow_launch_t<MTT, TWO, S1, true>(p0, nb, st) : flow_launch_t<MTT, TWO, S1, false>(p0, nb, st);
 }
 
 static void flow_geom(FlowWgP& p, int N, int D, int H, int W, int* nb) {
