@@ -226,9 +226,13 @@ constexpr int YROW = TX * 2;                                             // byte
 constexpr int NDY = (HVOX * 3 + 255) / 256;                              // dword loads per thread for the dy halo tile, Cout <= 3 (9)
 }
 
-template <int MT, bool TWO, int S1>
-__global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
-    constexpr int TZ = sp::TZ, TY = sp::TY, TX = sp::TX, TVOX = sp::TVOX, HZ = sp::HZ, HY = sp::HY, HX = sp::HX, HVOX = sp::HVOX, CHS = sp::CHS, YROW = sp::YROW, NDY = sp::NDY;
+// W8: eight waves -- wave pairs (w, w + 4) share the K-steps and take half of the M-tiles each: half the accumulators and half the staging registers per thread, so that
+// two 512-thread workgroups fit a CU (<= 128 registers) and twice as many loads are in flight
+template <int MT, bool TWO, int S1, bool W8>
+__global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) flow_wgrad_split_kernel(FlowWgP p) {
+    constexpr int NTHR = W8 ? 512 : 256, MTW = W8 ? MT / 2 : MT;
+    static_assert(!W8 || MT % 2 == 0, "M-tiles split over wave pairs");
+    constexpr int TZ = sp::TZ, TY = sp::TY, TX = sp::TX, TVOX = sp::TVOX, HZ = sp::HZ, HY = sp::HY, HX = sp::HX, HVOX = sp::HVOX, CHS = sp::CHS, YROW = sp::YROW, NDY = (sp::HVOX * 3 + NTHR - 1) / NTHR;
     (void)TZ;
     constexpr int NTT = TWO ? 2 : 1;
     constexpr int NCH = 16 + (TWO ? S1 : 0);                     // x planes: in2's 16 channels, then in1's S1
@@ -237,32 +241,34 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     unsigned char* xh = lds8;                                    // x planes: h | l
     unsigned char* yh = lds8 + 2 * XPL;                          // dy planes: h | l
-    float* smax = reinterpret_cast<float*>(lds8 + 2 * XPL + 2 * YPL);      // [8]: the waves' maxima of the x tile, of the dy tile
-    unsigned char* zrow = lds8 + 2 * XPL + 2 * YPL + 32;         // 16 zero bytes: the A fragment of padding rows
+    float* smax = reinterpret_cast<float*>(lds8 + 2 * XPL + 2 * YPL);      // [16]: the waves' maxima of the x tile (8 slots), of the dy tile (8 slots)
+    unsigned char* zrow = lds8 + 2 * XPL + 2 * YPL + 64;         // 16 zero bytes: the A fragment of padding rows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, g = lane >> 4;
     const int Cout = p.Cout, Cin = p.C1 + p.C2;
     const int Q2 = p.C2 / 4, Q1 = p.C1 / 4;
     if (threadIdx.x < 4) reinterpret_cast<unsigned*>(zrow)[threadIdx.x] = 0u;
+    if (threadIdx.x < 16) smax[threadIdx.x] = 0.f;
     // x planes of channels a tensor does not have stay zero for the whole launch
-    for (int t = threadIdx.x; t < 2 * XPL / 16; t += 256) reinterpret_cast<uint4*>(xh)[t] = make_uint4(0u, 0u, 0u, 0u);
+    for (int t = threadIdx.x; t < 2 * XPL / 16; t += NTHR) reinterpret_cast<uint4*>(xh)[t] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     // A rows of this lane: m = 16 mt + i -> (tap, co); byte offset of the row's window in the dy copies for K-step row pair (z, y): + (z * HY + y) * YROW
-    int offA[MT];
+    const int mt0 = W8 ? (wave >> 2) * MTW : 0;               // this wave's first M-tile
+    int offA[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + i;
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int m = 16 * (mt0 + mt) + i;
         const bool ok = m < 27 * Cout;
         const int tap = ok ? m / Cout : 13, co = ok ? m % Cout : 0;
         const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
         // dy[p - (tap - 1)]: halo row (z + 2 - tz, y + 2 - ty), x window starting at x + 2 - tx -> copy (2 - tx)
         offA[mt] = ok ? ((((2 - tx) * 3 + co) * HZ + (2 - tz)) * HY + (2 - ty)) * YROW + (g & 1) * 16 + (g >> 1) * YROW : -1;
     }
-    f32x4 acc[MT][NTT];
+    f32x4 acc[MTW][NTT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -271,15 +277,35 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
     const int t_begin = vb * per, t_end = min(p.ntiles, t_begin + per);
 
     // staging: a thread takes PAIRS of x-adjacent voxels of one channel quad (two 16-byte loads -> four packed fp16 pairs per plane, 4-byte LDS stores)
-    constexpr int NP2 = TVOX / 2 * 4 / 256;                      // pairs per thread, in2 with 4 quads (2)
-    constexpr int NP1 = TWO ? (TVOX / 2 * (S1 / 4) + 255) / 256 : 0;      // in1 (S1 = 8: 1, S1 = 16: 2)
+    constexpr int NP2 = TVOX / 2 * 4 / NTHR;                     // pairs per thread, in2 with 4 quads (2 | 1)
+    constexpr int NP1 = TWO ? (TVOX / 2 * (S1 / 4) + NTHR - 1) / NTHR : 0;      // in1 (S1 = 8: 1, S1 = 16: 2 | 1)
     float4 pa[NP2][2], pb[NP1 > 0 ? NP1 : 1][2];
     float pd[NDY];
+    // this thread's voxel pairs of the x tensors: byte offset of the pair's first voxel (its channel quad) relative to the tile's first voxel, local (x | y << 8 | z << 16)
+    int xo2[NP2], xl2[NP2], xo1[NP1 > 0 ? NP1 : 1], xl1[NP1 > 0 ? NP1 : 1];
+#pragma unroll
+    for (int it = 0; it < NP2; ++it) {
+        const int idx = threadIdx.x + it * NTHR;
+        const int c4 = Q2 > 0 ? idx % Q2 : 0, vp = Q2 > 0 ? idx / Q2 : TVOX;      // voxel pair vp: voxels 2 vp, 2 vp + 1 (same row)
+        const int v = 2 * vp, vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+        xo2[it] = (Q2 > 0 && v < TVOX) ? (((vz * p.H + vy) * p.W + vx) * p.C2 + c4 * 4) * 4 : -1;
+        xl2[it] = vx | vy << 8 | vz << 16;
+    }
+    if (TWO) {
+#pragma unroll
+        for (int it = 0; it < NP1; ++it) {
+            const int idx = threadIdx.x + it * NTHR;
+            const int c4 = Q1 > 0 ? idx % Q1 : 0, vp = Q1 > 0 ? idx / Q1 : TVOX;
+            const int v = 2 * vp, vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+            xo1[it] = (Q1 > 0 && v < TVOX) ? (((vz * p.H + vy) * p.W + vx) * p.C1 + c4 * 4) * 4 : -1;
+            xl1[it] = vx | vy << 8 | vz << 16;
+        }
+    }
     // this thread's dy halo elements (fixed for the launch): cout | hx << 8 | hy << 16 | hz << 24, -1 past the tile
     int pk[NDY];
 #pragma unroll
     for (int it = 0; it < NDY; ++it) {
-        const int idx = threadIdx.x + it * 256;
+        const int idx = threadIdx.x + it * NTHR;
         const int co = idx % Cout, hv = idx / Cout;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         pk[it] = hv < HVOX ? (co | hx << 8 | hy << 16 | hz << 24) : -1;
@@ -293,36 +319,31 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
         const unsigned long long vol = (unsigned long long)p.D * p.H * p.W;
         const __amdgpu_buffer_rsrc_t r2 = flow_rsrc(p.C2 > 0 ? p.in2 + (size_t)n * vol * p.C2 : p.dy, p.C2 > 0 ? (unsigned)(vol * p.C2 * 4ull) : 0u);
         const __amdgpu_buffer_rsrc_t r1 = flow_rsrc(p.C1 > 0 ? p.in1 + (size_t)n * vol * p.C1 : p.dy, p.C1 > 0 ? (unsigned)(vol * p.C1 * 4ull) : 0u);
+#if defined(DA_FWS_ABL) && (DA_FWS_ABL & 8)
+        auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float4 { return make_float4((float)off, 1.f, 2.f, 3.f); };      // timing only: no x loads
+#else
         auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float4 { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
+#endif
         const int Cd2 = Cout - p.Cd1;
         const __amdgpu_buffer_rsrc_t ry = flow_rsrc(p.dy + (size_t)n * vol * p.Cd1, (unsigned)(vol * p.Cd1 * 4ull));
         const __amdgpu_buffer_rsrc_t ry2 = flow_rsrc(Cd2 > 0 ? p.dyb + (size_t)n * vol * Cd2 : p.dy, Cd2 > 0 ? (unsigned)(vol * Cd2 * 4ull) : 0u);
+        // x loads: the thread's tile-relative byte offsets are fixed for the launch (xo2 / xo1: -1 = no such pair); per tile one scalar base and the ragged-edge test
+        const unsigned tb2 = (unsigned)(((z0 * p.H + y0) * p.W + x0) * p.C2 * 4), tb1 = (unsigned)(((z0 * p.H + y0) * p.W + x0) * p.C1 * 4);
+        const int lz = p.D - z0, ly = p.H - y0, lx = p.W - x0;      // local coordinates below these are inside the volume
 #pragma unroll
         for (int it = 0; it < NP2; ++it) {
-            int idx = threadIdx.x + it * 256;
-            asm volatile("" : "+v"(idx));
-            const int c4 = Q2 > 0 ? idx % Q2 : 0, vp = Q2 > 0 ? idx / Q2 : TVOX;      // voxel pair vp: voxels 2 vp, 2 vp + 1 (same row)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int v = 2 * vp + h2;
-                const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
-                const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
-                pa[it][h2] = ld4(r2, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C2 + c4 * 4) * 4) : 0xFFFFFFFFu);
-            }
+            const int vx = xl2[it] & 255, vy = (xl2[it] >> 8) & 255, vz = xl2[it] >> 16;
+            const bool ok = xo2[it] >= 0 && vz < lz && vy < ly;
+            pa[it][0] = ld4(r2, (ok && vx < lx) ? tb2 + (unsigned)xo2[it] : 0xFFFFFFFFu);
+            pa[it][1] = ld4(r2, (ok && vx + 1 < lx) ? tb2 + (unsigned)xo2[it] + (unsigned)p.C2 * 4u : 0xFFFFFFFFu);
         }
         if (TWO) {
 #pragma unroll
             for (int it = 0; it < NP1; ++it) {
-                int idx = threadIdx.x + it * 256;
-                asm volatile("" : "+v"(idx));
-                const int c4 = Q1 > 0 ? idx % Q1 : 0, vp = Q1 > 0 ? idx / Q1 : TVOX;
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const int v = 2 * vp + h2;
-                    const int x = x0 + (v & 15), y = y0 + ((v >> 4) & 7), z = z0 + (v >> 7);
-                    const bool ok = v < TVOX && z < p.D && y < p.H && x < p.W;
-                    pb[it][h2] = ld4(r1, ok ? (unsigned)((((z * p.H + y) * p.W + x) * p.C1 + c4 * 4) * 4) : 0xFFFFFFFFu);
-                }
+                const int vx = xl1[it] & 255, vy = (xl1[it] >> 8) & 255, vz = xl1[it] >> 16;
+                const bool ok = xo1[it] >= 0 && vz < lz && vy < ly;
+                pb[it][0] = ld4(r1, (ok && vx < lx) ? tb1 + (unsigned)xo1[it] : 0xFFFFFFFFu);
+                pb[it][1] = ld4(r1, (ok && vx + 1 < lx) ? tb1 + (unsigned)xo1[it] + (unsigned)p.C1 * 4u : 0xFFFFFFFFu);
             }
         }
 #pragma unroll
@@ -332,7 +353,11 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
             const bool ok = pk[it] >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             const unsigned vo = (unsigned)((z * p.H + y) * p.W + x);
             // (one load per tensor with the other tensor's lanes out of range -> 0: a per-lane choice of the DESCRIPTOR makes the compiler loop over the lanes)
+#if defined(DA_FWS_ABL) && (DA_FWS_ABL & 16)
+            float v = (float)vo;      // timing only: no dy loads
+#else
             float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (ok && co < p.Cd1) ? (vo * p.Cd1 + co) * 4u : 0xFFFFFFFFu, 0, 0));
+#endif
             if (Cd2 > 0) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry2, (ok && co >= p.Cd1) ? (vo * Cd2 + (co - p.Cd1)) * 4u : 0xFFFFFFFFu, 0, 0));
             pd[it] = v;
         }
@@ -351,11 +376,11 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
 #pragma unroll
         for (int it = 0; it < NDY; ++it) my = fmaxf(my, fabsf(pd[it]));
         mx = da_wave_max_nonneg(mx); my = da_wave_max_nonneg(my);
-        if (lane == 0) { smax[wave] = mx; smax[4 + wave] = my; }
+        if (lane == 0) { smax[wave] = mx; smax[8 + wave] = my; }
         __syncthreads();                                         // (also: every wave is done reading the previous tile)
-        const float4 m4 = *reinterpret_cast<const float4*>(smax), n4 = *reinterpret_cast<const float4*>(smax + 4);
-        mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)))));
-        my = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(n4.x, n4.y), fmaxf(n4.z, n4.w)))));
+        const float4 m4 = *reinterpret_cast<const float4*>(smax), m5 = *reinterpret_cast<const float4*>(smax + 4), n4 = *reinterpret_cast<const float4*>(smax + 8), n5 = *reinterpret_cast<const float4*>(smax + 12);      // (unused slots stay 0)
+        mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)), fmaxf(fmaxf(m5.x, m5.y), fmaxf(m5.z, m5.w))))));
+        my = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaxf(fmaxf(fmaxf(n4.x, n4.y), fmaxf(n4.z, n4.w)), fmaxf(fmaxf(n5.x, n5.y), fmaxf(n5.z, n5.w))))));
         const int ex = da_scale_exp(mx);
         int E = ex + da_scale_exp(my);
         if (!first_tile) E = min(E, Emin + 40);
@@ -365,6 +390,9 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
         // x planes: per channel of the quad the two voxels' halves side by side (one 4-byte store per plane)
         auto put_pair = [&](int idx, int Q, int chan0, const float4& v0, const float4& v1) {
             if (Q <= 0 || idx >= TVOX / 2 * Q) return;
+#if defined(DA_FWS_ABL) && (DA_FWS_ABL & 4)
+            if (v0.x != 12345.678f) return;      // timing only: no x planes
+#endif
             const int c4 = idx % Q, vp = idx / Q;
             uint2 h0, l0, h1, l1;
             da_split2(v0, sx, h0, l0); da_split2(v1, sx, h1, l1);
@@ -380,15 +408,19 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
             }
         };
 #pragma unroll
-        for (int it = 0; it < NP2; ++it) put_pair((int)threadIdx.x + it * 256, Q2, 0, pa[it][0], pa[it][1]);
+        for (int it = 0; it < NP2; ++it) put_pair((int)threadIdx.x + it * NTHR, Q2, 0, pa[it][0], pa[it][1]);
         if (TWO) {
 #pragma unroll
-            for (int it = 0; it < NP1; ++it) put_pair((int)threadIdx.x + it * 256, Q1, 16, pb[it][0], pb[it][1]);
+            for (int it = 0; it < NP1; ++it) put_pair((int)threadIdx.x + it * NTHR, Q1, 16, pb[it][0], pb[it][1]);
         }
         // dy copies: halo element (hz, hy, hx) of cout co lands at x = hx - s of copy s
 #pragma unroll
         for (int it = 0; it < NDY; ++it) {
+#if defined(DA_FWS_ABL) && (DA_FWS_ABL & 2)
+            if (pk[it] >= 0 && pd[it] == 12345.678f) {      // timing only: no dy copies
+#else
             if (pk[it] >= 0) {
+#endif
                 const int co = pk[it] & 255, hx = (pk[it] >> 8) & 255, hy = (pk[it] >> 16) & 255, hz = pk[it] >> 24;
                 const float a = pd[it] * sy;
                 const _Float16 h = (_Float16)a;
@@ -410,7 +442,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
     int Ecur = 0;
     if (t_begin < t_end) { issue(t_begin); Ecur = stage(); }
     __syncthreads();
-    const int zw = wave >> 1, yw = (wave & 1) * 4;
+    const int zw = (wave & 3) >> 1, yw = (wave & 1) * 4;
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool has_next = tile + 1 < t_end;
@@ -418,7 +450,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
         {
             const float f = da_acc_factor(Ecur - Eacc);          // the running sums into this tile's unit (exact)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt) acc[mt][nt] = acc[mt][nt] * f;
             Eacc = Ecur;
@@ -435,15 +467,19 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
                 if (TWO) B[NTT - 1][pl] = *reinterpret_cast<const f16x8*>(xh + pl * XPL + (16 + (i & (S1 - 1))) * CHS + vrow);
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTW; ++mt) {
                 const unsigned char* ap = offA[mt] >= 0 ? yh + offA[mt] + rowoff : zrow;
                 const f16x8 Ah = *reinterpret_cast<const f16x8*>(ap);
                 const f16x8 Al = *reinterpret_cast<const f16x8*>(offA[mt] >= 0 ? ap + YPL : zrow);
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt) {
+#if defined(DA_FWS_ABL) && (DA_FWS_ABL & 1)
+                    acc[mt][nt][0] += (float)Ah[0] * (float)B[nt][1][0] + (float)Al[0] * (float)B[nt][0][0];      // timing only
+#else
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, B[nt][1], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, B[nt][0], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, B[nt][0], acc[mt][nt], 0, 0, 0);
+#endif
                 }
             }
         }
@@ -457,12 +493,12 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(lds8);
     for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+        if ((wave & 3) == w) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt) {
-                    float4* slot = red + (mt * NTT + nt) * 64 + lane;
+                    float4* slot = red + ((mt0 + mt) * NTT + nt) * 64 + lane;
                     float4 cur = (w == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : *slot;
                     cur.x += acc[mt][nt][0] * inv1 * inv2; cur.y += acc[mt][nt][1] * inv1 * inv2; cur.z += acc[mt][nt][2] * inv1 * inv2; cur.w += acc[mt][nt][3] * inv1 * inv2;
                     *slot = cur;
@@ -472,7 +508,7 @@ __global__ void __launch_bounds__(256, 2) flow_wgrad_split_kernel(FlowWgP p) {
     }
     const int O = 27 * Cin * Cout;
     float* part = p.partial + (size_t)blockIdx.x * O;
-    for (int idx = threadIdx.x; idx < MT * NTT * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < MT * NTT * 64; idx += NTHR) {
         const int ln = idx & 63, q = idx >> 6;
         const int nt = q % NTT, mt = q / NTT;
         const float4 v = red[idx];
@@ -509,15 +545,20 @@ static int flow_launch_t(const FlowWgP& p, int nb, hipStream_t st) {
     return 0;
 }
 
-template <int MTT, bool TWO, int S1>
-static int flow_launch_split(const FlowWgP& p, int nb, hipStream_t st) {
-    const size_t shm = (size_t)2 * (16 + (TWO ? S1 : 0)) * sp::CHS + (size_t)2 * 3 * 3 * sp::HZ * sp::HY * sp::YROW + 48;
-    auto kern = flow_wgrad_split_kernel<MTT, TWO, S1>;
+template <int MTT, bool TWO, int S1, bool W8>
+static int flow_launch_split_t(const FlowWgP& p, int nb, hipStream_t st) {
+    const size_t shm = (size_t)2 * (16 + (TWO ? S1 : 0)) * sp::CHS + (size_t)2 * 3 * 3 * sp::HZ * sp::HY * sp::YROW + 80;
+    auto kern = flow_wgrad_split_kernel<MTT, TWO, S1, W8>;
     static bool attr_set = false;
     if (!attr_set) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); if (e != hipSuccess) return (int)e; attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), shm, st, p);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(W8 ? 512 : 256), shm, st, p);
     DA_LAUNCH_CHECK();
     return 0;
+}
+template <int MTT, bool TWO, int S1>
+static int flow_launch_split(const FlowWgP& p, int nb, hipStream_t st) {
+    static const bool w8 = [] { const char* e = getenv("DA_FLOW_WGRAD_W8"); return e && atoi(e) != 0; }();      // A/B: 1 = eight waves per workgroup (measured slower: 0.29 vs 0.24 ms)
+    return w8 ? flow_launch_split_t<MTT, TWO, S1, true>(p, nb, st) : flow_launch_split_t<MTT, TWO, S1, false>(p, nb, st);
 }
 
 // split matrix mode, fp32 tensors: the two-term fp16 kernel (its tile is 2 x 8 x 16: the geometry is re-derived); DA_NO_FLOW_WGRAD_SPLIT=1: the exact-fp32 kernel
