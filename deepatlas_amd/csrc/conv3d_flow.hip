@@ -575,7 +575,8 @@ static void flow_geom_split(FlowWgP& p, int* nb) {
 template <int MTT, bool TWO, int S1>
 static int flow_launch(const FlowWgP& p0, int& nb, hipStream_t st, int x_bf16) {      // nb: in = the fp32 kernel's workgroups, out = the number of partial rows written
     // (two window tensors -- the registration net's first layer, 1 + 1 -> 16, roles exchanged -- stay on the fp32 kernel: 0.225 ms there, 0.246 here with two loads per element)
-    if (flow_use_split(x_bf16) && p0.Cd1 == p0.Cout) {
+    static const bool two_win = [] { const char* e = getenv("DA_FLOW_WGRAD_SPLIT_2WIN"); return e && atoi(e) != 0; }();
+    if (flow_use_split(x_bf16) && (p0.Cd1 == p0.Cout || two_win)) {
         FlowWgP p = p0;
         flow_geom_split(p, &nb);
         return flow_launch_split<MTT, TWO, S1>(p, nb, st);
