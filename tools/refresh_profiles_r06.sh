@@ -46,8 +46,10 @@ if want kernels; then
   DA_MATRIX_MODE=2 timeout 300 python tools/bench_pointwise.py 2>&1 | grep -v amdgpu.ids > $O/pointwise_calls.txt
   { echo "# a tiny kernel on the main stream beside a whole-GPU kernel on a side stream (tools/debug/concurrency_probe.py): probe ms / big-kernel ms / probe start after the big kernel's start";
     for a in "--layer 8,16,3,1,160,192,160 --what wgrad" "--layer 32,16,16,1,160,192,160 --what wgrad" "--layer 32,16,16,1,160,192,160 --what fwd"; do DA_MATRIX_MODE=2 timeout 300 python tools/debug/concurrency_probe.py $a 2>&1 | grep -v amdgpu.ids; done; } > $O/concurrency_probe.txt
+  if ls deepatlas_amd/csrc/libda_D1.so > /dev/null 2>&1; then   # (needs the variant libraries: tools/ab/build_variant.sh D$v pointwise_mfma.hip "-DDA_DB_ABL=$v" for v in 1 2 4 8 15)
   { echo "# the fused up-sampler backward (deconv_bn_bwd_kernel) with pieces removed (tools/ab/deconv_bwd_ablate.sh; timing only): DA_DB_ABL bits 1 no MFMAs, 2 no weight-gradient half, 4 no gout / y loads, 8 no cross-wave sum + dx store";
     if ls deepatlas_amd/csrc/libda_D1.so > /dev/null 2>&1; then bash tools/ab/deconv_bwd_ablate.sh 2>&1 | grep -v "simple_timer\|amdgpu.ids"; fi; } > $O/deconv_bwd_ablate.txt
+  fi
   echo "# DA_MATRIX_MODE=2 (fp32_split: two-term fp16 split), tools/bench_conv.py --layer C1,C2,Cout,N,D,H,W; one process per layer and variant, same box" > $O/conv_layers_isolated.txt
   for e in "" "DA_FWDSP=1" "DA_FWDSP=1 DA_FWDSP8=1"; do
     echo "== ${e:-shipped kernels (conv3d_mfma.hip)}" >> $O/conv_layers_isolated.txt
